@@ -1,0 +1,256 @@
+// ref_driver.cpp -- driver around the UNMODIFIED reference classes (CMatrix / CKern / CGp), built by
+// oracle/Makefile from the sources where they lie under /root/reference into oracle/_ref/ref_driver.
+//
+// TEST INFRASTRUCTURE ONLY: this is the "real reference" leg of the oracle.  It is used
+// (i) to validate the plain-C restatement in oracle/gpc_oracle.c, (ii) to generate the golden vectors committed
+// under tests/golden/ (script: tests/golden/make_golden.py) and (iii) as bench.py's cpu_baseline (kind
+// "reference").  The product (gpc_amd/) never links, loads or executes it.
+//
+// Written against the reference's public class surface only (gp.cpp:240-406 shows the construction order this
+// mirrors: CCmpndKern + addKern, CGaussianNoise, CGp(kern, noise, X, FTC, -1, verbosity), setScale/setBias,
+// updateM).  C++98 on purpose: the reference only compiles with -std=gnu++98.
+//
+// Usage: ref_driver <kern|gp|time> <in.gpcb> <out.gpcb>
+#include <sys/time.h>
+#include <iostream>
+#include <vector>
+#include "CMatrix.h"
+#include "CKern.h"
+#include "CNoise.h"
+#include "CGp.h"
+extern "C" {
+#include "gpcb_io.h"
+}
+
+static double now_s()
+{
+  struct timeval tv;
+  gettimeofday(&tv, 0);
+  return tv.tv_sec + 1e-6 * tv.tv_usec;
+}
+
+static void toCMatrix(CMatrix& M, const gpcb_array* a)
+{
+  M.resize((unsigned int)a->rows, (unsigned int)a->cols);
+  for(int64_t j = 0; j < a->cols; j++)
+    for(int64_t i = 0; i < a->rows; i++)
+      M.setVal(a->data[i + a->rows * j], (unsigned int)i, (unsigned int)j);
+}
+
+static void writeCMatrix(FILE* fp, const char* name, const CMatrix& M)
+{
+  std::vector<double> buf((size_t)M.getRows() * M.getCols());
+  for(unsigned int j = 0; j < M.getCols(); j++)
+    for(unsigned int i = 0; i < M.getRows(); i++)
+      buf[i + (size_t)M.getRows() * j] = M.getVal(i, j);
+  gpcb_write(fp, name, M.getRows(), M.getCols(), buf.size() ? &buf[0] : 0);
+}
+
+// kernel type codes shared with include/gpc_hip.h (GPC_KERN_*) and oracle/gpc_oracle.h
+enum { K_RBF = 1, K_RBFARD = 2, K_WHITE = 3, K_BIAS = 4, K_LIN = 5 };
+
+// Build cmpnd{...} from "kern_types" (1 x T) and natural-space "kern_params" (1 x P, addKern order) or
+// transformed-space "kern_trans_params".
+static void buildKern(CCmpndKern& kern, const CMatrix& X, const gpcb_file& in)
+{
+  const gpcb_array* types = gpcb_need(&in, "kern_types");
+  for(int64_t t = 0; t < types->rows * types->cols; t++)
+  {
+    CKern* k = 0;
+    switch((int)types->data[t])
+    {
+    case K_RBF: k = new CRbfKern(X); break;
+    case K_RBFARD: k = new CRbfardKern(X); break;
+    case K_WHITE: k = new CWhiteKern(X); break;
+    case K_BIAS: k = new CBiasKern(X); break;
+    case K_LIN: k = new CLinKern(X); break;
+    default: std::cerr << "ref_driver: unknown kernel type" << std::endl; exit(2);
+    }
+    kern.addKern(k);   // clones (CKern.h:384)
+    delete k;
+  }
+  const gpcb_array* tparams = gpcb_find(&in, "kern_trans_params");
+  if(tparams)   // transformed-space parameters, as the reference's fixtures store them (testKern.cpp setTransParams)
+  {
+    CMatrix tp;
+    toCMatrix(tp, tparams);
+    kern.setTransParams(tp);
+    return;
+  }
+  const gpcb_array* params = gpcb_need(&in, "kern_params");
+  if((int64_t)kern.getNumParams() != params->rows * params->cols)
+  {
+    std::cerr << "ref_driver: expected " << kern.getNumParams() << " kernel params" << std::endl;
+    exit(2);
+  }
+  for(unsigned int i = 0; i < kern.getNumParams(); i++)
+    kern.setParam(params->data[i], i);
+}
+
+static int runKern(const gpcb_file& in, const char* outPath)
+{
+  CMatrix X, X2, covGrad, covGrad2;
+  toCMatrix(X, gpcb_need(&in, "X"));
+  toCMatrix(X2, gpcb_need(&in, "X2"));
+  toCMatrix(covGrad, gpcb_need(&in, "covGrad"));
+  toCMatrix(covGrad2, gpcb_need(&in, "covGrad2"));
+  covGrad.setSymmetric(true);
+  CCmpndKern kern(X);
+  buildKern(kern, X, in);
+
+  CMatrix K2(X.getRows(), X.getRows());
+  kern.compute(K2, X);
+  CMatrix K4(X.getRows(), X2.getRows());
+  kern.compute(K4, X, X2);
+  CMatrix k2(X.getRows(), 1);
+  kern.diagCompute(k2, X);
+  CMatrix g2(1, kern.getNumParams());
+  kern.getGradTransParams(g2, X, covGrad, false);
+  CMatrix g4(1, kern.getNumParams());
+  kern.getGradTransParams(g4, X, X2, covGrad2, false);
+  CMatrix tp(1, kern.getNumParams());
+  kern.getTransParams(tp);
+
+  FILE* fp = gpcb_open_write(outPath);
+  writeCMatrix(fp, "K2", K2);
+  writeCMatrix(fp, "K4", K4);
+  writeCMatrix(fp, "k2", k2);
+  writeCMatrix(fp, "g2", g2);
+  writeCMatrix(fp, "g4", g4);
+  writeCMatrix(fp, "trans_params", tp);
+  CMatrix np(1, kern.getNumParams());
+  kern.getParams(np);
+  writeCMatrix(fp, "nat_params", np);
+  fclose(fp);
+  return 0;
+}
+
+static int runGp(const gpcb_file& in, const char* outPath)
+{
+  CMatrix X, y, Xstar;
+  toCMatrix(X, gpcb_need(&in, "X"));
+  toCMatrix(y, gpcb_need(&in, "y"));
+  const gpcb_array* xs = gpcb_find(&in, "Xstar");
+  const gpcb_array* dump = gpcb_find(&in, "dump_matrices");
+  CCmpndKern kern(X);
+  buildKern(kern, X, in);
+  CGaussianNoise noise(&y);
+  noise.setBias(0.0);
+  CMatrix scale(1, y.getCols(), 1.0);
+  CMatrix bias(1, y.getCols(), 0.0);
+  if(gpcb_find(&in, "scale")) toCMatrix(scale, gpcb_find(&in, "scale"));
+  if(gpcb_find(&in, "bias")) toCMatrix(bias, gpcb_find(&in, "bias"));
+  else bias.deepCopy(meanCol(y));
+
+  CGp model(&kern, &noise, &X, CGp::FTC, (unsigned int)-1, 0);
+  model.setBetaVal(1);
+  model.setScale(scale);
+  model.setBias(bias);
+  model.updateM();
+
+  CMatrix g(1, model.getOptNumParams());
+  double t0 = now_s();
+  double ll = model.logLikelihoodGradient(g);
+  double t1 = now_s();
+  double ll2 = model.logLikelihood();
+  CMatrix params(1, model.getOptNumParams());
+  model.getOptParams(params);
+  model.updateAlpha();
+
+  FILE* fp = gpcb_open_write(outPath);
+  gpcb_write_scalar(fp, "ll", ll);
+  gpcb_write_scalar(fp, "ll_again", ll2);
+  gpcb_write_scalar(fp, "logdet", model.logDetK);
+  gpcb_write_scalar(fp, "t_llgrad", t1 - t0);
+  writeCMatrix(fp, "grads", g);
+  writeCMatrix(fp, "opt_params", params);
+  writeCMatrix(fp, "alpha", model.Alpha);
+  writeCMatrix(fp, "m", model.m);
+  if(dump && dump->data[0] != 0.0)
+  {
+    writeCMatrix(fp, "K", model.K);
+    writeCMatrix(fp, "L", model.LcholK);
+    writeCMatrix(fp, "invK", model.invK);
+    writeCMatrix(fp, "covGrad", model.covGrad);
+  }
+  if(xs)
+  {
+    toCMatrix(Xstar, xs);
+    CMatrix mu(Xstar.getRows(), y.getCols());
+    CMatrix var(Xstar.getRows(), y.getCols());
+    model.posteriorMeanVar(mu, var, Xstar);
+    writeCMatrix(fp, "mu", mu);
+    writeCMatrix(fp, "var", var);
+    CMatrix yPred(Xstar.getRows(), y.getCols());
+    CMatrix errBar(Xstar.getRows(), y.getCols());
+    model.out(yPred, errBar, Xstar);
+    writeCMatrix(fp, "yPred", yPred);
+    writeCMatrix(fp, "errBar", errBar);
+  }
+  fclose(fp);
+  return 0;
+}
+
+// Time the two phases of one CGp::updateK() (FTC) with the reference's own classes, as SURVEY.md section 6 did:
+// Gram build = the scalar computeElement double loop (CKern.h:128-144 == CGp.cpp:698-712), then
+// jitChol (CMatrix.cpp:767-804) + logDet.  "reps" repetitions; reports the minimum of each.
+static int runTime(const gpcb_file& in, const char* outPath)
+{
+  CMatrix X;
+  toCMatrix(X, gpcb_need(&in, "X"));
+  const gpcb_array* repsA = gpcb_find(&in, "reps");
+  int reps = repsA ? (int)repsA->data[0] : 1;
+  CCmpndKern kern(X);
+  buildKern(kern, X, in);
+  unsigned int N = X.getRows();
+  CMatrix K(N, N);
+  CMatrix L(N, N);
+  double tGram = 1e300, tChol = 1e300, logdet = 0.0, jit = 0.0;
+  for(int r = 0; r < reps; r++)
+  {
+    double t0 = now_s();
+    kern.compute(K, X);
+    double t1 = now_s();
+    jit = L.jitChol(K);
+    logdet = logDet(L);
+    double t2 = now_s();
+    if(t1 - t0 < tGram) tGram = t1 - t0;
+    if(t2 - t1 < tChol) tChol = t2 - t1;
+  }
+  FILE* fp = gpcb_open_write(outPath);
+  gpcb_write_scalar(fp, "t_gram", tGram);
+  gpcb_write_scalar(fp, "t_chol", tChol);
+  gpcb_write_scalar(fp, "logdet", logdet);
+  gpcb_write_scalar(fp, "jitter", jit);
+  fclose(fp);
+  return 0;
+}
+
+int main(int argc, char* argv[])
+{
+  if(argc != 4)
+  {
+    std::cerr << "usage: ref_driver <kern|gp|time> <in.gpcb> <out.gpcb>" << std::endl;
+    return 2;
+  }
+  gpcb_file in;
+  if(gpcb_read(argv[2], &in) != 0)
+  {
+    std::cerr << "ref_driver: cannot read " << argv[2] << std::endl;
+    return 2;
+  }
+  try
+  {
+    std::string mode(argv[1]);
+    if(mode == "kern") return runKern(in, argv[3]);
+    if(mode == "gp") return runGp(in, argv[3]);
+    if(mode == "time") return runTime(in, argv[3]);
+    std::cerr << "ref_driver: unknown mode " << mode << std::endl;
+    return 2;
+  }
+  catch(ndlexceptions::Error& err)
+  {
+    std::cerr << "ref_driver: reference threw: " << err.getMessage() << std::endl;
+    return 3;
+  }
+}

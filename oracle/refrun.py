@@ -1,0 +1,56 @@
+"""Run oracle/_ref/ref_driver (the compiled, unmodified reference) or oracle/oracle_driver (the C restatement).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, tests/golden/make_golden.py and bench.py's cpu_baseline leg.
+"""
+import os
+import subprocess
+import tempfile
+
+from . import gpcb
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF_DRIVER = os.path.join(HERE, "_ref", "ref_driver")
+PORT_DRIVER = os.path.join(HERE, "oracle_driver")
+MKL = os.environ.get("GPC_ORACLE_MKL", "/opt/conda/lib/libmkl_rt.so.1")
+
+KERN_CODES = {"rbf": 1, "rbfard": 2, "white": 3, "bias": 4, "lin": 5}
+
+
+def have_ref():
+    return os.path.exists(REF_DRIVER) and os.path.exists(MKL)
+
+
+def have_port():
+    return os.path.exists(PORT_DRIVER)
+
+
+def _run(exe, mode, arrays, env=None, timeout=3600):
+    with tempfile.TemporaryDirectory() as td:
+        fin, fout = os.path.join(td, "in.gpcb"), os.path.join(td, "out.gpcb")
+        gpcb.write(fin, arrays)
+        r = subprocess.run([exe, mode, fin, fout], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                           stdin=subprocess.DEVNULL, timeout=timeout)
+        if r.returncode != 0:
+            raise RuntimeError("%s %s failed (%d): %s" % (exe, mode, r.returncode, r.stderr.decode()[-2000:]))
+        return gpcb.read(fout)
+
+
+def run_ref(mode, arrays, threads=None, timeout=3600):
+    """mode in {'kern','gp','time'}; returns dict of output arrays."""
+    env = dict(os.environ)
+    env["LD_PRELOAD"] = MKL
+    if threads:
+        env["MKL_NUM_THREADS"] = str(threads)
+        env["OMP_NUM_THREADS"] = str(threads)
+    return _run(REF_DRIVER, mode, arrays, env=env, timeout=timeout)
+
+
+def run_port(mode, arrays, timeout=3600):
+    return _run(PORT_DRIVER, mode, arrays, timeout=timeout)
+
+
+def kern_arrays(kern):
+    """kern: list of (type_name, [natural params...]) -> the two spec arrays the drivers read."""
+    types = [KERN_CODES[t] for t, _ in kern]
+    params = [p for _, ps in kern for p in ps]
+    return {"kern_types": types, "kern_params": params}
