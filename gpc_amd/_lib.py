@@ -1,0 +1,107 @@
+"""ctypes binding of libgpc_hip.so (include/gpc_hip.h).  The library is the product; this file is plumbing.
+
+There is NO fallback: if the shared library is missing or a call fails, an exception is raised.
+"""
+import ctypes
+import os
+from ctypes import (POINTER, Structure, c_char, c_char_p, c_double, c_int, c_int32, c_int64, c_size_t, c_void_p)
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "libgpc_hip.so")
+
+GPC_OK = 0
+GPC_EINVAL, GPC_ENODEV, GPC_EHIP, GPC_ENOMEM, GPC_EUNSUPPORTED = -1, -2, -3, -4, -5
+_ERRNAMES = {-1: "GPC_EINVAL", -2: "GPC_ENODEV", -3: "GPC_EHIP", -4: "GPC_ENOMEM", -5: "GPC_EUNSUPPORTED"}
+
+GPC_KERN_RBF, GPC_KERN_RBFARD, GPC_KERN_WHITE, GPC_KERN_BIAS, GPC_KERN_LIN = 1, 2, 3, 4, 5
+GPC_MAX_TERMS, GPC_MAX_PARAMS, GPC_MAX_ARD_DIM = 8, 160, 64
+
+
+class GpcError(RuntimeError):
+    def __init__(self, rc, msg):
+        super().__init__("%s (%d): %s" % (_ERRNAMES.get(rc, "GPC_E?"), rc, msg))
+        self.rc = rc
+
+
+class KSpec(Structure):
+    """struct gpc_kspec (include/gpc_hip.h)."""
+    _fields_ = [("n_terms", c_int32),
+                ("types", c_int32 * GPC_MAX_TERMS),
+                ("offs", c_int32 * (GPC_MAX_TERMS + 1)),
+                ("params", c_double * GPC_MAX_PARAMS)]
+
+
+# name -> (restype, argtypes); the single source of truth the symbol-export test walks.
+I64, DP, VP = c_int64, c_void_p, c_void_p   # device pointers travel as void*
+SIGNATURES = {
+    "gpc_version": (c_int, []),
+    "gpc_last_error": (c_char_p, []),
+    "gpc_device_count": (c_int, [POINTER(c_int)]),
+    "gpc_set_device": (c_int, [c_int]),
+    "gpc_device_info": (c_int, [c_char_p, c_size_t, POINTER(c_int), POINTER(c_size_t), POINTER(c_int)]),
+    "gpc_malloc": (c_int, [POINTER(c_void_p), c_size_t]),
+    "gpc_free": (c_int, [c_void_p]),
+    "gpc_memcpy_h2d": (c_int, [c_void_p, c_void_p, c_size_t, VP]),
+    "gpc_memcpy_d2h": (c_int, [c_void_p, c_void_p, c_size_t, VP]),
+    "gpc_memcpy_d2d": (c_int, [c_void_p, c_void_p, c_size_t, VP]),
+    "gpc_memset": (c_int, [c_void_p, c_int, c_size_t, VP]),
+    "gpc_stream_sync": (c_int, [VP]),
+    "gpc_workspace_release": (c_int, []),
+    "gpc_gram_sym_f64": (c_int, [POINTER(KSpec), DP, I64, I64, I64, DP, I64, VP]),
+    "gpc_gram_cross_f64": (c_int, [POINTER(KSpec), DP, I64, I64, DP, I64, I64, I64, DP, I64, VP]),
+    "gpc_gram_diag_f64": (c_int, [POINTER(KSpec), DP, I64, I64, I64, DP, VP]),
+    "gpc_gram_block_f64": (c_int, [POINTER(KSpec), DP, I64, I64, I64, I64, I64, I64, I64, DP, I64, VP]),
+    "gpc_potrf_f64": (c_int, [c_char, I64, DP, I64, POINTER(c_int), VP]),
+    "gpc_chol_f64": (c_int, [c_char, I64, DP, I64, POINTER(c_int), VP]),
+    "gpc_potri_f64": (c_int, [c_char, I64, DP, I64, VP]),
+    "gpc_trsm_f64": (c_int, [c_char, c_char, c_char, c_char, I64, I64, c_double, DP, I64, DP, I64, VP]),
+    "gpc_logdet_chol_f64": (c_int, [I64, DP, I64, POINTER(c_double), VP]),
+    "gpc_gemm_f64": (c_int, [c_char, c_char, I64, I64, I64, c_double, DP, I64, DP, I64, c_double, DP, I64, VP]),
+    "gpc_syrk_f64": (c_int, [c_char, c_char, I64, I64, c_double, DP, I64, c_double, DP, I64, VP]),
+    "gpc_transpose_inplace_f64": (c_int, [I64, DP, I64, VP]),
+    "gpc_symmetrize_f64": (c_int, [c_char, I64, DP, I64, VP]),
+    "gpc_zero_triangle_f64": (c_int, [c_char, I64, DP, I64, VP]),
+    "gpc_add_diag_f64": (c_int, [I64, DP, I64, c_double, VP]),
+    "gpc_trace_f64": (c_int, [I64, DP, I64, POINTER(c_double), VP]),
+    "gpc_coldot_f64": (c_int, [I64, I64, DP, I64, DP, I64, POINTER(c_double), VP]),
+    "gpc_colnorm2_f64": (c_int, [I64, I64, DP, I64, DP, VP]),
+    "gpc_symv_f64": (c_int, [I64, c_double, DP, I64, DP, c_double, DP, VP]),
+    "gpc_covgrad_f64": (c_int, [I64, DP, I64, DP, DP, I64, VP]),
+    "gpc_kern_grad_f64": (c_int, [POINTER(KSpec), DP, I64, I64, I64, DP, I64, POINTER(c_double), VP]),
+    "gpc_gp_update_k_f64": (c_int, [POINTER(KSpec), DP, I64, I64, I64, DP, I64, POINTER(c_double),
+                                    POINTER(c_double), POINTER(c_int), VP]),
+    "gpc_gp_alpha_f64": (c_int, [I64, I64, DP, I64, DP, I64, DP, I64, VP]),
+    "gpc_gp_loglik_f64": (c_int, [I64, I64, DP, I64, DP, I64, c_double, POINTER(c_double), VP]),
+    "gpc_gp_posterior_f64": (c_int, [POINTER(KSpec), DP, I64, I64, I64, DP, I64, DP, I64, I64, DP, I64, I64,
+                                     DP, I64, DP, I64, DP, VP]),
+    "gpc_set_potrf_blocking": (c_int, [I64, I64]),
+    "gpc_profile_enable": (c_int, [c_int]),
+    "gpc_profile_read": (c_int, [c_int, POINTER(c_int64), POINTER(c_double), POINTER(c_double), c_int]),
+    "gpc_probe_mfma_f64": (c_int, [POINTER(c_double), VP]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libgpc_hip.so once; raises (never falls back) when it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("gpc_amd: %s not found -- build it with `python -c 'import __graft_entry__ as g; "
+                          "g.build()'` (hipcc --offload-arch=gfx950); there is no CPU fallback" % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)   # AttributeError here = header/library mismatch: fail loudly
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc != GPC_OK:
+        msg = load().gpc_last_error()
+        raise GpcError(rc, msg.decode() if msg else "")
+    return rc

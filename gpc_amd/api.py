@@ -1,0 +1,279 @@
+"""Thin torch-tensor front end over the C-ABI (include/gpc_hip.h).
+
+torch is used for device memory and streams only.  All matrices are COLUMN-MAJOR fp64 like the reference's CMatrix
+(CMatrix.h:30): a matrix of shape (rows, cols) is a tensor with strides (1, ld).  Every function here is a direct
+call into libgpc_hip.so on torch's current stream; nothing is computed in Python or by torch.
+"""
+import ctypes
+from ctypes import byref, c_char, c_double, c_int, c_void_p
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import KSpec, check
+
+_KERN_CODES = {"rbf": _lib.GPC_KERN_RBF, "rbfard": _lib.GPC_KERN_RBFARD, "white": _lib.GPC_KERN_WHITE,
+               "bias": _lib.GPC_KERN_BIAS, "lin": _lib.GPC_KERN_LIN}
+
+
+def kspec(terms):
+    """terms: list of (type_name, [natural-space params]) in CCmpndKern::addKern order -> KSpec."""
+    ks = KSpec()
+    if len(terms) > _lib.GPC_MAX_TERMS:
+        raise ValueError("too many kernel terms")
+    ks.n_terms = len(terms)
+    off = 0
+    for t, (name, params) in enumerate(terms):
+        ks.types[t] = _KERN_CODES[name]
+        ks.offs[t] = off
+        for p in params:
+            if off >= _lib.GPC_MAX_PARAMS:
+                raise ValueError("too many kernel parameters")
+            ks.params[off] = float(p)
+            off += 1
+    ks.offs[len(terms)] = off
+    return ks
+
+
+def n_params(ks):
+    return ks.offs[ks.n_terms]
+
+
+# ---- column-major tensors -----------------------------------------------------------------------------------------
+
+def empty(rows, cols, device="cuda"):
+    """Uninitialised column-major (rows x cols) fp64 matrix."""
+    return torch.empty((cols, rows), dtype=torch.float64, device=device).t()
+
+
+def zeros(rows, cols, device="cuda"):
+    return torch.zeros((cols, rows), dtype=torch.float64, device=device).t()
+
+
+def from_host(a, device="cuda"):
+    """numpy (rows x cols) -> column-major device tensor."""
+    a = np.asarray(a, dtype=np.float64)
+    if a.ndim == 1:
+        a = a.reshape(-1, 1)
+    t = torch.from_numpy(np.ascontiguousarray(a.T)).to(device)
+    return t.t()
+
+
+def to_host(t):
+    return t.detach().cpu().numpy().copy()
+
+
+def _chk(t):
+    if t.dtype != torch.float64 or t.dim() != 2:
+        raise TypeError("expected a 2-D float64 tensor")
+    if t.shape[0] > 1 and t.stride(0) != 1:
+        raise ValueError("matrix is not column-major (stride(0) must be 1)")
+    return t
+
+
+def ld(t):
+    _chk(t)
+    return t.stride(1) if t.shape[1] > 1 else max(1, t.shape[0])
+
+
+def ptr(t):
+    return c_void_p(t.data_ptr())
+
+
+def stream():
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def lib():
+    return _lib.load()
+
+
+def device_info():
+    name = ctypes.create_string_buffer(256)
+    cus, hbm, clk = c_int(0), ctypes.c_size_t(0), c_int(0)
+    check(lib().gpc_device_info(name, 256, byref(cus), byref(hbm), byref(clk)))
+    return {"name": name.value.decode(), "cu_count": cus.value, "hbm_bytes": hbm.value, "clock_khz": clk.value}
+
+
+def _c(ch):
+    return c_char(ch.encode())
+
+
+# ---- Gram ----------------------------------------------------------------------------------------------------------
+
+def gram_sym(ks, X, out=None):
+    N, D = X.shape
+    K = out if out is not None else empty(N, N, X.device)
+    check(lib().gpc_gram_sym_f64(byref(ks), ptr(X), N, D, ld(X), ptr(K), ld(K), stream()))
+    return K
+
+
+def gram_cross(ks, X, X2, out=None):
+    N, D = X.shape
+    N2 = X2.shape[0]
+    K = out if out is not None else empty(N, N2, X.device)
+    check(lib().gpc_gram_cross_f64(byref(ks), ptr(X), N, ld(X), ptr(X2), N2, ld(X2), D, ptr(K), ld(K), stream()))
+    return K
+
+
+def gram_diag(ks, X):
+    N, D = X.shape
+    d = empty(N, 1, X.device)
+    check(lib().gpc_gram_diag_f64(byref(ks), ptr(X), N, D, ld(X), ptr(d), stream()))
+    return d
+
+
+def gram_block(ks, X, i0, m, j0, n, out=None):
+    N, D = X.shape
+    K = out if out is not None else empty(m, n, X.device)
+    check(lib().gpc_gram_block_f64(byref(ks), ptr(X), N, D, ld(X), i0, m, j0, n, ptr(K), ld(K), stream()))
+    return K
+
+
+# ---- Cholesky pipeline ---------------------------------------------------------------------------------------------
+
+def potrf(A, uplo="L"):
+    info = c_int(0)
+    check(lib().gpc_potrf_f64(_c(uplo), A.shape[0], ptr(A), ld(A), byref(info), stream()))
+    return info.value
+
+
+def chol(A, uplo="U"):
+    info = c_int(0)
+    check(lib().gpc_chol_f64(_c(uplo), A.shape[0], ptr(A), ld(A), byref(info), stream()))
+    return info.value
+
+
+def potri(A, uplo="L"):
+    check(lib().gpc_potri_f64(_c(uplo), A.shape[0], ptr(A), ld(A), stream()))
+    return A
+
+
+def trsm(A, B, side="L", uplo="L", trans="N", diag="N", alpha=1.0):
+    check(lib().gpc_trsm_f64(_c(side), _c(uplo), _c(trans), _c(diag), B.shape[0], B.shape[1], alpha,
+                             ptr(A), ld(A), ptr(B), ld(B), stream()))
+    return B
+
+
+def logdet_chol(A):
+    out = c_double(0.0)
+    check(lib().gpc_logdet_chol_f64(A.shape[0], ptr(A), ld(A), byref(out), stream()))
+    return out.value
+
+
+def trace(A):
+    out = c_double(0.0)
+    check(lib().gpc_trace_f64(A.shape[0], ptr(A), ld(A), byref(out), stream()))
+    return out.value
+
+
+def gemm(A, B, C, transa="N", transb="N", alpha=1.0, beta=0.0):
+    M, N = C.shape
+    K = A.shape[1] if transa.upper() == "N" else A.shape[0]
+    check(lib().gpc_gemm_f64(_c(transa), _c(transb), M, N, K, alpha, ptr(A), ld(A), ptr(B), ld(B), beta,
+                             ptr(C), ld(C), stream()))
+    return C
+
+
+def syrk(A, C, uplo="L", trans="N", alpha=1.0, beta=0.0):
+    N = C.shape[0]
+    K = A.shape[1] if trans.upper() == "N" else A.shape[0]
+    check(lib().gpc_syrk_f64(_c(uplo), _c(trans), N, K, alpha, ptr(A), ld(A), beta, ptr(C), ld(C), stream()))
+    return C
+
+
+def transpose_(A):
+    check(lib().gpc_transpose_inplace_f64(A.shape[0], ptr(A), ld(A), stream()))
+    return A
+
+
+def symmetrize_(A, uplo="L"):
+    check(lib().gpc_symmetrize_f64(_c(uplo), A.shape[0], ptr(A), ld(A), stream()))
+    return A
+
+
+def zero_triangle_(A, uplo_to_zero):
+    check(lib().gpc_zero_triangle_f64(_c(uplo_to_zero), A.shape[0], ptr(A), ld(A), stream()))
+    return A
+
+
+def add_diag_(A, c):
+    check(lib().gpc_add_diag_f64(A.shape[0], ptr(A), ld(A), float(c), stream()))
+    return A
+
+
+def coldot(A, B):
+    M, nc = A.shape
+    out = (c_double * max(nc, 1))()
+    check(lib().gpc_coldot_f64(M, nc, ptr(A), ld(A), ptr(B), ld(B), out, stream()))
+    return np.array(out[:nc])
+
+
+def colnorm2(A):
+    M, nc = A.shape
+    out = empty(nc, 1, A.device)
+    check(lib().gpc_colnorm2_f64(M, nc, ptr(A), ld(A), ptr(out), stream()))
+    return out
+
+
+def symv(A, x, y=None, alpha=1.0, beta=0.0):
+    N = A.shape[0]
+    if y is None:
+        y = zeros(N, 1, A.device)
+    check(lib().gpc_symv_f64(N, alpha, ptr(A), ld(A), ptr(x), beta, ptr(y), stream()))
+    return y
+
+
+def covgrad(invK, a, out=None):
+    N = invK.shape[0]
+    cg = out if out is not None else empty(N, N, invK.device)
+    check(lib().gpc_covgrad_f64(N, ptr(invK), ld(invK), ptr(a), ptr(cg), ld(cg), stream()))
+    return cg
+
+
+def kern_grad(ks, X, covGrad):
+    N, D = X.shape
+    g = (c_double * max(n_params(ks), 1))()
+    check(lib().gpc_kern_grad_f64(byref(ks), ptr(X), N, D, ld(X), ptr(covGrad), ld(covGrad), g, stream()))
+    return np.array(g[:n_params(ks)])
+
+
+# ---- fused CGp (FTC) drivers ----------------------------------------------------------------------------------------
+
+def gp_update_k(ks, X, K=None):
+    """Gram + in-place lower Cholesky + log-determinant.  Returns (L (in K's storage), logdet, jitter, info)."""
+    N, D = X.shape
+    if K is None:
+        K = empty(N, N, X.device)
+    logdet, jit, info = c_double(0.0), c_double(0.0), c_int(0)
+    check(lib().gpc_gp_update_k_f64(byref(ks), ptr(X), N, D, ld(X), ptr(K), ld(K), byref(logdet), byref(jit),
+                                    byref(info), stream()))
+    return K, logdet.value, jit.value, info.value
+
+
+def gp_alpha(L, m, out=None):
+    N, d = m.shape
+    A = out if out is not None else empty(N, d, m.device)
+    check(lib().gpc_gp_alpha_f64(N, d, ptr(L), ld(L), ptr(m), ld(m), ptr(A), ld(A), stream()))
+    return A
+
+
+def gp_loglik(m, Alpha, logdet):
+    N, d = m.shape
+    ll = c_double(0.0)
+    check(lib().gpc_gp_loglik_f64(N, d, ptr(m), ld(m), ptr(Alpha), ld(Alpha), logdet, byref(ll), stream()))
+    return ll.value
+
+
+def gp_posterior(ks, X, L, Alpha, Xs, want_var=True):
+    N, D = X.shape
+    Ns = Xs.shape[0]
+    d = Alpha.shape[1]
+    kX = empty(N, Ns, X.device)
+    mu = empty(Ns, d, X.device)
+    var = empty(Ns, 1, X.device) if want_var else None
+    check(lib().gpc_gp_posterior_f64(byref(ks), ptr(X), N, D, ld(X), ptr(L), ld(L), ptr(Alpha), ld(Alpha), d,
+                                     ptr(Xs), Ns, ld(Xs), ptr(kX), ld(kX), ptr(mu), ld(mu),
+                                     ptr(var) if want_var else c_void_p(0), stream()))
+    return mu, var

@@ -1,0 +1,331 @@
+// gemm_f64.hip -- fp64 GEMM / SYRK on v_mfma_f64_16x16x4_f64 for gfx950.
+//
+// This is the O(N^3) engine of the Cholesky pipeline: the trailing SYRK update of the right-looking dpotrf, the
+// GEMM form of the panel triangular solve, and the block updates of dtrsm / dpotri (replaces the reference's
+// dsyrk_/dgemm_/dtrsm_ calls, lapack.h:165-218, as driven by CMatrix.cpp:272-295,371-432).
+//
+// Design (cdna_hip_programming.md section 5, adapted to fp64):
+//   * block tile 128 x 128, 4 waves (2 x 2), each wave a 64 x 64 patch = 4 x 4 MFMA tiles of 16 x 16,
+//     accumulators 16 x double4 = 128 VGPRs; 2 workgroups per CU (one wave of each per SIMD) so that one block's
+//     barrier / staging hides behind the other's MFMAs.  fp64 MFMA is slow (64 cycles per 16x16x4 per SIMD), so
+//     16 MFMAs = 1024 cycles pay for 8 ds_read_b64 per k-step: operand delivery is never the limiter.
+//   * K is staged 16 deep through LDS, double buffered, register-staged prefetch of the next stage issued
+//     before the MFMA block, one barrier per stage.
+//   * two LDS images per operand, both conflict-free for the 32-lane ds_read_b64 groups:
+//       MC (operand contiguous along its m/n index in memory): [k][m], row stride 144 doubles (144 = 16 mod 32)
+//       KC (operand contiguous along k in memory)            : [m][k], row stride 18 doubles
+//   * MFMA operand roles are swapped (A-operand <- our B tile, B-operand <- our A tile) so that the 16 lanes that
+//     share an accumulator register hold 16 consecutive rows of C: column-major stores go out in 128-byte runs.
+//   * workgroup -> tile map is XCD-aware: the dispatcher places block b on XCD b%8, so logical ids are dealt in
+//     contiguous chunks per XCD and consecutive ids walk 8 x 8 super-tiles; the 64 tiles a XCD has in flight share
+//     8 + 8 operand panels in its private L2.  Triangular (SYRK) launches enumerate lower super-tiles only.
+#include "gpc_common.hpp"
+#include <math.h>
+
+namespace gpc {
+
+namespace {
+
+constexpr int BM = 128;
+constexpr int BN = 128;
+constexpr int BK = 16;
+constexpr int STRIDE_MC = 144;  // [k][m] row stride in doubles
+constexpr int STRIDE_KC = 18;   // [m][k] row stride in doubles
+constexpr int OP_ELEMS = 2304;  // 16*144 == 128*18 doubles per operand per stage
+constexpr int STAGE_ELEMS = 2 * OP_ELEMS;
+constexpr int GEMM_LDS_BYTES = 2 * STAGE_ELEMS * 8;  // 73,728 B -> two workgroups per CU
+constexpr int SUPER = 8;
+
+struct GemmArgs {
+  const double* A;
+  const double* B;
+  double* C;
+  int64_t lda, ldb, ldc;
+  int64_t M, N, K;
+  double alpha, beta;
+  int tiles_m, tiles_n;
+  int super_m, super_n;  // super-tile counts
+  int tri;               // 0 full, 1 lower (i >= j, C square), 2 upper (i <= j, C square),
+                         // 3 lower trapezoid (i >= j, M >= N, full enumeration with skipped tiles)
+};
+
+// ---- global -> registers -------------------------------------------------------------------------------------
+// One operand stage = 128 (row index r) x 16 (k) doubles = 4 double2 per thread.
+// KC=false: element (r,k) at P[r + k*ld]; thread owns rows 2*lane, 2*lane+1 and k = wave + 4*i.
+// KC=true : element (r,k) at P[k + r*ld]; thread owns k = 2*(t&7), +1 and rows (t>>3) + 32*i.
+template <bool KC, bool VEC>
+__device__ __forceinline__ void load_stage(const double* __restrict__ P, int64_t ld, int64_t r0, int64_t rmax,
+                                           int64_t k0, int64_t kmax, bool full, double2_t (&reg)[4])
+{
+  const int t = threadIdx.x;
+  if(!KC) {
+    const int64_t r = r0 + 2 * (t & 63);
+    const int64_t kb = k0 + (t >> 6);
+#pragma unroll
+    for(int i = 0; i < 4; i++) {
+      const int64_t k = kb + 4 * i;
+      const double* p = P + r + k * ld;
+      if(VEC && full) {
+        reg[i] = *reinterpret_cast<const double2_t*>(p);
+      } else {
+        double2_t v = {0.0, 0.0};
+        if(k < kmax) {
+          if(r < rmax) v.x = p[0];
+          if(r + 1 < rmax) v.y = p[1];
+        }
+        reg[i] = v;
+      }
+    }
+  } else {
+    const int64_t k = k0 + 2 * (t & 7);
+    const int64_t rb = r0 + (t >> 3);
+#pragma unroll
+    for(int i = 0; i < 4; i++) {
+      const int64_t r = rb + 32 * i;
+      const double* p = P + k + r * ld;
+      if(VEC && full) {
+        reg[i] = *reinterpret_cast<const double2_t*>(p);
+      } else {
+        double2_t v = {0.0, 0.0};
+        if(r < rmax) {
+          if(k < kmax) v.x = p[0];
+          if(k + 1 < kmax) v.y = p[1];
+        }
+        reg[i] = v;
+      }
+    }
+  }
+}
+
+// ---- registers -> LDS ------------------------------------------------------------------------------------------
+template <bool KC>
+__device__ __forceinline__ void store_stage(double* __restrict__ lds, const double2_t (&reg)[4])
+{
+  const int t = threadIdx.x;
+  if(!KC) {
+    const int m = 2 * (t & 63);
+    const int kb = t >> 6;
+#pragma unroll
+    for(int i = 0; i < 4; i++)
+      *reinterpret_cast<double2_t*>(lds + (kb + 4 * i) * STRIDE_MC + m) = reg[i];
+  } else {
+    const int k = 2 * (t & 7);
+    const int rb = t >> 3;
+#pragma unroll
+    for(int i = 0; i < 4; i++)
+      *reinterpret_cast<double2_t*>(lds + (rb + 32 * i) * STRIDE_KC + k) = reg[i];
+  }
+}
+
+// LDS fragment address of (row = base + lane&15, k = kk*4 + lane>>4)
+template <bool KC>
+__device__ __forceinline__ int frag_off(int base, int kk, int lane)
+{
+  if(!KC) return (kk * 4 + (lane >> 4)) * STRIDE_MC + base + (lane & 15);
+  return (base + (lane & 15)) * STRIDE_KC + kk * 4 + (lane >> 4);
+}
+
+// logical block id -> (tile_i, tile_j); returns false if this slot has no tile
+__device__ __forceinline__ bool map_tile(const GemmArgs& g, int& ti, int& tj)
+{
+  // XCD-aware deal: hardware block b runs on XCD b % 8; give each XCD a contiguous range of logical ids.
+  const unsigned nb = gridDim.x;  // multiple of 8
+  const unsigned b = blockIdx.x;
+  const unsigned L = (b & 7u) * (nb >> 3) + (b >> 3);
+  const unsigned s = L / (SUPER * SUPER);
+  const unsigned w = L % (SUPER * SUPER);
+  int si, sj;
+  if(g.tri == 0 || g.tri == 3) {
+    if(s >= (unsigned)(g.super_m * g.super_n)) return false;
+    si = s % g.super_m;
+    sj = s / g.super_m;
+  } else {
+    // triangular numbering over super-tile rows: s = si*(si+1)/2 + sj, sj <= si
+    const unsigned total = (unsigned)g.super_m * (unsigned)(g.super_m + 1) / 2;
+    if(s >= total) return false;
+    int r = (int)((sqrt(8.0 * (double)s + 1.0) - 1.0) * 0.5);
+    while((unsigned)(r + 1) * (unsigned)(r + 2) / 2 <= s) r++;
+    while((unsigned)r * (unsigned)(r + 1) / 2 > s) r--;
+    si = r;
+    sj = (int)(s - (unsigned)r * (unsigned)(r + 1) / 2);
+    if(g.tri == 2) {  // upper: swap roles
+      int tmp = si;
+      si = sj;
+      sj = tmp;
+    }
+  }
+  ti = si * SUPER + (int)(w % SUPER);
+  tj = sj * SUPER + (int)(w / SUPER);
+  if(ti >= g.tiles_m || tj >= g.tiles_n) return false;
+  if((g.tri == 1 || g.tri == 3) && tj > ti) return false;
+  if(g.tri == 2 && tj < ti) return false;
+  return true;
+}
+
+template <bool A_KC, bool B_KC, bool VEC>
+__global__ void __launch_bounds__(256, 2) gemm_f64_kernel(const GemmArgs g)
+{
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  int ti, tj;
+  if(!map_tile(g, ti, tj)) return;
+
+  const int t = threadIdx.x;
+  const int lane = t & 63;
+  const int wave = t >> 6;
+  const int wm = wave & 1;
+  const int wn = wave >> 1;
+  const int64_t m0 = (int64_t)ti * BM;
+  const int64_t n0 = (int64_t)tj * BN;
+  const bool full_mn = (m0 + BM <= g.M) && (n0 + BN <= g.N);
+
+  double4_t acc[4][4];
+#pragma unroll
+  for(int i = 0; i < 4; i++)
+#pragma unroll
+    for(int j = 0; j < 4; j++) acc[i][j] = (double4_t){0.0, 0.0, 0.0, 0.0};
+
+  const int64_t KT = (g.K + BK - 1) / BK;
+  double2_t ra[4], rb[4];
+
+  if(KT > 0) {
+    const bool full0 = full_mn && (BK <= g.K);
+    load_stage<A_KC, VEC>(g.A, g.lda, m0, g.M, 0, g.K, full0, ra);
+    load_stage<B_KC, VEC>(g.B, g.ldb, n0, g.N, 0, g.K, full0, rb);
+    store_stage<A_KC>(lds, ra);
+    store_stage<B_KC>(lds + OP_ELEMS, rb);
+  }
+  __syncthreads();
+
+  for(int64_t kt = 0; kt < KT; kt++) {
+    const double* cur = lds + (kt & 1) * STAGE_ELEMS;
+    double* nxt = lds + ((kt + 1) & 1) * STAGE_ELEMS;
+    const bool more = (kt + 1 < KT);
+    if(more) {
+      const int64_t k0 = (kt + 1) * BK;
+      const bool fullk = full_mn && (k0 + BK <= g.K);
+      load_stage<A_KC, VEC>(g.A, g.lda, m0, g.M, k0, g.K, fullk, ra);
+      load_stage<B_KC, VEC>(g.B, g.ldb, n0, g.N, k0, g.K, fullk, rb);
+    }
+    const double* As = cur;
+    const double* Bs = cur + OP_ELEMS;
+#pragma unroll
+    for(int kk = 0; kk < 4; kk++) {
+      double a[4], b[4];
+#pragma unroll
+      for(int s = 0; s < 4; s++) {
+        a[s] = As[frag_off<A_KC>(wm * 64 + s * 16, kk, lane)];
+        b[s] = Bs[frag_off<B_KC>(wn * 64 + s * 16, kk, lane)];
+      }
+#pragma unroll
+      for(int tn = 0; tn < 4; tn++)
+#pragma unroll
+        for(int tm = 0; tm < 4; tm++)
+          acc[tm][tn] = __builtin_amdgcn_mfma_f64_16x16x4f64(b[tn], a[tm], acc[tm][tn], 0, 0, 0);
+    }
+    if(more) {
+      store_stage<A_KC>(nxt, ra);
+      store_stage<B_KC>(nxt + OP_ELEMS, rb);
+    }
+    __syncthreads();
+  }
+
+  // epilogue: lane l, register r of acc[tm][tn] holds C(m, n) with
+  //   m = m0 + wm*64 + tm*16 + (l & 15),   n = n0 + wn*64 + tn*16 + (l >> 4) + 4*r
+  const double alpha = g.alpha, beta = g.beta;
+  const bool diag_tile = (g.tri != 0) && (ti == tj);
+#pragma unroll
+  for(int tn = 0; tn < 4; tn++) {
+#pragma unroll
+    for(int tm = 0; tm < 4; tm++) {
+      const int64_t m = m0 + wm * 64 + tm * 16 + (lane & 15);
+#pragma unroll
+      for(int r = 0; r < 4; r++) {
+        const int64_t n = n0 + wn * 64 + tn * 16 + (lane >> 4) + 4 * r;
+        bool ok = full_mn || (m < g.M && n < g.N);
+        if(diag_tile) ok = ok && (g.tri == 2 ? (m <= n) : (m >= n));
+        if(ok) {
+          double* p = g.C + m + n * g.ldc;
+          double v = alpha * acc[tm][tn][r];
+          if(beta != 0.0) v += beta * (*p);
+          *p = v;
+        }
+      }
+    }
+  }
+}
+
+template <bool A_KC, bool B_KC, bool VEC>
+int launch(const GemmArgs& g, unsigned grid, hipStream_t s)
+{
+  static bool attr_set = false;
+  auto kern = gemm_f64_kernel<A_KC, B_KC, VEC>;
+  if(!attr_set) {
+    GPC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), GEMM_LDS_BYTES, s, g);
+  GPC_HIP_CHECK(hipGetLastError());
+  return GPC_OK;
+}
+
+}  // namespace
+
+int gemm(bool transa, bool transb, int64_t M, int64_t N, int64_t K, double alpha, const double* A, int64_t lda,
+         const double* B, int64_t ldb, double beta, double* C, int64_t ldc, int tri, hipStream_t s)
+{
+  if(M <= 0 || N <= 0) return GPC_OK;
+  GemmArgs g;
+  g.A = A;
+  g.B = B;
+  g.C = C;
+  g.lda = lda;
+  g.ldb = ldb;
+  g.ldc = ldc;
+  g.M = M;
+  g.N = N;
+  g.K = K < 0 ? 0 : K;
+  g.alpha = alpha;
+  g.beta = beta;
+  g.tiles_m = (int)((M + BM - 1) / BM);
+  g.tiles_n = (int)((N + BN - 1) / BN);
+  g.super_m = (g.tiles_m + SUPER - 1) / SUPER;
+  g.super_n = (g.tiles_n + SUPER - 1) / SUPER;
+  g.tri = tri;
+  if((tri == 1 || tri == 2) && M != N) {
+    set_error("triangular gemm needs a square C");
+    return GPC_EINVAL;
+  }
+  if(tri == 3 && M < N) {
+    set_error("trapezoid gemm needs M >= N");
+    return GPC_EINVAL;
+  }
+  uint64_t slots;
+  if(tri == 0 || tri == 3)
+    slots = (uint64_t)g.super_m * g.super_n * SUPER * SUPER;
+  else
+    slots = (uint64_t)g.super_m * (g.super_m + 1) / 2 * SUPER * SUPER;
+  slots = (slots + 7) & ~7ull;
+  if(slots > 0x7fffffffull) {
+    set_error("gemm grid too large");
+    return GPC_EINVAL;
+  }
+  // A is "k-contiguous" when transposed (stored K x M); B is k-contiguous when NOT transposed (stored K x N).
+  const bool a_kc = transa;
+  const bool b_kc = !transb;
+  const bool vec = ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B)) & 15) == 0 &&
+                   (lda % 2 == 0) && (ldb % 2 == 0);
+  const unsigned grid = (unsigned)slots;
+#define GPC_GEMM_CASE(AK, BK_)                                           \
+  if(a_kc == AK && b_kc == BK_) {                                        \
+    return vec ? launch<AK, BK_, true>(g, grid, s) : launch<AK, BK_, false>(g, grid, s); \
+  }
+  GPC_GEMM_CASE(false, false)
+  GPC_GEMM_CASE(false, true)
+  GPC_GEMM_CASE(true, false)
+  GPC_GEMM_CASE(true, true)
+#undef GPC_GEMM_CASE
+  return GPC_EINVAL;
+}
+
+}  // namespace gpc

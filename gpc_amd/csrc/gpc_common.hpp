@@ -1,0 +1,95 @@
+// gpc_common.hpp -- shared declarations of libgpc_hip.so (gfx950 only; no portability layer on purpose).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include "gpc_hip.h"
+
+namespace gpc {
+
+typedef double double2_t __attribute__((ext_vector_type(2)));
+typedef double double4_t __attribute__((ext_vector_type(4)));
+
+void set_error(const char* fmt, ...);
+
+#define GPC_HIP_CHECK(expr)                                                                          \
+  do {                                                                                               \
+    hipError_t e__ = (expr);                                                                         \
+    if(e__ != hipSuccess) {                                                                          \
+      gpc::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), __FILE__, __LINE__);    \
+      return GPC_EHIP;                                                                               \
+    }                                                                                                \
+  } while(0)
+
+#define GPC_CHECK(expr)                \
+  do {                                 \
+    int rc__ = (expr);                 \
+    if(rc__ != GPC_OK) return rc__;    \
+  } while(0)
+
+#define GPC_REQUIRE(cond, msg)                                  \
+  do {                                                          \
+    if(!(cond)) {                                               \
+      gpc::set_error("invalid argument: %s (%s)", msg, #cond);  \
+      return GPC_EINVAL;                                        \
+    }                                                           \
+  } while(0)
+
+inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+// Grow-only device scratch, one buffer per slot (slots are owned by the routine that names them).
+enum WorkspaceSlot {
+  WS_POTRF_INV = 0,   // inverted diagonal blocks (potrf / trsm / potri)
+  WS_TRSM_TMP = 1,    // out-of-place diagonal-block products
+  WS_REDUCE = 2,      // partial sums of reductions
+  WS_INFO = 3,        // device-side info / flags
+  WS_KERN = 4,        // kernel-gradient partials
+  WS_POTRI = 5,       // trtri scratch
+  WS_XSCALED = 6,     // reserved
+  WS_NSLOTS = 8
+};
+int workspace(int slot, size_t bytes, void** out);
+int ensure_device();
+
+// ---- internal (device-pointer) building blocks; all asynchronous on `s` ----------------------------------------
+// C := alpha*op(A)*op(B) + beta*C.  tri: 0 = full, 1 = write only i>=j (C square), 2 = only i<=j (C square),
+// 3 = only i>=j for a tall C (M >= N) whose (0,0) sits on the diagonal.
+int gemm(bool transa, bool transb, int64_t M, int64_t N, int64_t K, double alpha, const double* A, int64_t lda,
+         const double* B, int64_t ldb, double beta, double* C, int64_t ldc, int tri, hipStream_t s);
+int potrf_lower(int64_t N, double* A, int64_t lda, int* d_info, hipStream_t s);
+int trsm(char side, char uplo, char trans, char diag, int64_t M, int64_t Nrhs, double alpha, const double* A,
+         int64_t lda, double* B, int64_t ldb, hipStream_t s);
+int potri_full(bool lower, int64_t N, double* A, int64_t lda, hipStream_t s);
+int transpose_inplace(int64_t N, double* A, int64_t lda, hipStream_t s);
+int symmetrize(bool from_lower, int64_t N, double* A, int64_t lda, hipStream_t s);
+int zero_triangle(bool zero_lower, int64_t N, double* A, int64_t lda, hipStream_t s);
+int add_diag(int64_t N, double* A, int64_t lda, double c, hipStream_t s);
+// sum over the diagonal of f(A(i,i)): what = 0 trace, 1 sum of log.  Result to a host double (synchronises).
+int diag_reduce(int what, int64_t N, const double* A, int64_t lda, double* out_host, hipStream_t s);
+// Invert the jb x jb diagonal blocks of a triangular matrix (order N) into `inv` (block b at inv + b*jb*jb,
+// leading dimension jb, other triangle zero).  unit: treat the diagonal as ones.
+int invert_diag_blocks(bool lower, bool unit, int64_t N, int64_t jb, const double* A, int64_t lda, double* inv,
+                       hipStream_t s);
+
+// device-side kernel spec: terms collapsed into what a Gram element needs
+struct KSpecDev {
+  int n_rbf;                 // terms sharing the unscaled squared distance
+  double rbf_hiw[4];         // 0.5 * inverseWidth
+  double rbf_var[4];
+  int n_ard;
+  double ard_hiw[2];
+  double ard_var[2];
+  double ard_scale[2][GPC_MAX_ARD_DIM];
+  double lin_var;            // sum of linear variances (0 if none)
+  double bias_var;           // sum of bias variances
+  double white_var;          // sum of white variances
+  int need_dot;              // rbf or lin present
+};
+int collapse_kspec(const gpc_kspec* ks, int64_t D, KSpecDev* out);
+
+// Optional HIP-event instrumentation of the dominant launches (bench.py's roofline leg; off by default).
+enum ProfKind { PROF_SYRK = 0, PROF_GRAM = 1, PROF_NKINDS = 2 };
+void prof_begin(int kind, double algorithmic_work, hipStream_t s);
+void prof_end(int kind, hipStream_t s);
+
+}  // namespace gpc

@@ -1,0 +1,373 @@
+// gram.hip -- Gram-matrix construction for compound kernels (rbf, rbfard, white, bias, lin) on gfx950.
+//
+// Replaces the reference's scalar double loops: CKern::compute(K,X) (CKern.h:128-144) == CGp::_updateK FTC
+// (CGp.cpp:698-712), CKern::compute(K,X,X2) (CKern.h:146-157), CKern::diagCompute (CKern.h:49-55), with the element
+// formulas of CRbfKern::computeElement (CKern.cpp:1147-1154: variance*exp(-0.5*inverseWidth*dist2), dist2 by the
+// |x|^2+|x'|^2-2x.x' form of CMatrix::dist2Row, CMatrix.h:554-560), CRbfardKern::computeElement (CKern.cpp:3305-3316),
+// CWhiteKern (702-723), CBiasKern (989-1001), CLinKern (2328-2341), summed as CCmpndKern does (CKern.cpp:219-226).
+//
+// The kernel is HBM-write bound (8 N^2 bytes out, 8 N D in): each workgroup produces a 128 (i) x 32 (j) patch,
+// thread = 2 consecutive rows x 8 columns, so every store instruction of a wave is one contiguous 1 KiB run of a
+// column of K.  X is staged through LDS in 16-deep feature chunks ([d][i], i contiguous = as stored), the row norms
+// come from a pre-pass, and the cross term is an FMA dot product per pair.  The diagonal of the symmetric Gram uses
+// the reference's diagComputeElement values exactly (variance sums), not exp(-0).
+#include "gpc_common.hpp"
+#include <string.h>
+
+namespace gpc {
+
+namespace {
+
+constexpr int TI = 128;  // rows per workgroup
+constexpr int TJ = 32;   // columns per workgroup
+constexpr int DC = 16;   // feature chunk
+
+struct GramArgs {
+  const double* X;    // rows (i)
+  const double* X2;   // columns (j)
+  const double* n1;   // |x_i|^2
+  const double* n2;   // |x2_j|^2
+  double* K;
+  int64_t ldx, ldx2, ldk;
+  int64_t N, N2, D;
+  int64_t i_off, j_off;  // global indices of K(0,0) in the symmetric Gram (for the diagonal)
+  int sym_diag;          // 1: elements with global i == j take the diagComputeElement value
+};
+
+__global__ void __launch_bounds__(256) row_norms_kernel(const double* __restrict__ X, int64_t ldx, int64_t N,
+                                                        int64_t D, double* __restrict__ out)
+{
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if(i >= N) return;
+  double acc = 0.0;
+  for(int64_t d = 0; d < D; d++) {
+    const double x = X[i + d * ldx];
+    acc = fma(x, x, acc);
+  }
+  out[i] = acc;
+}
+
+template <bool DOT, int NARD>
+__global__ void __launch_bounds__(256) gram_kernel(const KSpecDev ks, const GramArgs g)
+{
+  __shared__ __attribute__((aligned(16))) double Xi[DC * TI];
+  __shared__ __attribute__((aligned(16))) double Xj[DC * TJ];
+  __shared__ __attribute__((aligned(16))) double Ai[(NARD > 0 ? DC * TI : 2)];
+  __shared__ __attribute__((aligned(16))) double Aj[(NARD > 0 ? DC * TJ : 2)];
+
+  const int t = threadIdx.x;
+  const int lane = t & 63, w = t >> 6;
+  const int64_t i0 = (int64_t)blockIdx.x * TI;
+  const int64_t j0 = (int64_t)blockIdx.y * TJ;
+  const int il = 2 * lane;  // local rows il, il+1
+  const int jl = 8 * w;     // local cols jl .. jl+7
+
+  double dot[2][8], ard[2][8];
+#pragma unroll
+  for(int a = 0; a < 2; a++)
+#pragma unroll
+    for(int b = 0; b < 8; b++) {
+      dot[a][b] = 0.0;
+      ard[a][b] = 0.0;
+    }
+
+  for(int64_t d0 = 0; d0 < g.D; d0 += DC) {
+    const int dc = (int)((g.D - d0 < DC) ? (g.D - d0) : DC);
+    // stage X rows: DC x 128 doubles, thread t loads (d = t>>4 .. , i = (t&15)*8 ...) -> simple strided loop
+    for(int idx = t; idx < DC * TI; idx += 256) {
+      const int d = idx / TI, i = idx % TI;
+      double v = 0.0;
+      if(d < dc && i0 + i < g.N) v = g.X[(i0 + i) + (d0 + d) * g.ldx];
+      if(DOT) Xi[idx] = v;
+      if(NARD > 0) Ai[idx] = v * sqrt(ks.ard_scale[0][(d0 + d) < GPC_MAX_ARD_DIM ? (d0 + d) : 0]);
+    }
+    for(int idx = t; idx < DC * TJ; idx += 256) {
+      const int d = idx / TJ, j = idx % TJ;
+      double v = 0.0;
+      if(d < dc && j0 + j < g.N2) v = g.X2[(j0 + j) + (d0 + d) * g.ldx2];
+      if(DOT) Xj[idx] = v;
+      if(NARD > 0) Aj[idx] = v * sqrt(ks.ard_scale[0][(d0 + d) < GPC_MAX_ARD_DIM ? (d0 + d) : 0]);
+    }
+    __syncthreads();
+    for(int d = 0; d < dc; d++) {
+      if(DOT) {
+        const double2_t xi = *reinterpret_cast<const double2_t*>(&Xi[d * TI + il]);
+        double xj[8];
+#pragma unroll
+        for(int q = 0; q < 4; q++) {
+          const double2_t v = *reinterpret_cast<const double2_t*>(&Xj[d * TJ + jl + 2 * q]);
+          xj[2 * q] = v.x;
+          xj[2 * q + 1] = v.y;
+        }
+#pragma unroll
+        for(int b = 0; b < 8; b++) {
+          dot[0][b] = fma(xi.x, xj[b], dot[0][b]);
+          dot[1][b] = fma(xi.y, xj[b], dot[1][b]);
+        }
+      }
+      if(NARD > 0) {
+        const double2_t xi = *reinterpret_cast<const double2_t*>(&Ai[d * TI + il]);
+        double xj[8];
+#pragma unroll
+        for(int q = 0; q < 4; q++) {
+          const double2_t v = *reinterpret_cast<const double2_t*>(&Aj[d * TJ + jl + 2 * q]);
+          xj[2 * q] = v.x;
+          xj[2 * q + 1] = v.y;
+        }
+#pragma unroll
+        for(int b = 0; b < 8; b++) {
+          const double e0 = xi.x - xj[b], e1 = xi.y - xj[b];
+          ard[0][b] = fma(e0, e0, ard[0][b]);
+          ard[1][b] = fma(e1, e1, ard[1][b]);
+        }
+      }
+    }
+    __syncthreads();
+  }
+
+  // epilogue
+  const int64_t gi = i0 + il;
+  double ni[2] = {0.0, 0.0};
+  if(DOT) {
+    if(gi < g.N) ni[0] = g.n1[gi];
+    if(gi + 1 < g.N) ni[1] = g.n1[gi + 1];
+  }
+  double diag_const = ks.bias_var + ks.white_var;
+  for(int r = 0; r < ks.n_rbf; r++) diag_const += ks.rbf_var[r];
+  for(int r = 0; r < ks.n_ard; r++) diag_const += ks.ard_var[r];
+  const bool vec_ok = ((g.ldk & 1) == 0) && ((reinterpret_cast<uintptr_t>(g.K) & 15) == 0);
+#pragma unroll
+  for(int b = 0; b < 8; b++) {
+    const int64_t gj = j0 + jl + b;
+    if(gj >= g.N2) continue;
+    const double nj = DOT ? g.n2[gj] : 0.0;
+    double out[2];
+#pragma unroll
+    for(int a = 0; a < 2; a++) {
+      double k = ks.bias_var;
+      if(DOT) {
+        const double d2 = ni[a] + nj - 2.0 * dot[a][b];
+        for(int r = 0; r < ks.n_rbf; r++) k += ks.rbf_var[r] * exp(-(ks.rbf_hiw[r] * d2));
+        k += ks.lin_var * dot[a][b];
+      }
+      if(NARD > 0) k += ks.ard_var[0] * exp(-(ard[a][b] * ks.ard_hiw[0]));
+      if(g.sym_diag && (g.i_off + gi + a == g.j_off + gj)) k = diag_const + (DOT ? ks.lin_var * ni[a] : 0.0);
+      out[a] = k;
+    }
+    double* p = g.K + gi + gj * g.ldk;
+    if(gi + 1 < g.N) {
+      if(vec_ok)
+        *reinterpret_cast<double2_t*>(p) = (double2_t){out[0], out[1]};
+      else {
+        p[0] = out[0];
+        p[1] = out[1];
+      }
+    } else if(gi < g.N) {
+      p[0] = out[0];
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256) gram_diag_kernel(const KSpecDev ks, const double* __restrict__ X,
+                                                        int64_t ldx, int64_t N, int64_t D, double* __restrict__ d)
+{
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if(i >= N) return;
+  double k = ks.bias_var + ks.white_var;
+  for(int r = 0; r < ks.n_rbf; r++) k += ks.rbf_var[r];
+  for(int r = 0; r < ks.n_ard; r++) k += ks.ard_var[r];
+  if(ks.lin_var != 0.0) {
+    double acc = 0.0;
+    for(int64_t q = 0; q < D; q++) {
+      const double x = X[i + q * ldx];
+      acc = fma(x, x, acc);
+    }
+    k += ks.lin_var * acc;
+  }
+  d[i] = k;
+}
+
+int launch_gram(const KSpecDev& ks, const GramArgs& g, hipStream_t s)
+{
+  if(g.N <= 0 || g.N2 <= 0) return GPC_OK;
+  const uint64_t gx = (uint64_t)((g.N + TI - 1) / TI);
+  const uint64_t gy = (uint64_t)((g.N2 + TJ - 1) / TJ);
+  if(gy > 65535) {
+    // split the column range (grid.y limit)
+    const int64_t step = 65535LL * TJ;
+    for(int64_t c0 = 0; c0 < g.N2; c0 += step) {
+      GramArgs h = g;
+      h.N2 = (g.N2 - c0 < step) ? (g.N2 - c0) : step;
+      h.X2 = g.X2 + c0;
+      h.n2 = g.n2 ? g.n2 + c0 : nullptr;
+      h.K = g.K + c0 * g.ldk;
+      h.j_off = g.j_off + c0;
+      GPC_CHECK(launch_gram(ks, h, s));
+    }
+    return GPC_OK;
+  }
+  const dim3 grid((unsigned)gx, (unsigned)gy), block(256);
+  const bool dot = ks.need_dot != 0;
+  // algorithmic bytes: the K block written + the X rows read once
+  prof_begin(PROF_GRAM, 8.0 * ((double)g.N * (double)g.N2 + (double)(g.N + g.N2) * (double)g.D), s);
+  if(dot && ks.n_ard == 0)
+    hipLaunchKernelGGL((gram_kernel<true, 0>), grid, block, 0, s, ks, g);
+  else if(dot && ks.n_ard == 1)
+    hipLaunchKernelGGL((gram_kernel<true, 1>), grid, block, 0, s, ks, g);
+  else if(!dot && ks.n_ard == 1)
+    hipLaunchKernelGGL((gram_kernel<false, 1>), grid, block, 0, s, ks, g);
+  else if(!dot && ks.n_ard == 0)
+    hipLaunchKernelGGL((gram_kernel<false, 0>), grid, block, 0, s, ks, g);
+  else {
+    set_error("gram: more than one rbfard term is not accelerated");
+    return GPC_EUNSUPPORTED;
+  }
+  prof_end(PROF_GRAM, s);
+  GPC_HIP_CHECK(hipGetLastError());
+  return GPC_OK;
+}
+
+int norms(const double* X, int64_t ldx, int64_t N, int64_t D, double* out, hipStream_t s)
+{
+  if(N <= 0) return GPC_OK;
+  hipLaunchKernelGGL(row_norms_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, X, ldx, N, D, out);
+  GPC_HIP_CHECK(hipGetLastError());
+  return GPC_OK;
+}
+
+}  // namespace
+
+int collapse_kspec(const gpc_kspec* ks, int64_t D, KSpecDev* o)
+{
+  if(!ks || ks->n_terms < 0 || ks->n_terms > GPC_MAX_TERMS) {
+    set_error("kernel spec: bad term count");
+    return GPC_EINVAL;
+  }
+  memset(o, 0, sizeof(*o));
+  for(int t = 0; t < ks->n_terms; t++) {
+    const int off = ks->offs[t], np = ks->offs[t + 1] - ks->offs[t];
+    if(off < 0 || np < 0 || off + np > GPC_MAX_PARAMS) {
+      set_error("kernel spec: bad parameter offsets");
+      return GPC_EINVAL;
+    }
+    const double* p = ks->params + off;
+    switch(ks->types[t]) {
+    case GPC_KERN_RBF:
+      if(np != 2) { set_error("rbf takes 2 parameters"); return GPC_EINVAL; }
+      if(o->n_rbf >= 4) { set_error("more than 4 rbf terms"); return GPC_EUNSUPPORTED; }
+      o->rbf_hiw[o->n_rbf] = 0.5 * p[0];
+      o->rbf_var[o->n_rbf] = p[1];
+      o->n_rbf++;
+      o->need_dot = 1;
+      break;
+    case GPC_KERN_RBFARD:
+      if(np != 2 + D) { set_error("rbfard takes 2+D parameters"); return GPC_EINVAL; }
+      if(D > GPC_MAX_ARD_DIM) { set_error("rbfard: input dimension above %d", GPC_MAX_ARD_DIM); return GPC_EUNSUPPORTED; }
+      if(o->n_ard >= 1) { set_error("more than one rbfard term"); return GPC_EUNSUPPORTED; }
+      o->ard_hiw[o->n_ard] = 0.5 * p[0];
+      o->ard_var[o->n_ard] = p[1];
+      for(int64_t q = 0; q < D; q++) o->ard_scale[o->n_ard][q] = p[2 + q];
+      o->n_ard++;
+      break;
+    case GPC_KERN_WHITE:
+      if(np != 1) { set_error("white takes 1 parameter"); return GPC_EINVAL; }
+      o->white_var += p[0];
+      break;
+    case GPC_KERN_BIAS:
+      if(np != 1) { set_error("bias takes 1 parameter"); return GPC_EINVAL; }
+      o->bias_var += p[0];
+      break;
+    case GPC_KERN_LIN:
+      if(np != 1) { set_error("lin takes 1 parameter"); return GPC_EINVAL; }
+      o->lin_var += p[0];
+      o->need_dot = 1;
+      break;
+    default:
+      set_error("kernel type %d is outside the accelerated set", ks->types[t]);
+      return GPC_EUNSUPPORTED;
+    }
+  }
+  return GPC_OK;
+}
+
+}  // namespace gpc
+
+using namespace gpc;
+
+static int gram_common(const gpc_kspec* ksp, const double* X, int64_t N, int64_t ldx, const double* X2, int64_t N2,
+                       int64_t ldx2, int64_t D, double* K, int64_t ldk, int64_t i_off, int64_t j_off, int sym_diag,
+                       bool same_x, hipStream_t s)
+{
+  KSpecDev ks;
+  GPC_CHECK(collapse_kspec(ksp, D, &ks));
+  if(!sym_diag) ks.white_var = 0.0;  // white is diagonal-only (CKern.cpp:702-723)
+  GramArgs g;
+  g.X = X;
+  g.X2 = X2;
+  g.K = K;
+  g.ldx = ldx;
+  g.ldx2 = ldx2;
+  g.ldk = ldk;
+  g.N = N;
+  g.N2 = N2;
+  g.D = D;
+  g.i_off = i_off;
+  g.j_off = j_off;
+  g.sym_diag = sym_diag;
+  g.n1 = g.n2 = nullptr;
+  if(ks.need_dot) {
+    void* ws = nullptr;
+    GPC_CHECK(workspace(WS_KERN, sizeof(double) * (size_t)(N + N2), &ws));
+    double* nn = static_cast<double*>(ws);
+    GPC_CHECK(norms(X, ldx, N, D, nn, s));
+    if(same_x) {
+      g.n1 = g.n2 = nn;
+    } else {
+      GPC_CHECK(norms(X2, ldx2, N2, D, nn + N, s));
+      g.n1 = nn;
+      g.n2 = nn + N;
+    }
+  }
+  return launch_gram(ks, g, s);
+}
+
+extern "C" int gpc_gram_sym_f64(const gpc_kspec* ks, const double* X, int64_t N, int64_t D, int64_t ldx, double* K,
+                                int64_t ldk, void* stream)
+{
+  GPC_CHECK(ensure_device());
+  GPC_REQUIRE(N >= 0 && D >= 0 && ldx >= N && ldk >= N, "gram_sym dims");
+  return gram_common(ks, X, N, ldx, X, N, ldx, D, K, ldk, 0, 0, 1, true, as_stream(stream));
+}
+
+extern "C" int gpc_gram_cross_f64(const gpc_kspec* ks, const double* X, int64_t N, int64_t ldx, const double* X2,
+                                  int64_t N2, int64_t ldx2, int64_t D, double* K, int64_t ldk, void* stream)
+{
+  GPC_CHECK(ensure_device());
+  GPC_REQUIRE(N >= 0 && N2 >= 0 && D >= 0 && ldx >= N && ldx2 >= N2 && ldk >= N, "gram_cross dims");
+  return gram_common(ks, X, N, ldx, X2, N2, ldx2, D, K, ldk, 0, 0, 0, false, as_stream(stream));
+}
+
+extern "C" int gpc_gram_block_f64(const gpc_kspec* ks, const double* X, int64_t N, int64_t D, int64_t ldx,
+                                  int64_t i0, int64_t m, int64_t j0, int64_t n, double* Kblk, int64_t ldk,
+                                  void* stream)
+{
+  GPC_CHECK(ensure_device());
+  GPC_REQUIRE(N >= 0 && D >= 0 && ldx >= N && i0 >= 0 && j0 >= 0 && m >= 0 && n >= 0 && i0 + m <= N &&
+                  j0 + n <= N && ldk >= m,
+              "gram_block dims");
+  return gram_common(ks, X + i0, m, ldx, X + j0, n, ldx, D, Kblk, ldk, i0, j0, 1, false, as_stream(stream));
+}
+
+extern "C" int gpc_gram_diag_f64(const gpc_kspec* ksp, const double* X, int64_t N, int64_t D, int64_t ldx,
+                                 double* d, void* stream)
+{
+  GPC_CHECK(ensure_device());
+  GPC_REQUIRE(N >= 0 && D >= 0 && ldx >= N, "gram_diag dims");
+  if(N == 0) return GPC_OK;
+  KSpecDev ks;
+  GPC_CHECK(collapse_kspec(ksp, D, &ks));
+  hipLaunchKernelGGL(gram_diag_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, as_stream(stream), ks, X,
+                     ldx, N, D, d);
+  GPC_HIP_CHECK(hipGetLastError());
+  return GPC_OK;
+}

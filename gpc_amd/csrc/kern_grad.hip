@@ -1,0 +1,363 @@
+// kern_grad.hip -- fused kernel-parameter gradient  g_p = sum_ij covGrad(i,j) * dK(i,j)/dtheta_p  for every natural
+// parameter of a compound kernel, in one pass over covGrad (HBM-read bound: 8 N^2 bytes in).
+//
+// Replaces the scalar O(N^2 D) loops of CCmpndKern::getGradParams (CKern.cpp:284-298) over its components:
+//   CRbfKern::getGradParams    (CKern.cpp:1204-1241): g_iw = -var * sum_{i<j} d2 k~ cg,  g_var = tr(cg) + 2 sum_{i<j} k~ cg
+//   CRbfardKern::getGradParams (CKern.cpp:3359-3403): same two plus g_s_k = 2 iw var sum_{i>j} k~ cg (xi xj - xi^2/2 - xj^2/2)
+//   CWhiteKern (735-739) tr(cg);  CBiasKern (1020-1024) sum(cg);  CLinKern (2369-2383) sum_ij cg x_i.x_j
+// written here over ALL ordered pairs (covGrad is symmetric, so 2*sum_{i<j} == sum_{i!=j}).
+// The chain rule to the transformed (optimiser) space, CKern::getGradTransParams (CKern.cpp:50-63), stays on the host.
+//
+// Tiling is the Gram kernel's (128 x 32 patch per tile, thread = 2 rows x 8 columns, covGrad read in contiguous
+// 1 KiB runs).  A fixed-size grid strides over the tiles and writes per-workgroup partial sums that the host adds in
+// a fixed order, so the result is deterministic.
+#include "gpc_common.hpp"
+#include <string.h>
+#include <stdlib.h>
+
+namespace gpc {
+
+namespace {
+
+constexpr int TI = 128;
+constexpr int TJ = 32;
+constexpr int DC = 16;
+constexpr int NP_MAIN = 16;  // rbf: 4 x (d2k, k); ard: (vk, k); lin; all; trace; 3 spare
+constexpr int ARD_PASS = 32;
+
+struct GradArgs {
+  const double* X;
+  const double* n1;
+  const double* cg;
+  int64_t ldx, ldc, N, D;
+  int64_t tiles_i, tiles_j;
+};
+
+__device__ __forceinline__ double block_sum(double v, double* sh)
+{
+  for(int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  __syncthreads();
+  if(lane == 0) sh[w] = v;
+  __syncthreads();
+  return sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+// Accumulate x_i.x_j (DOT) and sum_k s_k (x_ik - x_jk)^2 (ARD) for the thread's 2 x 8 patch of tile (i0, j0).
+template <bool DOT, bool ARD>
+__device__ __forceinline__ void tile_products(const KSpecDev& ks, const GradArgs& g, int64_t i0, int64_t j0,
+                                              double* Xi, double* Xj, double* Ai, double* Aj, double (&dot)[2][8],
+                                              double (&ard)[2][8])
+{
+  const int t = threadIdx.x;
+  const int il = 2 * (t & 63), jl = 8 * (t >> 6);
+#pragma unroll
+  for(int a = 0; a < 2; a++)
+#pragma unroll
+    for(int b = 0; b < 8; b++) {
+      dot[a][b] = 0.0;
+      ard[a][b] = 0.0;
+    }
+  for(int64_t d0 = 0; d0 < g.D; d0 += DC) {
+    const int dc = (int)((g.D - d0 < DC) ? (g.D - d0) : DC);
+    __syncthreads();
+    for(int idx = t; idx < DC * TI; idx += 256) {
+      const int d = idx / TI, i = idx % TI;
+      double v = 0.0;
+      if(d < dc && i0 + i < g.N) v = g.X[(i0 + i) + (d0 + d) * g.ldx];
+      if(DOT) Xi[idx] = v;
+      if(ARD) Ai[idx] = v * sqrt(ks.ard_scale[0][(d0 + d) < GPC_MAX_ARD_DIM ? (d0 + d) : 0]);
+    }
+    for(int idx = t; idx < DC * TJ; idx += 256) {
+      const int d = idx / TJ, j = idx % TJ;
+      double v = 0.0;
+      if(d < dc && j0 + j < g.N) v = g.X[(j0 + j) + (d0 + d) * g.ldx];
+      if(DOT) Xj[idx] = v;
+      if(ARD) Aj[idx] = v * sqrt(ks.ard_scale[0][(d0 + d) < GPC_MAX_ARD_DIM ? (d0 + d) : 0]);
+    }
+    __syncthreads();
+    for(int d = 0; d < dc; d++) {
+      if(DOT) {
+        const double2_t xi = *reinterpret_cast<const double2_t*>(&Xi[d * TI + il]);
+#pragma unroll
+        for(int b = 0; b < 8; b++) {
+          const double xj = Xj[d * TJ + jl + b];
+          dot[0][b] = fma(xi.x, xj, dot[0][b]);
+          dot[1][b] = fma(xi.y, xj, dot[1][b]);
+        }
+      }
+      if(ARD) {
+        const double2_t xi = *reinterpret_cast<const double2_t*>(&Ai[d * TI + il]);
+#pragma unroll
+        for(int b = 0; b < 8; b++) {
+          const double xj = Aj[d * TJ + jl + b];
+          const double e0 = xi.x - xj, e1 = xi.y - xj;
+          ard[0][b] = fma(e0, e0, ard[0][b]);
+          ard[1][b] = fma(e1, e1, ard[1][b]);
+        }
+      }
+    }
+  }
+}
+
+template <bool DOT, bool ARD>
+__global__ void __launch_bounds__(256) kern_grad_kernel(const KSpecDev ks, const GradArgs g,
+                                                        double* __restrict__ partial)
+{
+  __shared__ __attribute__((aligned(16))) double Xi[DC * TI];
+  __shared__ __attribute__((aligned(16))) double Xj[DC * TJ];
+  __shared__ __attribute__((aligned(16))) double Ai[ARD ? DC * TI : 2];
+  __shared__ __attribute__((aligned(16))) double Aj[ARD ? DC * TJ : 2];
+  __shared__ double sh[4];
+  const int t = threadIdx.x;
+  const int il = 2 * (t & 63), jl = 8 * (t >> 6);
+
+  double acc[NP_MAIN];
+#pragma unroll
+  for(int p = 0; p < NP_MAIN; p++) acc[p] = 0.0;
+
+  const int64_t total = g.tiles_i * g.tiles_j;
+  for(int64_t tile = blockIdx.x; tile < total; tile += gridDim.x) {
+    const int64_t i0 = (tile % g.tiles_i) * TI, j0 = (tile / g.tiles_i) * TJ;
+    double dot[2][8], ard[2][8];
+    tile_products<DOT, ARD>(ks, g, i0, j0, Xi, Xj, Ai, Aj, dot, ard);
+    const int64_t gi = i0 + il;
+    double ni[2] = {0.0, 0.0};
+    if(DOT) {
+      if(gi < g.N) ni[0] = g.n1[gi];
+      if(gi + 1 < g.N) ni[1] = g.n1[gi + 1];
+    }
+#pragma unroll
+    for(int b = 0; b < 8; b++) {
+      const int64_t gj = j0 + jl + b;
+      if(gj >= g.N) continue;
+      const double nj = DOT ? g.n1[gj] : 0.0;
+#pragma unroll
+      for(int a = 0; a < 2; a++) {
+        if(gi + a >= g.N) continue;
+        const double c = g.cg[(gi + a) + gj * g.ldc];
+        acc[12] += c;  // bias: sum of all
+        if(gi + a == gj) {
+          acc[13] += c;  // trace
+          if(DOT) acc[11] += c * ni[a];  // lin: x_i . x_i
+        } else {
+          if(DOT) {
+            const double d2 = ni[a] + nj - 2.0 * dot[a][b];
+#pragma unroll
+            for(int r = 0; r < 4; r++) {
+              if(r < ks.n_rbf) {
+                const double e = c * exp(-(ks.rbf_hiw[r] * d2));
+                acc[2 * r] += d2 * e;
+                acc[2 * r + 1] += e;
+              }
+            }
+            acc[11] += c * dot[a][b];
+          }
+          if(ARD) {
+            const double e = c * exp(-(ard[a][b] * ks.ard_hiw[0]));
+            acc[8] += ard[a][b] * e;
+            acc[9] += e;
+          }
+        }
+      }
+    }
+  }
+#pragma unroll
+  for(int p = 0; p < NP_MAIN; p++) {
+    const double r = block_sum(acc[p], sh);
+    if(t == 0) partial[(int64_t)blockIdx.x * NP_MAIN + p] = r;
+  }
+}
+
+// per-dimension ARD sums: S_k = sum_{i != j} cg(i,j) k~(i,j) (x_ik - x_jk)^2 for k in [dim0, dim0 + 32)
+__global__ void __launch_bounds__(256) ard_dim_grad_kernel(const KSpecDev ks, const GradArgs g, int64_t dim0,
+                                                           double* __restrict__ partial)
+{
+  __shared__ __attribute__((aligned(16))) double Xi[DC * TI];
+  __shared__ __attribute__((aligned(16))) double Xj[DC * TJ];
+  __shared__ __attribute__((aligned(16))) double Ai[DC * TI];
+  __shared__ __attribute__((aligned(16))) double Aj[DC * TJ];
+  __shared__ double sh[4];
+  const int t = threadIdx.x;
+  const int il = 2 * (t & 63), jl = 8 * (t >> 6);
+  double acc[ARD_PASS];
+#pragma unroll
+  for(int p = 0; p < ARD_PASS; p++) acc[p] = 0.0;
+
+  const int64_t total = g.tiles_i * g.tiles_j;
+  for(int64_t tile = blockIdx.x; tile < total; tile += gridDim.x) {
+    const int64_t i0 = (tile % g.tiles_i) * TI, j0 = (tile / g.tiles_i) * TJ;
+    double dot[2][8], ard[2][8];
+    tile_products<false, true>(ks, g, i0, j0, Xi, Xj, Ai, Aj, dot, ard);
+    const int64_t gi = i0 + il;
+    double W[2][8];
+#pragma unroll
+    for(int b = 0; b < 8; b++) {
+      const int64_t gj = j0 + jl + b;
+#pragma unroll
+      for(int a = 0; a < 2; a++) {
+        double w = 0.0;
+        if(gj < g.N && gi + a < g.N && gi + a != gj)
+          w = g.cg[(gi + a) + gj * g.ldc] * exp(-(ard[a][b] * ks.ard_hiw[0]));
+        W[a][b] = w;
+      }
+    }
+#pragma unroll
+    for(int c = 0; c < ARD_PASS / DC; c++) {
+      const int64_t d0 = dim0 + c * DC;
+      if(d0 >= g.D) break;
+      const int dc = (int)((g.D - d0 < DC) ? (g.D - d0) : DC);
+      __syncthreads();
+      for(int idx = t; idx < DC * TI; idx += 256) {
+        const int d = idx / TI, i = idx % TI;
+        Xi[idx] = (d < dc && i0 + i < g.N) ? g.X[(i0 + i) + (d0 + d) * g.ldx] : 0.0;
+      }
+      for(int idx = t; idx < DC * TJ; idx += 256) {
+        const int d = idx / TJ, j = idx % TJ;
+        Xj[idx] = (d < dc && j0 + j < g.N) ? g.X[(j0 + j) + (d0 + d) * g.ldx] : 0.0;
+      }
+      __syncthreads();
+#pragma unroll
+      for(int d = 0; d < DC; d++) {
+        if(d < dc) {
+          const double2_t xi = *reinterpret_cast<const double2_t*>(&Xi[d * TI + il]);
+          double s = 0.0;
+#pragma unroll
+          for(int b = 0; b < 8; b++) {
+            const double xj = Xj[d * TJ + jl + b];
+            const double e0 = xi.x - xj, e1 = xi.y - xj;
+            s = fma(W[0][b] * e0, e0, s);
+            s = fma(W[1][b] * e1, e1, s);
+          }
+          acc[c * DC + d] += s;
+        }
+      }
+    }
+  }
+#pragma unroll
+  for(int p = 0; p < ARD_PASS; p++) {
+    const double r = block_sum(acc[p], sh);
+    if(t == 0) partial[(int64_t)blockIdx.x * ARD_PASS + p] = r;
+  }
+}
+
+__global__ void __launch_bounds__(256) row_norms_kernel2(const double* __restrict__ X, int64_t ldx, int64_t N,
+                                                         int64_t D, double* __restrict__ out)
+{
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if(i >= N) return;
+  double acc = 0.0;
+  for(int64_t d = 0; d < D; d++) {
+    const double x = X[i + d * ldx];
+    acc = fma(x, x, acc);
+  }
+  out[i] = acc;
+}
+
+int fetch_partials(const double* d_p, int64_t nblk, int np, double* sums, hipStream_t s)
+{
+  const size_t n = (size_t)nblk * np;
+  double* h = (double*)malloc(sizeof(double) * n);
+  if(!h) return GPC_ENOMEM;
+  hipError_t e = hipMemcpyAsync(h, d_p, sizeof(double) * n, hipMemcpyDeviceToHost, s);
+  if(e == hipSuccess) e = hipStreamSynchronize(s);
+  if(e != hipSuccess) {
+    free(h);
+    set_error("kern_grad copy-back failed: %s", hipGetErrorString(e));
+    return GPC_EHIP;
+  }
+  for(int p = 0; p < np; p++) {
+    double a = 0.0;
+    for(int64_t b = 0; b < nblk; b++) a += h[b * np + p];
+    sums[p] = a;
+  }
+  free(h);
+  return GPC_OK;
+}
+
+}  // namespace
+}  // namespace gpc
+
+using namespace gpc;
+
+extern "C" int gpc_kern_grad_f64(const gpc_kspec* ksp, const double* X, int64_t N, int64_t D, int64_t ldx,
+                                 const double* covGrad, int64_t ldc, double* gout, void* stream)
+{
+  GPC_CHECK(ensure_device());
+  GPC_REQUIRE(ksp && gout && N >= 0 && D >= 0 && ldx >= (N > 1 ? N : 1) && ldc >= (N > 1 ? N : 1), "kern_grad args");
+  hipStream_t s = as_stream(stream);
+  KSpecDev ks;
+  GPC_CHECK(collapse_kspec(ksp, D, &ks));
+  const int nparams = ksp->offs[ksp->n_terms];
+  for(int p = 0; p < nparams; p++) gout[p] = 0.0;
+  if(N == 0) return GPC_OK;
+
+  GradArgs g;
+  g.X = X;
+  g.cg = covGrad;
+  g.ldx = ldx;
+  g.ldc = ldc;
+  g.N = N;
+  g.D = D;
+  g.tiles_i = (N + TI - 1) / TI;
+  g.tiles_j = (N + TJ - 1) / TJ;
+  const int64_t total = g.tiles_i * g.tiles_j;
+  const int64_t nblk = total < 2048 ? total : 2048;
+
+  void* ws = nullptr;
+  const size_t pbytes = sizeof(double) * (size_t)nblk * (NP_MAIN > ARD_PASS ? NP_MAIN : ARD_PASS);
+  GPC_CHECK(workspace(WS_KERN, sizeof(double) * (size_t)N + pbytes, &ws));
+  double* nrm = static_cast<double*>(ws);
+  double* partial = nrm + N;
+  g.n1 = nrm;
+  if(ks.need_dot) {
+    hipLaunchKernelGGL(row_norms_kernel2, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, X, ldx, N, D, nrm);
+  }
+  const bool dot = ks.need_dot != 0, ard = ks.n_ard > 0;
+  if(dot && ard)
+    hipLaunchKernelGGL((kern_grad_kernel<true, true>), dim3((unsigned)nblk), dim3(256), 0, s, ks, g, partial);
+  else if(dot)
+    hipLaunchKernelGGL((kern_grad_kernel<true, false>), dim3((unsigned)nblk), dim3(256), 0, s, ks, g, partial);
+  else if(ard)
+    hipLaunchKernelGGL((kern_grad_kernel<false, true>), dim3((unsigned)nblk), dim3(256), 0, s, ks, g, partial);
+  else
+    hipLaunchKernelGGL((kern_grad_kernel<false, false>), dim3((unsigned)nblk), dim3(256), 0, s, ks, g, partial);
+  GPC_HIP_CHECK(hipGetLastError());
+  double S[NP_MAIN];
+  GPC_CHECK(fetch_partials(partial, nblk, NP_MAIN, S, s));
+
+  double Sdim[GPC_MAX_ARD_DIM];
+  if(ard) {
+    for(int64_t dim0 = 0; dim0 < D; dim0 += ARD_PASS) {
+      hipLaunchKernelGGL(ard_dim_grad_kernel, dim3((unsigned)nblk), dim3(256), 0, s, ks, g, dim0, partial);
+      GPC_HIP_CHECK(hipGetLastError());
+      double tmp[ARD_PASS];
+      GPC_CHECK(fetch_partials(partial, nblk, ARD_PASS, tmp, s));
+      for(int q = 0; q < ARD_PASS && dim0 + q < D; q++) Sdim[dim0 + q] = tmp[q];
+    }
+  }
+
+  // assemble in spec order
+  int irbf = 0;
+  for(int t = 0; t < ksp->n_terms; t++) {
+    double* gt = gout + ksp->offs[t];
+    const double* p = ksp->params + ksp->offs[t];
+    switch(ksp->types[t]) {
+    case GPC_KERN_RBF:
+      gt[0] = -0.5 * p[1] * S[2 * irbf];
+      gt[1] = S[13] + S[2 * irbf + 1];
+      irbf++;
+      break;
+    case GPC_KERN_RBFARD:
+      gt[0] = -0.5 * p[1] * S[8];
+      gt[1] = S[13] + S[9];
+      for(int64_t q = 0; q < D; q++) gt[2 + q] = -0.5 * p[0] * p[1] * Sdim[q];
+      break;
+    case GPC_KERN_WHITE: gt[0] = S[13]; break;
+    case GPC_KERN_BIAS: gt[0] = S[12]; break;
+    case GPC_KERN_LIN: gt[0] = S[11]; break;
+    default: break;
+    }
+  }
+  return GPC_OK;
+}

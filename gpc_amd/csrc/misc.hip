@@ -1,0 +1,349 @@
+// misc.hip -- the O(N^2) / O(N) helpers around the Cholesky pipeline (HBM-bound; coalesced, no MFMA).
+//
+// Each routine names the reference code it stands in for:
+//   transpose_inplace  CMatrix::trans -> dtransr_ (CMatrix.h:789-801, ndlfortran.f:2064)
+//   symmetrize         CMatrix::copySymmetric / the mirror step of pdinv (CMatrix.cpp:425-430)
+//   zero_triangle      the zero-fill of CMatrix::chol (CMatrix.cpp:384-403)
+//   add_diag           CMatrix::addDiag (CMatrix.h:841) -- jitChol's jitter
+//   diag_reduce        trace() and logDet() (CMatrix.cpp:404-412)
+//   coldot/colnorm2    ddot_/dnrm2_ per column (CGp.cpp:553-559, 606, 928-930)
+//   symv               dsymv_ (lapack.h:130-140)
+//   covgrad            CGp::updateCovGradient (CGp.cpp:666-679)
+#include "gpc_common.hpp"
+
+namespace gpc {
+
+namespace {
+
+constexpr int TT = 32;  // transpose tile
+
+// In-place transpose: one workgroup per tile pair (bi >= bj); both tiles staged through LDS, written swapped.
+__global__ void __launch_bounds__(256) transpose_inplace_kernel(double* __restrict__ A, int64_t lda, int64_t N,
+                                                                int ntiles)
+{
+  __shared__ double Ta[TT][TT + 1];
+  __shared__ double Tb[TT][TT + 1];
+  // triangular block index -> (bi, bj), bj <= bi
+  const unsigned s = blockIdx.x;
+  int r = (int)((sqrt(8.0 * (double)s + 1.0) - 1.0) * 0.5);
+  while((unsigned)(r + 1) * (unsigned)(r + 2) / 2 <= s) r++;
+  while((unsigned)r * (unsigned)(r + 1) / 2 > s) r--;
+  const int bi = r, bj = (int)(s - (unsigned)r * (unsigned)(r + 1) / 2);
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // ty in 0..7
+  const int64_t i0 = (int64_t)bi * TT, j0 = (int64_t)bj * TT;
+  for(int c = ty; c < TT; c += 8) {
+    const int64_t i = i0 + tx, j = j0 + c;
+    Ta[c][tx] = (i < N && j < N) ? A[i + j * lda] : 0.0;  // tile (bi,bj): rows i0.., cols j0..
+    const int64_t i2 = j0 + tx, j2 = i0 + c;
+    Tb[c][tx] = (i2 < N && j2 < N) ? A[i2 + j2 * lda] : 0.0;  // tile (bj,bi)
+  }
+  __syncthreads();
+  for(int c = ty; c < TT; c += 8) {
+    // new tile (bi,bj)(i,j) = old A(j,i) = tile (bj,bi) element (row j-j0 = c, col i-i0 = tx) -> Tb[tx][c]
+    const int64_t i = i0 + tx, j = j0 + c;
+    if(i < N && j < N) A[i + j * lda] = Tb[tx][c];
+    if(bi != bj) {
+      const int64_t i2 = j0 + tx, j2 = i0 + c;
+      if(i2 < N && j2 < N) A[i2 + j2 * lda] = Ta[tx][c];
+    }
+  }
+}
+
+// dst triangle := transpose of src triangle (from_lower: upper(i<j) := lower(j,i)).  Tile pairs through LDS so both
+// the read and the write are coalesced.
+__global__ void __launch_bounds__(256) symmetrize_kernel(double* __restrict__ A, int64_t lda, int64_t N,
+                                                         int from_lower)
+{
+  __shared__ double Ta[TT][TT + 1];
+  const unsigned s = blockIdx.x;
+  int r = (int)((sqrt(8.0 * (double)s + 1.0) - 1.0) * 0.5);
+  while((unsigned)(r + 1) * (unsigned)(r + 2) / 2 <= s) r++;
+  while((unsigned)r * (unsigned)(r + 1) / 2 > s) r--;
+  const int bi = r, bj = (int)(s - (unsigned)r * (unsigned)(r + 1) / 2);  // bj <= bi
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  // source tile: lower tile (bi,bj) if from_lower else upper tile (bj,bi)
+  const int64_t si0 = (int64_t)(from_lower ? bi : bj) * TT, sj0 = (int64_t)(from_lower ? bj : bi) * TT;
+  for(int c = ty; c < TT; c += 8) {
+    const int64_t i = si0 + tx, j = sj0 + c;
+    Ta[c][tx] = (i < N && j < N) ? A[i + j * lda] : 0.0;
+  }
+  __syncthreads();
+  // destination tile is the mirror: rows sj0.., cols si0..; dest(i,j) = src(j,i) = Ta[col = i-sj0... ]
+  for(int c = ty; c < TT; c += 8) {
+    const int64_t i = sj0 + tx, j = si0 + c;  // dest element
+    if(i < N && j < N) {
+      const bool strictly = from_lower ? (i < j) : (i > j);  // only the strictly-other triangle is overwritten
+      if(strictly) A[i + j * lda] = Ta[tx][c];               // src(row = j - si0 = c, col = i - sj0 = tx)
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256) zero_triangle_kernel(double* __restrict__ A, int64_t lda, int64_t N,
+                                                            int zero_lower, int64_t j0)
+{
+  const int64_t j = j0 + blockIdx.y;
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if(i < N && j < N) {
+    if(zero_lower ? (i > j) : (i < j)) A[i + j * lda] = 0.0;
+  }
+}
+
+__global__ void __launch_bounds__(256) add_diag_kernel(double* __restrict__ A, int64_t lda, int64_t N, double c)
+{
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if(i < N) A[i + i * lda] += c;
+}
+
+__device__ __forceinline__ double block_sum_256(double v, double* sh)
+{
+  for(int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if(lane == 0) sh[w] = v;
+  __syncthreads();
+  double r = 0.0;
+  if(threadIdx.x == 0) r = sh[0] + sh[1] + sh[2] + sh[3];
+  __syncthreads();
+  return r;  // valid on thread 0
+}
+
+// partial[b] = sum over this block's diagonal entries of f(A(i,i))
+__global__ void __launch_bounds__(256) diag_reduce_kernel(const double* __restrict__ A, int64_t lda, int64_t N,
+                                                          int what, double* __restrict__ partial)
+{
+  __shared__ double sh[4];
+  double v = 0.0;
+  for(int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < N; i += (int64_t)gridDim.x * 256) {
+    const double a = A[i + i * lda];
+    v += what == 1 ? log(a) : a;
+  }
+  const double r = block_sum_256(v, sh);
+  if(threadIdx.x == 0) partial[blockIdx.x] = r;
+}
+
+// out[j*gridDim.x + b] = partial sum over rows of A(i,j)*B(i,j)
+__global__ void __launch_bounds__(256) coldot_kernel(const double* __restrict__ A, int64_t lda,
+                                                     const double* __restrict__ B, int64_t ldb, int64_t M,
+                                                     double* __restrict__ partial)
+{
+  __shared__ double sh[4];
+  const int64_t j = blockIdx.y;
+  double v = 0.0;
+  for(int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < M; i += (int64_t)gridDim.x * 256)
+    v += A[i + j * lda] * B[i + j * ldb];
+  const double r = block_sum_256(v, sh);
+  if(threadIdx.x == 0) partial[j * gridDim.x + blockIdx.x] = r;
+}
+
+// out[j] = sum_i A(i,j)^2 : one workgroup per column (columns are independent test points)
+__global__ void __launch_bounds__(256) colnorm2_kernel(const double* __restrict__ A, int64_t lda, int64_t M,
+                                                       double* __restrict__ out)
+{
+  __shared__ double sh[4];
+  const int64_t j = blockIdx.x;
+  double v = 0.0;
+  for(int64_t i = threadIdx.x; i < M; i += 256) {
+    const double a = A[i + j * lda];
+    v += a * a;
+  }
+  const double r = block_sum_256(v, sh);
+  if(threadIdx.x == 0) out[j] = r;
+}
+
+// y := alpha*A*x + beta*y, A full symmetric storage: use columns (coalesced along i): y_i = sum_j A(i,j) x_j.
+// One thread per row i, loop over j in chunks staged through LDS for x.
+__global__ void __launch_bounds__(256) symv_kernel(const double* __restrict__ A, int64_t lda, int64_t N,
+                                                   double alpha, const double* __restrict__ x, double beta,
+                                                   double* __restrict__ y, int64_t jchunk)
+{
+  __shared__ double xs[256];
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t jbeg = (int64_t)blockIdx.y * jchunk;
+  const int64_t jend = (jbeg + jchunk < N) ? (jbeg + jchunk) : N;
+  double acc = 0.0;
+  for(int64_t j0 = jbeg; j0 < jend; j0 += 256) {
+    const int64_t jj = j0 + threadIdx.x;
+    xs[threadIdx.x] = (jj < jend) ? x[jj] : 0.0;
+    __syncthreads();
+    const int lim = (int)((jend - j0 < 256) ? (jend - j0) : 256);
+    if(i < N)
+      for(int c = 0; c < lim; c++) acc += A[i + (j0 + c) * lda] * xs[c];
+    __syncthreads();
+  }
+  if(i < N) {
+    // blockIdx.y == 0 applies beta; other chunks accumulate (y pre-scaled by the host wrapper when gridDim.y > 1)
+    if(gridDim.y == 1)
+      y[i] = alpha * acc + (beta != 0.0 ? beta * y[i] : 0.0);
+    else
+      atomicAdd(&y[i], alpha * acc);
+  }
+}
+
+__global__ void __launch_bounds__(256) scale_vec_kernel(double* __restrict__ y, int64_t N, double beta)
+{
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if(i < N) y[i] = (beta != 0.0) ? beta * y[i] : 0.0;
+}
+
+// covGrad(i,j) = -0.5*(invK(i,j) - a_i a_j)
+__global__ void __launch_bounds__(256) covgrad_kernel(const double* __restrict__ invK, int64_t ldi,
+                                                      const double* __restrict__ a, double* __restrict__ cg,
+                                                      int64_t ldc, int64_t N, int64_t j0)
+{
+  const int64_t j = j0 + blockIdx.y;
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if(i < N) cg[i + j * ldc] = -0.5 * (invK[i + j * ldi] - a[i] * a[j]);
+}
+
+int reduce_partials_to_host(const double* d_partial, int64_t ncols, int64_t nb, double* out_host, hipStream_t s)
+{
+  // small: copy partials back and finish on the host in a fixed order (deterministic)
+  const size_t n = (size_t)(ncols * nb);
+  double* h = (double*)malloc(sizeof(double) * n);
+  if(!h) return GPC_ENOMEM;
+  hipError_t e = hipMemcpyAsync(h, d_partial, sizeof(double) * n, hipMemcpyDeviceToHost, s);
+  if(e == hipSuccess) e = hipStreamSynchronize(s);
+  if(e != hipSuccess) {
+    free(h);
+    set_error("reduction copy-back failed: %s", hipGetErrorString(e));
+    return GPC_EHIP;
+  }
+  for(int64_t j = 0; j < ncols; j++) {
+    double acc = 0.0;
+    for(int64_t b = 0; b < nb; b++) acc += h[j * nb + b];
+    out_host[j] = acc;
+  }
+  free(h);
+  return GPC_OK;
+}
+
+inline unsigned tri_count(int64_t nt) { return (unsigned)(nt * (nt + 1) / 2); }
+
+}  // namespace
+
+int transpose_inplace(int64_t N, double* A, int64_t lda, hipStream_t s)
+{
+  if(N <= 1) return GPC_OK;
+  const int64_t nt = (N + TT - 1) / TT;
+  hipLaunchKernelGGL(transpose_inplace_kernel, dim3(tri_count(nt)), dim3(256), 0, s, A, lda, N, (int)nt);
+  GPC_HIP_CHECK(hipGetLastError());
+  return GPC_OK;
+}
+
+int symmetrize(bool from_lower, int64_t N, double* A, int64_t lda, hipStream_t s)
+{
+  if(N <= 1) return GPC_OK;
+  const int64_t nt = (N + TT - 1) / TT;
+  hipLaunchKernelGGL(symmetrize_kernel, dim3(tri_count(nt)), dim3(256), 0, s, A, lda, N, from_lower ? 1 : 0);
+  GPC_HIP_CHECK(hipGetLastError());
+  return GPC_OK;
+}
+
+int zero_triangle(bool zero_lower, int64_t N, double* A, int64_t lda, hipStream_t s)
+{
+  if(N <= 1) return GPC_OK;
+  for(int64_t j0 = 0; j0 < N; j0 += 32768) {  // grid.y limit
+    const int64_t nc = (N - j0 < 32768) ? (N - j0) : 32768;
+    hipLaunchKernelGGL(zero_triangle_kernel, dim3((unsigned)((N + 255) / 256), (unsigned)nc), dim3(256), 0, s, A,
+                       lda, N, zero_lower ? 1 : 0, j0);
+  }
+  GPC_HIP_CHECK(hipGetLastError());
+  return GPC_OK;
+}
+
+int add_diag(int64_t N, double* A, int64_t lda, double c, hipStream_t s)
+{
+  if(N <= 0) return GPC_OK;
+  hipLaunchKernelGGL(add_diag_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, A, lda, N, c);
+  GPC_HIP_CHECK(hipGetLastError());
+  return GPC_OK;
+}
+
+int diag_reduce(int what, int64_t N, const double* A, int64_t lda, double* out_host, hipStream_t s)
+{
+  *out_host = 0.0;
+  if(N <= 0) return GPC_OK;
+  int64_t nb = (N + 255) / 256;
+  if(nb > 1024) nb = 1024;
+  void* ws = nullptr;
+  GPC_CHECK(workspace(WS_REDUCE, sizeof(double) * (size_t)nb, &ws));
+  hipLaunchKernelGGL(diag_reduce_kernel, dim3((unsigned)nb), dim3(256), 0, s, A, lda, N, what,
+                     static_cast<double*>(ws));
+  GPC_HIP_CHECK(hipGetLastError());
+  return reduce_partials_to_host(static_cast<double*>(ws), 1, nb, out_host, s);
+}
+
+}  // namespace gpc
+
+using namespace gpc;
+
+extern "C" int gpc_coldot_f64(int64_t M, int64_t ncols, const double* A, int64_t lda, const double* B, int64_t ldb,
+                              double* out, void* stream)
+{
+  GPC_CHECK(ensure_device());
+  GPC_REQUIRE(M >= 0 && ncols >= 0 && ncols <= 65535, "coldot dims");
+  if(ncols == 0) return GPC_OK;
+  hipStream_t s = as_stream(stream);
+  int64_t nb = (M + 255) / 256;
+  if(nb > 256) nb = 256;
+  if(nb < 1) nb = 1;
+  void* ws = nullptr;
+  GPC_CHECK(workspace(WS_REDUCE, sizeof(double) * (size_t)(nb * ncols), &ws));
+  hipLaunchKernelGGL(coldot_kernel, dim3((unsigned)nb, (unsigned)ncols), dim3(256), 0, s, A, lda, B, ldb, M,
+                     static_cast<double*>(ws));
+  GPC_HIP_CHECK(hipGetLastError());
+  return reduce_partials_to_host(static_cast<double*>(ws), ncols, nb, out, s);
+}
+
+extern "C" int gpc_colnorm2_f64(int64_t M, int64_t ncols, const double* A, int64_t lda, double* out_dev,
+                                void* stream)
+{
+  GPC_CHECK(ensure_device());
+  GPC_REQUIRE(M >= 0 && ncols >= 0, "colnorm2 dims");
+  if(ncols == 0) return GPC_OK;
+  hipLaunchKernelGGL(colnorm2_kernel, dim3((unsigned)ncols), dim3(256), 0, as_stream(stream), A, lda, M, out_dev);
+  GPC_HIP_CHECK(hipGetLastError());
+  return GPC_OK;
+}
+
+extern "C" int gpc_symv_f64(int64_t N, double alpha, const double* A, int64_t lda, const double* x, double beta,
+                            double* y, void* stream)
+{
+  GPC_CHECK(ensure_device());
+  GPC_REQUIRE(N >= 0 && lda >= N, "symv dims");
+  if(N == 0) return GPC_OK;
+  hipStream_t s = as_stream(stream);
+  const unsigned gx = (unsigned)((N + 255) / 256);
+  // split the j range so that at least ~1024 workgroups are in flight on large N
+  unsigned gy = 1;
+  if(gx < 1024) {
+    gy = (1024 + gx - 1) / gx;
+    const unsigned maxy = (unsigned)((N + 1023) / 1024);
+    if(gy > maxy) gy = maxy;
+    if(gy < 1) gy = 1;
+  }
+  int64_t jchunk = (N + gy - 1) / gy;
+  jchunk = ((jchunk + 255) / 256) * 256;
+  gy = (unsigned)((N + jchunk - 1) / jchunk);
+  if(gy > 1) {
+    hipLaunchKernelGGL(scale_vec_kernel, dim3(gx), dim3(256), 0, s, y, N, beta);
+  }
+  hipLaunchKernelGGL(symv_kernel, dim3(gx, gy), dim3(256), 0, s, A, lda, N, alpha, x, beta, y, jchunk);
+  GPC_HIP_CHECK(hipGetLastError());
+  return GPC_OK;
+}
+
+extern "C" int gpc_covgrad_f64(int64_t N, const double* invK, int64_t ldi, const double* a, double* covGrad,
+                               int64_t ldc, void* stream)
+{
+  GPC_CHECK(ensure_device());
+  GPC_REQUIRE(N >= 0 && ldi >= N && ldc >= N, "covgrad dims");
+  if(N == 0) return GPC_OK;
+  hipStream_t s = as_stream(stream);
+  for(int64_t j0 = 0; j0 < N; j0 += 32768) {
+    const int64_t nc = (N - j0 < 32768) ? (N - j0) : 32768;
+    hipLaunchKernelGGL(covgrad_kernel, dim3((unsigned)((N + 255) / 256), (unsigned)nc), dim3(256), 0, s,
+                       invK, ldi, a, covGrad, ldc, N, j0);
+  }
+  GPC_HIP_CHECK(hipGetLastError());
+  return GPC_OK;
+}

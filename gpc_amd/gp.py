@@ -1,0 +1,143 @@
+"""Python mirror of the reference's CGp (FTC branches only) on top of the C-ABI.
+
+Method names and semantics follow CGp.cpp so that the parity tests read like testGp.cpp: getOptParams /
+setOptParams work in the transformed (optimiser) space, logLikelihood includes the -d*N*0.5*log(2*pi) constant
+(CGp.cpp:1010-1013), logLikelihoodGradient returns dL/d(transformed kernel params) (CGp.cpp:1016-1144),
+posteriorMeanVar applies the output scale and bias (CGp.cpp:548-625) and out() adds the Gaussian noise model
+(CNoise.cpp:475-490).  All arithmetic on N x N objects happens in libgpc_hip.so.
+"""
+import math
+
+import numpy as np
+
+from . import api
+
+LIM_VAL = 36.0            # CTransform.h:18
+EPS = 2.220446049250313e-16   # ndlutil::EPS
+
+
+def _atox(kind, a):
+    if kind == "exp":        # CExpTransform::atox, CTransform.cpp:31-43
+        return math.exp(min(max(a, -LIM_VAL), LIM_VAL))
+    if a < -LIM_VAL:         # CSigmoidTransform::atox, CTransform.cpp:97-105
+        return EPS
+    if a < LIM_VAL:
+        return 1.0 / (1.0 + math.exp(-a))
+    return 1.0 - EPS
+
+
+def _xtoa(kind, x):
+    if kind == "exp":
+        return math.log(x)
+    return math.log(x / (1.0 - x))
+
+
+def _gradfact(kind, x):
+    return x if kind == "exp" else x * (1.0 - x)
+
+
+def param_transforms(terms):
+    """Per-parameter transform kinds in CCmpndKern order (rbfard input scales are sigmoid, CKern.cpp:3214-3217)."""
+    kinds = []
+    for name, params in terms:
+        for i in range(len(params)):
+            kinds.append("sigmoid" if (name == "rbfard" and i >= 2) else "exp")
+    return kinds
+
+
+class CGp:
+    FTC = 0
+
+    def __init__(self, terms, X, y, scale=None, bias=None, device="cuda"):
+        self.terms = [(n, list(map(float, p))) for n, p in terms]
+        self.kinds = param_transforms(self.terms)
+        self.device = device
+        X = np.asarray(X, dtype=np.float64)
+        y = np.asarray(y, dtype=np.float64).reshape(X.shape[0], -1)
+        self.N, self.D = X.shape
+        self.d = y.shape[1]
+        self.scale = np.ones(self.d) if scale is None else np.asarray(scale, dtype=np.float64).reshape(-1)
+        self.bias = y.mean(axis=0) if bias is None else np.asarray(bias, dtype=np.float64).reshape(-1)
+        self.X = api.from_host(X, device)
+        self.y = y
+        # CGp::updateM (CGp.cpp:248-260): m = (y - bias) / scale
+        self.m = api.from_host((y - self.bias[None, :]) / self.scale[None, :], device)
+        self.noise_sigma2 = 1e-6   # CGaussianNoise default (CNoise.cpp:340-346), noise bias 0
+        self._dirty()
+
+    def _dirty(self):
+        self.L = None
+        self.logDetK = None
+        self.Alpha = None
+        self.invK = None
+        self.jitter = 0.0
+
+    # ---- parameters ---------------------------------------------------------------------------------------------
+    def _flat(self):
+        return [p for _, ps in self.terms for p in ps]
+
+    def getOptNumParams(self):
+        return len(self.kinds)
+
+    def getOptParams(self):
+        return np.array([_xtoa(k, x) for k, x in zip(self.kinds, self._flat())])
+
+    def setOptParams(self, a):
+        it = iter([_atox(k, float(v)) for k, v in zip(self.kinds, a)])
+        self.terms = [(n, [next(it) for _ in ps]) for n, ps in self.terms]
+        self._dirty()      # setOptParams sets KupToDate=false (CGp.cpp:387-389)
+
+    def kspec(self):
+        return api.kspec(self.terms)
+
+    # ---- CGp::updateK (FTC) ---------------------------------------------------------------------------------------
+    def updateK(self):
+        if self.L is None:
+            K, logdet, jit, info = api.gp_update_k(self.kspec(), self.X)
+            if info != 0:
+                raise np.linalg.LinAlgError("MatrixNonPosDef: leading minor %d (jitter %g)" % (info, jit))
+            self.L, self.logDetK, self.jitter = K, logdet, jit
+
+    def updateAlpha(self):
+        self.updateK()
+        if self.Alpha is None:
+            self.Alpha = api.gp_alpha(self.L, self.m)
+
+    def logLikelihood(self):
+        self.updateAlpha()
+        return api.gp_loglik(self.m, self.Alpha, self.logDetK)
+
+    def updateInvK(self):
+        self.updateK()
+        if self.invK is None:
+            inv = self.L.clone()   # keeps the column-major strides
+            api.potri(inv, "L")
+            self.invK = inv
+
+    def logLikelihoodGradient(self):
+        """Returns (g wrt transformed kernel parameters, logLikelihood) like CGp::logLikelihoodGradient."""
+        self.updateAlpha()
+        self.updateInvK()
+        ks = self.kspec()
+        g = np.zeros(self.getOptNumParams())
+        cg = api.empty(self.N, self.N, self.device)
+        for j in range(self.d):
+            a = self.Alpha[:, j:j + 1]
+            api.covgrad(self.invK, a, out=cg)          # CGp::updateCovGradient
+            g += api.kern_grad(ks, self.X, cg)         # CKern::getGradParams
+        # CKern::getGradTransParams (CKern.cpp:50-63): chain rule through the transforms
+        g *= np.array([_gradfact(k, x) for k, x in zip(self.kinds, self._flat())])
+        return g, self.logLikelihood()
+
+    # ---- prediction -------------------------------------------------------------------------------------------------
+    def posteriorMeanVar(self, Xs):
+        self.updateAlpha()
+        Xs_d = api.from_host(np.asarray(Xs, dtype=np.float64), self.device)
+        mu, var = api.gp_posterior(self.kspec(), self.X, self.L, self.Alpha, Xs_d)
+        mu = api.to_host(mu) * self.scale[None, :] + self.bias[None, :]
+        var = np.repeat(api.to_host(var), self.d, axis=1) * (self.scale[None, :] ** 2)
+        return mu, var
+
+    def out(self, Xs):
+        mu, var = self.posteriorMeanVar(Xs)
+        return mu, np.sqrt(var + self.noise_sigma2)   # CGaussianNoise::out, noise bias 0

@@ -1,0 +1,186 @@
+/* gpc_hip.h -- C-ABI of libgpc_hip.so: the MI355X (gfx950) exact-GP hot path of GPc.
+ *
+ * This is the drop-in boundary.  GPc has no plugin registry: its FTC hot path reaches its
+ * arithmetic through (b2) the Fortran-ABI BLAS/LAPACK declared in the reference's lapack.h and through the scalar
+ * kernel loops of CKern/CGp.  Each entry point below names the reference interface it replaces (file:line in
+ * /root/reference).  Conventions differ from the Fortran ABI on purpose:
+ *   - plain C, scalars by value, 64-bit sizes (the reference's 32-bit sizes overflow at N >= 46341, CMatrix.h:1231),
+ *   - every matrix pointer is a DEVICE pointer (HBM) unless the parameter is documented "host",
+ *   - column-major with explicit leading dimension, exactly like lapack.h,
+ *   - return value: GPC_OK or a negative GPC_E* code; no exceptions cross the boundary.  LAPACK-style `info`
+ *     (>0 = order of the first non-positive-definite leading minor, lapack.h:59-65) is returned through a host int*,
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream).  Calls that return a host scalar
+ *     (info, logdet, dot products, gradients) synchronise that stream before returning; all others are asynchronous.
+ * There is no CPU fallback behind any of these symbols: without a gfx950 device they return GPC_ENODEV.
+ */
+#ifndef GPC_HIP_H
+#define GPC_HIP_H
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GPC_OK 0
+#define GPC_EINVAL (-1)   /* bad argument (maps to the reference's MatrixError / DIMENSIONMATCH throws) */
+#define GPC_ENODEV (-2)   /* no HIP device / kernel image not loadable */
+#define GPC_EHIP (-3)     /* a HIP runtime call failed; see gpc_last_error() */
+#define GPC_ENOMEM (-4)   /* workspace allocation failed */
+#define GPC_EUNSUPPORTED (-5) /* kernel spec outside the accelerated set (rbf, rbfard, white, bias, lin) */
+
+/* ---- kernel specification ------------------------------------------------------------------------------------
+ * Flat POD description of a CCmpndKern (CKern.h:475, components summed: CKern.cpp:219-226).  `types[t]` is one of
+ * GPC_KERN_*; the natural-space (untransformed) parameters of term t are params[offs[t] .. offs[t+1]) in the
+ * reference's own order:
+ *   rbf    (CKern.cpp:1057-1072): inverseWidth, variance          k = variance * exp(-0.5*inverseWidth*|x-x'|^2)
+ *   rbfard (CKern.cpp:3199-3219): inverseWidth, variance, scale_1..scale_D
+ *   white  (CKern.cpp:641-649)  : variance   (diagonal of the symmetric Gram only; zero in cross-Grams, CKern.cpp:702-723)
+ *   bias   (CKern.cpp:928-936)  : variance
+ *   lin    (CKern.cpp:2328-2341): variance   k = variance * x.x'
+ */
+#define GPC_KERN_RBF 1
+#define GPC_KERN_RBFARD 2
+#define GPC_KERN_WHITE 3
+#define GPC_KERN_BIAS 4
+#define GPC_KERN_LIN 5
+#define GPC_MAX_TERMS 8
+#define GPC_MAX_PARAMS 160
+#define GPC_MAX_ARD_DIM 64
+
+typedef struct gpc_kspec {
+  int32_t n_terms;
+  int32_t types[GPC_MAX_TERMS];
+  int32_t offs[GPC_MAX_TERMS + 1];
+  double params[GPC_MAX_PARAMS];   /* host values, natural space */
+} gpc_kspec;
+
+/* ---- library / device ---------------------------------------------------------------------------------------- */
+int gpc_version(void);                           /* 100*major + minor */
+const char* gpc_last_error(void);                /* text of the last GPC_EHIP / GPC_EINVAL on this thread */
+int gpc_device_count(int* count);
+int gpc_set_device(int device);
+int gpc_device_info(char* name, size_t name_len, int* cu_count, size_t* hbm_bytes, int* clock_khz);
+
+/* Device memory for callers that do not bring their own (the C++ CMatrix uses these; Python callers pass torch
+ * tensors' data_ptr()).  Replaces `new double[nrows*ncols]`, CMatrix.cpp:644-666. */
+int gpc_malloc(void** dptr, size_t bytes);
+int gpc_free(void* dptr);
+int gpc_memcpy_h2d(void* dst_dev, const void* src_host, size_t bytes, void* stream);
+int gpc_memcpy_d2h(void* dst_host, const void* src_dev, size_t bytes, void* stream);
+int gpc_memcpy_d2d(void* dst_dev, const void* src_dev, size_t bytes, void* stream);
+int gpc_memset(void* dst_dev, int byte, size_t bytes, void* stream);
+int gpc_stream_sync(void* stream);
+int gpc_workspace_release(void);                 /* free the library's grow-only scratch buffers */
+
+/* ---- Gram construction ----------------------------------------------------------------------------------------
+ * X is N x D column-major (ldx >= N).  Replaces the scalar computeElement double loops. */
+
+/* Full symmetric K(i,j)=K(j,i), diagonal from diagComputeElement (white added):
+ * CKern::compute(K,X) CKern.h:128-144 == CGp::_updateK FTC CGp.cpp:698-712. */
+int gpc_gram_sym_f64(const gpc_kspec* ks, const double* X, int64_t N, int64_t D, int64_t ldx,
+                     double* K, int64_t ldk, void* stream);
+/* Cross Gram K(i,j)=k(X_i, X2_j), N x N2 (white contributes 0): CKern::compute(K,X,X2) CKern.h:146-157. */
+int gpc_gram_cross_f64(const gpc_kspec* ks, const double* X, int64_t N, int64_t ldx,
+                       const double* X2, int64_t N2, int64_t ldx2, int64_t D,
+                       double* K, int64_t ldk, void* stream);
+/* Diagonal d(i)=k(X_i,X_i): CKern::diagCompute CKern.h:49-55. */
+int gpc_gram_diag_f64(const gpc_kspec* ks, const double* X, int64_t N, int64_t D, int64_t ldx,
+                      double* d, void* stream);
+/* An m x n block K(i0+i, j0+j) of the SYMMETRIC Gram of X (white lands where i0+i == j0+j).  Used to generate a
+ * 2-D block-cyclic distribution in place; same arithmetic as gpc_gram_sym_f64. */
+int gpc_gram_block_f64(const gpc_kspec* ks, const double* X, int64_t N, int64_t D, int64_t ldx,
+                       int64_t i0, int64_t m, int64_t j0, int64_t n, double* Kblk, int64_t ldk, void* stream);
+
+/* ---- Cholesky / triangular pipeline ---------------------------------------------------------------------------- */
+
+/* dpotrf (lapack.h:59-65; CMatrix::potrf CMatrix.cpp:371-379).  uplo 'L'/'l' or 'U'/'u'; only that triangle of A is
+ * read and written.  *info (host): 0 ok, k>0 leading minor k not positive definite (factorisation abandoned there). */
+int gpc_potrf_f64(char uplo, int64_t N, double* A, int64_t lda, int* info, void* stream);
+/* CMatrix::chol(): potrf + zero the other triangle (CMatrix.cpp:380-403). */
+int gpc_chol_f64(char uplo, int64_t N, double* A, int64_t lda, int* info, void* stream);
+/* dpotri + mirror (lapack.h:67-73; CMatrix::pdinv(U) CMatrix.cpp:421-432): on entry A holds the factor in triangle
+ * `uplo`; on exit A holds the FULL symmetric inverse. */
+int gpc_potri_f64(char uplo, int64_t N, double* A, int64_t lda, void* stream);
+/* dtrsm (lapack.h:208-218; CMatrix::trsm CMatrix.cpp:272-295): B := alpha * op(A)^-1 B (side 'L') or
+ * alpha * B op(A)^-1 (side 'R'); B is M x Nrhs; A triangular of order M (L) or Nrhs (R). */
+int gpc_trsm_f64(char side, char uplo, char trans, char diag, int64_t M, int64_t Nrhs, double alpha,
+                 const double* A, int64_t lda, double* B, int64_t ldb, void* stream);
+/* logDet of a Cholesky factor: 2*sum(log(diag)) (CMatrix.cpp:404-412).  *out is a host double. */
+int gpc_logdet_chol_f64(int64_t N, const double* A, int64_t lda, double* out, void* stream);
+/* dgemm (lapack.h:165-181; CMatrix::gemm): C := alpha*op(A)*op(B) + beta*C, C is M x N, inner dimension K. */
+int gpc_gemm_f64(char transa, char transb, int64_t M, int64_t N, int64_t K, double alpha,
+                 const double* A, int64_t lda, const double* B, int64_t ldb, double beta,
+                 double* C, int64_t ldc, void* stream);
+/* dsyrk (lapack.h:183-193; CMatrix::syrk): C := alpha*A*A' + beta*C ('N', A is N x K) or alpha*A'*A + beta*C
+ * ('T', A is K x N); only triangle `uplo` of C is written. */
+int gpc_syrk_f64(char uplo, char trans, int64_t N, int64_t K, double alpha, const double* A, int64_t lda,
+                 double beta, double* C, int64_t ldc, void* stream);
+/* In-place transpose of a square matrix (CMatrix::trans -> dtransr_, CMatrix.h:789-801, ndlfortran.f:2064). */
+int gpc_transpose_inplace_f64(int64_t N, double* A, int64_t lda, void* stream);
+/* Copy triangle `uplo` onto the other one (CMatrix::copySymmetric) / zero the other one. */
+int gpc_symmetrize_f64(char uplo, int64_t N, double* A, int64_t lda, void* stream);
+int gpc_zero_triangle_f64(char uplo_to_zero, int64_t N, double* A, int64_t lda, void* stream);
+/* A(i,i) += c (CMatrix::addDiag CMatrix.h:841, the jitter step of jitChol CMatrix.cpp:767-804). */
+int gpc_add_diag_f64(int64_t N, double* A, int64_t lda, double c, void* stream);
+/* trace(A) to a host double (jitChol's 1e-6*tr/N). */
+int gpc_trace_f64(int64_t N, const double* A, int64_t lda, double* out, void* stream);
+
+/* ---- vectors / reductions used by CGp's FTC branches ------------------------------------------------------------ */
+/* out[j] = sum_i A(i,j)*B(i,j), j < ncols (ddot per column: CGp.cpp:553-559, 928-930).  out is host. */
+int gpc_coldot_f64(int64_t M, int64_t ncols, const double* A, int64_t lda, const double* B, int64_t ldb,
+                   double* out, void* stream);
+/* out[j] = sum_i A(i,j)^2 (dnrm2^2 per column, CGp.cpp:606).  out is a DEVICE vector. */
+int gpc_colnorm2_f64(int64_t M, int64_t ncols, const double* A, int64_t lda, double* out_dev, void* stream);
+/* dsymv-equivalent y := alpha*A*x + beta*y with A full symmetric storage (lapack.h:130-140). */
+int gpc_symv_f64(int64_t N, double alpha, const double* A, int64_t lda, const double* x, double beta, double* y,
+                 void* stream);
+/* covGrad := -0.5*(invK - a a')  (CGp::updateCovGradient CGp.cpp:666-679; a = invK*m_j, N x 1 device vector). */
+int gpc_covgrad_f64(int64_t N, const double* invK, int64_t ldi, const double* a, double* covGrad, int64_t ldc,
+                    void* stream);
+/* g[p] = sum_ij covGrad(i,j) * dK(i,j)/dtheta_p for every natural parameter of the spec, in spec order
+ * (CCmpndKern::getGradParams CKern.cpp:284-298 -> CRbfKern 1204-1241, CRbfardKern 3359-3403, white 735-739,
+ * bias 1020-1024, lin).  covGrad must be symmetric N x N.  g is a HOST vector of offs[n_terms] doubles. */
+int gpc_kern_grad_f64(const gpc_kspec* ks, const double* X, int64_t N, int64_t D, int64_t ldx,
+                      const double* covGrad, int64_t ldc, double* g, void* stream);
+
+/* ---- fused drivers (one call = one reference method) ------------------------------------------------------------- */
+
+/* One CGp::updateK() (FTC; CGp.cpp:682-712, 877-891) without the explicit inverse: K := Gram(X), K := chol_L(K) in
+ * place (lower, other triangle untouched), *logdet = log|K|.  Applies jitChol's jitter schedule (CMatrix.cpp:767-804)
+ * when the factorisation fails, regenerating K; *jitter_added receives the total jitter on the diagonal (0 if none).
+ * *info as gpc_potrf_f64 for the LAST attempt. */
+int gpc_gp_update_k_f64(const gpc_kspec* ks, const double* X, int64_t N, int64_t D, int64_t ldx,
+                        double* K, int64_t ldk, double* logdet, double* jitter_added, int* info, void* stream);
+/* CGp::updateAlpha FTC (CGp.cpp:469-489): Alpha := L^-T L^-1 m, both N x d, Alpha overwritten (may alias a copy of m). */
+int gpc_gp_alpha_f64(int64_t N, int64_t d, const double* L, int64_t ldl, const double* m, int64_t ldm,
+                     double* Alpha, int64_t lda, void* stream);
+/* CGp::logLikelihood FTC (CGp.cpp:913-938, 1002-1013), given L, logdet, m and Alpha:
+ * ll = -0.5*(sum_j m_j.alpha_j + d*logdet) - d*N*0.5*log(2*pi).  *ll is host. */
+int gpc_gp_loglik_f64(int64_t N, int64_t d, const double* m, int64_t ldm, const double* Alpha, int64_t lda,
+                      double logdet, double* ll, void* stream);
+/* CGp::posteriorMeanVar FTC (CGp.cpp:642-663, 548-625) before output scale/bias: mu(Ns x d) = kX' Alpha,
+ * var(Ns) = k(x*,x*) - |L^-1 kX_col|^2.  kX_work is an N x Ns device scratch (destroyed, as in the reference).
+ * mu and var are DEVICE buffers. */
+int gpc_gp_posterior_f64(const gpc_kspec* ks, const double* X, int64_t N, int64_t D, int64_t ldx,
+                         const double* L, int64_t ldl, const double* Alpha, int64_t lda, int64_t d,
+                         const double* Xs, int64_t Ns, int64_t ldxs,
+                         double* kX_work, int64_t ldkx, double* mu, int64_t ldmu, double* var, void* stream);
+
+/* ---- measurement hooks (bench.py) -------------------------------------------------------------------------------
+ * When enabled, HIP events bracket every launch of the two dominant kernels on the stream they are launched on:
+ * kind 0 = the trailing SYRK update of gpc_potrf_f64 (work unit: flops), kind 1 = the Gram kernel (work unit:
+ * algorithmic bytes).  gpc_profile_read synchronises, sums the event intervals and optionally resets. */
+int gpc_profile_enable(int on);
+int gpc_profile_read(int kind, int64_t* launches, double* total_ms, double* algorithmic_work, int reset);
+/* Pure-MFMA fp64 micro-benchmark (v_mfma_f64_16x16x4_f64 issue rate on every SIMD): the measured ceiling the
+ * roofline fraction is quoted against next to the datasheet peak. */
+int gpc_probe_mfma_f64(double* tflops, void* stream);
+
+/* ---- tuning knobs (also read from env GPC_NB / GPC_JB on first use) ---------------------------------------------- */
+int gpc_set_potrf_blocking(int64_t nb_outer, int64_t jb_inner);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GPC_HIP_H */

@@ -66,8 +66,9 @@ static void buildKern(CCmpndKern& kern, const CMatrix& X, const gpcb_file& in)
     case K_LIN: k = new CLinKern(X); break;
     default: std::cerr << "ref_driver: unknown kernel type" << std::endl; exit(2);
     }
-    kern.addKern(k);   // clones (CKern.h:384)
-    delete k;
+    kern.addKern(k);   // clones (CKern.h:384).  Deliberately NOT deleted, as in gp.cpp:240-349: CRbfardKern's copy
+                       // constructor assigns `scales` with CMatrix's default (shallow) operator=, so the clone
+                       // shares the original's buffer.
   }
   const gpcb_array* tparams = gpcb_find(&in, "kern_trans_params");
   if(tparams)   // transformed-space parameters, as the reference's fixtures store them (testKern.cpp setTransParams)

@@ -1,0 +1,396 @@
+"""GPU parity tests (-m gpu): the HIP path, called through the C-ABI, against
+  (a) the reference's own fixtures (tests/golden/*.npz converted from /root/reference/matfiles),
+  (b) golden vectors produced by the compiled, unmodified reference (tests/golden/make_golden.py),
+  (c) independent numpy/scipy fp64 evaluations of the same operation.
+Tolerances: 1e-10 absolute for Gram entries (the reference's ndlutil::MATCHTOL, ndlutil.h:33), 1e-8 for the trsm
+fixture (testMatrix.cpp:606-835), 1e-8 RELATIVE for log-likelihood / alpha / predictive mean and variance
+(BASELINE.json north_star).
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+MATCHTOL = 1e-10
+REL = 1e-8
+
+
+@pytest.fixture(scope="module")
+def api():
+    import torch
+    assert torch.cuda.is_available(), "-m gpu tests need a GPU"
+    from gpc_amd import api as a
+    a.lib()   # raises if libgpc_hip.so is missing: no silent fallback
+    return a
+
+
+def rel(a, b):
+    a, b = np.asarray(a, float), np.asarray(b, float)
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
+
+
+def spd(n, seed, cond_shift=1.0):
+    rng = np.random.RandomState(seed)
+    A = rng.randn(n, n)
+    return A @ A.T / n + cond_shift * np.eye(n)
+
+
+# ---- GEMM / SYRK ------------------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("ta,tb", [("N", "N"), ("N", "T"), ("T", "N"), ("T", "T")])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 16), (256, 384, 64), (37, 53, 29), (300, 1, 64), (129, 130, 131),
+                                   (1, 1, 1), (64, 200, 0)])
+def test_gemm_vs_numpy(api, ta, tb, M, N, K):
+    rng = np.random.RandomState(M * 7 + N * 3 + K)
+    A = rng.randn(*((M, K) if ta == "N" else (K, M)))
+    B = rng.randn(*((K, N) if tb == "N" else (N, K)))
+    C = rng.randn(M, N)
+    ref = 1.5 * (A if ta == "N" else A.T) @ (B if tb == "N" else B.T) - 0.5 * C
+    Ad, Bd = api.from_host(A), api.from_host(B)
+    Cd = api.from_host(C)
+    api.gemm(Ad, Bd, Cd, ta, tb, alpha=1.5, beta=-0.5)
+    assert np.abs(api.to_host(Cd) - ref).max() < 1e-12 * max(1, K)
+
+
+def test_gemm_fixture(api, golden):
+    g = golden("gemm")   # gemmMatrixTest.mat, testMatrix.cpp:269-330 (the four trans combinations, in this order)
+    alpha, beta = float(g["alpha"].ravel()[0]), float(g["beta"].ravel()[0])
+    F = api.from_host(g["F"])
+    api.gemm(api.from_host(g["D"]), api.from_host(g["E"]), F, "N", "N", alpha, beta)
+    assert np.abs(api.to_host(F) - g["GEMM1"]).max() < MATCHTOL
+    G = api.from_host(g["G"])
+    api.gemm(api.from_host(g["D"]), api.from_host(g["E"]), G, "T", "T", alpha, beta)
+    assert np.abs(api.to_host(G) - g["GEMM2"]).max() < MATCHTOL
+    C = api.from_host(g["GEMM1"])     # the reference reuses GEMM1 / GEMM2 as the C operand of cases 3 and 4
+    api.gemm(api.from_host(g["D"]), api.from_host(g["H"]), C, "N", "T", alpha, beta)
+    assert np.abs(api.to_host(C) - g["GEMM3"]).max() < MATCHTOL
+    C = api.from_host(g["GEMM2"])
+    api.gemm(api.from_host(g["D"]), api.from_host(g["H"]), C, "T", "N", alpha, beta)
+    assert np.abs(api.to_host(C) - g["GEMM4"]).max() < MATCHTOL
+
+
+def test_syrk_fixture(api, golden):
+    g = golden("syrk")   # syrkMatrixTest.mat, testMatrix.cpp:336-390: CMatrix::syrk = dsyrk + copySymmetric
+    alpha, beta = float(g["alpha"].ravel()[0]), float(g["beta"].ravel()[0])
+    for uplo, trans, cin, want in (("U", "N", "C", "SYRK1"), ("L", "N", "C", "SYRK1"),
+                                   ("U", "T", "D", "SYRK2"), ("L", "T", "D", "SYRK2")):
+        F = api.from_host(g[cin])
+        api.syrk(api.from_host(g["A"]), F, uplo, trans, alpha, beta)
+        api.symmetrize_(F, uplo)
+        assert np.abs(api.to_host(F) - g[want]).max() < MATCHTOL, (uplo, trans)
+
+
+@pytest.mark.parametrize("uplo", ["L", "U"])
+@pytest.mark.parametrize("trans", ["N", "T"])
+@pytest.mark.parametrize("N,K", [(128, 64), (300, 77), (1000, 130)])
+def test_syrk_touches_one_triangle(api, uplo, trans, N, K):
+    rng = np.random.RandomState(N + K)
+    A = rng.randn(*((N, K) if trans == "N" else (K, N)))
+    C = rng.randn(N, N)
+    full = -1.0 * (A @ A.T if trans == "N" else A.T @ A) + 1.0 * C
+    Cd = api.from_host(C)
+    api.syrk(api.from_host(A), Cd, uplo, trans, alpha=-1.0, beta=1.0)
+    out = api.to_host(Cd)
+    tri = np.tril if uplo == "L" else np.triu
+    other = np.triu if uplo == "L" else np.tril
+    assert np.abs(tri(out) - tri(full)).max() < 1e-11
+    k = 1 if uplo == "L" else -1
+    assert np.array_equal(other(out, k), other(C, k))     # the other triangle is untouched, bit for bit
+
+
+# ---- Cholesky -----------------------------------------------------------------------------------------------------------
+
+def test_chol_fixture(api, golden):
+    g = golden("chol11")   # choleskyMatrixTest.mat, testMatrix.cpp:206-235
+    for uplo, key in (("U", "U"), ("L", "L")):
+        A = api.from_host(g["C"])
+        assert api.chol(A, uplo) == 0
+        assert np.abs(api.to_host(A) - g[key]).max() < MATCHTOL
+
+
+@pytest.mark.parametrize("N", [1, 2, 63, 64, 65, 200, 513, 1000, 2500])
+@pytest.mark.parametrize("uplo", ["L", "U"])
+def test_potrf_vs_numpy(api, N, uplo):
+    A = spd(N, N)
+    junk = np.random.RandomState(1).randn(N, N)
+    inp = np.tril(A) + np.triu(junk, 1) if uplo == "L" else np.triu(A) + np.tril(junk, -1)
+    Ad = api.from_host(inp)
+    assert api.potrf(Ad, uplo) == 0
+    out = api.to_host(Ad)
+    L = np.linalg.cholesky(A)
+    if uplo == "L":
+        assert rel(np.tril(out), L) < 1e-12
+        assert np.array_equal(np.triu(out, 1), np.triu(junk, 1))   # LAPACK leaves the other triangle alone
+    else:
+        assert rel(np.triu(out), L.T) < 1e-12
+        assert np.array_equal(np.tril(out, -1), np.tril(junk, -1))
+
+
+def test_potrf_reports_failing_minor(api):
+    N = 300
+    A = spd(N, 3)
+    A[170, 170] = -1.0     # leading minor of order 171 is not positive definite
+    Ad = api.from_host(A)
+    assert api.potrf(Ad, "L") == 171
+    Ad = api.from_host(A)
+    assert api.potrf(Ad, "U") == 171
+
+
+def test_potrf_blocking_invariance(api):
+    # different outer panel widths give the same factor up to rounding
+    N = 1500
+    A = spd(N, 11)
+    outs = []
+    for nb in (64, 256, 512, 1024):
+        api.check(api.lib().gpc_set_potrf_blocking(nb, 64))
+        Ad = api.from_host(A)
+        assert api.potrf(Ad, "L") == 0
+        outs.append(np.tril(api.to_host(Ad)))
+    api.check(api.lib().gpc_set_potrf_blocking(512, 64))
+    for o in outs[1:]:
+        assert rel(o, outs[0]) < 1e-12
+
+
+def test_logdet_and_trace(api):
+    N = 777
+    A = spd(N, 5)
+    Ad = api.from_host(A)
+    assert abs(api.trace(Ad) - np.trace(A)) < 1e-10
+    assert api.potrf(Ad, "L") == 0
+    sign, ld = np.linalg.slogdet(A)
+    assert abs(api.logdet_chol(Ad) - ld) < 1e-9 * abs(ld)
+
+
+@pytest.mark.parametrize("N", [5, 64, 100, 333, 1024])
+@pytest.mark.parametrize("uplo", ["L", "U"])
+def test_potri_vs_numpy(api, N, uplo):
+    A = spd(N, N + 1)
+    Ad = api.from_host(A)
+    assert api.potrf(Ad, uplo) == 0
+    api.potri(Ad, uplo)
+    out = api.to_host(Ad)
+    assert rel(out, np.linalg.inv(A)) < 1e-10
+    assert np.array_equal(out, out.T)
+
+
+# ---- TRSM ------------------------------------------------------------------------------------------------------------------
+
+def test_trsm_fixture_all_16_variants(api, golden):
+    g = golden("trsm16x30")   # trsmMatrixTest.mat, testMatrix.cpp:606-835 (tolerance 1e-8 there)
+    B, alpha = g["B"], float(g["alpha"].ravel()[0])
+    # order of the 16 cases in testMatrix.cpp: side L with (L,U) x (N,T) x (N,U) then side R likewise
+    mats = {("L", "L", "N"): "L", ("L", "L", "U"): "LU", ("L", "U", "N"): "U", ("L", "U", "U"): "UU",
+            ("R", "L", "N"): "L2", ("R", "L", "U"): "L2U", ("R", "U", "N"): "U2", ("R", "U", "U"): "U2U"}
+    found = 0
+    targets = [g["TRSM%d" % i] for i in range(1, 17)]
+    for (side, uplo, diag), mname in mats.items():
+        T = g[mname]
+        for trans in ("N", "T"):
+            Bd = api.from_host(B)
+            api.trsm(api.from_host(T), Bd, side, uplo, trans, diag, alpha)
+            out = api.to_host(Bd)
+            # independent check
+            Tm = np.tril(T) if uplo == "L" else np.triu(T)
+            if diag == "U":
+                Tm = Tm - np.diag(np.diag(Tm)) + np.eye(Tm.shape[0])
+            op = Tm if trans == "N" else Tm.T
+            ref = alpha * (np.linalg.solve(op, B) if side == "L" else np.linalg.solve(op.T, B.T).T)
+            assert rel(out, ref) < 1e-9, (side, uplo, trans, diag)
+            # and it must be one of the reference's 16 stored answers
+            if any(np.abs(out - t).max() < 1e-8 * max(1.0, np.abs(t).max()) for t in targets):
+                found += 1
+    assert found == 16
+
+
+@pytest.mark.parametrize("side,uplo,trans,diag", [("L", "L", "N", "N"), ("L", "L", "T", "N"), ("L", "U", "N", "U"),
+                                                  ("R", "L", "T", "N"), ("R", "U", "N", "N"), ("R", "L", "N", "U")])
+@pytest.mark.parametrize("M,Nrhs", [(300, 1), (200, 300), (1000, 65)])
+def test_trsm_vs_numpy(api, side, uplo, trans, diag, M, Nrhs):
+    rng = np.random.RandomState(M + Nrhs)
+    nt = M if side == "L" else Nrhs
+    T = rng.randn(nt, nt) / np.sqrt(nt) + 2.0 * np.eye(nt)
+    B = rng.randn(M, Nrhs)
+    Bd = api.from_host(B)
+    api.trsm(api.from_host(T), Bd, side, uplo, trans, diag, 0.75)
+    Tm = np.tril(T) if uplo == "L" else np.triu(T)
+    if diag == "U":
+        Tm = Tm - np.diag(np.diag(Tm)) + np.eye(nt)
+    op = Tm if trans == "N" else Tm.T
+    ref = 0.75 * (np.linalg.solve(op, B) if side == "L" else np.linalg.solve(op.T, B.T).T)
+    assert rel(api.to_host(Bd), ref) < 1e-10
+
+
+def test_transpose_symmetrize_zero(api):
+    for N in (1, 31, 32, 33, 100, 1000):
+        A = np.random.RandomState(N).randn(N, N)
+        Ad = api.from_host(A)
+        api.transpose_(Ad)
+        assert np.array_equal(api.to_host(Ad), A.T)
+        for uplo in ("L", "U"):
+            Ad = api.from_host(A)
+            api.symmetrize_(Ad, uplo)
+            tri = np.tril(A) if uplo == "L" else np.triu(A)
+            assert np.array_equal(api.to_host(Ad), tri + tri.T - np.diag(np.diag(A)))
+            Ad = api.from_host(A)
+            api.zero_triangle_(Ad, uplo)
+            assert np.array_equal(api.to_host(Ad), np.triu(A) if uplo == "L" else np.tril(A))
+
+
+# ---- Gram / kernel gradients -------------------------------------------------------------------------------------------------
+
+KERN_FIXTURES = ["kern_rbf", "kern_rbfard", "kern_white", "kern_bias", "kern_lin", "kern_cmpnd_rbf_bias_white",
+                 "kern_cmpnd_rbfard_bias_white", "kern_cmpnd_rbf_lin_bias_white", "kern_cmpnd_rbf_rbf_rbfard"]
+
+
+def terms_from_fixture(g, D):
+    terms, off = [], 0
+    for t in g["types"]:
+        t = str(t)
+        n = {"rbf": 2, "rbfard": 2 + D, "white": 1, "bias": 1, "lin": 1}[t]
+        terms.append((t, list(g["nat_params"].ravel()[off:off + n])))
+        off += n
+    return terms
+
+
+@pytest.mark.parametrize("name", KERN_FIXTURES)
+def test_gram_fixtures(api, golden, name):
+    g = golden(name)     # testKern.cpp:246-304
+    X, X2 = g["X"], g["X2"]
+    ks = api.kspec(terms_from_fixture(g, X.shape[1]))
+    Xd, X2d = api.from_host(X), api.from_host(X2)
+    K2 = api.to_host(api.gram_sym(ks, Xd))
+    assert np.abs(K2 - g["K2"]).max() < MATCHTOL
+    assert np.array_equal(K2, K2.T)
+    K4 = api.to_host(api.gram_cross(ks, Xd, X2d))
+    assert np.abs(K4 - g["K4"]).max() < MATCHTOL
+    k2 = api.to_host(api.gram_diag(ks, Xd))
+    assert np.abs(k2 - g["k2"]).max() < MATCHTOL
+    # block generation agrees with the full symmetric Gram bit for bit
+    blk = api.to_host(api.gram_block(ks, Xd, 30, 50, 10, 70))
+    assert np.array_equal(blk, K2[30:80, 10:80])
+
+
+@pytest.mark.parametrize("name", KERN_FIXTURES)
+def test_kern_grad_fixtures(api, golden, name):
+    from gpc_amd import gp as gpmod
+    g = golden(name)     # testKern.cpp:280-304: getGradTransParams(g, X, covGrad)
+    X = g["X"]
+    terms = terms_from_fixture(g, X.shape[1])
+    ks = api.kspec(terms)
+    cg = g["covGrad"]
+    cg = 0.5 * (cg + cg.T) if not np.array_equal(cg, cg.T) else cg
+    nat = api.kern_grad(ks, api.from_host(X), api.from_host(cg))
+    kinds = gpmod.param_transforms(terms)
+    flat = [p for _, ps in terms for p in ps]
+    got = nat * np.array([gpmod._gradfact(k, x) for k, x in zip(kinds, flat)])
+    if np.array_equal(g["covGrad"], g["covGrad"].T):
+        want = g["g2"].ravel()
+        assert np.abs(got - want).max() < 1e-9 * max(1.0, np.abs(want).max())
+
+
+# ---- CGp (FTC) ---------------------------------------------------------------------------------------------------------------
+
+def run_gp_fixture(api, g, X, y, scale=None, bias=None):
+    from gpc_amd.gp import CGp
+    terms = terms_from_fixture(g, X.shape[1])
+    model = CGp(terms, X, y, scale=scale, bias=bias)
+    ll = model.logLikelihood()
+    assert abs(ll - g["ll"].ravel()[0]) <= REL * abs(g["ll"].ravel()[0])
+    assert abs(model.logDetK - g["logdet"].ravel()[0]) <= REL * abs(g["logdet"].ravel()[0])
+    assert rel(api.to_host(model.Alpha), g["alpha"]) < REL
+    mu, var = model.posteriorMeanVar(g["Xstar"])
+    assert rel(mu, g["mu"]) < REL
+    assert rel(var, g["var"]) < REL
+    yPred, errBar = model.out(g["Xstar"])
+    assert rel(errBar, g["errBar"]) < REL
+    grads, ll2 = model.logLikelihoodGradient()
+    assert ll2 == ll
+    assert rel(grads, g["grads"].ravel()) < REL
+    assert rel(model.getOptParams(), g["opt_params"].ravel()) < 1e-12
+    if "sample_i" in g:
+        ii, jj = g["sample_i"], g["sample_j"]
+        L = api.to_host(model.L)
+        lo_i, lo_j = np.maximum(ii, jj), np.minimum(ii, jj)
+        assert np.abs(L[lo_i, lo_j] - g["L_samples"]).max() < 1e-9 * np.abs(g["L_samples"]).max()
+        K = api.to_host(api.gram_sym(model.kspec(), model.X))
+        assert np.abs(K[ii, jj] - g["K_samples"]).max() < MATCHTOL
+        model.updateInvK()
+        invK = api.to_host(model.invK)
+        assert np.abs(invK[ii, jj] - g["invK_samples"]).max() < REL * np.abs(g["invK_samples"]).max()
+    return model
+
+
+@pytest.mark.parametrize("name", ["gp_ftc500", "gp_ftc500_rbw"])
+def test_gp_ftc500_fixture(api, golden, name):
+    g = golden(name)     # testGpftc.mat (testGp.cpp:105-152) + compiled-reference outputs
+    run_gp_fixture(api, g, g["X"], g["y"], scale=g["scale"].ravel(), bias=g["bias"].ravel())
+    if "mat_ll" in g:
+        # the .mat golden omits -d*N*0.5*log(2*pi)
+        assert abs(g["ll"].ravel()[0] + 500 * 0.9189385332046727 - g["mat_ll"].ravel()[0]) < 1e-9
+
+
+@pytest.mark.parametrize("name,cfg", [("synth_cfg2_256", "cfg2"), ("synth_cfg2_1024", "cfg2"),
+                                      ("synth_cfg3_1024", "cfg3"), ("synth_cfg4_1024", "cfg4"),
+                                      ("synth_cfg2_2048", "cfg2")])
+def test_gp_synthetic_goldens(api, golden, name, cfg):
+    from gpc_amd import synth
+    g = golden(name)
+    N, D, seed = int(g["N"]), int(g["D"]), int(g["seed"])
+    X, y = synth.make_xy(N, D, seed)
+    assert X.sum() == g["x_checksum"] and y.sum() == g["y_checksum"]   # same arrays as when the golden was made
+    run_gp_fixture(api, g, X, y)
+
+
+def test_gp_ard_golden(api, golden):
+    from gpc_amd import synth
+    g = golden("synth_ard_512")
+    X, y = synth.make_xy(512, 4, 77)
+    assert X.sum() == g["x_checksum"]
+    run_gp_fixture(api, g, X, y)
+
+
+def test_jitter_schedule(api):
+    # duplicated inputs + pure rbf => singular K; jitChol's schedule (CMatrix.cpp:767-804) must rescue it
+    from gpc_amd import synth
+    X, _ = synth.make_xy(200, 2, 5)
+    X = np.vstack([X, X])
+    ks = api.kspec([("rbf", [1.0, 1.0])])
+    K, logdet, jit, info = api.gp_update_k(ks, api.from_host(X))
+    assert info == 0 and jit > 0.0
+    # the accumulated jitter is a partial sum of 1e-6 * 10^k * mean(diag) (mean(diag) = 1 here)
+    k = int(round(np.log10(jit / 1e-6)))
+    assert abs(jit - sum(1e-6 * 10 ** i for i in range(k + 1))) < 1e-12 * jit * 10
+
+
+# ---- full-size properties (BASELINE config 2) -----------------------------------------------------------------------------------
+
+def test_cfg2_full_size_properties(api):
+    """N = 8192, D = 8 rbf: size-independent properties of the factor and the solves."""
+    import torch
+    from gpc_amd import synth
+    c = synth.CONFIGS["cfg2"]
+    X, y = synth.make_xy(c["N"], c["D"], 1234)
+    ks = api.kspec(c["kern"])
+    Xd = api.from_host(X)
+    K = api.gram_sym(ks, Xd)
+    Kh_cols = api.to_host(K[:, :8])
+    L, logdet, jit, info = api.gp_update_k(ks, Xd)
+    assert info == 0 and jit == 0.0
+    # (L L') e_j == K e_j on sampled columns
+    Lh = torch.tril(L)
+    E = torch.zeros((c["N"], 8), dtype=torch.float64, device="cuda")
+    for j in range(8):
+        E[j, j] = 1.0
+    R = (Lh @ (Lh.t() @ E)).cpu().numpy()
+    assert np.abs(R - Kh_cols).max() < 1e-11
+    # K alpha == m
+    m = api.from_host(y - y.mean())
+    alpha = api.gp_alpha(L, m)
+    Kfull = api.gram_sym(ks, Xd)
+    resid = (Kfull @ alpha - m).abs().max().item()
+    assert resid < 1e-7 * float(alpha.abs().max().item())
+    # log-likelihood is finite and reproducible
+    ll1 = api.gp_loglik(m, alpha, logdet)
+    L2, logdet2, _, _ = api.gp_update_k(ks, Xd)
+    assert logdet2 == logdet and torch.equal(torch.tril(L2), torch.tril(L))
+    assert np.isfinite(ll1)
