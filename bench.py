@@ -1,0 +1,163 @@
+#!/usr/bin/env python
+"""bench.py -- N x N RBF Gram build + Cholesky factors/sec on MI355X (BASELINE.json's metric).
+
+One "step" = one CGp::updateK()-equivalent (FTC): Gram build of the config's kernel from X resident in HBM, blocked
+Cholesky in place, log-determinant (gpc_gp_update_k_f64).  Default workload = BASELINE config 3 (N = 65 536, D = 32,
+rbf + white, the configuration the north-star target is quoted on; K is 34.4 GB and fits one 288 GB GPU).
+`--workload cfg2` runs config 2 (N = 8 192, D = 8, rbf).
+
+N > 1 GPUs (launched by torch.distributed.run, one process per GPU): see DESIGN.md "multi-GPU".  Until the 2-D
+block-cyclic factorisation lands, every rank factors an independent replica of the workload (weak scaling, no
+data-path collective); `value` is then the aggregate factors/s of all ranks.
+
+Prints ONE JSON line on rank 0.  The `roofline` object is measured live with HIP events bracketing the dominant
+kernel (the trailing SYRK update on fp64 MFMA) on the stream it is launched on; `cpu_baseline` times the compiled
+reference (oracle/_ref, kind "reference") or, when that binary or MKL is absent, the C restatement (kind "port")
+on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FP64_MFMA_PEAK_TFLOPS = 78.6      # 256 CU x 4 SIMD x 2.4 GHz x 32 flop/clk (AMD MI355X fp64 matrix)
+HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: 8 TB/s HBM3E
+
+
+def cpu_baseline(cfg, sample_n, seed):
+    """Reference semantics of one updateK (scalar Gram loop + jitChol) on a bounded sample, on the host cores."""
+    from gpc_amd import synth
+    from oracle import refrun, portrun
+    X, _ = synth.make_xy(sample_n, cfg["D"], seed)
+    cores = os.cpu_count() or 1
+    t0 = time.time()
+    if refrun.have_ref():
+        arrays = dict(refrun.kern_arrays(cfg["kern"]))
+        arrays.update({"X": X, "reps": 1.0})
+        r = refrun.run_ref("time", arrays, threads=cores)
+        kind, used = "reference", cores
+    elif refrun.have_port():
+        sample_n = min(sample_n, 2048)
+        X = X[:sample_n]
+        r = portrun.time_update_k(cfg["kern"], X, reps=1)
+        kind, used = "port", 1
+    else:
+        return None
+    tg, tc = float(r["t_gram"][0, 0]), float(r["t_chol"][0, 0])
+    return {"value": 1.0 / (tg + tc), "unit": "factors/s at the sample size", "cores": used, "kind": kind,
+            "sample": "N=%d D=%d same kernel, one CGp::updateK (scalar Gram loop %.2f s + jitChol %.2f s; "
+                      "BLAS threads = cores for the reference, the Gram loop is single-threaded); wall %.1f s"
+                      % (sample_n, cfg["D"], tg, tc, time.time() - t0)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default=os.environ.get("GPC_BENCH_WORKLOAD", "cfg3"))
+    ap.add_argument("--n", type=int, default=0, help="override N (debug)")
+    ap.add_argument("--cpu-sample-n", type=int, default=8192)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from gpc_amd import api, synth
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    api.lib()
+
+    cfg = dict(synth.CONFIGS[args.workload])
+    if args.n:
+        cfg["N"] = args.n
+    N, D = cfg["N"], cfg["D"]
+    X, _ = synth.make_xy(N, D, seed=1234 + rank)
+    Xd = api.from_host(X)
+    ks = api.kspec(cfg["kern"])
+    K = api.empty(N, N)
+
+    def step():
+        _, logdet, jit, info = api.gp_update_k(ks, Xd, K)
+        assert info == 0, "factorisation failed (info=%d)" % info
+        return logdet
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    api.check(api.lib().gpc_profile_enable(1))
+    import ctypes
+    for kind in (0, 1):
+        api.check(api.lib().gpc_profile_read(kind, None, None, None, 1))
+    sync()
+    t0 = time.perf_counter()
+    logdet = 0.0
+    for _ in range(args.steps):
+        logdet = step()
+    sync()
+    dt = time.perf_counter() - t0
+    api.check(api.lib().gpc_profile_enable(0))
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    def prof(kind):
+        n, ms, w = ctypes.c_int64(0), ctypes.c_double(0.0), ctypes.c_double(0.0)
+        api.check(api.lib().gpc_profile_read(kind, ctypes.byref(n), ctypes.byref(ms), ctypes.byref(w), 1))
+        return n.value, ms.value, w.value
+
+    syrk_n, syrk_ms, syrk_flops = prof(0)
+    gram_n, gram_ms, gram_bytes = prof(1)
+
+    if rank == 0:
+        probe = ctypes.c_double(0.0)
+        api.check(api.lib().gpc_probe_mfma_f64(ctypes.byref(probe), api.stream()))
+        achieved = syrk_flops / (syrk_ms * 1e-3) * 1e-12 if syrk_ms > 0 else 0.0
+        potrf_flops = N ** 3 / 3.0
+        roof = {"bound": "mfma", "kernel": "gemm_f64_kernel (trailing SYRK of gpc_potrf_f64)",
+                "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": None,
+                "launches_per_step": syrk_n / max(1, args.steps),
+                "avg_launch_ms": syrk_ms / max(1, syrk_n),
+                "algorithmic_flops_per_launch": syrk_flops / max(1, syrk_n),
+                "mfma_f64_probe_tflops": probe.value,
+                "whole_factor_tflops": potrf_flops * args.steps / dt * 1e-12,
+                "gram": {"bound": "hbm", "achieved": gram_bytes / (gram_ms * 1e-3) * 1e-9 if gram_ms > 0 else 0.0,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "avg_launch_ms": gram_ms / max(1, gram_n)}}
+        roof["gram"]["frac"] = roof["gram"]["achieved"] / HBM_PEAK_GBS
+        out = {"metric": "N x N RBF Gram build + Cholesky factors/sec", "value": world * args.steps / dt,
+               "unit": "factors/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+               "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+               "config": {"workload": "%s: N=%d D=%d kernel=%s, one CGp::updateK (Gram + dpotrf + logdet) per step"
+                                      % (args.workload, N, D, "+".join(t for t, _ in cfg["kern"])),
+                          "parallelism": "1 GPU" if world == 1 else "%d independent replicas" % world,
+                          "logdet": logdet},
+               "roofline": roof}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(cfg, min(args.cpu_sample_n, N), 1234)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -62,6 +62,7 @@ SIGNATURES = {
     "gpc_symmetrize_f64": (c_int, [c_char, I64, DP, I64, VP]),
     "gpc_zero_triangle_f64": (c_int, [c_char, I64, DP, I64, VP]),
     "gpc_add_diag_f64": (c_int, [I64, DP, I64, c_double, VP]),
+    "gpc_ref_trans_rounding_f64": (c_int, [I64, DP, I64, VP]),
     "gpc_trace_f64": (c_int, [I64, DP, I64, POINTER(c_double), VP]),
     "gpc_coldot_f64": (c_int, [I64, I64, DP, I64, DP, I64, POINTER(c_double), VP]),
     "gpc_colnorm2_f64": (c_int, [I64, I64, DP, I64, DP, VP]),

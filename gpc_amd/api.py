@@ -67,13 +67,16 @@ def to_host(t):
 def _chk(t):
     if t.dtype != torch.float64 or t.dim() != 2:
         raise TypeError("expected a 2-D float64 tensor")
-    if t.shape[0] > 1 and t.stride(0) != 1:
-        raise ValueError("matrix is not column-major (stride(0) must be 1)")
+    if t.numel() > 0 and t.shape[0] > 1 and t.stride(0) != 1:
+        raise ValueError("matrix is not column-major (stride(0) must be 1), got shape %s strides %s"
+                         % (tuple(t.shape), tuple(t.stride())))
     return t
 
 
 def ld(t):
     _chk(t)
+    if t.numel() == 0:
+        return max(1, t.shape[0])
     return t.stride(1) if t.shape[1] > 1 else max(1, t.shape[0])
 
 
@@ -200,6 +203,12 @@ def zero_triangle_(A, uplo_to_zero):
 
 def add_diag_(A, c):
     check(lib().gpc_add_diag_f64(A.shape[0], ptr(A), ld(A), float(c), stream()))
+    return A
+
+
+def ref_trans_rounding_(A):
+    """The reference's fp32 rounding of the strictly-lower triangle of LcholK (see include/gpc_hip.h)."""
+    check(lib().gpc_ref_trans_rounding_f64(A.shape[0], ptr(A), ld(A), stream()))
     return A
 
 

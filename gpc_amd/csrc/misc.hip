@@ -88,6 +88,15 @@ __global__ void __launch_bounds__(256) zero_triangle_kernel(double* __restrict__
   }
 }
 
+// A(i,j) := (double)(float)A(i,j) for i > j: what the reference's in-place transpose does to LcholK (see capi).
+__global__ void __launch_bounds__(256) round_lower_f32_kernel(double* __restrict__ A, int64_t lda, int64_t N,
+                                                              int64_t j0)
+{
+  const int64_t j = j0 + blockIdx.y;
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if(i < N && j < N && i > j) A[i + j * lda] = (double)(float)A[i + j * lda];
+}
+
 __global__ void __launch_bounds__(256) add_diag_kernel(double* __restrict__ A, int64_t lda, int64_t N, double c)
 {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -275,6 +284,20 @@ int diag_reduce(int what, int64_t N, const double* A, int64_t lda, double* out_h
 }  // namespace gpc
 
 using namespace gpc;
+
+extern "C" int gpc_ref_trans_rounding_f64(int64_t N, double* A, int64_t lda, void* stream)
+{
+  GPC_CHECK(ensure_device());
+  GPC_REQUIRE(N >= 0 && lda >= (N > 1 ? N : 1), "ref_trans_rounding dims");
+  hipStream_t s = as_stream(stream);
+  for(int64_t j0 = 0; j0 < N; j0 += 32768) {
+    const int64_t nc = (N - j0 < 32768) ? (N - j0) : 32768;
+    hipLaunchKernelGGL(round_lower_f32_kernel, dim3((unsigned)((N + 255) / 256), (unsigned)nc), dim3(256), 0, s, A,
+                       lda, N, j0);
+  }
+  GPC_HIP_CHECK(hipGetLastError());
+  return GPC_OK;
+}
 
 extern "C" int gpc_coldot_f64(int64_t M, int64_t ncols, const double* A, int64_t lda, const double* B, int64_t ldb,
                               double* out, void* stream)

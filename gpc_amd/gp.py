@@ -5,8 +5,15 @@ setOptParams work in the transformed (optimiser) space, logLikelihood includes t
 (CGp.cpp:1010-1013), logLikelihoodGradient returns dL/d(transformed kernel params) (CGp.cpp:1016-1144),
 posteriorMeanVar applies the output scale and bias (CGp.cpp:548-625) and out() adds the Gaussian noise model
 (CNoise.cpp:475-490).  All arithmetic on N x N objects happens in libgpc_hip.so.
+
+Reference quirk reproduced by default (`ref_trans_rounding=True`): a reference built from ndlfortran.f keeps the
+strictly-lower part of LcholK rounded to single precision (see gpc_ref_trans_rounding_f64 in include/gpc_hip.h), which
+shows up at ~1e-7 relative in Alpha and in the predictive mean/variance but NOT in logDetK / invK / the
+log-likelihood and its gradient.  With the flag on, Alpha/mean/variance match that reference to 1e-8; with it off
+(or GPC_EXACT_TRANS=1 in the environment) everything is plain fp64.
 """
 import math
+import os
 
 import numpy as np
 
@@ -48,10 +55,13 @@ def param_transforms(terms):
 class CGp:
     FTC = 0
 
-    def __init__(self, terms, X, y, scale=None, bias=None, device="cuda"):
+    def __init__(self, terms, X, y, scale=None, bias=None, device="cuda", ref_trans_rounding=None):
         self.terms = [(n, list(map(float, p))) for n, p in terms]
         self.kinds = param_transforms(self.terms)
         self.device = device
+        if ref_trans_rounding is None:
+            ref_trans_rounding = os.environ.get("GPC_EXACT_TRANS", "0") != "1"
+        self.ref_trans_rounding = bool(ref_trans_rounding)
         X = np.asarray(X, dtype=np.float64)
         y = np.asarray(y, dtype=np.float64).reshape(X.shape[0], -1)
         self.N, self.D = X.shape
@@ -66,9 +76,11 @@ class CGp:
         self._dirty()
 
     def _dirty(self):
-        self.L = None
+        self.L = None          # LcholK (lower); strictly-lower part fp32-rounded when ref_trans_rounding
         self.logDetK = None
-        self.Alpha = None
+        self.invKm = None      # invK * m, exact fp64 (what dsymv(invK, m) gives the reference, CGp.cpp:928)
+        self.quad = None       # m_j' invK m_j per output
+        self.Alpha = None      # CGp::Alpha = LcholK^-T LcholK^-1 m with the model's LcholK
         self.invK = None
         self.jitter = 0.0
 
@@ -90,40 +102,55 @@ class CGp:
     def kspec(self):
         return api.kspec(self.terms)
 
-    # ---- CGp::updateK (FTC) ---------------------------------------------------------------------------------------
-    def updateK(self):
-        if self.L is None:
-            K, logdet, jit, info = api.gp_update_k(self.kspec(), self.X)
-            if info != 0:
-                raise np.linalg.LinAlgError("MatrixNonPosDef: leading minor %d (jitter %g)" % (info, jit))
-            self.L, self.logDetK, self.jitter = K, logdet, jit
+    # ---- CGp::updateK (FTC): _updateK + _updateInvK ------------------------------------------------------------------
+    def updateK(self, need_inverse=False):
+        if self.L is not None and (self.invK is not None or not need_inverse):
+            return
+        K, logdet, jit, info = api.gp_update_k(self.kspec(), self.X)
+        if info != 0:
+            raise np.linalg.LinAlgError("MatrixNonPosDef: leading minor %d (jitter %g)" % (info, jit))
+        self.logDetK, self.jitter = logdet, jit
+        self.invKm = api.gp_alpha(K, self.m)                 # exact K^-1 m
+        self.quad = api.coldot(self.m, self.invKm)
+        if need_inverse:
+            inv = K.clone()                                   # keeps the column-major strides
+            api.potri(inv, "L")                               # invK.pdinv(LcholK), CGp.cpp:889
+            self.invK = inv
+        if self.ref_trans_rounding:
+            api.ref_trans_rounding_(K)                        # LcholK.trans() of the Fortran-built reference
+            self.Alpha = None
+        else:
+            self.Alpha = self.invKm
+        self.L = K
 
     def updateAlpha(self):
         self.updateK()
         if self.Alpha is None:
-            self.Alpha = api.gp_alpha(self.L, self.m)
+            self.Alpha = api.gp_alpha(self.L, self.m)         # CGp::updateAlpha, CGp.cpp:469-489
 
     def logLikelihood(self):
-        self.updateAlpha()
-        return api.gp_loglik(self.m, self.Alpha, self.logDetK)
+        """CGp::logLikelihood FTC, CGp.cpp:913-938, 1002-1013."""
+        self.updateK()
+        L = 0.0
+        for j in range(self.d):
+            L += self.quad[j]
+            L += self.logDetK
+        L *= -0.5
+        L -= self.d * self.N * 0.91893853320467274178
+        return L
 
     def updateInvK(self):
-        self.updateK()
-        if self.invK is None:
-            inv = self.L.clone()   # keeps the column-major strides
-            api.potri(inv, "L")
-            self.invK = inv
+        self.updateK(need_inverse=True)
 
     def logLikelihoodGradient(self):
         """Returns (g wrt transformed kernel parameters, logLikelihood) like CGp::logLikelihoodGradient."""
-        self.updateAlpha()
-        self.updateInvK()
+        self.updateK(need_inverse=True)
         ks = self.kspec()
         g = np.zeros(self.getOptNumParams())
         cg = api.empty(self.N, self.N, self.device)
         for j in range(self.d):
-            a = self.Alpha[:, j:j + 1]
-            api.covgrad(self.invK, a, out=cg)          # CGp::updateCovGradient
+            a = self.invKm[:, j:j + 1]
+            api.covgrad(self.invK, a, out=cg)          # CGp::updateCovGradient, CGp.cpp:666-679
             g += api.kern_grad(ks, self.X, cg)         # CKern::getGradParams
         # CKern::getGradTransParams (CKern.cpp:50-63): chain rule through the transforms
         g *= np.array([_gradfact(k, x) for k, x in zip(self.kinds, self._flat())])

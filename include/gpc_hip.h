@@ -123,6 +123,14 @@ int gpc_symmetrize_f64(char uplo, int64_t N, double* A, int64_t lda, void* strea
 int gpc_zero_triangle_f64(char uplo_to_zero, int64_t N, double* A, int64_t lda, void* stream);
 /* A(i,i) += c (CMatrix::addDiag CMatrix.h:841, the jitter step of jitChol CMatrix.cpp:767-804). */
 int gpc_add_diag_f64(int64_t N, double* A, int64_t lda, double c, void* stream);
+/* Reference-compatibility quirk.  CGp::_updateInvK makes LcholK lower with CMatrix::trans() -> dtransr_
+ * (CGp.cpp:890, CMatrix.h:789-801).  In ndlfortran.f:2138-2157 the swap temporary B is implicitly REAL, so a
+ * reference built from the Fortran source (make.linux: gfortran; SURVEY 8c: flang) stores every strictly-lower
+ * element of LcholK rounded to SINGLE precision (the diagonal and invK/logDetK are unaffected; the f2c twin
+ * ndlfortran.c:1232 declares it doublereal and is exact).  Alpha and the predictive mean/variance of that build carry
+ * the ~1e-7 relative error.  This entry point applies exactly that rounding, A(i,j) := (double)(float)A(i,j), i > j,
+ * so the CGp layer can reproduce the reference's numbers to 1e-8; the kernels themselves never round. */
+int gpc_ref_trans_rounding_f64(int64_t N, double* A, int64_t lda, void* stream);
 /* trace(A) to a host double (jitChol's 1e-6*tr/N). */
 int gpc_trace_f64(int64_t N, const double* A, int64_t lda, double* out, void* stream);
 

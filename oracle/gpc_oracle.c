@@ -1,0 +1,758 @@
+/* gpc_oracle.c -- plain-C CPU restatement of GPc's exact-GP (FTC) hot path.  TEST INFRASTRUCTURE ONLY; see
+ * gpc_oracle.h for the scope, the parity status ("pinned") and the rules on who may call this. */
+#include "gpc_oracle.h"
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#include <ctype.h>
+
+#define A_(i, j) A[(i) + (size_t)(j) * lda]
+#define HALFLOGTWOPI 0.91893853320467274178 /* ndlutil::HALFLOGTWOPI */
+#define LIMVAL 36.0                         /* CTransform.h:18 */
+#define EPS_ 2.220446049250313e-16          /* ndlutil::EPS */
+
+/* ---- BLAS-1 pieces the reference reaches through CMatrix -------------------------------------------------------- */
+
+/* dnrm2 (reference BLAS, scaled form), strided: CMatrix::normRow, CMatrix.h:580-584 */
+static double nrm2(long n, const double* x, long inc)
+{
+  double scale = 0.0, ssq = 1.0;
+  long i;
+  if(n < 1) return 0.0;
+  if(n == 1) return fabs(x[0]);
+  for(i = 0; i < n; i++) {
+    const double v = x[i * inc];
+    if(v != 0.0) {
+      const double a = fabs(v);
+      if(scale < a) {
+        ssq = 1.0 + ssq * (scale / a) * (scale / a);
+        scale = a;
+      } else {
+        ssq += (a / scale) * (a / scale);
+      }
+    }
+  }
+  return scale * sqrt(ssq);
+}
+
+/* ddot: in the reference build the strided Fortran loop of ndlfortran.f:569 shadows the BLAS symbol */
+static double dot(long n, const double* x, long incx, const double* y, long incy)
+{
+  double s = 0.0;
+  long i;
+  for(i = 0; i < n; i++) s += x[i * incx] * y[i * incy];
+  return s;
+}
+
+/* CMatrix::dist2Row, CMatrix.h:554-560: norm2Row(i) + A.norm2Row(k) - 2*dotRowRow(i, A, k); norm2Row = dnrm2^2
+ * (CMatrix.h:586-593). */
+double orc_dist2_row(const double* X1, long ld1, long i, const double* X2, long ld2, long k, long D)
+{
+  const double n1 = nrm2(D, X1 + i, ld1), n2 = nrm2(D, X2 + k, ld2);
+  return n1 * n1 + n2 * n2 - 2.0 * dot(D, X2 + k, ld2, X1 + i, ld1);
+}
+
+/* ---- LAPACK pieces ------------------------------------------------------------------------------------------------ */
+
+/* dpotrf via the unblocked dpotf2 recurrences (reference LAPACK): CMatrix::potrf, CMatrix.cpp:371-379; the info
+ * convention is lapack.h:59-65. */
+int orc_potrf(char uplo, long N, double* A, long lda)
+{
+  long i, j, k;
+  if(toupper(uplo) == 'U') {
+    for(j = 0; j < N; j++) {
+      double ajj = A_(j, j) - dot(j, &A_(0, j), 1, &A_(0, j), 1);
+      if(!(ajj > 0.0)) {
+        A_(j, j) = ajj;
+        return (int)(j + 1);
+      }
+      ajj = sqrt(ajj);
+      A_(j, j) = ajj;
+      for(i = j + 1; i < N; i++) { /* row j right of the diagonal: dgemv('T') then dscal */
+        double s = A_(j, i);
+        for(k = 0; k < j; k++) s -= A_(k, j) * A_(k, i);
+        A_(j, i) = s / ajj;
+      }
+    }
+  } else {
+    for(j = 0; j < N; j++) {
+      double ajj = A_(j, j) - dot(j, &A_(j, 0), lda, &A_(j, 0), lda);
+      if(!(ajj > 0.0)) {
+        A_(j, j) = ajj;
+        return (int)(j + 1);
+      }
+      ajj = sqrt(ajj);
+      A_(j, j) = ajj;
+      for(i = j + 1; i < N; i++) A_(i, j) -= dot(j, &A_(i, 0), lda, &A_(j, 0), lda);
+      for(i = j + 1; i < N; i++) A_(i, j) /= ajj;
+    }
+  }
+  return 0;
+}
+
+/* CMatrix::chol(type), CMatrix.cpp:380-398: potrf then zero the other triangle */
+int orc_chol(char uplo, long N, double* A, long lda)
+{
+  long i, j;
+  const int info = orc_potrf(uplo, N, A, lda);
+  if(info != 0) return info;
+  if(toupper(uplo) == 'L') {
+    for(j = 0; j < N; j++)
+      for(i = 0; i < j; i++) A_(i, j) = 0.0;
+  } else {
+    for(i = 0; i < N; i++)
+      for(j = 0; j < i; j++) A_(i, j) = 0.0;
+  }
+  return 0;
+}
+
+/* CMatrix::jitChol, CMatrix.cpp:767-804.  A is modified by addDiag on every failure; returns the CURRENT jitter value
+ * (the next candidate, even when none was added: SURVEY 0-7 iii).  *info != 0 mirrors the MatrixNonPosDef throws. */
+double orc_jitchol(long N, double* A, double* U, int max_tries, int* info)
+{
+  long i;
+  double tr = 0.0, jitter;
+  int tries = 0, success = 0;
+  for(i = 0; i < N; i++) tr += A[i + (size_t)i * N];
+  jitter = 1e-6 * tr / (double)N;
+  *info = 0;
+  while(!success && tries < max_tries) {
+    memcpy(U, A, sizeof(double) * (size_t)N * N); /* deepCopy(A) */
+    if(orc_chol('U', N, U, N) == 0) {
+      success = 1;
+    } else {
+      for(i = 0; i < N; i++) A[i + (size_t)i * N] += jitter; /* A.addDiag(jitter) */
+      jitter *= 10.0;
+      tries++;
+      if(jitter > 10.0) {
+        *info = 1;
+        return jitter;
+      }
+    }
+  }
+  if(tries >= max_tries) *info = 1;
+  return jitter;
+}
+
+/* logDet(U), CMatrix.cpp:404-412 */
+double orc_logdet(long N, const double* U, long ldu)
+{
+  double s = 0.0;
+  long i;
+  for(i = 0; i < N; i++) s += log(U[i + (size_t)i * ldu]);
+  return 2.0 * s;
+}
+
+/* CMatrix::pdinv(U), CMatrix.cpp:421-432: deepCopy(U); dpotri('U') = dtrtri('U','N') then dlauum('U') (reference
+ * LAPACK, unblocked dtrti2 / dlauu2 recurrences); then mirror the upper triangle into the lower one. */
+void orc_pdinv_upper(long N, const double* U, double* A)
+{
+  const long lda = N;
+  long i, j, k;
+  memcpy(A, U, sizeof(double) * (size_t)N * N);
+  /* dtrti2, upper, non-unit: column j of inv(U) */
+  for(j = 0; j < N; j++) {
+    double ajj;
+    A_(j, j) = 1.0 / A_(j, j);
+    ajj = -A_(j, j);
+    /* x := inv(U)(0:j,0:j) * U(0:j, j)  (dtrmv upper no-trans on the already inverted leading block), then scale */
+    for(k = 0; k < j; k++) {
+      const double t = A_(k, j);
+      if(t != 0.0) {
+        for(i = 0; i < k; i++) A_(i, j) += t * A_(i, k);
+        A_(k, j) = t * A_(k, k);
+      }
+    }
+    for(i = 0; i < j; i++) A_(i, j) *= ajj;
+  }
+  /* dlauu2, upper: A := V * V' with V = inv(U) upper triangular */
+  for(i = 0; i < N; i++) {
+    const double aii = A_(i, i);
+    if(i < N - 1) {
+      A_(i, i) = dot(N - i, &A_(i, i), lda, &A_(i, i), lda);
+      /* A(0:i, i) := aii * A(0:i, i) + A(0:i, i+1:N) * A(i, i+1:N)' */
+      for(k = 0; k < i; k++) {
+        double s = aii * A_(k, i);
+        for(j = i + 1; j < N; j++) s += A_(k, j) * A_(i, j);
+        A_(k, i) = s;
+      }
+    } else {
+      for(k = 0; k <= i; k++) A_(k, i) *= aii;
+    }
+  }
+  for(i = 0; i < N; i++)
+    for(j = 0; j < i; j++) A_(i, j) = A_(j, i);
+}
+
+/* CMatrix::trans for a square matrix (CMatrix.h:789-801) -> dtransr_, square branch, ndlfortran.f:2138-2157:
+ *     DO I=1,N-1; DO J=I+1,N:  I1 = (I,J);  I2 = (J,I);  B = A(I1); A(I1) = A(I2); A(I2) = B
+ * Only A is declared DOUBLE PRECISION there; the temporary B is implicitly REAL.  A reference built from the Fortran
+ * source (make.linux uses gfortran; SURVEY 8c uses flang) therefore stores the element that lands BELOW the diagonal
+ * rounded to single precision, the one that lands above it exactly.  (The f2c twin, ndlfortran.c:1232, declares
+ * `doublereal b` and is exact.)  orc_exact_trans = 1 restates the f2c behaviour instead. */
+int orc_exact_trans = 0;
+void orc_trans(long N, double* A)
+{
+  long i, j;
+  for(i = 0; i < N - 1; i++)
+    for(j = i + 1; j < N; j++) {
+      const size_t i1 = (size_t)i + (size_t)j * N; /* (I,J), upper */
+      const size_t i2 = (size_t)j + (size_t)i * N; /* (J,I), lower */
+      if(orc_exact_trans) {
+        const double b = A[i1];
+        A[i1] = A[i2];
+        A[i2] = b;
+      } else {
+        const float b = (float)A[i1];
+        A[i1] = A[i2];
+        A[i2] = (double)b;
+      }
+    }
+}
+
+/* dtrsm (reference BLAS loops): CMatrix::trsm, CMatrix.cpp:272-295; lapack.h:208-218 */
+void orc_trsm(char side, char uplo, char trans, char diag, long M, long N, double alpha, const double* A, long lda,
+              double* B, long ldb)
+{
+#define B_(i, j) B[(i) + (size_t)(j) * ldb]
+  const int lside = toupper(side) == 'L', upper = toupper(uplo) == 'U', notr = toupper(trans) == 'N',
+            nounit = toupper(diag) == 'N';
+  long i, j, k;
+  if(M == 0 || N == 0) return;
+  if(alpha == 0.0) {
+    for(j = 0; j < N; j++)
+      for(i = 0; i < M; i++) B_(i, j) = 0.0;
+    return;
+  }
+  if(lside) {
+    if(notr) { /* B := alpha * inv(A) * B */
+      for(j = 0; j < N; j++) {
+        if(alpha != 1.0)
+          for(i = 0; i < M; i++) B_(i, j) *= alpha;
+        if(upper) {
+          for(k = M - 1; k >= 0; k--) {
+            if(B_(k, j) != 0.0) {
+              if(nounit) B_(k, j) /= A_(k, k);
+              for(i = 0; i < k; i++) B_(i, j) -= B_(k, j) * A_(i, k);
+            }
+          }
+        } else {
+          for(k = 0; k < M; k++) {
+            if(B_(k, j) != 0.0) {
+              if(nounit) B_(k, j) /= A_(k, k);
+              for(i = k + 1; i < M; i++) B_(i, j) -= B_(k, j) * A_(i, k);
+            }
+          }
+        }
+      }
+    } else { /* B := alpha * inv(A') * B */
+      for(j = 0; j < N; j++) {
+        if(upper) {
+          for(i = 0; i < M; i++) {
+            double t = alpha * B_(i, j);
+            for(k = 0; k < i; k++) t -= A_(k, i) * B_(k, j);
+            if(nounit) t /= A_(i, i);
+            B_(i, j) = t;
+          }
+        } else {
+          for(i = M - 1; i >= 0; i--) {
+            double t = alpha * B_(i, j);
+            for(k = i + 1; k < M; k++) t -= A_(k, i) * B_(k, j);
+            if(nounit) t /= A_(i, i);
+            B_(i, j) = t;
+          }
+        }
+      }
+    }
+  } else {
+    if(notr) { /* B := alpha * B * inv(A) */
+      if(upper) {
+        for(j = 0; j < N; j++) {
+          if(alpha != 1.0)
+            for(i = 0; i < M; i++) B_(i, j) *= alpha;
+          for(k = 0; k < j; k++)
+            if(A_(k, j) != 0.0)
+              for(i = 0; i < M; i++) B_(i, j) -= A_(k, j) * B_(i, k);
+          if(nounit) {
+            const double t = 1.0 / A_(j, j);
+            for(i = 0; i < M; i++) B_(i, j) *= t;
+          }
+        }
+      } else {
+        for(j = N - 1; j >= 0; j--) {
+          if(alpha != 1.0)
+            for(i = 0; i < M; i++) B_(i, j) *= alpha;
+          for(k = j + 1; k < N; k++)
+            if(A_(k, j) != 0.0)
+              for(i = 0; i < M; i++) B_(i, j) -= A_(k, j) * B_(i, k);
+          if(nounit) {
+            const double t = 1.0 / A_(j, j);
+            for(i = 0; i < M; i++) B_(i, j) *= t;
+          }
+        }
+      }
+    } else { /* B := alpha * B * inv(A') */
+      if(upper) {
+        for(k = N - 1; k >= 0; k--) {
+          if(nounit) {
+            const double t = 1.0 / A_(k, k);
+            for(i = 0; i < M; i++) B_(i, k) *= t;
+          }
+          for(j = 0; j < k; j++)
+            if(A_(j, k) != 0.0) {
+              const double t = A_(j, k);
+              for(i = 0; i < M; i++) B_(i, j) -= t * B_(i, k);
+            }
+          if(alpha != 1.0)
+            for(i = 0; i < M; i++) B_(i, k) *= alpha;
+        }
+      } else {
+        for(k = 0; k < N; k++) {
+          if(nounit) {
+            const double t = 1.0 / A_(k, k);
+            for(i = 0; i < M; i++) B_(i, k) *= t;
+          }
+          for(j = k + 1; j < N; j++)
+            if(A_(j, k) != 0.0) {
+              const double t = A_(j, k);
+              for(i = 0; i < M; i++) B_(i, j) -= t * B_(i, k);
+            }
+          if(alpha != 1.0)
+            for(i = 0; i < M; i++) B_(i, k) *= alpha;
+        }
+      }
+    }
+  }
+#undef B_
+}
+
+/* dsymv('U'): CMatrix::symvColCol as used by CGp.cpp:675, 928 */
+void orc_symv_upper(long N, const double* A, const double* x, double* y)
+{
+  const long lda = N;
+  long i, j;
+  for(i = 0; i < N; i++) y[i] = 0.0;
+  for(j = 0; j < N; j++) {
+    const double t1 = x[j];
+    double t2 = 0.0;
+    for(i = 0; i < j; i++) {
+      y[i] += t1 * A_(i, j);
+      t2 += A_(i, j) * x[i];
+    }
+    y[j] += t1 * A_(j, j) + t2;
+  }
+}
+
+/* ---- kernels --------------------------------------------------------------------------------------------------------- */
+
+/* CCmpndKern::computeElement, CKern.cpp:219-226: sum of the components' computeElement */
+double orc_kern_element(const orc_kspec* ks, const double* X1, long ld1, long i, const double* X2, long ld2, long j,
+                        long D)
+{
+  double k = 0.0;
+  int t;
+  long q;
+  for(t = 0; t < ks->n_terms; t++) {
+    const double* p = ks->params + ks->offs[t];
+    switch(ks->types[t]) {
+    case ORC_KERN_RBF: { /* CRbfKern::computeElement, CKern.cpp:1147-1154 */
+      double v = orc_dist2_row(X1, ld1, i, X2, ld2, j, D);
+      v = 0.5 * v * p[0];
+      k += p[1] * exp(-v);
+      break;
+    }
+    case ORC_KERN_RBFARD: { /* CRbfardKern::computeElement, CKern.cpp:3305-3316 */
+      double val = 0.0;
+      for(q = 0; q < D; q++) {
+        double x = X1[i + q * ld1];
+        x = x - X2[j + q * ld2];
+        val += x * p[2 + q] * x;
+      }
+      k += p[1] * exp(-val * p[0] * 0.5);
+      break;
+    }
+    case ORC_KERN_WHITE: /* CWhiteKern::computeElement returns 0, CKern.cpp:702-705 */ break;
+    case ORC_KERN_BIAS: k += p[0]; break; /* CKern.cpp:989-993 */
+    case ORC_KERN_LIN: k += p[0] * dot(D, X2 + j, ld2, X1 + i, ld1); break; /* CKern.cpp:2328-2332 */
+    default: break;
+    }
+  }
+  return k;
+}
+
+/* CCmpndKern::diagComputeElement, CKern.cpp:165-171 */
+double orc_kern_diag_element(const orc_kspec* ks, const double* X, long ld, long i, long D)
+{
+  double k = 0.0;
+  int t;
+  for(t = 0; t < ks->n_terms; t++) {
+    const double* p = ks->params + ks->offs[t];
+    switch(ks->types[t]) {
+    case ORC_KERN_RBF: k += p[1]; break;    /* CKern.cpp:1074-1077 */
+    case ORC_KERN_RBFARD: k += p[1]; break; /* CKern.cpp:3294-3297 */
+    case ORC_KERN_WHITE: k += p[0]; break;  /* CKern.cpp:646-649 */
+    case ORC_KERN_BIAS: k += p[0]; break;   /* CKern.cpp:933-936 */
+    case ORC_KERN_LIN: {                    /* CKern.cpp:2262-2265: variance * norm2Row */
+      const double n = nrm2(D, X + i, ld);
+      k += p[0] * n * n;
+      break;
+    }
+    default: break;
+    }
+  }
+  return k;
+}
+
+/* CKern::compute(K, X), CKern.h:128-144 == CGp::_updateK FTC, CGp.cpp:698-712 */
+void orc_gram_sym(const orc_kspec* ks, const double* X, long N, long D, double* K)
+{
+  long i, j;
+  for(i = 0; i < N; i++) {
+    for(j = 0; j < i; j++) {
+      const double k = orc_kern_element(ks, X, N, i, X, N, j, D);
+      K[i + (size_t)j * N] = k;
+      K[j + (size_t)i * N] = k;
+    }
+    K[i + (size_t)i * N] = orc_kern_diag_element(ks, X, N, i, D);
+  }
+}
+
+/* CKern::compute(K, X, X2), CKern.h:146-157 */
+void orc_gram_cross(const orc_kspec* ks, const double* X, long N, const double* X2, long N2, long D, double* K)
+{
+  long i, j;
+  for(i = 0; i < N; i++)
+    for(j = 0; j < N2; j++) K[i + (size_t)j * N] = orc_kern_element(ks, X, N, i, X2, N2, j, D);
+}
+
+/* CKern::diagCompute, CKern.h:49-55 */
+void orc_gram_diag(const orc_kspec* ks, const double* X, long N, long D, double* d)
+{
+  long i;
+  for(i = 0; i < N; i++) d[i] = orc_kern_diag_element(ks, X, N, i, D);
+}
+
+/* CCmpndKern::getGradParams(g, X, covGrad), CKern.cpp:284-298, over the components' own loops */
+void orc_kern_grad_sym(const orc_kspec* ks, const double* X, long N, long D, const double* cg, double* g)
+{
+#define CG(i, j) cg[(i) + (size_t)(j) * N]
+  int t;
+  long i, j, q;
+  for(t = 0; t < ks->n_terms; t++) {
+    const double* p = ks->params + ks->offs[t];
+    double* gt = g + ks->offs[t];
+    switch(ks->types[t]) {
+    case ORC_KERN_RBF: { /* CRbfKern::getGradParams, CKern.cpp:1204-1241 */
+      double g1 = 0.0, g2 = 0.0;
+      const double halfIw = 0.5 * p[0], halfVar = 0.5 * p[1];
+      for(j = 0; j < N; j++) {
+        g2 += CG(j, j);
+        for(i = 0; i < j; i++) {
+          const double dist2 = orc_dist2_row(X, N, i, X, N, j, D);
+          const double k = exp(-dist2 * halfIw);
+          const double kcg = k * CG(i, j);
+          g1 -= 2.0 * halfVar * dist2 * kcg;
+          g2 += 2.0 * kcg;
+        }
+      }
+      gt[0] = g1;
+      gt[1] = g2;
+      break;
+    }
+    case ORC_KERN_RBFARD: { /* CRbfardKern::getGradParams, CKern.cpp:3359-3403 */
+      double g1 = 0.0, g2 = 0.0;
+      const double halfIw = 0.5 * p[0];
+      for(q = 0; q < D; q++) gt[2 + q] = 0.0;
+      for(i = 0; i < N; i++) {
+        for(j = 0; j < i; j++) {
+          double val = 0.0, kcg;
+          for(q = 0; q < D; q++) {
+            double x = X[i + q * N];
+            x -= X[j + q * N];
+            val += x * p[2 + q] * x;
+          }
+          kcg = exp(-halfIw * val) * CG(i, j);
+          g1 -= 0.5 * val * kcg * p[1];
+          g2 += kcg;
+          for(q = 0; q < D; q++) {
+            const double xi = X[i + q * N], xj = X[j + q * N];
+            gt[2 + q] += p[0] * kcg * (xi * xj - .5 * xi * xi - .5 * xj * xj) * p[1];
+          }
+        }
+      }
+      g1 *= 2.0;
+      g2 *= 2.0;
+      for(i = 0; i < N; i++) g2 += CG(i, i);
+      for(q = 0; q < D; q++) gt[2 + q] *= 2.0;
+      gt[0] = g1;
+      gt[1] = g2;
+      break;
+    }
+    case ORC_KERN_WHITE: { /* trace(covGrad), CKern.cpp:735-739 */
+      double s = 0.0;
+      for(i = 0; i < N; i++) s += CG(i, i);
+      gt[0] = s;
+      break;
+    }
+    case ORC_KERN_BIAS: { /* covGrad.sum(), CKern.cpp:1020-1024 */
+      double s = 0.0;
+      for(j = 0; j < N; j++)
+        for(i = 0; i < N; i++) s += CG(i, j);
+      gt[0] = s;
+      break;
+    }
+    case ORC_KERN_LIN: { /* CKern.cpp:2369-2383 */
+      double s = 0.0;
+      for(i = 0; i < N; i++)
+        for(j = 0; j < N; j++) s += dot(D, X + j, N, X + i, N) * CG(i, j);
+      gt[0] = s;
+      break;
+    }
+    default: break;
+    }
+  }
+#undef CG
+}
+
+/* CCmpndKern::getGradParams(g, X, X2, covGrad): rbf CKern.cpp:1175-1202, rbfard 3318-3357, white 730-734,
+ * bias 1015-1019, lin 2354-2368 */
+void orc_kern_grad_cross(const orc_kspec* ks, const double* X, long N, const double* X2, long N2, long D,
+                         const double* cg, double* g)
+{
+#define CG(i, j) cg[(i) + (size_t)(j) * N]
+  int t;
+  long i, j, q;
+  for(t = 0; t < ks->n_terms; t++) {
+    const double* p = ks->params + ks->offs[t];
+    double* gt = g + ks->offs[t];
+    switch(ks->types[t]) {
+    case ORC_KERN_RBF: {
+      double g1 = 0.0, g2 = 0.0;
+      for(j = 0; j < N; j++)
+        for(i = 0; i < N2; i++) {
+          const double dist2 = orc_dist2_row(X2, N2, i, X, N, j, D);
+          const double kcg = exp(-dist2 * 0.5 * p[0]) * CG(j, i);
+          g1 -= 0.5 * p[1] * dist2 * kcg;
+          g2 += kcg;
+        }
+      gt[0] = g1;
+      gt[1] = g2;
+      break;
+    }
+    case ORC_KERN_RBFARD: {
+      double g1 = 0.0, g2 = 0.0;
+      for(q = 0; q < D; q++) gt[2 + q] = 0.0;
+      for(i = 0; i < N; i++)
+        for(j = 0; j < N2; j++) {
+          double val = 0.0, kcg;
+          for(q = 0; q < D; q++) {
+            double x = X[i + q * N];
+            x -= X2[j + q * N2];
+            val += x * p[2 + q] * x;
+          }
+          kcg = exp(-0.5 * p[0] * val) * CG(i, j);
+          g1 -= 0.5 * val * kcg * p[1];
+          g2 += kcg;
+          for(q = 0; q < D; q++) {
+            const double xi = X[i + q * N], xj = X2[j + q * N2];
+            gt[2 + q] += p[0] * kcg * (xi * xj - .5 * xi * xi - .5 * xj * xj) * p[1];
+          }
+        }
+      gt[0] = g1;
+      gt[1] = g2;
+      break;
+    }
+    case ORC_KERN_WHITE: gt[0] = 0.0; break;
+    case ORC_KERN_BIAS: {
+      double s = 0.0;
+      for(j = 0; j < N2; j++)
+        for(i = 0; i < N; i++) s += CG(i, j);
+      gt[0] = s;
+      break;
+    }
+    case ORC_KERN_LIN: {
+      double s = 0.0;
+      for(i = 0; i < N; i++)
+        for(j = 0; j < N2; j++) s += dot(D, X2 + j, N2, X + i, N) * CG(i, j);
+      gt[0] = s;
+      break;
+    }
+    default: break;
+    }
+  }
+#undef CG
+}
+
+/* transform kind of parameter q of term type: rbfard input scales are sigmoid (CKern.cpp:3214-3217), all other
+ * parameters of the in-scope kernels are exp ("defaultPositive"). */
+static int is_sigmoid(int type, int q) { return type == ORC_KERN_RBFARD && q >= 2; }
+
+/* CKern::getGradTransParams, CKern.cpp:50-63, with CExpTransform::gradfact = x and CSigmoidTransform::gradfact =
+ * x(1-x) (CTransform.cpp:50-53, 109-112) */
+void orc_grad_to_trans(const orc_kspec* ks, long D, double* g)
+{
+  int t, q;
+  (void)D;
+  for(t = 0; t < ks->n_terms; t++)
+    for(q = 0; q < ks->offs[t + 1] - ks->offs[t]; q++) {
+      const double x = ks->params[ks->offs[t] + q];
+      g[ks->offs[t] + q] *= is_sigmoid(ks->types[t], q) ? x * (1.0 - x) : x;
+    }
+}
+
+/* CTransformable::getTransParams via xtoa: log(x) (CTransform.cpp:44-49) / invSigmoid (CTransform.cpp:106-108) */
+void orc_trans_params(const orc_kspec* ks, long D, double* a)
+{
+  int t, q;
+  (void)D;
+  for(t = 0; t < ks->n_terms; t++)
+    for(q = 0; q < ks->offs[t + 1] - ks->offs[t]; q++) {
+      const double x = ks->params[ks->offs[t] + q];
+      a[ks->offs[t] + q] = is_sigmoid(ks->types[t], q) ? log(x / (1.0 - x)) : log(x);
+    }
+}
+
+/* ---- CGp (FTC) --------------------------------------------------------------------------------------------------------- */
+
+orc_gp* orc_gp_create(const orc_kspec* ks, const double* X, long N, long D, const double* y, long d,
+                      const double* scale, const double* bias)
+{
+  long i, j;
+  orc_gp* gp = (orc_gp*)calloc(1, sizeof(orc_gp));
+  gp->N = N;
+  gp->D = D;
+  gp->d = d;
+  gp->ks = *ks;
+  gp->X = X;
+  gp->m = (double*)malloc(sizeof(double) * (size_t)N * d);
+  gp->scale = (double*)malloc(sizeof(double) * d);
+  gp->bias = (double*)malloc(sizeof(double) * d);
+  gp->K = (double*)malloc(sizeof(double) * (size_t)N * N);       /* CGp::initStoreage, CGp.cpp:171-175 */
+  gp->L = (double*)malloc(sizeof(double) * (size_t)N * N);
+  gp->invK = (double*)malloc(sizeof(double) * (size_t)N * N);
+  gp->covGrad = (double*)malloc(sizeof(double) * (size_t)N * N);
+  gp->Alpha = (double*)malloc(sizeof(double) * (size_t)N * d);
+  for(j = 0; j < d; j++) {
+    gp->scale[j] = scale ? scale[j] : 1.0;
+    if(bias) {
+      gp->bias[j] = bias[j];
+    } else { /* gp.cpp:384-385: bias = meanCol(y) */
+      double s = 0.0;
+      for(i = 0; i < N; i++) s += y[i + (size_t)j * N];
+      gp->bias[j] = s / (double)N;
+    }
+    /* CGp::updateM, CGp.cpp:248-260 */
+    for(i = 0; i < N; i++) gp->m[i + (size_t)j * N] = (y[i + (size_t)j * N] - gp->bias[j]) / gp->scale[j];
+  }
+  return gp;
+}
+
+void orc_gp_free(orc_gp* gp)
+{
+  if(!gp) return;
+  free(gp->m);
+  free(gp->scale);
+  free(gp->bias);
+  free(gp->K);
+  free(gp->L);
+  free(gp->invK);
+  free(gp->covGrad);
+  free(gp->Alpha);
+  free(gp);
+}
+
+/* CGp::updateK, CGp.cpp:682-691: _updateK (698-712) then _updateInvK FTC (881-891):
+ * jitChol -> logDet -> pdinv -> trans */
+int orc_gp_update_k(orc_gp* gp)
+{
+  const long N = gp->N;
+  orc_gram_sym(&gp->ks, gp->X, N, gp->D, gp->K);
+  gp->jitter = orc_jitchol(N, gp->K, gp->L, 20, &gp->info);
+  if(gp->info != 0) return gp->info;
+  gp->logDetK = orc_logdet(N, gp->L, N);
+  orc_pdinv_upper(N, gp->L, gp->invK);
+  orc_trans(N, gp->L); /* LcholK.trans(): now lower */
+  return 0;
+}
+
+/* CGp::updateAlpha FTC, CGp.cpp:469-489 */
+void orc_gp_update_alpha(orc_gp* gp)
+{
+  memcpy(gp->Alpha, gp->m, sizeof(double) * (size_t)gp->N * gp->d);
+  orc_trsm('l', 'l', 'n', 'n', gp->N, gp->d, 1.0, gp->L, gp->N, gp->Alpha, gp->N);
+  orc_trsm('l', 'l', 't', 'n', gp->N, gp->d, 1.0, gp->L, gp->N, gp->Alpha, gp->N);
+}
+
+/* CGp::logLikelihood FTC, CGp.cpp:913-938 and 1002-1013 (K must be up to date) */
+double orc_gp_loglik(orc_gp* gp)
+{
+  const long N = gp->N;
+  long j;
+  double L = 0.0;
+  double* invKm = (double*)malloc(sizeof(double) * N);
+  for(j = 0; j < gp->d; j++) {
+    orc_symv_upper(N, gp->invK, gp->m + (size_t)j * N, invKm);
+    L += dot(N, invKm, 1, gp->m + (size_t)j * N, 1);
+    L += gp->logDetK;
+  }
+  free(invKm);
+  L *= -0.5;
+  L -= (double)gp->d * (double)N * HALFLOGTWOPI;
+  return L;
+}
+
+/* CGp::logLikelihoodGradient / updateG FTC, CGp.cpp:1016-1079, 1080-1117; updateCovGradient 666-679 */
+double orc_gp_loglik_grad(orc_gp* gp, double* g)
+{
+  const long N = gp->N;
+  const int np = gp->ks.offs[gp->ks.n_terms];
+  long i, j, c;
+  int q;
+  double* invKm = (double*)malloc(sizeof(double) * N);
+  double* tmp = (double*)malloc(sizeof(double) * (np > 0 ? np : 1));
+  for(q = 0; q < np; q++) g[q] = 0.0;
+  for(j = 0; j < gp->d; j++) {
+    orc_symv_upper(N, gp->invK, gp->m + (size_t)j * N, invKm);
+    /* covGrad = invK; syr(invKm, -1, "u") + copySymmetric (CMatrix.h:526-533); scale(-0.5) */
+    for(c = 0; c < N; c++)
+      for(i = 0; i <= c; i++) {
+        const double v = -0.5 * (gp->invK[i + (size_t)c * N] - invKm[i] * invKm[c]);
+        gp->covGrad[i + (size_t)c * N] = v;
+        gp->covGrad[c + (size_t)i * N] = v;
+      }
+    orc_kern_grad_sym(&gp->ks, gp->X, N, gp->D, gp->covGrad, tmp);
+    orc_grad_to_trans(&gp->ks, gp->D, tmp);
+    for(q = 0; q < np; q++) g[q] += tmp[q];
+  }
+  free(invKm);
+  free(tmp);
+  return orc_gp_loglik(gp);
+}
+
+/* CGp::posteriorMeanVar FTC, CGp.cpp:642-663 -> _testComputeKx 540-547, _posteriorMean 548-574,
+ * _posteriorVar 575-625 */
+void orc_gp_posterior(orc_gp* gp, const double* Xs, long Ns, double* mu, double* var)
+{
+  const long N = gp->N;
+  long i, j;
+  double* kX = (double*)malloc(sizeof(double) * (size_t)N * Ns);
+  orc_gram_cross(&gp->ks, gp->X, N, Xs, Ns, gp->D, kX);
+  for(i = 0; i < Ns; i++)
+    for(j = 0; j < gp->d; j++) {
+      double v = dot(N, gp->Alpha + (size_t)j * N, 1, kX + (size_t)i * N, 1);
+      if(gp->scale[j] != 1.0) v *= gp->scale[j];
+      if(gp->bias[j] != 0.0) v += gp->bias[j];
+      mu[i + (size_t)j * Ns] = v;
+    }
+  orc_trsm('L', 'L', 'N', 'N', N, Ns, 1.0, gp->L, N, kX, N);
+  for(i = 0; i < Ns; i++) {
+    const double n = nrm2(N, kX + (size_t)i * N, 1); /* norm2Col = dnrm2^2, CMatrix.h:601-608 */
+    const double vs = orc_kern_diag_element(&gp->ks, Xs, Ns, i, gp->D) - n * n;
+    for(j = 0; j < gp->d; j++) {
+      double v = vs;
+      if(gp->scale[j] != 1.0) v *= gp->scale[j] * gp->scale[j];
+      var[i + (size_t)j * Ns] = v;
+    }
+  }
+  free(kX);
+}

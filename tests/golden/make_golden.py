@@ -35,6 +35,9 @@ def save(name, **arrays):
 def kern_fixture(matname, types, outname):
     """<type>KernTest.mat (testKern.cpp:190-304): X, X2, transformed params, covGrads -> K2, K4, k2, g2, g4."""
     m = sio.loadmat(os.path.join(MAT, matname + ".mat"))
+    for k in ("K2", "K4", "k2"):          # whiteKernTest.mat stores K2 / K4 as MATLAB sparse matrices
+        if hasattr(m[k], "toarray"):
+            m[k] = m[k].toarray()
     arrays = {"kern_types": [refrun.KERN_CODES[t] for t in types], "kern_trans_params": m["params"],
               "X": m["X"], "X2": m["X2"], "covGrad": m["covGrad"], "covGrad2": m["covGrad2"]}
     ref = refrun.run_ref("kern", arrays)
