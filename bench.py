@@ -128,8 +128,9 @@ def main():
     gram_n, gram_ms, gram_bytes = prof(1)
 
     if rank == 0:
-        probe = ctypes.c_double(0.0)
-        api.check(api.lib().gpc_probe_mfma_f64(ctypes.byref(probe), api.stream()))
+        probe, pcyc, pclk = ctypes.c_double(0.0), ctypes.c_double(0.0), ctypes.c_double(0.0)
+        api.check(api.lib().gpc_probe_mfma_f64(ctypes.byref(probe), ctypes.byref(pcyc), ctypes.byref(pclk),
+                                               api.stream()))
         achieved = syrk_flops / (syrk_ms * 1e-3) * 1e-12 if syrk_ms > 0 else 0.0
         potrf_flops = N ** 3 / 3.0
         roof = {"bound": "mfma", "kernel": "gemm_f64_kernel (trailing SYRK of gpc_potrf_f64)",
@@ -138,7 +139,8 @@ def main():
                 "launches_per_step": syrk_n / max(1, args.steps),
                 "avg_launch_ms": syrk_ms / max(1, syrk_n),
                 "algorithmic_flops_per_launch": syrk_flops / max(1, syrk_n),
-                "mfma_f64_probe_tflops": probe.value,
+                "mfma_f64_probe_tflops": probe.value, "mfma_f64_probe_cycles_per_mfma": pcyc.value,
+                "mfma_f64_probe_clock_ghz": pclk.value,
                 "whole_factor_tflops": potrf_flops * args.steps / dt * 1e-12,
                 "gram": {"bound": "hbm", "achieved": gram_bytes / (gram_ms * 1e-3) * 1e-9 if gram_ms > 0 else 0.0,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "avg_launch_ms": gram_ms / max(1, gram_n)}}

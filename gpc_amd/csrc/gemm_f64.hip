@@ -21,8 +21,11 @@
 //     8 + 8 operand panels in its private L2.  Triangular (SYRK) launches enumerate lower super-tiles only.
 #include "gpc_common.hpp"
 #include <math.h>
+#include <stdlib.h>
 
 namespace gpc {
+
+int g_gemm_variant = -1;  // -1: read GPC_GEMM_VARIANT on first use; 0 generic only; 1 fast 4-wave; 2 fast 8-wave
 
 namespace {
 
@@ -45,6 +48,7 @@ struct GemmArgs {
   double alpha, beta;
   int tiles_m, tiles_n;
   int super_m, super_n;  // super-tile counts
+  int debug_same_rows;   // ablation knob (env GPC_GEMM_DEBUG_SAMEROWS): never set in production
   int tri;               // 0 full, 1 lower (i >= j, C square), 2 upper (i <= j, C square),
                          // 3 lower trapezoid (i >= j, M >= N, full enumeration with skipped tiles)
 };
@@ -132,30 +136,50 @@ __device__ __forceinline__ bool map_tile(const GemmArgs& g, int& ti, int& tj)
   const unsigned nb = gridDim.x;  // multiple of 8
   const unsigned b = blockIdx.x;
   const unsigned L = (b & 7u) * (nb >> 3) + (b >> 3);
-  const unsigned s = L / (SUPER * SUPER);
-  const unsigned w = L % (SUPER * SUPER);
-  int si, sj;
+  int si, sj, di, dj;
   if(g.tri == 0 || g.tri == 3) {
+    const unsigned s = L / (SUPER * SUPER);
+    const unsigned w = L % (SUPER * SUPER);
     if(s >= (unsigned)(g.super_m * g.super_n)) return false;
     si = s % g.super_m;
     sj = s / g.super_m;
+    di = (int)(w % SUPER);
+    dj = (int)(w / SUPER);
   } else {
-    // triangular numbering over super-tile rows: s = si*(si+1)/2 + sj, sj <= si
-    const unsigned total = (unsigned)g.super_m * (unsigned)(g.super_m + 1) / 2;
-    if(s >= total) return false;
-    int r = (int)((sqrt(8.0 * (double)s + 1.0) - 1.0) * 0.5);
-    while((unsigned)(r + 1) * (unsigned)(r + 2) / 2 <= s) r++;
-    while((unsigned)r * (unsigned)(r + 1) / 2 > s) r--;
+    // Compact enumeration of the VALID lower tiles so that every XCD chunk holds the same number of real tiles:
+    // super-tile row r holds r full super-tiles (64 tiles each) and one diagonal super-tile (36 lower tiles);
+    // tiles before row r: cum(r) = 32 r^2 + 4 r.
+    const unsigned S = (unsigned)g.super_m;
+    if(L >= 32u * S * S + 4u * S) return false;
+    int r = (int)((sqrt(16.0 + 128.0 * (double)L) - 4.0) * (1.0 / 64.0));
+    while(32u * (unsigned)(r + 1) * (unsigned)(r + 1) + 4u * (unsigned)(r + 1) <= L) r++;
+    while(32u * (unsigned)r * (unsigned)r + 4u * (unsigned)r > L) r--;
+    const unsigned rem = L - (32u * (unsigned)r * (unsigned)r + 4u * (unsigned)r);
     si = r;
-    sj = (int)(s - (unsigned)r * (unsigned)(r + 1) / 2);
+    if(rem < 64u * (unsigned)r) {
+      sj = (int)(rem >> 6);
+      di = (int)(rem & 7u);
+      dj = (int)((rem >> 3) & 7u);
+    } else {
+      const unsigned q = rem - 64u * (unsigned)r;  // 0..35: triangular inside the diagonal super-tile
+      sj = r;
+      int a = (int)((sqrt(8.0 * (double)q + 1.0) - 1.0) * 0.5);
+      while((unsigned)(a + 1) * (unsigned)(a + 2) / 2 <= q) a++;
+      while((unsigned)a * (unsigned)(a + 1) / 2 > q) a--;
+      di = a;
+      dj = (int)(q - (unsigned)a * (unsigned)(a + 1) / 2);
+    }
     if(g.tri == 2) {  // upper: swap roles
       int tmp = si;
       si = sj;
       sj = tmp;
+      tmp = di;
+      di = dj;
+      dj = tmp;
     }
   }
-  ti = si * SUPER + (int)(w % SUPER);
-  tj = sj * SUPER + (int)(w / SUPER);
+  ti = si * SUPER + di;
+  tj = sj * SUPER + dj;
   if(ti >= g.tiles_m || tj >= g.tiles_n) return false;
   if((g.tri == 1 || g.tri == 3) && tj > ti) return false;
   if(g.tri == 2 && tj < ti) return false;
@@ -254,6 +278,153 @@ __global__ void __launch_bounds__(256, 2) gemm_f64_kernel(const GemmArgs g)
   }
 }
 
+// ---- fast path: C := alpha * A * B' + beta * C with both operands contiguous along their row index (the SYRK /
+// panel-solve / trapezoid shapes of the Cholesky), K % 16 == 0, even leading dimensions, 16-byte aligned bases.
+//   * branch-free staging: per-thread operand pointers are computed once and advanced by a constant per stage; edge
+//     tiles clamp their row index instead of predicating (stores are masked), so the loop body has no control flow;
+//   * the next stage's global loads are issued after the first 16 MFMAs of the current stage, i.e. in the shadow of a
+//     busy matrix pipe, and land ~3000 cycles before the ds_write that consumes them;
+//   * NWN = 2: 4 waves, 64 x 64 per wave (2 waves/SIMD with two workgroups per CU);
+//     NWN = 4: 8 waves, 64 x 32 per wave (<= 128 VGPRs -> 4 waves/SIMD).
+template <int NWN>
+__global__ void __launch_bounds__(128 * NWN, NWN) gemm_nt_fast_kernel(const GemmArgs g)
+{
+  constexpr int NT = 256 / (64 * NWN) * 2;  // n-subtiles per wave: NWN=2 -> 4, NWN=4 -> 2
+  constexpr int NL = 8 / (2 * NWN);         // double2 loads per operand per thread per stage: 2 or 1... see below
+  static_assert(NWN == 2 || NWN == 4, "wave grid");
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  int ti, tj;
+  if(!map_tile(g, ti, tj)) return;
+  constexpr int NTHREADS = 128 * NWN;
+  constexpr int KROWS = NTHREADS / 64;      // k rows covered per pass: 4 or 8
+  constexpr int PASSES = BK / KROWS;        // 4 or 2
+  (void)NL;
+
+  const int t = threadIdx.x;
+  const int lane = t & 63;
+  const int wave = t >> 6;
+  const int wm = wave & 1;
+  const int wn = wave >> 1;  // 0..NWN-1
+  const int64_t m0 = (int64_t)ti * BM;
+  const int64_t n0 = (int64_t)tj * BN;
+
+  // staging pointers (rows clamped into the matrix; M, N are even and >= 2 on this path)
+  int64_t ra = m0 + 2 * lane, rb = n0 + 2 * lane;
+  if(g.debug_same_rows) {  // ablation: every tile reads operand rows 0..127 (all L2 hits); results are wrong
+    ra = 2 * lane;
+    rb = 2 * lane;
+  }
+  if(ra > g.M - 2) ra = g.M - 2;
+  if(rb > g.N - 2) rb = g.N - 2;
+  const double* pa = g.A + ra + (int64_t)(t >> 6) * g.lda;
+  const double* pb = g.B + rb + (int64_t)(t >> 6) * g.ldb;
+  const int64_t stepa = (int64_t)KROWS * g.lda, stepb = (int64_t)KROWS * g.ldb;
+  const int64_t stagea = (int64_t)BK * g.lda, stageb = (int64_t)BK * g.ldb;
+  const int lds_w = (t >> 6) * STRIDE_MC + 2 * lane;  // [k][m] image, k = (t>>6) + KROWS*i
+
+  double4_t acc[4][NT];
+#pragma unroll
+  for(int i = 0; i < 4; i++)
+#pragma unroll
+    for(int j = 0; j < NT; j++) acc[i][j] = (double4_t){0.0, 0.0, 0.0, 0.0};
+
+  const int64_t KT = g.K / BK;
+  double2_t ra_[PASSES], rb_[PASSES];
+  if(KT > 0) {
+#pragma unroll
+    for(int i = 0; i < PASSES; i++) {
+      ra_[i] = *reinterpret_cast<const double2_t*>(pa + i * stepa);
+      rb_[i] = *reinterpret_cast<const double2_t*>(pb + i * stepb);
+    }
+#pragma unroll
+    for(int i = 0; i < PASSES; i++) {
+      *reinterpret_cast<double2_t*>(lds + lds_w + i * KROWS * STRIDE_MC) = ra_[i];
+      *reinterpret_cast<double2_t*>(lds + OP_ELEMS + lds_w + i * KROWS * STRIDE_MC) = rb_[i];
+    }
+  }
+  __syncthreads();
+
+  const int fa = wm * 64 + (lane & 15) + (lane >> 4) * STRIDE_MC;               // + s*16 + kk*4*STRIDE_MC
+  const int fb = wn * (16 * NT) + (lane & 15) + (lane >> 4) * STRIDE_MC;
+
+  for(int64_t kt = 0; kt < KT; kt++) {
+    const double* As = lds + (kt & 1) * STAGE_ELEMS;
+    const double* Bs = As + OP_ELEMS;
+    double* nxt = lds + ((kt + 1) & 1) * STAGE_ELEMS;
+    const bool more = (kt + 1 < KT);
+#pragma unroll
+    for(int kk = 0; kk < 4; kk++) {
+      double a[4], b[NT];
+#pragma unroll
+      for(int s = 0; s < 4; s++) a[s] = As[fa + s * 16 + kk * 4 * STRIDE_MC];
+#pragma unroll
+      for(int s = 0; s < NT; s++) b[s] = Bs[fb + s * 16 + kk * 4 * STRIDE_MC];
+#pragma unroll
+      for(int tn = 0; tn < NT; tn++)
+#pragma unroll
+        for(int tm = 0; tm < 4; tm++)
+          acc[tm][tn] = __builtin_amdgcn_mfma_f64_16x16x4f64(b[tn], a[tm], acc[tm][tn], 0, 0, 0);
+      if(kk == 0 && more) {
+        // issue the next stage's loads behind the first MFMA group
+        pa += stagea;
+        pb += stageb;
+#pragma unroll
+        for(int i = 0; i < PASSES; i++) {
+          ra_[i] = *reinterpret_cast<const double2_t*>(pa + i * stepa);
+          rb_[i] = *reinterpret_cast<const double2_t*>(pb + i * stepb);
+        }
+      }
+    }
+    if(more) {
+#pragma unroll
+      for(int i = 0; i < PASSES; i++) {
+        *reinterpret_cast<double2_t*>(nxt + lds_w + i * KROWS * STRIDE_MC) = ra_[i];
+        *reinterpret_cast<double2_t*>(nxt + OP_ELEMS + lds_w + i * KROWS * STRIDE_MC) = rb_[i];
+      }
+    }
+    __syncthreads();
+  }
+
+  const double alpha = g.alpha, beta = g.beta;
+  const bool full_mn = (m0 + BM <= g.M) && (n0 + BN <= g.N);
+  const bool diag_tile = (g.tri != 0) && (ti == tj);
+#pragma unroll
+  for(int tn = 0; tn < NT; tn++) {
+#pragma unroll
+    for(int tm = 0; tm < 4; tm++) {
+      const int64_t m = m0 + wm * 64 + tm * 16 + (lane & 15);
+#pragma unroll
+      for(int r = 0; r < 4; r++) {
+        const int64_t n = n0 + wn * (16 * NT) + tn * 16 + (lane >> 4) + 4 * r;
+        bool ok = full_mn || (m < g.M && n < g.N);
+        if(diag_tile) ok = ok && (g.tri == 2 ? (m <= n) : (m >= n));
+        if(ok) {
+          double* p = g.C + m + n * g.ldc;
+          double v = alpha * acc[tm][tn][r];
+          if(beta != 0.0) v += beta * (*p);
+          *p = v;
+        }
+      }
+    }
+  }
+}
+
+
+template <int NWN>
+int launch_fast(const GemmArgs& g, unsigned grid, hipStream_t s)
+{
+  static bool attr_set = false;
+  auto kern = gemm_nt_fast_kernel<NWN>;
+  if(!attr_set) {
+    GPC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(128 * NWN), GEMM_LDS_BYTES, s, g);
+  GPC_HIP_CHECK(hipGetLastError());
+  return GPC_OK;
+}
+
 template <bool A_KC, bool B_KC, bool VEC>
 int launch(const GemmArgs& g, unsigned grid, hipStream_t s)
 {
@@ -292,6 +463,11 @@ int gemm(bool transa, bool transb, int64_t M, int64_t N, int64_t K, double alpha
   g.super_m = (g.tiles_m + SUPER - 1) / SUPER;
   g.super_n = (g.tiles_n + SUPER - 1) / SUPER;
   g.tri = tri;
+  {
+    static int dbg = -1;
+    if(dbg < 0) dbg = getenv("GPC_GEMM_DEBUG_SAMEROWS") ? 1 : 0;
+    g.debug_same_rows = dbg;
+  }
   if((tri == 1 || tri == 2) && M != N) {
     set_error("triangular gemm needs a square C");
     return GPC_EINVAL;
@@ -304,7 +480,7 @@ int gemm(bool transa, bool transb, int64_t M, int64_t N, int64_t K, double alpha
   if(tri == 0 || tri == 3)
     slots = (uint64_t)g.super_m * g.super_n * SUPER * SUPER;
   else
-    slots = (uint64_t)g.super_m * (g.super_m + 1) / 2 * SUPER * SUPER;
+    slots = 32ull * g.super_m * g.super_m + 4ull * g.super_m;  // valid lower tiles of full 8 x 8 super-tiles
   slots = (slots + 7) & ~7ull;
   if(slots > 0x7fffffffull) {
     set_error("gemm grid too large");
@@ -316,7 +492,15 @@ int gemm(bool transa, bool transb, int64_t M, int64_t N, int64_t K, double alpha
   const bool vec = ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B)) & 15) == 0 &&
                    (lda % 2 == 0) && (ldb % 2 == 0);
   const unsigned grid = (unsigned)slots;
-#define GPC_GEMM_CASE(AK, BK_)                                           \
+  if(g_gemm_variant < 0) {
+    const char* e = getenv("GPC_GEMM_VARIANT");
+    g_gemm_variant = e ? atoi(e) : 2;
+    if(g_gemm_variant < 0 || g_gemm_variant > 2) g_gemm_variant = 2;
+  }
+  if(g_gemm_variant > 0 && !a_kc && !b_kc && vec && g.K > 0 && (g.K % BK) == 0 && (M % 2) == 0 && (N % 2) == 0) {
+    return g_gemm_variant == 2 ? launch_fast<4>(g, grid, s) : launch_fast<2>(g, grid, s);
+  }
+#define GPC_GEMM_CASE(AK, BK_)                                         \
   if(a_kc == AK && b_kc == BK_) {                                        \
     return vec ? launch<AK, BK_, true>(g, grid, s) : launch<AK, BK_, false>(g, grid, s); \
   }
@@ -329,3 +513,13 @@ int gemm(bool transa, bool transb, int64_t M, int64_t N, int64_t K, double alpha
 }
 
 }  // namespace gpc
+
+extern "C" int gpc_set_gemm_variant(int v)
+{
+  if(v < 0 || v > 2) {
+    gpc::set_error("gemm variant must be 0 (generic), 1 (fast, 4 waves) or 2 (fast, 8 waves)");
+    return GPC_EINVAL;
+  }
+  gpc::g_gemm_variant = v;
+  return GPC_OK;
+}

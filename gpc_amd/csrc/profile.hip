@@ -28,19 +28,30 @@ Rec take()
   return r;
 }
 
-// 4 independent accumulator chains per wave, 8 waves per CU-slot: pure issue-rate measurement
+// Pure issue-rate measurement: 8 independent accumulator chains per wave kept in VGPRs by inline asm (the builtin
+// form makes hipcc shuttle the loop-carried accumulators between VGPRs and AGPRs every iteration).  Thread 0 of
+// block 0 also reports shader cycles (s_memtime) for its own loop.
 __global__ void __launch_bounds__(256) mfma_f64_probe_kernel(double* out, int iters)
 {
-  double4_t c0 = {0, 0, 0, 0}, c1 = c0, c2 = c0, c3 = c0;
+  double4_t c0 = {0, 0, 0, 0}, c1 = c0, c2 = c0, c3 = c0, c4 = c0, c5 = c0, c6 = c0, c7 = c0;
   const double a = 1.0 + threadIdx.x * 1e-9, b = 1.0 - threadIdx.x * 1e-9;
+  const unsigned long long t0 = __builtin_readcyclecounter();
   for(int i = 0; i < iters; i++) {
-    c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c0, 0, 0, 0);
-    c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c1, 0, 0, 0);
-    c2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c2, 0, 0, 0);
-    c3 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c3, 0, 0, 0);
+    asm volatile("v_mfma_f64_16x16x4_f64 %0, %8, %9, %0\n"
+                 "v_mfma_f64_16x16x4_f64 %1, %8, %9, %1\n"
+                 "v_mfma_f64_16x16x4_f64 %2, %8, %9, %2\n"
+                 "v_mfma_f64_16x16x4_f64 %3, %8, %9, %3\n"
+                 "v_mfma_f64_16x16x4_f64 %4, %8, %9, %4\n"
+                 "v_mfma_f64_16x16x4_f64 %5, %8, %9, %5\n"
+                 "v_mfma_f64_16x16x4_f64 %6, %8, %9, %6\n"
+                 "v_mfma_f64_16x16x4_f64 %7, %8, %9, %7\n"
+                 : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3), "+v"(c4), "+v"(c5), "+v"(c6), "+v"(c7)
+                 : "v"(a), "v"(b));
   }
-  const double4_t s = c0 + c1 + c2 + c3;
-  if(s.x == 123.456) out[0] = s.x + s.y + s.z + s.w;  // keep the chain alive
+  const unsigned long long t1 = __builtin_readcyclecounter();
+  const double4_t s = c0 + c1 + c2 + c3 + c4 + c5 + c6 + c7;
+  if(s.x == 123.456) out[1] = s.x + s.y + s.z + s.w;  // keep the chains alive
+  if(blockIdx.x == 0 && threadIdx.x == 0) out[0] = (double)(t1 - t0);
 }
 }  // namespace
 
@@ -98,7 +109,7 @@ extern "C" int gpc_profile_read(int kind, int64_t* launches, double* total_ms, d
   return GPC_OK;
 }
 
-extern "C" int gpc_probe_mfma_f64(double* tflops, void* stream)
+extern "C" int gpc_probe_mfma_f64(double* tflops, double* cycles_per_mfma_per_simd, double* clock_ghz, void* stream)
 {
   GPC_CHECK(ensure_device());
   GPC_REQUIRE(tflops != nullptr, "null output");
@@ -109,7 +120,8 @@ extern "C" int gpc_probe_mfma_f64(double* tflops, void* stream)
   GPC_HIP_CHECK(hipGetDeviceProperties(&p, dev));
   void* ws = nullptr;
   GPC_CHECK(workspace(WS_REDUCE, 256, &ws));
-  const int blocks = p.multiProcessorCount * 2, iters = 20000;
+  const int waves_per_simd = 2;
+  const int blocks = p.multiProcessorCount * waves_per_simd, iters = 10000;
   hipEvent_t a, b;
   GPC_HIP_CHECK(hipEventCreate(&a));
   GPC_HIP_CHECK(hipEventCreate(&b));
@@ -122,7 +134,11 @@ extern "C" int gpc_probe_mfma_f64(double* tflops, void* stream)
   GPC_HIP_CHECK(hipEventElapsedTime(&ms, a, b));
   (void)hipEventDestroy(a);
   (void)hipEventDestroy(b);
-  const double flops = (double)blocks * 4.0 /*waves*/ * (double)iters * 4.0 /*mfma*/ * 2048.0;
+  const double flops = (double)blocks * 4.0 /*waves*/ * (double)iters * 8.0 /*mfma*/ * 2048.0;
   *tflops = flops / ((double)ms * 1e-3) * 1e-12;
+  double cyc = 0.0;
+  GPC_HIP_CHECK(hipMemcpy(&cyc, ws, sizeof(double), hipMemcpyDeviceToHost));
+  if(cycles_per_mfma_per_simd) *cycles_per_mfma_per_simd = cyc / ((double)iters * 8.0 * (double)waves_per_simd);
+  if(clock_ghz) *clock_ghz = cyc / ((double)ms * 1e-3) * 1e-9;
   return GPC_OK;
 }

@@ -182,11 +182,14 @@ int gpc_gp_posterior_f64(const gpc_kspec* ks, const double* X, int64_t N, int64_
 int gpc_profile_enable(int on);
 int gpc_profile_read(int kind, int64_t* launches, double* total_ms, double* algorithmic_work, int reset);
 /* Pure-MFMA fp64 micro-benchmark (v_mfma_f64_16x16x4_f64 issue rate on every SIMD): the measured ceiling the
- * roofline fraction is quoted against next to the datasheet peak. */
-int gpc_probe_mfma_f64(double* tflops, void* stream);
+ * roofline fraction is quoted against next to the datasheet peak.  Also returns the shader cycles per MFMA per SIMD
+ * (s_memtime) and the effective shader clock during the probe; either pointer may be NULL. */
+int gpc_probe_mfma_f64(double* tflops, double* cycles_per_mfma_per_simd, double* clock_ghz, void* stream);
 
 /* ---- tuning knobs (also read from env GPC_NB / GPC_JB on first use) ---------------------------------------------- */
 int gpc_set_potrf_blocking(int64_t nb_outer, int64_t jb_inner);
+/* GEMM kernel variant for the A*B^T shapes: 0 generic, 1 fast 4-wave, 2 fast 8-wave (default; env GPC_GEMM_VARIANT). */
+int gpc_set_gemm_variant(int variant);
 
 #ifdef __cplusplus
 }
