@@ -66,10 +66,6 @@ int zero_triangle(bool zero_lower, int64_t N, double* A, int64_t lda, hipStream_
 int add_diag(int64_t N, double* A, int64_t lda, double c, hipStream_t s);
 // sum over the diagonal of f(A(i,i)): what = 0 trace, 1 sum of log.  Result to a host double (synchronises).
 int diag_reduce(int what, int64_t N, const double* A, int64_t lda, double* out_host, hipStream_t s);
-// Invert the jb x jb diagonal blocks of a triangular matrix (order N) into `inv` (block b at inv + b*jb*jb,
-// leading dimension jb, other triangle zero).  unit: treat the diagonal as ones.
-int invert_diag_blocks(bool lower, bool unit, int64_t N, int64_t jb, const double* A, int64_t lda, double* inv,
-                       hipStream_t s);
 
 // device-side kernel spec: terms collapsed into what a Gram element needs
 struct KSpecDev {

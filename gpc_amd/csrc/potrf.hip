@@ -3,177 +3,233 @@
 // Replaces dpotrf_ as called by CMatrix::potrf / chol / jitChol (CMatrix.cpp:371-403, 767-804; lapack.h:59-65).
 //
 // Structure:
-//   outer panels of NB columns (default 512): after a panel is final, ONE SYRK  A22 -= L21 * L21'  of depth NB runs on
-//   the fp64 MFMA tiles of gemm_f64.hip -- this is where N^3/3 of the flops go, and a deep k keeps the read+write of
-//   A22 (8 N^2 bytes per panel) at NB/8 flop per byte;
-//   inside a panel, JB = 64 columns at a time:
-//     1. potf2_inv_kernel: one workgroup holds the 64 x 64 diagonal block in LDS, factors it column by column
-//        (fp64 VALU, one barrier per column) and inverts the triangular factor by 16 x 16 blocks;
-//     2. the panel solve  L21 := A21 * L11^-T  is then a plain GEMM against the inverted block (MFMA, in place,
-//        every workgroup owns whole rows);
-//     3. the still-to-be-factored columns of the panel are updated with that 64-deep block column (lower trapezoid).
+//   outer panels of NB columns (default 512).  After panel k is final its trailing update A22 -= L21 * L21' (depth NB,
+//   fp64 MFMA tiles of gemm_f64.hip, N^3/3 of the flops) is split in two launches:
+//       U1(k): the NB columns that form panel k+1 (lower trapezoid),   U2(k): everything to the right of them.
+//   LOOK-AHEAD: U1/U2 run on the caller's stream, the panels on a second, high-priority stream; panel k+1 starts as
+//   soon as U1(k) is done and is factored while U2(k) keeps every CU busy.  The chain of small latency-bound panel
+//   kernels (N/64 diagonal blocks) therefore disappears behind the SYRK as long as U2 is longer than a panel.
+//   inside a panel, JB = 64 columns at a time, three launches:
+//     1. potf2_kernel: one workgroup, the 64 x 64 diagonal block lives in REGISTERS (thread = one row x 16 columns,
+//        rotated so that the active column group is always register slot 0: the loop stays rolled and the code small,
+//        which matters more than anything else for a one-shot latency-bound kernel -- a fully unrolled version spent
+//        its time on instruction-cache misses); per column one LDS broadcast of the pivot column and one barrier;
+//     2. panel_trsm_kernel: L21 := A21 * L11^-T by true substitution, one wave per 64 rows, the 64-vector of a row
+//        handled in 16-wide register blocks (16 x 16 triangular solve in registers, rank-16 updates against LDS);
+//     3. the still-to-be-factored columns of the panel are updated with that 64-deep block column (MFMA GEMM, lower
+//        trapezoid).
 //   A non-positive pivot writes the LAPACK `info` (1-based order of the failing minor) to a device word; later
 //   diagonal kernels turn into no-ops and the host reads the word once at the end.
 #include "gpc_common.hpp"
 #include <stdlib.h>
+#include <vector>
 
 namespace gpc {
 
 namespace {
 
 constexpr int JB = 64;
-constexpr int LDP = 65;  // padded leading dimension of the LDS images
 
 int64_t g_nb_outer = 0;
+int g_lookahead = -1;
 
-// W := inverse of the lower-triangular 64 x 64 matrix L (both LDS, leading dimension LDP); T is a 16 x 48 scratch.
-// All 256 threads of the workgroup call this.  Padding rows/cols of L must be identity.
-__device__ void tri_inverse_64(const double* __restrict__ L, double* __restrict__ W, double* __restrict__ T)
+// Factor the n x n (n <= 64) diagonal block at A (lower, in place).  col0 = global index of the block's first
+// column, for `info`.  Thread t owns row r = t & 63 and, at outer step jq, the columns c = 4 (q + jq) + g in register
+// slot q (g = t >> 6 = the wave index).
+__global__ void __launch_bounds__(256) potf2_kernel(double* __restrict__ A, int64_t lda, int n,
+                                                    int* __restrict__ info, int64_t col0)
 {
-  const int t = threadIdx.x;
-  for(int idx = t; idx < JB * LDP; idx += 256) W[idx] = 0.0;
-  __syncthreads();
-  // phase A: the four 16 x 16 diagonal blocks, one column per thread, forward substitution
-  if(t < 64) {
-    const int b = t >> 4, c = t & 15;
-    const int o = b * 16;
-    for(int i = c; i < 16; i++) {
-      double sum = (i == c) ? 1.0 : 0.0;
-      for(int k = c; k < i; k++) sum -= L[(o + i) + (o + k) * LDP] * W[(o + k) + (o + c) * LDP];
-      W[(o + i) + (o + c) * LDP] = sum / L[(o + i) + (o + i) * LDP];
-    }
-  }
-  __syncthreads();
-  // phase B: block rows 1..3:  W(bi,bj) = -W(bi,bi) * sum_{bk=bj}^{bi-1} L(bi,bk) * W(bk,bj)
-  const int r = t & 15, c = t >> 4;  // element inside a 16 x 16 block
-  for(int bi = 1; bi < 4; bi++) {
-    for(int bj = 0; bj < bi; bj++) {
-      double sum = 0.0;
-      for(int k = bj * 16; k < bi * 16; k++) sum += L[(bi * 16 + r) + k * LDP] * W[k + (bj * 16 + c) * LDP];
-      T[r + (bj * 16 + c) * 16] = sum;
-    }
-    __syncthreads();
-    for(int bj = 0; bj < bi; bj++) {
-      double sum = 0.0;
-      for(int k = 0; k <= r; k++) sum += W[(bi * 16 + r) + (bi * 16 + k) * LDP] * T[k + (bj * 16 + c) * 16];
-      W[(bi * 16 + r) + (bj * 16 + c) * LDP] = -sum;
-    }
-    __syncthreads();
-  }
-}
-
-// Factor the n x n (n <= 64) diagonal block at A (lower, in place) and write inv(L) (64 x 64, ld 64, zero-padded
-// identity) to `inv`.  col0 = global index of the block's first column, for `info`.
-__global__ void __launch_bounds__(256) potf2_inv_kernel(double* __restrict__ A, int64_t lda, int n,
-                                                        double* __restrict__ inv, int* __restrict__ info,
-                                                        int64_t col0)
-{
-  __shared__ double S[JB * LDP];
-  __shared__ double W[JB * LDP];
-  __shared__ double T[16 * 48];
+  __shared__ double col[2][JB];
+  __shared__ double Lout[JB * JB];
   const int t = threadIdx.x;
   if(*info != 0) return;  // an earlier block already failed: uniform exit
+  const int r = t & 63, g = t >> 6;
 
-  for(int idx = t; idx < JB * JB; idx += 256) {
-    const int i = idx & 63, j = idx >> 6;
+  double a[16];
+#pragma unroll
+  for(int q = 0; q < 16; q++) {
+    const int c = 4 * q + g;
     double v = 0.0;
-    if(i < n && j < n) {
-      if(i >= j) v = A[i + (int64_t)j * lda];
-    } else if(i == j) {
-      v = 1.0;
+    if(r < n && c < n) {
+      if(r >= c) v = A[r + (int64_t)c * lda];
+    } else if(r == c) {
+      v = 1.0;  // identity padding
     }
-    S[i + j * LDP] = v;
+    a[q] = v;
   }
-  __syncthreads();
 
-  const int il = t & 63, cg = t >> 6;
-  for(int j = 0; j < n; j++) {
-    const double ajj = S[j + j * LDP];
-    if(!(ajj > 0.0)) {  // also catches NaN; uniform across the workgroup
-      if(t == 0) atomicCAS(info, 0, (int)(col0 + j + 1));
-      return;
+#pragma unroll 1
+  for(int jq = 0; jq < 16; jq++) {
+#pragma unroll
+    for(int jj = 0; jj < 4; jj++) {
+      const int j = 4 * jq + jj;
+      if(g == jj) col[jj & 1][r] = a[0];  // publish column j (owned by wave jj, always in slot 0)
+      __syncthreads();
+      const double* cj = col[jj & 1];
+      const double pj = cj[j];
+      if(!(pj > 0.0)) {  // also catches NaN; uniform across the workgroup
+        if(t == 0) atomicCAS(info, 0, (int)(col0 + j + 1));
+        return;
+      }
+      const double cr = cj[r];
+      // the owner wave records the finished column: L(j,j) = sqrt(pivot), L(r,j) = a(r,j) / sqrt(pivot).  It goes to
+      // LDS, not to global memory: a global store inside this loop makes every barrier wait for its completion
+      // (~1 us per column).
+      const double d = sqrt(pj);
+      const double rs = 1.0 / d;            // one sqrt + one divide per column (both wave-uniform)
+      const double lr = cr * rs;            // L(r,j)
+      if(g == jj) Lout[j * JB + r] = (r == j) ? d : lr;
+      const double lrj = lr * rs;           // a(r,j) / pivot
+      // branch-free: unconditional (clamped) LDS reads issued together, the predicate applied by select.  With the
+      // reads inside 16 divergent `if`s every one of them became its own LDS round trip (4x slower kernel).
+      double cv[16];
+#pragma unroll
+      for(int q = 0; q < 16; q++) cv[q] = cj[(4 * (q + jq) + g) & 63];
+      // Slot q >= 1 holds a column right of j by construction, so it needs no predicate at all; slot 0 does only when
+      // its column is left of / equal to j (g <= jj).  Elements above the diagonal (c > r) and slots rotated past
+      // column 63 are updated with meaningless values: they are never read by any valid entry and never stored.
+      a[0] -= (g > jj) ? lrj * cv[0] : 0.0;
+#pragma unroll
+      for(int q = 1; q < 16; q++) a[q] -= lrj * cv[q];
+      // the next column uses the other half of `col`; its barrier orders that write after these reads
     }
-    const double rinv = 1.0 / ajj;
-    if(il > j && il < n) {
-      const double lij = S[il + j * LDP] * rinv;
-      for(int c = j + 1 + cg; c <= il; c += 4) S[il + c * LDP] -= lij * S[c + j * LDP];
-    }
-    __syncthreads();
-  }
-  // scale the columns: L(j,j) = sqrt(pivot), L(i,j) = S(i,j)/sqrt(pivot)
-  for(int idx = t; idx < JB * JB; idx += 256) {
-    const int i = idx & 63, j = idx >> 6;
-    if(i < n && j < n && i >= j) {
-      const double d = sqrt(S[j + j * LDP]);
-      const double v = (i == j) ? d : S[i + j * LDP] / d;
-      W[i + j * LDP] = v;  // stash; S(j,j) is still needed by other threads
-    }
+#pragma unroll
+    for(int q = 0; q < 15; q++) a[q] = a[q + 1];  // rotate: next column group into slot 0
   }
   __syncthreads();
-  for(int idx = t; idx < JB * JB; idx += 256) {
-    const int i = idx & 63, j = idx >> 6;
-    if(i < n && j < n && i >= j) {
-      const double v = W[i + j * LDP];
-      S[i + j * LDP] = v;
-      A[i + (int64_t)j * lda] = v;
-    }
-  }
-  __syncthreads();
-  tri_inverse_64(S, W, T);
-  for(int idx = t; idx < JB * JB; idx += 256) {
-    const int i = idx & 63, j = idx >> 6;
-    inv[i + j * JB] = W[i + j * LDP];
+#pragma unroll
+  for(int q = 0; q < 16; q++) {
+    const int c = 4 * q + g;
+    if(r < n && c < n && r >= c) A[r + (int64_t)c * lda] = Lout[c * JB + r];
   }
 }
 
-// Invert diagonal blocks of a triangular matrix (general trsm / potri support).  One workgroup per block.
-__global__ void __launch_bounds__(256) tri_inv_blocks_kernel(const double* __restrict__ A, int64_t lda, int64_t N,
-                                                             int lower, int unit, double* __restrict__ inv)
+// X := B * L^-T in place for B (M x n, n <= 64) and the lower-triangular n x n block L: one wave per 64 rows.
+// Row x solves  x L' = b  by forward substitution over 16-wide blocks held in registers.
+constexpr int LSTR = 66;  // row stride of the L image (even: 16-byte aligned broadcast reads)
+__global__ void __launch_bounds__(64) panel_trsm_kernel(const double* __restrict__ L, int64_t ldl, int n,
+                                                        double* __restrict__ B, int64_t ldb, int64_t M)
 {
-  __shared__ double S[JB * LDP];
-  __shared__ double W[JB * LDP];
-  __shared__ double T[16 * 48];
-  const int t = threadIdx.x;
-  const int64_t o = (int64_t)blockIdx.x * JB;
-  const int n = (int)((N - o) < JB ? (N - o) : JB);
-  const double* Ab = A + o + o * lda;
-  // Load as a LOWER triangular matrix: an upper block is loaded transposed (inv(U) = inv(U')').
-  for(int idx = t; idx < JB * JB; idx += 256) {
-    const int i = idx & 63, j = idx >> 6;
-    double v = 0.0;
-    if(i < n && j < n) {
-      if(i > j) v = lower ? Ab[i + (int64_t)j * lda] : Ab[j + (int64_t)i * lda];
-      else if(i == j) v = unit ? 1.0 : Ab[i + (int64_t)i * lda];
-    } else if(i == j) {
-      v = 1.0;
+  __shared__ __attribute__((aligned(16))) double Ls[JB * LSTR];  // Ls[c*LSTR + k] = L(c,k), identity padded
+  __shared__ double V[JB * JB];                                   // V[c*64 + lane] = B(row, c)
+  __shared__ double Dinv[JB];                                     // 1 / L(c,c)
+  const int lane = threadIdx.x;
+  const int64_t row = (int64_t)blockIdx.x * JB + lane;
+  // all global loads are issued in batches of 16 before any is consumed: a rolled load->LDS loop would pay the full
+  // memory latency 64 times in a row
+#pragma unroll 1
+  for(int k0 = 0; k0 < JB; k0 += 16) {
+    double v[16], b[16];
+#pragma unroll
+    for(int u = 0; u < 16; u++) {
+      const int k = k0 + u;  // L(lane, k): coalesced along the lane
+      v[u] = (lane < n && k < n && k <= lane) ? L[lane + (int64_t)k * ldl] : ((lane == k && lane >= n) ? 1.0 : 0.0);
+      b[u] = (k < n && row < M) ? B[row + (int64_t)k * ldb] : 0.0;
     }
-    S[i + j * LDP] = v;
+#pragma unroll
+    for(int u = 0; u < 16; u++) {
+      Ls[lane * LSTR + k0 + u] = v[u];
+      V[(k0 + u) * JB + lane] = b[u];
+    }
   }
+  Dinv[lane] = 1.0 / ((lane < n) ? L[lane + (int64_t)lane * ldl] : 1.0);
   __syncthreads();
-  tri_inverse_64(S, W, T);
-  double* out = inv + (int64_t)blockIdx.x * JB * JB;
-  for(int idx = t; idx < JB * JB; idx += 256) {
-    const int i = idx & 63, j = idx >> 6;
-    out[i + j * JB] = lower ? W[i + j * LDP] : W[j + i * LDP];
+
+#pragma unroll 1
+  for(int blk = 0; blk < 4; blk++) {
+    const int o = blk * 16;
+    double x[16];
+#pragma unroll
+    for(int i = 0; i < 16; i++) x[i] = V[(o + i) * JB + lane];
+    // 16 x 16 triangular solve in registers; the L entries are wave-uniform LDS reads
+#pragma unroll
+    for(int i = 0; i < 16; i++) {
+      double s = x[i];
+#pragma unroll
+      for(int k = 0; k < i; k++) s -= x[k] * Ls[(o + i) * LSTR + o + k];
+      x[i] = s * Dinv[o + i];   // reciprocal diagonal, formed once per workgroup (an fp64 divide is ~200 cycles)
+    }
+#pragma unroll
+    for(int i = 0; i < 16; i++) V[(o + i) * JB + lane] = x[i];
+    // rank-16 update of the columns still to be solved
+#pragma unroll 4
+    for(int c = o + 16; c < JB; c++) {
+      const double* lc = &Ls[c * LSTR + o];
+      double s0 = V[c * JB + lane], s1 = 0.0, s2 = 0.0, s3 = 0.0;
+#pragma unroll
+      for(int k = 0; k < 16; k += 4) {
+        s0 -= x[k] * lc[k];
+        s1 -= x[k + 1] * lc[k + 1];
+        s2 -= x[k + 2] * lc[k + 2];
+        s3 -= x[k + 3] * lc[k + 3];
+      }
+      V[c * JB + lane] = (s0 + s1) + (s2 + s3);
+    }
   }
+  if(row < M) {
+#pragma unroll 8
+    for(int c = 0; c < n; c++) B[row + (int64_t)c * ldb] = V[c * JB + lane];
+  }
+}
+
+// second stream + event pool for the look-ahead (created once per process and device)
+struct LookAhead {
+  hipStream_t panel = nullptr;
+  int dev = -1;
+  std::vector<hipEvent_t> ev;
+  size_t next = 0;
+  hipEvent_t get()
+  {
+    if(next == ev.size()) {
+      hipEvent_t e;
+      if(hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
+      ev.push_back(e);
+    }
+    return ev[next++];
+  }
+};
+LookAhead g_la;
+
+int ensure_lookahead()
+{
+  int dev = 0;
+  GPC_HIP_CHECK(hipGetDevice(&dev));
+  if(g_la.panel && g_la.dev == dev) return GPC_OK;
+  int lo = 0, hi = 0;
+  GPC_HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+  GPC_HIP_CHECK(hipStreamCreateWithPriority(&g_la.panel, hipStreamNonBlocking, hi));
+  g_la.dev = dev;
+  g_la.ev.clear();
+  return GPC_OK;
+}
+
+// factor the NB-wide panel starting at column k0 (all rows below it), on stream s
+int factor_panel(int64_t N, double* A, int64_t lda, int64_t k0, int64_t nbk, int* d_info, hipStream_t s)
+{
+  const int64_t kend = k0 + nbk;
+  for(int64_t j0 = k0; j0 < kend; j0 += JB) {
+    const int64_t jb = (kend - j0 < JB) ? (kend - j0) : JB;
+    double* Ajj = A + j0 + j0 * lda;
+    hipLaunchKernelGGL(potf2_kernel, dim3(1), dim3(256), 0, s, Ajj, lda, (int)jb, d_info, j0);
+    GPC_HIP_CHECK(hipGetLastError());
+    const int64_t below = N - (j0 + jb);
+    if(below <= 0) continue;
+    double* A21 = A + (j0 + jb) + j0 * lda;
+    // L21 := A21 * L11^-T by substitution
+    hipLaunchKernelGGL(panel_trsm_kernel, dim3((unsigned)((below + JB - 1) / JB)), dim3(64), 0, s, Ajj, lda, (int)jb,
+                       A21, lda, below);
+    GPC_HIP_CHECK(hipGetLastError());
+    // update the not-yet-factored columns of this panel: lower trapezoid below the diagonal
+    const int64_t nc = kend - (j0 + jb);
+    if(nc > 0) {
+      double* A22 = A + (j0 + jb) + (j0 + jb) * lda;
+      GPC_CHECK(gemm(false, true, below, nc, jb, -1.0, A21, lda, A21, lda, 1.0, A22, lda, 3, s));
+    }
+  }
+  return GPC_OK;
 }
 
 }  // namespace
-
-int invert_diag_blocks(bool lower, bool unit, int64_t N, int64_t jb, const double* A, int64_t lda, double* inv,
-                       hipStream_t s)
-{
-  if(jb != JB) {
-    set_error("invert_diag_blocks: block size must be 64");
-    return GPC_EINVAL;
-  }
-  if(N <= 0) return GPC_OK;
-  const unsigned nblk = (unsigned)((N + JB - 1) / JB);
-  hipLaunchKernelGGL(tri_inv_blocks_kernel, dim3(nblk), dim3(256), 0, s, A, lda, N, lower ? 1 : 0, unit ? 1 : 0,
-                     inv);
-  GPC_HIP_CHECK(hipGetLastError());
-  return GPC_OK;
-}
 
 static int64_t outer_nb()
 {
@@ -190,40 +246,75 @@ int potrf_lower(int64_t N, double* A, int64_t lda, int* d_info, hipStream_t s)
 {
   if(N <= 0) return GPC_OK;
   const int64_t NB = outer_nb();
-  void* ws = nullptr;
-  GPC_CHECK(workspace(WS_POTRF_INV, sizeof(double) * JB * JB * (size_t)((N + JB - 1) / JB), &ws));
-  double* invs = static_cast<double*>(ws);
+  if(g_lookahead < 0) {
+    const char* e = getenv("GPC_LOOKAHEAD");
+    g_lookahead = e ? (atoi(e) != 0) : 1;
+  }
+  const bool la = g_lookahead && N > 2 * NB;
+
+  if(!la) {
+    for(int64_t k0 = 0; k0 < N; k0 += NB) {
+      const int64_t nbk = (N - k0 < NB) ? (N - k0) : NB;
+      const int64_t kend = k0 + nbk;
+      GPC_CHECK(factor_panel(N, A, lda, k0, nbk, d_info, s));
+      const int64_t mt = N - kend;
+      if(mt > 0) {
+        const double* L21 = A + kend + k0 * lda;
+        double* A22 = A + kend + kend * lda;
+        prof_begin(PROF_SYRK, (double)mt * (double)(mt + 1) * (double)nbk, s);  // lower-triangle SYRK flops
+        GPC_CHECK(gemm(false, true, mt, mt, nbk, -1.0, L21, lda, L21, lda, 1.0, A22, lda, 1, s));
+        prof_end(PROF_SYRK, s);
+      }
+    }
+    return GPC_OK;
+  }
+
+  // ---- look-ahead: panels on g_la.panel, trailing updates on the caller's stream ------------------------------------
+  GPC_CHECK(ensure_lookahead());
+  hipStream_t sp = g_la.panel;
+  g_la.next = 0;
+  hipEvent_t e0 = g_la.get();
+  if(!e0) return GPC_EHIP;
+  GPC_HIP_CHECK(hipEventRecord(e0, s));           // everything queued before this call (the Gram build, memset of info)
+  GPC_HIP_CHECK(hipStreamWaitEvent(sp, e0, 0));
+  GPC_CHECK(factor_panel(N, A, lda, 0, (N < NB ? N : NB), d_info, sp));
+  hipEvent_t e_panel = g_la.get();
+  if(!e_panel) return GPC_EHIP;
+  GPC_HIP_CHECK(hipEventRecord(e_panel, sp));
 
   for(int64_t k0 = 0; k0 < N; k0 += NB) {
     const int64_t nbk = (N - k0 < NB) ? (N - k0) : NB;
     const int64_t kend = k0 + nbk;
-    for(int64_t j0 = k0; j0 < kend; j0 += JB) {
-      const int64_t jb = (kend - j0 < JB) ? (kend - j0) : JB;
-      double* Ajj = A + j0 + j0 * lda;
-      double* inv = invs + (j0 / JB) * JB * JB;
-      hipLaunchKernelGGL(potf2_inv_kernel, dim3(1), dim3(256), 0, s, Ajj, lda, (int)jb, inv, d_info, j0);
-      GPC_HIP_CHECK(hipGetLastError());
-      const int64_t below = N - (j0 + jb);
-      if(below <= 0) continue;
-      double* A21 = A + (j0 + jb) + j0 * lda;
-      // L21 := A21 * inv(L11)'   (in place: C tile spans all jb <= 128 columns, rows are private to a workgroup)
-      GPC_CHECK(gemm(false, true, below, jb, jb, 1.0, A21, lda, inv, JB, 0.0, A21, lda, 0, s));
-      // update the not-yet-factored columns of this panel: lower trapezoid below the diagonal
-      const int64_t nc = kend - (j0 + jb);
-      if(nc > 0) {
-        double* A22 = A + (j0 + jb) + (j0 + jb) * lda;
-        GPC_CHECK(gemm(false, true, below, nc, jb, -1.0, A21, lda, A21, lda, 1.0, A22, lda, 3, s));
-      }
-    }
     const int64_t mt = N - kend;
-    if(mt > 0) {
-      const double* L21 = A + kend + k0 * lda;
-      double* A22 = A + kend + kend * lda;
-      prof_begin(PROF_SYRK, (double)mt * (double)(mt + 1) * (double)nbk, s);  // lower-triangle SYRK flops
-      GPC_CHECK(gemm(false, true, mt, mt, nbk, -1.0, L21, lda, L21, lda, 1.0, A22, lda, 1, s));
+    if(mt <= 0) break;
+    const double* L21 = A + kend + k0 * lda;
+    double* A22 = A + kend + kend * lda;
+    const int64_t nb1 = (mt < NB) ? mt : NB;       // width of the next panel
+    GPC_HIP_CHECK(hipStreamWaitEvent(s, e_panel, 0));  // panel k is final
+    // U1(k): the columns of panel k+1 (lower trapezoid mt x nb1)
+    prof_begin(PROF_SYRK, (2.0 * (double)mt - (double)nb1 + 1.0) * (double)nb1 * (double)nbk, s);
+    GPC_CHECK(gemm(false, true, mt, nb1, nbk, -1.0, L21, lda, L21, lda, 1.0, A22, lda, 3, s));
+    prof_end(PROF_SYRK, s);
+    hipEvent_t e_u1 = g_la.get();
+    if(!e_u1) return GPC_EHIP;
+    GPC_HIP_CHECK(hipEventRecord(e_u1, s));
+    // panel k+1 on the panel stream, concurrently with U2(k)
+    GPC_HIP_CHECK(hipStreamWaitEvent(sp, e_u1, 0));
+    GPC_CHECK(factor_panel(N, A, lda, kend, nb1, d_info, sp));
+    e_panel = g_la.get();
+    if(!e_panel) return GPC_EHIP;
+    GPC_HIP_CHECK(hipEventRecord(e_panel, sp));
+    // U2(k): everything right of panel k+1
+    const int64_t m2 = mt - nb1;
+    if(m2 > 0) {
+      const double* L2 = L21 + nb1;
+      double* A33 = A22 + nb1 + nb1 * lda;
+      prof_begin(PROF_SYRK, (double)m2 * (double)(m2 + 1) * (double)nbk, s);
+      GPC_CHECK(gemm(false, true, m2, m2, nbk, -1.0, L2, lda, L2, lda, 1.0, A33, lda, 1, s));
       prof_end(PROF_SYRK, s);
     }
   }
+  GPC_HIP_CHECK(hipStreamWaitEvent(s, e_panel, 0));  // join: the caller's stream sees the finished factor
   return GPC_OK;
 }
 
@@ -240,5 +331,11 @@ extern "C" int gpc_set_potrf_blocking(int64_t nb_outer, int64_t jb_inner)
     return GPC_EINVAL;
   }
   gpc::g_nb_outer = nb_outer;
+  return GPC_OK;
+}
+
+extern "C" int gpc_set_potrf_lookahead(int on)
+{
+  gpc::g_lookahead = on ? 1 : 0;
   return GPC_OK;
 }

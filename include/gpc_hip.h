@@ -188,6 +188,9 @@ int gpc_probe_mfma_f64(double* tflops, double* cycles_per_mfma_per_simd, double*
 
 /* ---- tuning knobs (also read from env GPC_NB / GPC_JB on first use) ---------------------------------------------- */
 int gpc_set_potrf_blocking(int64_t nb_outer, int64_t jb_inner);
+/* Look-ahead of depth 1 in gpc_potrf_f64 (panel k+1 on a second, high-priority HIP stream while the trailing update
+ * of panel k runs); on by default, env GPC_LOOKAHEAD=0 or this call turn it off. */
+int gpc_set_potrf_lookahead(int on);
 /* GEMM kernel variant for the A*B^T shapes: 0 generic, 1 fast 4-wave, 2 fast 8-wave (default; env GPC_GEMM_VARIANT). */
 int gpc_set_gemm_variant(int variant);
 
