@@ -13,6 +13,7 @@
 // the reference's diagComputeElement values exactly (variance sums), not exp(-0).
 #include "gpc_common.hpp"
 #include <string.h>
+#include <stdlib.h>
 
 namespace gpc {
 
@@ -32,6 +33,7 @@ struct GramArgs {
   int64_t N, N2, D;
   int64_t i_off, j_off;  // global indices of K(0,0) in the symmetric Gram (for the diagonal)
   int sym_diag;          // 1: elements with global i == j take the diagComputeElement value
+  int debug;             // ablation knob (env GPC_GRAM_DEBUG): 1 no exp, 2 no MFMA loop, 3 no stores; 0 in production
 };
 
 __global__ void __launch_bounds__(256) row_norms_kernel(const double* __restrict__ X, int64_t ldx, int64_t N,
@@ -168,6 +170,253 @@ __global__ void __launch_bounds__(256) gram_kernel(const KSpecDev ks, const Gram
   }
 }
 
+// ---- MFMA variant for the distance-based terms (rbf / lin / bias / white: the BASELINE configs) ----------------------
+// The cross term x_i . x_j of all pairs of a 128 (i) x 64 (j) patch goes through v_mfma_f64_16x16x4_f64: fp64 MFMA
+// has the same peak rate as the fp64 VALU on gfx950, but it runs on the matrix pipe, so the VALU is left with the
+// epilogue alone (|x|^2 + |x'|^2 - 2 x.x', exp, scale) and the two overlap.  4 waves as 2 (i) x 2 (j), each 64 x 32 =
+// 4 x 2 MFMA tiles; operand roles are swapped as in gemm_f64.hip so that the 16 lanes sharing an accumulator register
+// hold 16 consecutive rows of K (128-byte store runs).  LDS row strides 144 / 80 doubles keep the 32-lane
+// ds_read_b64 groups conflict-free.
+constexpr int MI = 128, MJ = 64, SI = 144, SJ = 80;
+constexpr int MDC = 32;  // feature chunk of the MFMA variant: D <= 32 needs a single staging round trip
+
+__global__ void __launch_bounds__(256, 2) gram_mfma_kernel(const KSpecDev ks, const GramArgs g)
+{
+  __shared__ double Xi[MDC * SI];
+  __shared__ double Xj[MDC * SJ];
+  const int t = threadIdx.x;
+  const int lane = t & 63, w = t >> 6;
+  const int wm = w & 1, wn = w >> 1;
+  const int64_t i0 = (int64_t)blockIdx.x * MI;
+  const int64_t j0 = (int64_t)blockIdx.y * MJ;
+
+  double4_t acc[4][2];
+#pragma unroll
+  for(int a = 0; a < 4; a++)
+#pragma unroll
+    for(int b = 0; b < 2; b++) acc[a][b] = (double4_t){0.0, 0.0, 0.0, 0.0};
+
+  // the row norms of this lane's 4 rows and 8 columns are requested first: their latency hides behind the main loop
+  double ni[4], njv[2][4];
+#pragma unroll
+  for(int tm = 0; tm < 4; tm++) {
+    const int64_t gi = i0 + wm * 64 + tm * 16 + (lane & 15);
+    ni[tm] = (gi < g.N) ? g.n1[gi] : 0.0;
+  }
+#pragma unroll
+  for(int tn = 0; tn < 2; tn++)
+#pragma unroll
+    for(int r = 0; r < 4; r++) {
+      const int64_t gj = j0 + wn * 32 + tn * 16 + (lane >> 4) + 4 * r;
+      njv[tn][r] = (gj < g.N2) ? g.n2[gj] : 0.0;
+    }
+
+  for(int64_t d0 = 0; d0 < g.D; d0 += MDC) {
+    const int dc = (int)((g.D - d0 < MDC) ? (g.D - d0) : MDC);
+    // stage 32 x 128 and 32 x 64 (zero filled past D and past the matrix edge): 16 + 8 loads per thread, all issued
+    // before any is consumed
+    double vi[16], vj[8];
+#pragma unroll
+    for(int u = 0; u < 16; u++) {
+      const int idx = t + 256 * u;
+      const int d = idx >> 7, i = idx & 127;
+      vi[u] = (d < dc && i0 + i < g.N) ? g.X[(i0 + i) + (d0 + d) * g.ldx] : 0.0;
+    }
+#pragma unroll
+    for(int u = 0; u < 8; u++) {
+      const int idx = t + 256 * u;
+      const int d = idx >> 6, j = idx & 63;
+      vj[u] = (d < dc && j0 + j < g.N2) ? g.X2[(j0 + j) + (d0 + d) * g.ldx2] : 0.0;
+    }
+    __syncthreads();  // previous chunk's fragment reads are done
+#pragma unroll
+    for(int u = 0; u < 16; u++) {
+      const int idx = t + 256 * u;
+      Xi[(idx >> 7) * SI + (idx & 127)] = vi[u];
+    }
+#pragma unroll
+    for(int u = 0; u < 8; u++) {
+      const int idx = t + 256 * u;
+      Xj[(idx >> 6) * SJ + (idx & 63)] = vj[u];
+    }
+    __syncthreads();
+    const int nk = (g.debug == 2) ? 0 : ((dc + 3) >> 2);
+    for(int kk = 0; kk < nk; kk++) {
+      double a[4], b[2];
+      const int kr = kk * 4 + (lane >> 4);
+#pragma unroll
+      for(int s = 0; s < 4; s++) a[s] = Xi[kr * SI + wm * 64 + s * 16 + (lane & 15)];
+#pragma unroll
+      for(int s = 0; s < 2; s++) b[s] = Xj[kr * SJ + wn * 32 + s * 16 + (lane & 15)];
+#pragma unroll
+      for(int tn = 0; tn < 2; tn++)
+#pragma unroll
+        for(int tm = 0; tm < 4; tm++)
+          acc[tm][tn] = __builtin_amdgcn_mfma_f64_16x16x4f64(b[tn], a[tm], acc[tm][tn], 0, 0, 0);
+    }
+  }
+
+  // epilogue: lane l, register r of acc[tm][tn] is the pair
+  //   i = i0 + wm*64 + tm*16 + (l & 15),   j = j0 + wn*32 + tn*16 + (l >> 4) + 4*r
+  double diag_const = ks.bias_var + ks.white_var;
+  for(int r = 0; r < ks.n_rbf; r++) diag_const += ks.rbf_var[r];
+#pragma unroll
+  for(int tn = 0; tn < 2; tn++) {
+#pragma unroll
+    for(int r = 0; r < 4; r++) {
+      const int64_t gj = j0 + wn * 32 + tn * 16 + (lane >> 4) + 4 * r;
+      if(gj >= g.N2) continue;
+      const double nj = njv[tn][r];
+#pragma unroll
+      for(int tm = 0; tm < 4; tm++) {
+        const int64_t gi = i0 + wm * 64 + tm * 16 + (lane & 15);
+        if(gi >= g.N) continue;
+        const double dot = acc[tm][tn][r];
+        const double d2 = ni[tm] + nj - 2.0 * dot;
+        double k = ks.bias_var + ks.lin_var * dot;
+        if(g.debug == 1) k += d2;
+        else
+          for(int q = 0; q < ks.n_rbf; q++) k += ks.rbf_var[q] * exp(-(ks.rbf_hiw[q] * d2));
+        if(g.sym_diag && (g.i_off + gi == g.j_off + gj)) k = diag_const + ks.lin_var * ni[tm];
+        if(g.debug != 3 || k == 123.456) g.K[gi + gj * g.ldk] = k;
+      }
+    }
+  }
+}
+
+// Persistent form of the MFMA variant for D <= 32 (every BASELINE config): a workgroup keeps its 128 rows of X in
+// LDS and walks a range of 64-column tiles.  The per-tile variant above turned out to be bound by per-workgroup
+// start-up latency (kernarg fetch, first global loads, two barriers: ~13 us of lifetime for ~3 us of work with only
+// two workgroups resident per CU); here the next tile's X2 rows and norms are requested before the current tile's
+// MFMAs and epilogue, one barrier per tile, so the memory latency hides behind compute and the kernel can approach
+// the HBM write rate.
+template <int NRBF>
+__global__ void __launch_bounds__(256, 2) gram_mfma_persist_kernel(const KSpecDev ks, const GramArgs g,
+                                                                   int jt_per_block)
+{
+  __shared__ double Xi[MDC * SI];
+  __shared__ double Xj[2][MDC * SJ];
+  const int t = threadIdx.x;
+  const int lane = t & 63, w = t >> 6;
+  const int wm = w & 1, wn = w >> 1;
+  const int64_t i0 = (int64_t)blockIdx.x * MI;
+  const int64_t tiles_j = (g.N2 + MJ - 1) / MJ;
+  const int64_t jt0 = (int64_t)blockIdx.y * jt_per_block;
+  int64_t jt1 = jt0 + jt_per_block;
+  if(jt1 > tiles_j) jt1 = tiles_j;
+  if(jt0 >= jt1) return;
+  const int dc = (int)g.D;          // <= 32 on this path
+  const int nk = (dc + 3) >> 2;
+
+  // this workgroup's 128 rows, staged once
+  {
+    double vi[16];
+#pragma unroll
+    for(int u = 0; u < 16; u++) {
+      const int idx = t + 256 * u;
+      const int d = idx >> 7, i = idx & 127;
+      vi[u] = (d < dc && i0 + i < g.N) ? g.X[(i0 + i) + (int64_t)d * g.ldx] : 0.0;
+    }
+#pragma unroll
+    for(int u = 0; u < 16; u++) {
+      const int idx = t + 256 * u;
+      Xi[(idx >> 7) * SI + (idx & 127)] = vi[u];
+    }
+  }
+  double ni[4];
+#pragma unroll
+  for(int tm = 0; tm < 4; tm++) {
+    const int64_t gi = i0 + wm * 64 + tm * 16 + (lane & 15);
+    ni[tm] = (gi < g.N) ? g.n1[gi] : 0.0;
+  }
+  double diag_const = ks.bias_var + ks.white_var;
+  for(int r = 0; r < ks.n_rbf; r++) diag_const += ks.rbf_var[r];
+
+  // prefetch registers for the next tile
+  double vj[8], njn[2][4];
+  auto prefetch = [&](int64_t jt) {
+    const int64_t j0 = jt * MJ;
+#pragma unroll
+    for(int u = 0; u < 8; u++) {
+      const int idx = t + 256 * u;
+      const int d = idx >> 6, j = idx & 63;
+      vj[u] = (d < dc && j0 + j < g.N2) ? g.X2[(j0 + j) + (int64_t)d * g.ldx2] : 0.0;
+    }
+#pragma unroll
+    for(int tn = 0; tn < 2; tn++)
+#pragma unroll
+      for(int r = 0; r < 4; r++) {
+        const int64_t gj = j0 + wn * 32 + tn * 16 + (lane >> 4) + 4 * r;
+        njn[tn][r] = (gj < g.N2) ? g.n2[gj] : 0.0;
+      }
+  };
+  prefetch(jt0);
+
+  for(int64_t jt = jt0; jt < jt1; jt++) {
+    double* Xjb = Xj[(jt - jt0) & 1];
+    const int64_t j0 = jt * MJ;
+    double njv[2][4];
+#pragma unroll
+    for(int u = 0; u < 8; u++) {
+      const int idx = t + 256 * u;
+      Xjb[(idx >> 6) * SJ + (idx & 63)] = vj[u];
+    }
+#pragma unroll
+    for(int tn = 0; tn < 2; tn++)
+#pragma unroll
+      for(int r = 0; r < 4; r++) njv[tn][r] = njn[tn][r];
+    __syncthreads();   // tile jt is visible; every wave is past its reads of the other buffer (tile jt-1)
+    if(jt + 1 < jt1) prefetch(jt + 1);
+
+    double4_t acc[4][2];
+#pragma unroll
+    for(int a = 0; a < 4; a++)
+#pragma unroll
+      for(int b = 0; b < 2; b++) acc[a][b] = (double4_t){0.0, 0.0, 0.0, 0.0};
+    for(int kk = 0; kk < nk; kk++) {
+      double a[4], b[2];
+      const int kr = kk * 4 + (lane >> 4);
+#pragma unroll
+      for(int s = 0; s < 4; s++) a[s] = Xi[kr * SI + wm * 64 + s * 16 + (lane & 15)];
+#pragma unroll
+      for(int s = 0; s < 2; s++) b[s] = Xjb[kr * SJ + wn * 32 + s * 16 + (lane & 15)];
+#pragma unroll
+      for(int tn = 0; tn < 2; tn++)
+#pragma unroll
+        for(int tm = 0; tm < 4; tm++)
+          acc[tm][tn] = __builtin_amdgcn_mfma_f64_16x16x4f64(b[tn], a[tm], acc[tm][tn], 0, 0, 0);
+    }
+    // branch-free epilogue: all 32 values of the lane are computed unconditionally (edge lanes work on zero-filled
+    // data) so that the independent exp chains interleave; only the stores are predicated.
+    const bool full = (i0 + MI <= g.N) && (j0 + MJ <= g.N2);
+#pragma unroll
+    for(int tn = 0; tn < 2; tn++) {
+#pragma unroll
+      for(int r = 0; r < 4; r++) {
+        const int64_t gj = j0 + wn * 32 + tn * 16 + (lane >> 4) + 4 * r;
+        const double nj = njv[tn][r];
+        double kv[4];
+#pragma unroll
+        for(int tm = 0; tm < 4; tm++) {
+          const double dot = acc[tm][tn][r];
+          const double d2 = ni[tm] + nj - 2.0 * dot;
+          double k = ks.bias_var + ks.lin_var * dot;
+#pragma unroll
+          for(int q = 0; q < NRBF; q++) k += ks.rbf_var[q] * exp(-(ks.rbf_hiw[q] * d2));
+          kv[tm] = k;
+        }
+#pragma unroll
+        for(int tm = 0; tm < 4; tm++) {
+          const int64_t gi = i0 + wm * 64 + tm * 16 + (lane & 15);
+          double k = kv[tm];
+          if(g.sym_diag && (g.i_off + gi == g.j_off + gj)) k = diag_const + ks.lin_var * ni[tm];
+          if(full || (gi < g.N && gj < g.N2)) g.K[gi + gj * g.ldk] = k;
+        }
+      }
+    }
+  }
+}
+
 __global__ void __launch_bounds__(256) gram_diag_kernel(const KSpecDev ks, const double* __restrict__ X,
                                                         int64_t ldx, int64_t N, int64_t D, double* __restrict__ d)
 {
@@ -190,6 +439,37 @@ __global__ void __launch_bounds__(256) gram_diag_kernel(const KSpecDev ks, const
 int launch_gram(const KSpecDev& ks, const GramArgs& g, hipStream_t s)
 {
   if(g.N <= 0 || g.N2 <= 0) return GPC_OK;
+  static int use_mfma = -1;
+  if(use_mfma < 0) {
+    const char* e = getenv("GPC_GRAM_MFMA");
+    use_mfma = e ? (atoi(e) != 0) : 1;
+  }
+  if(use_mfma && ks.need_dot && ks.n_ard == 0 && (g.N2 + MJ - 1) / MJ <= 65535) {
+    const int64_t tiles_i = (g.N + MI - 1) / MI, tiles_j = (g.N2 + MJ - 1) / MJ;
+    prof_begin(PROF_GRAM, 8.0 * ((double)g.N * (double)g.N2 + (double)(g.N + g.N2) * (double)g.D), s);
+    if(g.D <= MDC && use_mfma != 2) {
+      // persistent walk over column tiles: about 2048 workgroups in total, each with a contiguous range of tiles
+      int64_t nsplit = (2048 + tiles_i - 1) / tiles_i;
+      if(nsplit > tiles_j) nsplit = tiles_j;
+      if(nsplit < 1) nsplit = 1;
+      const int64_t per = (tiles_j + nsplit - 1) / nsplit;
+      nsplit = (tiles_j + per - 1) / per;
+      const dim3 grid((unsigned)tiles_i, (unsigned)nsplit), block(256);
+      switch(ks.n_rbf) {
+      case 0: hipLaunchKernelGGL(gram_mfma_persist_kernel<0>, grid, block, 0, s, ks, g, (int)per); break;
+      case 1: hipLaunchKernelGGL(gram_mfma_persist_kernel<1>, grid, block, 0, s, ks, g, (int)per); break;
+      case 2: hipLaunchKernelGGL(gram_mfma_persist_kernel<2>, grid, block, 0, s, ks, g, (int)per); break;
+      case 3: hipLaunchKernelGGL(gram_mfma_persist_kernel<3>, grid, block, 0, s, ks, g, (int)per); break;
+      default: hipLaunchKernelGGL(gram_mfma_persist_kernel<4>, grid, block, 0, s, ks, g, (int)per); break;
+      }
+    } else {
+      const dim3 grid((unsigned)tiles_i, (unsigned)tiles_j), block(256);
+      hipLaunchKernelGGL(gram_mfma_kernel, grid, block, 0, s, ks, g);
+    }
+    prof_end(PROF_GRAM, s);
+    GPC_HIP_CHECK(hipGetLastError());
+    return GPC_OK;
+  }
   const uint64_t gx = (uint64_t)((g.N + TI - 1) / TI);
   const uint64_t gy = (uint64_t)((g.N2 + TJ - 1) / TJ);
   if(gy > 65535) {
@@ -314,6 +594,11 @@ static int gram_common(const gpc_kspec* ksp, const double* X, int64_t N, int64_t
   g.i_off = i_off;
   g.j_off = j_off;
   g.sym_diag = sym_diag;
+  {
+    static int dbg = -1;
+    if(dbg < 0) { const char* e = getenv("GPC_GRAM_DEBUG"); dbg = e ? atoi(e) : 0; }
+    g.debug = dbg;
+  }
   g.n1 = g.n2 = nullptr;
   if(ks.need_dot) {
     void* ws = nullptr;
