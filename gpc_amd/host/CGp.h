@@ -1,0 +1,104 @@
+// CGp.h -- GPc's exact Gaussian-process model, FTC branches (reference CGp.h:14-491, CGp.cpp), on libgpc_hip.so.
+//
+// Same construction and call protocol as the reference (gp.cpp:379-419): the model BORROWS the kernel, the noise
+// model and X (the caller keeps them alive); setScale / setBias / updateM, then optimise(); out() for predictions.
+// All N x N objects (K -> LcholK, invK, covGrad) live in HBM and never visit the host.  Compared with the
+// reference's four resident N x N matrices (CGp.cpp:171-174) this model keeps one (the factor, in K's storage) for
+// likelihood / prediction and three only while a gradient is being evaluated.
+//
+// Not provided: the sparse approximations (DTC, FITC, PITC, DTCVAR), GP-LVM (optimiseX) and learnt output scales;
+// asking for them throws ndlexceptions::NotImplementedError.
+#ifndef GPC_AMD_CGP_H
+#define GPC_AMD_CGP_H
+#include <iostream>
+#include <string>
+#include "CKern.h"
+#include "CMatrix.h"
+#include "CNoise.h"
+#include "COptimisable.h"
+
+class CGp : public CProbabilisticOptimisable {
+ public:
+  enum { FTC, DTC, FITC, PITC, DTCVAR };
+  CGp(CKern* kernel, CNoise* nois, CMatrix* Xin, int approxType = FTC, unsigned int actSetSize = 0, int verbos = 2);
+  ~CGp();
+
+  // CMapModel interface (CGp.cpp:445-460)
+  void out(CMatrix& yPred, const CMatrix& inData) const;
+  void out(CMatrix& yPred, CMatrix& probPred, const CMatrix& inData) const;
+  void posteriorMeanVar(CMatrix& mu, CMatrix& varSigma, const CMatrix& X) const;   // CGp.cpp:642-663
+
+  // COptimisable interface
+  unsigned int getOptNumParams() const { return pkern->getNumParams(); }
+  void getOptParams(CMatrix& param) const;      // transformed kernel parameters, CGp.cpp:330-372
+  void setOptParams(const CMatrix& param);      // marks K dirty, CGp.cpp:387-443
+  double logLikelihood() const;                 // CGp.cpp:913-1014
+  double logLikelihoodGradient(CMatrix& g) const;   // CGp.cpp:1016-1144
+  void optimise(unsigned int iters = 1000);     // CGp.cpp:1537-1551
+  void display(std::ostream& os) const;
+
+  void updateM() const;                         // CGp.cpp:248-260
+  void updateK() const;                         // CGp.cpp:682-691 (+ _updateK 698-712, _updateInvK 877-891)
+  void updateAlpha() const;                     // CGp.cpp:469-489
+  void setScale(const CMatrix& s) { scale.deepCopy(s); MupToDate = false; AlphaUpToDate = false; }
+  void setBias(const CMatrix& b) { bias.deepCopy(b); MupToDate = false; AlphaUpToDate = false; }
+  double getScaleVal(unsigned int j) const { return scale.getVal(j); }
+  double getBiasVal(unsigned int j) const { return bias.getVal(j); }
+  void setBetaVal(double) {}                    // irrelevant for FTC (gp.cpp:402)
+  void setOutputScaleLearnt(bool v)
+  {
+    if(v) throw ndlexceptions::NotImplementedError("learnt output scales are outside the accelerated FTC path");
+  }
+  bool isOutputScaleLearnt() const { return false; }
+  bool isOutputBiasLearnt() const { return false; }
+  bool isSparseApproximation() const { return false; }
+  bool isOptimiseX() const { return false; }
+  int getApproximationType() const { return FTC; }
+  unsigned int getNumData() const { return pX->getRows(); }
+  unsigned int getInputDim() const { return pX->getCols(); }
+  unsigned int getOutputDim() const { return py->getCols(); }
+  unsigned int getNumActive() const { return numActive; }
+  std::string getNoiseType() const { return pnoise->getType(); }
+  const CKern* getKernel() const { return pkern; }
+  double getLogDetK() const { updateK(); return logDetK; }
+  double getJitter() const { return lastJitter; }
+  // Reproduce the single-precision LcholK of a Fortran-built reference (gpc_ref_trans_rounding_f64 in gpc_hip.h).
+  // Default on; GPC_EXACT_TRANS=1 in the environment or setReferenceTransRounding(false) give plain fp64.
+  void setReferenceTransRounding(bool v) { refTransRounding = v; KupToDate = false; AlphaUpToDate = false; }
+  bool isReferenceTransRounding() const { return refTransRounding; }
+
+  // text model file (CGp.cpp:1656-1682)
+  void writeParamsToStream(std::ostream& out) const;
+  void toStream(std::ostream& out) const;
+  void toFile(const std::string fileName, const std::string comment = "") const;
+
+  CMatrix* pX;   // public in the reference as well (CGp.h:352-356)
+  CMatrix* py;
+
+ private:
+  void ensureDeviceInputs() const;
+  void releaseGradientBuffers() const;
+  CKern* pkern;
+  CNoise* pnoise;
+  unsigned int numActive;
+  CMatrix scale, bias;
+  bool refTransRounding;
+  // caches (mutable, as in the reference: the model is not re-entrant)
+  mutable CMatrix m;          // host N x d
+  mutable bool MupToDate, KupToDate, AlphaUpToDate, invKupToDate;
+  mutable double* dX;         // device copy of X (N x D)
+  mutable double* dM;         // device copy of m
+  mutable double* dL;         // device N x N: LcholK (lower) in K's storage
+  mutable double* dInvKm;     // device N x d: invK * m (exact fp64)
+  mutable double* dAlpha;     // device N x d: LcholK^-T LcholK^-1 m with the model's LcholK
+  mutable double* dInvK;      // device N x N, only while gradients are in use
+  mutable double* dCovGrad;   // device N x N, only while gradients are in use
+  mutable std::vector<double> quad;   // m_j' invK m_j
+  mutable double logDetK;
+  mutable double lastJitter;
+  mutable bool needInverse;
+};
+
+void writeGpToStream(const CGp& model, std::ostream& out);
+void writeGpToFile(const CGp& model, const std::string modelFileName, const std::string comment = "");
+#endif

@@ -1,0 +1,181 @@
+// gp.cpp -- the `gp` command line (reference gp.cpp:3-985) for the accelerated exact-GP path:
+//     gp [-v verbosity] [-s seed] learn [flags] trainData.svml [modelFile]
+// Same flags, defaults and model construction as the reference's `learn` (gp.cpp:86-437) for the kernels the HIP
+// path covers (rbf, lin, bias, white, `-i 1` for rbfard): kernel = cmpnd{ <-k kernels, default rbf>, bias, white },
+// Gaussian noise, bias = mean(y) unless -C 0, FTC only.  The other commands (display, gnuplot, relearn) and the
+// sparse approximations are outside the hot path.
+#include <cstdlib>
+#include <iostream>
+#include <string>
+#include <vector>
+#include "CClctrl.h"
+#include "CGp.h"
+#include "CKern.h"
+#include "CNoise.h"
+
+class CClgp : public CClctrl {
+ public:
+  CClgp(int argc, char** argv) : CClctrl(argc, argv) {}
+  void learn();
+  void helpInfo();
+};
+
+void CClgp::helpInfo()
+{
+  std::cout << "gp [-v verbosity] [-s seed] learn [-k kernel [-g gamma] [-v variance] [-i 0|1]]... [-C 0|1] [-S 0|1]\n"
+               "   [-# iterations] [-O scg] [-A ftc] trainData.svml [modelFile]\n"
+               "kernels: rbf (with -i 1: rbfard), lin, bias, white.  bias and white terms are always appended.\n";
+}
+
+void CClgp::learn()
+{
+  incrementArgument();
+  setMode("learn");
+  std::string optimiser = "scg", approxTypeStr = "ftc", modelFileName = "gp_model";
+  std::vector<std::string> kernelTypes;
+  std::vector<double> rbfInvWidths, variances;
+  std::vector<bool> selectInputs;
+  bool centreData = true, scaleData = false, outputScaleLearnt = false;
+  int iters = 1000;
+  while(isFlags()) {
+    if(isCurrentArgumentFlag()) {
+      if(isCurrentArg("-?", "--?") || isCurrentArg("-h", "--help")) { helpInfo(); exitNormal(); }
+      else if(isCurrentArg("-C", "--Centre-data")) { incrementArgument(); centreData = getBoolFromCurrentArgument(); }
+      else if(isCurrentArg("-L", "--Learn-scales")) { incrementArgument(); outputScaleLearnt = getBoolFromCurrentArgument(); }
+      else if(isCurrentArg("-S", "--Scale-data")) { incrementArgument(); scaleData = getBoolFromCurrentArgument(); }
+      else if(isCurrentArg("-a", "--active-set-size")) { incrementArgument(); }
+      else if(isCurrentArg("-A", "--Approximation-type")) { incrementArgument(); approxTypeStr = getCurrentArgument(); }
+      else if(isCurrentArg("-k", "--kernel")) {
+        incrementArgument();
+        kernelTypes.push_back(getCurrentArgument());
+        rbfInvWidths.push_back(-1.0);
+        variances.push_back(-1.0);
+        selectInputs.push_back(false);
+      }
+      else if(isCurrentArg("-g", "--gamma")) {
+        incrementArgument();
+        if(kernelTypes.empty()) exitError("Inverse width specification must come after covariance function type is specified.");
+        if(kernelTypes.back() != "rbf") exitError("Inverse width parameter only valid for RBF covariance function.");
+        rbfInvWidths.back() = 2 * getDoubleFromCurrentArgument();   // gp.cpp:168
+      }
+      else if(isCurrentArg("-v", "--variance")) {
+        incrementArgument();
+        if(kernelTypes.empty()) exitError("Variance parameter specification must come after covariance function type is specified.");
+        variances.back() = getDoubleFromCurrentArgument();
+      }
+      else if(isCurrentArg("-i", "--input-select")) {
+        incrementArgument();
+        if(kernelTypes.empty()) exitError("Input selection flag must come after covariance function type is specified.");
+        selectInputs.back() = getBoolFromCurrentArgument();
+      }
+      else if(isCurrentArg("-O", "--optimiser")) { incrementArgument(); optimiser = getCurrentArgument(); }
+      else if(isCurrentArg("-#", "--#iterations")) { incrementArgument(); iters = getIntFromCurrentArgument(); }
+      else if(isCurrentArg("-f", "--file-format")) { incrementArgument(); setFileFormat(getIntFromCurrentArgument()); }
+      else unrecognisedFlag();
+      incrementArgument();
+    } else {
+      setFlags(false);
+    }
+  }
+  if(getCurrentArgumentNo() >= argc) exitError("There are not enough input parameters.");
+  const std::string trainDataFileName = getCurrentArgument();
+  if(getCurrentArgumentNo() + 1 < argc) modelFileName = argv[getCurrentArgumentNo() + 1];
+  if(approxTypeStr != "ftc") exitError("Only the full (ftc) model runs on the accelerated path: " + approxTypeStr + ".");
+  if(optimiser != "scg") exitError("Unrecognised optimiser type: " + optimiser + " (scg is the one provided).");
+
+  CMatrix X, y;
+  readData(X, y, trainDataFileName);
+
+  // covariance function (gp.cpp:240-349)
+  CCmpndKern kern(X);
+  for(size_t i = 0; i < kernelTypes.size(); i++) {
+    CKern* k = 0;
+    if(kernelTypes[i] == "rbf") {
+      if(selectInputs[i]) k = new CRbfardKern(X);
+      else k = new CRbfKern(X);
+      if(rbfInvWidths[i] != -1.0) k->setParam(rbfInvWidths[i], 0);
+      if(variances[i] != -1.0) k->setParam(variances[i], 1);
+    } else if(kernelTypes[i] == "lin") {
+      if(selectInputs[i]) exitError("linard is outside the accelerated kernel set.");
+      k = new CLinKern(X);
+      if(variances[i] != -1.0) k->setParam(variances[i], 0);
+    } else if(kernelTypes[i] == "bias") {
+      k = new CBiasKern(X);
+      if(variances[i] != -1.0) k->setParam(variances[i], 0);
+    } else if(kernelTypes[i] == "white") {
+      k = new CWhiteKern(X);
+      if(variances[i] != -1.0) k->setParam(variances[i], 0);
+    } else {
+      exitError("Covariance function " + kernelTypes[i] + " is outside the accelerated set (rbf, lin, bias, white).");
+    }
+    kern.addKern(k);
+    delete k;   // addKern cloned it
+  }
+  if(kern.getNumKerns() == 0) {
+    CRbfKern defaultKern(X);
+    kern.addKern(&defaultKern);
+  }
+  CBiasKern biasKern(X);
+  CWhiteKern whiteKern(X);
+  kern.addKern(&biasKern);
+  kern.addKern(&whiteKern);
+
+  CGaussianNoise noise(&y);
+  noise.setBias(0.0);
+  CMatrix scale(1, y.getCols(), 1.0);
+  CMatrix bias(1, y.getCols(), 0.0);
+  if(centreData) bias.deepCopy(meanCol(y));
+  if(scaleData) scale.deepCopy(stdCol(y));
+
+  CGp model(&kern, &noise, &X, CGp::FTC, (unsigned int)-1, getVerbosity());
+  model.setDefaultOptimiser(CGp::SCG);
+  model.setBetaVal(1);
+  model.setScale(scale);
+  model.setBias(bias);
+  model.updateM();
+  model.setOutputScaleLearnt(outputScaleLearnt);
+  model.optimise(iters);
+
+  std::string comment = "Run as:";
+  for(int i = 0; i < argc; i++) {
+    comment += " ";
+    comment += argv[i];
+  }
+  comment += " with seed " + std::to_string(getSeed()) + ".";
+  writeGpToFile(model, modelFileName, comment);
+  if(getVerbosity() > 1)
+    std::cout << "Objective evaluations: " << model.funcEvals << "  gradient evaluations: " << model.gradEvals
+              << "  SCG iterations: " << model.getIterations() << std::endl;
+}
+
+int main(int argc, char* argv[])
+{
+  CClgp command(argc, argv);
+  command.setFlags(true);
+  command.setVerbosity(2);
+  command.setSeed(0);
+  command.setMode("gp");
+  try {
+    while(command.isFlags()) {
+      if(command.isCurrentArgumentFlag()) {
+        if(command.isCurrentArg("-?", "--?") || command.isCurrentArg("-h", "--help")) { command.helpInfo(); return 0; }
+        else if(command.isCurrentArg("-v", "--verbosity")) { command.incrementArgument(); command.setVerbosity(command.getIntFromCurrentArgument()); }
+        else if(command.isCurrentArg("-s", "--seed")) { command.incrementArgument(); command.setSeed(command.getIntFromCurrentArgument()); }
+        else command.unrecognisedFlag();
+        command.incrementArgument();
+      } else if(command.getCurrentArgumentNo() < argc && command.getCurrentArgument() == "learn") {
+        command.learn();
+        return 0;
+      } else {
+        command.exitError("Invalid gp command provided (this build implements `learn`).");
+      }
+    }
+  } catch(ndlexceptions::Error& err) {
+    command.exitError(err.getMessage());
+  } catch(std::bad_alloc&) {
+    command.exitError("Out of memory.");
+  } catch(std::exception& err) {
+    command.exitError(std::string("Unhandled exception: ") + err.what());
+  }
+  return 0;
+}

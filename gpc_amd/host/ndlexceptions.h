@@ -1,0 +1,79 @@
+// ndlexceptions.h -- exception types of the host layer, named as in the reference (ndlexceptions.h:12-260) so that
+// code written against GPc's classes catches the same things.  Only the ones the FTC hot path can raise are provided.
+#ifndef GPC_AMD_NDLEXCEPTIONS_H
+#define GPC_AMD_NDLEXCEPTIONS_H
+#include <stdexcept>
+#include <string>
+
+namespace ndlexceptions {
+
+class Error : public std::exception {
+ public:
+  Error() : msg("Unknown error") {}
+  explicit Error(const std::string& m) : msg(m) {}
+  virtual ~Error() throw() {}
+  virtual const char* what() const throw() { return msg.c_str(); }
+  std::string getMessage() const { return msg; }
+
+ private:
+  std::string msg;
+};
+
+class NotImplementedError : public Error {
+ public:
+  explicit NotImplementedError(const std::string& m) : Error(m) {}
+};
+class RuntimeError : public Error {
+ public:
+  explicit RuntimeError(const std::string& m) : Error(m) {}
+};
+class CommandLineError : public Error {
+ public:
+  explicit CommandLineError(const std::string& m) : Error(m) {}
+};
+class FileError : public Error {
+ public:
+  explicit FileError(const std::string& m) : Error(m) {}
+};
+class FileReadError : public FileError {
+ public:
+  explicit FileReadError(const std::string& f) : FileError("Unable to read file " + f) {}
+};
+class FileWriteError : public FileError {
+ public:
+  explicit FileWriteError(const std::string& f) : FileError("Unable to write file " + f) {}
+};
+class FileFormatError : public FileError {
+ public:
+  FileFormatError(const std::string& f, const std::string& note = "") : FileError("File " + f + " has the wrong format. " + note) {}
+};
+class StreamFormatError : public Error {
+ public:
+  StreamFormatError(const std::string& field, const std::string& note = "")
+      : Error("Stream format error reading field '" + field + "'. " + note) {}
+};
+class StreamVersionError : public Error {
+ public:
+  StreamVersionError() : Error("Stream version error") {}
+};
+class MatrixError : public Error {
+ public:
+  MatrixError() : Error("Matrix error") {}
+  explicit MatrixError(const std::string& m) : Error(m) {}
+};
+class MatrixNonPosDef : public MatrixError {
+ public:
+  MatrixNonPosDef() : MatrixError("Matrix is not positive definite") {}
+};
+class MatrixConditionError : public MatrixError {
+ public:
+  MatrixConditionError() : MatrixError("Matrix has condition error") {}
+};
+// raised when libgpc_hip.so reports an error (no device, HIP failure...): there is no CPU fallback to catch it
+class DeviceError : public Error {
+ public:
+  explicit DeviceError(const std::string& m) : Error("libgpc_hip: " + m) {}
+};
+
+}  // namespace ndlexceptions
+#endif

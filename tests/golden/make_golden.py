@@ -146,5 +146,31 @@ def main():
     save("synth_ard_512", N=512, D=4, seed=77, x_checksum=X.sum(), y_checksum=y.sum(), **g)
 
 
+def sinc_golden():
+    """Config 1: the reference's own `gp -v 3 -s 1 learn -# 100 examples/sinc.svml` (README.md:86-107): per-iteration
+    SCG objective and scale, final kernel parameters (from the model file, hexfloat -> exact doubles), final ll."""
+    import re
+    import subprocess
+    import tempfile
+    ref_gp = os.path.join(ROOT, "oracle", "_ref", "gp")
+    svml = os.path.join(OUT, "sinc.svml")          # copy of the reference's examples/sinc.svml (a data file)
+    with tempfile.TemporaryDirectory() as td:
+        model = os.path.join(td, "sinc.model")
+        env = dict(os.environ, LD_PRELOAD=refrun.MKL)
+        r = subprocess.run([ref_gp, "-v", "3", "-s", "1", "learn", "-#", "100", svml, model], env=env,
+                           stdin=subprocess.DEVNULL, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, check=True)
+        log = r.stdout.decode()
+        its = re.findall(r"^Iteration: (\d+) Error: (\S+) Scale: (\S+)$", log, flags=re.M)
+        ll = float(re.findall(r"^Log likelihood: (\S+)$", log, flags=re.M)[-1])
+        rows = [ln.split() for ln in open(model) if ln.startswith("0x") or re.match(r"^-?\d", ln)]
+        vals = [[float.fromhex(t) if "x" in t else float(t) for t in row] for row in rows]
+    # model file order: scale, bias, rbf(2), bias kern, white kern, noise(2)
+    flat = [v for row in vals for v in row]
+    save("sinc_scg", errors=np.array([float(e) for _, e, _ in its]), scales=np.array([float(sc) for _, _, sc in its]),
+         n_iters=len(its), ll_printed=ll, model_scale=flat[0], model_bias=flat[1],
+         kern_params=np.array(flat[2:6]), noise_params=np.array(flat[6:8]))
+
+
 if __name__ == "__main__":
     main()
+    sinc_golden()

@@ -1,0 +1,180 @@
+// hosttest.cpp -- exercises the C++ class surface (CMatrix / CKern / CGp) the way the reference's testMatrix.cpp,
+// testKern.cpp and testGp.cpp do, printing `name v1 v2 ...` lines (17 significant digits) that
+// tests/test_host_layer.py compares with the oracle / golden vectors.  Built by gpc_amd/host/Makefile.
+//   gp_hosttest matrix
+//   gp_hosttest gp X.txt y.txt Xs.txt "rbf:1,1;bias:0.135;white:0.135" [exact]
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <iostream>
+#include <sstream>
+#include <string>
+#include <vector>
+#include "CGp.h"
+#include "CKern.h"
+#include "CMatrix.h"
+#include "CNoise.h"
+
+static void printMat(const char* name, const CMatrix& M)
+{
+  std::printf("%s", name);
+  for(unsigned int j = 0; j < M.getCols(); j++)
+    for(unsigned int i = 0; i < M.getRows(); i++) std::printf(" %.17g", M.getVal(i, j));
+  std::printf("\n");
+}
+
+static int testMatrix()
+{
+  const unsigned int n = 37;
+  CMatrix B(n, n), A(n, n);
+  unsigned long s = 12345;
+  for(unsigned int i = 0; i < n * n; i++) {
+    s = s * 6364136223846793005ULL + 1442695040888963407ULL;
+    B.setVal(((double)((s >> 33) & 0xffffff) / 16777216.0) - 0.5, i);
+  }
+  A.setSymmetric(true);
+  A.syrk(B, 1.0, 0.0, "l", "n");   // A = B B'
+  A.addDiag(1.0);
+  // chol("U") / chol("L"): U'U == A == L L'
+  CMatrix U(A), L(A), R(n, n);
+  U.setSymmetric(true);
+  U.chol("U");
+  L.setSymmetric(true);
+  L.chol("L");
+  R.gemm(U, U, 1.0, 0.0, "t", "n");
+  std::printf("chol_U_residual %.3e\n", R.maxAbsDiff(A));
+  R.gemm(L, L, 1.0, 0.0, "n", "t");
+  std::printf("chol_L_residual %.3e\n", R.maxAbsDiff(A));
+  // logDet, pdinv, trans (the _updateInvK sequence, CGp.cpp:881-891)
+  std::printf("logdet %.17g\n", logDet(U));
+  CMatrix invA(n, n);
+  invA.setSymmetric(true);
+  invA.pdinv(U);
+  R.gemm(invA, A, 1.0, 0.0, "n", "n");
+  CMatrix I(n, n);
+  for(unsigned int i = 0; i < n; i++) I.setVal(1.0, i, i);
+  std::printf("pdinv_residual %.3e\n", R.maxAbsDiff(I));
+  CMatrix Lt(U);
+  Lt.trans();
+  std::printf("trans_vs_cholL %.3e\n", Lt.maxAbsDiff(L));
+  // trsm: solve L X = C then check L X == C
+  CMatrix C(n, 5), X(n, 5);
+  for(unsigned int i = 0; i < n * 5; i++) C.setVal(std::sin(0.37 * i), i);
+  X.deepCopy(C);
+  X.trsm(L, 1.0, "l", "l", "n", "n");
+  CMatrix LX(n, 5);
+  LX.gemm(L, X, 1.0, 0.0, "n", "n");
+  std::printf("trsm_residual %.3e\n", LX.maxAbsDiff(C));
+  // jitChol on a rank-deficient matrix: must add jitter and succeed; returns the NEXT candidate (reference quirk)
+  CMatrix S(n, n);
+  S.setSymmetric(true);
+  CMatrix v(n, 1);
+  for(unsigned int i = 0; i < n; i++) v.setVal(1.0 + 0.1 * i, i);
+  S.syrk(v, 1.0, 0.0, "u", "n");   // rank one
+  CMatrix F(n, n);
+  const double tr0 = S.trace();
+  const double jit = F.jitChol(S);
+  std::printf("jitchol_ratio %.17g\n", jit / (1e-6 * tr0 / n));
+  // non-PD must throw MatrixNonPosDef from potrf
+  CMatrix Nn(2, 2);
+  Nn.setVal(1.0, 0, 0); Nn.setVal(2.0, 0, 1); Nn.setVal(2.0, 1, 0); Nn.setVal(1.0, 1, 1);
+  Nn.setSymmetric(true);
+  try { Nn.potrf("U"); std::printf("nonpd_throw 0\n"); }
+  catch(ndlexceptions::MatrixNonPosDef&) { std::printf("nonpd_throw 1\n"); }
+  // flags gate the operations as in the reference
+  CMatrix G(3, 3);
+  try { G.potrf("U"); std::printf("flag_gate 0\n"); }
+  catch(ndlexceptions::MatrixError&) { std::printf("flag_gate 1\n"); }
+  // CMatrix::max() bug-compatibility: only first and last elements are compared
+  CMatrix mx(1, 4);
+  mx.setVal(1.0, 0); mx.setVal(9.0, 1); mx.setVal(7.0, 2); mx.setVal(3.0, 3);
+  std::printf("max_quirk %.17g\n", mx.max());
+  return 0;
+}
+
+static void buildKern(CCmpndKern& kern, const CMatrix& X, const std::string& spec)
+{
+  std::stringstream ss(spec);
+  std::string term;
+  while(std::getline(ss, term, ';')) {
+    const size_t c = term.find(':');
+    const std::string type = term.substr(0, c);
+    std::vector<double> p;
+    std::stringstream ps(term.substr(c + 1));
+    std::string tok;
+    while(std::getline(ps, tok, ',')) p.push_back(std::atof(tok.c_str()));
+    CKern* k = 0;
+    if(type == "rbf") k = new CRbfKern(X);
+    else if(type == "rbfard") k = new CRbfardKern(X);
+    else if(type == "white") k = new CWhiteKern(X);
+    else if(type == "bias") k = new CBiasKern(X);
+    else if(type == "lin") k = new CLinKern(X);
+    else { std::fprintf(stderr, "unknown kernel %s\n", type.c_str()); std::exit(2); }
+    for(size_t i = 0; i < p.size(); i++) k->setParam(p[i], (unsigned int)i);
+    kern.addKern(k);
+    delete k;
+  }
+}
+
+static int testGp(int argc, char** argv)
+{
+  if(argc < 6) { std::fprintf(stderr, "usage: gp_hosttest gp X y Xs kernspec [exact]\n"); return 2; }
+  CMatrix X, y, Xs;
+  X.fromUnheadedFile(argv[2]);
+  y.fromUnheadedFile(argv[3]);
+  Xs.fromUnheadedFile(argv[4]);
+  CCmpndKern kern(X);
+  buildKern(kern, X, argv[5]);
+  CGaussianNoise noise(&y);
+  noise.setBias(0.0);
+  CMatrix scale(1, y.getCols(), 1.0), bias(1, y.getCols(), 0.0);
+  bias.deepCopy(meanCol(y));
+  CGp model(&kern, &noise, &X, CGp::FTC, (unsigned int)-1, 0);
+  if(argc > 6 && std::string(argv[6]) == "exact") model.setReferenceTransRounding(false);
+  model.setBetaVal(1);
+  model.setScale(scale);
+  model.setBias(bias);
+  model.updateM();
+  CMatrix g(1, model.getOptNumParams()), params(1, model.getOptNumParams());
+  const double ll = model.logLikelihoodGradient(g);
+  model.getOptParams(params);
+  std::printf("ll %.17g\n", ll);
+  std::printf("ll_again %.17g\n", model.logLikelihood());
+  std::printf("logdet %.17g\n", model.getLogDetK());
+  printMat("grads", g);
+  printMat("opt_params", params);
+  CMatrix mu(Xs.getRows(), y.getCols()), var(Xs.getRows(), y.getCols());
+  model.posteriorMeanVar(mu, var, Xs);
+  printMat("mu", mu);
+  printMat("var", var);
+  CMatrix yPred(Xs.getRows(), y.getCols()), errBar(Xs.getRows(), y.getCols());
+  model.out(yPred, errBar, Xs);
+  printMat("errBar", errBar);
+  // kernel surface: whole-matrix compute vs the scalar computeElement path
+  CMatrix K(X.getRows(), X.getRows());
+  kern.compute(K, X);
+  double worst = 0.0;
+  for(unsigned int i = 0; i < X.getRows(); i += 7)
+    for(unsigned int j = 0; j < X.getRows(); j += 5) {
+      const double e = (i == j) ? kern.diagComputeElement(X, i) : kern.computeElement(X, i, X, j);
+      worst = std::fmax(worst, std::fabs(e - K.getVal(i, j)));
+    }
+  std::printf("compute_vs_element %.3e\n", worst);
+  // setOptParams / getOptParams round trip marks K dirty and reproduces the likelihood
+  model.setOptParams(params);
+  std::printf("ll_roundtrip %.17g\n", model.logLikelihood());
+  return 0;
+}
+
+int main(int argc, char** argv)
+{
+  try {
+    if(argc >= 2 && std::string(argv[1]) == "matrix") return testMatrix();
+    if(argc >= 2 && std::string(argv[1]) == "gp") return testGp(argc, argv);
+    std::fprintf(stderr, "usage: gp_hosttest matrix | gp ...\n");
+    return 2;
+  } catch(ndlexceptions::Error& e) {
+    std::fprintf(stderr, "exception: %s\n", e.getMessage().c_str());
+    return 3;
+  }
+}

@@ -1,0 +1,46 @@
+#!/bin/bash
+# Produces the rocprofv3 summaries committed under profiles/ (run on the GPU box: gpurun -- bash tools/make_profiles.sh r01)
+TAG=${1:-r01}
+export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+OUT=$R/gpurun_out/profiles_$TAG
+mkdir -p $OUT; cd /tmp
+summ() { # db-dir label
+python - "$1" "$2" <<PY
+import sqlite3, glob, sys
+for f in glob.glob(sys.argv[1] + "/**/*.db", recursive=True):
+    cur = sqlite3.connect(f).cursor()
+    print("# %s : rocprofv3 --kernel-trace --stats (top kernels; durations in ms)" % sys.argv[2])
+    print("%-72s %8s %14s %12s %7s" % ("kernel", "calls", "total_ms", "avg_ms", "pct"))
+    for r in cur.execute("select name, total_calls, total_duration, average, percentage from top_kernels limit 14"):
+        print("%-72s %8d %14.1f %12.2f %6.1f%%" % (r[0][:72], r[1], r[2] / 1e3, r[3] / 1e3, r[4]))
+PY
+}
+# 1. kernel traces of the bench command itself
+for wl in cfg3 cfg2; do
+  steps=1; [ $wl = cfg2 ] && steps=3
+  rm -rf /tmp/kt_$wl
+  timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/kt_$wl -o t -- python $R/bench.py --workload $wl --steps $steps --warmup 1 --no-cpu-baseline > $OUT/bench_${wl}_under_trace.json 2> /dev/null
+  summ /tmp/kt_$wl "python bench.py --workload $wl --steps $steps --warmup 1 --no-cpu-baseline" > $OUT/kernel_trace_${wl}.txt
+done
+# 2. PMC passes on ONE big trailing-update launch (tools/one_syrk.py: M=16384, K=512, 3 launches), separate runs
+pmc() { # name counters...
+  n=$1; shift
+  rm -rf /tmp/pmc_$n
+  timeout 300 rocprofv3 --pmc "$@" -d /tmp/pmc_$n -o p -- python $R/tools/one_syrk.py 2 16384 512 > /dev/null 2>&1
+  echo "# rocprofv3 --pmc $* -- python tools/one_syrk.py 2 16384 512   (per-dispatch sums over all XCDs/SEs)" > $OUT/pmc_syrk_$n.txt
+  python $R/tools/pmc_query.py /tmp/pmc_$n gemm >> $OUT/pmc_syrk_$n.txt 2>&1
+}
+pmc mfma SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE
+pmc lds SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_INSTS_VALU SQ_INSTS_VMEM
+pmc fetch FETCH_SIZE
+pmc write WRITE_SIZE
+pmc tcc TCC_HIT_sum TCC_MISS_sum
+# 3. the Gram kernel alone (HBM bytes)
+for c in FETCH_SIZE WRITE_SIZE; do
+  rm -rf /tmp/pmc_g$c
+  timeout 300 rocprofv3 --pmc $c -d /tmp/pmc_g$c -o p -- python $R/tools/gram_bench.py 32768 32 > /dev/null 2>&1
+  echo "# rocprofv3 --pmc $c -- python tools/gram_bench.py 32768 32" > $OUT/pmc_gram_$c.txt
+  python $R/tools/pmc_query.py /tmp/pmc_g$c gram_mfma >> $OUT/pmc_gram_$c.txt 2>&1
+done
+ls -la $OUT
