@@ -6,9 +6,10 @@ Cholesky in place, log-determinant (gpc_gp_update_k_f64).  Default workload = BA
 rbf + white, the configuration the north-star target is quoted on; K is 34.4 GB and fits one 288 GB GPU).
 `--workload cfg2` runs config 2 (N = 8 192, D = 8, rbf).
 
-N > 1 GPUs (launched by torch.distributed.run, one process per GPU): see DESIGN.md "multi-GPU".  Until the 2-D
-block-cyclic factorisation lands, every rank factors an independent replica of the workload (weak scaling, no
-data-path collective); `value` is then the aggregate factors/s of all ranks.
+N > 1 GPUs (launched by torch.distributed.run, one process per GPU): ONE factorisation of the same workload spread
+over the ranks by gpc_amd/dist.py (1-D block-cyclic column panels, panel broadcasts over RCCL/xGMI, look-ahead), so
+the total work is fixed ("scaling": "strong") and `value` is still whole-job factors/s.  GPC_BENCH_REPLICAS=1 runs
+independent replicas instead (weak scaling, no collective).
 
 Prints ONE JSON line on rank 0.  The `roofline` object is measured live with HIP events bracketing the dominant
 kernel (the trailing SYRK update on fp64 MFMA) on the stream it is launched on; `cpu_baseline` times the compiled
@@ -56,6 +57,10 @@ def cpu_baseline(cfg, sample_n, seed):
                       % (sample_n, cfg["D"], tg, tc, time.time() - t0)}
 
 
+def jobs_flops(world, replicas):
+    return world if replicas else 1
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -78,22 +83,33 @@ def main():
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        opts = dist.ProcessGroupNCCL.Options(is_high_priority_stream=True)   # panel broadcasts overtake the SYRK
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), pg_options=opts)
     api.lib()
+    replicas = world > 1 and os.environ.get("GPC_BENCH_REPLICAS", "0") == "1"
+    # GPC_BENCH_DIST=1: drive the block-cyclic code path on ONE GPU too (P = 1, no collective) to price its overhead
+    distributed = (world > 1 and not replicas) or os.environ.get("GPC_BENCH_DIST", "0") == "1"
 
     cfg = dict(synth.CONFIGS[args.workload])
     if args.n:
         cfg["N"] = args.n
     N, D = cfg["N"], cfg["D"]
-    X, _ = synth.make_xy(N, D, seed=1234 + rank)
-    Xd = api.from_host(X)
-    ks = api.kspec(cfg["kern"])
-    K = api.empty(N, N)
+    X, _ = synth.make_xy(N, D, seed=1234 + (rank if replicas else 0))
+    if distributed:
+        from gpc_amd import dist as gdist
+        g = gdist.DistGp(cfg["kern"], X)
 
-    def step():
-        _, logdet, jit, info = api.gp_update_k(ks, Xd, K)
-        assert info == 0, "factorisation failed (info=%d)" % info
-        return logdet
+        def step():
+            return g.update_k()
+    else:
+        Xd = api.from_host(X)
+        ks = api.kspec(cfg["kern"])
+        K = api.empty(N, N)
+
+        def step():
+            _, logdet, jit, info = api.gp_update_k(ks, Xd, K)
+            assert info == 0, "factorisation failed (info=%d)" % info
+            return logdet
 
     def sync():
         if world > 1:
@@ -133,7 +149,8 @@ def main():
                                                api.stream()))
         achieved = syrk_flops / (syrk_ms * 1e-3) * 1e-12 if syrk_ms > 0 else 0.0
         potrf_flops = N ** 3 / 3.0
-        roof = {"bound": "mfma", "kernel": "gemm_f64_kernel (trailing SYRK of gpc_potrf_f64)",
+        roof = {"bound": "mfma", "kernel": "gemm_nt_fast_kernel<4> (trailing SYRK launches U1+U2 of %s)"
+                                           % ("gpc_syrk_blockcyclic_f64, rank 0" if distributed else "gpc_potrf_f64"),
                 "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": None,
                 "launches_per_step": syrk_n / max(1, args.steps),
@@ -141,17 +158,22 @@ def main():
                 "algorithmic_flops_per_launch": syrk_flops / max(1, syrk_n),
                 "mfma_f64_probe_tflops": probe.value, "mfma_f64_probe_cycles_per_mfma": pcyc.value,
                 "mfma_f64_probe_clock_ghz": pclk.value,
-                "whole_factor_tflops": potrf_flops * args.steps / dt * 1e-12,
+                "whole_factor_tflops": jobs_flops(world, replicas) * potrf_flops * args.steps / dt * 1e-12,
                 "gram": {"bound": "hbm", "achieved": gram_bytes / (gram_ms * 1e-3) * 1e-9 if gram_ms > 0 else 0.0,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "avg_launch_ms": gram_ms / max(1, gram_n)}}
         roof["gram"]["frac"] = roof["gram"]["achieved"] / HBM_PEAK_GBS
-        out = {"metric": "N x N RBF Gram build + Cholesky factors/sec", "value": world * args.steps / dt,
+        jobs = world if replicas else 1
+        out = {"metric": "N x N RBF Gram build + Cholesky factors/sec", "value": jobs * args.steps / dt,
                "unit": "factors/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-               "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+               "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+               "scaling": "strong" if distributed else "weak",
                "vs_baseline": None, "dtype": "f64", "data": "synthetic",
                "config": {"workload": "%s: N=%d D=%d kernel=%s, one CGp::updateK (Gram + dpotrf + logdet) per step"
                                       % (args.workload, N, D, "+".join(t for t, _ in cfg["kern"])),
-                          "parallelism": "1 GPU" if world == 1 else "%d independent replicas" % world,
+                          "parallelism": "1 GPU" if world == 1 else
+                          ("%d independent replicas" % world if replicas else
+                           "1-D block-cyclic column panels over %d GPUs (nb=%d), RCCL panel broadcast, look-ahead 1"
+                           % (world, g.nb)),
                           "logdet": logdet},
                "roofline": roof}
         if world == 1 and not args.no_cpu_baseline:

@@ -286,3 +286,20 @@ def gp_posterior(ks, X, L, Alpha, Xs, want_var=True):
                                      ptr(Xs), Ns, ld(Xs), ptr(kX), ld(kX), ptr(mu), ld(mu),
                                      ptr(var) if want_var else c_void_p(0), stream()))
     return mu, var
+
+
+# ---- building blocks of the block-cyclic multi-GPU factorisation (gpc_amd/dist.py) ----------------------------------
+
+def potrf_panel(panel, col0, d_info):
+    """Factor the tall panel (M x nb view, diagonal block on top) in place; asynchronous.  d_info: int32 device tensor."""
+    M, nb = panel.shape
+    check(lib().gpc_potrf_panel_f64(M, nb, ptr(panel), ld(panel), col0, c_void_p(d_info.data_ptr()), stream()))
+    return panel
+
+
+def syrk_blockcyclic(P, C, row0, j0, pstride, nb, alpha=-1.0, beta=1.0):
+    """C(m,c) += alpha * P(m,:) . P(gcol(c) - row0,:) on and below the global diagonal (see include/gpc_hip.h)."""
+    M, ncols = C.shape
+    check(lib().gpc_syrk_blockcyclic_f64(M, ncols, P.shape[1], alpha, ptr(P), ld(P), beta, ptr(C), ld(C), row0, j0,
+                                         pstride, nb, stream()))
+    return C

@@ -25,6 +25,8 @@
 
 namespace gpc {
 
+extern int g_stair_args_set;
+extern int64_t g_stair[4];
 int g_gemm_variant = -1;  // -1: read GPC_GEMM_VARIANT on first use; 0 generic only; 1 fast 4-wave; 2 fast 8-wave
 
 namespace {
@@ -51,6 +53,11 @@ struct GemmArgs {
   int debug_same_rows;   // ablation knob (env GPC_GEMM_DEBUG_SAMEROWS): never set in production
   int tri;               // 0 full, 1 lower (i >= j, C square), 2 upper (i <= j, C square),
                          // 3 lower trapezoid (i >= j, M >= N, full enumeration with skipped tiles)
+                         // 4 block-cyclic staircase (fast NT kernel only): local column c of C is GLOBAL column
+                         //   gcol(c) = (stair_j0 + (c / stair_nb) * stair_pstride) * stair_nb + c % stair_nb,
+                         //   row m of A / C is global row stair_row0 + m, the B operand row for column c is
+                         //   gcol(c) - stair_row0, and only global_row >= global_col is written
+  int64_t stair_nb, stair_pstride, stair_j0, stair_row0;
 };
 
 // ---- global -> registers -------------------------------------------------------------------------------------
@@ -137,7 +144,19 @@ __device__ __forceinline__ bool map_tile(const GemmArgs& g, int& ti, int& tj)
   const unsigned b = blockIdx.x;
   const unsigned L = (b & 7u) * (nb >> 3) + (b >> 3);
   int si, sj, di, dj;
-  if(g.tri == 0 || g.tri == 3) {
+  if(g.tri == 4) {
+    // Block-cyclic staircase: which super-tiles are empty depends on the panel owner pattern, so contiguous chunks
+    // would leave some XCDs with nothing but skipped tiles.  Deal whole super-tiles round-robin instead (super-tile s
+    // -> XCD s % 8): each one still lives in a single L2 and the empty ones spread evenly.
+    const unsigned i = b >> 3;
+    const unsigned s = (i / (SUPER * SUPER)) * 8u + (b & 7u);
+    const unsigned w = i % (SUPER * SUPER);
+    if(s >= (unsigned)(g.super_m * g.super_n)) return false;
+    si = s % g.super_m;
+    sj = s / g.super_m;
+    di = (int)(w % SUPER);
+    dj = (int)(w / SUPER);
+  } else if(g.tri == 0 || g.tri == 3) {
     const unsigned s = L / (SUPER * SUPER);
     const unsigned w = L % (SUPER * SUPER);
     if(s >= (unsigned)(g.super_m * g.super_n)) return false;
@@ -308,14 +327,22 @@ __global__ void __launch_bounds__(128 * NWN, NWN) gemm_nt_fast_kernel(const Gemm
   const int64_t m0 = (int64_t)ti * BM;
   const int64_t n0 = (int64_t)tj * BN;
 
+  // block-cyclic staircase: global column of this tile's first column; tiles entirely above the diagonal are skipped
+  int64_t gcol0 = 0;
+  if(g.tri == 4) {
+    gcol0 = (g.stair_j0 + (n0 / g.stair_nb) * g.stair_pstride) * g.stair_nb + (n0 % g.stair_nb);
+    if(g.stair_row0 + m0 + BM - 1 < gcol0) return;
+  }
   // staging pointers (rows clamped into the matrix; M, N are even and >= 2 on this path)
-  int64_t ra = m0 + 2 * lane, rb = n0 + 2 * lane;
+  int64_t ra = m0 + 2 * lane, rb = (g.tri == 4 ? gcol0 - g.stair_row0 : n0) + 2 * lane;
+  const int64_t rbmax = (g.tri == 4 ? g.M : g.N) - 2;
   if(g.debug_same_rows) {  // ablation: every tile reads operand rows 0..127 (all L2 hits); results are wrong
     ra = 2 * lane;
     rb = 2 * lane;
   }
   if(ra > g.M - 2) ra = g.M - 2;
-  if(rb > g.N - 2) rb = g.N - 2;
+  if(rb > rbmax) rb = rbmax;
+  if(rb < 0) rb = 0;
   const double* pa = g.A + ra + (int64_t)(t >> 6) * g.lda;
   const double* pb = g.B + rb + (int64_t)(t >> 6) * g.ldb;
   const int64_t stepa = (int64_t)KROWS * g.lda, stepb = (int64_t)KROWS * g.ldb;
@@ -397,7 +424,8 @@ __global__ void __launch_bounds__(128 * NWN, NWN) gemm_nt_fast_kernel(const Gemm
       for(int r = 0; r < 4; r++) {
         const int64_t n = n0 + wn * (16 * NT) + tn * 16 + (lane >> 4) + 4 * r;
         bool ok = full_mn || (m < g.M && n < g.N);
-        if(diag_tile) ok = ok && (g.tri == 2 ? (m <= n) : (m >= n));
+        if(g.tri == 4) ok = ok && (g.stair_row0 + m >= gcol0 + (n - n0));
+        else if(diag_tile) ok = ok && (g.tri == 2 ? (m <= n) : (m >= n));
         if(ok) {
           double* p = g.C + m + n * g.ldc;
           double v = alpha * acc[tm][tn][r];
@@ -463,6 +491,17 @@ int gemm(bool transa, bool transb, int64_t M, int64_t N, int64_t K, double alpha
   g.super_m = (g.tiles_m + SUPER - 1) / SUPER;
   g.super_n = (g.tiles_n + SUPER - 1) / SUPER;
   g.tri = tri;
+  g.stair_nb = g.stair_pstride = g.stair_j0 = g.stair_row0 = 0;
+  if(tri == 4) {
+    if(!g_stair_args_set) {
+      set_error("staircase gemm must be called through syrk_blockcyclic");
+      return GPC_EINVAL;
+    }
+    g.stair_nb = g_stair[0];
+    g.stair_pstride = g_stair[1];
+    g.stair_j0 = g_stair[2];
+    g.stair_row0 = g_stair[3];
+  }
   {
     static int dbg = -1;
     if(dbg < 0) dbg = getenv("GPC_GEMM_DEBUG_SAMEROWS") ? 1 : 0;
@@ -477,7 +516,9 @@ int gemm(bool transa, bool transb, int64_t M, int64_t N, int64_t K, double alpha
     return GPC_EINVAL;
   }
   uint64_t slots;
-  if(tri == 0 || tri == 3)
+  if(tri == 4)
+    slots = (((uint64_t)g.super_m * g.super_n + 7) / 8) * 8 * SUPER * SUPER;
+  else if(tri == 0 || tri == 3)
     slots = (uint64_t)g.super_m * g.super_n * SUPER * SUPER;
   else
     slots = 32ull * g.super_m * g.super_m + 4ull * g.super_m;  // valid lower tiles of full 8 x 8 super-tiles
@@ -497,6 +538,7 @@ int gemm(bool transa, bool transb, int64_t M, int64_t N, int64_t K, double alpha
     g_gemm_variant = e ? atoi(e) : 2;
     if(g_gemm_variant < 0 || g_gemm_variant > 2) g_gemm_variant = 2;
   }
+  if(tri == 4) return g_gemm_variant == 1 ? launch_fast<2>(g, grid, s) : launch_fast<4>(g, grid, s);
   if(g_gemm_variant > 0 && !a_kc && !b_kc && vec && g.K > 0 && (g.K % BK) == 0 && (M % 2) == 0 && (N % 2) == 0) {
     return g_gemm_variant == 2 ? launch_fast<4>(g, grid, s) : launch_fast<2>(g, grid, s);
   }
@@ -510,6 +552,28 @@ int gemm(bool transa, bool transb, int64_t M, int64_t N, int64_t K, double alpha
   GPC_GEMM_CASE(true, true)
 #undef GPC_GEMM_CASE
   return GPC_EINVAL;
+}
+
+int g_stair_args_set = 0;
+int64_t g_stair[4];
+
+int syrk_blockcyclic(int64_t M, int64_t ncols, int64_t K, double alpha, const double* P, int64_t ldp, double beta,
+                     double* C, int64_t ldc, int64_t row0, int64_t j0, int64_t pstride, int64_t nb, hipStream_t s)
+{
+  if(M <= 0 || ncols <= 0) return GPC_OK;
+  if(nb <= 0 || nb % BN != 0 || K % BK != 0 || K <= 0 || (M & 1) || (ldp & 1) ||
+     (reinterpret_cast<uintptr_t>(P) & 15) != 0) {
+    set_error("syrk_blockcyclic: needs nb %% 128 == 0, K %% 16 == 0, even M / ldp and a 16-byte aligned panel");
+    return GPC_EINVAL;
+  }
+  g_stair[0] = nb;
+  g_stair[1] = pstride;
+  g_stair[2] = j0;
+  g_stair[3] = row0;
+  g_stair_args_set = 1;
+  const int rc = gemm(false, true, M, ncols, K, alpha, P, ldp, P, ldp, beta, C, ldc, 4, s);
+  g_stair_args_set = 0;
+  return rc;
 }
 
 }  // namespace gpc

@@ -134,6 +134,22 @@ int gpc_ref_trans_rounding_f64(int64_t N, double* A, int64_t lda, void* stream);
 /* trace(A) to a host double (jitChol's 1e-6*tr/N). */
 int gpc_trace_f64(int64_t N, const double* A, int64_t lda, double* out, void* stream);
 
+/* ---- building blocks of the 1-D block-cyclic multi-GPU factorisation (gpc_amd/dist.py) ------
+ * Panel j (nb columns) of the N x N matrix lives on rank j % P.  A rank stores its panels side by side, every local
+ * column holding all N rows. */
+
+/* Factor one tall panel in place (dpotrf of the nb x nb diagonal block + dtrsm of the M-nb rows below it; the
+ * owner-local part of a right-looking step).  Fully asynchronous: a non-positive pivot writes the LAPACK info
+ * (col0 + its 1-based column) into the DEVICE word *d_info, which the caller zeroes once and reads at the end. */
+int gpc_potrf_panel_f64(int64_t M, int64_t nb, double* A, int64_t lda, int64_t col0, int* d_info, void* stream);
+/* Trailing update of ALL local panels with one received panel, in one launch:
+ *   C(m, c) += alpha * sum_k P(m, k) * P(gcol(c) - row0, k)   for global_row = row0 + m >= gcol(c) (beta scales C),
+ * where local column c of the M x ncols view C is GLOBAL column gcol(c) = (j0 + (c / nb) * pstride) * nb + c % nb
+ * and row m of C and of the panel P (M x K) is global row row0 + m.  nb must be a multiple of 128, K of 16. */
+int gpc_syrk_blockcyclic_f64(int64_t M, int64_t ncols, int64_t K, double alpha, const double* P, int64_t ldp,
+                             double beta, double* C, int64_t ldc, int64_t row0, int64_t j0, int64_t pstride,
+                             int64_t nb, void* stream);
+
 /* ---- vectors / reductions used by CGp's FTC branches ------------------------------------------------------------ */
 /* out[j] = sum_i A(i,j)*B(i,j), j < ncols (ddot per column: CGp.cpp:553-559, 928-930).  out is host. */
 int gpc_coldot_f64(int64_t M, int64_t ncols, const double* A, int64_t lda, const double* B, int64_t ldb,
