@@ -57,6 +57,23 @@ def cpu_baseline(cfg, sample_n, seed):
                       % (sample_n, cfg["D"], tg, tc, time.time() - t0)}
 
 
+def pmc_traffic(workload, single_gpu_path):
+    """HBM bytes per trailing-update launch from the committed PMC passes of THIS command (tools/pmc_bench_traffic.sh ->
+    profiles/rNN_pmc_bench_traffic.json); None when no such profile exists for the workload being run."""
+    import glob
+    if workload != "cfg3" or not single_gpu_path:
+        return None, None
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_bench_traffic.json")))
+    if not files:
+        return None, None
+    try:
+        with open(files[-1]) as f:
+            j = json.load(f)
+        return float(j["hbm_bytes_per_launch"]), os.path.relpath(files[-1], ROOT)
+    except (OSError, ValueError, KeyError):
+        return None, None
+
+
 def jobs_flops(world, replicas):
     return world if replicas else 1
 
@@ -141,6 +158,14 @@ def main():
         return n.value, ms.value, w.value
 
     syrk_n, syrk_ms, syrk_flops = prof(0)
+    # algorithmic HBM bytes of the trailing updates of one factor: each reads its panel rows once (8*m*NB) and reads +
+    # writes the lower triangle it updates (2 * 8 * m(m+1)/2); summed over the panels k of width NB = 512
+    nbp = 512
+    syrk_bytes = 0.0
+    for k0 in range(nbp, N, nbp):
+        m = N - k0
+        syrk_bytes += 8.0 * m * nbp + 8.0 * m * (m + 1)
+    syrk_bytes *= args.steps
     gram_n, gram_ms, gram_bytes = prof(1)
 
     if rank == 0:
@@ -149,10 +174,14 @@ def main():
                                                api.stream()))
         achieved = syrk_flops / (syrk_ms * 1e-3) * 1e-12 if syrk_ms > 0 else 0.0
         potrf_flops = N ** 3 / 3.0
-        roof = {"bound": "mfma", "kernel": "gemm_nt_fast_kernel<4> (trailing SYRK launches U1+U2 of %s)"
+        traffic, traffic_src = pmc_traffic(args.workload if not args.n else "custom", not distributed)
+        roof = {"bound": "mfma", "kernel": "gemm_nt_fast_kernel<4, 1> (trailing SYRK launches U1+U2 of %s)"
                                            % ("gpc_syrk_blockcyclic_f64, rank 0" if distributed else "gpc_potrf_f64"),
                 "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": None,
+                "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": traffic,
+                "traffic_unit": "HBM bytes per launch = (2 x FETCH_SIZE + WRITE_SIZE) x 1024, rocprofv3 --pmc passes of "
+                                "this command", "traffic_source": traffic_src,
+                "algorithmic_bytes_per_launch": syrk_bytes / max(1, syrk_n),
                 "launches_per_step": syrk_n / max(1, args.steps),
                 "avg_launch_ms": syrk_ms / max(1, syrk_n),
                 "algorithmic_flops_per_launch": syrk_flops / max(1, syrk_n),

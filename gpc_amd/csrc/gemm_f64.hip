@@ -25,6 +25,7 @@
 
 namespace gpc {
 
+int g_gemm_trailing = 0;  // TrailingScope (gpc_common.hpp)
 extern int g_stair_args_set;
 extern int64_t g_stair[4];
 int g_gemm_variant = -1;  // -1: read GPC_GEMM_VARIANT on first use; 0 generic only; 1 fast 4-wave; 2 fast 8-wave
@@ -305,7 +306,10 @@ __global__ void __launch_bounds__(256, 2) gemm_f64_kernel(const GemmArgs g)
 //     busy matrix pipe, and land ~3000 cycles before the ds_write that consumes them;
 //   * NWN = 2: 4 waves, 64 x 64 per wave (2 waves/SIMD with two workgroups per CU);
 //     NWN = 4: 8 waves, 64 x 32 per wave (<= 128 VGPRs -> 4 waves/SIMD).
-template <int NWN>
+//   * ROLE changes nothing but the kernel's NAME: 1 = a trailing update of the Cholesky (the launches bench.py's roofline
+//     times with HIP events), 0 = everything else (in-panel updates, trsm/potri products, plain gpc_gemm_f64 calls), so
+//     that rocprofv3's per-kernel statistics separate the two populations.
+template <int NWN, int ROLE>
 __global__ void __launch_bounds__(128 * NWN, NWN) gemm_nt_fast_kernel(const GemmArgs g)
 {
   constexpr int NT = 256 / (64 * NWN) * 2;  // n-subtiles per wave: NWN=2 -> 4, NWN=4 -> 2
@@ -438,11 +442,11 @@ __global__ void __launch_bounds__(128 * NWN, NWN) gemm_nt_fast_kernel(const Gemm
 }
 
 
-template <int NWN>
-int launch_fast(const GemmArgs& g, unsigned grid, hipStream_t s)
+template <int NWN, int ROLE>
+int launch_fast_role(const GemmArgs& g, unsigned grid, hipStream_t s)
 {
   static bool attr_set = false;
-  auto kern = gemm_nt_fast_kernel<NWN>;
+  auto kern = gemm_nt_fast_kernel<NWN, ROLE>;
   if(!attr_set) {
     GPC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES));
@@ -451,6 +455,12 @@ int launch_fast(const GemmArgs& g, unsigned grid, hipStream_t s)
   hipLaunchKernelGGL(kern, dim3(grid), dim3(128 * NWN), GEMM_LDS_BYTES, s, g);
   GPC_HIP_CHECK(hipGetLastError());
   return GPC_OK;
+}
+
+template <int NWN>
+int launch_fast(const GemmArgs& g, unsigned grid, hipStream_t s)
+{
+  return g_gemm_trailing ? launch_fast_role<NWN, 1>(g, grid, s) : launch_fast_role<NWN, 0>(g, grid, s);
 }
 
 template <bool A_KC, bool B_KC, bool VEC>

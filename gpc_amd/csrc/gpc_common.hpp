@@ -56,6 +56,12 @@ int ensure_device();
 // 3 = only i>=j for a tall C (M >= N) whose (0,0) sits on the diagonal.
 int gemm(bool transa, bool transb, int64_t M, int64_t N, int64_t K, double alpha, const double* A, int64_t lda,
          const double* B, int64_t ldb, double beta, double* C, int64_t ldc, int tri, hipStream_t s);
+// While one of these is alive the fast GEMM launches under its "trailing update" kernel name (see gemm_f64.hip, ROLE).
+extern int g_gemm_trailing;
+struct TrailingScope {
+  TrailingScope() { g_gemm_trailing = 1; }
+  ~TrailingScope() { g_gemm_trailing = 0; }
+};
 int potrf_lower(int64_t N, double* A, int64_t lda, int* d_info, hipStream_t s);
 int potrf_panel(int64_t M, int64_t nb, double* A, int64_t lda, int* d_info, int64_t col0, hipStream_t s);
 int syrk_blockcyclic(int64_t M, int64_t ncols, int64_t K, double alpha, const double* P, int64_t ldp, double beta,

@@ -290,6 +290,7 @@ int potrf_lower(int64_t N, double* A, int64_t lda, int* d_info, hipStream_t s)
         const double* L21 = A + kend + k0 * lda;
         double* A22 = A + kend + kend * lda;
         prof_begin(PROF_SYRK, (double)mt * (double)(mt + 1) * (double)nbk, s);  // lower-triangle SYRK flops
+        TrailingScope role;
         GPC_CHECK(gemm(false, true, mt, mt, nbk, -1.0, L21, lda, L21, lda, 1.0, A22, lda, 1, s));
         prof_end(PROF_SYRK, s);
       }
@@ -321,7 +322,10 @@ int potrf_lower(int64_t N, double* A, int64_t lda, int* d_info, hipStream_t s)
     GPC_HIP_CHECK(hipStreamWaitEvent(s, e_panel, 0));  // panel k is final
     // U1(k): the columns of panel k+1 (lower trapezoid mt x nb1)
     prof_begin(PROF_SYRK, (2.0 * (double)mt - (double)nb1 + 1.0) * (double)nb1 * (double)nbk, s);
-    GPC_CHECK(gemm(false, true, mt, nb1, nbk, -1.0, L21, lda, L21, lda, 1.0, A22, lda, 3, s));
+    {
+      TrailingScope role;
+      GPC_CHECK(gemm(false, true, mt, nb1, nbk, -1.0, L21, lda, L21, lda, 1.0, A22, lda, 3, s));
+    }
     prof_end(PROF_SYRK, s);
     hipEvent_t e_u1 = g_la.get();
     if(!e_u1) return GPC_EHIP;
@@ -338,6 +342,7 @@ int potrf_lower(int64_t N, double* A, int64_t lda, int* d_info, hipStream_t s)
       const double* L2 = L21 + nb1;
       double* A33 = A22 + nb1 + nb1 * lda;
       prof_begin(PROF_SYRK, (double)m2 * (double)(m2 + 1) * (double)nbk, s);
+      TrailingScope role;
       GPC_CHECK(gemm(false, true, m2, m2, nbk, -1.0, L2, lda, L2, lda, 1.0, A33, lda, 1, s));
       prof_end(PROF_SYRK, s);
     }
@@ -388,7 +393,11 @@ extern "C" int gpc_syrk_blockcyclic_f64(int64_t M, int64_t ncols, int64_t K, dou
   }
   hipStream_t s = gpc::as_stream(stream);
   gpc::prof_begin(gpc::PROF_SYRK, 2.0 * (double)K * entries, s);
-  const int rc = gpc::syrk_blockcyclic(M, ncols, K, alpha, P, ldp, beta, C, ldc, row0, j0, pstride, nb, s);
+  int rc;
+  {
+    gpc::TrailingScope role;
+    rc = gpc::syrk_blockcyclic(M, ncols, K, alpha, P, ldp, beta, C, ldc, row0, j0, pstride, nb, s);
+  }
   gpc::prof_end(gpc::PROF_SYRK, s);
   return rc;
 }
