@@ -159,12 +159,17 @@ def main():
 
     syrk_n, syrk_ms, syrk_flops = prof(0)
     # algorithmic HBM bytes of the trailing updates of one factor: each reads its panel rows once (8*m*NB) and reads +
-    # writes the lower triangle it updates (2 * 8 * m(m+1)/2); summed over the panels k of width NB = 512
-    nbp = 512
-    syrk_bytes = 0.0
-    for k0 in range(nbp, N, nbp):
-        m = N - k0
-        syrk_bytes += 8.0 * m * nbp + 8.0 * m * (m + 1)
+    # writes the lower triangle it updates (2 * 8 * m(m+1)/2); summed over the panels
+    syrk_bytes, k0 = 0.0, 0
+    fixed_nb = int(os.environ.get("GPC_NB", "0"))
+    while k0 < N:
+        rem = N - k0
+        nbp = fixed_nb if fixed_nb >= 64 else (1024 if rem >= 12288 else 512)   # potrf.hip panel_width()
+        nbp = min(nbp, rem)
+        m = rem - nbp
+        if m > 0:
+            syrk_bytes += 8.0 * m * nbp + 8.0 * m * (m + 1)
+        k0 += nbp
     syrk_bytes *= args.steps
     gram_n, gram_ms, gram_bytes = prof(1)
 

@@ -259,30 +259,40 @@ int potrf_panel(int64_t M, int64_t nb, double* A, int64_t lda, int* d_info, int6
   return GPC_OK;
 }
 
-static int64_t outer_nb()
+// Width of the panel that starts with `rem` columns still to factor.  Fixed when GPC_NB / gpc_set_potrf_blocking says
+// so; otherwise 1024 while the trailing matrix is large (the update kernel's per-tile start-up and C read-modify-write
+// are amortised over a K twice as deep: 58.4 -> 61.1 TF at N = 65 536, and the longer panel still hides behind U2)
+// and 512 once it is small enough for the panel chain to show (measured cross-over between N = 16 384 and 32 768).
+static int64_t panel_width(int64_t rem)
 {
-  if(g_nb_outer <= 0) {
+  if(g_nb_outer == 0) {
     const char* e = getenv("GPC_NB");
-    int64_t v = e ? atoll(e) : 0;
-    if(v < JB) v = 512;
-    g_nb_outer = (v / JB) * JB;
+    const int64_t v = e ? atoll(e) : 0;
+    g_nb_outer = (v >= JB) ? (v / JB) * JB : -1;   // -1 = adaptive
   }
-  return g_nb_outer;
+  if(g_nb_outer > 0) return g_nb_outer;
+  static int64_t sw = -1;
+  if(sw < 0) {
+    const char* e = getenv("GPC_NB_SWITCH");
+    sw = e ? atoll(e) : 12288;
+  }
+  return rem >= sw ? 1024 : 512;
 }
 
 int potrf_lower(int64_t N, double* A, int64_t lda, int* d_info, hipStream_t s)
 {
   if(N <= 0) return GPC_OK;
-  const int64_t NB = outer_nb();
   if(g_lookahead < 0) {
     const char* e = getenv("GPC_LOOKAHEAD");
     g_lookahead = e ? (atoi(e) != 0) : 1;
   }
-  const bool la = g_lookahead && N > 2 * NB;
+  const bool la = g_lookahead && N > 2 * panel_width(N);
 
   if(!la) {
-    for(int64_t k0 = 0; k0 < N; k0 += NB) {
-      const int64_t nbk = (N - k0 < NB) ? (N - k0) : NB;
+    int64_t nbk = 0;
+    for(int64_t k0 = 0; k0 < N; k0 += nbk) {
+      const int64_t NB = panel_width(N - k0);
+      nbk = (N - k0 < NB) ? (N - k0) : NB;
       const int64_t kend = k0 + nbk;
       GPC_CHECK(factor_panel(N, A, lda, k0, nbk, d_info, s));
       const int64_t mt = N - kend;
@@ -306,19 +316,21 @@ int potrf_lower(int64_t N, double* A, int64_t lda, int* d_info, hipStream_t s)
   if(!e0) return GPC_EHIP;
   GPC_HIP_CHECK(hipEventRecord(e0, s));           // everything queued before this call (the Gram build, memset of info)
   GPC_HIP_CHECK(hipStreamWaitEvent(sp, e0, 0));
-  GPC_CHECK(factor_panel(N, A, lda, 0, (N < NB ? N : NB), d_info, sp));
+  int64_t nbk = (N < panel_width(N)) ? N : panel_width(N), nb_next = 0;
+  GPC_CHECK(factor_panel(N, A, lda, 0, nbk, d_info, sp));
   hipEvent_t e_panel = g_la.get();
   if(!e_panel) return GPC_EHIP;
   GPC_HIP_CHECK(hipEventRecord(e_panel, sp));
 
-  for(int64_t k0 = 0; k0 < N; k0 += NB) {
-    const int64_t nbk = (N - k0 < NB) ? (N - k0) : NB;
+  for(int64_t k0 = 0; k0 < N; k0 += nbk, nbk = nb_next) {
     const int64_t kend = k0 + nbk;
     const int64_t mt = N - kend;
     if(mt <= 0) break;
+    const int64_t NB = panel_width(mt);
     const double* L21 = A + kend + k0 * lda;
     double* A22 = A + kend + kend * lda;
     const int64_t nb1 = (mt < NB) ? mt : NB;       // width of the next panel
+    nb_next = nb1;
     GPC_HIP_CHECK(hipStreamWaitEvent(s, e_panel, 0));  // panel k is final
     // U1(k): the columns of panel k+1 (lower trapezoid mt x nb1)
     prof_begin(PROF_SYRK, (2.0 * (double)mt - (double)nb1 + 1.0) * (double)nb1 * (double)nbk, s);
@@ -363,7 +375,7 @@ extern "C" int gpc_set_potrf_blocking(int64_t nb_outer, int64_t jb_inner)
     gpc::set_error("outer block must be a positive multiple of 64");
     return GPC_EINVAL;
   }
-  gpc::g_nb_outer = nb_outer;
+  gpc::g_nb_outer = nb_outer;   // fixed from now on (adaptive widths only when never set and GPC_NB is absent)
   return GPC_OK;
 }
 
