@@ -303,3 +303,21 @@ def syrk_blockcyclic(P, C, row0, j0, pstride, nb, alpha=-1.0, beta=1.0):
     check(lib().gpc_syrk_blockcyclic_f64(M, ncols, P.shape[1], alpha, ptr(P), ld(P), beta, ptr(C), ld(C), row0, j0,
                                          pstride, nb, stream()))
     return C
+
+
+# ---- GP-LVM passes (gpc_amd/gplvm.py) --------------------------------------------------------------------------------
+
+def covgrad_multi(invK, A, out=None):
+    """G = -0.5 * (d * invK - A A'), A = invK m (N x d)."""
+    N, d = A.shape
+    cg = out if out is not None else empty(N, N, invK.device)
+    check(lib().gpc_covgrad_multi_f64(N, d, ptr(invK), ld(invK), ptr(A), ld(A), ptr(cg), ld(cg), stream()))
+    return cg
+
+
+def kern_gradx(ks, X, covGrad, out=None):
+    """dL/dX contribution of the kernel: gX(i,q) = sum_n covGrad(n,i) dk(x_i,x_n)/dx_iq (CGplvm.cpp:573-604)."""
+    N, D = X.shape
+    gX = out if out is not None else empty(N, D, X.device)
+    check(lib().gpc_kern_gradx_f64(byref(ks), ptr(X), N, D, ld(X), ptr(covGrad), ld(covGrad), ptr(gX), ld(gX), stream()))
+    return gX

@@ -1,0 +1,190 @@
+// gplvm.hip -- the two extra kernels the GP-LVM objective needs on top of the exact-GP path.
+//
+//  gpc_covgrad_multi_f64   G = sum_j covGrad_j = -0.5 * (d * invK - A A'),  A = invK * m  (N x d)
+//      CGplvm::updateCovGradient (CGplvm.cpp:365-378) is called once per output dimension j and followed, each time,
+//      by a kernel-parameter pass and a dL/dX pass (CGplvm.cpp:585-604).  Both passes are linear in covGrad, so the
+//      d matrices are summed first: one N^2 pass instead of d (HBM: read invK, write G).
+//  gpc_kern_gradx_f64      gX(i,q) = sum_n 2 G(n,i) dk(x_i,x_n)/dx_iq   (n != i)   +   G(i,i) dk(x_i,x_i)/dx_iq
+//      Replaces CCmpndKern::getGradX (CKern.cpp:184-193; N matrices of N x q, components CRbfKern 1115-1135,
+//      CRbfardKern 3268-3293, CLinKern 2291-2308, white/bias: nothing), the x2 / diagonal fix-up of
+//      CGplvm.cpp:573-584 and the N q d dotColCol calls of CGplvm.cpp:597-603 by ONE pass over G (HBM-read bound,
+//      8 N^2 bytes; nothing of size N^2 q is ever formed).  The only kernel with a diagonal derivative is the linear one
+//      (CLinKern::getDiagGradX, CKern.cpp:2310-2322: 2 variance x_i), which is what the n == i term of the sum gives
+//      anyway, so the diagonal needs no special case.
+//
+// Thread layout of the dX kernel: a workgroup owns 64 rows i (lane = row) and a slice of the columns n; its 4 waves
+// take every 4th column of the slice, so x_n is wave-uniform (broadcast loads) and G(i,n) = G(n,i) is read coalesced
+// along i.  Column slices write partial sums that a second tiny kernel adds in a fixed order (deterministic).
+#include "gpc_common.hpp"
+
+namespace gpc {
+
+namespace {
+
+__global__ void __launch_bounds__(256) covgrad_multi_kernel(const double* __restrict__ invK, int64_t ldi,
+                                                            const double* __restrict__ A, int64_t lda, int d,
+                                                            double* __restrict__ cg, int64_t ldc, int64_t N, int64_t j0)
+{
+  const int64_t j = j0 + blockIdx.y;
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if(i >= N) return;
+  double aa = 0.0;
+  for(int k = 0; k < d; k++) aa += A[i + k * lda] * A[j + k * lda];
+  cg[i + j * ldc] = -0.5 * ((double)d * invK[i + j * ldi] - aa);
+}
+
+struct GradXArgs {
+  const double* X;
+  const double* G;
+  double* part;      // [nsplit][D][N]
+  int64_t ldx, ldg, N;
+  int D, nsplit;
+  int64_t cols_per_split;
+};
+
+template <int DMAX>
+__global__ void __launch_bounds__(256) kern_gradx_kernel(const KSpecDev ks, const GradXArgs g)
+{
+  __shared__ double red[3][64][DMAX + 1];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int64_t i = (int64_t)blockIdx.x * 64 + lane;
+  const int64_t ic = (i < g.N) ? i : g.N - 1;   // clamped: loads stay unconditional, the store is masked
+  const int64_t nbeg = (int64_t)blockIdx.y * g.cols_per_split;
+  int64_t nend = nbeg + g.cols_per_split;
+  if(nend > g.N) nend = g.N;
+
+  double xi[DMAX], acc[DMAX];
+#pragma unroll
+  for(int q = 0; q < DMAX; q++) {
+    xi[q] = (q < g.D) ? g.X[ic + (int64_t)q * g.ldx] : 0.0;
+    acc[q] = 0.0;
+  }
+  const bool has_rbf = ks.n_rbf > 0, has_ard = ks.n_ard > 0;
+  const double lin2 = 2.0 * ks.lin_var;
+
+  for(int64_t n = nbeg + w; n < nend; n += 4) {
+    const double gv = g.G[ic + n * g.ldg];   // G(i,n) == G(n,i)
+    double dx[DMAX], xn[DMAX];
+    double d2 = 0.0, d2a = 0.0;
+#pragma unroll
+    for(int q = 0; q < DMAX; q++) {
+      xn[q] = (q < g.D) ? g.X[n + (int64_t)q * g.ldx] : 0.0;   // wave-uniform address
+      dx[q] = xn[q] - xi[q];
+      d2 += dx[q] * dx[q];
+      if(has_ard) d2a += ks.ard_scale[0][q < GPC_MAX_ARD_DIM ? q : 0] * dx[q] * dx[q];
+    }
+    double crbf = 0.0;
+    if(has_rbf) {
+      for(int t = 0; t < ks.n_rbf; t++) crbf += 2.0 * ks.rbf_hiw[t] * ks.rbf_var[t] * exp(-ks.rbf_hiw[t] * d2);
+    }
+    double card = 0.0;
+    if(has_ard) card = 2.0 * ks.ard_hiw[0] * ks.ard_var[0] * exp(-ks.ard_hiw[0] * d2a);
+    const double g2 = 2.0 * gv;
+    const double a = g2 * crbf, b = g2 * card, c = gv * lin2;
+#pragma unroll
+    for(int q = 0; q < DMAX; q++) {
+      double v = a * dx[q] + c * xn[q];
+      if(has_ard) v += b * ks.ard_scale[0][q < GPC_MAX_ARD_DIM ? q : 0] * dx[q];
+      acc[q] += v;
+    }
+  }
+  // add the four waves' partial sums in a fixed order
+  if(w > 0) {
+#pragma unroll
+    for(int q = 0; q < DMAX; q++) red[w - 1][lane][q] = acc[q];
+  }
+  __syncthreads();
+  if(w == 0 && i < g.N) {
+#pragma unroll
+    for(int q = 0; q < DMAX; q++) {
+      if(q < g.D) {
+        const double v = ((acc[q] + red[0][lane][q]) + red[1][lane][q]) + red[2][lane][q];
+        g.part[((int64_t)blockIdx.y * g.D + q) * g.N + i] = v;
+      }
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256) gradx_reduce_kernel(const double* __restrict__ part, int nsplit, int D, int64_t N,
+                                                           double* __restrict__ out, int64_t ldo)
+{
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int q = blockIdx.y;
+  if(i >= N) return;
+  double v = 0.0;
+  for(int s = 0; s < nsplit; s++) v += part[((int64_t)s * D + q) * N + i];
+  out[i + (int64_t)q * ldo] = v;
+}
+
+}  // namespace
+
+}  // namespace gpc
+
+using namespace gpc;
+
+extern "C" int gpc_covgrad_multi_f64(int64_t N, int64_t d, const double* invK, int64_t ldi, const double* A, int64_t lda,
+                                     double* covGrad, int64_t ldc, void* stream)
+{
+  GPC_CHECK(ensure_device());
+  GPC_REQUIRE(N >= 0 && d >= 0 && d <= 4096 && ldi >= (N > 1 ? N : 1) && ldc >= (N > 1 ? N : 1) &&
+                  lda >= (N > 1 ? N : 1),
+              "covgrad_multi dims");
+  if(N == 0) return GPC_OK;
+  hipStream_t s = as_stream(stream);
+  for(int64_t j0 = 0; j0 < N; j0 += 32768) {
+    const int64_t nc = (N - j0 < 32768) ? (N - j0) : 32768;
+    hipLaunchKernelGGL(covgrad_multi_kernel, dim3((unsigned)((N + 255) / 256), (unsigned)nc), dim3(256), 0, s, invK, ldi,
+                       A, lda, (int)d, covGrad, ldc, N, j0);
+  }
+  GPC_HIP_CHECK(hipGetLastError());
+  return GPC_OK;
+}
+
+extern "C" int gpc_kern_gradx_f64(const gpc_kspec* ksp, const double* X, int64_t N, int64_t D, int64_t ldx,
+                                  const double* covGrad, int64_t ldc, double* gX, int64_t ldg, void* stream)
+{
+  GPC_CHECK(ensure_device());
+  GPC_REQUIRE(ksp && N >= 0 && D >= 0 && ldx >= (N > 1 ? N : 1) && ldc >= (N > 1 ? N : 1) && ldg >= (N > 1 ? N : 1),
+              "kern_gradx args");
+  if(D > 16) {
+    set_error("kern_gradx: latent dimension %lld > 16 is outside the accelerated set", (long long)D);
+    return GPC_EUNSUPPORTED;
+  }
+  KSpecDev ks;
+  GPC_CHECK(collapse_kspec(ksp, D, &ks));
+  if(ks.n_ard > 1) {
+    set_error("kern_gradx: at most one rbfard term");
+    return GPC_EUNSUPPORTED;
+  }
+  if(N == 0 || D == 0) return GPC_OK;
+  hipStream_t s = as_stream(stream);
+  const int64_t rb = (N + 63) / 64;
+  int64_t nsplit = (1024 + rb - 1) / rb;               // >= ~1024 workgroups when N allows it
+  const int64_t maxsplit = (N + 15) / 16;              // at least 16 columns (4 per wave) per slice
+  if(nsplit > maxsplit) nsplit = maxsplit;
+  if(nsplit < 1) nsplit = 1;
+  if(nsplit > 65535) nsplit = 65535;
+  GradXArgs g;
+  g.X = X;
+  g.G = covGrad;
+  g.ldx = ldx;
+  g.ldg = ldc;
+  g.N = N;
+  g.D = (int)D;
+  g.cols_per_split = (N + nsplit - 1) / nsplit;
+  nsplit = (N + g.cols_per_split - 1) / g.cols_per_split;
+  g.nsplit = (int)nsplit;
+  void* ws = nullptr;
+  GPC_CHECK(workspace(WS_KERN, sizeof(double) * (size_t)nsplit * (size_t)D * (size_t)N, &ws));
+  g.part = static_cast<double*>(ws);
+  const dim3 grid((unsigned)rb, (unsigned)nsplit);
+  if(D <= 4)
+    hipLaunchKernelGGL(kern_gradx_kernel<4>, grid, dim3(256), 0, s, ks, g);
+  else
+    hipLaunchKernelGGL(kern_gradx_kernel<16>, grid, dim3(256), 0, s, ks, g);
+  GPC_HIP_CHECK(hipGetLastError());
+  hipLaunchKernelGGL(gradx_reduce_kernel, dim3((unsigned)((N + 255) / 256), (unsigned)D), dim3(256), 0, s, g.part,
+                     (int)nsplit, (int)D, N, gX, ldg);
+  GPC_HIP_CHECK(hipGetLastError());
+  return GPC_OK;
+}

@@ -191,6 +191,18 @@ int gpc_gp_posterior_f64(const gpc_kspec* ks, const double* X, int64_t N, int64_
                          const double* Xs, int64_t Ns, int64_t ldxs,
                          double* kX_work, int64_t ldkx, double* mu, int64_t ldmu, double* var, void* stream);
 
+/* ---- GP-LVM objective: the two passes CGplvm adds to the exact-GP path -------------- */
+/* G = sum over the d output dimensions of CGplvm::updateCovGradient (CGplvm.cpp:365-378):
+ * G = -0.5 * (d * invK - A A'), A = invK * m (N x d).  The kernel-parameter and dL/dX passes are linear in covGrad,
+ * so one summed matrix replaces the reference's d separate ones. */
+int gpc_covgrad_multi_f64(int64_t N, int64_t d, const double* invK, int64_t ldi, const double* A, int64_t lda,
+                          double* covGrad, int64_t ldc, void* stream);
+/* gX(i,q) = sum_n covGrad(n,i) * d k(x_i,x_n)/d x_iq, counted as CGplvm.cpp:573-604 counts it (factor 2 off the
+ * diagonal, CKern::getDiagGradX on it): replaces CCmpndKern::getGradX (CKern.cpp:184-193; rbf 1115-1135, rbfard
+ * 3268-3293, lin 2291-2308) and the dotColCol loop.  covGrad symmetric N x N, X and gX N x D (D <= 16). */
+int gpc_kern_gradx_f64(const gpc_kspec* ks, const double* X, int64_t N, int64_t D, int64_t ldx,
+                       const double* covGrad, int64_t ldc, double* gX, int64_t ldg, void* stream);
+
 /* ---- measurement hooks (bench.py) -------------------------------------------------------------------------------
  * When enabled, HIP events bracket every launch of the two dominant kernels on the stream they are launched on:
  * kind 0 = the trailing SYRK update of gpc_potrf_f64 (work unit: flops), kind 1 = the Gram kernel (work unit:

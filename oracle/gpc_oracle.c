@@ -756,3 +756,128 @@ void orc_gp_posterior(orc_gp* gp, const double* Xs, long Ns, double* mu, double*
   }
   free(kX);
 }
+
+/* ---- GP-LVM (no dynamics, no back constraints, scales not learnt) ------------------- */
+
+/* CCmpndKern::getGradX(gX, X, row, X2 = X), CKern.cpp:184-193: gX(k,j) = sum over components of
+ * d k(x_row, x_k) / d x_row,j.  gX is N x D. */
+void orc_kern_gradx_row(const orc_kspec* ks, const double* X, long N, long D, long row, double* gX)
+{
+  int t;
+  long k, j;
+  for(k = 0; k < N * D; k++) gX[k] = 0.0;
+  for(t = 0; t < ks->n_terms; t++) {
+    const double* p = ks->params + ks->offs[t];
+    switch(ks->types[t]) {
+    case ORC_KERN_RBF: { /* CRbfKern::getGradX, CKern.cpp:1115-1135 */
+      const double wi2 = 0.5 * p[0], pf = p[1] * p[0];
+      for(k = 0; k < N; k++) {
+        const double n2 = orc_dist2_row(X, N, row, X, N, k, D);
+        for(j = 0; j < D; j++) gX[k + j * N] += pf * (X[k + j * N] - X[row + j * N]) * exp(-n2 * wi2);
+      }
+      break;
+    }
+    case ORC_KERN_RBFARD: { /* CRbfardKern::getGradX, CKern.cpp:3268-3293 */
+      const double wi2 = 0.5 * p[0], pf = p[1] * p[0];
+      for(k = 0; k < N; k++) {
+        double n2 = 0.0;
+        for(j = 0; j < D; j++) {
+          double x = X[row + j * N];
+          x = x - X[k + j * N];
+          n2 += x * p[2 + j] * x;
+        }
+        for(j = 0; j < D; j++)
+          gX[k + j * N] += pf * (X[k + j * N] - X[row + j * N]) * exp(-n2 * wi2) * p[2 + j];
+      }
+      break;
+    }
+    case ORC_KERN_LIN: /* CLinKern::getGradX, CKern.cpp:2291-2308 */
+      for(k = 0; k < N; k++)
+        for(j = 0; j < D; j++) gX[k + j * N] += p[0] * X[k + j * N];
+      break;
+    default: break; /* white (CKern.cpp:681-690) and bias (968-977) contribute nothing */
+    }
+  }
+}
+
+/* CCmpndKern::getDiagGradX, CKern.cpp:194-203: only the linear kernel has one (2 variance X, CKern.cpp:2310-2322) */
+void orc_kern_diag_gradx(const orc_kspec* ks, const double* X, long N, long D, double* gD)
+{
+  int t;
+  long k;
+  for(k = 0; k < N * D; k++) gD[k] = 0.0;
+  for(t = 0; t < ks->n_terms; t++)
+    if(ks->types[t] == ORC_KERN_LIN)
+      for(k = 0; k < N * D; k++) gD[k] += 2.0 * ks->params[ks->offs[t]] * X[k];
+}
+
+/* CGplvm::updateK + logLikelihood + logLikelihoodGradient, CGplvm.cpp:402-446, 493-553, 555-716, for the plain model
+ * gplvm.cpp builds by default (dynamicsLearnt = backConstrained = inputScaleLearnt = false).
+ *   m: N x d centred data (CScaleNoise::updateSites, CNoise.cpp:710-721), X: N x q latent points.
+ *   g (may be NULL): nk transformed-kernel-parameter gradients, then dL/dX column by column (CGplvm.cpp:257-290).
+ * Returns the log-likelihood (which, unlike CGp's, carries no -dN/2 log 2 pi term); *info = chol's LAPACK info. */
+double orc_gplvm_loglik_grad(const orc_kspec* ks, const double* m, long N, long d, const double* X, long q,
+                             int regularise, double* g, double* logdet_out, int* info)
+{
+  const int nk = ks->offs[ks->n_terms];
+  const size_t NN = (size_t)N * N;
+  double* K = (double*)malloc(sizeof(double) * NN);
+  double* U = (double*)malloc(sizeof(double) * NN);
+  double* invK = (double*)malloc(sizeof(double) * NN);
+  double* invKm = (double*)malloc(sizeof(double) * N);
+  double L = 0.0, logDetK;
+  long i, j, c, k;
+  orc_gram_sym(ks, X, N, q, K);                        /* _updateK, CGplvm.cpp:418-432 */
+  memcpy(U, K, sizeof(double) * NN);                   /* _updateInvK, 435-446: chol (no jitter), logDet, pdinv */
+  *info = orc_chol('U', N, U, N);
+  if(*info != 0) {
+    free(K); free(U); free(invK); free(invKm);
+    return 0.0;
+  }
+  logDetK = orc_logdet(N, U, N);
+  if(logdet_out) *logdet_out = logDetK;
+  orc_pdinv_upper(N, U, invK);
+  for(j = 0; j < d; j++) {                             /* logLikelihood, 493-553 */
+    orc_symv_upper(N, invK, m + (size_t)j * N, invKm);
+    L += dot(N, invKm, 1, m + (size_t)j * N, 1);
+    L += logDetK;
+  }
+  if(regularise)
+    for(j = 0; j < q; j++) {
+      const double n = nrm2(N, X + (size_t)j * N, 1);  /* norm2Col = dnrm2^2 */
+      L += n * n;
+    }
+  L *= -0.5;
+  if(g) {                                              /* logLikelihoodGradient, 555-716 */
+    double* covGrad = (double*)malloc(sizeof(double) * NN);
+    double* gXi = (double*)malloc(sizeof(double) * (size_t)N * q);
+    double* gD = (double*)malloc(sizeof(double) * (size_t)N * q);
+    double* tmp = (double*)malloc(sizeof(double) * (nk > 0 ? nk : 1));
+    for(k = 0; k < nk + N * q; k++) g[k] = 0.0;
+    orc_kern_diag_gradx(ks, X, N, q, gD);
+    for(j = 0; j < d; j++) {
+      orc_symv_upper(N, invK, m + (size_t)j * N, invKm);   /* updateCovGradient, 365-378 */
+      for(c = 0; c < N; c++)
+        for(i = 0; i <= c; i++) {
+          const double v = -0.5 * (invK[i + (size_t)c * N] - invKm[i] * invKm[c]);
+          covGrad[i + (size_t)c * N] = v;
+          covGrad[c + (size_t)i * N] = v;
+        }
+      orc_kern_grad_sym(ks, X, N, q, covGrad, tmp);
+      orc_grad_to_trans(ks, q, tmp);
+      for(k = 0; k < nk; k++) g[k] += tmp[k];
+      for(i = 0; i < N; i++) {
+        orc_kern_gradx_row(ks, X, N, q, i, gXi);
+        for(k = 0; k < N * q; k++) gXi[k] *= 2.0;         /* "accounts for symmetric covariance", 577 */
+        for(k = 0; k < q; k++) gXi[i + k * N] = gD[i + k * N];
+        for(k = 0; k < q; k++) g[nk + i + N * k] += dot(N, gXi + (size_t)k * N, 1, covGrad + (size_t)i * N, 1);
+      }
+    }
+    if(regularise)
+      for(i = 0; i < N; i++)
+        for(k = 0; k < q; k++) g[nk + i + N * k] += -X[i + N * k];
+    free(covGrad); free(gXi); free(gD); free(tmp);
+  }
+  free(K); free(U); free(invK); free(invKm);
+  return L;
+}

@@ -87,4 +87,10 @@ void orc_gp_update_alpha(orc_gp* gp);                 /* CGp::updateAlpha */
 double orc_gp_loglik(orc_gp* gp);                     /* CGp::logLikelihood */
 double orc_gp_loglik_grad(orc_gp* gp, double* g);     /* CGp::logLikelihoodGradient (transformed kernel params) */
 void orc_gp_posterior(orc_gp* gp, const double* Xs, long Ns, double* mu, double* var); /* posteriorMeanVar */
+
+/* ---- CGplvm (plain model: no dynamics / back constraints / learnt scales) ----------------------------------------- */
+void orc_kern_gradx_row(const orc_kspec* ks, const double* X, long N, long D, long row, double* gX);
+void orc_kern_diag_gradx(const orc_kspec* ks, const double* X, long N, long D, double* gD);
+double orc_gplvm_loglik_grad(const orc_kspec* ks, const double* m, long N, long d, const double* X, long q,
+                             int regularise, double* g, double* logdet_out, int* info);
 #endif

@@ -1,7 +1,7 @@
 /* oracle_driver.c -- command-line front end of the plain-C restatement (gpc_oracle.c), speaking the same GPCB1
  * container and the same modes as oracle/ref_driver.cpp so that tests can run both side by side.
  *
- * TEST INFRASTRUCTURE ONLY.  Usage: oracle_driver <kern|gp|time|chol|trsm> <in.gpcb> <out.gpcb>
+ * TEST INFRASTRUCTURE ONLY.  Usage: oracle_driver <kern|gp|time|chol|trsm|gplvm> <in.gpcb> <out.gpcb>
  */
 #include <stdio.h>
 #include <stdlib.h>
@@ -198,11 +198,46 @@ static int run_trsm(const gpcb_file* in, const char* out)
   return 0;
 }
 
+/* same inputs as ref_driver's gplvm mode: Y (N x d, centred here as CScaleNoise does with bias = meanCol(Y), scale 1),
+ * X (N x q), kernel, optional regularise flag -> ll, g, logdet, m */
+static int run_gplvm(const gpcb_file* in, const char* out)
+{
+  const gpcb_array *Y = gpcb_need(in, "Y"), *X = gpcb_need(in, "X"), *reg = gpcb_find(in, "regularise");
+  const long N = Y->rows, d = Y->cols, q = X->cols;
+  orc_kspec ks;
+  int nk, info = 0;
+  long i, j;
+  double *m, *g, ll, logdet = 0.0, infod;
+  FILE* fp;
+  build_kspec(in, q, &ks);
+  nk = ks.offs[ks.n_terms];
+  m = malloc(sizeof(double) * N * d);
+  g = malloc(sizeof(double) * (nk + N * q));
+  for(j = 0; j < d; j++) {
+    double mean = 0.0;   /* meanCol: sum / nrows (CMatrix.cpp sumCol then scale) */
+    for(i = 0; i < N; i++) mean += Y->data[i + j * N];
+    mean /= (double)N;
+    for(i = 0; i < N; i++) m[i + j * N] = (Y->data[i + j * N] - mean) / 1.0;
+  }
+  ll = orc_gplvm_loglik_grad(&ks, m, N, d, X->data, q, reg ? reg->data[0] != 0.0 : 1, g, &logdet, &info);
+  infod = (double)info;
+  fp = gpcb_open_write(out);
+  gpcb_write(fp, "ll", 1, 1, &ll);
+  gpcb_write(fp, "g", 1, nk + N * q, g);
+  gpcb_write(fp, "logdet", 1, 1, &logdet);
+  gpcb_write(fp, "info", 1, 1, &infod);
+  gpcb_write(fp, "m", N, d, m);
+  fclose(fp);
+  free(m);
+  free(g);
+  return 0;
+}
+
 int main(int argc, char** argv)
 {
   gpcb_file in;
   if(argc != 4) {
-    fprintf(stderr, "usage: oracle_driver <kern|gp|time|chol|trsm> <in.gpcb> <out.gpcb>\n");
+    fprintf(stderr, "usage: oracle_driver <kern|gp|time|chol|trsm|gplvm> <in.gpcb> <out.gpcb>\n");
     return 2;
   }
   if(gpcb_read(argv[2], &in) != 0) {
@@ -214,6 +249,7 @@ int main(int argc, char** argv)
   if(strcmp(argv[1], "time") == 0) return run_time(&in, argv[3]);
   if(strcmp(argv[1], "chol") == 0) return run_chol(&in, argv[3]);
   if(strcmp(argv[1], "trsm") == 0) return run_trsm(&in, argv[3]);
+  if(strcmp(argv[1], "gplvm") == 0) return run_gplvm(&in, argv[3]);
   fprintf(stderr, "oracle_driver: unknown mode %s\n", argv[1]);
   return 2;
 }

@@ -45,3 +45,11 @@ def trsm(A, B, side, uplo, trans, diag, alpha):
     _need()
     flags = [side.upper() == "L", uplo.upper() == "U", trans.upper() != "N", diag.upper() == "U"]
     return refrun.run_port("trsm", {"A": A, "B": B, "flags": np.array(flags, dtype=float), "alpha": alpha})["X"]
+
+
+def gplvm(terms, Y, X, regularise=True):
+    """CGplvm objective + gradient (plain model) at latent points X: dict with ll, g, logdet, info, m."""
+    _need()
+    arrays = dict(refrun.kern_arrays(terms))
+    arrays.update({"Y": Y, "X": X, "regularise": 1.0 if regularise else 0.0})
+    return refrun.run_port("gplvm", arrays)

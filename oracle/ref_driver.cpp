@@ -10,7 +10,7 @@
 // mirrors: CCmpndKern + addKern, CGaussianNoise, CGp(kern, noise, X, FTC, -1, verbosity), setScale/setBias,
 // updateM).  C++98 on purpose: the reference only compiles with -std=gnu++98.
 //
-// Usage: ref_driver <kern|gp|time> <in.gpcb> <out.gpcb>
+// Usage: ref_driver <kern|gp|time|gplvm> <in.gpcb> <out.gpcb>
 #include <sys/time.h>
 #include <iostream>
 #include <vector>
@@ -18,6 +18,7 @@
 #include "CKern.h"
 #include "CNoise.h"
 #include "CGp.h"
+#include "CGplvm.h"
 extern "C" {
 #include "gpcb_io.h"
 }
@@ -227,6 +228,73 @@ static int runTime(const gpcb_file& in, const char* outPath)
   return 0;
 }
 
+// GP-LVM: construction order of gplvm.cpp:364-545 (kernel on the latent X, CScaleNoise
+// centred / unscaled, CGplvm(kern, noise, q, verbosity) whose constructor runs the PCA initialisation), then the
+// objective and its gradient at the given point and, optionally, an SCG run.
+struct GplvmPeek : public CGplvm   // logDetK is protected (CGplvm.h:283)
+{
+  GplvmPeek(CKern* k, CScaleNoise* n, int q, int v) : CGplvm(k, n, q, v) {}
+  double logDet() const { return logDetK; }
+};
+
+static int runGplvm(const gpcb_file& in, const char* outPath)
+{
+  CMatrix Y;
+  toCMatrix(Y, gpcb_need(&in, "Y"));
+  const int q = (int)gpcb_need(&in, "latent_dim")->data[0];
+  const gpcb_array* xin = gpcb_find(&in, "X");
+  const gpcb_array* it = gpcb_find(&in, "iters");
+  const gpcb_array* reg = gpcb_find(&in, "regularise");
+  CMatrix X(Y.getRows(), q);
+  CCmpndKern kern(X);
+  buildKern(kern, X, in);
+  CScaleNoise noise(&Y);
+  CMatrix params(1, 2 * Y.getCols());
+  noise.getParams(params);
+  for(unsigned int j = 0; j < Y.getCols(); j++)
+    params.setVal(1.0, j + Y.getCols());   // centreData = true, scaleData = false (gplvm.cpp:106-107)
+  noise.setParams(params);
+  GplvmPeek model(&kern, &noise, q, 0);
+  if(reg) model.setLatentRegularised(reg->data[0] != 0.0);
+
+  FILE* fp = gpcb_open_write(outPath);
+  writeCMatrix(fp, "X_pca", *model.pX);
+  writeCMatrix(fp, "m", model.m);
+  CMatrix p(1, model.getOptNumParams());
+  model.getOptParams(p);
+  if(xin)
+  {
+    const unsigned int nk = kern.getNumParams();
+    for(int64_t j = 0; j < xin->cols; j++)
+      for(int64_t i = 0; i < xin->rows; i++)
+        p.setVal(xin->data[i + xin->rows * j], nk + (unsigned int)(i + xin->rows * j));
+    model.setOptParams(p);
+  }
+  writeCMatrix(fp, "params0", p);
+  CMatrix g(1, model.getOptNumParams());
+  const double ll = model.logLikelihoodGradient(g);
+  CMatrix llm(1, 1, ll);
+  writeCMatrix(fp, "ll", llm);
+  writeCMatrix(fp, "g", g);
+  CMatrix ld(1, 1, model.logDet());
+  writeCMatrix(fp, "logdet", ld);
+  if(it && it->data[0] > 0)
+  {
+    model.setDefaultOptimiser(CGplvm::SCG);
+    model.optimise((int)it->data[0]);
+    model.getOptParams(p);
+    writeCMatrix(fp, "params_final", p);
+    writeCMatrix(fp, "X_final", *model.pX);
+    CMatrix llf(1, 1, model.logLikelihood());
+    writeCMatrix(fp, "ll_final", llf);
+    CMatrix np(1, kern.getNumParams());
+    kern.getParams(np);
+    writeCMatrix(fp, "kern_final", np);
+  }
+  fclose(fp);
+  return 0;
+}
+
 int main(int argc, char* argv[])
 {
   if(argc != 4)
@@ -246,6 +314,7 @@ int main(int argc, char* argv[])
     if(mode == "kern") return runKern(in, argv[3]);
     if(mode == "gp") return runGp(in, argv[3]);
     if(mode == "time") return runTime(in, argv[3]);
+    if(mode == "gplvm") return runGplvm(in, argv[3]);
     std::cerr << "ref_driver: unknown mode " << mode << std::endl;
     return 2;
   }

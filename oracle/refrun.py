@@ -54,3 +54,14 @@ def kern_arrays(kern):
     types = [KERN_CODES[t] for t, _ in kern]
     params = [p for _, ps in kern for p in ps]
     return {"kern_types": types, "kern_params": params}
+
+
+def gplvm_ref(terms, Y, latent_dim, X=None, iters=0, regularise=True, threads=None):
+    """The compiled reference's CGplvm: PCA init (X_pca), objective/gradient at X (default: the PCA init) and,
+    with iters > 0, an SCG run (params_final, X_final, ll_final, kern_final)."""
+    arrays = dict(kern_arrays(terms))
+    arrays.update({"Y": Y, "latent_dim": float(latent_dim), "iters": float(iters),
+                   "regularise": 1.0 if regularise else 0.0})
+    if X is not None:
+        arrays["X"] = X
+    return run_ref("gplvm", arrays, threads=threads)

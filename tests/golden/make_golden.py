@@ -171,6 +171,67 @@ def sinc_golden():
          kern_params=np.array(flat[2:6]), noise_params=np.array(flat[6:8]))
 
 
+def read_svml(path, nrows=None):
+    """SVMlight rows `label idx:val ...` -> (Y dense, labels); missing features are 0 (CClctrl.cpp:57-180)."""
+    rows, labs = [], []
+    for line in open(path):
+        line = line.split("#")[0].strip()
+        if not line:
+            continue
+        parts = line.split()
+        labs.append(float(parts[0]))
+        rows.append({int(t.split(":")[0]): float(t.split(":")[1]) for t in parts[1:]})
+        if nrows and len(rows) >= nrows:
+            break
+    D = max(max(r) for r in rows)
+    Y = np.zeros((len(rows), D))
+    for i, r in enumerate(rows):
+        for k, v in r.items():
+            Y[i, k - 1] = v
+    return Y, np.array(labs)
+
+
+def gplvm_golden():
+    """Config 5 (GP-LVM on examples/oilTrain.svml): the compiled reference's CGplvm on the oil data.
+      * N = 200 (first rows): PCA initialisation, objective and full gradient at the PCA point and at a perturbed
+        point, for the `-k rbf -i 1` kernel (rbfard+bias+white at its initial parameters), the default rbf+bias+white
+        and a compound with a linear term (the only kernel with a diagonal dk/dX);
+      * N = 1000: objective/gradient at the PCA point and the end state of `gplvm learn -k rbf -i 1 -# 100` (the
+        reference stops after 16 SCG iterations by its own convergence test)."""
+    import shutil
+    src = "/root/reference/examples/oilTrain.svml"
+    dst = os.path.join(OUT, "oilTrain.svml")          # a data file of the reference, kept as a fixture
+    if os.path.exists(src):
+        shutil.copyfile(src, dst)
+    Yall, labs = read_svml(dst)
+    e2 = float(np.exp(-2.0))
+    kerns = {"ard": [("rbfard", [1.0, 1.0, 0.5, 0.5]), ("bias", [e2]), ("white", [e2])],
+             "rbf": [("rbf", [1.0, 1.0]), ("bias", [e2]), ("white", [e2])],
+             "lin": [("rbf", [2.0, 0.7]), ("lin", [0.3]), ("bias", [0.1]), ("white", [0.05])]}
+    out = {}
+    Y = Yall[:200]
+    rng = np.random.RandomState(5)
+    for name, terms in kerns.items():
+        r = refrun.gplvm_ref(terms, Y, 2)
+        Xp = r["X_pca"] + 0.05 * rng.randn(*r["X_pca"].shape)
+        r2 = refrun.gplvm_ref(terms, Y, 2, X=Xp)
+        out.update({"n200_%s_ll" % name: r["ll"], "n200_%s_g" % name: r["g"], "n200_%s_logdet" % name: r["logdet"],
+                    "n200_%s_Xp" % name: Xp, "n200_%s_ll_p" % name: r2["ll"], "n200_%s_g_p" % name: r2["g"]})
+        out["n200_X_pca"] = r["X_pca"]
+        out["n200_m"] = r["m"]
+    r = refrun.gplvm_ref(kerns["ard"], Yall, 2, iters=100)
+    out.update({"n1000_X_pca": r["X_pca"], "n1000_ll": r["ll"], "n1000_g": r["g"], "n1000_logdet": r["logdet"],
+                "n1000_params_final": r["params_final"], "n1000_X_final": r["X_final"],
+                "n1000_ll_final": r["ll_final"], "n1000_kern_final": r["kern_final"]})
+    print("reference end state: kern", r["kern_final"], "ll", r["ll_final"])
+    save("gplvm_oil", **out)
+
+
 if __name__ == "__main__":
-    main()
-    sinc_golden()
+    what = sys.argv[1] if len(sys.argv) > 1 else "all"
+    if what in ("all", "main"):
+        main()
+    if what in ("all", "sinc"):
+        sinc_golden()
+    if what in ("all", "gplvm"):
+        gplvm_golden()
