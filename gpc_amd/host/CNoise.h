@@ -1,5 +1,6 @@
-// CNoise.h -- the Gaussian noise model of the FTC path (reference CNoise.h / CNoise.cpp:330-500): it only supplies
-// the output bias and sigma2 that CGp::out adds to the predictive mean / variance.
+// CNoise.h -- the noise models of the accelerated paths: CGaussianNoise for CGp (reference CNoise.cpp:330-500: it only
+// supplies the output bias and sigma2 that CGp::out adds to the predictive mean / variance) and CScaleNoise for CGplvm
+// (CNoise.h:399-470, CNoise.cpp:539-790: per-output bias and scale that turn the targets into the centred matrix m).
 #ifndef GPC_AMD_CNOISE_H
 #define GPC_AMD_CNOISE_H
 #include <cmath>
@@ -65,5 +66,94 @@ class CGaussianNoise : public CNoise {
  private:
   double sigma2;
   CMatrix bias;
+};
+
+// CScaleNoise (reference CNoise.h:399-470): m = (y - bias) / scale, bias = meanCol(y), scale = sqrt(varCol(y)) clipped at
+// EPS (initParams, CNoise.cpp:576-587); gplvm.cpp:498-507 then resets bias to 0 unless -C 1 and scale to 1 unless -S 1.
+class CScaleNoise : public CNoise {
+ public:
+  explicit CScaleNoise(CMatrix* pyin) : sigma2(1e-6), bias(1, pyin->getCols(), 0.0), scale(1, pyin->getCols(), 1.0)
+  {
+    py = pyin;
+    const unsigned int N = py->getRows();
+    for(unsigned int j = 0; j < py->getCols(); j++) {
+      double s = 0.0;
+      for(unsigned int i = 0; i < N; i++) s += py->getVal(i, j);
+      const double mean = s / (double)N;
+      double v = 0.0;   // varCol: mean of squares minus squared mean (CMatrix.cpp varCol)
+      for(unsigned int i = 0; i < N; i++) v += py->getVal(i, j) * py->getVal(i, j);
+      v = v / (double)N - mean * mean;
+      double sd = std::sqrt(v);
+      if(!(sd >= 2.220446049250313e-16)) sd = 2.220446049250313e-16;
+      bias.setVal(mean, 0, j);
+      scale.setVal(sd, 0, j);
+    }
+  }
+  std::string getType() const { return "scale"; }
+  unsigned int getOutputDim() const { return py->getCols(); }
+  unsigned int getNumParams() const { return 2 * getOutputDim(); }
+  double getBias(unsigned int j) const { return bias.getVal(0, j); }
+  void setBias(double v, unsigned int j) { bias.setVal(v, 0, j); }
+  double getScale(unsigned int j) const { return scale.getVal(0, j); }
+  void setScale(double v, unsigned int j) { scale.setVal(v, 0, j); }
+  double getTarget(unsigned int i, unsigned int j) const { return py->getVal(i, j); }
+  void getParams(CMatrix& p) const   // [bias..., scale...], CNoise.cpp:636-646
+  {
+    for(unsigned int j = 0; j < getOutputDim(); j++) {
+      p.setVal(bias.getVal(0, j), 0, j);
+      p.setVal(scale.getVal(0, j), 0, j + getOutputDim());
+    }
+  }
+  void setParams(const CMatrix& p)   // CNoise.cpp:611-625
+  {
+    for(unsigned int j = 0; j < getOutputDim(); j++) {
+      bias.setVal(p.getVal(0, j), 0, j);
+      scale.setVal(p.getVal(0, j + getOutputDim()), 0, j);
+    }
+  }
+  // CScaleNoise::updateSites for every row (CNoise.cpp:710-721): m = (y - bias) ./ scale
+  void computeM(CMatrix& m) const
+  {
+    m.resize(py->getRows(), py->getCols());
+    for(unsigned int j = 0; j < py->getCols(); j++)
+      for(unsigned int i = 0; i < py->getRows(); i++)
+        m.setVal((py->getVal(i, j) - bias.getVal(0, j)) / scale.getVal(0, j), i, j);
+  }
+  // CScaleNoise::out, CNoise.cpp:736-753: y = mu * scale + bias
+  void out(CMatrix& yPred, const CMatrix& mu, const CMatrix&) const
+  {
+    for(unsigned int i = 0; i < yPred.getRows(); i++)
+      for(unsigned int j = 0; j < yPred.getCols(); j++)
+        yPred.setVal(mu.getVal(i, j) * scale.getVal(0, j) + bias.getVal(0, j), i, j);
+  }
+  void out(CMatrix& yPred, CMatrix& errorBar, const CMatrix& mu, const CMatrix& varSigma) const
+  {
+    out(yPred, mu, varSigma);
+    for(unsigned int i = 0; i < yPred.getRows(); i++)
+      for(unsigned int j = 0; j < yPred.getCols(); j++)
+        errorBar.setVal(std::sqrt(varSigma.getVal(i, j) + sigma2) * scale.getVal(0, j), i, j);
+  }
+  void writeParamsToStream(std::ostream& out) const
+  {
+    out << "baseType=noise" << std::endl << "type=scale" << std::endl;
+    out << "outputDim=" << getOutputDim() << std::endl << "numParams=" << getNumParams() << std::endl;
+    CMatrix par(1, getNumParams());
+    getParams(par);
+    out << "version=0.200000" << std::endl;
+    par.writeParamsToStream(out);
+  }
+  std::ostream& display(std::ostream& os) const   // CNoise.cpp:588-601
+  {
+    os << "Scale Noise: " << std::endl;
+    for(unsigned int j = 0; j < bias.getCols(); j++) {
+      os << "Bias on process " << j << ": " << bias.getVal(0, j) << std::endl;
+      os << "Scale on process " << j << ": " << scale.getVal(0, j) << std::endl;
+    }
+    return os;
+  }
+
+ private:
+  double sigma2;
+  CMatrix bias, scale;
 };
 #endif

@@ -1,0 +1,207 @@
+// gplvm.cpp -- the `gplvm` command line (reference gplvm.cpp:3-933) for the accelerated GP-LVM path:
+//     gplvm [-v verbosity] [-s seed] learn [flags] trainData.svml [modelFile]
+// Same flags, defaults and model construction as the reference's `learn` (gplvm.cpp:86-560) for what the HIP path
+// covers: kernel = cmpnd{ <-k kernels, default rbf>, bias, white } on a q-dimensional latent space (-x, default 2),
+// CScaleNoise centred (-C) and optionally scaled (-S), PCA initialisation, latent regulariser (-R), SCG.
+// Dynamics (-D), back constraints (-c) and learnt scales (-L 1) are outside the hot path and rejected.
+#include <cstdlib>
+#include <iostream>
+#include <string>
+#include <vector>
+#include <sys/time.h>
+#include "CClctrl.h"
+#include "CGplvm.h"
+#include "CKern.h"
+#include "CNoise.h"
+
+class CClgplvm : public CClctrl {
+ public:
+  CClgplvm(int argc, char** argv) : CClctrl(argc, argv) {}
+  void learn();
+  void helpInfo();
+};
+
+void CClgplvm::helpInfo()
+{
+  std::cout << "gplvm [-v verbosity] [-s seed] learn [-x latentDim] [-k kernel [-g gamma] [-v variance] [-i 0|1]]...\n"
+               "      [-C 0|1] [-S 0|1] [-R 0|1] [-# iterations] [-O scg] trainData.svml [modelFile]\n"
+               "kernels: rbf (with -i 1: rbfard), lin.  bias and white terms are always appended.\n";
+}
+
+static double nowSeconds()
+{
+  struct timeval tv;
+  gettimeofday(&tv, 0);
+  return tv.tv_sec + 1e-6 * tv.tv_usec;
+}
+
+void CClgplvm::learn()
+{
+  incrementArgument();
+  setMode("learn");
+  std::string optimiser = "scg", modelFileName = "gplvm_model", initialisationType = "pca";
+  std::vector<std::string> kernelTypes;
+  std::vector<double> rbfInvWidths, variances;
+  std::vector<bool> selectInputs;
+  bool centreData = true, scaleData = false, regulariseLatent = true, inputScaleLearnt = false;
+  int iters = 1000, latentDim = 2;
+  while(isFlags()) {
+    if(isCurrentArgumentFlag()) {
+      if(isCurrentArg("-?", "--?") || isCurrentArg("-h", "--help")) { helpInfo(); exitNormal(); }
+      else if(isCurrentArg("-x", "--latent-dim")) { incrementArgument(); latentDim = getIntFromCurrentArgument(); }
+      else if(isCurrentArg("-c", "--constrained")) exitError("Back constraints are outside the accelerated GP-LVM path.");
+      else if(isCurrentArg("-D", "--dynamics-kernel")) exitError("Dynamics are outside the accelerated GP-LVM path.");
+      else if(isCurrentArg("-C", "--Centre-data")) { incrementArgument(); centreData = getBoolFromCurrentArgument(); }
+      else if(isCurrentArg("-I", "--Initialise")) { incrementArgument(); initialisationType = getCurrentArgument(); }
+      else if(isCurrentArg("-L", "--Learn-scales")) { incrementArgument(); inputScaleLearnt = getBoolFromCurrentArgument(); }
+      else if(isCurrentArg("-R", "--Regularise")) { incrementArgument(); regulariseLatent = getBoolFromCurrentArgument(); }
+      else if(isCurrentArg("-S", "--Scale-data")) { incrementArgument(); scaleData = getBoolFromCurrentArgument(); }
+      else if(isCurrentArg("-O", "--optimiser")) { incrementArgument(); optimiser = getCurrentArgument(); }
+      else if(isCurrentArg("-k", "--kernel")) {
+        incrementArgument();
+        kernelTypes.push_back(getCurrentArgument());
+        rbfInvWidths.push_back(-1.0);
+        variances.push_back(-1.0);
+        selectInputs.push_back(false);
+      }
+      else if(isCurrentArg("-g", "--gamma")) {
+        incrementArgument();
+        if(kernelTypes.empty()) exitError("Inverse width specification must come after kernel type is specified.");
+        if(kernelTypes.back() != "rbf") exitError("Inverse width parameter only valid for RBF kernel.");
+        rbfInvWidths.back() = 2 * getDoubleFromCurrentArgument();   // gplvm.cpp:238
+      }
+      else if(isCurrentArg("-v", "--variance")) {
+        incrementArgument();
+        if(kernelTypes.empty()) exitError("Variance parameter specification must come after kernel type is specified.");
+        variances.back() = getDoubleFromCurrentArgument();
+      }
+      else if(isCurrentArg("-i", "--input-select")) {
+        incrementArgument();
+        if(kernelTypes.empty()) exitError("Input selection flag must come after kernel type is specified.");
+        selectInputs.back() = getBoolFromCurrentArgument();
+      }
+      else if(isCurrentArg("-#", "--#iterations")) { incrementArgument(); iters = getIntFromCurrentArgument(); }
+      else if(isCurrentArg("-f", "--file-format")) { incrementArgument(); setFileFormat(getIntFromCurrentArgument()); }
+      else unrecognisedFlag();
+      incrementArgument();
+    } else {
+      setFlags(false);
+    }
+  }
+  if(getCurrentArgumentNo() >= argc) exitError("There are not enough input parameters.");
+  const std::string trainDataFileName = getCurrentArgument();
+  if(getCurrentArgumentNo() + 1 < argc) modelFileName = argv[getCurrentArgumentNo() + 1];
+  if(optimiser != "scg") exitError("Unrecognised model optimiser type (scg is the one provided).");
+  if(initialisationType != "pca") exitError("Unknown initialisation type: " + initialisationType);
+  if(inputScaleLearnt) exitError("Learnt scales are outside the accelerated GP-LVM path.");
+
+  CMatrix Y, labs;
+  readData(Y, labs, trainDataFileName);
+  // integer class labels are carried into the model file only (gplvm.cpp:345-362)
+  std::vector<int> labels;
+  bool labelsProvided = true;
+  for(unsigned int i = 0; i < labs.getRows() && labelsProvided; i++) {
+    const double val = labs.getVal(i);
+    const int intVal = (int)val;
+    if((val - (double)intVal) != 0) {
+      std::cout << "Ignoring data labels." << std::endl;
+      labelsProvided = false;
+      labels.clear();
+    } else {
+      labels.push_back(intVal);
+    }
+  }
+
+  CMatrix X(Y.getRows(), latentDim);
+  CCmpndKern kern(X);
+  for(size_t i = 0; i < kernelTypes.size(); i++) {
+    CKern* k = 0;
+    if(kernelTypes[i] == "rbf") {
+      if(selectInputs[i]) k = new CRbfardKern(X);
+      else k = new CRbfKern(X);
+      if(rbfInvWidths[i] != -1.0) k->setParam(rbfInvWidths[i], 0);
+      if(variances[i] != -1.0) k->setParam(variances[i], 1);
+    } else if(kernelTypes[i] == "lin") {
+      if(selectInputs[i]) exitError("linard is outside the accelerated kernel set.");
+      k = new CLinKern(X);
+      if(variances[i] != -1.0) k->setParam(variances[i], 0);
+    } else {
+      exitError("Unknown kernel type: " + kernelTypes[i] + " (accelerated set: rbf, lin; bias and white are always added).");
+    }
+    kern.addKern(k);
+    delete k;
+  }
+  if(kern.getNumKerns() == 0) {   // gplvm.cpp:466-473
+    CRbfKern defaultKern(X);
+    kern.addKern(&defaultKern);
+  }
+  CBiasKern biasKern(X);
+  CWhiteKern whiteKern(X);
+  kern.addKern(&biasKern);
+  kern.addKern(&whiteKern);
+
+  CScaleNoise noise(&Y);
+  for(unsigned int j = 0; j < Y.getCols(); j++) {   // gplvm.cpp:498-507
+    if(!centreData) noise.setBias(0.0, j);
+    if(!scaleData) noise.setScale(1.0, j);
+  }
+
+  CGplvm model(&kern, &noise, latentDim, getVerbosity());
+  model.setLatentRegularised(regulariseLatent);
+  std::cout << "Optimiser is " << optimiser;
+  model.setDefaultOptimiser(CGplvm::SCG);
+  const double t0 = nowSeconds();
+  model.optimise(iters);
+  const double t1 = nowSeconds();
+  if(labelsProvided) model.setLabels(labels);
+
+  std::string comment = "Run as:";
+  for(int i = 0; i < argc; i++) {
+    comment += " ";
+    comment += argv[i];
+  }
+  comment += " with seed " + std::to_string(getSeed()) + ".";
+  writeGplvmToFile(model, modelFileName, comment);
+  if(getVerbosity() > 1) {
+    const unsigned int evals = model.funcEvals + model.gradEvals;
+    std::cout << "Objective evaluations: " << model.funcEvals << "  gradient evaluations: " << model.gradEvals
+              << "  SCG iterations: " << model.getIterations() << std::endl;
+    std::cout << "Optimisation wall time: " << (t1 - t0) << " s  (" << (evals > 0 ? evals / (t1 - t0) : 0.0)
+              << " kernel-rebuild + Cholesky evaluations/s)" << std::endl;
+    const std::streamsize prec = std::cout.precision(15);
+    std::cout << "Final log likelihood: " << model.logLikelihood() << std::endl;
+    std::cout.precision(prec);
+  }
+}
+
+int main(int argc, char* argv[])
+{
+  CClgplvm command(argc, argv);
+  command.setFlags(true);
+  command.setVerbosity(2);
+  command.setSeed(0);
+  command.setMode("gplvm");
+  try {
+    while(command.isFlags()) {
+      if(command.isCurrentArgumentFlag()) {
+        if(command.isCurrentArg("-?", "--?") || command.isCurrentArg("-h", "--help")) { command.helpInfo(); return 0; }
+        else if(command.isCurrentArg("-v", "--verbosity")) { command.incrementArgument(); command.setVerbosity(command.getIntFromCurrentArgument()); }
+        else if(command.isCurrentArg("-s", "--seed")) { command.incrementArgument(); command.setSeed(command.getIntFromCurrentArgument()); }
+        else command.unrecognisedFlag();
+        command.incrementArgument();
+      } else if(command.getCurrentArgumentNo() < argc && command.getCurrentArgument() == "learn") {
+        command.learn();
+        return 0;
+      } else {
+        command.exitError("Invalid gplvm command provided (this build implements `learn`).");
+      }
+    }
+  } catch(ndlexceptions::Error& err) {
+    command.exitError(err.getMessage());
+  } catch(std::bad_alloc&) {
+    command.exitError("Out of memory.");
+  } catch(std::exception& err) {
+    command.exitError(std::string("Unhandled exception: ") + err.what());
+  }
+  return 0;
+}

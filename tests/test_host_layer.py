@@ -124,3 +124,36 @@ def test_gp_learn_sinc_matches_the_reference_run(tmp_path):
     assert rel(flat[2:6], g["kern_params"]) < 1e-6
     txt = open(model).read()
     assert "type=cmpnd" in txt and "numKerns=3" in txt and "numActive=4294967295" in txt
+
+
+@pytest.mark.gpu
+def test_gplvm_learn_oil_matches_the_reference_run(tmp_path):
+    """BASELINE config 5: `gplvm learn -k rbf -i 1 -# 100 examples/oilTrain.svml` (N = 1000, q = 2, rbfard+bias+white).
+    The compiled reference stops after 16 SCG iterations by its own convergence test; its end state (kernel parameters,
+    latent coordinates, log-likelihood) is the golden.  LAPACK leaves the sign of the PCA eigenvectors open, so latent
+    columns are compared up to sign; the bar is 1e-6 (BASELINE.json)."""
+    g = dict(np.load(os.path.join(GOLDEN, "gplvm_oil.npz")))
+    model = tmp_path / "oil.model"
+    out = _run([os.path.join(HOST, "gplvm"), "-v", "3", "learn", "-k", "rbf", "-i", "1", "-#", "100",
+                os.path.join(GOLDEN, "oilTrain.svml"), str(model)])
+    its = re.findall(r"^Iteration: (\d+) Error: (\S+) Scale: (\S+)$", out, flags=re.M)
+    assert len(its) == 16, out[-2000:]
+    ll = float(re.findall(r"^Final log likelihood: (\S+)$", out, flags=re.M)[-1])
+    assert abs(ll - g["n1000_ll_final"][0, 0]) <= 1e-8 * abs(g["n1000_ll_final"][0, 0])
+    lines = open(model).read().splitlines()
+    start = [i for i, ln in enumerate(lines) if ln.startswith("Y:12,X:2")][0]
+    rows = np.array([[float(t) for t in ln.split()] for ln in lines[start + 1:start + 1001]])
+    assert rows.shape == (1000, 15)                                # 12 outputs, 2 latent coordinates, label
+    X = rows[:, 12:14]
+    ref = g["n1000_X_final"]
+    for c in range(2):
+        s = np.sign(np.dot(X[:, c], ref[:, c]))
+        assert np.abs(s * X[:, c] - ref[:, c]).max() <= 1e-6 * max(1.0, np.abs(ref[:, c]).max())
+    # kernel parameters: the numeric rows between the header and the data block, in addKern order
+    kp = []
+    for i, ln in enumerate(lines[:start]):
+        if re.match(r"^-?\d", ln) and "=" not in ln:
+            kp.append([float(t) for t in ln.split()])
+    kern = np.array(kp[0] + kp[1] + kp[2])
+    assert rel(kern, g["n1000_kern_final"].ravel()) < 1e-6
+    assert "type=gplvm" in "\n".join(lines[:12]) and "type=rbfard" in "\n".join(lines[:40])
