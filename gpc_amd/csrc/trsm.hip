@@ -10,6 +10,7 @@
 // The FTC paths use side 'L', lower: (N) then (T) for alpha = K^-1 m (CGp.cpp:481-483) and (N) with nrhs = N* for the
 // predictive variance (CGp.cpp:603).
 #include "gpc_common.hpp"
+#include <stdlib.h>
 #include <ctype.h>
 
 namespace gpc {
@@ -93,6 +94,232 @@ __global__ void __launch_bounds__(64) trsm_diag_kernel(const double* __restrict_
   }
 }
 
+// ---- few right-hand sides (nrhs <= 16): L x = b and L' x = b for a lower-triangular L -------------------------------
+// CGp::updateAlpha (CGp.cpp:469-489) and CGplvm solve against one to a dozen vectors.  A GEMM-shaped update wastes a
+// 128-wide tile on them and the chain of N/64 (diagonal kernel + GEMM) launches is pure latency (94 ms for the two
+// solves at N = 32 768).  Here one launch per 64-row block does both halves of a substitution step:
+//   every workgroup re-solves the 64 x 64 diagonal system in LDS (redundant, but it removes a launch and a round trip
+//   through HBM from the chain; workgroup 0 stores the solution), then applies x_b to its share of the remaining
+//   right-hand side.  The update streams the 64-wide panel of L once: the solve reads L exactly once overall (4 N^2
+//   bytes) -- the HBM bound SURVEY.md section 8d names for this phase.
+constexpr int TV_MAXRHS = 16;
+
+__device__ __forceinline__ double readlane_f64(double v, int lane)
+{
+  union { double d; int i[2]; } u;
+  u.d = v;
+  u.i[0] = __builtin_amdgcn_readlane(u.i[0], lane);
+  u.i[1] = __builtin_amdgcn_readlane(u.i[1], lane);
+  return u.d;
+}
+
+// Solve the nb x nb (nb <= 64) diagonal system for d right-hand sides; wave w takes the vectors w, w+4, ...
+// P holds the triangle so that lane i reads the coefficient of unknown k at P[k*65 + i]; Y[v*64 + i] in/out.
+// forward: k ascending, lanes i > k updated (L x = b); else k descending, lanes i < k (L' x = b).
+__device__ __forceinline__ void tv_solve64(const double* P, const double* Dinv, double* Y, int nb, int d, bool forward,
+                                           bool unit)
+{
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if(w >= d) return;   // this wave has no vector to solve
+  const double dinv = unit ? 1.0 : Dinv[lane];
+  // the lane's coefficients of all 64 unknowns in registers: the 64-step chain below then touches neither LDS nor
+  // memory (with the coefficient read inside the loop every step paid an LDS round trip: 6 us per vector)
+  double pk[64];
+#pragma unroll
+  for(int k = 0; k < 64; k++) pk[k] = P[k * 65 + lane];
+  for(int v = w; v < d; v += 4) {
+    double y = Y[v * 64 + lane], x = 0.0;
+    if(forward) {
+#pragma unroll
+      for(int k = 0; k < 64; k++) {
+        const double xk = readlane_f64(y * dinv, k);
+        x = (lane == k) ? xk : x;
+        y -= (lane > k) ? pk[k] * xk : 0.0;
+      }
+    } else {
+#pragma unroll
+      for(int k = 63; k >= 0; k--) {
+        const double xk = readlane_f64(y * dinv, k);
+        x = (lane == k) ? xk : x;
+        y -= (lane < k) ? pk[k] * xk : 0.0;
+      }
+    }
+    Y[v * 64 + lane] = x;
+  }
+}
+
+// One forward step: block rows [b0, b0+nb) of L x = b; then b[r] -= L(r, b0:b0+nb) x_b for the rows r below.
+// Workgroup = 64 rows x 4 waves; wave w owns the columns b0 + 16 w .. + 15 of the panel.  Its 16 panel loads are issued
+// FIRST, before the diagonal solve they do not depend on: the step then costs one memory round trip, not five.
+__global__ void __launch_bounds__(256) trsv_step_n_kernel(const double* __restrict__ L, int64_t ldl,
+                                                          double* __restrict__ B, int64_t ldb, int64_t M, int64_t b0,
+                                                          int nb, int d, int unit, double* __restrict__ Xout)
+{
+  __shared__ double P[64 * 65];
+  __shared__ double Dinv[64];
+  __shared__ double Y[TV_MAXRHS * 64];
+  __shared__ double Red[3][TV_MAXRHS][64];
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const int64_t r = b0 + nb + (int64_t)blockIdx.x * 64 + lane;
+  const int64_t rc = (r < M) ? r : (M - 1);
+  double a[16];
+#pragma unroll
+  for(int u = 0; u < 16; u++) {
+    const int k = (16 * w + u < nb) ? (16 * w + u) : (nb - 1);   // clamped: x is zero past a ragged block
+    a[u] = L[rc + (b0 + k) * ldl];
+  }
+  {
+    double pa[16];   // P[k*65 + i] = L(b0+i, b0+k): a global column k is contiguous along i
+#pragma unroll
+    for(int u = 0; u < 16; u++) {
+      const int k = w + 4 * u;
+      const bool in = (k < nb && lane < nb && lane >= k);
+      const double x = L[(b0 + (in ? lane : 0)) + (b0 + (in ? k : 0)) * ldl];
+      pa[u] = in ? x : ((lane == k) ? 1.0 : 0.0);
+    }
+#pragma unroll
+    for(int u = 0; u < 16; u++) {
+      const int k = w + 4 * u;
+      P[k * 65 + lane] = pa[u];
+      if(lane == k) Dinv[k] = 1.0 / pa[u];
+    }
+  }
+  for(int v = w; v < d; v += 4) Y[v * 64 + lane] = (lane < nb) ? B[(b0 + lane) + (int64_t)v * ldb] : 0.0;
+  __syncthreads();
+  tv_solve64(P, Dinv, Y, nb, d, true, unit != 0);
+  __syncthreads();
+  // the solution goes to a side buffer: other workgroups may still be reading b_b from B (copied back at the end)
+  if(blockIdx.x == 0)
+    for(int v = w; v < d; v += 4)
+      if(lane < nb) Xout[(b0 + lane) + (int64_t)v * M] = Y[v * 64 + lane];
+  double acc[TV_MAXRHS];
+#pragma unroll
+  for(int v = 0; v < TV_MAXRHS; v++) acc[v] = 0.0;
+#pragma unroll
+  for(int u = 0; u < 16; u++)
+#pragma unroll
+    for(int v = 0; v < TV_MAXRHS; v++)
+      if(v < d) acc[v] += a[u] * Y[v * 64 + 16 * w + u];
+  if(w > 0) {
+#pragma unroll
+    for(int v = 0; v < TV_MAXRHS; v++)
+      if(v < d) Red[w - 1][v][lane] = acc[v];
+  }
+  __syncthreads();
+  if(w == 0 && r < M) {
+#pragma unroll
+    for(int v = 0; v < TV_MAXRHS; v++)
+      if(v < d) B[r + (int64_t)v * ldb] -= ((acc[v] + Red[0][v][lane]) + Red[1][v][lane]) + Red[2][v][lane];
+  }
+}
+
+// One backward step of L' x = b: block [b0, b0+nb); then b[c] -= sum_r L(b0+r, c) x_b[r] for the columns c < b0.
+__global__ void __launch_bounds__(256) trsv_step_t_kernel(const double* __restrict__ L, int64_t ldl,
+                                                          double* __restrict__ B, int64_t ldb, int64_t M, int64_t b0,
+                                                          int nb, int d, int unit, double* __restrict__ Xout)
+{
+  __shared__ double P[64 * 65];
+  __shared__ double Dinv[64];
+  __shared__ double Y[TV_MAXRHS * 64];
+  __shared__ double Tt[64 * 65];
+  __shared__ double Red[3][TV_MAXRHS][64];
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  // the wave's 16 update columns are requested first: they do not depend on the solve below
+  const int64_t c0 = (int64_t)blockIdx.x * 64 + w * 16;
+  double a[16];
+  {
+    const int64_t rl = b0 + ((lane < nb) ? lane : 0);
+#pragma unroll
+    for(int u = 0; u < 16; u++) {
+      const int64_t c = (c0 + u < b0) ? (c0 + u) : (b0 - 1);
+      const double x = L[rl + (c > 0 ? c : 0) * ldl];
+      a[u] = (c0 + u < b0 && lane < nb) ? x : 0.0;
+    }
+  }
+  // the system is L_bb' : unknown k couples to lane i < k through L(b0+k, b0+i) -> P[k*65 + i]; filled transposed from
+  // the coalesced column reads (stride 65 keeps both the writes and the later row reads conflict-free)
+  {
+    double pa[16];
+#pragma unroll
+    for(int u = 0; u < 16; u++) {
+      const int c = w + 4 * u;
+      const bool in = (c < nb && lane < nb && lane >= c);
+      const double a = L[(b0 + (in ? lane : 0)) + (b0 + (in ? c : 0)) * ldl];   // L(b0+lane, b0+c)
+      pa[u] = in ? a : ((lane == c) ? 1.0 : 0.0);
+    }
+#pragma unroll
+    for(int u = 0; u < 16; u++) {
+      const int c = w + 4 * u;
+      P[lane * 65 + c] = pa[u];
+      if(lane == c) Dinv[c] = 1.0 / pa[u];
+    }
+  }
+  for(int v = w; v < d; v += 4) Y[v * 64 + lane] = (lane < nb) ? B[(b0 + lane) + (int64_t)v * ldb] : 0.0;
+  __syncthreads();
+  tv_solve64(P, Dinv, Y, nb, d, false, unit != 0);
+  __syncthreads();
+  // the solution goes to a side buffer: other workgroups may still be reading b_b from B (copied back at the end)
+  if(blockIdx.x == 0)
+    for(int v = w; v < d; v += 4)
+      if(lane < nb) Xout[(b0 + lane) + (int64_t)v * M] = Y[v * 64 + lane];
+  // update for the workgroup's 64 columns: the 64 x 64 patch (lane = row as loaded) is turned through LDS so that a
+  // thread owns a COLUMN and a quarter of the rows -- plain in-thread sums instead of a 6-step cross-lane reduction
+  // per column and vector
+#pragma unroll
+  for(int u = 0; u < 16; u++) Tt[(16 * w + u) * 65 + lane] = a[u];
+  __syncthreads();
+  double acc[TV_MAXRHS];
+#pragma unroll
+  for(int v = 0; v < TV_MAXRHS; v++) acc[v] = 0.0;
+#pragma unroll
+  for(int j = 0; j < 16; j++) {
+    const double lv = Tt[lane * 65 + 16 * w + j];   // L(b0 + 16w + j, c), c = this lane's column
+#pragma unroll
+    for(int v = 0; v < TV_MAXRHS; v++)
+      if(v < d) acc[v] += lv * Y[v * 64 + 16 * w + j];
+  }
+  if(w > 0) {
+#pragma unroll
+    for(int v = 0; v < TV_MAXRHS; v++)
+      if(v < d) Red[w - 1][v][lane] = acc[v];
+  }
+  __syncthreads();
+  const int64_t c = (int64_t)blockIdx.x * 64 + lane;
+  if(w == 0 && c < b0) {
+#pragma unroll
+    for(int v = 0; v < TV_MAXRHS; v++)
+      if(v < d) B[c + (int64_t)v * ldb] -= ((acc[v] + Red[0][v][lane]) + Red[1][v][lane]) + Red[2][v][lane];
+  }
+}
+
+int trsv_lower(bool tr, bool unit, int64_t M, int64_t d, const double* L, int64_t ldl, double* B, int64_t ldb,
+               hipStream_t s)
+{
+  void* ws = nullptr;
+  GPC_CHECK(workspace(WS_TRSM_TMP, sizeof(double) * (size_t)M * (size_t)d, &ws));
+  double* Xout = static_cast<double*>(ws);
+  const int64_t nblk = (M + JB - 1) / JB;
+  for(int64_t step = 0; step < nblk; step++) {
+    const int64_t b = tr ? (nblk - 1 - step) : step;
+    const int64_t b0 = b * JB;
+    const int nb = (int)((M - b0 < JB) ? (M - b0) : JB);
+    if(!tr) {
+      const int64_t rest = M - (b0 + nb);
+      const unsigned grid = (unsigned)(rest > 0 ? (rest + 63) / 64 : 1);
+      hipLaunchKernelGGL(trsv_step_n_kernel, dim3(grid), dim3(256), 0, s, L, ldl, B, ldb, M, b0, nb, (int)d,
+                         unit ? 1 : 0, Xout);
+    } else {
+      const unsigned grid = (unsigned)(b0 > 0 ? (b0 + 63) / 64 : 1);
+      hipLaunchKernelGGL(trsv_step_t_kernel, dim3(grid), dim3(256), 0, s, L, ldl, B, ldb, M, b0, nb, (int)d,
+                         unit ? 1 : 0, Xout);
+    }
+  }
+  GPC_HIP_CHECK(hipGetLastError());
+  GPC_HIP_CHECK(hipMemcpy2DAsync(B, sizeof(double) * (size_t)ldb, Xout, sizeof(double) * (size_t)M,
+                                 sizeof(double) * (size_t)M, (size_t)d, hipMemcpyDeviceToDevice, s));
+  return GPC_OK;
+}
+
 int scale_matrix(int64_t M, int64_t N, double alpha, double* B, int64_t ldb, hipStream_t s)
 {
   if(M <= 0 || N <= 0 || alpha == 1.0) return GPC_OK;
@@ -170,6 +397,15 @@ int trsm(char side, char uplo, char trans, char diag, int64_t M, int64_t Nrhs, d
   if(M < 0 || Nrhs < 0 || lda < (nt > 1 ? nt : 1) || ldb < (M > 1 ? M : 1)) {
     set_error("trsm: bad dimensions");
     return GPC_EINVAL;
+  }
+  static int fast_rhs = -1;
+  if(fast_rhs < 0) {
+    const char* e = getenv("GPC_TRSV");
+    fast_rhs = e ? atoi(e) : 1;
+  }
+  if(fast_rhs && sd == 'L' && ul == 'L' && Nrhs > 0 && Nrhs <= TV_MAXRHS && M > 0) {
+    GPC_CHECK(scale_matrix(M, Nrhs, alpha, B, ldb, s));
+    return trsv_lower(tc != 'N', dg == 'U', M, Nrhs, A, lda, B, ldb, s);
   }
   return trsm_impl(sd == 'L', ul == 'L', tc != 'N', dg == 'U', M, Nrhs, alpha, A, lda, B, ldb, false, s);
 }

@@ -1,15 +1,14 @@
 #!/bin/bash
-# kernel-trace only (fast). usage: trace.sh TAG WORKLOAD STEPS [env...]
-TAG=$1; WL=$2; STEPS=$3
+# usage (on the GPU box): bash tools/trace.sh <label> <command...>   -> prints the top kernels of the command
 export TMPDIR=/tmp
-OUT=$GRAFT_REPO_ROOT/gpurun_out/trace_${TAG}
-mkdir -p $OUT; cd /tmp
-timeout 600 rocprofv3 --kernel-trace --stats -d $OUT -o t -- python $GRAFT_REPO_ROOT/bench.py --workload $WL --steps $STEPS --warmup 1 --no-cpu-baseline > $OUT/bench.json 2> $OUT/err.log
-python - <<PY
-import sqlite3, glob
-for f in glob.glob("$OUT/**/*.db", recursive=True):
+L=$1; shift
+rm -rf /tmp/tr_$L; cd /tmp
+rocprofv3 --kernel-trace --stats -d /tmp/tr_$L -o t -- "$@" > /tmp/tr_$L.out 2>&1
+python - /tmp/tr_$L <<'PY'
+import sqlite3, glob, sys
+for f in glob.glob(sys.argv[1] + "/**/*.db", recursive=True):
     cur = sqlite3.connect(f).cursor()
-    print("== top kernels", f.split('/')[-1])
+    print("%-80s %8s %12s %10s %7s" % ("kernel", "calls", "total_ms", "avg_us", "pct"))
     for r in cur.execute("select name, total_calls, total_duration, average, percentage from top_kernels limit 12"):
-        print("%-70s calls %6d total_us %10.1f avg_us %9.2f  %5.1f%%" % (r[0][:70], r[1], r[2]/1.0, r[3], r[4]))
+        print("%-80s %8d %12.2f %10.1f %6.1f%%" % (r[0][:80], r[1], r[2] / 1e3, r[3], r[4]))
 PY
