@@ -26,6 +26,7 @@
 namespace gpc {
 
 int g_gemm_trailing = 0;  // TrailingScope (gpc_common.hpp)
+int g_gemm_kstart = 0;    // KStartScope (gpc_common.hpp)
 extern int g_stair_args_set;
 extern int64_t g_stair[4];
 int g_gemm_variant = -1;  // -1: read GPC_GEMM_VARIANT on first use; 0 generic only; 1 fast 4-wave; 2 fast 8-wave
@@ -52,6 +53,8 @@ struct GemmArgs {
   int tiles_m, tiles_n;
   int super_m, super_n;  // super-tile counts
   int debug_same_rows;   // ablation knob (env GPC_GEMM_DEBUG_SAMEROWS): never set in production
+  int kstart;            // fast NT kernel only: both operands are upper triangular (square product, K == M == N):
+                         // a tile's k-loop starts at its first row m0 (everything left of it is zero)
   int atomic_c;          // beta == 1: accumulate into C with no-return fp64 atomics instead of load + add + store
   int tri;               // 0 full, 1 lower (i >= j, C square), 2 upper (i <= j, C square),
                          // 3 lower trapezoid (i >= j, M >= N, full enumeration with skipped tiles)
@@ -144,7 +147,10 @@ __device__ __forceinline__ bool map_tile(const GemmArgs& g, int& ti, int& tj)
   // XCD-aware deal: hardware block b runs on XCD b % 8; give each XCD a contiguous range of logical ids.
   const unsigned nb = gridDim.x;  // multiple of 8
   const unsigned b = blockIdx.x;
-  const unsigned L = (b & 7u) * (nb >> 3) + (b >> 3);
+  unsigned L = (b & 7u) * (nb >> 3) + (b >> 3);
+  // k-start products (potri): a tile's cost falls with its row, so contiguous chunks would hand one XCD all the long
+  // tiles.  Deal groups of 64 consecutive ids (about one super-tile: the L2 locality survives) round-robin instead.
+  if(g.kstart) L = (((b >> 3) >> 6) * 8u + (b & 7u)) * 64u + ((b >> 3) & 63u);
   int si, sj, di, dj;
   if(g.tri == 4) {
     // Block-cyclic staircase: which super-tiles are empty depends on the panel owner pattern, so contiguous chunks
@@ -348,8 +354,10 @@ __global__ void __launch_bounds__(128 * NWN, NWN) gemm_nt_fast_kernel(const Gemm
   if(ra > g.M - 2) ra = g.M - 2;
   if(rb > rbmax) rb = rbmax;
   if(rb < 0) rb = 0;
-  const double* pa = g.A + ra + (int64_t)(t >> 6) * g.lda;
-  const double* pb = g.B + rb + (int64_t)(t >> 6) * g.ldb;
+  // upper-triangular operands (potri's V V'): rows >= m0 of A are zero left of column m0, so the product starts there
+  const int64_t kfirst = g.kstart ? (m0 / BK) * BK : 0;
+  const double* pa = g.A + ra + ((int64_t)(t >> 6) + kfirst) * g.lda;
+  const double* pb = g.B + rb + ((int64_t)(t >> 6) + kfirst) * g.ldb;
   const int64_t stepa = (int64_t)KROWS * g.lda, stepb = (int64_t)KROWS * g.ldb;
   const int64_t stagea = (int64_t)BK * g.lda, stageb = (int64_t)BK * g.ldb;
   const int lds_w = (t >> 6) * STRIDE_MC + 2 * lane;  // [k][m] image, k = (t>>6) + KROWS*i
@@ -360,7 +368,7 @@ __global__ void __launch_bounds__(128 * NWN, NWN) gemm_nt_fast_kernel(const Gemm
 #pragma unroll
     for(int j = 0; j < NT; j++) acc[i][j] = (double4_t){0.0, 0.0, 0.0, 0.0};
 
-  const int64_t KT = g.K / BK;
+  const int64_t KT = (g.K - kfirst) / BK;
   double2_t ra_[PASSES], rb_[PASSES];
   if(KT > 0) {
 #pragma unroll
@@ -510,6 +518,7 @@ int gemm(bool transa, bool transb, int64_t M, int64_t N, int64_t K, double alpha
     use_atomic = e ? (atoi(e) != 0) : 1;
   }
   g.atomic_c = (beta == 1.0 && use_atomic) ? 1 : 0;
+  g.kstart = (g_gemm_kstart && !transa && transb && M == N && K == M && tri == 1) ? 1 : 0;
   g.tiles_m = (int)((M + BM - 1) / BM);
   g.tiles_n = (int)((N + BN - 1) / BN);
   g.super_m = (g.tiles_m + SUPER - 1) / SUPER;
@@ -547,6 +556,7 @@ int gemm(bool transa, bool transb, int64_t M, int64_t N, int64_t K, double alpha
   else
     slots = 32ull * g.super_m * g.super_m + 4ull * g.super_m;  // valid lower tiles of full 8 x 8 super-tiles
   slots = (slots + 7) & ~7ull;
+  if(g_gemm_kstart) slots = (slots + 511) & ~511ull;   // whole groups of 64 ids per XCD (map_tile's k-start deal)
   if(slots > 0x7fffffffull) {
     set_error("gemm grid too large");
     return GPC_EINVAL;

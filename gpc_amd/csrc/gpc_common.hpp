@@ -62,6 +62,12 @@ struct TrailingScope {
   TrailingScope() { g_gemm_trailing = 1; }
   ~TrailingScope() { g_gemm_trailing = 0; }
 };
+// While alive: A * B' products whose operands are UPPER triangular start each tile's k-loop at the tile's first row.
+extern int g_gemm_kstart;
+struct KStartScope {
+  KStartScope() { g_gemm_kstart = 1; }
+  ~KStartScope() { g_gemm_kstart = 0; }
+};
 int potrf_lower(int64_t N, double* A, int64_t lda, int* d_info, hipStream_t s);
 int potrf_panel(int64_t M, int64_t nb, double* A, int64_t lda, int* d_info, int64_t col0, hipStream_t s);
 int syrk_blockcyclic(int64_t M, int64_t ncols, int64_t K, double alpha, const double* P, int64_t ldp, double beta,

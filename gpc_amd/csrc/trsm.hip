@@ -332,52 +332,81 @@ int scale_matrix(int64_t M, int64_t N, double alpha, double* B, int64_t ldb, hip
   return GPC_OK;
 }
 
-// tri_rhs: the right-hand side is itself lower triangular with the same blocking (B = I for trtri); only the
-// columns that can be non-zero are touched.  Only meaningful for side L / effective-lower / forward.
-int trsm_impl(bool left, bool lower, bool tr, bool unit, int64_t M, int64_t Nrhs, double alpha, const double* A,
-              int64_t lda, double* B, int64_t ldb, bool tri_rhs, hipStream_t s)
+// One 64-blocked substitution sweep over the diagonal range [lo, hi) of the triangular matrix, applied to nvec vectors
+// (columns of B for side L, rows of B for side R).  Only B's blocks inside [lo, hi) are read and written.
+int trsm_sweep(bool left, bool eff_lower, bool tr, bool unit, int64_t lo, int64_t hi, int64_t nvec, const double* A,
+               int64_t lda, double* B, int64_t ldb, hipStream_t s)
 {
-  if(M <= 0 || Nrhs <= 0) return GPC_OK;
-  const int64_t nt = left ? M : Nrhs;
-  const int64_t nblk = (nt + JB - 1) / JB;
-  GPC_CHECK(scale_matrix(M, Nrhs, alpha, B, ldb, s));
-
-  const bool eff_lower = (lower != tr);  // is op(A) lower triangular?
-  // left : op(A) X = B.  eff_lower -> forward over row blocks, else backward.
-  // right: X op(A) = B.  eff_lower -> backward over column blocks, else forward.
   const bool forward = left ? eff_lower : !eff_lower;
+  const int64_t nblk = (hi - lo + JB - 1) / JB;
   for(int64_t step = 0; step < nblk; step++) {
-    const int64_t b = forward ? step : (nblk - 1 - step);
-    const int64_t b0 = b * JB;
-    const int64_t nb = (nt - b0 < JB) ? (nt - b0) : JB;
+    const int64_t b0 = lo + (forward ? step : (nblk - 1 - step)) * JB;
+    const int64_t nb = (hi - b0 < JB) ? (hi - b0) : JB;
     const double* Abb = A + b0 + b0 * lda;
-    // "rest" = the blocks still to be solved
-    const int64_t r0 = forward ? (b0 + nb) : 0;
-    const int64_t nrest = forward ? (nt - (b0 + nb)) : b0;
+    const int64_t r0 = forward ? (b0 + nb) : lo;                  // "rest" = the blocks of the range still to be solved
+    const int64_t nrest = forward ? (hi - (b0 + nb)) : (b0 - lo);
     if(left) {
-      const int64_t ncols = tri_rhs ? ((b0 + nb < Nrhs) ? (b0 + nb) : Nrhs) : Nrhs;
       double* Bb = B + b0;
       // S = op(A_bb): lower iff eff_lower
-      hipLaunchKernelGGL(trsm_diag_kernel, dim3((unsigned)((ncols + JB - 1) / JB)), dim3(64), 0, s, Abb, lda,
-                         (int)nb, eff_lower ? 1 : 0, tr ? 1 : 0, unit ? 1 : 0, Bb, ldb, ncols, 1);
+      hipLaunchKernelGGL(trsm_diag_kernel, dim3((unsigned)((nvec + JB - 1) / JB)), dim3(64), 0, s, Abb, lda, (int)nb,
+                         eff_lower ? 1 : 0, tr ? 1 : 0, unit ? 1 : 0, Bb, ldb, nvec, 1);
       if(nrest > 0) {
         // op(A)[rest, b]: not transposed -> A(rest rows, b cols); transposed -> A(b rows, rest cols)'
         const double* Arb = tr ? (A + b0 + r0 * lda) : (A + r0 + b0 * lda);
-        GPC_CHECK(gemm(tr, false, nrest, ncols, nb, -1.0, Arb, lda, Bb, ldb, 1.0, B + r0, ldb, 0, s));
+        GPC_CHECK(gemm(tr, false, nrest, nvec, nb, -1.0, Arb, lda, Bb, ldb, 1.0, B + r0, ldb, 0, s));
       }
     } else {
       double* Bb = B + b0 * ldb;
       // rows of X_b solve x' op(A_bb) = b'  <=>  op(A_bb)' x = b: S = op(A_bb)', lower iff op(A_bb) is upper
-      hipLaunchKernelGGL(trsm_diag_kernel, dim3((unsigned)((M + JB - 1) / JB)), dim3(64), 0, s, Abb, lda, (int)nb,
-                         eff_lower ? 0 : 1, tr ? 0 : 1, unit ? 1 : 0, Bb, ldb, M, 0);
+      hipLaunchKernelGGL(trsm_diag_kernel, dim3((unsigned)((nvec + JB - 1) / JB)), dim3(64), 0, s, Abb, lda, (int)nb,
+                         eff_lower ? 0 : 1, tr ? 0 : 1, unit ? 1 : 0, Bb, ldb, nvec, 0);
       if(nrest > 0) {
         // op(A)[b, rest]: not transposed -> A(b rows, rest cols); transposed -> A(rest rows, b cols)'
         const double* Abr = tr ? (A + r0 + b0 * lda) : (A + b0 + r0 * lda);
-        GPC_CHECK(gemm(false, tr, M, nrest, nb, -1.0, Bb, ldb, Abr, lda, 1.0, B + r0 * ldb, ldb, 0, s));
+        GPC_CHECK(gemm(false, tr, nvec, nrest, nb, -1.0, Bb, ldb, Abr, lda, 1.0, B + r0 * ldb, ldb, 0, s));
       }
     }
   }
   GPC_HIP_CHECK(hipGetLastError());
+  return GPC_OK;
+}
+
+// Two-level blocked triangular solve.  Outer blocks of NBT = 512: a 64-blocked sweep solves the diagonal block, then
+// ONE GEMM of depth 512 updates everything still to be solved (the 64-deep updates of a single-level scheme ran the
+// GEMM kernel at a quarter of its rate).  For side R with a transposed lower factor the outer update is
+// X_b * L(rest, b)' -- both operands row-contiguous, i.e. the fast NT kernel of gemm_f64.hip.
+// tri_rhs: the right-hand side is the identity (trtri): in forward order the vectors beyond the current block are
+// still exactly zero, so only the first `hi` of them are touched.
+constexpr int64_t NBT = 512;
+int trsm_impl(bool left, bool lower, bool tr, bool unit, int64_t M, int64_t Nrhs, double alpha, const double* A,
+              int64_t lda, double* B, int64_t ldb, bool tri_rhs, hipStream_t s)
+{
+  if(M <= 0 || Nrhs <= 0) return GPC_OK;
+  const int64_t nt = left ? M : Nrhs;          // order of the triangular matrix
+  const int64_t nvec_all = left ? Nrhs : M;    // number of vectors being solved for
+  GPC_CHECK(scale_matrix(M, Nrhs, alpha, B, ldb, s));
+  const bool eff_lower = (lower != tr);  // is op(A) lower triangular?
+  // left : op(A) X = B.  eff_lower -> forward over row blocks, else backward.
+  // right: X op(A) = B.  eff_lower -> backward over column blocks, else forward.
+  const bool forward = left ? eff_lower : !eff_lower;
+  const int64_t nouter = (nt + NBT - 1) / NBT;
+  for(int64_t ob = 0; ob < nouter; ob++) {
+    const int64_t lo = (forward ? ob : (nouter - 1 - ob)) * NBT;
+    const int64_t hi = (lo + NBT < nt) ? (lo + NBT) : nt;
+    const int64_t nvec = (tri_rhs && forward && hi < nvec_all) ? hi : nvec_all;
+    GPC_CHECK(trsm_sweep(left, eff_lower, tr, unit, lo, hi, nvec, A, lda, B, ldb, s));
+    const int64_t r0 = forward ? hi : 0;
+    const int64_t nrest = forward ? (nt - hi) : lo;
+    if(nrest <= 0) continue;
+    const int64_t kb = hi - lo;
+    if(left) {
+      const double* Arb = tr ? (A + lo + r0 * lda) : (A + r0 + lo * lda);
+      GPC_CHECK(gemm(tr, false, nrest, nvec, kb, -1.0, Arb, lda, B + lo, ldb, 1.0, B + r0, ldb, 0, s));
+    } else {
+      const double* Abr = tr ? (A + r0 + lo * lda) : (A + lo + r0 * lda);
+      GPC_CHECK(gemm(false, tr, nvec, nrest, kb, -1.0, B + lo * ldb, ldb, Abr, lda, 1.0, B + r0 * ldb, ldb, 0, s));
+    }
+  }
   return GPC_OK;
 }
 
@@ -410,9 +439,13 @@ int trsm(char side, char uplo, char trans, char diag, int64_t M, int64_t Nrhs, d
   return trsm_impl(sd == 'L', ul == 'L', tc != 'N', dg == 'U', M, Nrhs, alpha, A, lda, B, ldb, false, s);
 }
 
-// A (factor in triangle uplo) -> full symmetric inverse of the factored matrix, in place.
-//   lower: K^-1 = W' W with W = L^-1;  upper (K = U'U): K^-1 = V V' with V = U^-1 = (L^-1)' for L = U'.
-// The upper case is handled by transposing in place, so only the lower algorithm exists.
+// A (factor in triangle uplo) -> full symmetric inverse of the factored matrix, in place (dpotri + mirror).
+//   lower: K^-1 = L^-T L^-1 = V V' with V = L^-T (upper triangular).
+//   1. V := I * L^-T by the right-side solve (side R, lower, transposed): its rank-512 updates X_b * L(rest, b)' are in
+//      the NT form of the fast GEMM kernel, and the identity right-hand side keeps the work at N^3/3 (tri_rhs);
+//   2. lower(A) := V V' with the same kernel, every tile starting its k-loop at its own first row (V(i,k) = 0 for
+//      k < i): N^3/3 again instead of N^3;  3. mirror.
+// The upper case (K = U'U) is handled by transposing in place, so only the lower algorithm exists.
 int potri_full(bool lower, int64_t N, double* A, int64_t lda, hipStream_t s)
 {
   if(N <= 0) return GPC_OK;
@@ -426,10 +459,12 @@ int potri_full(bool lower, int64_t N, double* A, int64_t lda, hipStream_t s)
                        N, j0);
   }
   GPC_HIP_CHECK(hipGetLastError());
-  // W := L^-1 (lower triangular; the strictly upper part of W stays exactly zero)
-  GPC_CHECK(trsm_impl(true, true, false, false, N, N, 1.0, A, lda, W, N, true, s));
-  // lower(A) := W' W, then mirror
-  GPC_CHECK(gemm(true, false, N, N, N, 1.0, W, N, W, N, 0.0, A, lda, 1, s));
+  // V := L^-T (upper triangular; the strictly lower part of W stays exactly zero)
+  GPC_CHECK(trsm_impl(false, true, true, false, N, N, 1.0, A, lda, W, N, true, s));
+  {
+    KStartScope ks;   // tiles skip the k < first-row part of the product (zeros of the upper-triangular operand)
+    GPC_CHECK(gemm(false, true, N, N, N, 1.0, W, N, W, N, 0.0, A, lda, 1, s));
+  }
   GPC_CHECK(symmetrize(true, N, A, lda, s));
   return GPC_OK;
 }
