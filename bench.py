@@ -36,7 +36,7 @@ def cpu_baseline(cfg, sample_n, seed):
     from gpc_amd import synth
     from oracle import refrun, portrun
     X, _ = synth.make_xy(sample_n, cfg["D"], seed)
-    cores = os.cpu_count() or 1
+    cores = min(os.cpu_count() or 1, 64)     # BLAS threads; more than 64 only slow a factorisation of this size down
     t0 = time.time()
     if refrun.have_ref():
         arrays = dict(refrun.kern_arrays(cfg["kern"]))
@@ -85,7 +85,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default=os.environ.get("GPC_BENCH_WORKLOAD", "cfg3"))
     ap.add_argument("--n", type=int, default=0, help="override N (debug)")
-    ap.add_argument("--cpu-sample-n", type=int, default=8192)
+    ap.add_argument("--cpu-sample-n", type=int, default=4096)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -173,6 +173,33 @@ def main():
     syrk_bytes *= args.steps
     gram_n, gram_ms, gram_bytes = prof(1)
 
+    phases = None
+    if rank == 0 and not distributed and not replicas and os.environ.get("GPC_BENCH_PHASES", "1") == "1":
+        # The other phases of one likelihood / gradient evaluation on the factor just computed, timed with events on
+        # torch's current stream (the stream every C-ABI call above ran on).  NOT part of `value`.
+        def timed(fn):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            r = fn()
+            e1.record()
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1), r
+        _, yv = synth.make_xy(N, D, seed=1234)
+        yd = api.from_host(yv)
+        al = api.empty(N, 1)
+        t_alpha, _ = timed(lambda: api.gp_alpha(K, yd, out=al))            # CGp::updateAlpha: two triangular solves
+        t_ll, ll = timed(lambda: api.gp_loglik(yd, al, logdet))
+        phases = {"alpha_2trsv_ms": t_alpha, "alpha_algorithmic_GBs": 8.0 * N * N / (t_alpha * 1e-3) * 1e-9,
+                  "loglik_ms": t_ll, "loglik": ll}
+        try:
+            inv = K.clone()
+            t_potri, _ = timed(lambda: api.potri(inv, "L"))                # CMatrix::pdinv for the gradient
+            phases.update({"potri_ms": t_potri, "potri_tflops_at_2N3_over_3": 2.0 * N ** 3 / 3.0 / (t_potri * 1e-3) * 1e-12})
+            del inv
+        except (RuntimeError, api._lib.GpcError) as e:                      # not enough HBM for the two extra N x N buffers
+            phases["potri_ms"] = None
+            phases["potri_skipped"] = str(e)[:100]
+
     if rank == 0:
         probe, pcyc, pclk = ctypes.c_double(0.0), ctypes.c_double(0.0), ctypes.c_double(0.0)
         api.check(api.lib().gpc_probe_mfma_f64(ctypes.byref(probe), ctypes.byref(pcyc), ctypes.byref(pclk),
@@ -210,6 +237,10 @@ def main():
                            % (world, g.nb)),
                           "logdet": logdet},
                "roofline": roof}
+        if phases is not None:
+            phases["gram_ms"] = gram_ms / max(1, gram_n)
+            phases["potrf_logdet_ms"] = dt / args.steps * 1e3 - phases["gram_ms"]
+            out["phases"] = phases
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, min(args.cpu_sample_n, N), 1234)
         print(json.dumps(out))
