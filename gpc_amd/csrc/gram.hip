@@ -33,6 +33,8 @@ struct GramArgs {
   int64_t N, N2, D;
   int64_t i_off, j_off;  // global indices of K(0,0) in the symmetric Gram (for the diagonal)
   int sym_diag;          // 1: elements with global i == j take the diagComputeElement value
+  int mirror;            // 1: the whole symmetric Gram of one X is being built: tiles left of the diagonal block are
+                         //    computed once and stored twice (K(i,j) and K(j,i)); tiles right of it are skipped
   int debug;             // ablation knob (env GPC_GRAM_DEBUG): 1 no exp, 2 no MFMA loop, 3 no stores; 0 in production
 };
 
@@ -300,7 +302,7 @@ __global__ void __launch_bounds__(256, 2) gram_mfma_persist_kernel(const KSpecDe
   const int lane = t & 63, w = t >> 6;
   const int wm = w & 1, wn = w >> 1;
   const int64_t i0 = (int64_t)blockIdx.x * MI;
-  const int64_t tiles_j = (g.N2 + MJ - 1) / MJ;
+  int64_t tiles_j = (g.N2 + MJ - 1) / MJ;
   const int64_t jt0 = (int64_t)blockIdx.y * jt_per_block;
   int64_t jt1 = jt0 + jt_per_block;
   if(jt1 > tiles_j) jt1 = tiles_j;
@@ -411,6 +413,7 @@ __global__ void __launch_bounds__(256, 2) gram_mfma_persist_kernel(const KSpecDe
           const int64_t gi = i0 + wm * 64 + tm * 16 + (lane & 15);
           double k = kv[tm];
           if(g.sym_diag && (g.i_off + gi == g.j_off + gj)) k = diag_const + ks.lin_var * ni[tm];
+          kv[tm] = k;
           if((full || (gi < g.N && gj < g.N2)) && (g.debug != 3 || k == 123.456)) g.K[gi + gj * g.ldk] = k;
         }
       }
@@ -437,6 +440,163 @@ __global__ void __launch_bounds__(256) gram_diag_kernel(const KSpecDev ks, const
   d[i] = k;
 }
 
+// ---- full symmetric build: every element computed once, stored twice ---------------------------------------------------
+// The whole Gram matrix of one X (CKern::compute(K, X), CKern.h:128-144: K(i,j) = K(j,i) = computeElement).  Row block I
+// (128 rows) walks the 64-column tiles left of and inside its own diagonal block only; a tile strictly left of the
+// diagonal block is also written to its mirror position.  Halving the dot products and the exponentials is what
+// matters: both cost more than the stores.
+//   * the row block's MFMA operand fragments live in REGISTERS for the whole walk (4 x 8 doubles per lane), so LDS holds
+//     only the double-buffered column tile and the mirror staging;
+//   * the mirror goes through a wave-private LDS patch (64 x 16 at a time) so that it leaves as 128-byte runs along j,
+//     like the direct store (writing it straight from the accumulator layout -- 32-byte runs -- was slower than not
+//     exploiting symmetry at all).
+constexpr int TS = 17;   // row stride of the mirror staging patch (doubles)
+template <int NRBF, int NK>
+__global__ void __launch_bounds__(256, 2) gram_sym_kernel(const KSpecDev ks, const GramArgs g, int jt_per_block)
+{
+  __shared__ double Xj[2][MDC * SJ];
+  __shared__ double Nj[2][MJ];
+  __shared__ double Tm[4][64 * TS];
+  const int t = threadIdx.x;
+  const int lane = t & 63, w = t >> 6;
+  const int wm = w & 1, wn = w >> 1;
+  const int64_t i0 = (int64_t)blockIdx.x * MI;
+  int64_t tiles_j = (g.N + MJ - 1) / MJ;
+  if(tiles_j > 2 * ((int64_t)blockIdx.x + 1)) tiles_j = 2 * ((int64_t)blockIdx.x + 1);
+  const int64_t jt0 = (int64_t)blockIdx.y * jt_per_block;
+  int64_t jt1 = jt0 + jt_per_block;
+  if(jt1 > tiles_j) jt1 = tiles_j;
+  if(jt0 >= jt1) return;
+  const int dc = (int)g.D;          // <= 4 NK on this path
+
+  // this wave's 64 rows as MFMA fragments: a[kk][tm] = X(i0 + wm*64 + tm*16 + (lane & 15), 4 kk + (lane >> 4)).
+  // Loads are unconditional with clamped indices (no branches): rows past N are never stored, and feature slots past
+  // D meet an exactly-zero column operand in the product.
+  double af[NK][4];
+#pragma unroll
+  for(int kk = 0; kk < NK; kk++)
+#pragma unroll
+    for(int tm = 0; tm < 4; tm++) {
+      int64_t gi = i0 + wm * 64 + tm * 16 + (lane & 15);
+      if(gi > g.N - 1) gi = g.N - 1;
+      int kr = kk * 4 + (lane >> 4);
+      if(kr > dc - 1) kr = dc - 1;
+      af[kk][tm] = g.X[gi + (int64_t)kr * g.ldx];
+    }
+  double ni[4];
+#pragma unroll
+  for(int tm = 0; tm < 4; tm++) {
+    int64_t gi = i0 + wm * 64 + tm * 16 + (lane & 15);
+    if(gi > g.N - 1) gi = g.N - 1;
+    ni[tm] = g.n1[gi];
+  }
+  double diag_const = ks.bias_var + ks.white_var;
+  for(int r = 0; r < ks.n_rbf; r++) diag_const += ks.rbf_var[r];
+
+  const int ws = __builtin_amdgcn_readfirstlane(w);
+  double vj[8], vn;   // next tile's rows (and, in the first 64 threads, their norms), in flight during this tile
+  auto prefetch = [&](int64_t jt) {
+    const int64_t j0 = jt * MJ;
+    int64_t gj = j0 + lane;
+    if(gj > g.N - 1) gj = g.N - 1;
+    // feature index d = wave + 4u is wave-uniform: a scalar base per load and ONE vector offset for all of them (with
+    // per-thread 64-bit addresses the eight pointers were spilled to scratch and reloaded every tile)
+#pragma unroll
+    for(int u = 0; u < 8; u++) {
+      const int d = ws + 4 * u;
+      vj[u] = 0.0;
+      if(d < dc) vj[u] = (g.X + (int64_t)d * g.ldx)[gj];
+    }
+    vn = g.n1[gj];
+  };
+  prefetch(jt0);
+  double* Tw = Tm[w];
+
+  for(int64_t jt = jt0; jt < jt1; jt++) {
+    double* Xjb = Xj[(jt - jt0) & 1];
+    double* Njb = Nj[(jt - jt0) & 1];
+    const int64_t j0 = jt * MJ;
+#pragma unroll
+    for(int u = 0; u < 8; u++) {
+      const int idx = t + 256 * u;
+      Xjb[(idx >> 6) * SJ + (idx & 63)] = vj[u];
+    }
+    if(t < MJ) Njb[t] = vn;
+    __syncthreads();   // tile jt is visible; every wave is past its reads of the other buffer (tile jt-1)
+    if(jt + 1 < jt1) prefetch(jt + 1);
+
+    double4_t acc[4][2];
+#pragma unroll
+    for(int a = 0; a < 4; a++)
+#pragma unroll
+      for(int b = 0; b < 2; b++) acc[a][b] = (double4_t){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for(int kk = 0; kk < NK; kk++) {
+      double b[2];
+      const int kr = kk * 4 + (lane >> 4);
+#pragma unroll
+      for(int s2 = 0; s2 < 2; s2++) b[s2] = Xjb[kr * SJ + wn * 32 + s2 * 16 + (lane & 15)];
+#pragma unroll
+      for(int tn = 0; tn < 2; tn++)
+#pragma unroll
+        for(int tm = 0; tm < 4; tm++)
+          acc[tm][tn] = __builtin_amdgcn_mfma_f64_16x16x4f64(b[tn], af[kk][tm], acc[tm][tn], 0, 0, 0);
+    }
+    const bool full = (i0 + MI <= g.N) && (j0 + MJ <= g.N);
+    const bool mirror = (j0 + MJ <= i0);   // strictly left of the diagonal block (workgroup-uniform)
+#pragma unroll
+    for(int tn = 0; tn < 2; tn++) {
+#pragma unroll
+      for(int r = 0; r < 4; r++) {
+        __builtin_amdgcn_sched_barrier(0);   // keep the unrolled (tn, r) bodies apart: interleaved they spill
+        const int jl = wn * 32 + tn * 16 + (lane >> 4) + 4 * r;
+        const int64_t gj = j0 + jl;
+        const double nj = Njb[jl];
+        // two rows at a time: enough independent exp chains to overlap, few enough to stay in registers
+#pragma unroll
+        for(int th = 0; th < 4; th += 2) {
+          double kv[2];
+#pragma unroll
+          for(int u = 0; u < 2; u++) {
+            const int tm = th + u;
+            const double dot = acc[tm][tn][r];
+            const double d2 = ni[tm] + nj - 2.0 * dot;
+            double k = ks.bias_var + ks.lin_var * dot;
+#pragma unroll
+            for(int q = 0; q < NRBF; q++) k += ks.rbf_var[q] * exp(-(ks.rbf_hiw[q] * d2));
+            kv[u] = k;
+          }
+#pragma unroll
+          for(int u = 0; u < 2; u++) {
+            const int tm = th + u;
+            const int64_t gi = i0 + wm * 64 + tm * 16 + (lane & 15);
+            double k = kv[u];
+            if(gi == gj) k = diag_const + ks.lin_var * ni[tm];   // diagComputeElement
+            if(full || (gi < g.N && gj < g.N)) g.K[gi + gj * g.ldk] = k;
+            if(mirror) Tw[(tm * 16 + (lane & 15)) * TS + 4 * r + (lane >> 4)] = k;
+          }
+        }
+      }
+      if(mirror) {
+        // the wave's 64 (i) x 16 (j) patch of this tn, now read with lanes along j: K(j, i), 128-byte runs
+        __builtin_amdgcn_wave_barrier();
+        const int jl = lane & 15;
+        const int64_t gj = j0 + wn * 32 + tn * 16 + jl;
+        double* Kcol = g.K + gj + (i0 + wm * 64 + (lane >> 4)) * g.ldk;
+        const int64_t step4 = 4 * g.ldk;
+#pragma unroll 4
+        for(int u = 0; u < 16; u++) {
+          const int il = 4 * u + (lane >> 4);
+          const double k = Tw[il * TS + jl];
+          if(full || (i0 + wm * 64 + il < g.N && gj < g.N)) *Kcol = k;
+          Kcol += step4;
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+    }
+  }
+}
+
 int launch_gram(const KSpecDev& ks, const GramArgs& g, hipStream_t s)
 {
   if(g.N <= 0 || g.N2 <= 0) return GPC_OK;
@@ -453,9 +613,31 @@ int launch_gram(const KSpecDev& ks, const GramArgs& g, hipStream_t s)
       int64_t nsplit = (2048 + tiles_i - 1) / tiles_i;
       if(nsplit > tiles_j) nsplit = tiles_j;
       if(nsplit < 1) nsplit = 1;
-      const int64_t per = (tiles_j + nsplit - 1) / nsplit;
+      int64_t per = (tiles_j + nsplit - 1) / nsplit;
+      if(g.mirror) {
+        // triangular work: row block I only walks 2I + 2 tiles, so short chunks keep the workgroups comparable
+        static int64_t sym_per = -1;
+        if(sym_per < 0) { const char* e = getenv("GPC_GRAM_PER"); sym_per = e ? atoll(e) : 48; }
+        if(per > sym_per) per = sym_per;
+      }
       nsplit = (tiles_j + per - 1) / per;
       const dim3 grid((unsigned)tiles_i, (unsigned)nsplit), block(256);
+      if(g.mirror && (ks.n_rbf == 1 || ks.n_rbf == 2)) {
+        const int nkk = (int)((g.D + 3) / 4);
+#define GPC_SYM_LAUNCH(R, K) hipLaunchKernelGGL((gram_sym_kernel<R, K>), grid, block, 0, s, ks, g, (int)per)
+        if(ks.n_rbf == 1) {
+          if(nkk <= 1) GPC_SYM_LAUNCH(1, 1);
+          else if(nkk <= 2) GPC_SYM_LAUNCH(1, 2);
+          else if(nkk <= 4) GPC_SYM_LAUNCH(1, 4);
+          else GPC_SYM_LAUNCH(1, 8);
+        } else {
+          if(nkk <= 1) GPC_SYM_LAUNCH(2, 1);
+          else if(nkk <= 2) GPC_SYM_LAUNCH(2, 2);
+          else if(nkk <= 4) GPC_SYM_LAUNCH(2, 4);
+          else GPC_SYM_LAUNCH(2, 8);
+        }
+#undef GPC_SYM_LAUNCH
+      } else
       switch(ks.n_rbf) {
       case 0: hipLaunchKernelGGL(gram_mfma_persist_kernel<0>, grid, block, 0, s, ks, g, (int)per); break;
       case 1: hipLaunchKernelGGL(gram_mfma_persist_kernel<1>, grid, block, 0, s, ks, g, (int)per); break;
@@ -464,8 +646,10 @@ int launch_gram(const KSpecDev& ks, const GramArgs& g, hipStream_t s)
       default: hipLaunchKernelGGL(gram_mfma_persist_kernel<4>, grid, block, 0, s, ks, g, (int)per); break;
       }
     } else {
+      GramArgs h = g;
+      h.mirror = 0;
       const dim3 grid((unsigned)tiles_i, (unsigned)tiles_j), block(256);
-      hipLaunchKernelGGL(gram_mfma_kernel, grid, block, 0, s, ks, g);
+      hipLaunchKernelGGL(gram_mfma_kernel, grid, block, 0, s, ks, h);
     }
     prof_end(PROF_GRAM, s);
     GPC_HIP_CHECK(hipGetLastError());
@@ -595,6 +779,12 @@ static int gram_common(const gpc_kspec* ksp, const double* X, int64_t N, int64_t
   g.i_off = i_off;
   g.j_off = j_off;
   g.sym_diag = sym_diag;
+  {
+    static int sym = -1;
+    if(sym < 0) { const char* e = getenv("GPC_GRAM_SYM"); sym = e ? (atoi(e) != 0) : 1; }
+    // "mirror" request; honoured by the persistent MFMA kernel only (launch_gram clears it on the other paths)
+    g.mirror = (sym && same_x && sym_diag && X == X2 && N == N2 && i_off == 0 && j_off == 0) ? 1 : 0;
+  }
   {
     static int dbg = -1;
     if(dbg < 0) { const char* e = getenv("GPC_GRAM_DEBUG"); dbg = e ? atoi(e) : 0; }
