@@ -135,6 +135,17 @@ def default_nb():
     return int(os.environ.get("GPC_DIST_NB", "512"))
 
 
+class _Works(object):
+    """Several asynchronous collectives waited for as one."""
+
+    def __init__(self, works):
+        self.works = works
+
+    def wait(self):
+        for w in self.works:
+            w.wait()
+
+
 class DistGp(object):
     """Block-cyclic counterpart of CGp's FTC state: factor of K (distributed), log|K|, L^-1 y, and what follows.
 
@@ -151,6 +162,10 @@ class DistGp(object):
         self.nb = int(nb) if nb else default_nb()
         # collectives are skipped in a 1-rank job unless GPC_DIST_FORCE_COMM=1 (exercises the RCCL calls on one GPU)
         self.comm = self.P > 1 or (dist.is_initialized() and os.environ.get("GPC_DIST_FORCE_COMM", "0") == "1")
+        # width of the column slabs a panel is factored and broadcast in (0 = whole panel in one piece)
+        self.slab = int(os.environ.get("GPC_DIST_SLAB", "128"))
+        if self.slab % 128 != 0 or self.slab < 0:
+            raise ValueError("GPC_DIST_SLAB must be 0 or a multiple of 128")
         if self.nb % 128 != 0:
             raise ValueError("panel width must be a multiple of 128")
         X = np.asarray(X, dtype=np.float64)
@@ -257,14 +272,31 @@ class DistGp(object):
                 st.wait(st.panel, self._free[k % 2])
             flat, view = self.buf_view(k)
             ev_fact = None
-            if self.owner(k) == self.rank:
+            own = self.owner(k) == self.rank
+            w, M = self.width(k), self.Mtot - k * self.nb
+            sb = self.slab if (self.comm and self.slab > 0) else w
+            works = []
+            if own:
                 st.wait(st.panel, after)
                 pv = self.panel_view(k)
-                self.ops.potrf_panel(pv, k * self.nb, self.info)
+            # The panel leaves in column slabs: slab s is final as soon as it is factored, so its broadcast overlaps
+            # the factorisation of slabs s+1.. (a slab of whole columns is one contiguous piece of the buffer).
+            for c0 in range(0, w, sb):
+                ws = min(sb, w - c0)
+                if own:
+                    self.ops.potrf_panel(pv[c0:, c0:c0 + ws], k * self.nb + c0, self.info)
+                    if self.comm:
+                        view[:, c0:c0 + ws].copy_(pv[:, c0:c0 + ws])
+                wk = self._bcast(flat[c0 * M:(c0 + ws) * M], self.owner(k))
+                if wk is not None:
+                    works.append(wk)
+                if own and c0 + ws < w:
+                    # right-looking step inside the panel: the columns still to be factored take this slab's update
+                    r0 = k * self.nb + c0 + ws
+                    self.ops.syrk_blockcyclic(pv[c0 + ws:, c0:c0 + ws], pv[c0 + ws:, c0 + ws:w], r0, r0 // sb, 1, sb)
+            if own:
                 ev_fact = st.record(st.panel)
-                if self.comm:
-                    view.copy_(pv)
-            work = self._bcast(flat, self.owner(k))
+            work = _Works(works) if works else None
             ev_recv = st.record(st.panel)
         self._inflight[k % 2] = (work, ev_recv)
         return work, ev_recv, ev_fact

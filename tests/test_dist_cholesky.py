@@ -70,10 +70,12 @@ def _check(res, exp, Ns, tol):
         np.testing.assert_array_equal(r["alpha"], res[0]["alpha"])
 
 
-@pytest.mark.parametrize("world,N,Ns,d", [(1, 300, 5, 1), (2, 700, 37, 2), (3, 900, 0, 1), (2, 512, 8, 1)])
-def test_blockcyclic_orchestration_gloo_cpu(world, N, Ns, d, tmp_path):
-    """ragged last panel, odd row count (padding row), more ranks than fit evenly, no test points."""
-    res = _run(world, "numpy", N, 3, d, Ns, 128, tmp_path)
+@pytest.mark.parametrize("world,N,Ns,d,nb", [(1, 300, 5, 1, 128), (2, 700, 37, 2, 128), (3, 900, 0, 1, 128),
+                                                (2, 512, 8, 1, 128), (2, 1100, 3, 2, 384), (3, 1300, 0, 1, 256)])
+def test_blockcyclic_orchestration_gloo_cpu(world, N, Ns, d, nb, tmp_path):
+    """ragged last panel, odd row count (padding row), more ranks than fit evenly, no test points; nb > 128: the
+    panels are factored and broadcast in 128-column slabs (ragged last slab included)."""
+    res = _run(world, "numpy", N, 3, d, Ns, nb, tmp_path)
     _check(res, _expected(N, 3, d, Ns), Ns, 1e-11)
     assert sum(int(r["ncols"]) for r in res) == N
 
