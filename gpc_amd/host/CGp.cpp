@@ -6,6 +6,7 @@
 #include <fstream>
 #include <vector>
 #include "gpc_hip.h"
+#include "ndlstream.h"
 
 static const double HALFLOGTWOPI = 0.91893853320467274178;   // ndlutil::HALFLOGTWOPI
 
@@ -24,7 +25,8 @@ double* devAlloc(size_t n)
 }  // namespace
 
 CGp::CGp(CKern* kernel, CNoise* nois, CMatrix* Xin, int approxType, unsigned int actSetSize, int verbos)
-    : pX(Xin), py(nois->py), pkern(kernel), pnoise(nois), numActive(actSetSize), scale(1, nois->getOutputDim(), 1.0),
+    : pX(Xin), py(nois->py), pkern(kernel), pnoise(nois), ownsKernNoise(false), fileNumData(0), fileInputDim(0),
+      numActive(actSetSize), scale(1, nois->getOutputDim(), 1.0),
       bias(1, nois->getOutputDim(), 0.0), refTransRounding(true), MupToDate(false), KupToDate(false),
       AlphaUpToDate(false), invKupToDate(false), dX(0), dM(0), dL(0), dInvKm(0), dAlpha(0), dInvK(0), dCovGrad(0),
       logDetK(0.0), lastJitter(0.0), needInverse(false)
@@ -37,8 +39,37 @@ CGp::CGp(CKern* kernel, CNoise* nois, CMatrix* Xin, int approxType, unsigned int
   const char* e = std::getenv("GPC_EXACT_TRANS");
   if(e && e[0] == '1') refTransRounding = false;
 }
+CGp::CGp()
+    : pX(0), py(0), pkern(0), pnoise(0), ownsKernNoise(true), fileNumData(0), fileInputDim(0), numActive(0), scale(1, 1, 1.0),
+      bias(1, 1, 0.0), refTransRounding(true), MupToDate(false), KupToDate(false), AlphaUpToDate(false),
+      invKupToDate(false), dX(0), dM(0), dL(0), dInvKm(0), dAlpha(0), dInvK(0), dCovGrad(0), logDetK(0.0), lastJitter(0.0),
+      needInverse(false)
+{
+  const char* e = std::getenv("GPC_EXACT_TRANS");
+  if(e && e[0] == '1') refTransRounding = false;
+}
+void CGp::setData(CMatrix* Xin, CMatrix* yin)
+{
+  if(Xin->getRows() != yin->getRows()) throw ndlexceptions::MatrixError("CGp: X and the targets disagree on the number of data");
+  if(yin->getCols() != scale.getCols()) throw ndlexceptions::MatrixError("CGp: targets do not have the model's output dimension");
+  pX = Xin;
+  py = yin;
+  pnoise->py = yin;
+  devFree(dX);   // re-staged from the new X on the next updateK
+  devFree(dM);
+  devFree(dL);
+  devFree(dInvKm);
+  devFree(dAlpha);
+  devFree(dInvK);
+  devFree(dCovGrad);
+  MupToDate = KupToDate = AlphaUpToDate = invKupToDate = false;
+}
 CGp::~CGp()
 {
+  if(ownsKernNoise) {
+    delete pkern;
+    delete pnoise;
+  }
   devFree(dX);
   devFree(dM);
   devFree(dL);
@@ -253,7 +284,7 @@ void CGp::display(std::ostream& os) const
   os << "Scale: " << scale << std::endl;
   pnoise->display(os);
   pkern->display(os);
-  if(py && pX) os << "Log likelihood: " << logLikelihood() << std::endl;
+  if(py && pX) os << "Log likelihood: " << logLikelihood() << std::endl;   // a model read from a file has no data yet
 }
 
 void CGp::writeParamsToStream(std::ostream& out) const
@@ -272,6 +303,41 @@ void CGp::writeParamsToStream(std::ostream& out) const
   out << "version=0.200000" << std::endl;
   pnoise->writeParamsToStream(out);
 }
+void CGp::readParamsFromStream(std::istream& in)
+{
+  // CGp::readParamsFromStream, CGp.cpp:1606-1650 (FTC models only)
+  const std::string base = ndlstream::readField(in, "baseType");
+  if(base != "dataModel") throw ndlexceptions::StreamFormatError("baseType", "Error mismatch between saved base type, " + base + ", and Class base type, dataModel.");
+  const std::string type = ndlstream::readField(in, "type");
+  if(type != "gp") throw ndlexceptions::StreamFormatError("type", "Error mismatch between saved type, " + type + ", and Class type, gp.");
+  fileNumData = (unsigned int)ndlstream::readInt(in, "numData");
+  const unsigned int outDim = (unsigned int)ndlstream::readInt(in, "outputDim");
+  fileInputDim = (unsigned int)ndlstream::readInt(in, "inputDim");
+  const long approx = ndlstream::readInt(in, "sparseApproximation");
+  if(approx != FTC) throw ndlexceptions::NotImplementedError("sparse approximations (DTC/FITC/PITC/DTCVAR) are outside the accelerated FTC path");
+  numActive = (unsigned int)std::strtoul(ndlstream::readField(in, "numActive").c_str(), 0, 10);
+  if(ndlstream::readBool(in, "learnScale")) throw ndlexceptions::NotImplementedError("learnt output scales are outside the accelerated FTC path");
+  (void)ndlstream::readBool(in, "learnBias");
+  scale.fromStream(in);
+  bias.fromStream(in);
+  if(scale.getCols() != outDim || bias.getCols() != outDim) throw ndlexceptions::StreamFormatError("outputDim", "scale / bias do not match the output dimension");
+  if(ownsKernNoise) {
+    delete pkern;
+    delete pnoise;
+  }
+  pkern = 0;
+  pnoise = 0;
+  ownsKernNoise = true;
+  pkern = readKernFromStream(in);
+  pnoise = readNoiseFromStream(in);
+  if(pkern->getInputDim() != fileInputDim) throw ndlexceptions::StreamFormatError("inputDim", "kernel input dimension does not match the model's");
+  MupToDate = KupToDate = AlphaUpToDate = invKupToDate = false;
+}
+void CGp::fromStream(std::istream& in)
+{
+  ndlstream::readVersion(in);
+  readParamsFromStream(in);
+}
 void CGp::toStream(std::ostream& out) const
 {
   out << "version=0.200000" << std::endl;
@@ -288,4 +354,30 @@ void writeGpToStream(const CGp& model, std::ostream& out) { model.toStream(out);
 void writeGpToFile(const CGp& model, const std::string modelFileName, const std::string comment)
 {
   model.toFile(modelFileName, comment);
+}
+CGp* readGpFromStream(std::istream& in)
+{
+  CGp* pmodel = new CGp();
+  try {
+    pmodel->fromStream(in);
+  } catch(...) {
+    delete pmodel;
+    throw;
+  }
+  return pmodel;
+}
+CGp* readGpFromFile(const std::string modelFileName, int verbosity)
+{
+  if(verbosity > 0) std::cout << "Loading model file." << std::endl;
+  std::ifstream in(modelFileName.c_str());
+  if(!in.is_open()) throw ndlexceptions::FileReadError(modelFileName);
+  CGp* pmodel = 0;
+  try {
+    pmodel = readGpFromStream(in);
+  } catch(ndlexceptions::StreamFormatError& err) {
+    throw ndlexceptions::FileFormatError(modelFileName, err.getMessage());
+  }
+  pmodel->setVerbosity(verbosity);
+  if(verbosity > 0) std::cout << "... done." << std::endl;
+  return pmodel;
 }

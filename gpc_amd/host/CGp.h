@@ -21,6 +21,7 @@ class CGp : public CProbabilisticOptimisable {
  public:
   enum { FTC, DTC, FITC, PITC, DTCVAR };
   CGp(CKern* kernel, CNoise* nois, CMatrix* Xin, int approxType = FTC, unsigned int actSetSize = 0, int verbos = 2);
+  CGp();   // for readGpFromStream: the kernel and noise model read from the file are OWNED by the model
   ~CGp();
 
   // CMapModel interface (CGp.cpp:445-460)
@@ -54,9 +55,11 @@ class CGp : public CProbabilisticOptimisable {
   bool isSparseApproximation() const { return false; }
   bool isOptimiseX() const { return false; }
   int getApproximationType() const { return FTC; }
-  unsigned int getNumData() const { return pX->getRows(); }
-  unsigned int getInputDim() const { return pX->getCols(); }
-  unsigned int getOutputDim() const { return py->getCols(); }
+  unsigned int getNumData() const { return pX ? pX->getRows() : fileNumData; }
+  unsigned int getInputDim() const { return pX ? pX->getCols() : fileInputDim; }
+  unsigned int getOutputDim() const { return py ? py->getCols() : scale.getCols(); }
+  // `gp relearn` attaches the data to a model read from a file (gp.cpp:484-487: py, updateM, pX)
+  void setData(CMatrix* Xin, CMatrix* yin);
   unsigned int getNumActive() const { return numActive; }
   std::string getNoiseType() const { return pnoise->getType(); }
   const CKern* getKernel() const { return pkern; }
@@ -67,9 +70,11 @@ class CGp : public CProbabilisticOptimisable {
   void setReferenceTransRounding(bool v) { refTransRounding = v; KupToDate = false; AlphaUpToDate = false; }
   bool isReferenceTransRounding() const { return refTransRounding; }
 
-  // text model file (CGp.cpp:1656-1682)
+  // text model file (CGp.cpp:1606-1682)
   void writeParamsToStream(std::ostream& out) const;
+  void readParamsFromStream(std::istream& in);
   void toStream(std::ostream& out) const;
+  void fromStream(std::istream& in);
   void toFile(const std::string fileName, const std::string comment = "") const;
 
   CMatrix* pX;   // public in the reference as well (CGp.h:352-356)
@@ -80,6 +85,8 @@ class CGp : public CProbabilisticOptimisable {
   void releaseGradientBuffers() const;
   CKern* pkern;
   CNoise* pnoise;
+  bool ownsKernNoise;
+  unsigned int fileNumData, fileInputDim;   // as recorded in the model file, until data are attached
   unsigned int numActive;
   CMatrix scale, bias;
   bool refTransRounding;
@@ -101,4 +108,6 @@ class CGp : public CProbabilisticOptimisable {
 
 void writeGpToStream(const CGp& model, std::ostream& out);
 void writeGpToFile(const CGp& model, const std::string modelFileName, const std::string comment = "");
+CGp* readGpFromStream(std::istream& in);
+CGp* readGpFromFile(const std::string modelFileName, int verbosity = 2);   // CGp.cpp:1684-1707
 #endif

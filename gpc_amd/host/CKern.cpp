@@ -1,5 +1,6 @@
 // CKern.cpp -- see CKern.h.
 #include "CKern.h"
+#include "ndlstream.h"
 #include <cmath>
 #include <cstring>
 
@@ -410,4 +411,52 @@ std::ostream& CCmpndKern::display(std::ostream& os) const
   os << "Compound kernel:" << std::endl;
   for(size_t i = 0; i < components.size(); i++) components[i]->display(os);
   return os;
+}
+
+// ---- model-file reader (reference CKern.cpp:100-112, 125-140, 4192-4260) ----------------------------------------------
+void CKern::readParamsFromStream(std::istream& in)
+{
+  setInputDim((unsigned int)ndlstream::readInt(in, "inputDim"));
+  const unsigned int nPars = (unsigned int)ndlstream::readInt(in, "numParams");
+  CMatrix par(1, nPars);
+  par.fromStream(in);
+  if(nPars != getNumParams())
+    throw ndlexceptions::StreamFormatError("numParams", "Listed number of parameters does not match computed number of parameters.");
+  setParams(par);
+  const long numPriors = ndlstream::readInt(in, "numPriors");
+  if(numPriors != 0) throw ndlexceptions::NotImplementedError("parameter priors (CDist) are outside the accelerated path");
+}
+void CCmpndKern::readParamsFromStream(std::istream& in)
+{
+  setInputDim((unsigned int)ndlstream::readInt(in, "inputDim"));
+  (void)ndlstream::readInt(in, "numParams");
+  const unsigned int numKerns = (unsigned int)ndlstream::readInt(in, "numKerns");
+  for(unsigned int i = 0; i < numKerns; i++) {
+    CKern* k = readKernFromStream(in);
+    addKern(k);   // clones
+    delete k;
+  }
+}
+CKern* readKernFromStream(std::istream& in)
+{
+  ndlstream::readVersion(in);
+  const std::string base = ndlstream::readField(in, "baseType");
+  if(base != "kern")
+    throw ndlexceptions::StreamFormatError("baseType", "Error mismatch between saved base type, " + base + ", and Class base type, kern.");
+  const std::string type = ndlstream::readField(in, "type");
+  CKern* k = 0;
+  if(type == "white") k = new CWhiteKern(1u);
+  else if(type == "bias") k = new CBiasKern(1u);
+  else if(type == "rbf") k = new CRbfKern(1u);
+  else if(type == "lin") k = new CLinKern(1u);
+  else if(type == "rbfard") k = new CRbfardKern(1u);
+  else if(type == "cmpnd") k = new CCmpndKern();
+  else throw ndlexceptions::StreamFormatError("type", "Kernel type " + type + " is outside the accelerated set (rbf, rbfard, lin, bias, white, cmpnd)");
+  try {
+    k->readParamsFromStream(in);
+  } catch(...) {
+    delete k;
+    throw;
+  }
+  return k;
 }

@@ -61,6 +61,7 @@ class CKern : public CTransformable {
   bool isStationary() const { return stationary; }
   double priorLogProb() const { return 0.0; }   // no priors in scope (CDist is out of scope; CGp.cpp:1011 adds 0)
   virtual void writeParamsToStream(std::ostream& out) const;
+  virtual void readParamsFromStream(std::istream& in);   // CKern.cpp:100-112 (after baseType/type were consumed)
   void toStream(std::ostream& out) const
   {
     out << "version=0.200000" << std::endl;
@@ -212,10 +213,13 @@ class CCmpndKern : public CKern {
   std::string getParamName(unsigned int paramNo) const;
   void appendKspec(gpc_kspec& ks) const;
   void writeParamsToStream(std::ostream& out) const;
+  void readParamsFromStream(std::istream& in);            // CComponentKern, CKern.cpp:125-140
   std::ostream& display(std::ostream& os) const;
 
  private:
   void _init();
   std::vector<CKern*> components;
 };
+// readKernFromStream (CKern.cpp:4192-4260) for the kernel types of the accelerated set; the caller owns the result.
+CKern* readKernFromStream(std::istream& in);
 #endif

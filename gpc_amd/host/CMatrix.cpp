@@ -1,6 +1,7 @@
 // CMatrix.cpp -- see CMatrix.h.  Host-side bookkeeping plus calls into libgpc_hip.so (include/gpc_hip.h); no LAPACK,
 // no CPU fallback for the factorisation / solve members.
 #include "CMatrix.h"
+#include "ndlstream.h"
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -571,15 +572,7 @@ void CMatrix::fromUnheadedFile(const std::string fileName)
   if(!in) throw ndlexceptions::FileReadError(fileName);
   fromUnheadedStream(in);
 }
-static std::string readField(std::istream& in, const std::string& name)
-{
-  std::string line;
-  if(!std::getline(in, line)) throw ndlexceptions::StreamFormatError(name, "unexpected end of stream");
-  if(!line.empty() && line[line.size() - 1] == '\r') line.erase(line.size() - 1);
-  const size_t eq = line.find('=');
-  if(eq == std::string::npos || line.substr(0, eq) != name) throw ndlexceptions::StreamFormatError(name, "got '" + line + "'");
-  return line.substr(eq + 1);
-}
+using ndlstream::readField;
 void CMatrix::writeParamsToStream(std::ostream& out) const
 {
   out << "baseType=matrix" << std::endl << "type=doubleMatrix" << std::endl;
@@ -594,7 +587,7 @@ void CMatrix::readParamsFromStream(std::istream& in)
   resize(nr, nc);
   std::string line;
   for(int i = 0; i < nr; i++) {
-    if(!std::getline(in, line)) throw ndlexceptions::StreamFormatError("matrix", "Incorrect number of rows in matrix.");
+    if(!ndlstream::getline(in, line)) throw ndlexceptions::StreamFormatError("matrix", "Incorrect number of rows in matrix.");
     std::istringstream ss(line);
     std::string tok;
     int j = 0;
@@ -604,6 +597,11 @@ void CMatrix::readParamsFromStream(std::istream& in)
     }
     if(j != nc) throw ndlexceptions::StreamFormatError("matrix", "Incorrect number of columns");
   }
+}
+void CMatrix::fromStream(std::istream& in)   // CStreamInterface::fromStream: version line, then the parameters
+{
+  ndlstream::readVersion(in);
+  readParamsFromStream(in);
 }
 std::ostream& operator<<(std::ostream& os, const CMatrix& A)
 {

@@ -114,6 +114,7 @@ class CMatrix {
   void fromUnheadedFile(const std::string fileName);
   void writeParamsToStream(std::ostream& out) const;   // version/baseType/type/numRows/numCols + rows
   void readParamsFromStream(std::istream& in);
+  void fromStream(std::istream& in);
 
  private:
   void alloc(size_t rows, size_t cols, Residence r);

@@ -7,6 +7,7 @@
 #include <iostream>
 #include <string>
 #include "CMatrix.h"
+#include "ndlstream.h"
 
 class CNoise {
  public:
@@ -26,9 +27,15 @@ class CNoise {
 class CGaussianNoise : public CNoise {
  public:
   explicit CGaussianNoise(CMatrix* pyin) : sigma2(1e-6), bias(1, pyin->getCols(), 0.0) { py = pyin; }   // CNoise.cpp:340-346
+  explicit CGaussianNoise(unsigned int outDim) : sigma2(1e-6), bias(1, outDim, 0.0) {}   // read from a model file: no targets yet
   std::string getType() const { return "gaussian"; }
-  unsigned int getOutputDim() const { return py->getCols(); }
+  unsigned int getOutputDim() const { return bias.getCols(); }
   void setBias(double v) { bias.setVals(v); }
+  void setParams(const CMatrix& par)   // [bias..., sigma2], CNoise.cpp:401-410
+  {
+    for(unsigned int j = 0; j < getOutputDim(); j++) bias.setVal(par.getVal(0, j), 0, j);
+    sigma2 = par.getVal(0, getOutputDim());
+  }
   void setBias(const CMatrix& b) { bias.deepCopy(b); }
   double getBiasVal(unsigned int j) const { return bias.getVal(0, j); }
   double getSigma2() const { return sigma2; }
@@ -156,4 +163,25 @@ class CScaleNoise : public CNoise {
   double sigma2;
   CMatrix bias, scale;
 };
+// readNoiseFromStream (CNoise.cpp:1813-1836) for the Gaussian noise model; the caller owns the result.
+inline CNoise* readNoiseFromStream(std::istream& in)
+{
+  ndlstream::readVersion(in);
+  const std::string base = ndlstream::readField(in, "baseType");
+  if(base != "noise")
+    throw ndlexceptions::StreamFormatError("baseType", "Error mismatch between saved base type, " + base + ", and Class base type, noise.");
+  const std::string type = ndlstream::readField(in, "type");
+  if(type != "gaussian")
+    throw ndlexceptions::StreamFormatError("type", "Noise type " + type + " is outside the accelerated path (gaussian)");
+  // CNoise::readParamsFromStream, CNoise.cpp:286-305
+  const unsigned int outDim = (unsigned int)ndlstream::readInt(in, "outputDim");
+  const unsigned int numPar = (unsigned int)ndlstream::readInt(in, "numParams");
+  CMatrix par(1, numPar);
+  par.fromStream(in);
+  if(numPar != outDim + 1)
+    throw ndlexceptions::StreamFormatError("numParams", "Number of parameters in file does not match computed number.");
+  CGaussianNoise* n = new CGaussianNoise(outDim);
+  n->setParams(par);
+  return n;
+}
 #endif

@@ -2,8 +2,8 @@
 //     gp [-v verbosity] [-s seed] learn [flags] trainData.svml [modelFile]
 // Same flags, defaults and model construction as the reference's `learn` (gp.cpp:86-437) for the kernels the HIP
 // path covers (rbf, lin, bias, white, `-i 1` for rbfard): kernel = cmpnd{ <-k kernels, default rbf>, bias, white },
-// Gaussian noise, bias = mean(y) unless -C 0, FTC only.  The other commands (display, gnuplot, relearn) and the
-// sparse approximations are outside the hot path.
+// Gaussian noise, bias = mean(y) unless -C 0, FTC only.  `relearn` and `display` read the reference's text model files
+// (and the ones this tool writes); `gnuplot` and the sparse approximations are outside the hot path.
 #include <cstdlib>
 #include <iostream>
 #include <string>
@@ -17,12 +17,16 @@ class CClgp : public CClctrl {
  public:
   CClgp(int argc, char** argv) : CClctrl(argc, argv) {}
   void learn();
+  void relearn();
+  void display();
   void helpInfo();
 };
 
 void CClgp::helpInfo()
 {
-  std::cout << "gp [-v verbosity] [-s seed] learn [-k kernel [-g gamma] [-v variance] [-i 0|1]]... [-C 0|1] [-S 0|1]\n"
+  std::cout << "gp [-v verbosity] [-s seed] relearn [-# iterations] trainData.svml [modelFile] [newModelFile]\n"
+               "gp display [modelFile]\n"
+               "gp [-v verbosity] [-s seed] learn [-k kernel [-g gamma] [-v variance] [-i 0|1]]... [-C 0|1] [-S 0|1]\n"
                "   [-# iterations] [-O scg] [-A ftc] trainData.svml [modelFile]\n"
                "kernels: rbf (with -i 1: rbfard), lin, bias, white.  bias and white terms are always appended.\n";
 }
@@ -148,6 +152,69 @@ void CClgp::learn()
               << "  SCG iterations: " << model.getIterations() << std::endl;
 }
 
+// gp relearn [-# iterations] trainData.svml [modelFile] [newModelFile]  (gp.cpp:439-534): continue the optimisation of a
+// stored model on (possibly new) data of the same input dimension.
+void CClgp::relearn()
+{
+  incrementArgument();
+  setMode("relearn");
+  std::string optimiser = "scg", modelFileName = "gp_model", newModelFileName = "gp_model";
+  int iters = 1000;
+  while(isFlags()) {
+    if(isCurrentArgumentFlag()) {
+      if(isCurrentArg("-?", "--?") || isCurrentArg("-h", "--help")) { helpInfo(); exitNormal(); }
+      else if(isCurrentArg("-O", "--optimiser")) { incrementArgument(); optimiser = getCurrentArgument(); }
+      else if(isCurrentArg("-#", "--#iterations")) { incrementArgument(); iters = getIntFromCurrentArgument(); }
+      else unrecognisedFlag();
+      incrementArgument();
+    } else {
+      setFlags(false);
+    }
+  }
+  if(getCurrentArgumentNo() >= argc) exitError("There are not enough input parameters.");
+  const std::string trainDataFileName = getCurrentArgument();
+  if(getCurrentArgumentNo() + 1 < argc) modelFileName = argv[getCurrentArgumentNo() + 1];
+  if(getCurrentArgumentNo() + 2 < argc) newModelFileName = argv[getCurrentArgumentNo() + 2];
+  if(optimiser != "scg") exitError("Unrecognised optimiser type: " + optimiser + " (scg is the one provided).");
+  CMatrix X, y;
+  readData(X, y, trainDataFileName);
+  CGp* pmodel = readGpFromFile(modelFileName, getVerbosity());
+  if(pmodel->getInputDim() != X.getCols())
+    throw ndlexceptions::Error(trainDataFileName + ": input data is not of correct dimension");
+  pmodel->setData(&X, &y);   // pmodel->py = &y; updateM(); pmodel->pX = &X  (gp.cpp:484-487)
+  pmodel->updateM();
+  pmodel->setDefaultOptimiser(CGp::SCG);
+  pmodel->optimise(iters);
+  std::string comment = "Run as:";
+  for(int i = 0; i < argc; i++) {
+    comment += " ";
+    comment += argv[i];
+  }
+  comment += " with seed " + std::to_string(getSeed()) + ".";
+  writeGpToFile(*pmodel, newModelFileName, comment);
+  delete pmodel;
+}
+
+// gp display [modelFile]  (gp.cpp:536-565)
+void CClgp::display()
+{
+  incrementArgument();
+  setMode("display");
+  while(isFlags()) {
+    if(isCurrentArgumentFlag()) {
+      if(isCurrentArg("-?", "--?") || isCurrentArg("-h", "--help")) { helpInfo(); exitNormal(); }
+      else unrecognisedFlag();
+      incrementArgument();
+    } else {
+      setFlags(false);
+    }
+  }
+  const std::string modelFileName = (getCurrentArgumentNo() >= argc) ? "gp_model" : getCurrentArgument();
+  CGp* pmodel = readGpFromFile(modelFileName, getVerbosity());
+  pmodel->display(std::cout);
+  delete pmodel;
+}
+
 int main(int argc, char* argv[])
 {
   CClgp command(argc, argv);
@@ -166,8 +233,14 @@ int main(int argc, char* argv[])
       } else if(command.getCurrentArgumentNo() < argc && command.getCurrentArgument() == "learn") {
         command.learn();
         return 0;
+      } else if(command.getCurrentArgumentNo() < argc && command.getCurrentArgument() == "relearn") {
+        command.relearn();
+        return 0;
+      } else if(command.getCurrentArgumentNo() < argc && command.getCurrentArgument() == "display") {
+        command.display();
+        return 0;
       } else {
-        command.exitError("Invalid gp command provided (this build implements `learn`).");
+        command.exitError("Invalid gp command provided (this build implements learn, relearn and display).");
       }
     }
   } catch(ndlexceptions::Error& err) {

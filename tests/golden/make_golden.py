@@ -171,6 +171,34 @@ def sinc_golden():
          kern_params=np.array(flat[2:6]), noise_params=np.array(flat[6:8]))
 
 
+def model_golden():
+    """Model-file fixtures: OUTPUT files of the compiled reference's own `gp` tool on sinc --
+    after 20 iterations and at convergence (hexadecimal floats, as its libstdc++ writes them) -- and the parameters it
+    reaches when `gp relearn -# 30` continues from the 20-iteration file."""
+    import re
+    import subprocess
+    import tempfile
+    ref_gp = os.path.join(ROOT, "oracle", "_ref", "gp")
+    svml = os.path.join(OUT, "sinc.svml")
+    env = dict(os.environ, LD_PRELOAD=refrun.MKL)
+
+    def params(path):
+        rows = [ln.split() for ln in open(path) if (ln.startswith("0x") or re.match(r"^-?\d", ln)) and "=" not in ln]
+        return np.array([float.fromhex(t) if "x" in t else float(t) for row in rows for t in row])
+
+    with tempfile.TemporaryDirectory() as td:
+        run = lambda args: subprocess.run([ref_gp] + args, env=env, stdin=subprocess.DEVNULL, stdout=subprocess.DEVNULL,
+                                          stderr=subprocess.DEVNULL, check=True, cwd=td)
+        run(["-v", "0", "-s", "1", "learn", "-#", "100", svml, "final.model"])
+        run(["-v", "0", "-s", "1", "learn", "-#", "20", svml, "m20.model"])
+        run(["-v", "0", "-s", "1", "relearn", "-#", "30", svml, "m20.model", "m50.model"])
+        for src, dst in (("final.model", "sinc_ref_final.model"), ("m20.model", "sinc_ref_iter20.model")):
+            with open(os.path.join(td, src)) as f, open(os.path.join(OUT, dst), "w") as g:
+                g.write("".join(ln for ln in f if not ln.startswith("#")))      # drop the "Run as" comment (paths)
+        save("sinc_relearn", iter20=params(os.path.join(td, "m20.model")), relearn30=params(os.path.join(td, "m50.model")),
+             final=params(os.path.join(td, "final.model")))
+
+
 def read_svml(path, nrows=None):
     """SVMlight rows `label idx:val ...` -> (Y dense, labels); missing features are 0 (CClctrl.cpp:57-180)."""
     rows, labs = [], []
@@ -235,3 +263,5 @@ if __name__ == "__main__":
         sinc_golden()
     if what in ("all", "gplvm"):
         gplvm_golden()
+    if what in ("all", "model"):
+        model_golden()

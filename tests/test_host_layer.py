@@ -157,3 +157,40 @@ def test_gplvm_learn_oil_matches_the_reference_run(tmp_path):
     kern = np.array(kp[0] + kp[1] + kp[2])
     assert rel(kern, g["n1000_kern_final"].ravel()) < 1e-6
     assert "type=gplvm" in "\n".join(lines[:12]) and "type=rbfard" in "\n".join(lines[:40])
+
+
+def _model_numbers(path):
+    rows = [ln.split() for ln in open(path) if (ln.startswith("0x") or re.match(r"^-?\d", ln)) and "=" not in ln]
+    return np.array([float.fromhex(t) if "x" in t else float(t) for row in rows for t in row])
+
+
+def test_gp_display_reads_the_reference_model_file():
+    """CPU: `gp display` parses a model file written by the compiled reference (hexadecimal floats) -- no GPU involved."""
+    if not os.path.exists(os.path.join(HOST, "gp")):
+        pytest.skip("host layer not built")
+    g = dict(np.load(os.path.join(GOLDEN, "sinc_relearn.npz")))
+    out = _run([os.path.join(HOST, "gp"), "display", os.path.join(GOLDEN, "sinc_ref_final.model")])
+    vals = [float(v) for v in re.findall(r"^(?:inverseWidth|variance): (\S+)$", out, flags=re.M)]
+    assert len(vals) == 4
+    assert np.allclose(vals, g["final"][2:6], rtol=2e-6)          # printed with 6 significant digits
+    assert "Data Set Size: 40" in out and "Compound kernel:" in out
+
+
+@pytest.mark.gpu
+def test_gp_relearn_continues_like_the_reference(tmp_path):
+    """`gp relearn -# 30` from the reference's 20-iteration model file reaches the parameters the reference's own relearn
+    reaches; the file it writes is read back by `gp display`."""
+    g = dict(np.load(os.path.join(GOLDEN, "sinc_relearn.npz")))
+    new = tmp_path / "m50.model"
+    _run([os.path.join(HOST, "gp"), "-v", "0", "-s", "1", "relearn", "-#", "30", os.path.join(GOLDEN, "sinc.svml"),
+          os.path.join(GOLDEN, "sinc_ref_iter20.model"), str(new)])
+    got = _model_numbers(str(new))
+    assert got.shape == g["relearn30"].shape
+    assert rel(got[2:6], g["relearn30"][2:6]) < 1e-6
+    assert abs(got[1] - g["relearn30"][1]) < 1e-15 and got[0] == 1.0
+    out = _run([os.path.join(HOST, "gp"), "display", str(new)])
+    assert "Compound kernel:" in out
+    import shutil
+    keep = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(keep):
+        shutil.copyfile(str(new), os.path.join(keep, "sinc_relearn_written_by_this_build.model"))

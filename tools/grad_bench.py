@@ -1,0 +1,42 @@
+#!/usr/bin/env python
+"""HBM-bound passes of one gradient evaluation on one size: covGrad, kernel-parameter gradient, dL/dX (run on the GPU box)."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from gpc_amd import api
+
+def bench(fn, reps=3):
+    fn(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 32768
+D = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+X = torch.randn((D, N), dtype=torch.float64, device="cuda").t()
+invK = torch.randn((N, N), dtype=torch.float64, device="cuda").t()
+a = torch.randn((1, N), dtype=torch.float64, device="cuda").t()
+A12 = torch.randn((12, N), dtype=torch.float64, device="cuda").t()
+cg = api.empty(N, N)
+GB = 8.0 * N * N * 1e-9
+for name, terms in (("rbf+white", [("rbf", [1.0, 1.0]), ("white", [0.1])]),
+                    ("rbfard+bias+white", [("rbfard", [1.0, 1.0] + [0.5] * D), ("bias", [0.1]), ("white", [0.1])])):
+    ks = api.kspec(terms)
+    t = bench(lambda: api.kern_grad(ks, X, invK))
+    print("N=%d D=%d kern_grad %-18s %8.3f ms  %7.0f GB/s (reads 8N^2)" % (N, D, name, t, GB / t * 1e3))
+    if D <= 16:
+        t = bench(lambda: api.kern_gradx(ks, X, invK))
+        print("N=%d D=%d kern_gradx %-17s %8.3f ms  %7.0f GB/s (reads 8N^2)" % (N, D, name, t, GB / t * 1e3))
+t = bench(lambda: api.covgrad(invK, a, out=cg))
+print("N=%d covgrad (d=1)        %8.3f ms  %7.0f GB/s (reads + writes 16N^2)" % (N, t, 2 * GB / t * 1e3))
+t = bench(lambda: api.covgrad_multi(invK, A12, out=cg))
+print("N=%d covgrad_multi (d=12) %8.3f ms  %7.0f GB/s" % (N, t, 2 * GB / t * 1e3))
+y = api.zeros(N, 1)
+t = bench(lambda: api.symv(invK, a, y))
+print("N=%d symv                 %8.3f ms  %7.0f GB/s (reads 8N^2)" % (N, t, GB / t * 1e3))
+t = bench(lambda: api.symmetrize_(invK, "L"))
+print("N=%d symmetrize           %8.3f ms  %7.0f GB/s (reads 4N^2 + writes 4N^2)" % (N, t, GB / t * 1e3))
+t = bench(lambda: api.transpose_(invK))
+print("N=%d transpose in place   %8.3f ms  %7.0f GB/s (reads + writes 16N^2)" % (N, t, 2 * GB / t * 1e3))
