@@ -35,7 +35,7 @@ struct GramArgs {
   int sym_diag;          // 1: elements with global i == j take the diagComputeElement value
   int mirror;            // 1: the whole symmetric Gram of one X is being built: tiles left of the diagonal block are
                          //    computed once and stored twice (K(i,j) and K(j,i)); tiles right of it are skipped
-  int debug;             // ablation knob (env GPC_GRAM_DEBUG): 1 no exp, 2 no MFMA loop, 3 no stores; 0 in production
+  int debug;             // ablation knob (env GPC_GRAM_DEBUG): 2 no MFMA loop, 3 no stores; 0 in production
 };
 
 __global__ void __launch_bounds__(256) row_norms_kernel(const double* __restrict__ X, int64_t ldx, int64_t N,
@@ -179,6 +179,23 @@ __global__ void __launch_bounds__(256) gram_kernel(const KSpecDev ks, const Gram
 // 4 x 2 MFMA tiles; operand roles are swapped as in gemm_f64.hip so that the 16 lanes sharing an accumulator register
 // hold 16 consecutive rows of K (128-byte store runs).  LDS row strides 144 / 80 doubles keep the 32-lane
 // ds_read_b64 groups conflict-free.
+// One Gram element from the two squared norms and the dot product, with the contractions written out so that every
+// MFMA-path kernel (per-tile, persistent, symmetric) rounds identically: the block build used by the multi-GPU path
+// and the mirrored single-GPU build give the same bits.
+template <int NRBF>
+__device__ __forceinline__ double gram_value(const KSpecDev& ks, double ni, double nj, double dot, int n_rbf_rt)
+{
+  const double d2 = fma(-2.0, dot, ni + nj);
+  double k = fma(ks.lin_var, dot, ks.bias_var);
+  if(NRBF >= 0) {
+#pragma unroll
+    for(int q = 0; q < (NRBF >= 0 ? NRBF : 0); q++) k = fma(ks.rbf_var[q], exp(-(ks.rbf_hiw[q] * d2)), k);
+  } else {
+    for(int q = 0; q < n_rbf_rt; q++) k = fma(ks.rbf_var[q], exp(-(ks.rbf_hiw[q] * d2)), k);
+  }
+  return k;
+}
+
 constexpr int MI = 128, MJ = 64, SI = 144, SJ = 80;
 constexpr int MDC = 32;  // feature chunk of the MFMA variant: D <= 32 needs a single staging round trip
 
@@ -274,12 +291,8 @@ __global__ void __launch_bounds__(256, 2) gram_mfma_kernel(const KSpecDev ks, co
         const int64_t gi = i0 + wm * 64 + tm * 16 + (lane & 15);
         if(gi >= g.N) continue;
         const double dot = acc[tm][tn][r];
-        const double d2 = ni[tm] + nj - 2.0 * dot;
-        double k = ks.bias_var + ks.lin_var * dot;
-        if(g.debug == 1) k += d2;
-        else
-          for(int q = 0; q < ks.n_rbf; q++) k += ks.rbf_var[q] * exp(-(ks.rbf_hiw[q] * d2));
-        if(g.sym_diag && (g.i_off + gi == g.j_off + gj)) k = diag_const + ks.lin_var * ni[tm];
+        double k = gram_value<-1>(ks, ni[tm], nj, dot, ks.n_rbf);
+        if(g.sym_diag && (g.i_off + gi == g.j_off + gj)) k = fma(ks.lin_var, ni[tm], diag_const);
         if(g.debug != 3 || k == 123.456) g.K[gi + gj * g.ldk] = k;
       }
     }
@@ -400,19 +413,13 @@ __global__ void __launch_bounds__(256, 2) gram_mfma_persist_kernel(const KSpecDe
         double kv[4];
 #pragma unroll
         for(int tm = 0; tm < 4; tm++) {
-          const double dot = acc[tm][tn][r];
-          const double d2 = ni[tm] + nj - 2.0 * dot;
-          double k = ks.bias_var + ks.lin_var * dot;
-#pragma unroll
-          for(int q = 0; q < NRBF; q++)
-            k += (g.debug == 1) ? ks.rbf_var[q] * d2 : ks.rbf_var[q] * exp(-(ks.rbf_hiw[q] * d2));
-          kv[tm] = k;
+          kv[tm] = gram_value<NRBF>(ks, ni[tm], nj, acc[tm][tn][r], 0);
         }
 #pragma unroll
         for(int tm = 0; tm < 4; tm++) {
           const int64_t gi = i0 + wm * 64 + tm * 16 + (lane & 15);
           double k = kv[tm];
-          if(g.sym_diag && (g.i_off + gi == g.j_off + gj)) k = diag_const + ks.lin_var * ni[tm];
+          if(g.sym_diag && (g.i_off + gi == g.j_off + gj)) k = fma(ks.lin_var, ni[tm], diag_const);
           kv[tm] = k;
           if((full || (gi < g.N && gj < g.N2)) && (g.debug != 3 || k == 123.456)) g.K[gi + gj * g.ldk] = k;
         }
@@ -559,19 +566,14 @@ __global__ void __launch_bounds__(256, 2) gram_sym_kernel(const KSpecDev ks, con
 #pragma unroll
           for(int u = 0; u < 2; u++) {
             const int tm = th + u;
-            const double dot = acc[tm][tn][r];
-            const double d2 = ni[tm] + nj - 2.0 * dot;
-            double k = ks.bias_var + ks.lin_var * dot;
-#pragma unroll
-            for(int q = 0; q < NRBF; q++) k += ks.rbf_var[q] * exp(-(ks.rbf_hiw[q] * d2));
-            kv[u] = k;
+            kv[u] = gram_value<NRBF>(ks, ni[tm], nj, acc[tm][tn][r], 0);
           }
 #pragma unroll
           for(int u = 0; u < 2; u++) {
             const int tm = th + u;
             const int64_t gi = i0 + wm * 64 + tm * 16 + (lane & 15);
             double k = kv[u];
-            if(gi == gj) k = diag_const + ks.lin_var * ni[tm];   // diagComputeElement
+            if(gi == gj) k = fma(ks.lin_var, ni[tm], diag_const);   // diagComputeElement
             if(full || (gi < g.N && gj < g.N)) g.K[gi + gj * g.ldk] = k;
             if(mirror) Tw[(tm * 16 + (lane & 15)) * TS + 4 * r + (lane >> 4)] = k;
           }

@@ -417,3 +417,79 @@ def test_cfg2_full_size_properties(api):
     L2, logdet2, _, _ = api.gp_update_k(ks, Xd)
     assert logdet2 == logdet and torch.equal(torch.tril(L2), torch.tril(L))
     assert np.isfinite(ll1)
+
+
+# ---- edge cases and BASELINE config 3 at full size ---------------------------------------------------------------------------------
+
+def test_empty_and_degenerate_sizes(api):
+    """N = 0 / nrhs = 0 / D = 1 calls are no-ops or trivial, never errors (the reference's loops simply do not run)."""
+    import torch
+    ks = api.kspec([("rbf", [1.0, 1.0]), ("white", [0.1])])
+    X0 = torch.empty((1, 0), dtype=torch.float64, device="cuda").t()           # 0 x 1
+    K0 = api.gram_sym(ks, X0)
+    assert tuple(K0.shape) == (0, 0)
+    assert api.potrf(K0, "L") == 0
+    B0 = torch.empty((0, 5), dtype=torch.float64, device="cuda").t()           # 5 x 0: no right-hand sides
+    L = api.from_host(np.eye(5))
+    api.trsm(L, B0)
+    X1 = api.from_host(np.array([[0.3]]))
+    K1 = api.gram_sym(ks, X1)
+    assert abs(api.to_host(K1)[0, 0] - 1.1) < 1e-15
+    assert api.potrf(K1, "L") == 0 and abs(api.to_host(K1)[0, 0] - np.sqrt(1.1)) < 1e-15
+    assert np.array_equal(api.kern_grad(ks, X0, K0), np.zeros(3))
+
+
+def test_gram_symmetric_build_is_bitwise_the_block_build(api):
+    """the mirrored symmetric kernel and the generic block kernel produce the same bits (ragged N, D not a multiple of 4)"""
+    import torch
+    rng = np.random.RandomState(11)
+    for N, D, terms in ((1000, 7, [("rbf", [0.3, 1.2]), ("bias", [0.1]), ("white", [0.2])]),
+                        (777, 32, [("rbf", [0.05, 1.0]), ("rbf", [0.5, 0.3]), ("white", [0.1])]),
+                        (130, 1, [("rbf", [1.0, 1.0]), ("lin", [0.5]), ("white", [0.01])])):
+        X = api.from_host(rng.randn(N, D))
+        ks = api.kspec(terms)
+        K = api.to_host(api.gram_sym(ks, X))
+        assert np.array_equal(K, K.T)
+        Kb = api.to_host(api.gram_block(ks, X, 0, N, 0, N))
+        assert np.array_equal(K, Kb)
+
+
+def test_cfg3_full_size_properties(api):
+    """BASELINE config 3 at its full size (N = 65 536, D = 32, rbf + white; 34 GB per matrix): sampled columns of
+    L L' against K, K alpha = m, (K^-1 K) e_j = e_j for the explicit inverse, symmetry of the mirrored Gram build."""
+    import torch
+    from gpc_amd import synth
+    if torch.cuda.get_device_properties(0).total_memory < 200e9:
+        pytest.skip("needs ~140 GB of HBM")
+    c = synth.CONFIGS["cfg3"]
+    N = c["N"]
+    X, y = synth.make_xy(N, c["D"], 1234)
+    ks = api.kspec(c["kern"])
+    Xd = api.from_host(X)
+    K = api.gram_sym(ks, Xd)
+    idx = torch.tensor([0, 1, 4095, 32768, 65000, N - 1], device="cuda")
+    assert torch.equal(K[idx, :], K[:, idx].t())                               # mirrored build is exactly symmetric
+    blk = api.gram_block(ks, Xd, 30000, 300, 100, 200)
+    assert torch.equal(blk, K[30000:30300, 100:300])
+    Kcols = K[:, idx].clone()
+    L, logdet, jit, info = api.gp_update_k(ks, Xd, K)
+    assert info == 0 and jit == 0.0 and np.isfinite(logdet)
+    # (L L')(i, j) for the sampled columns j and all rows i >= j: only lower-triangle entries of L are involved
+    for q, j in enumerate(idx.tolist()):
+        col = L[j:, :j + 1] @ L[j, :j + 1]
+        assert float((col - Kcols[j:, q]).abs().max()) < 1e-10
+    m = api.from_host(y - y.mean())
+    alpha = api.gp_alpha(L, m)
+    Kfull = api.gram_sym(ks, Xd)
+    resid = float((Kfull @ alpha - m).abs().max())
+    assert resid < 1e-9 * max(1.0, float(alpha.abs().max()))
+    del Kfull
+    inv = L.clone()
+    api.potri(inv, "L")
+    E = torch.zeros((N, 4), dtype=torch.float64, device="cuda")
+    for q, j in enumerate([0, 777, 40000, N - 1]):
+        E[j, q] = 1.0
+    Kfull = api.gram_sym(ks, Xd)
+    Z = Kfull @ (inv @ E)
+    assert float((Z - E).abs().max()) < 1e-9
+    assert torch.equal(inv[idx, :], inv[:, idx].t())
