@@ -276,8 +276,9 @@ class DistGp(object):
             w, M = self.width(k), self.Mtot - k * self.nb
             sb = self.slab if (self.comm and self.slab > 0) else w
             works = []
+            after_first, after_rest = after if isinstance(after, tuple) else (after, None)
             if own:
-                st.wait(st.panel, after)
+                st.wait(st.panel, after_first)
                 pv = self.panel_view(k)
             # The panel leaves in column slabs: slab s is final as soon as it is factored, so its broadcast overlaps
             # the factorisation of slabs s+1.. (a slab of whole columns is one contiguous piece of the buffer).
@@ -292,6 +293,9 @@ class DistGp(object):
                     works.append(wk)
                 if own and c0 + ws < w:
                     # right-looking step inside the panel: the columns still to be factored take this slab's update
+                    if after_rest is not None:
+                        st.wait(st.panel, after_rest)     # ... once the previous panel's update has reached them
+                        after_rest = None
                     r0 = k * self.nb + c0 + ws
                     self.ops.syrk_blockcyclic(pv[c0 + ws:, c0:c0 + ws], pv[c0 + ws:, c0 + ws:w], r0, r0 // sb, 1, sb)
             if own:
@@ -328,8 +332,14 @@ class DistGp(object):
             if k + 1 < T and self.owner(k + 1) == r:
                 # U1: the next panel first, so that its factorisation overlaps the rest of this update
                 w1 = self.width(k + 1)
-                self.ops.syrk_blockcyclic(Pk, self.A[row0:, c0:c0 + w1], row0, k + 1, P, nb)
+                sa = min(self.slab, w1) if (self.comm and self.slab > 0) else w1
+                # ... and its first slab before the rest of it: that slab's factorisation is what the chain waits for
+                self.ops.syrk_blockcyclic(Pk, self.A[row0:, c0:c0 + sa], row0, k + 1, P, nb)
                 u1 = st.record(st.main)
+                if sa < w1:
+                    self.ops.syrk_blockcyclic(Pk, self.A[row0:, c0 + sa:c0 + w1], row0, (row0 + sa) // self.slab, 1,
+                                              self.slab)
+                    u1 = (u1, st.record(st.main))
                 c0 += w1
                 l0 += 1
             if k + 1 < T:

@@ -52,6 +52,14 @@ def main():
             api.potrf_panel(pan, k * nb, info)
         t_copy = timeit(lambda: pan.copy_(keep))
         t_fact = timeit(fact) - t_copy
+        def fact_slabs(sb=128):
+            pan.copy_(keep)
+            for c0 in range(0, nb, sb):
+                api.potrf_panel(pan[c0:, c0:c0 + sb], k * nb + c0, info)
+                if c0 + sb < nb:
+                    r0 = k * nb + c0 + sb
+                    api.syrk_blockcyclic(pan[c0 + sb:, c0:c0 + sb], pan[c0 + sb:, c0 + sb:nb], r0, r0 // sb, 1, sb)
+        t_slab = timeit(fact_slabs) - t_copy
         flat = torch.empty(M * nb, dtype=torch.float64, device="cuda")
         view = flat.view(nb, M).t()
         src = A[k * nb:, 0:nb]
@@ -68,7 +76,7 @@ def main():
             g0 = mine[l] * nb
             entries += (N - g0) * nb - 0.5 * nb * (nb - 1)
         assert int(info.item()) == 0
-        out.append({"k": k, "M": M, "panel_factor_ms": t_fact, "pack_ms": t_pack, "update_ms": t_upd,
+        out.append({"k": k, "M": M, "panel_factor_ms": t_fact, "panel_factor_128slabs_ms": t_slab, "pack_ms": t_pack, "update_ms": t_upd,
                     "update_tflops": 2.0 * nb * entries / (t_upd * 1e-3) * 1e-12,
                     "panel_bytes_MB": M * nb * 8 / 1e6})
     print(json.dumps({"N": N, "P": P, "nb": nb, "rank": r, "pieces": out}))
