@@ -36,11 +36,24 @@ int g_lookahead = -1;
 // Factor the n x n (n <= 64) diagonal block at A (lower, in place).  col0 = global index of the block's first
 // column, for `info`.  Thread t owns row r = t & 63 and, at outer step jq, the columns c = 4 (q + jq) + g in register
 // slot q (g = t >> 6 = the wave index).
+// 1 / p for a positive pivot: v_rcp_f64 seed + two Newton steps (5 dependent instructions instead of the ~12 of an
+// IEEE division: this sits on the column-to-column critical path of potf2).  Out-of-range pivots take the division.
+__device__ __forceinline__ double pivot_rcp(double p)
+{
+  if(!(p > 1e-280 && p < 1e280)) return 1.0 / p;
+  double x = __builtin_amdgcn_rcp(p);
+  double e = fma(-p, x, 1.0);
+  x = fma(x, e, x);
+  e = fma(-p, x, 1.0);
+  return fma(x, e, x);
+}
+
 __global__ void __launch_bounds__(256) potf2_kernel(double* __restrict__ A, int64_t lda, int n,
                                                     int* __restrict__ info, int64_t col0)
 {
   __shared__ double col[2][JB];
-  __shared__ double Lout[JB * JB];
+  __shared__ double Lout[JB * JB];   // raw (unscaled) finished columns: a(r,j) after the updates of columns < j
+  __shared__ double piv[JB];         // pivots a(j,j)
   const int t = threadIdx.x;
   if(*info != 0) return;  // an earlier block already failed: uniform exit
   const int r = t & 63, g = t >> 6;
@@ -72,14 +85,15 @@ __global__ void __launch_bounds__(256) potf2_kernel(double* __restrict__ A, int6
         return;
       }
       const double cr = cj[r];
-      // the owner wave records the finished column: L(j,j) = sqrt(pivot), L(r,j) = a(r,j) / sqrt(pivot).  It goes to
-      // LDS, not to global memory: a global store inside this loop makes every barrier wait for its completion
-      // (~1 us per column).
-      const double d = sqrt(pj);
-      const double rs = 1.0 / d;            // one sqrt + one divide per column (both wave-uniform)
-      const double lr = cr * rs;            // L(r,j)
-      if(g == jj) Lout[j * JB + r] = (r == j) ? d : lr;
-      const double lrj = lr * rs;           // a(r,j) / pivot
+      // The finished column is recorded RAW (a(r,j) and the pivot); L(r,j) = a(r,j) / sqrt(pivot) is formed for the
+      // whole block after the loop, in parallel.  Inside the loop only a(r,j) / pivot is needed, so the sqrt and the
+      // division are off the 64-step critical path (they used to be most of it).  It goes to LDS, not to global
+      // memory: a global store inside this loop makes every barrier wait for its completion (~1 us per column).
+      if(g == jj) {
+        Lout[j * JB + r] = cr;
+        if(r == j) piv[j] = pj;
+      }
+      const double lrj = cr * pivot_rcp(pj);  // a(r,j) / pivot
       // branch-free: unconditional (clamped) LDS reads issued together, the predicate applied by select.  With the
       // reads inside 16 divergent `if`s every one of them became its own LDS round trip (4x slower kernel).
       double cv[16];
@@ -97,10 +111,12 @@ __global__ void __launch_bounds__(256) potf2_kernel(double* __restrict__ A, int6
     for(int q = 0; q < 15; q++) a[q] = a[q + 1];  // rotate: next column group into slot 0
   }
   __syncthreads();
+  if(t < JB) piv[t] = sqrt(piv[t]);   // L(j,j)
+  __syncthreads();
 #pragma unroll
   for(int q = 0; q < 16; q++) {
     const int c = 4 * q + g;
-    if(r < n && c < n && r >= c) A[r + (int64_t)c * lda] = Lout[c * JB + r];
+    if(r < n && c < n && r >= c) A[r + (int64_t)c * lda] = (r == c) ? piv[c] : Lout[c * JB + r] / piv[c];
   }
 }
 
