@@ -518,7 +518,7 @@ int gemm(bool transa, bool transb, int64_t M, int64_t N, int64_t K, double alpha
     use_atomic = e ? (atoi(e) != 0) : 1;
   }
   g.atomic_c = (beta == 1.0 && use_atomic) ? 1 : 0;
-  g.kstart = (g_gemm_kstart && !transa && transb && M == N && K == M && tri == 1) ? 1 : 0;
+  g.kstart = (g_gemm_kstart && !transa && transb && M == N && K >= M && tri == 1) ? 1 : 0;
   g.tiles_m = (int)((M + BM - 1) / BM);
   g.tiles_n = (int)((N + BN - 1) / BN);
   g.super_m = (g.tiles_m + SUPER - 1) / SUPER;

@@ -49,21 +49,57 @@ __global__ void __launch_bounds__(64) trsm_diag_kernel(const double* __restrict_
   __shared__ double V[JB * (JB + 1)];
   const int t = threadIdx.x;
   const int64_t v0 = (int64_t)blockIdx.x * JB;
-  // triangle: S[i*(JB+1) + k] = S(i,k); rows are read by all lanes at the same address (broadcast)
-  for(int idx = t; idx < nb * nb; idx += 64) {
-    const int i = idx % nb, k = idx / nb;           // coalesced along the stored column
-    const double a = Abb[i + (int64_t)k * lda];     // A_bb(i,k)
-    if(a_trans) S[k * (JB + 1) + i] = a;            // S(k,i) = A_bb(i,k)
-    else S[i * (JB + 1) + k] = a;
+  // triangle: S[i*(JB+1) + k] = S(i,k); rows are read by all lanes at the same address (broadcast).
+  // All global loads are issued in batches of 16 before they are consumed: the rolled load -> LDS loops this kernel
+  // started with paid the memory latency ~190 times in a row (64 us per launch on a 1000-row right-hand side).
+  {
+    const int i = (t < nb) ? t : (nb - 1);
+#pragma unroll 1
+    for(int k0 = 0; k0 < JB; k0 += 16) {
+      double a[16];
+#pragma unroll
+      for(int u = 0; u < 16; u++) {
+        const int k = (k0 + u < nb) ? (k0 + u) : (nb - 1);
+        a[u] = Abb[i + (int64_t)k * lda];   // A_bb(i,k), coalesced along the stored column
+      }
+#pragma unroll
+      for(int u = 0; u < 16; u++) {
+        const int k = k0 + u;
+        if(t < nb && k < nb) {
+          if(a_trans) S[k * (JB + 1) + t] = a[u];   // S(k,i) = A_bb(i,k)
+          else S[t * (JB + 1) + k] = a[u];
+        }
+      }
+    }
   }
   // vectors: V[k*(JB+1) + v]
   if(vec_is_col) {
-    for(int v = 0; v < JB; v++) {
-      if(v0 + v < nvec && t < nb) V[t * (JB + 1) + v] = B[t + (v0 + v) * ldb];
+    const int tt = (t < nb) ? t : (nb - 1);
+#pragma unroll 1
+    for(int w0 = 0; w0 < JB; w0 += 16) {
+      double b[16];
+#pragma unroll
+      for(int u = 0; u < 16; u++) {
+        const int64_t v = (v0 + w0 + u < nvec) ? (v0 + w0 + u) : (nvec - 1);
+        b[u] = B[tt + v * ldb];
+      }
+#pragma unroll
+      for(int u = 0; u < 16; u++)
+        if(v0 + w0 + u < nvec && t < nb) V[t * (JB + 1) + w0 + u] = b[u];
     }
   } else {
-    for(int k = 0; k < nb; k++) {
-      if(v0 + t < nvec) V[k * (JB + 1) + t] = B[(v0 + t) + (int64_t)k * ldb];
+    const int64_t vv = (v0 + t < nvec) ? (v0 + t) : (nvec - 1);
+#pragma unroll 1
+    for(int k0 = 0; k0 < JB; k0 += 16) {
+      double b[16];
+#pragma unroll
+      for(int u = 0; u < 16; u++) {
+        const int k = (k0 + u < nb) ? (k0 + u) : (nb - 1);
+        b[u] = B[vv + (int64_t)k * ldb];
+      }
+#pragma unroll
+      for(int u = 0; u < 16; u++)
+        if(k0 + u < nb && v0 + t < nvec) V[(k0 + u) * (JB + 1) + t] = b[u];
     }
   }
   __syncthreads();
@@ -450,8 +486,11 @@ int potri_full(bool lower, int64_t N, double* A, int64_t lda, hipStream_t s)
 {
   if(N <= 0) return GPC_OK;
   if(!lower) GPC_CHECK(transpose_inplace(N, A, lda, s));
+  // W is N x Np, Np = N rounded up to the GEMM kernel's k-step: the extra columns stay zero, so the product over Np
+  // columns is the product over N and sizes that are not multiples of 16 still take the fast kernel
+  const int64_t Np = (N + 15) & ~(int64_t)15;
   void* ws = nullptr;
-  GPC_CHECK(workspace(WS_POTRI, sizeof(double) * (size_t)N * (size_t)N, &ws));
+  GPC_CHECK(workspace(WS_POTRI, sizeof(double) * (size_t)N * (size_t)Np, &ws));
   double* W = static_cast<double*>(ws);
   for(int64_t j0 = 0; j0 < N; j0 += 32768) {
     const int64_t nc = (N - j0 < 32768) ? (N - j0) : 32768;
@@ -459,11 +498,12 @@ int potri_full(bool lower, int64_t N, double* A, int64_t lda, hipStream_t s)
                        N, j0);
   }
   GPC_HIP_CHECK(hipGetLastError());
+  if(Np > N) GPC_HIP_CHECK(hipMemsetAsync(W + (size_t)N * N, 0, sizeof(double) * (size_t)N * (size_t)(Np - N), s));
   // V := L^-T (upper triangular; the strictly lower part of W stays exactly zero)
   GPC_CHECK(trsm_impl(false, true, true, false, N, N, 1.0, A, lda, W, N, true, s));
   {
     KStartScope ks;   // tiles skip the k < first-row part of the product (zeros of the upper-triangular operand)
-    GPC_CHECK(gemm(false, true, N, N, N, 1.0, W, N, W, N, 0.0, A, lda, 1, s));
+    GPC_CHECK(gemm(false, true, N, N, Np, 1.0, W, N, W, N, 0.0, A, lda, 1, s));
   }
   GPC_CHECK(symmetrize(true, N, A, lda, s));
   return GPC_OK;
