@@ -185,8 +185,11 @@ __device__ __forceinline__ void tv_solve64(const double* P, const double* Dinv, 
 }
 
 // One forward step: block rows [b0, b0+nb) of L x = b; then b[r] -= L(r, b0:b0+nb) x_b for the rows r below.
-// Workgroup = 64 rows x 4 waves; wave w owns the columns b0 + 16 w .. + 15 of the panel.  Its 16 panel loads are issued
-// FIRST, before the diagonal solve they do not depend on: the step then costs one memory round trip, not five.
+// A workgroup (4 waves; wave w owns the columns b0 + 16 w .. + 15 of the panel) solves the diagonal block ONCE and then
+// walks groups of 64 rows (group index blockIdx.x, + gridDim.x, ...): at most ~512 workgroups are launched, so on a
+// long panel the redundant solve is paid in one round instead of once per 64 rows, and the next group's 16 panel
+// loads are always in flight behind the current group's arithmetic.  The first group's loads are issued before the
+// solve they do not depend on.
 __global__ void __launch_bounds__(256) trsv_step_n_kernel(const double* __restrict__ L, int64_t ldl,
                                                           double* __restrict__ B, int64_t ldb, int64_t M, int64_t b0,
                                                           int nb, int d, int unit, double* __restrict__ Xout)
@@ -196,14 +199,21 @@ __global__ void __launch_bounds__(256) trsv_step_n_kernel(const double* __restri
   __shared__ double Y[TV_MAXRHS * 64];
   __shared__ double Red[3][TV_MAXRHS][64];
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
-  const int64_t r = b0 + nb + (int64_t)blockIdx.x * 64 + lane;
-  const int64_t rc = (r < M) ? r : (M - 1);
-  double a[16];
+  const int64_t rest = M - (b0 + nb);
+  const int64_t ngroups = (rest + 63) / 64;
+  const double* Lpan = L + (b0 + (int64_t)((16 * w < nb) ? 16 * w : 0)) * ldl;   // this wave's 16 columns
+  auto load_group = [&](int64_t grp, double (&a)[16]) {
+    int64_t r = b0 + nb + grp * 64 + lane;
+    if(r > M - 1) r = M - 1;
 #pragma unroll
-  for(int u = 0; u < 16; u++) {
-    const int k = (16 * w + u < nb) ? (16 * w + u) : (nb - 1);   // clamped: x is zero past a ragged block
-    a[u] = L[rc + (b0 + k) * ldl];
-  }
+    for(int u = 0; u < 16; u++) {
+      const int k = (16 * w + u < nb) ? u : 0;   // clamped: x is zero past a ragged block
+      a[u] = Lpan[r + (int64_t)k * ldl];
+    }
+  };
+  double a[16], an[16];
+  int64_t grp = blockIdx.x;
+  if(grp < ngroups) load_group(grp, a);
   {
     double pa[16];   // P[k*65 + i] = L(b0+i, b0+k): a global column k is contiguous along i
 #pragma unroll
@@ -228,28 +238,40 @@ __global__ void __launch_bounds__(256) trsv_step_n_kernel(const double* __restri
   if(blockIdx.x == 0)
     for(int v = w; v < d; v += 4)
       if(lane < nb) Xout[(b0 + lane) + (int64_t)v * M] = Y[v * 64 + lane];
-  double acc[TV_MAXRHS];
+  bool first = true;
+  for(; grp < ngroups; grp += gridDim.x) {
+    const int64_t nxt = grp + gridDim.x;
+    if(nxt < ngroups) load_group(nxt, an);
+    double acc[TV_MAXRHS];
 #pragma unroll
-  for(int v = 0; v < TV_MAXRHS; v++) acc[v] = 0.0;
+    for(int v = 0; v < TV_MAXRHS; v++) acc[v] = 0.0;
 #pragma unroll
-  for(int u = 0; u < 16; u++)
+    for(int u = 0; u < 16; u++)
 #pragma unroll
-    for(int v = 0; v < TV_MAXRHS; v++)
-      if(v < d) acc[v] += a[u] * Y[v * 64 + 16 * w + u];
-  if(w > 0) {
+      for(int v = 0; v < TV_MAXRHS; v++)
+        if(v < d) acc[v] += a[u] * Y[v * 64 + 16 * w + u];
+    if(!first) __syncthreads();   // the previous group's sums have been consumed
+    first = false;
+    if(w > 0) {
 #pragma unroll
-    for(int v = 0; v < TV_MAXRHS; v++)
-      if(v < d) Red[w - 1][v][lane] = acc[v];
-  }
-  __syncthreads();
-  if(w == 0 && r < M) {
+      for(int v = 0; v < TV_MAXRHS; v++)
+        if(v < d) Red[w - 1][v][lane] = acc[v];
+    }
+    __syncthreads();
+    const int64_t r = b0 + nb + grp * 64 + lane;
+    if(w == 0 && r < M) {
 #pragma unroll
-    for(int v = 0; v < TV_MAXRHS; v++)
-      if(v < d) B[r + (int64_t)v * ldb] -= ((acc[v] + Red[0][v][lane]) + Red[1][v][lane]) + Red[2][v][lane];
+      for(int v = 0; v < TV_MAXRHS; v++)
+        if(v < d) B[r + (int64_t)v * ldb] -= ((acc[v] + Red[0][v][lane]) + Red[1][v][lane]) + Red[2][v][lane];
+    }
+#pragma unroll
+    for(int u = 0; u < 16; u++) a[u] = an[u];
   }
 }
 
 // One backward step of L' x = b: block [b0, b0+nb); then b[c] -= sum_r L(b0+r, c) x_b[r] for the columns c < b0.
+// Same structure: one solve per workgroup, then a walk over groups of 64 columns; a wave loads 16 columns of a group
+// (lane = row of the block), the next group's loads in flight behind the current one.
 __global__ void __launch_bounds__(256) trsv_step_t_kernel(const double* __restrict__ L, int64_t ldl,
                                                           double* __restrict__ B, int64_t ldb, int64_t M, int64_t b0,
                                                           int nb, int d, int unit, double* __restrict__ Xout)
@@ -260,19 +282,21 @@ __global__ void __launch_bounds__(256) trsv_step_t_kernel(const double* __restri
   __shared__ double Tt[64 * 65];
   __shared__ double Red[3][TV_MAXRHS][64];
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
-  // the wave's 16 update columns are requested first: they do not depend on the solve below
-  const int64_t c0 = (int64_t)blockIdx.x * 64 + w * 16;
-  double a[16];
-  {
-    const int64_t rl = b0 + ((lane < nb) ? lane : 0);
+  const int64_t ngroups = (b0 + 63) / 64;
+  const int64_t rl = b0 + ((lane < nb) ? lane : 0);
+  auto load_group = [&](int64_t grp, double (&a)[16]) {
 #pragma unroll
     for(int u = 0; u < 16; u++) {
-      const int64_t c = (c0 + u < b0) ? (c0 + u) : (b0 - 1);
-      const double x = L[rl + (c > 0 ? c : 0) * ldl];
-      a[u] = (c0 + u < b0 && lane < nb) ? x : 0.0;
+      const int64_t c = grp * 64 + 16 * w + u;
+      const int64_t cc = (c < b0) ? c : (b0 - 1);
+      const double x = L[rl + (cc > 0 ? cc : 0) * ldl];
+      a[u] = (c < b0 && lane < nb) ? x : 0.0;
     }
-  }
-  // the system is L_bb' : unknown k couples to lane i < k through L(b0+k, b0+i) -> P[k*65 + i]; filled transposed from
+  };
+  double a[16], an[16];
+  int64_t grp = blockIdx.x;
+  if(grp < ngroups) load_group(grp, a);
+  // the system is L_bb': unknown k couples to lane i < k through L(b0+k, b0+i) -> P[k*65 + i]; filled transposed from
   // the coalesced column reads (stride 65 keeps both the writes and the later row reads conflict-free)
   {
     double pa[16];
@@ -280,8 +304,8 @@ __global__ void __launch_bounds__(256) trsv_step_t_kernel(const double* __restri
     for(int u = 0; u < 16; u++) {
       const int c = w + 4 * u;
       const bool in = (c < nb && lane < nb && lane >= c);
-      const double a = L[(b0 + (in ? lane : 0)) + (b0 + (in ? c : 0)) * ldl];   // L(b0+lane, b0+c)
-      pa[u] = in ? a : ((lane == c) ? 1.0 : 0.0);
+      const double x = L[(b0 + (in ? lane : 0)) + (b0 + (in ? c : 0)) * ldl];   // L(b0+lane, b0+c)
+      pa[u] = in ? x : ((lane == c) ? 1.0 : 0.0);
     }
 #pragma unroll
     for(int u = 0; u < 16; u++) {
@@ -294,37 +318,45 @@ __global__ void __launch_bounds__(256) trsv_step_t_kernel(const double* __restri
   __syncthreads();
   tv_solve64(P, Dinv, Y, nb, d, false, unit != 0);
   __syncthreads();
-  // the solution goes to a side buffer: other workgroups may still be reading b_b from B (copied back at the end)
   if(blockIdx.x == 0)
     for(int v = w; v < d; v += 4)
       if(lane < nb) Xout[(b0 + lane) + (int64_t)v * M] = Y[v * 64 + lane];
-  // update for the workgroup's 64 columns: the 64 x 64 patch (lane = row as loaded) is turned through LDS so that a
+  // update, one group of 64 columns at a time: the 64 x 64 patch (lane = row as loaded) is turned through LDS so that a
   // thread owns a COLUMN and a quarter of the rows -- plain in-thread sums instead of a 6-step cross-lane reduction
   // per column and vector
+  bool first = true;
+  for(; grp < ngroups; grp += gridDim.x) {
+    const int64_t nxt = grp + gridDim.x;
+    if(nxt < ngroups) load_group(nxt, an);
+    if(!first) __syncthreads();   // the previous group's patch and sums have been consumed
+    first = false;
 #pragma unroll
-  for(int u = 0; u < 16; u++) Tt[(16 * w + u) * 65 + lane] = a[u];
-  __syncthreads();
-  double acc[TV_MAXRHS];
+    for(int u = 0; u < 16; u++) Tt[(16 * w + u) * 65 + lane] = a[u];
+    __syncthreads();
+    double acc[TV_MAXRHS];
 #pragma unroll
-  for(int v = 0; v < TV_MAXRHS; v++) acc[v] = 0.0;
+    for(int v = 0; v < TV_MAXRHS; v++) acc[v] = 0.0;
 #pragma unroll
-  for(int j = 0; j < 16; j++) {
-    const double lv = Tt[lane * 65 + 16 * w + j];   // L(b0 + 16w + j, c), c = this lane's column
+    for(int j = 0; j < 16; j++) {
+      const double lv = Tt[lane * 65 + 16 * w + j];   // L(b0 + 16w + j, c), c = this lane's column
 #pragma unroll
-    for(int v = 0; v < TV_MAXRHS; v++)
-      if(v < d) acc[v] += lv * Y[v * 64 + 16 * w + j];
-  }
-  if(w > 0) {
+      for(int v = 0; v < TV_MAXRHS; v++)
+        if(v < d) acc[v] += lv * Y[v * 64 + 16 * w + j];
+    }
+    if(w > 0) {
 #pragma unroll
-    for(int v = 0; v < TV_MAXRHS; v++)
-      if(v < d) Red[w - 1][v][lane] = acc[v];
-  }
-  __syncthreads();
-  const int64_t c = (int64_t)blockIdx.x * 64 + lane;
-  if(w == 0 && c < b0) {
+      for(int v = 0; v < TV_MAXRHS; v++)
+        if(v < d) Red[w - 1][v][lane] = acc[v];
+    }
+    __syncthreads();
+    const int64_t c = grp * 64 + lane;
+    if(w == 0 && c < b0) {
 #pragma unroll
-    for(int v = 0; v < TV_MAXRHS; v++)
-      if(v < d) B[c + (int64_t)v * ldb] -= ((acc[v] + Red[0][v][lane]) + Red[1][v][lane]) + Red[2][v][lane];
+      for(int v = 0; v < TV_MAXRHS; v++)
+        if(v < d) B[c + (int64_t)v * ldb] -= ((acc[v] + Red[0][v][lane]) + Red[1][v][lane]) + Red[2][v][lane];
+    }
+#pragma unroll
+    for(int u = 0; u < 16; u++) a[u] = an[u];
   }
 }
 
@@ -339,14 +371,19 @@ int trsv_lower(bool tr, bool unit, int64_t M, int64_t d, const double* L, int64_
     const int64_t b = tr ? (nblk - 1 - step) : step;
     const int64_t b0 = b * JB;
     const int nb = (int)((M - b0 < JB) ? (M - b0) : JB);
+    // at most 512 workgroups (two per CU): on a long panel each one walks several 64-row / 64-column groups
     if(!tr) {
       const int64_t rest = M - (b0 + nb);
-      const unsigned grid = (unsigned)(rest > 0 ? (rest + 63) / 64 : 1);
-      hipLaunchKernelGGL(trsv_step_n_kernel, dim3(grid), dim3(256), 0, s, L, ldl, B, ldb, M, b0, nb, (int)d,
+      int64_t grid = (rest + 63) / 64;
+      if(grid < 1) grid = 1;
+      if(grid > 512) grid = 512;
+      hipLaunchKernelGGL(trsv_step_n_kernel, dim3((unsigned)grid), dim3(256), 0, s, L, ldl, B, ldb, M, b0, nb, (int)d,
                          unit ? 1 : 0, Xout);
     } else {
-      const unsigned grid = (unsigned)(b0 > 0 ? (b0 + 63) / 64 : 1);
-      hipLaunchKernelGGL(trsv_step_t_kernel, dim3(grid), dim3(256), 0, s, L, ldl, B, ldb, M, b0, nb, (int)d,
+      int64_t grid = (b0 + 63) / 64;
+      if(grid < 1) grid = 1;
+      if(grid > 512) grid = 512;
+      hipLaunchKernelGGL(trsv_step_t_kernel, dim3((unsigned)grid), dim3(256), 0, s, L, ldl, B, ldb, M, b0, nb, (int)d,
                          unit ? 1 : 0, Xout);
     }
   }
