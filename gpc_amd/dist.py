@@ -86,6 +86,12 @@ class HipOps(object):
     def trsm(self, A, B, trans):
         self.api.trsm(A, B, side="L", uplo="L", trans=trans, diag="N")
 
+    def trace(self, A):
+        return self.api.trace(A)
+
+    def add_diag(self, A, c):
+        self.api.add_diag_(A, c)
+
 
 class _NoStream(object):
     """Stream/event stand-in for CPU tensors (gloo tests): everything is synchronous."""
@@ -362,13 +368,43 @@ class DistGp(object):
         self.factored = int(info.item()) == 0
         return int(info.item())
 
-    def update_k(self):
-        """CGp::updateK (FTC) on the distributed matrix: Gram, factor, log|K|.  Raises if K is not positive definite
-        (the jitter schedule of CMatrix::jitChol is a single-GPU feature so far)."""
+    def _add_diag(self, c):
+        """K(i,i) += c on the locally owned diagonal blocks (CMatrix::addDiag, the jitter of jitChol)."""
+        for j in self.mine:
+            w = self.width(j)
+            self.ops.add_diag(self.panel_view(j)[:w, :], c)
+
+    def _trace(self):
+        """trace(K) from the locally owned diagonal blocks (all ranks get the global sum)."""
+        s = 0.0
+        for j in self.mine:
+            w = self.width(j)
+            s += self.ops.trace(self.panel_view(j)[:w, :])
+        t = torch.tensor([s], dtype=torch.float64, device=self.A.device)
+        return float(self._allreduce_sum(t).item())
+
+    def update_k(self, max_tries=20):
+        """CGp::updateK (FTC) on the distributed matrix: Gram, factor, log|K|, with CMatrix::jitChol's jitter schedule
+        (CMatrix.cpp:767-804) when a pivot fails: first candidate 1e-6 * trace(K) / N, x10 per retry, accumulated on the
+        diagonal of a regenerated K; gives up when the candidate exceeds 10 or after 20 tries."""
         self.fill()
-        info = self.factor()
-        if info != 0:
-            raise ArithmeticError("distributed Cholesky: leading minor %d is not positive definite" % info)
+        jitter, total, tries = None, 0.0, 0
+        while True:
+            if jitter is None:
+                trace = self._trace()              # one scalar all-reduce; K is still intact here
+                jitter = 1e-6 * trace / float(self.N)
+            info = self.factor()
+            if info == 0:
+                break
+            total += jitter
+            jitter *= 10.0
+            tries += 1
+            if jitter > 10.0 or tries >= max_tries:
+                raise ArithmeticError("distributed Cholesky: leading minor %d is not positive definite after %d jitter "
+                                      "steps (total %g)" % (info, tries, total))
+            self.fill()
+            self._add_diag(total)
+        self.jitter = total
         s = 0.0
         for j in self.mine:
             w = self.width(j)

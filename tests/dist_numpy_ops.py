@@ -111,3 +111,10 @@ class NumpyOps(object):
     def trsm(self, A, B, trans):
         b = B.numpy()
         b[...] = sla.solve_triangular(np.tril(A.numpy()), b, lower=True, trans=1 if trans == "T" else 0)
+
+    def trace(self, A):
+        return float(np.trace(A.numpy()))
+
+    def add_diag(self, A, c):
+        a = A.numpy()
+        a[np.diag_indices(min(a.shape))] += c

@@ -46,12 +46,33 @@ def run(rank, world, port, flavour, N, D, d, Ns, nb, terms, outdir):
         logdet = g.update_k()
         ll = g.log_likelihood()
         al = g.alpha()
-        res = {"logdet": logdet, "ll": ll, "alpha": al.cpu().numpy().copy(), "ncols": g.ncols}
+        res = {"logdet": logdet, "ll": ll, "alpha": al.cpu().numpy().copy(), "ncols": g.ncols, "jitter": g.jitter}
         if Ns:
             mu, var = g.posterior(al)
             res["mu"] = mu.cpu().numpy().copy()
             res["var"] = var.cpu().numpy().copy()
         res["L"] = g.gather_factor() if flavour != "hip-rccl" else np.tril(g.A[:N, :N].cpu().numpy())
         np.savez(os.path.join(outdir, "rank%d.npz" % rank), **res)
+    finally:
+        dist.destroy_process_group()
+
+
+def singular_inputs():
+    rng = np.random.RandomState(3)
+    X = rng.randn(300, 2)
+    X[150:] = X[:150]            # every point twice: K is exactly singular
+    return X
+
+
+def run_singular(rank, world, port, terms, outdir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from gpc_amd import dist as gdist
+        from dist_numpy_ops import NumpyOps
+        g = gdist.DistGp(terms, singular_inputs(), nb=128, ops=NumpyOps())
+        logdet = g.update_k()
+        np.savez(os.path.join(outdir, "sing%d.npz" % rank), jitter=g.jitter, logdet=logdet)
     finally:
         dist.destroy_process_group()

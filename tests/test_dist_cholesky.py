@@ -80,6 +80,29 @@ def test_blockcyclic_orchestration_gloo_cpu(world, N, Ns, d, nb, tmp_path):
     assert sum(int(r["ncols"]) for r in res) == N
 
 
+def test_blockcyclic_jitter_schedule_gloo_cpu(tmp_path):
+    """a singular Gram matrix (duplicated inputs, no white term): the distributed updateK walks jitChol's schedule and
+    ends with the same total jitter on every rank as the single-matrix rule gives"""
+    terms = [("rbf", [1.0, 1.0])]
+    port = _free_port()
+    mp.spawn(dist_worker.run_singular, args=(2, port, terms, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = (dict(np.load(os.path.join(str(tmp_path), "sing%d.npz" % r))) for r in range(2))
+    assert r0["jitter"] == r1["jitter"] and r0["jitter"] > 0
+    X = dist_worker.singular_inputs()
+    K = kern(terms, X, X, (0, 0))
+    jit, total = 1e-6 * np.trace(K) / K.shape[0], 0.0
+    while True:                                   # CMatrix::jitChol on the same matrix
+        try:
+            np.linalg.cholesky(K + total * np.eye(K.shape[0]))
+            break
+        except np.linalg.LinAlgError:
+            total += jit
+            jit *= 10.0
+    assert abs(float(r0["jitter"]) - total) <= 1e-15 * max(total, 1.0)
+    L = np.linalg.cholesky(K + total * np.eye(K.shape[0]))
+    assert abs(float(r0["logdet"]) - 2 * np.log(np.diag(L)).sum()) <= 1e-6 * abs(2 * np.log(np.diag(L)).sum())
+
+
 def test_index_helpers():
     from gpc_amd import dist as gdist
     g = gdist.DistGp.__new__(gdist.DistGp)
