@@ -91,6 +91,10 @@ def main():
 
     import torch
     import torch.distributed as dist
+    if not os.path.exists(os.path.join(ROOT, "gpc_amd", "lib", "libgpc_hip.so")) and \
+            int(os.environ.get("LOCAL_RANK", "0")) == 0 and int(os.environ.get("WORLD_SIZE", "1")) == 1:
+        import __graft_entry__           # a checkout without the built library: build it (single-process runs only)
+        __graft_entry__.build()
     from gpc_amd import api, synth
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
