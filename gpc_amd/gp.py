@@ -76,7 +76,8 @@ class CGp:
         self._dirty()
 
     def _dirty(self):
-        self.L = None          # LcholK (lower); strictly-lower part fp32-rounded when ref_trans_rounding
+        self.L = None          # LcholK (lower); strictly-lower part fp32-rounded once updateAlpha ran (ref_trans_rounding)
+        self.L_rounded = False
         self.logDetK = None
         self.invKm = None      # invK * m, exact fp64 (what dsymv(invK, m) gives the reference, CGp.cpp:928)
         self.quad = None       # m_j' invK m_j per output
@@ -106,6 +107,13 @@ class CGp:
     def updateK(self, need_inverse=False):
         if self.L is not None and (self.invK is not None or not need_inverse):
             return
+        if self.L is not None and need_inverse and not self.L_rounded:
+            # the factor of the current parameters is still exact: the gradient only adds the inverse (no second
+            # Gram build + factorisation when SCG asks for the gradient where it has just evaluated the objective)
+            inv = self.L.clone()
+            api.potri(inv, "L")
+            self.invK = inv
+            return
         K, logdet, jit, info = api.gp_update_k(self.kspec(), self.X)
         if info != 0:
             raise np.linalg.LinAlgError("MatrixNonPosDef: leading minor %d (jitter %g)" % (info, jit))
@@ -116,16 +124,16 @@ class CGp:
             inv = K.clone()                                   # keeps the column-major strides
             api.potri(inv, "L")                               # invK.pdinv(LcholK), CGp.cpp:889
             self.invK = inv
-        if self.ref_trans_rounding:
-            api.ref_trans_rounding_(K)                        # LcholK.trans() of the Fortran-built reference
-            self.Alpha = None
-        else:
-            self.Alpha = self.invKm
         self.L = K
+        self.L_rounded = False                                # the reference's fp32 rounding is applied by updateAlpha
+        self.Alpha = None if self.ref_trans_rounding else self.invKm
 
     def updateAlpha(self):
         self.updateK()
         if self.Alpha is None:
+            if self.ref_trans_rounding and not self.L_rounded:
+                api.ref_trans_rounding_(self.L)               # LcholK.trans() of the Fortran-built reference
+                self.L_rounded = True
             self.Alpha = api.gp_alpha(self.L, self.m)         # CGp::updateAlpha, CGp.cpp:469-489
 
     def logLikelihood(self):

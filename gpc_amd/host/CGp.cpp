@@ -28,8 +28,8 @@ CGp::CGp(CKern* kernel, CNoise* nois, CMatrix* Xin, int approxType, unsigned int
     : pX(Xin), py(nois->py), pkern(kernel), pnoise(nois), ownsKernNoise(false), fileNumData(0), fileInputDim(0),
       numActive(actSetSize), scale(1, nois->getOutputDim(), 1.0),
       bias(1, nois->getOutputDim(), 0.0), refTransRounding(true), MupToDate(false), KupToDate(false),
-      AlphaUpToDate(false), invKupToDate(false), dX(0), dM(0), dL(0), dInvKm(0), dAlpha(0), dInvK(0), dCovGrad(0),
-      logDetK(0.0), lastJitter(0.0), needInverse(false)
+      AlphaUpToDate(false), invKupToDate(false), LcholRounded(false), dX(0), dM(0), dL(0), dInvKm(0), dAlpha(0), dInvK(0),
+      dCovGrad(0), logDetK(0.0), lastJitter(0.0), needInverse(false)
 {
   if(Xin->getRows() != nois->getNumData())
     throw ndlexceptions::MatrixError("CGp: X and the targets disagree on the number of data");   // CGp.cpp:60
@@ -42,7 +42,7 @@ CGp::CGp(CKern* kernel, CNoise* nois, CMatrix* Xin, int approxType, unsigned int
 CGp::CGp()
     : pX(0), py(0), pkern(0), pnoise(0), ownsKernNoise(true), fileNumData(0), fileInputDim(0), numActive(0), scale(1, 1, 1.0),
       bias(1, 1, 0.0), refTransRounding(true), MupToDate(false), KupToDate(false), AlphaUpToDate(false),
-      invKupToDate(false), dX(0), dM(0), dL(0), dInvKm(0), dAlpha(0), dInvK(0), dCovGrad(0), logDetK(0.0), lastJitter(0.0),
+      invKupToDate(false), LcholRounded(false), dX(0), dM(0), dL(0), dInvKm(0), dAlpha(0), dInvK(0), dCovGrad(0), logDetK(0.0), lastJitter(0.0),
       needInverse(false)
 {
   const char* e = std::getenv("GPC_EXACT_TRANS");
@@ -107,6 +107,15 @@ void CGp::updateK() const
   if(KupToDate && (invKupToDate || !needInverse)) return;
   ensureDeviceInputs();
   const int64_t N = getNumData(), D = getInputDim(), d = getOutputDim();
+  if(KupToDate && needInverse && !LcholRounded) {
+    // The factor of the current parameters is still exact in dL (SCG asks for the gradient at the point whose
+    // objective it has just evaluated): only the inverse is missing -- no second Gram build + factorisation.
+    if(!dInvK) dInvK = devAlloc((size_t)N * N);
+    gpcCheck(gpc_memcpy_d2d(dInvK, dL, sizeof(double) * (size_t)N * N, 0));
+    gpcCheck(gpc_potri_f64('L', N, dInvK, N, 0));
+    invKupToDate = true;
+    return;
+  }
   if(!dL) dL = devAlloc((size_t)N * N);
   if(!dInvKm) dInvKm = devAlloc((size_t)N * d);
   gpc_kspec ks;
@@ -132,8 +141,10 @@ void CGp::updateK() const
   } else {
     invKupToDate = false;
   }
-  // LcholK.trans() (CGp.cpp:890): a reference built from ndlfortran.f leaves the strictly-lower part in single precision
-  if(refTransRounding) gpcCheck(gpc_ref_trans_rounding_f64(N, dL, N, 0));
+  // LcholK.trans() (CGp.cpp:890) of a reference built from ndlfortran.f leaves the strictly-lower part of LcholK in
+  // single precision.  Only Alpha and the predictions read LcholK, so that rounding is applied lazily, by
+  // updateAlpha(): during optimisation (likelihood and gradient only) the factor stays exact and reusable.
+  LcholRounded = false;
   KupToDate = true;
   AlphaUpToDate = false;
 }
@@ -145,6 +156,10 @@ void CGp::updateAlpha() const
   updateK();
   const int64_t N = getNumData(), d = getOutputDim();
   if(!dAlpha) dAlpha = devAlloc((size_t)N * d);
+  if(refTransRounding && !LcholRounded) {
+    gpcCheck(gpc_ref_trans_rounding_f64(N, dL, N, 0));
+    LcholRounded = true;
+  }
   if(refTransRounding)
     gpcCheck(gpc_gp_alpha_f64(N, d, dL, N, dM, N, dAlpha, N, 0));   // Alpha.trsm(LcholK ...) twice, CGp.cpp:481-483
   else
@@ -155,6 +170,7 @@ void CGp::updateAlpha() const
 double CGp::logLikelihood() const
 {
   updateM();
+  needInverse = false;   // the likelihood alone never needs invK; a gradient at the same point adds it from the factor
   updateK();
   double L = 0.0;
   for(unsigned int j = 0; j < getOutputDim(); j++) {   // CGp.cpp:923-932

@@ -93,6 +93,7 @@ class CGp : public CProbabilisticOptimisable {
   // caches (mutable, as in the reference: the model is not re-entrant)
   mutable CMatrix m;          // host N x d
   mutable bool MupToDate, KupToDate, AlphaUpToDate, invKupToDate;
+  mutable bool LcholRounded;  // dL carries the reference's fp32 rounding (applied lazily by updateAlpha)
   mutable double* dX;         // device copy of X (N x D)
   mutable double* dM;         // device copy of m
   mutable double* dL;         // device N x N: LcholK (lower) in K's storage

@@ -493,3 +493,26 @@ def test_cfg3_full_size_properties(api):
     Z = Kfull @ (inv @ E)
     assert float((Z - E).abs().max()) < 1e-9
     assert torch.equal(inv[idx, :], inv[:, idx].t())
+
+
+def test_gradient_reuses_the_factor_of_the_objective(api, golden):
+    """SCG asks for the gradient where it has just evaluated the objective: the model then only adds the inverse to the
+    factor it already holds.  Same bits as a fresh evaluation, also after predictions rounded LcholK (reference quirk)."""
+    from gpc_amd.gp import CGp
+    from gpc_amd import synth
+    c = synth.scaled_config("cfg2", 1024)
+    X, y = synth.make_xy(1024, c["D"], 1234)
+    g = golden("synth_cfg2_1024")
+    fresh = CGp(c["kern"], X, y)
+    g0, ll0 = fresh.logLikelihoodGradient()
+    m = CGp(c["kern"], X, y)
+    ll1 = m.logLikelihood()
+    assert m.invK is None
+    g1, ll1b = m.logLikelihoodGradient()                     # factor reused
+    assert ll1 == ll0 == ll1b and np.array_equal(g1, g0)
+    mu, var = m.posteriorMeanVar(g["Xstar"])                 # rounds LcholK like the reference
+    assert rel(mu, g["mu"]) < 1e-8 and rel(var, g["var"]) < 1e-8
+    m.invK = None
+    g2, _ = m.logLikelihoodGradient()                        # must NOT be derived from the rounded factor
+    assert np.array_equal(g2, g0)
+    assert rel(g0, g["grads"].ravel()) < 1e-8
