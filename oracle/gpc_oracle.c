@@ -881,3 +881,190 @@ double orc_gplvm_loglik_grad(const orc_kspec* ks, const double* m, long N, long 
   free(K); free(U); free(invK); free(invKm);
   return L;
 }
+
+/* ---- sparse approximation DTC (spherical noise, inducing points optimised) --------------- */
+
+/* CCmpndKern::getGradX(gX, X, row, X2): gX(k,j) = d k(x_row, x2_k) / d x_row,j, N2 x D (CKern.cpp:184-193; components
+ * as in orc_kern_gradx_row) */
+void orc_kern_gradx_row2(const orc_kspec* ks, const double* X, long ldx, long row, const double* X2, long N2, long D,
+                         double* gX)
+{
+  int t;
+  long k, j;
+  for(k = 0; k < N2 * D; k++) gX[k] = 0.0;
+  for(t = 0; t < ks->n_terms; t++) {
+    const double* p = ks->params + ks->offs[t];
+    switch(ks->types[t]) {
+    case ORC_KERN_RBF: {
+      const double wi2 = 0.5 * p[0], pf = p[1] * p[0];
+      for(k = 0; k < N2; k++) {
+        const double n2 = orc_dist2_row(X, ldx, row, X2, N2, k, D);
+        for(j = 0; j < D; j++) gX[k + j * N2] += pf * (X2[k + j * N2] - X[row + j * ldx]) * exp(-n2 * wi2);
+      }
+      break;
+    }
+    case ORC_KERN_RBFARD: {
+      const double wi2 = 0.5 * p[0], pf = p[1] * p[0];
+      for(k = 0; k < N2; k++) {
+        double n2 = 0.0;
+        for(j = 0; j < D; j++) {
+          double x = X[row + j * ldx];
+          x = x - X2[k + j * N2];
+          n2 += x * p[2 + j] * x;
+        }
+        for(j = 0; j < D; j++)
+          gX[k + j * N2] += pf * (X2[k + j * N2] - X[row + j * ldx]) * exp(-n2 * wi2) * p[2 + j];
+      }
+      break;
+    }
+    case ORC_KERN_LIN:
+      for(k = 0; k < N2; k++)
+        for(j = 0; j < D; j++) gX[k + j * N2] += p[0] * X2[k + j * N2];
+      break;
+    default: break;
+    }
+  }
+}
+
+static void mm(int ta, int tb, long M, long N, long K, double alpha, const double* A, long lda, const double* B, long ldb,
+               double beta, double* C, long ldc)   /* dgemm */
+{
+  long i, j, k;
+  for(j = 0; j < N; j++)
+    for(i = 0; i < M; i++) {
+      double s = 0.0;
+      for(k = 0; k < K; k++) s += (ta ? A[k + i * lda] : A[i + k * lda]) * (tb ? B[j + k * ldb] : B[k + j * ldb]);
+      C[i + j * ldc] = alpha * s + (beta != 0.0 ? beta * C[i + j * ldc] : 0.0);
+    }
+}
+
+/* CGp with approximationType DTC: updateK (CGp.cpp:713-735), _updateInvK (896-909), updateAD (751-776), logLikelihood
+ * (939-961, 1002-1013), gpCovGrads (1252-1316), updateG (1146-1190), logLikelihoodGradient (1016-1079), updateAlpha
+ * (490-497), _posteriorMean / _posteriorVar (548-599).
+ *   X N x D, m N x d (centred / scaled targets), Xu M x D inducing inputs, beta = noise precision.
+ *   g (may be NULL): [d/dX_u column by column (M*D)] [kernel, transformed (nk)] [d/d log beta]  (CGp.cpp:330-385)
+ *   alpha (may be NULL) M x d;  Xs (may be NULL) Ns x D -> mu Ns x d, var Ns.
+ * Returns the log-likelihood; *info != 0 if a Cholesky failed even with jitter. */
+double orc_gp_dtc(const orc_kspec* ks, const double* X, long N, long D, const double* m, long d, const double* Xu, long M,
+                  double beta, double* g, double* alpha, const double* Xs, long Ns, double* mu, double* var, int* info)
+{
+  const int nk = ks->offs[ks->n_terms];
+  const size_t MM = (size_t)M * M, MN = (size_t)M * N;
+  double* Kuu = (double*)malloc(sizeof(double) * MM);
+  double* Kuf = (double*)malloc(sizeof(double) * MN);
+  double* U = (double*)malloc(sizeof(double) * MM);
+  double* invKuu = (double*)malloc(sizeof(double) * MM);
+  double* A = (double*)malloc(sizeof(double) * MM);
+  double* LA = (double*)malloc(sizeof(double) * MM);
+  double* Ainv = (double*)malloc(sizeof(double) * MM);
+  double* e = (double*)malloc(sizeof(double) * M);
+  double* invAe = (double*)malloc(sizeof(double) * M);
+  double logDetKuu, logDetA, L = 0.0;
+  long i, j, k, n;
+  *info = 0;
+  orc_gram_sym(ks, Xu, M, D, Kuu);                                   /* K_uu */
+  for(n = 0; n < N; n++)                                             /* K_uf(i,n) = k(xu_i, x_n) */
+    for(i = 0; i < M; i++) Kuf[i + (size_t)n * M] = orc_kern_element(ks, Xu, M, i, X, N, n, D);
+  orc_jitchol(M, Kuu, U, 20, info);                                  /* _updateInvK */
+  if(*info != 0) goto done;
+  logDetKuu = orc_logdet(M, U, M);
+  orc_pdinv_upper(M, U, invKuu);
+  memcpy(A, Kuu, sizeof(double) * MM);                               /* updateAD: A = K_uf K_uf' + K_uu / beta */
+  mm(0, 1, M, M, N, 1.0, Kuf, M, Kuf, M, 1.0 / beta, A, M);
+  orc_jitchol(M, A, LA, 20, info);
+  if(*info != 0) goto done;
+  logDetA = orc_logdet(M, LA, M);
+  orc_pdinv_upper(M, LA, Ainv);
+  orc_trans(M, LA);                                                  /* LcholA.trans(): lower (fp32 quirk included) */
+  L += (double)d * (((double)M - (double)N) * log(beta) - logDetKuu + logDetA);
+  for(j = 0; j < d; j++) {
+    mm(0, 0, M, 1, N, 1.0, Kuf, M, m + (size_t)j * N, N, 0.0, e, M);
+    orc_symv_upper(M, Ainv, e, invAe);                               /* Ainv is fully symmetric */
+    L -= beta * (dot(M, invAe, 1, e, 1) - dot(N, m + (size_t)j * N, 1, m + (size_t)j * N, 1));
+  }
+  L *= -0.5;
+  L -= (double)d * (double)N * HALFLOGTWOPI;
+  if(alpha) {                                                        /* updateAlpha */
+    mm(0, 0, M, d, N, 1.0, Kuf, M, m, N, 0.0, alpha, M);
+    orc_trsm('l', 'l', 'n', 'n', M, d, 1.0, LA, M, alpha, M);
+    orc_trsm('l', 'l', 't', 'n', M, d, 1.0, LA, M, alpha, M);
+  }
+  if(Xs && Ns > 0) {                                                 /* posteriorMeanVar */
+    double* kX = (double*)malloc(sizeof(double) * M * Ns);
+    double* W = (double*)malloc(sizeof(double) * MM);
+    double* st = (double*)malloc(sizeof(double) * M * Ns);
+    for(n = 0; n < Ns; n++)
+      for(i = 0; i < M; i++) kX[i + n * M] = orc_kern_element(ks, Xu, M, i, Xs, Ns, n, D);
+    for(k = 0; k < (long)MM; k++) W[k] = invKuu[k] - Ainv[k] / beta;
+    mm(0, 0, M, Ns, M, 1.0, W, M, kX, M, 0.0, st, M);
+    for(n = 0; n < Ns; n++) {
+      if(var) var[n] = orc_kern_diag_element(ks, Xs, Ns, n, D) - dot(M, kX + n * M, 1, st + n * M, 1) + 1.0 / beta;
+      if(mu && alpha)
+        for(j = 0; j < d; j++) mu[n + j * Ns] = dot(M, alpha + (size_t)j * M, 1, kX + n * M, 1);
+    }
+    free(kX); free(W); free(st);
+  }
+  if(g) {                                                            /* gpCovGrads + updateG */
+    double* E = (double*)malloc(sizeof(double) * M * d);
+    double* EET = (double*)malloc(sizeof(double) * MM);
+    double* AinvEET = (double*)malloc(sizeof(double) * MM);
+    double* AEA = (double*)malloc(sizeof(double) * MM);
+    double* gKuu = (double*)malloc(sizeof(double) * MM);
+    double* AinvKuf = (double*)malloc(sizeof(double) * MN);
+    double* EMT = (double*)malloc(sizeof(double) * MN);
+    double* AinvEMT = (double*)malloc(sizeof(double) * MN);
+    double* gKuf = (double*)malloc(sizeof(double) * MN);
+    double* t1 = (double*)malloc(sizeof(double) * (nk > 0 ? nk : 1));
+    double* t2 = (double*)malloc(sizeof(double) * (nk > 0 ? nk : 1));
+    double* gKX = (double*)malloc(sizeof(double) * M * D);
+    double* gKXuf = (double*)malloc(sizeof(double) * N * D);
+    double* dg = (double*)malloc(sizeof(double) * M * D);
+    double gb, tmp;
+    mm(0, 0, M, d, N, 1.0, Kuf, M, m, N, 0.0, E, M);
+    mm(0, 1, M, M, d, 1.0, E, M, E, M, 0.0, EET, M);
+    mm(0, 0, M, M, M, 1.0, Ainv, M, EET, M, 0.0, AinvEET, M);
+    mm(0, 0, M, M, M, 1.0, AinvEET, M, Ainv, M, 0.0, AEA, M);
+    for(k = 0; k < (long)MM; k++) gKuu[k] = 0.5 * ((double)d * (invKuu[k] - Ainv[k] / beta) - AEA[k]);
+    mm(0, 0, M, N, M, 1.0, Ainv, M, Kuf, M, 0.0, AinvKuf, M);
+    mm(0, 1, M, N, d, 1.0, E, M, m, N, 0.0, EMT, M);
+    mm(0, 0, M, N, M, 1.0, Ainv, M, EMT, M, 0.0, AinvEMT, M);
+    mm(0, 0, M, N, M, 1.0, AinvEET, M, AinvKuf, M, 0.0, gKuf, M);
+    for(k = 0; k < (long)MN; k++) gKuf[k] = -(beta * (gKuf[k] - AinvEMT[k])) - (double)d * AinvKuf[k];
+    gb = (double)(N - M) / beta;
+    tmp = 0.0;
+    for(k = 0; k < (long)MM; k++) tmp += Ainv[k] * Kuu[k];
+    gb += tmp / (beta * beta);
+    gb *= (double)d;
+    tmp = 0.0;
+    for(k = 0; k < (long)MM; k++) tmp += AEA[k] * Kuu[k];
+    gb += tmp / beta;
+    for(j = 0; j < d; j++) gb -= dot(N, m + (size_t)j * N, 1, m + (size_t)j * N, 1);
+    for(i = 0; i < M; i++) gb += AinvEET[i + i * M];
+    gb *= 0.5;
+    /* kernel parameters: symmetric pass on X_u against gK_uu + cross pass (X_u, X) against gK_uf, each transformed */
+    orc_kern_grad_sym(ks, Xu, M, D, gKuu, t1);
+    orc_grad_to_trans(ks, D, t1);
+    orc_kern_grad_cross(ks, Xu, M, X, N, D, gKuf, t2);
+    orc_grad_to_trans(ks, D, t2);
+    /* d/dX_u (CGp.cpp:1160-1182) */
+    orc_kern_diag_gradx(ks, Xu, M, D, dg);
+    for(i = 0; i < M; i++) {
+      orc_kern_gradx_row2(ks, Xu, M, i, X, N, D, gKXuf);
+      orc_kern_gradx_row2(ks, Xu, M, i, Xu, M, D, gKX);
+      for(k = 0; k < M * D; k++) gKX[k] *= 2.0;
+      for(j = 0; j < D; j++) gKX[i + j * M] = dg[i + j * M];
+      for(j = 0; j < D; j++) {
+        double s = dot(M, gKX + (size_t)j * M, 1, gKuu + (size_t)i * M, 1);
+        s += dot(N, gKXuf + (size_t)j * N, 1, gKuf + i, M);   /* dotColRow(j, gK_uf, i) */
+        g[i + j * M] = s;
+      }
+    }
+    for(k = 0; k < nk; k++) g[M * D + k] = t1[k] + t2[k];
+    g[M * D + nk] = gb * beta;                                       /* exp transform: gradfact(beta) = beta */
+    free(E); free(EET); free(AinvEET); free(AEA); free(gKuu); free(AinvKuf); free(EMT); free(AinvEMT); free(gKuf);
+    free(t1); free(t2); free(gKX); free(gKXuf); free(dg);
+  }
+done:
+  free(Kuu); free(Kuf); free(U); free(invKuu); free(A); free(LA); free(Ainv); free(e); free(invAe);
+  return L;
+}

@@ -93,4 +93,10 @@ void orc_kern_gradx_row(const orc_kspec* ks, const double* X, long N, long D, lo
 void orc_kern_diag_gradx(const orc_kspec* ks, const double* X, long N, long D, double* gD);
 double orc_gplvm_loglik_grad(const orc_kspec* ks, const double* m, long N, long d, const double* X, long q,
                              int regularise, double* g, double* logdet_out, int* info);
+
+/* ---- CGp, approximation type DTC -------------------------------------------------------------------------------- */
+void orc_kern_gradx_row2(const orc_kspec* ks, const double* X, long ldx, long row, const double* X2, long N2, long D,
+                         double* gX);
+double orc_gp_dtc(const orc_kspec* ks, const double* X, long N, long D, const double* m, long d, const double* Xu, long M,
+                  double beta, double* g, double* alpha, const double* Xs, long Ns, double* mu, double* var, int* info);
 #endif

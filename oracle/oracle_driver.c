@@ -1,7 +1,7 @@
 /* oracle_driver.c -- command-line front end of the plain-C restatement (gpc_oracle.c), speaking the same GPCB1
  * container and the same modes as oracle/ref_driver.cpp so that tests can run both side by side.
  *
- * TEST INFRASTRUCTURE ONLY.  Usage: oracle_driver <kern|gp|time|chol|trsm|gplvm> <in.gpcb> <out.gpcb>
+ * TEST INFRASTRUCTURE ONLY.  Usage: oracle_driver <kern|gp|time|chol|trsm|gplvm|dtc> <in.gpcb> <out.gpcb>
  */
 #include <stdio.h>
 #include <stdlib.h>
@@ -233,11 +233,58 @@ static int run_gplvm(const gpcb_file* in, const char* out)
   return 0;
 }
 
+/* same inputs as ref_driver's dtc mode: X, y (centred here with bias = meanCol(y), scale 1), X_u, beta, optional Xstar */
+static int run_dtc(const gpcb_file* in, const char* out)
+{
+  const gpcb_array *X = gpcb_need(in, "X"), *y = gpcb_need(in, "y"), *Xu = gpcb_need(in, "X_u"),
+                   *xs = gpcb_find(in, "Xstar"), *ex = gpcb_find(in, "exact_trans");
+  const double beta = gpcb_need(in, "beta")->data[0];
+  const long N = X->rows, D = X->cols, d = y->cols, M = Xu->rows, Ns = xs ? xs->rows : 0;
+  orc_kspec ks;
+  int nk, info = 0;
+  long i, j;
+  double *m, *g, *alpha, *mu = 0, *var = 0, *means, ll, infod;
+  FILE* fp;
+  build_kspec(in, D, &ks);
+  nk = ks.offs[ks.n_terms];
+  orc_exact_trans = (ex && ex->data[0] != 0.0) ? 1 : 0;
+  m = malloc(sizeof(double) * N * d);
+  means = malloc(sizeof(double) * d);
+  for(j = 0; j < d; j++) {
+    double mean = 0.0;
+    for(i = 0; i < N; i++) mean += y->data[i + j * N];
+    mean /= (double)N;
+    means[j] = mean;
+    for(i = 0; i < N; i++) m[i + j * N] = (y->data[i + j * N] - mean) * (1 / 1.0);
+  }
+  g = malloc(sizeof(double) * (M * D + nk + 1));
+  alpha = malloc(sizeof(double) * M * d);
+  if(Ns) {
+    mu = malloc(sizeof(double) * Ns * d);
+    var = malloc(sizeof(double) * Ns);
+  }
+  ll = orc_gp_dtc(&ks, X->data, N, D, m, d, Xu->data, M, beta, g, alpha, xs ? xs->data : 0, Ns, mu, var, &info);
+  for(j = 0; j < d && Ns; j++)   /* _posteriorMean adds the output bias (CGp.cpp:566-573) */
+    for(i = 0; i < Ns; i++) mu[i + j * Ns] += means[j];
+  infod = (double)info;
+  fp = gpcb_open_write(out);
+  gpcb_write(fp, "ll", 1, 1, &ll);
+  gpcb_write(fp, "grads", 1, M * D + nk + 1, g);
+  gpcb_write(fp, "alpha", M, d, alpha);
+  gpcb_write(fp, "info", 1, 1, &infod);
+  if(Ns) {
+    gpcb_write(fp, "mu", Ns, d, mu);
+    gpcb_write(fp, "var", Ns, 1, var);
+  }
+  fclose(fp);
+  return 0;
+}
+
 int main(int argc, char** argv)
 {
   gpcb_file in;
   if(argc != 4) {
-    fprintf(stderr, "usage: oracle_driver <kern|gp|time|chol|trsm|gplvm> <in.gpcb> <out.gpcb>\n");
+    fprintf(stderr, "usage: oracle_driver <kern|gp|time|chol|trsm|gplvm|dtc> <in.gpcb> <out.gpcb>\n");
     return 2;
   }
   if(gpcb_read(argv[2], &in) != 0) {
@@ -250,6 +297,7 @@ int main(int argc, char** argv)
   if(strcmp(argv[1], "chol") == 0) return run_chol(&in, argv[3]);
   if(strcmp(argv[1], "trsm") == 0) return run_trsm(&in, argv[3]);
   if(strcmp(argv[1], "gplvm") == 0) return run_gplvm(&in, argv[3]);
+  if(strcmp(argv[1], "dtc") == 0) return run_dtc(&in, argv[3]);
   fprintf(stderr, "oracle_driver: unknown mode %s\n", argv[1]);
   return 2;
 }

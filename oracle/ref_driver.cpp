@@ -10,7 +10,7 @@
 // mirrors: CCmpndKern + addKern, CGaussianNoise, CGp(kern, noise, X, FTC, -1, verbosity), setScale/setBias,
 // updateM).  C++98 on purpose: the reference only compiles with -std=gnu++98.
 //
-// Usage: ref_driver <kern|gp|time|gplvm> <in.gpcb> <out.gpcb>
+// Usage: ref_driver <kern|gp|time|gplvm|dtc> <in.gpcb> <out.gpcb>
 #include <sys/time.h>
 #include <iostream>
 #include <vector>
@@ -231,6 +231,67 @@ static int runTime(const gpcb_file& in, const char* outPath)
 // GP-LVM: construction order of gplvm.cpp:364-545 (kernel on the latent X, CScaleNoise
 // centred / unscaled, CGplvm(kern, noise, q, verbosity) whose constructor runs the PCA initialisation), then the
 // objective and its gradient at the given point and, optionally, an SCG run.
+// Sparse approximation DTC: the reference's CGp with approxType = DTC, numActive inducing
+// points.  The constructor picks a random subset of X for X_u (CGp.cpp:268-277); this driver overwrites X_u (and beta)
+// with the given values so that the result does not depend on the reference's random number generator.
+static int runDtc(const gpcb_file& in, const char* outPath)
+{
+  CMatrix X, y, Xu, Xstar;
+  toCMatrix(X, gpcb_need(&in, "X"));
+  toCMatrix(y, gpcb_need(&in, "y"));
+  toCMatrix(Xu, gpcb_need(&in, "X_u"));
+  const double beta = gpcb_need(&in, "beta")->data[0];
+  const gpcb_array* xs = gpcb_find(&in, "Xstar");
+  const gpcb_array* it = gpcb_find(&in, "iters");
+  CCmpndKern kern(X);
+  buildKern(kern, X, in);
+  CGaussianNoise noise(&y);
+  noise.setBias(0.0);
+  CMatrix scale(1, y.getCols(), 1.0);
+  CMatrix bias(1, y.getCols(), 0.0);
+  bias.deepCopy(meanCol(y));
+  CGp model(&kern, &noise, &X, CGp::DTC, Xu.getRows(), 0);
+  model.setBetaVal(beta);
+  model.setScale(scale);
+  model.setBias(bias);
+  model.updateM();
+  model.X_u.deepCopy(Xu);
+  model.setKupToDate(false);
+
+  CMatrix params(1, model.getOptNumParams());
+  model.getOptParams(params);
+  CMatrix g(1, model.getOptNumParams());
+  const double ll = model.logLikelihoodGradient(g);
+  FILE* fp = gpcb_open_write(outPath);
+  gpcb_write_scalar(fp, "ll", ll);
+  writeCMatrix(fp, "grads", g);
+  writeCMatrix(fp, "opt_params", params);
+  writeCMatrix(fp, "m", model.m);
+  gpcb_write_scalar(fp, "logDetA", model.logDetA);
+  gpcb_write_scalar(fp, "logDetK_uu", model.logDetK_uu);
+  model.updateAlpha();
+  writeCMatrix(fp, "alpha", model.Alpha);
+  if(xs)
+  {
+    toCMatrix(Xstar, xs);
+    CMatrix mu(Xstar.getRows(), y.getCols());
+    CMatrix var(Xstar.getRows(), y.getCols());
+    model.posteriorMeanVar(mu, var, Xstar);
+    writeCMatrix(fp, "mu", mu);
+    writeCMatrix(fp, "var", var);
+  }
+  if(it && it->data[0] > 0)
+  {
+    model.setDefaultOptimiser(CGp::SCG);
+    model.optimise((int)it->data[0]);
+    model.getOptParams(params);
+    writeCMatrix(fp, "params_final", params);
+    gpcb_write_scalar(fp, "ll_final", model.logLikelihood());
+  }
+  fclose(fp);
+  return 0;
+}
+
 struct GplvmPeek : public CGplvm   // logDetK is protected (CGplvm.h:283)
 {
   GplvmPeek(CKern* k, CScaleNoise* n, int q, int v) : CGplvm(k, n, q, v) {}
@@ -315,6 +376,7 @@ int main(int argc, char* argv[])
     if(mode == "gp") return runGp(in, argv[3]);
     if(mode == "time") return runTime(in, argv[3]);
     if(mode == "gplvm") return runGplvm(in, argv[3]);
+    if(mode == "dtc") return runDtc(in, argv[3]);
     std::cerr << "ref_driver: unknown mode " << mode << std::endl;
     return 2;
   }

@@ -199,6 +199,33 @@ def model_golden():
              final=params(os.path.join(td, "final.model")))
 
 
+def dtc_golden():
+    """Sparse approximation DTC: the compiled reference's CGp(approxType = DTC) on seeded
+    synthetic problems with given inducing inputs X_u and noise precision beta: log-likelihood, the full gradient
+    (d/dX_u, kernel parameters, log beta), Alpha, predictive mean / variance; for the first case also the parameters an
+    SCG run of 15 iterations reaches."""
+    e2 = float(np.exp(-2.0))
+    cases = {"a": (300, 3, 20, 100.0, [("rbf", [1.0, 1.0]), ("bias", [e2]), ("white", [e2])], 15),
+             "b": (300, 3, 20, 50.0, [("rbfard", [1.3, 0.8, 0.3, 0.9, 0.5]), ("lin", [0.2]), ("white", [0.05])], 0),
+             "c": (2000, 8, 128, 1000.0, [("rbf", [0.25, 1.0]), ("white", [0.01])], 0)}
+    out = {}
+    for name, (N, D, M, beta, terms, iters) in cases.items():
+        X, y = synth.make_xy(N, D, seed=5)
+        rng = np.random.RandomState(1)
+        Xu = X[np.sort(rng.choice(N, M, replace=False))].copy() + 0.01 * rng.randn(M, D)
+        Xs = synth.make_xstar(16, D, seed=5)
+        arr = dict(refrun.kern_arrays(terms))
+        arr.update({"X": X, "y": y, "X_u": Xu, "beta": beta, "Xstar": Xs, "iters": float(iters)})
+        r = refrun.run_ref("dtc", arr)
+        out.update({name + "_N": N, name + "_D": D, name + "_M": M, name + "_beta": beta, name + "_Xu": Xu,
+                    name + "_Xstar": Xs, name + "_ll": r["ll"], name + "_grads": r["grads"], name + "_alpha": r["alpha"],
+                    name + "_mu": r["mu"], name + "_var": r["var"], name + "_opt_params": r["opt_params"]})
+        if iters:
+            out[name + "_params_final"] = r["params_final"]
+            out[name + "_ll_final"] = r["ll_final"]
+    save("gp_dtc", **out)
+
+
 def read_svml(path, nrows=None):
     """SVMlight rows `label idx:val ...` -> (Y dense, labels); missing features are 0 (CClctrl.cpp:57-180)."""
     rows, labs = [], []
@@ -265,3 +292,5 @@ if __name__ == "__main__":
         gplvm_golden()
     if what in ("all", "model"):
         model_golden()
+    if what in ("all", "dtc"):
+        dtc_golden()
