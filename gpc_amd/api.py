@@ -321,3 +321,23 @@ def kern_gradx(ks, X, covGrad, out=None):
     gX = out if out is not None else empty(N, D, X.device)
     check(lib().gpc_kern_gradx_f64(byref(ks), ptr(X), N, D, ld(X), ptr(covGrad), ld(covGrad), ptr(gX), ld(gX), stream()))
     return gX
+
+
+# ---- cross-Gram gradient passes (sparse approximations) ----------------------------------------------------------------
+
+def kern_grad_cross(ks, X, X2, covGrad):
+    """Natural-parameter gradient of a cross Gram: sum_{i,n} covGrad(i,n) dk(x_i, x2_n)/dtheta (covGrad is N x N2)."""
+    N, D = X.shape
+    g = (c_double * max(n_params(ks), 1))()
+    check(lib().gpc_kern_grad_cross_f64(byref(ks), ptr(X), N, ld(X), ptr(X2), X2.shape[0], ld(X2), D, ptr(covGrad),
+                                        ld(covGrad), g, stream()))
+    return np.array(g[:n_params(ks)])
+
+
+def kern_gradx_cross(ks, X, X2, covGrad, out=None):
+    """gX(i,q) = sum_n covGrad(i,n) dk(x_i, x2_n)/dx_iq (N x D)."""
+    N, D = X.shape
+    gX = out if out is not None else empty(N, D, X.device)
+    check(lib().gpc_kern_gradx_cross_f64(byref(ks), ptr(X), N, ld(X), ptr(X2), X2.shape[0], ld(X2), D, ptr(covGrad),
+                                         ld(covGrad), ptr(gX), ld(gX), stream()))
+    return gX

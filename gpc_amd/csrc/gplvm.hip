@@ -16,6 +16,7 @@
 // take every 4th column of the slice, so x_n is wave-uniform (broadcast loads) and G(i,n) = G(n,i) is read coalesced
 // along i.  Column slices write partial sums that a second tiny kernel adds in a fixed order (deterministic).
 #include "gpc_common.hpp"
+#include <vector>
 
 namespace gpc {
 
@@ -34,12 +35,14 @@ __global__ void __launch_bounds__(256) covgrad_multi_kernel(const double* __rest
 }
 
 struct GradXArgs {
-  const double* X;
-  const double* G;
-  double* part;      // [nsplit][D][N]
-  int64_t ldx, ldg, N;
+  const double* X;    // rows i (the points the derivative is taken at), N x D
+  const double* X2;   // columns n, N2 x D (== X for the symmetric pass)
+  const double* G;    // N x N2
+  double* part;       // [nsplit][D][N]
+  int64_t ldx, ldx2, ldg, N, N2;
   int D, nsplit;
   int64_t cols_per_split;
+  double pair_factor;  // 2 for the symmetric pass (CGplvm.cpp:577, CGp.cpp:1168), 1 for a cross Gram
 };
 
 template <int DMAX>
@@ -51,7 +54,7 @@ __global__ void __launch_bounds__(256) kern_gradx_kernel(const KSpecDev ks, cons
   const int64_t ic = (i < g.N) ? i : g.N - 1;   // clamped: loads stay unconditional, the store is masked
   const int64_t nbeg = (int64_t)blockIdx.y * g.cols_per_split;
   int64_t nend = nbeg + g.cols_per_split;
-  if(nend > g.N) nend = g.N;
+  if(nend > g.N2) nend = g.N2;
 
   double xi[DMAX], acc[DMAX];
 #pragma unroll
@@ -60,7 +63,7 @@ __global__ void __launch_bounds__(256) kern_gradx_kernel(const KSpecDev ks, cons
     acc[q] = 0.0;
   }
   const bool has_rbf = ks.n_rbf > 0, has_ard = ks.n_ard > 0;
-  const double lin2 = 2.0 * ks.lin_var;
+  const double lin2 = g.pair_factor * ks.lin_var;
 
   for(int64_t n = nbeg + w; n < nend; n += 4) {
     const double gv = g.G[ic + n * g.ldg];   // G(i,n) == G(n,i)
@@ -68,7 +71,7 @@ __global__ void __launch_bounds__(256) kern_gradx_kernel(const KSpecDev ks, cons
     double d2 = 0.0, d2a = 0.0;
 #pragma unroll
     for(int q = 0; q < DMAX; q++) {
-      xn[q] = (q < g.D) ? g.X[n + (int64_t)q * g.ldx] : 0.0;   // wave-uniform address
+      xn[q] = (q < g.D) ? g.X2[n + (int64_t)q * g.ldx2] : 0.0;   // wave-uniform address
       dx[q] = xn[q] - xi[q];
       d2 += dx[q] * dx[q];
       if(has_ard) d2a += ks.ard_scale[0][q < GPC_MAX_ARD_DIM ? q : 0] * dx[q] * dx[q];
@@ -79,7 +82,7 @@ __global__ void __launch_bounds__(256) kern_gradx_kernel(const KSpecDev ks, cons
     }
     double card = 0.0;
     if(has_ard) card = 2.0 * ks.ard_hiw[0] * ks.ard_var[0] * exp(-ks.ard_hiw[0] * d2a);
-    const double g2 = 2.0 * gv;
+    const double g2 = g.pair_factor * gv;
     const double a = g2 * crbf, b = g2 * card, c = gv * lin2;
 #pragma unroll
     for(int q = 0; q < DMAX; q++) {
@@ -103,6 +106,78 @@ __global__ void __launch_bounds__(256) kern_gradx_kernel(const KSpecDev ks, cons
       }
     }
   }
+}
+
+// Kernel-parameter sums of a CROSS Gram in one pass over covGrad (N x N2):  CCmpndKern::getGradParams(g, X, X2, covGrad)
+// (rbf CKern.cpp:1175-1202, rbfard 3318-3357, bias 1015-1019, lin 2354-2368, white 730-734 = 0), needed by the sparse
+// approximations for K_uf (CGp.cpp:1153).  Per workgroup NPC partial sums; the host adds them in a fixed order.
+//   [2t], [2t+1]  rbf term t: sum cg k~ d2, sum cg k~      [8], [9] rbfard: the same with the scaled distance
+//   [10] sum cg (bias)   [11] sum cg x_i.x2_n (lin)   [12 + q] rbfard: sum cg k~ (x_iq - x2_nq)^2
+constexpr int NPC = 12 + 16;
+template <int DMAX>
+__global__ void __launch_bounds__(256) kern_grad_cross_kernel(const KSpecDev ks, const GradXArgs g, double* __restrict__ partial)
+{
+  __shared__ double red[4];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int64_t i = (int64_t)blockIdx.x * 64 + lane;
+  const bool row_ok = i < g.N;
+  const int64_t ic = row_ok ? i : g.N - 1;
+  const int64_t nbeg = (int64_t)blockIdx.y * g.cols_per_split;
+  int64_t nend = nbeg + g.cols_per_split;
+  if(nend > g.N2) nend = g.N2;
+  double xi[DMAX], sdim[DMAX], srbf[8], sard1 = 0.0, sard2 = 0.0, sbias = 0.0, slin = 0.0;
+#pragma unroll
+  for(int q = 0; q < DMAX; q++) {
+    xi[q] = (q < g.D) ? g.X[ic + (int64_t)q * g.ldx] : 0.0;
+    sdim[q] = 0.0;
+  }
+#pragma unroll
+  for(int q = 0; q < 8; q++) srbf[q] = 0.0;
+  const bool has_ard = ks.n_ard > 0;
+  for(int64_t n = nbeg + w; n < nend; n += 4) {
+    const double cg = row_ok ? g.G[ic + n * g.ldg] : 0.0;
+    double d2 = 0.0, d2a = 0.0, dot = 0.0, dq[DMAX];
+#pragma unroll
+    for(int q = 0; q < DMAX; q++) {
+      const double xn = (q < g.D) ? g.X2[n + (int64_t)q * g.ldx2] : 0.0;   // wave-uniform address
+      const double dx = xi[q] - xn;
+      dq[q] = dx * dx;
+      d2 += dq[q];
+      dot += xi[q] * xn;
+      if(has_ard) d2a += ks.ard_scale[0][q < GPC_MAX_ARD_DIM ? q : 0] * dq[q];
+    }
+    for(int t = 0; t < ks.n_rbf; t++) {
+      const double kcg = exp(-ks.rbf_hiw[t] * d2) * cg;
+      srbf[2 * t] += kcg * d2;
+      srbf[2 * t + 1] += kcg;
+    }
+    if(has_ard) {
+      const double kcg = exp(-ks.ard_hiw[0] * d2a) * cg;
+      sard1 += kcg * d2a;
+      sard2 += kcg;
+#pragma unroll
+      for(int q = 0; q < DMAX; q++) sdim[q] += kcg * dq[q];
+    }
+    sbias += cg;
+    slin += cg * dot;
+  }
+  // block sums, one value at a time (fixed order: lanes by shuffle, then the four waves)
+  double* out = partial + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * NPC;
+  auto block_store = [&](double v, int slot) {
+    for(int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    __syncthreads();
+    if(lane == 0) red[w] = v;
+    __syncthreads();
+    if(threadIdx.x == 0) out[slot] = ((red[0] + red[1]) + red[2]) + red[3];
+  };
+#pragma unroll
+  for(int q = 0; q < 8; q++) block_store(srbf[q], q);
+  block_store(sard1, 8);
+  block_store(sard2, 9);
+  block_store(sbias, 10);
+  block_store(slin, 11);
+#pragma unroll
+  for(int q = 0; q < 16; q++) block_store(q < DMAX ? sdim[q < DMAX ? q : 0] : 0.0, 12 + q);
 }
 
 __global__ void __launch_bounds__(256) gradx_reduce_kernel(const double* __restrict__ part, int nsplit, int D, int64_t N,
@@ -140,14 +215,12 @@ extern "C" int gpc_covgrad_multi_f64(int64_t N, int64_t d, const double* invK, i
   return GPC_OK;
 }
 
-extern "C" int gpc_kern_gradx_f64(const gpc_kspec* ksp, const double* X, int64_t N, int64_t D, int64_t ldx,
-                                  const double* covGrad, int64_t ldc, double* gX, int64_t ldg, void* stream)
+static int launch_gradx(const gpc_kspec* ksp, const double* X, int64_t N, int64_t ldx, const double* X2, int64_t N2,
+                        int64_t ldx2, int64_t D, const double* covGrad, int64_t ldc, double* gX, int64_t ldg,
+                        double pair_factor, hipStream_t s)
 {
-  GPC_CHECK(ensure_device());
-  GPC_REQUIRE(ksp && N >= 0 && D >= 0 && ldx >= (N > 1 ? N : 1) && ldc >= (N > 1 ? N : 1) && ldg >= (N > 1 ? N : 1),
-              "kern_gradx args");
   if(D > 16) {
-    set_error("kern_gradx: latent dimension %lld > 16 is outside the accelerated set", (long long)D);
+    set_error("kern_gradx: input dimension %lld > 16 is outside the accelerated set", (long long)D);
     return GPC_EUNSUPPORTED;
   }
   KSpecDev ks;
@@ -157,22 +230,27 @@ extern "C" int gpc_kern_gradx_f64(const gpc_kspec* ksp, const double* X, int64_t
     return GPC_EUNSUPPORTED;
   }
   if(N == 0 || D == 0) return GPC_OK;
-  hipStream_t s = as_stream(stream);
   const int64_t rb = (N + 63) / 64;
-  int64_t nsplit = (1024 + rb - 1) / rb;               // >= ~1024 workgroups when N allows it
-  const int64_t maxsplit = (N + 15) / 16;              // at least 16 columns (4 per wave) per slice
+  int64_t nsplit = (1024 + rb - 1) / rb;               // >= ~1024 workgroups when the sizes allow it
+  const int64_t maxsplit = (N2 + 15) / 16;             // at least 16 columns (4 per wave) per slice
   if(nsplit > maxsplit) nsplit = maxsplit;
   if(nsplit < 1) nsplit = 1;
   if(nsplit > 65535) nsplit = 65535;
   GradXArgs g;
   g.X = X;
+  g.X2 = X2;
   g.G = covGrad;
   g.ldx = ldx;
+  g.ldx2 = ldx2;
   g.ldg = ldc;
   g.N = N;
+  g.N2 = N2;
   g.D = (int)D;
-  g.cols_per_split = (N + nsplit - 1) / nsplit;
-  nsplit = (N + g.cols_per_split - 1) / g.cols_per_split;
+  g.pair_factor = pair_factor;
+  g.cols_per_split = (N2 + nsplit - 1) / nsplit;
+  if(g.cols_per_split < 1) g.cols_per_split = 1;
+  nsplit = (N2 + g.cols_per_split - 1) / g.cols_per_split;
+  if(nsplit < 1) nsplit = 1;
   g.nsplit = (int)nsplit;
   void* ws = nullptr;
   GPC_CHECK(workspace(WS_KERN, sizeof(double) * (size_t)nsplit * (size_t)D * (size_t)N, &ws));
@@ -186,5 +264,111 @@ extern "C" int gpc_kern_gradx_f64(const gpc_kspec* ksp, const double* X, int64_t
   hipLaunchKernelGGL(gradx_reduce_kernel, dim3((unsigned)((N + 255) / 256), (unsigned)D), dim3(256), 0, s, g.part,
                      (int)nsplit, (int)D, N, gX, ldg);
   GPC_HIP_CHECK(hipGetLastError());
+  return GPC_OK;
+}
+
+extern "C" int gpc_kern_gradx_f64(const gpc_kspec* ksp, const double* X, int64_t N, int64_t D, int64_t ldx,
+                                  const double* covGrad, int64_t ldc, double* gX, int64_t ldg, void* stream)
+{
+  GPC_CHECK(ensure_device());
+  GPC_REQUIRE(ksp && N >= 0 && D >= 0 && ldx >= (N > 1 ? N : 1) && ldc >= (N > 1 ? N : 1) && ldg >= (N > 1 ? N : 1),
+              "kern_gradx args");
+  return launch_gradx(ksp, X, N, ldx, X, N, ldx, D, covGrad, ldc, gX, ldg, 2.0, as_stream(stream));
+}
+
+extern "C" int gpc_kern_gradx_cross_f64(const gpc_kspec* ksp, const double* X, int64_t N, int64_t ldx, const double* X2,
+                                        int64_t N2, int64_t ldx2, int64_t D, const double* covGrad, int64_t ldc, double* gX,
+                                        int64_t ldg, void* stream)
+{
+  GPC_CHECK(ensure_device());
+  GPC_REQUIRE(ksp && N >= 0 && N2 >= 0 && D >= 0 && ldx >= (N > 1 ? N : 1) && ldx2 >= (N2 > 1 ? N2 : 1) &&
+                  ldc >= (N > 1 ? N : 1) && ldg >= (N > 1 ? N : 1),
+              "kern_gradx_cross args");
+  if(N2 == 0) {   // empty sum
+    if(N > 0 && D > 0) GPC_HIP_CHECK(hipMemset2DAsync(gX, sizeof(double) * (size_t)ldg, 0, sizeof(double) * (size_t)N, (size_t)D, as_stream(stream)));
+    return GPC_OK;
+  }
+  return launch_gradx(ksp, X, N, ldx, X2, N2, ldx2, D, covGrad, ldc, gX, ldg, 1.0, as_stream(stream));
+}
+
+extern "C" int gpc_kern_grad_cross_f64(const gpc_kspec* ksp, const double* X, int64_t N, int64_t ldx, const double* X2,
+                                       int64_t N2, int64_t ldx2, int64_t D, const double* covGrad, int64_t ldc,
+                                       double* gout, void* stream)
+{
+  GPC_CHECK(ensure_device());
+  GPC_REQUIRE(ksp && gout && N >= 0 && N2 >= 0 && D >= 0 && ldx >= (N > 1 ? N : 1) && ldx2 >= (N2 > 1 ? N2 : 1) &&
+                  ldc >= (N > 1 ? N : 1),
+              "kern_grad_cross args");
+  if(D > 16) {
+    set_error("kern_grad_cross: input dimension %lld > 16 is outside the accelerated set", (long long)D);
+    return GPC_EUNSUPPORTED;
+  }
+  hipStream_t s = as_stream(stream);
+  KSpecDev ks;
+  GPC_CHECK(collapse_kspec(ksp, D, &ks));
+  const int nparams = ksp->offs[ksp->n_terms];
+  for(int p = 0; p < nparams; p++) gout[p] = 0.0;
+  if(N == 0 || N2 == 0) return GPC_OK;
+  const int64_t rb = (N + 63) / 64;
+  int64_t nsplit = (512 + rb - 1) / rb;
+  const int64_t maxsplit = (N2 + 15) / 16;
+  if(nsplit > maxsplit) nsplit = maxsplit;
+  if(nsplit < 1) nsplit = 1;
+  if(nsplit > 65535) nsplit = 65535;
+  GradXArgs g;
+  g.X = X;
+  g.X2 = X2;
+  g.G = covGrad;
+  g.ldx = ldx;
+  g.ldx2 = ldx2;
+  g.ldg = ldc;
+  g.N = N;
+  g.N2 = N2;
+  g.D = (int)D;
+  g.pair_factor = 1.0;
+  g.part = nullptr;
+  g.cols_per_split = (N2 + nsplit - 1) / nsplit;
+  nsplit = (N2 + g.cols_per_split - 1) / g.cols_per_split;
+  g.nsplit = (int)nsplit;
+  const int64_t nblk = rb * nsplit;
+  void* ws = nullptr;
+  GPC_CHECK(workspace(WS_KERN, sizeof(double) * (size_t)nblk * NPC, &ws));
+  double* partial = static_cast<double*>(ws);
+  const dim3 grid((unsigned)rb, (unsigned)nsplit);
+  if(D <= 4)
+    hipLaunchKernelGGL(kern_grad_cross_kernel<4>, grid, dim3(256), 0, s, ks, g, partial);
+  else
+    hipLaunchKernelGGL(kern_grad_cross_kernel<16>, grid, dim3(256), 0, s, ks, g, partial);
+  GPC_HIP_CHECK(hipGetLastError());
+  std::vector<double> h((size_t)nblk * NPC);
+  GPC_HIP_CHECK(hipMemcpyAsync(h.data(), partial, sizeof(double) * h.size(), hipMemcpyDeviceToHost, s));
+  GPC_HIP_CHECK(hipStreamSynchronize(s));
+  double S[NPC];
+  for(int q = 0; q < NPC; q++) {
+    double acc = 0.0;
+    for(int64_t b = 0; b < nblk; b++) acc += h[(size_t)b * NPC + q];
+    S[q] = acc;
+  }
+  int irbf = 0;
+  for(int t = 0; t < ksp->n_terms; t++) {
+    double* gt = gout + ksp->offs[t];
+    const double* p = ksp->params + ksp->offs[t];
+    switch(ksp->types[t]) {
+    case GPC_KERN_RBF:
+      gt[0] = -0.5 * p[1] * S[2 * irbf];
+      gt[1] = S[2 * irbf + 1];
+      irbf++;
+      break;
+    case GPC_KERN_RBFARD:
+      gt[0] = -0.5 * p[1] * S[8];
+      gt[1] = S[9];
+      for(int64_t q = 0; q < D; q++) gt[2 + q] = -0.5 * p[0] * p[1] * S[12 + q];
+      break;
+    case GPC_KERN_WHITE: gt[0] = 0.0; break;
+    case GPC_KERN_BIAS: gt[0] = S[10]; break;
+    case GPC_KERN_LIN: gt[0] = S[11]; break;
+    default: break;
+    }
+  }
   return GPC_OK;
 }

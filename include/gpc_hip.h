@@ -203,6 +203,18 @@ int gpc_covgrad_multi_f64(int64_t N, int64_t d, const double* invK, int64_t ldi,
 int gpc_kern_gradx_f64(const gpc_kspec* ks, const double* X, int64_t N, int64_t D, int64_t ldx,
                        const double* covGrad, int64_t ldc, double* gX, int64_t ldg, void* stream);
 
+/* ---- cross-Gram gradient passes (sparse approximations; CGp.cpp:1146-1190) ------------ */
+/* g_p = sum_{i,n} covGrad(i,n) dk(x_i, x2_n)/dtheta_p, natural parameters in spec order:
+ * CCmpndKern::getGradParams(g, X, X2, covGrad) (rbf CKern.cpp:1175-1202, rbfard 3318-3357, bias 1015-1019, lin 2354-2368;
+ * white contributes 0, 730-734).  covGrad is N x N2; g is a host array; D <= 16. */
+int gpc_kern_grad_cross_f64(const gpc_kspec* ks, const double* X, int64_t N, int64_t ldx, const double* X2, int64_t N2,
+                            int64_t ldx2, int64_t D, const double* covGrad, int64_t ldc, double* g, void* stream);
+/* gX(i,q) = sum_n covGrad(i,n) d k(x_i, x2_n)/d x_iq: CKern::getGradX(gKX, X, i, X2) + dotColRow over n
+ * (CGp.cpp:1163-1176, the K_uf part of the inducing-input gradient).  gX is N x D (D <= 16). */
+int gpc_kern_gradx_cross_f64(const gpc_kspec* ks, const double* X, int64_t N, int64_t ldx, const double* X2, int64_t N2,
+                             int64_t ldx2, int64_t D, const double* covGrad, int64_t ldc, double* gX, int64_t ldg,
+                             void* stream);
+
 /* ---- measurement hooks (bench.py) -------------------------------------------------------------------------------
  * When enabled, HIP events bracket every launch of the two dominant kernels on the stream they are launched on:
  * kind 0 = the trailing SYRK update of gpc_potrf_f64 (work unit: flops), kind 1 = the Gram kernel (work unit:

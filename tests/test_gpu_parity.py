@@ -293,6 +293,42 @@ def test_kern_grad_fixtures(api, golden, name):
         assert np.abs(got - want).max() < 1e-9 * max(1.0, np.abs(want).max())
 
 
+@pytest.mark.parametrize("name", KERN_FIXTURES)
+def test_kern_grad_cross_fixtures(api, golden, name):
+    """testKern.cpp:280-304: getGradTransParams(g, X, X2, covGrad2) -- the cross-Gram parameter gradient (g4)"""
+    from gpc_amd import gp as gpmod
+    g = golden(name)
+    X, X2 = g["X"], g["X2"]
+    if X.shape[1] > 16:
+        pytest.skip("cross gradient passes cover D <= 16")
+    terms = terms_from_fixture(g, X.shape[1])
+    ks = api.kspec(terms)
+    nat = api.kern_grad_cross(ks, api.from_host(X), api.from_host(X2), api.from_host(g["covGrad2"]))
+    kinds = gpmod.param_transforms(terms)
+    flat = [p for _, ps in terms for p in ps]
+    got = nat * np.array([gpmod._gradfact(k, x) for k, x in zip(kinds, flat)])
+    want = g["g4"].ravel()
+    assert np.abs(got - want).max() < 1e-9 * max(1.0, np.abs(want).max())
+
+
+def test_kern_gradx_cross_vs_numpy(api):
+    """gX(i,q) = sum_n covGrad(i,n) dk(x_i, x2_n)/dx_iq for rbf + rbfard + lin (+ bias, white: no contribution),
+    ragged sizes, against the formulas of CKern.cpp:1115-1135, 3268-3293, 2291-2308 written out in numpy"""
+    rng = np.random.RandomState(4)
+    for N, N2, D in ((37, 501, 3), (130, 64, 1), (64, 1000, 9)):
+        X, X2, G = rng.randn(N, D), rng.randn(N2, D), rng.randn(N, N2)
+        s = rng.rand(D) * 0.8 + 0.1
+        terms = [("rbf", [0.7, 1.3]), ("rbfard", [1.1, 0.6] + list(s)), ("lin", [0.4]), ("bias", [0.2]), ("white", [0.1])]
+        diff = X2[None, :, :] - X[:, None, :]                      # x2_n - x_i
+        d2 = (diff ** 2).sum(-1)
+        d2a = ((diff ** 2) * s[None, None, :]).sum(-1)
+        want = np.einsum("in,inq->iq", G * 0.7 * 1.3 * np.exp(-0.5 * 0.7 * d2), diff)
+        want += np.einsum("in,inq->iq", G * 1.1 * 0.6 * np.exp(-0.5 * 1.1 * d2a), diff * s[None, None, :])
+        want += 0.4 * G @ X2
+        got = api.to_host(api.kern_gradx_cross(api.kspec(terms), api.from_host(X), api.from_host(X2), api.from_host(G)))
+        assert np.abs(got - want).max() < 1e-11 * max(1.0, np.abs(want).max())
+
+
 # ---- CGp (FTC) ---------------------------------------------------------------------------------------------------------------
 
 def run_gp_fixture(api, g, X, y, scale=None, bias=None):
