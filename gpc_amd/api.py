@@ -341,3 +341,9 @@ def kern_gradx_cross(ks, X, X2, covGrad, out=None):
     check(lib().gpc_kern_gradx_cross_f64(byref(ks), ptr(X), N, ld(X), ptr(X2), X2.shape[0], ld(X2), D, ptr(covGrad),
                                          ld(covGrad), ptr(gX), ld(gX), stream()))
     return gX
+
+
+def axpby_(alpha, X, beta, Y):
+    """Y := alpha X + beta Y (elementwise)."""
+    check(lib().gpc_axpby_f64(Y.shape[0], Y.shape[1], alpha, ptr(X), ld(X), beta, ptr(Y), ld(Y), stream()))
+    return Y

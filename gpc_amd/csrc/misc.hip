@@ -203,6 +203,17 @@ __global__ void __launch_bounds__(256) covgrad_kernel(const double* __restrict__
   if(i < N) cg[i + j * ldc] = -0.5 * (invK[i + j * ldi] - a[i] * a[j]);
 }
 
+// Y := alpha X + beta Y, elementwise over an M x N block (daxpy_ / dscal_ / dcopy_ of lapack.h:78-111 in one kernel)
+__global__ void __launch_bounds__(256) axpby_kernel(int64_t M, double alpha, const double* __restrict__ X, int64_t ldx,
+                                                    double beta, double* __restrict__ Y, int64_t ldy, int64_t j0)
+{
+  const int64_t j = j0 + blockIdx.y;
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if(i >= M) return;
+  const double x = (alpha == 0.0) ? 0.0 : alpha * X[i + j * ldx];
+  Y[i + j * ldy] = (beta == 0.0) ? x : fma(beta, Y[i + j * ldy], x);
+}
+
 int reduce_partials_to_host(const double* d_partial, int64_t ncols, int64_t nb, double* out_host, hipStream_t s)
 {
   // small: copy partials back and finish on the host in a fixed order (deterministic)
@@ -366,6 +377,22 @@ extern "C" int gpc_covgrad_f64(int64_t N, const double* invK, int64_t ldi, const
     const int64_t nc = (N - j0 < 32768) ? (N - j0) : 32768;
     hipLaunchKernelGGL(covgrad_kernel, dim3((unsigned)((N + 255) / 256), (unsigned)nc), dim3(256), 0, s,
                        invK, ldi, a, covGrad, ldc, N, j0);
+  }
+  GPC_HIP_CHECK(hipGetLastError());
+  return GPC_OK;
+}
+
+extern "C" int gpc_axpby_f64(int64_t M, int64_t N, double alpha, const double* X, int64_t ldx, double beta, double* Y,
+                             int64_t ldy, void* stream)
+{
+  GPC_CHECK(ensure_device());
+  GPC_REQUIRE(M >= 0 && N >= 0 && ldx >= (M > 1 ? M : 1) && ldy >= (M > 1 ? M : 1), "axpby dims");
+  if(M == 0 || N == 0) return GPC_OK;
+  hipStream_t s = as_stream(stream);
+  for(int64_t j0 = 0; j0 < N; j0 += 32768) {
+    const int64_t nc = (N - j0 < 32768) ? (N - j0) : 32768;
+    hipLaunchKernelGGL(axpby_kernel, dim3((unsigned)((M + 255) / 256), (unsigned)nc), dim3(256), 0, s, M, alpha, X, ldx,
+                       beta, Y, ldy, j0);
   }
   GPC_HIP_CHECK(hipGetLastError());
   return GPC_OK;

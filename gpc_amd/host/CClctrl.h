@@ -4,6 +4,7 @@
 #define GPC_AMD_CCLCTRL_H
 #include <string>
 #include "CMatrix.h"
+#include "ndlutil.h"
 
 class CClctrl {
  public:
@@ -27,7 +28,7 @@ class CClctrl {
   int getVerbosity() const { return verbosity; }
   void setVerbosity(int v) { verbosity = v; }
   unsigned long getSeed() const { return seed; }
-  void setSeed(unsigned long s) { seed = s; }
+  void setSeed(unsigned long s) { seed = s; ndlutil::init_genrand(s); }   // CClctrl.h:78-81
   int getFileFormat() const { return fileFormat; }
   void setFileFormat(int f) { fileFormat = f; }
   std::string getMode() const { return mode; }

@@ -1,12 +1,14 @@
 // CGp.cpp -- see CGp.h.  Every O(N^2) / O(N^3) step is a call into libgpc_hip.so; the host keeps the dirty flags,
 // the parameter vector and the O(N d) / O(N* d) results.
 #include "CGp.h"
+#include <algorithm>
 #include <cmath>
 #include <cstdlib>
 #include <fstream>
 #include <vector>
 #include "gpc_hip.h"
 #include "ndlstream.h"
+#include "ndlutil.h"
 
 static const double HALFLOGTWOPI = 0.91893853320467274178;   // ndlutil::HALFLOGTWOPI
 
@@ -24,26 +26,38 @@ double* devAlloc(size_t n)
 }
 }  // namespace
 
-CGp::CGp(CKern* kernel, CNoise* nois, CMatrix* Xin, int approxType, unsigned int actSetSize, int verbos)
+CGp::CGp(CKern* kernel, CNoise* nois, CMatrix* Xin, int approx, unsigned int actSetSize, int verbos)
     : pX(Xin), py(nois->py), pkern(kernel), pnoise(nois), ownsKernNoise(false), fileNumData(0), fileInputDim(0),
       numActive(actSetSize), scale(1, nois->getOutputDim(), 1.0),
       bias(1, nois->getOutputDim(), 0.0), refTransRounding(true), MupToDate(false), KupToDate(false),
       AlphaUpToDate(false), invKupToDate(false), LcholRounded(false), dX(0), dM(0), dL(0), dInvKm(0), dAlpha(0), dInvK(0),
-      dCovGrad(0), logDetK(0.0), lastJitter(0.0), needInverse(false)
+      dCovGrad(0), logDetK(0.0), lastJitter(0.0), needInverse(false), approxType(approx), betaVal(1e3),
+      inducingFixed(false), dXu(0), dKuu(0), dKuf(0), dInvKuu(0), dA(0), dAinv(0), dLA(0), dE(0), dAlphaU(0),
+      logDetKuu(0.0), logDetA(0.0), LArounded(false)
 {
   if(Xin->getRows() != nois->getNumData())
     throw ndlexceptions::MatrixError("CGp: X and the targets disagree on the number of data");   // CGp.cpp:60
-  if(approxType != FTC)
-    throw ndlexceptions::NotImplementedError("sparse approximations (DTC/FITC/PITC/DTCVAR) are outside the accelerated FTC path");
+  if(approxType != FTC && approxType != DTC)
+    throw ndlexceptions::NotImplementedError("of the sparse approximations only DTC runs on the accelerated path (FITC/PITC/DTCVAR do not)");
   setVerbosity(verbos);
   const char* e = std::getenv("GPC_EXACT_TRANS");
   if(e && e[0] == '1') refTransRounding = false;
+  if(isSparseApproximation()) {
+    // CGp::initVals, CGp.cpp:262-277: beta = 1e3, the inducing inputs are a sorted random subset of the data
+    if(numActive > getNumData())
+      throw ndlexceptions::Error("Number of active points has to be less than number of data.");
+    std::vector<unsigned long> ind = ndlutil::randpermTrunc(getNumData(), numActive);
+    std::sort(ind.begin(), ind.end());
+    X_u.resize(numActive, getInputDim());
+    for(unsigned int i = 0; i < ind.size(); i++) X_u.copyRowRow(i, *pX, (unsigned int)ind[i]);
+  }
 }
 CGp::CGp()
     : pX(0), py(0), pkern(0), pnoise(0), ownsKernNoise(true), fileNumData(0), fileInputDim(0), numActive(0), scale(1, 1, 1.0),
       bias(1, 1, 0.0), refTransRounding(true), MupToDate(false), KupToDate(false), AlphaUpToDate(false),
       invKupToDate(false), LcholRounded(false), dX(0), dM(0), dL(0), dInvKm(0), dAlpha(0), dInvK(0), dCovGrad(0), logDetK(0.0), lastJitter(0.0),
-      needInverse(false)
+      needInverse(false), approxType(FTC), betaVal(1e3), inducingFixed(false), dXu(0), dKuu(0), dKuf(0), dInvKuu(0), dA(0),
+      dAinv(0), dLA(0), dE(0), dAlphaU(0), logDetKuu(0.0), logDetA(0.0), LArounded(false)
 {
   const char* e = std::getenv("GPC_EXACT_TRANS");
   if(e && e[0] == '1') refTransRounding = false;
@@ -62,6 +76,8 @@ void CGp::setData(CMatrix* Xin, CMatrix* yin)
   devFree(dAlpha);
   devFree(dInvK);
   devFree(dCovGrad);
+  devFree(dKuf);
+  devFree(dE);
   MupToDate = KupToDate = AlphaUpToDate = invKupToDate = false;
 }
 CGp::~CGp()
@@ -77,6 +93,15 @@ CGp::~CGp()
   devFree(dAlpha);
   devFree(dInvK);
   devFree(dCovGrad);
+  devFree(dXu);
+  devFree(dKuu);
+  devFree(dKuf);
+  devFree(dInvKuu);
+  devFree(dA);
+  devFree(dAinv);
+  devFree(dLA);
+  devFree(dE);
+  devFree(dAlphaU);
 }
 
 void CGp::updateM() const
@@ -104,6 +129,10 @@ void CGp::ensureDeviceInputs() const
 
 void CGp::updateK() const
 {
+  if(isSparseApproximation()) {
+    updateKdtc();
+    return;
+  }
   if(KupToDate && (invKupToDate || !needInverse)) return;
   ensureDeviceInputs();
   const int64_t N = getNumData(), D = getInputDim(), d = getOutputDim();
@@ -154,6 +183,18 @@ void CGp::updateAlpha() const
   if(AlphaUpToDate && KupToDate) return;
   updateM();
   updateK();
+  if(isSparseApproximation()) {
+    // Alpha = LcholA^-T LcholA^-1 K_uf m (CGp.cpp:490-497); LcholA carries the fp32 quirk of LcholA.trans() (765)
+    const int64_t M = numActive, dd = getOutputDim();
+    if(!dAlphaU) dAlphaU = devAlloc((size_t)M * dd);
+    if(refTransRounding && !LArounded) {
+      gpcCheck(gpc_ref_trans_rounding_f64(M, dLA, M, 0));
+      LArounded = true;
+    }
+    gpcCheck(gpc_gp_alpha_f64(M, dd, dLA, M, dE, M, dAlphaU, M, 0));
+    AlphaUpToDate = true;
+    return;
+  }
   const int64_t N = getNumData(), d = getOutputDim();
   if(!dAlpha) dAlpha = devAlloc((size_t)N * d);
   if(refTransRounding && !LcholRounded) {
@@ -170,6 +211,7 @@ void CGp::updateAlpha() const
 double CGp::logLikelihood() const
 {
   updateM();
+  if(isSparseApproximation()) return logLikelihoodDtc();
   needInverse = false;   // the likelihood alone never needs invK; a gradient at the same point adds it from the factor
   updateK();
   double L = 0.0;
@@ -188,6 +230,10 @@ double CGp::logLikelihoodGradient(CMatrix& g) const
   // updateG (CGp.cpp:1080-1117): for every output, covGrad = -0.5 (invK - invKm invKm') and the kernel's
   // getGradTransParams against it, accumulated; then the log-likelihood itself.
   if(!MupToDate) updateM();
+  if(isSparseApproximation()) {
+    gradientDtc(g);
+    return logLikelihood();
+  }
   needInverse = true;
   updateK();
   const int64_t N = getNumData(), D = getInputDim();
@@ -213,18 +259,32 @@ double CGp::logLikelihoodGradient(CMatrix& g) const
 
 void CGp::getOptParams(CMatrix& param) const
 {
+  // CGp.cpp:330-385: [X_u column by column, unless fixed] [transformed kernel parameters] [log beta]
+  unsigned int counter = 0;
+  if(isSparseApproximation() && !inducingFixed)
+    for(unsigned int j = 0; j < getInputDim(); j++)
+      for(unsigned int i = 0; i < numActive; i++) param.setVal(X_u.getVal(i, j), counter++);
   CMatrix tp(1, pkern->getNumParams());
   pkern->getTransParams(tp);
-  for(unsigned int i = 0; i < pkern->getNumParams(); i++) param.setVal(tp.getVal(i), i);
+  for(unsigned int i = 0; i < pkern->getNumParams(); i++) param.setVal(tp.getVal(i), counter++);
+  if(isSparseApproximation()) param.setVal(std::log(betaVal), counter++);   // betaTransform = exp (CExpTransform::xtoa)
 }
 void CGp::setOptParams(const CMatrix& param)
 {
   KupToDate = false;   // CGp.cpp:389
   invKupToDate = false;
   AlphaUpToDate = false;
+  unsigned int counter = 0;
+  if(isSparseApproximation() && !inducingFixed)
+    for(unsigned int j = 0; j < getInputDim(); j++)
+      for(unsigned int i = 0; i < numActive; i++) X_u.setVal(param.getVal(counter++), i, j);
   CMatrix tp(1, pkern->getNumParams());
-  for(unsigned int i = 0; i < pkern->getNumParams(); i++) tp.setVal(param.getVal(i), i);
+  for(unsigned int i = 0; i < pkern->getNumParams(); i++) tp.setVal(param.getVal(counter++), i);
   pkern->setTransParams(tp);
+  if(isSparseApproximation()) {
+    CTransform expT(CTransform::EXP);
+    betaVal = expT.atox(param.getVal(counter++));
+  }
 }
 
 void CGp::posteriorMeanVar(CMatrix& mu, CMatrix& varSigma, const CMatrix& Xin) const
@@ -233,6 +293,10 @@ void CGp::posteriorMeanVar(CMatrix& mu, CMatrix& varSigma, const CMatrix& Xin) c
   if(mu.getCols() != d || varSigma.getCols() != d || mu.getRows() != Ns || varSigma.getRows() != Ns)
     throw ndlexceptions::MatrixError("posteriorMeanVar: output dimensions");   // CGp.cpp:644-647
   if(Xin.getCols() != D) throw ndlexceptions::MatrixError("posteriorMeanVar: input dimension");
+  if(isSparseApproximation()) {
+    posteriorDtc(mu, varSigma, Xin);
+    return;
+  }
   updateAlpha();
   gpc_kspec ks;
   pkern->toKspec(ks);
@@ -303,13 +367,229 @@ void CGp::display(std::ostream& os) const
   if(py && pX) os << "Log likelihood: " << logLikelihood() << std::endl;   // a model read from a file has no data yet
 }
 
+// ---- sparse approximation DTC ----------------------------------------------------------------------------------------
+// jitChol of a device matrix that is not a Gram matrix of inputs (here A = K_uf K_uf' + K_uu / beta): CMatrix::jitChol's
+// schedule (CMatrix.cpp:767-804) -- first jitter 1e-6 trace(A)/M, x10 per retry, added to A itself.
+static double devJitChol(int64_t M, double* dA, double* dL)
+{
+  double tr = 0.0;
+  gpcCheck(gpc_trace_f64(M, dA, M, &tr, 0));
+  double jitter = 1e-6 * tr / (double)(M > 0 ? M : 1), total = 0.0;
+  for(int tries = 0;;) {
+    int info = 0;
+    gpcCheck(gpc_memcpy_d2d(dL, dA, sizeof(double) * (size_t)M * M, 0));
+    gpcCheck(gpc_potrf_f64('L', M, dL, M, &info, 0));
+    if(info == 0) return total;
+    gpcCheck(gpc_add_diag_f64(M, dA, M, jitter, 0));
+    total += jitter;
+    jitter *= 10.0;
+    tries++;
+    if(jitter > 10.0 || tries >= 20) throw ndlexceptions::MatrixNonPosDef();
+  }
+}
+
+void CGp::updateKdtc() const
+{
+  if(KupToDate) return;
+  ensureDeviceInputs();
+  const int64_t N = getNumData(), D = getInputDim(), d = getOutputDim(), M = numActive;
+  if(!dXu) dXu = devAlloc((size_t)M * D);
+  if(!dKuu) dKuu = devAlloc((size_t)M * M);
+  if(!dKuf) dKuf = devAlloc((size_t)M * N);
+  if(!dInvKuu) dInvKuu = devAlloc((size_t)M * M);
+  if(!dA) dA = devAlloc((size_t)M * M);
+  if(!dAinv) dAinv = devAlloc((size_t)M * M);
+  if(!dLA) dLA = devAlloc((size_t)M * M);
+  if(!dE) dE = devAlloc((size_t)M * d);
+  gpcCheck(gpc_memcpy_h2d(dXu, X_u.getVals(), sizeof(double) * (size_t)M * D, 0));
+  gpc_kspec ks;
+  pkern->toKspec(ks);
+  // _updateK, CGp.cpp:713-735: K_uu (symmetric, with the white term on its diagonal) and K_uf = k(X_u, X)
+  gpcCheck(gpc_gram_sym_f64(&ks, dXu, M, D, M, dKuu, M, 0));
+  gpcCheck(gpc_gram_cross_f64(&ks, dXu, M, M, dX, N, N, D, dKuf, M, 0));
+  // _updateInvK, CGp.cpp:896-909: jitChol(K_uu) (which adds any jitter to K_uu itself), logDet, pdinv
+  double jit = 0.0;
+  int info = 0;
+  gpcCheck(gpc_gp_update_k_f64(&ks, dXu, M, D, M, dInvKuu, M, &logDetKuu, &jit, &info, 0));
+  if(info != 0) throw ndlexceptions::MatrixNonPosDef();
+  if(jit > 0.0) gpcCheck(gpc_add_diag_f64(M, dKuu, M, jit, 0));
+  if(jit > 1e-2 && getVerbosity() > 2)
+    std::cout << "Warning: jitter of " << jit << " added to K_uu in _updateInvK()." << std::endl;
+  gpcCheck(gpc_potri_f64('L', M, dInvKuu, M, 0));
+  // updateAD, CGp.cpp:751-776: A = K_uf K_uf' + K_uu / beta; LcholA, logDetA, Ainv
+  gpcCheck(gpc_memcpy_d2d(dA, dKuu, sizeof(double) * (size_t)M * M, 0));
+  gpcCheck(gpc_gemm_f64('N', 'T', M, M, N, 1.0, dKuf, M, dKuf, M, 1.0 / betaVal, dA, M, 0));
+  const double jitA = devJitChol(M, dA, dLA);
+  if(jitA > 1e-2 && getVerbosity() > 2)
+    std::cout << "Warning: jitter of " << jitA << " added to A in updateAD()." << std::endl;
+  gpcCheck(gpc_logdet_chol_f64(M, dLA, M, &logDetA, 0));
+  gpcCheck(gpc_memcpy_d2d(dAinv, dLA, sizeof(double) * (size_t)M * M, 0));
+  gpcCheck(gpc_potri_f64('L', M, dAinv, M, 0));
+  LArounded = false;
+  // E = K_uf m (used by the likelihood, Alpha and the gradient)
+  gpcCheck(gpc_gemm_f64('N', 'N', M, d, N, 1.0, dKuf, M, dM, N, 0.0, dE, M, 0));
+  KupToDate = true;
+  AlphaUpToDate = false;
+}
+
+double CGp::logLikelihoodDtc() const
+{
+  updateK();
+  const int64_t N = getNumData(), d = getOutputDim(), M = numActive;
+  double* dInvAe = devAlloc((size_t)M * d);
+  std::vector<double> eAe((size_t)d), mm((size_t)d);
+  try {
+    gpcCheck(gpc_gemm_f64('N', 'N', M, d, M, 1.0, dAinv, M, dE, M, 0.0, dInvAe, M, 0));
+    gpcCheck(gpc_coldot_f64(M, d, dInvAe, M, dE, M, &eAe[0], 0));
+    gpcCheck(gpc_coldot_f64(N, d, dM, N, dM, N, &mm[0], 0));
+  } catch(...) {
+    devFree(dInvAe);
+    throw;
+  }
+  devFree(dInvAe);
+  // CGp.cpp:939-961
+  double L = (double)d * (((double)M - (double)N) * std::log(betaVal) - logDetKuu + logDetA);
+  for(int64_t j = 0; j < d; j++) L -= betaVal * (eAe[j] - mm[j]);
+  L *= -0.5;
+  L += pkern->priorLogProb();
+  L -= (double)d * (double)N * HALFLOGTWOPI;
+  return L;
+}
+
+void CGp::gradientDtc(CMatrix& g) const
+{
+  updateK();
+  const int64_t N = getNumData(), D = getInputDim(), d = getOutputDim(), M = numActive;
+  const unsigned int nk = pkern->getNumParams();
+  if(g.getRows() != 1 || g.getCols() != getOptNumParams())
+    throw ndlexceptions::MatrixError("logLikelihoodGradient: g must be 1 x nParams");
+  const double beta = betaVal, dd = (double)d;
+  double *dEET = devAlloc((size_t)M * M), *dAinvEET = devAlloc((size_t)M * M), *dAEA = devAlloc((size_t)M * M),
+         *dGKuu = devAlloc((size_t)M * M), *dAinvKuf = devAlloc((size_t)M * N), *dGKuf = devAlloc((size_t)M * N),
+         *dGXa = devAlloc((size_t)M * D), *dGXb = devAlloc((size_t)M * D);
+  gpc_kspec ks;
+  pkern->toKspec(ks);
+  std::vector<double> t1(nk > 0 ? nk : 1), t2(nk > 0 ? nk : 1), gxa((size_t)M * D), gxb((size_t)M * D), tmp((size_t)(M > d ? M : d));
+  double gb = 0.0;
+  try {
+    // gpCovGrads, CGp.cpp:1252-1316
+    gpcCheck(gpc_gemm_f64('N', 'T', M, M, d, 1.0, dE, M, dE, M, 0.0, dEET, M, 0));
+    gpcCheck(gpc_gemm_f64('N', 'N', M, M, M, 1.0, dAinv, M, dEET, M, 0.0, dAinvEET, M, 0));
+    gpcCheck(gpc_gemm_f64('N', 'N', M, M, M, 1.0, dAinvEET, M, dAinv, M, 0.0, dAEA, M, 0));
+    // gK_uu = 0.5 * (d * (invK_uu - Ainv / beta) - AinvEETAinv)
+    gpcCheck(gpc_axpby_f64(M, M, 0.5 * dd, dInvKuu, M, 0.0, dGKuu, M, 0));
+    gpcCheck(gpc_axpby_f64(M, M, -0.5 * dd / beta, dAinv, M, 1.0, dGKuu, M, 0));
+    gpcCheck(gpc_axpby_f64(M, M, -0.5, dAEA, M, 1.0, dGKuu, M, 0));
+    // gK_uf = -beta * (AinvEET * AinvK_uf - Ainv * E m') - d * AinvK_uf, with Ainv * (E m') = (Ainv E) m'
+    gpcCheck(gpc_gemm_f64('N', 'N', M, N, M, 1.0, dAinv, M, dKuf, M, 0.0, dAinvKuf, M, 0));
+    double* dAinvE = dEET;   // EET is no longer needed: reuse its storage (M x d <= M x M when d <= M)
+    const bool ownAinvE = d > M;
+    if(ownAinvE) dAinvE = devAlloc((size_t)M * d);
+    gpcCheck(gpc_gemm_f64('N', 'N', M, d, M, 1.0, dAinv, M, dE, M, 0.0, dAinvE, M, 0));
+    gpcCheck(gpc_gemm_f64('N', 'T', M, N, d, beta, dAinvE, M, dM, N, 0.0, dGKuf, M, 0));             //  beta * AinvEMT
+    gpcCheck(gpc_gemm_f64('N', 'N', M, N, M, -beta, dAinvEET, M, dAinvKuf, M, 1.0, dGKuf, M, 0));    // -beta * AinvEET AinvK_uf
+    gpcCheck(gpc_axpby_f64(M, N, -dd, dAinvKuf, M, 1.0, dGKuf, M, 0));
+    if(ownAinvE) devFree(dAinvE);
+    // d/d beta
+    double trAK = 0.0, trAEAK = 0.0, trAinvEET = 0.0;
+    std::vector<double> cd((size_t)M), mm((size_t)d);
+    gpcCheck(gpc_coldot_f64(M, M, dAinv, M, dKuu, M, &cd[0], 0));
+    for(int64_t i = 0; i < M; i++) trAK += cd[i];
+    gpcCheck(gpc_coldot_f64(M, M, dAEA, M, dKuu, M, &cd[0], 0));
+    for(int64_t i = 0; i < M; i++) trAEAK += cd[i];
+    gpcCheck(gpc_trace_f64(M, dAinvEET, M, &trAinvEET, 0));
+    gpcCheck(gpc_coldot_f64(N, d, dM, N, dM, N, &mm[0], 0));
+    gb = (double)(N - M) / beta;
+    gb += trAK / (beta * beta);
+    gb *= dd;
+    gb += trAEAK / beta;
+    for(int64_t j = 0; j < d; j++) gb -= mm[j];
+    gb += trAinvEET;
+    gb *= 0.5;
+    // kernel parameters (CGp.cpp:1149-1158) and inducing inputs (1160-1176)
+    gpcCheck(gpc_kern_grad_f64(&ks, dXu, M, D, M, dGKuu, M, &t1[0], 0));
+    gpcCheck(gpc_kern_grad_cross_f64(&ks, dXu, M, M, dX, N, N, D, dGKuf, M, &t2[0], 0));
+    if(!inducingFixed) {
+      gpcCheck(gpc_kern_gradx_f64(&ks, dXu, M, D, M, dGKuu, M, dGXa, M, 0));
+      gpcCheck(gpc_kern_gradx_cross_f64(&ks, dXu, M, M, dX, N, N, D, dGKuf, M, dGXb, M, 0));
+      gpcCheck(gpc_memcpy_d2h(&gxa[0], dGXa, sizeof(double) * gxa.size(), 0));
+      gpcCheck(gpc_memcpy_d2h(&gxb[0], dGXb, sizeof(double) * gxb.size(), 0));
+    }
+  } catch(...) {
+    devFree(dEET); devFree(dAinvEET); devFree(dAEA); devFree(dGKuu); devFree(dAinvKuf); devFree(dGKuf); devFree(dGXa); devFree(dGXb);
+    throw;
+  }
+  devFree(dEET); devFree(dAinvEET); devFree(dAEA); devFree(dGKuu); devFree(dAinvKuf); devFree(dGKuf); devFree(dGXa); devFree(dGXb);
+  // chain rule for the kernel parameters: each pass is transformed on its own in the reference; the sum is the same
+  for(unsigned int i = 0; i < nk; i++) t1[i] += t2[i];
+  for(unsigned int t = 0; t < pkern->getNumTransforms(); t++) {
+    const unsigned int idx = pkern->getTransformIndex(t);
+    t1[idx] *= pkern->getTransformGradFact(pkern->getParam(idx), t);
+  }
+  unsigned int counter = 0;
+  if(!inducingFixed)
+    for(int64_t j = 0; j < D; j++)
+      for(int64_t i = 0; i < M; i++) g.setVal(gxa[i + j * M] + gxb[i + j * M], 0, counter++);
+  for(unsigned int i = 0; i < nk; i++) g.setVal(t1[i], 0, counter++);
+  g.setVal(gb * beta, 0, counter++);   // gBeta * gradfact(beta), CGp.cpp:1071-1074
+}
+
+void CGp::posteriorDtc(CMatrix& mu, CMatrix& varSigma, const CMatrix& Xin) const
+{
+  // CGp.cpp:540-599 with the sparse branches: kX = k(X_u, X*), mu = kX' Alpha, var = k** - kX' (invK_uu - Ainv/beta) kX + 1/beta
+  updateAlpha();
+  const int64_t D = getInputDim(), d = getOutputDim(), M = numActive, Ns = Xin.getRows();
+  gpc_kspec ks;
+  pkern->toKspec(ks);
+  double *dXs = devAlloc((size_t)Ns * D), *dKx = devAlloc((size_t)M * Ns), *dW = devAlloc((size_t)M * M),
+         *dSt = devAlloc((size_t)M * Ns), *dMu = devAlloc((size_t)Ns * d), *dKss = devAlloc((size_t)Ns);
+  std::vector<double> hmu((size_t)Ns * d), kss((size_t)Ns), q((size_t)Ns);
+  try {
+    gpcCheck(gpc_memcpy_h2d(dXs, Xin.getVals(), sizeof(double) * (size_t)Ns * D, 0));
+    gpcCheck(gpc_gram_cross_f64(&ks, dXu, M, M, dXs, Ns, Ns, D, dKx, M, 0));
+    gpcCheck(gpc_gemm_f64('T', 'N', Ns, d, M, 1.0, dKx, M, dAlphaU, M, 0.0, dMu, Ns, 0));
+    gpcCheck(gpc_axpby_f64(M, M, 1.0, dInvKuu, M, 0.0, dW, M, 0));
+    gpcCheck(gpc_axpby_f64(M, M, -1.0 / betaVal, dAinv, M, 1.0, dW, M, 0));
+    gpcCheck(gpc_gemm_f64('N', 'N', M, Ns, M, 1.0, dW, M, dKx, M, 0.0, dSt, M, 0));
+    gpcCheck(gpc_coldot_f64(M, Ns, dKx, M, dSt, M, &q[0], 0));
+    gpcCheck(gpc_gram_diag_f64(&ks, dXs, Ns, D, Ns, dKss, 0));
+    gpcCheck(gpc_memcpy_d2h(&kss[0], dKss, sizeof(double) * kss.size(), 0));
+    gpcCheck(gpc_memcpy_d2h(&hmu[0], dMu, sizeof(double) * hmu.size(), 0));
+  } catch(...) {
+    devFree(dXs); devFree(dKx); devFree(dW); devFree(dSt); devFree(dMu); devFree(dKss);
+    throw;
+  }
+  devFree(dXs); devFree(dKx); devFree(dW); devFree(dSt); devFree(dMu); devFree(dKss);
+  for(int64_t i = 0; i < Ns; i++) {
+    double vs0 = kss[i] - q[i];
+    if(!(vs0 >= 0.0)) throw ndlexceptions::Error("posterior variance is negative");   // CHECKZEROORPOSITIVE, CGp.cpp:591
+    vs0 += 1.0 / betaVal;
+    for(int64_t j = 0; j < d; j++) {
+      double muv = hmu[i + j * Ns], vs = vs0;
+      const double sc = scale.getVal((unsigned int)j), bi = bias.getVal((unsigned int)j);
+      if(sc != 1.0) { muv *= sc; vs *= sc * sc; }
+      if(bi != 0.0) muv += bi;
+      mu.setVal(muv, (unsigned int)i, (unsigned int)j);
+      varSigma.setVal(vs, (unsigned int)i, (unsigned int)j);
+    }
+  }
+}
+
 void CGp::writeParamsToStream(std::ostream& out) const
 {
+  // CGp::writeParamsToStream, CGp.cpp:1656-1682
   out << "baseType=dataModel" << std::endl << "type=gp" << std::endl;
   out << "numData=" << getNumData() << std::endl << "outputDim=" << getOutputDim() << std::endl;
   out << "inputDim=" << getInputDim() << std::endl;
   out << "sparseApproximation=" << getApproximationType() << std::endl;
-  out << "numActive=" << 4294967295u << std::endl;   // (unsigned)-1 for FTC, as the reference writes it (gp.cpp:352)
+  if(isSparseApproximation()) out << "numActive=" << numActive << std::endl;
+  else out << "numActive=" << 4294967295u << std::endl;   // (unsigned)-1 for FTC, as the reference writes it (gp.cpp:352)
+  if(isSparseApproximation()) {
+    // the reference keeps beta as a numData x outputDim matrix of identical values (CGp.cpp:184-190) and writes it whole
+    CMatrix betaMat(getNumData(), getOutputDim(), betaVal);
+    out << "version=0.200000" << std::endl;
+    betaMat.writeParamsToStream(out);
+  }
   out << "learnScale=0" << std::endl << "learnBias=0" << std::endl;
   out << "version=0.200000" << std::endl;
   scale.writeParamsToStream(out);
@@ -318,6 +598,11 @@ void CGp::writeParamsToStream(std::ostream& out) const
   pkern->toStream(out);
   out << "version=0.200000" << std::endl;
   pnoise->writeParamsToStream(out);
+  if(isSparseApproximation()) {
+    out << "fixInducing=" << (inducingFixed ? 1 : 0) << std::endl;
+    out << "version=0.200000" << std::endl;
+    X_u.writeParamsToStream(out);
+  }
 }
 void CGp::readParamsFromStream(std::istream& in)
 {
@@ -330,8 +615,15 @@ void CGp::readParamsFromStream(std::istream& in)
   const unsigned int outDim = (unsigned int)ndlstream::readInt(in, "outputDim");
   fileInputDim = (unsigned int)ndlstream::readInt(in, "inputDim");
   const long approx = ndlstream::readInt(in, "sparseApproximation");
-  if(approx != FTC) throw ndlexceptions::NotImplementedError("sparse approximations (DTC/FITC/PITC/DTCVAR) are outside the accelerated FTC path");
+  if(approx != FTC && approx != DTC) throw ndlexceptions::NotImplementedError("of the sparse approximations only DTC runs on the accelerated path");
+  approxType = (int)approx;
   numActive = (unsigned int)std::strtoul(ndlstream::readField(in, "numActive").c_str(), 0, 10);
+  if(isSparseApproximation()) {
+    CMatrix betaMat;
+    betaMat.fromStream(in);
+    if(betaMat.getRows() < 1 || betaMat.getCols() < 1) throw ndlexceptions::StreamFormatError("beta", "empty matrix");
+    betaVal = betaMat.getVal(0, 0);
+  }
   if(ndlstream::readBool(in, "learnScale")) throw ndlexceptions::NotImplementedError("learnt output scales are outside the accelerated FTC path");
   (void)ndlstream::readBool(in, "learnBias");
   scale.fromStream(in);
@@ -347,6 +639,12 @@ void CGp::readParamsFromStream(std::istream& in)
   pkern = readKernFromStream(in);
   pnoise = readNoiseFromStream(in);
   if(pkern->getInputDim() != fileInputDim) throw ndlexceptions::StreamFormatError("inputDim", "kernel input dimension does not match the model's");
+  if(isSparseApproximation()) {
+    inducingFixed = ndlstream::readBool(in, "fixInducing");
+    X_u.fromStream(in);
+    if(X_u.getCols() != fileInputDim) throw ndlexceptions::StreamFormatError("inputDim", "X_u columns doesn't match input dimension.");
+    if(X_u.getRows() != numActive) throw ndlexceptions::StreamFormatError("numActive", "X_u rows do not match the number of active points");
+  }
   MupToDate = KupToDate = AlphaUpToDate = invKupToDate = false;
 }
 void CGp::fromStream(std::istream& in)

@@ -6,8 +6,11 @@
 // reference's four resident N x N matrices (CGp.cpp:171-174) this model keeps one (the factor, in K's storage) for
 // likelihood / prediction and three only while a gradient is being evaluated.
 //
-// Not provided: the sparse approximations (DTC, FITC, PITC, DTCVAR), GP-LVM (optimiseX) and learnt output scales;
-// asking for them throws ndlexceptions::NotImplementedError.
+// The sparse approximation DTC (CGp.cpp:713-776, 939-961, 1146-1316) is provided as well: numActive inducing inputs
+// X_u (a random subset of X, optimised unless setInducingFixed(true)), noise precision beta; everything of size
+// M x N (K_uf, its gradient) lives in HBM, M = numActive.
+// Not provided: FITC, PITC, DTCVAR, GP-LVM through CGp (optimiseX; see CGplvm) and learnt output scales; asking for
+// them throws ndlexceptions::NotImplementedError.
 #ifndef GPC_AMD_CGP_H
 #define GPC_AMD_CGP_H
 #include <iostream>
@@ -30,7 +33,12 @@ class CGp : public CProbabilisticOptimisable {
   void posteriorMeanVar(CMatrix& mu, CMatrix& varSigma, const CMatrix& X) const;   // CGp.cpp:642-663
 
   // COptimisable interface
-  unsigned int getOptNumParams() const { return pkern->getNumParams(); }
+  unsigned int getOptNumParams() const   // CGp.cpp:297-327
+  {
+    unsigned int tot = pkern->getNumParams();
+    if(isSparseApproximation()) tot += (inducingFixed ? 0 : numActive * getInputDim()) + 1;
+    return tot;
+  }
   void getOptParams(CMatrix& param) const;      // transformed kernel parameters, CGp.cpp:330-372
   void setOptParams(const CMatrix& param);      // marks K dirty, CGp.cpp:387-443
   double logLikelihood() const;                 // CGp.cpp:913-1014
@@ -45,16 +53,19 @@ class CGp : public CProbabilisticOptimisable {
   void setBias(const CMatrix& b) { bias.deepCopy(b); MupToDate = false; AlphaUpToDate = false; }
   double getScaleVal(unsigned int j) const { return scale.getVal(j); }
   double getBiasVal(unsigned int j) const { return bias.getVal(j); }
-  void setBetaVal(double) {}                    // irrelevant for FTC (gp.cpp:402)
+  void setBetaVal(double v) { betaVal = v; KupToDate = false; AlphaUpToDate = false; }   // noise precision (DTC)
+  double getBetaVal() const { return betaVal; }
+  void setInducingFixed(bool v) { inducingFixed = v; }
+  bool isInducingFixed() const { return inducingFixed; }
   void setOutputScaleLearnt(bool v)
   {
     if(v) throw ndlexceptions::NotImplementedError("learnt output scales are outside the accelerated FTC path");
   }
   bool isOutputScaleLearnt() const { return false; }
   bool isOutputBiasLearnt() const { return false; }
-  bool isSparseApproximation() const { return false; }
+  bool isSparseApproximation() const { return approxType != FTC; }
   bool isOptimiseX() const { return false; }
-  int getApproximationType() const { return FTC; }
+  int getApproximationType() const { return approxType; }
   unsigned int getNumData() const { return pX ? pX->getRows() : fileNumData; }
   unsigned int getInputDim() const { return pX ? pX->getCols() : fileInputDim; }
   unsigned int getOutputDim() const { return py ? py->getCols() : scale.getCols(); }
@@ -79,10 +90,21 @@ class CGp : public CProbabilisticOptimisable {
 
   CMatrix* pX;   // public in the reference as well (CGp.h:352-356)
   CMatrix* py;
+  CMatrix X_u;   // inducing inputs (numActive x inputDim), DTC
 
  private:
   void ensureDeviceInputs() const;
   void releaseGradientBuffers() const;
+  void updateKdtc() const;                       // CGp.cpp:713-735 + 896-909 + 751-776
+  double logLikelihoodDtc() const;               // CGp.cpp:939-961
+  void gradientDtc(CMatrix& g) const;            // CGp.cpp:1146-1190, 1252-1316
+  void posteriorDtc(CMatrix& mu, CMatrix& varSigma, const CMatrix& Xin) const;
+  int approxType;
+  double betaVal;
+  bool inducingFixed;
+  mutable double *dXu, *dKuu, *dKuf, *dInvKuu, *dA, *dAinv, *dLA, *dE, *dAlphaU;
+  mutable double logDetKuu, logDetA;
+  mutable bool LArounded;
   CKern* pkern;
   CNoise* pnoise;
   bool ownsKernNoise;

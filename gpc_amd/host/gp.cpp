@@ -27,7 +27,7 @@ void CClgp::helpInfo()
   std::cout << "gp [-v verbosity] [-s seed] relearn [-# iterations] trainData.svml [modelFile] [newModelFile]\n"
                "gp display [modelFile]\n"
                "gp [-v verbosity] [-s seed] learn [-k kernel [-g gamma] [-v variance] [-i 0|1]]... [-C 0|1] [-S 0|1]\n"
-               "   [-# iterations] [-O scg] [-A ftc] trainData.svml [modelFile]\n"
+               "   [-# iterations] [-O scg] [-A ftc|dtc [-a activeSetSize]] trainData.svml [modelFile]\n"
                "kernels: rbf (with -i 1: rbfard), lin, bias, white.  bias and white terms are always appended.\n";
 }
 
@@ -40,14 +40,14 @@ void CClgp::learn()
   std::vector<double> rbfInvWidths, variances;
   std::vector<bool> selectInputs;
   bool centreData = true, scaleData = false, outputScaleLearnt = false;
-  int iters = 1000;
+  int iters = 1000, activeSetSize = -1, approxType = CGp::FTC;
   while(isFlags()) {
     if(isCurrentArgumentFlag()) {
       if(isCurrentArg("-?", "--?") || isCurrentArg("-h", "--help")) { helpInfo(); exitNormal(); }
       else if(isCurrentArg("-C", "--Centre-data")) { incrementArgument(); centreData = getBoolFromCurrentArgument(); }
       else if(isCurrentArg("-L", "--Learn-scales")) { incrementArgument(); outputScaleLearnt = getBoolFromCurrentArgument(); }
       else if(isCurrentArg("-S", "--Scale-data")) { incrementArgument(); scaleData = getBoolFromCurrentArgument(); }
-      else if(isCurrentArg("-a", "--active-set-size")) { incrementArgument(); }
+      else if(isCurrentArg("-a", "--active-set-size")) { incrementArgument(); activeSetSize = getIntFromCurrentArgument(); }
       else if(isCurrentArg("-A", "--Approximation-type")) { incrementArgument(); approxTypeStr = getCurrentArgument(); }
       else if(isCurrentArg("-k", "--kernel")) {
         incrementArgument();
@@ -84,7 +84,15 @@ void CClgp::learn()
   if(getCurrentArgumentNo() >= argc) exitError("There are not enough input parameters.");
   const std::string trainDataFileName = getCurrentArgument();
   if(getCurrentArgumentNo() + 1 < argc) modelFileName = argv[getCurrentArgumentNo() + 1];
-  if(approxTypeStr != "ftc") exitError("Only the full (ftc) model runs on the accelerated path: " + approxTypeStr + ".");
+  if(approxTypeStr == "ftc") {   // gp.cpp:351-377
+    approxType = CGp::FTC;
+    activeSetSize = -1;
+  } else if(approxTypeStr == "dtc") {
+    approxType = CGp::DTC;
+    if(activeSetSize == -1) exitError("You must choose an active set size (option -a) for the command learn.");
+  } else {
+    exitError("Of the sparse approximations only dtc runs on the accelerated path: " + approxTypeStr + ".");
+  }
   if(optimiser != "scg") exitError("Unrecognised optimiser type: " + optimiser + " (scg is the one provided).");
 
   CMatrix X, y;
@@ -131,7 +139,7 @@ void CClgp::learn()
   if(centreData) bias.deepCopy(meanCol(y));
   if(scaleData) scale.deepCopy(stdCol(y));
 
-  CGp model(&kern, &noise, &X, CGp::FTC, (unsigned int)-1, getVerbosity());
+  CGp model(&kern, &noise, &X, approxType, (unsigned int)activeSetSize, getVerbosity());
   model.setDefaultOptimiser(CGp::SCG);
   model.setBetaVal(1);
   model.setScale(scale);

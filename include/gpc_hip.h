@@ -150,6 +150,11 @@ int gpc_syrk_blockcyclic_f64(int64_t M, int64_t ncols, int64_t K, double alpha, 
                              double beta, double* C, int64_t ldc, int64_t row0, int64_t j0, int64_t pstride,
                              int64_t nb, void* stream);
 
+/* Y := alpha*X + beta*Y elementwise, M x N (CMatrix::axpy / scale / deepCopy: daxpy_, dscal_, dcopy_, lapack.h:78-111).
+ * alpha == 0 ignores X's contents, beta == 0 ignores Y's (no NaN propagation from uninitialised storage). */
+int gpc_axpby_f64(int64_t M, int64_t N, double alpha, const double* X, int64_t ldx, double beta, double* Y, int64_t ldy,
+                  void* stream);
+
 /* ---- vectors / reductions used by CGp's FTC branches ------------------------------------------------------------ */
 /* out[j] = sum_i A(i,j)*B(i,j), j < ncols (ddot per column: CGp.cpp:553-559, 928-930).  out is host. */
 int gpc_coldot_f64(int64_t M, int64_t ncols, const double* A, int64_t lda, const double* B, int64_t ldb,

@@ -226,6 +226,37 @@ def dtc_golden():
     save("gp_dtc", **out)
 
 
+def sinc_dtc_golden():
+    """`gp -s 3 learn -A dtc -a 10 sinc.svml` of the compiled reference: the inducing inputs its seeded Mersenne twister
+    picks (-# 0: nothing optimised yet) and the state after 40 SCG iterations."""
+    import re
+    import subprocess
+    import tempfile
+    ref_gp = os.path.join(ROOT, "oracle", "_ref", "gp")
+    svml = os.path.join(OUT, "sinc.svml")
+    env = dict(os.environ, LD_PRELOAD=refrun.MKL)
+
+    def numbers(path):
+        rows = [ln.split() for ln in open(path) if (ln.startswith("0x") or re.match(r"^-?(\d|0x)", ln)) and "=" not in ln]
+        return [[float.fromhex(t) if "x" in t else float(t) for t in row] for row in rows]
+
+    with tempfile.TemporaryDirectory() as td:
+        for iters, name in ((0, "m0"), (40, "m40")):
+            r = subprocess.run([ref_gp, "-v", "3", "-s", "3", "learn", "-A", "dtc", "-a", "10", "-#", str(iters), svml, name],
+                               env=env, stdin=subprocess.DEVNULL, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, check=True,
+                               cwd=td)
+            if iters:
+                log = r.stdout.decode()
+        n0, n40 = numbers(os.path.join(td, "m0")), numbers(os.path.join(td, "m40"))
+        ll = float(re.findall(r"^Log likelihood: (\S+)$", log, flags=re.M)[-1])
+        its = len(re.findall(r"^Iteration: ", log, flags=re.M))
+    # rows: 40 beta rows (N x 1), scale, bias, rbf(2), bias kern, white kern, noise(2), then the 10 rows of X_u
+    Xu0 = np.array([r[0] for r in n0[-10:]])
+    Xu40 = np.array([r[0] for r in n40[-10:]])
+    kern40 = np.array(n40[42] + n40[43] + n40[44])
+    save("sinc_dtc", Xu0=Xu0, Xu40=Xu40, kern40=kern40, beta40=n40[0][0], ll40_printed=ll, n_iters=its)
+
+
 def read_svml(path, nrows=None):
     """SVMlight rows `label idx:val ...` -> (Y dense, labels); missing features are 0 (CClctrl.cpp:57-180)."""
     rows, labs = [], []
@@ -294,3 +325,4 @@ if __name__ == "__main__":
         model_golden()
     if what in ("all", "dtc"):
         dtc_golden()
+        sinc_dtc_golden()

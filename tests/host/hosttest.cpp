@@ -166,11 +166,54 @@ static int testGp(int argc, char** argv)
   return 0;
 }
 
+// sparse approximation DTC: gp_hosttest dtc X y Xs kernspec Xu beta [iters]
+static int testDtc(int argc, char** argv)
+{
+  if(argc < 8) { std::fprintf(stderr, "usage: gp_hosttest dtc X y Xs kernspec Xu beta [iters]\n"); return 2; }
+  CMatrix X, y, Xs, Xu;
+  X.fromUnheadedFile(argv[2]);
+  y.fromUnheadedFile(argv[3]);
+  Xs.fromUnheadedFile(argv[4]);
+  Xu.fromUnheadedFile(argv[6]);
+  CCmpndKern kern(X);
+  buildKern(kern, X, argv[5]);
+  CGaussianNoise noise(&y);
+  noise.setBias(0.0);
+  CMatrix scale(1, y.getCols(), 1.0), bias(1, y.getCols(), 0.0);
+  bias.deepCopy(meanCol(y));
+  CGp model(&kern, &noise, &X, CGp::DTC, Xu.getRows(), 0);
+  model.setBetaVal(std::atof(argv[7]));
+  model.setScale(scale);
+  model.setBias(bias);
+  model.updateM();
+  model.X_u.deepCopy(Xu);
+  CMatrix g(1, model.getOptNumParams()), params(1, model.getOptNumParams());
+  model.getOptParams(params);
+  model.setOptParams(params);   // marks K dirty with the given inducing inputs
+  const double ll = model.logLikelihoodGradient(g);
+  std::printf("ll %.17g\n", ll);
+  printMat("grads", g);
+  printMat("opt_params", params);
+  CMatrix mu(Xs.getRows(), y.getCols()), var(Xs.getRows(), y.getCols());
+  model.posteriorMeanVar(mu, var, Xs);
+  printMat("mu", mu);
+  printMat("var", var);
+  if(argc > 8 && std::atoi(argv[8]) > 0) {
+    model.setDefaultOptimiser(CGp::SCG);
+    model.optimise(std::atoi(argv[8]));
+    model.getOptParams(params);
+    printMat("params_final", params);
+    std::printf("ll_final %.17g\n", model.logLikelihood());
+  }
+  return 0;
+}
+
 int main(int argc, char** argv)
 {
   try {
     if(argc >= 2 && std::string(argv[1]) == "matrix") return testMatrix();
     if(argc >= 2 && std::string(argv[1]) == "gp") return testGp(argc, argv);
+    if(argc >= 2 && std::string(argv[1]) == "dtc") return testDtc(argc, argv);
     std::fprintf(stderr, "usage: gp_hosttest matrix | gp ...\n");
     return 2;
   } catch(ndlexceptions::Error& e) {
