@@ -6,7 +6,8 @@
  *
  * Parity status: PINNED -- checked (tests/test_oracle_golden.py) against the reference's own fixtures
  * (rbf/rbfard/white/bias/lin KernTest.mat, choleskyMatrixTest.mat, trsmMatrixTest.mat, testGpftc.mat) and against
- * outputs of the unmodified reference compiled here (oracle/_ref, golden vectors under tests/golden/).
+ * outputs of the unmodified reference compiled here (oracle/_ref, golden vectors under tests/golden/); the GP-LVM and
+ * DTC restatements against the compiled reference's CGplvm / CGp(DTC) (tests/test_gplvm.py, tests/test_dtc.py).
  *
  * Every function cites the reference code it follows (file:line under /root/reference).  The arithmetic below
  * lapack.h lives in a third-party, un-vendored, unpinned BLAS/LAPACK (make.linux:8 `-llapack -lblas`; MKL 2021.4
