@@ -32,13 +32,13 @@ CGp::CGp(CKern* kernel, CNoise* nois, CMatrix* Xin, int approx, unsigned int act
       bias(1, nois->getOutputDim(), 0.0), refTransRounding(true), MupToDate(false), KupToDate(false),
       AlphaUpToDate(false), invKupToDate(false), LcholRounded(false), dX(0), dM(0), dL(0), dInvKm(0), dAlpha(0), dInvK(0),
       dCovGrad(0), logDetK(0.0), lastJitter(0.0), needInverse(false), approxType(approx), betaVal(1e3),
-      inducingFixed(false), dXu(0), dKuu(0), dKuf(0), dInvKuu(0), dA(0), dAinv(0), dLA(0), dE(0), dAlphaU(0),
-      logDetKuu(0.0), logDetA(0.0), LArounded(false)
+      inducingFixed(false), dXu(0), dKuu(0), dKuf(0), dInvKuu(0), dA(0), dAinv(0), dLA(0), dE(0), dAlphaU(0), dIKK(0),
+      logDetKuu(0.0), logDetA(0.0), sumDiagD(0.0), LArounded(false)
 {
   if(Xin->getRows() != nois->getNumData())
     throw ndlexceptions::MatrixError("CGp: X and the targets disagree on the number of data");   // CGp.cpp:60
-  if(approxType != FTC && approxType != DTC)
-    throw ndlexceptions::NotImplementedError("of the sparse approximations only DTC runs on the accelerated path (FITC/PITC/DTCVAR do not)");
+  if(approxType != FTC && approxType != DTC && approxType != DTCVAR)
+    throw ndlexceptions::NotImplementedError("of the sparse approximations DTC and DTCVAR run on the accelerated path (FITC/PITC do not)");
   setVerbosity(verbos);
   const char* e = std::getenv("GPC_EXACT_TRANS");
   if(e && e[0] == '1') refTransRounding = false;
@@ -57,7 +57,7 @@ CGp::CGp()
       bias(1, 1, 0.0), refTransRounding(true), MupToDate(false), KupToDate(false), AlphaUpToDate(false),
       invKupToDate(false), LcholRounded(false), dX(0), dM(0), dL(0), dInvKm(0), dAlpha(0), dInvK(0), dCovGrad(0), logDetK(0.0), lastJitter(0.0),
       needInverse(false), approxType(FTC), betaVal(1e3), inducingFixed(false), dXu(0), dKuu(0), dKuf(0), dInvKuu(0), dA(0),
-      dAinv(0), dLA(0), dE(0), dAlphaU(0), logDetKuu(0.0), logDetA(0.0), LArounded(false)
+      dAinv(0), dLA(0), dE(0), dAlphaU(0), dIKK(0), logDetKuu(0.0), logDetA(0.0), sumDiagD(0.0), LArounded(false)
 {
   const char* e = std::getenv("GPC_EXACT_TRANS");
   if(e && e[0] == '1') refTransRounding = false;
@@ -78,6 +78,7 @@ void CGp::setData(CMatrix* Xin, CMatrix* yin)
   devFree(dCovGrad);
   devFree(dKuf);
   devFree(dE);
+  devFree(dIKK);
   MupToDate = KupToDate = AlphaUpToDate = invKupToDate = false;
 }
 CGp::~CGp()
@@ -102,6 +103,7 @@ CGp::~CGp()
   devFree(dLA);
   devFree(dE);
   devFree(dAlphaU);
+  devFree(dIKK);
 }
 
 void CGp::updateM() const
@@ -426,6 +428,24 @@ void CGp::updateKdtc() const
   gpcCheck(gpc_memcpy_d2d(dAinv, dLA, sizeof(double) * (size_t)M * M, 0));
   gpcCheck(gpc_potri_f64('L', M, dAinv, M, 0));
   LArounded = false;
+  if(approxType == DTCVAR) {
+    // CGp.cpp:766-774: V = (invK_uu K_uf) .* K_uf, diagD = beta (diagK - column sums of V); only its sum is ever used
+    if(!dIKK) dIKK = devAlloc((size_t)M * N);
+    gpcCheck(gpc_gemm_f64('N', 'N', M, N, M, 1.0, dInvKuu, M, dKuf, M, 0.0, dIKK, M, 0));
+    std::vector<double> cs((size_t)N), dk((size_t)N);
+    gpcCheck(gpc_coldot_f64(M, N, dIKK, M, dKuf, M, &cs[0], 0));
+    double* dDiag = devAlloc((size_t)N);
+    try {
+      gpcCheck(gpc_gram_diag_f64(&ks, dX, N, D, N, dDiag, 0));
+      gpcCheck(gpc_memcpy_d2h(&dk[0], dDiag, sizeof(double) * dk.size(), 0));
+    } catch(...) {
+      devFree(dDiag);
+      throw;
+    }
+    devFree(dDiag);
+    sumDiagD = 0.0;
+    for(int64_t n = 0; n < N; n++) sumDiagD += betaVal * (dk[n] - cs[n]);
+  }
   // E = K_uf m (used by the likelihood, Alpha and the gradient)
   gpcCheck(gpc_gemm_f64('N', 'N', M, d, N, 1.0, dKuf, M, dM, N, 0.0, dE, M, 0));
   KupToDate = true;
@@ -450,6 +470,7 @@ double CGp::logLikelihoodDtc() const
   // CGp.cpp:939-961
   double L = (double)d * (((double)M - (double)N) * std::log(betaVal) - logDetKuu + logDetA);
   for(int64_t j = 0; j < d; j++) L -= betaVal * (eAe[j] - mm[j]);
+  if(approxType == DTCVAR) L += (double)d * sumDiagD;   // CGp.cpp:955-956
   L *= -0.5;
   L += pkern->priorLogProb();
   L -= (double)d * (double)N * HALFLOGTWOPI;
@@ -480,6 +501,8 @@ void CGp::gradientDtc(CMatrix& g) const
     gpcCheck(gpc_axpby_f64(M, M, 0.5 * dd, dInvKuu, M, 0.0, dGKuu, M, 0));
     gpcCheck(gpc_axpby_f64(M, M, -0.5 * dd / beta, dAinv, M, 1.0, dGKuu, M, 0));
     gpcCheck(gpc_axpby_f64(M, M, -0.5, dAEA, M, 1.0, dGKuu, M, 0));
+    if(approxType == DTCVAR)   // gK_uu.syrk(invK_uuK_uf, -beta d, 1.0) before the 0.5 (CGp.cpp:1275-1279)
+      gpcCheck(gpc_gemm_f64('N', 'T', M, M, N, -0.5 * beta * dd, dIKK, M, dIKK, M, 1.0, dGKuu, M, 0));
     // gK_uf = -beta * (AinvEET * AinvK_uf - Ainv * E m') - d * AinvK_uf, with Ainv * (E m') = (Ainv E) m'
     gpcCheck(gpc_gemm_f64('N', 'N', M, N, M, 1.0, dAinv, M, dKuf, M, 0.0, dAinvKuf, M, 0));
     double* dAinvE = dEET;   // EET is no longer needed: reuse its storage (M x d <= M x M when d <= M)
@@ -489,6 +512,7 @@ void CGp::gradientDtc(CMatrix& g) const
     gpcCheck(gpc_gemm_f64('N', 'T', M, N, d, beta, dAinvE, M, dM, N, 0.0, dGKuf, M, 0));             //  beta * AinvEMT
     gpcCheck(gpc_gemm_f64('N', 'N', M, N, M, -beta, dAinvEET, M, dAinvKuf, M, 1.0, dGKuf, M, 0));    // -beta * AinvEET AinvK_uf
     gpcCheck(gpc_axpby_f64(M, N, -dd, dAinvKuf, M, 1.0, dGKuf, M, 0));
+    if(approxType == DTCVAR) gpcCheck(gpc_axpby_f64(M, N, beta * dd, dIKK, M, 1.0, dGKuf, M, 0));   // CGp.cpp:1292-1295
     if(ownAinvE) devFree(dAinvE);
     // d/d beta
     double trAK = 0.0, trAEAK = 0.0, trAinvEET = 0.0;
@@ -505,6 +529,7 @@ void CGp::gradientDtc(CMatrix& g) const
     gb += trAEAK / beta;
     for(int64_t j = 0; j < d; j++) gb -= mm[j];
     gb += trAinvEET;
+    if(approxType == DTCVAR) gb -= dd * sumDiagD / beta;   // CGp.cpp:1309-1312
     gb *= 0.5;
     // kernel parameters (CGp.cpp:1149-1158) and inducing inputs (1160-1176)
     gpcCheck(gpc_kern_grad_f64(&ks, dXu, M, D, M, dGKuu, M, &t1[0], 0));
@@ -522,6 +547,26 @@ void CGp::gradientDtc(CMatrix& g) const
   devFree(dEET); devFree(dAinvEET); devFree(dAEA); devFree(dGKuu); devFree(dAinvKuf); devFree(dGKuf); devFree(dGXa); devFree(dGXb);
   // chain rule for the kernel parameters: each pass is transformed on its own in the reference; the sum is the same
   for(unsigned int i = 0; i < nk; i++) t1[i] += t2[i];
+  if(approxType == DTCVAR) {
+    // the diagonal term: gLambda = -0.5 d beta for every point (CGp.cpp:1314-1317) against dk(x_i,x_i)/dtheta
+    // (CKern::getDiagGradParams, CKern.h:198-213): variance-type parameters get N gLambda, lin gets gLambda sum |x_i|^2
+    const double gl = -0.5 * dd * beta;
+    std::vector<double> xx((size_t)D);
+    gpcCheck(gpc_coldot_f64(N, D, dX, N, dX, N, &xx[0], 0));
+    double sumx2 = 0.0;
+    for(int64_t q = 0; q < D; q++) sumx2 += xx[q];
+    for(int t = 0; t < ks.n_terms; t++) {
+      const int off = ks.offs[t];
+      switch(ks.types[t]) {
+      case GPC_KERN_RBF:
+      case GPC_KERN_RBFARD: t1[off + 1] += (double)N * gl; break;
+      case GPC_KERN_WHITE:
+      case GPC_KERN_BIAS: t1[off] += (double)N * gl; break;
+      case GPC_KERN_LIN: t1[off] += gl * sumx2; break;
+      default: break;
+      }
+    }
+  }
   for(unsigned int t = 0; t < pkern->getNumTransforms(); t++) {
     const unsigned int idx = pkern->getTransformIndex(t);
     t1[idx] *= pkern->getTransformGradFact(pkern->getParam(idx), t);
@@ -615,7 +660,8 @@ void CGp::readParamsFromStream(std::istream& in)
   const unsigned int outDim = (unsigned int)ndlstream::readInt(in, "outputDim");
   fileInputDim = (unsigned int)ndlstream::readInt(in, "inputDim");
   const long approx = ndlstream::readInt(in, "sparseApproximation");
-  if(approx != FTC && approx != DTC) throw ndlexceptions::NotImplementedError("of the sparse approximations only DTC runs on the accelerated path");
+  if(approx != FTC && approx != DTC && approx != DTCVAR)
+    throw ndlexceptions::NotImplementedError("of the sparse approximations DTC and DTCVAR run on the accelerated path");
   approxType = (int)approx;
   numActive = (unsigned int)std::strtoul(ndlstream::readField(in, "numActive").c_str(), 0, 10);
   if(isSparseApproximation()) {

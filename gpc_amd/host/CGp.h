@@ -6,10 +6,10 @@
 // reference's four resident N x N matrices (CGp.cpp:171-174) this model keeps one (the factor, in K's storage) for
 // likelihood / prediction and three only while a gradient is being evaluated.
 //
-// The sparse approximation DTC (CGp.cpp:713-776, 939-961, 1146-1316) is provided as well: numActive inducing inputs
+// The sparse approximations DTC and DTCVAR (CGp.cpp:713-776, 939-961, 1146-1316) are provided as well: numActive inducing inputs
 // X_u (a random subset of X, optimised unless setInducingFixed(true)), noise precision beta; everything of size
 // M x N (K_uf, its gradient) lives in HBM, M = numActive.
-// Not provided: FITC, PITC, DTCVAR, GP-LVM through CGp (optimiseX; see CGplvm) and learnt output scales; asking for
+// Not provided: FITC, PITC, GP-LVM through CGp (optimiseX; see CGplvm) and learnt output scales; asking for
 // them throws ndlexceptions::NotImplementedError.
 #ifndef GPC_AMD_CGP_H
 #define GPC_AMD_CGP_H
@@ -103,7 +103,8 @@ class CGp : public CProbabilisticOptimisable {
   double betaVal;
   bool inducingFixed;
   mutable double *dXu, *dKuu, *dKuf, *dInvKuu, *dA, *dAinv, *dLA, *dE, *dAlphaU;
-  mutable double logDetKuu, logDetA;
+  mutable double* dIKK;        // invK_uu * K_uf (M x N), DTCVAR only
+  mutable double logDetKuu, logDetA, sumDiagD;
   mutable bool LArounded;
   CKern* pkern;
   CNoise* pnoise;

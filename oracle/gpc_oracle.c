@@ -946,7 +946,8 @@ static void mm(int ta, int tb, long M, long N, long K, double alpha, const doubl
  *   alpha (may be NULL) M x d;  Xs (may be NULL) Ns x D -> mu Ns x d, var Ns.
  * Returns the log-likelihood; *info != 0 if a Cholesky failed even with jitter. */
 double orc_gp_dtc(const orc_kspec* ks, const double* X, long N, long D, const double* m, long d, const double* Xu, long M,
-                  double beta, double* g, double* alpha, const double* Xs, long Ns, double* mu, double* var, int* info)
+                  double beta, int dtcvar, double* g, double* alpha, const double* Xs, long Ns, double* mu, double* var,
+                  int* info)
 {
   const int nk = ks->offs[ks->n_terms];
   const size_t MM = (size_t)M * M, MN = (size_t)M * N;
@@ -959,7 +960,8 @@ double orc_gp_dtc(const orc_kspec* ks, const double* X, long N, long D, const do
   double* Ainv = (double*)malloc(sizeof(double) * MM);
   double* e = (double*)malloc(sizeof(double) * M);
   double* invAe = (double*)malloc(sizeof(double) * M);
-  double logDetKuu, logDetA, L = 0.0;
+  double logDetKuu, logDetA, L = 0.0, sumDiagD = 0.0;
+  double* iKK = NULL;   /* invK_uu K_uf (DTCVAR) */
   long i, j, k, n;
   *info = 0;
   orc_gram_sym(ks, Xu, M, D, Kuu);                                   /* K_uu */
@@ -976,12 +978,23 @@ double orc_gp_dtc(const orc_kspec* ks, const double* X, long N, long D, const do
   logDetA = orc_logdet(M, LA, M);
   orc_pdinv_upper(M, LA, Ainv);
   orc_trans(M, LA);                                                  /* LcholA.trans(): lower (fp32 quirk included) */
+  if(dtcvar) {
+    /* DTCVAR, CGp.cpp:766-774: V = (invK_uu K_uf) .* K_uf; diagD = beta (diagK - column sums of V) */
+    iKK = (double*)malloc(sizeof(double) * MN);
+    mm(0, 0, M, N, M, 1.0, invKuu, M, Kuf, M, 0.0, iKK, M);
+    for(n = 0; n < N; n++) {
+      double cs = 0.0;
+      for(i = 0; i < M; i++) cs += iKK[i + (size_t)n * M] * Kuf[i + (size_t)n * M];
+      sumDiagD += beta * (orc_kern_diag_element(ks, X, N, n, D) - cs);
+    }
+  }
   L += (double)d * (((double)M - (double)N) * log(beta) - logDetKuu + logDetA);
   for(j = 0; j < d; j++) {
     mm(0, 0, M, 1, N, 1.0, Kuf, M, m + (size_t)j * N, N, 0.0, e, M);
     orc_symv_upper(M, Ainv, e, invAe);                               /* Ainv is fully symmetric */
     L -= beta * (dot(M, invAe, 1, e, 1) - dot(N, m + (size_t)j * N, 1, m + (size_t)j * N, 1));
   }
+  if(dtcvar) L += (double)d * sumDiagD;                               /* CGp.cpp:955-956 */
   L *= -0.5;
   L -= (double)d * (double)N * HALFLOGTWOPI;
   if(alpha) {                                                        /* updateAlpha */
@@ -1024,12 +1037,16 @@ double orc_gp_dtc(const orc_kspec* ks, const double* X, long N, long D, const do
     mm(0, 1, M, M, d, 1.0, E, M, E, M, 0.0, EET, M);
     mm(0, 0, M, M, M, 1.0, Ainv, M, EET, M, 0.0, AinvEET, M);
     mm(0, 0, M, M, M, 1.0, AinvEET, M, Ainv, M, 0.0, AEA, M);
-    for(k = 0; k < (long)MM; k++) gKuu[k] = 0.5 * ((double)d * (invKuu[k] - Ainv[k] / beta) - AEA[k]);
+    for(k = 0; k < (long)MM; k++) gKuu[k] = (double)d * (invKuu[k] - Ainv[k] / beta) - AEA[k];
+    if(dtcvar) mm(0, 1, M, M, N, -beta * (double)d, iKK, M, iKK, M, 1.0, gKuu, M);   /* syrk, CGp.cpp:1275-1279 */
+    for(k = 0; k < (long)MM; k++) gKuu[k] *= 0.5;
     mm(0, 0, M, N, M, 1.0, Ainv, M, Kuf, M, 0.0, AinvKuf, M);
     mm(0, 1, M, N, d, 1.0, E, M, m, N, 0.0, EMT, M);
     mm(0, 0, M, N, M, 1.0, Ainv, M, EMT, M, 0.0, AinvEMT, M);
     mm(0, 0, M, N, M, 1.0, AinvEET, M, AinvKuf, M, 0.0, gKuf, M);
     for(k = 0; k < (long)MN; k++) gKuf[k] = -(beta * (gKuf[k] - AinvEMT[k])) - (double)d * AinvKuf[k];
+    if(dtcvar)
+      for(k = 0; k < (long)MN; k++) gKuf[k] += beta * (double)d * iKK[k];                /* CGp.cpp:1292-1295 */
     gb = (double)(N - M) / beta;
     tmp = 0.0;
     for(k = 0; k < (long)MM; k++) tmp += Ainv[k] * Kuu[k];
@@ -1040,12 +1057,30 @@ double orc_gp_dtc(const orc_kspec* ks, const double* X, long N, long D, const do
     gb += tmp / beta;
     for(j = 0; j < d; j++) gb -= dot(N, m + (size_t)j * N, 1, m + (size_t)j * N, 1);
     for(i = 0; i < M; i++) gb += AinvEET[i + i * M];
+    if(dtcvar) gb -= (double)d * sumDiagD / beta;                                          /* CGp.cpp:1309-1312 */
     gb *= 0.5;
     /* kernel parameters: symmetric pass on X_u against gK_uu + cross pass (X_u, X) against gK_uf, each transformed */
     orc_kern_grad_sym(ks, Xu, M, D, gKuu, t1);
     orc_grad_to_trans(ks, D, t1);
     orc_kern_grad_cross(ks, Xu, M, X, N, D, gKuf, t2);
     orc_grad_to_trans(ks, D, t2);
+    if(dtcvar) {
+      /* the diagonal term's effect on the kernel parameters: gLambda = -0.5 d beta for every point (CGp.cpp:1314-1317),
+       * CKern::getDiagGradParams (CKern.h:198-213) = getGradParams on each single point, summed; then transformed */
+      double* t3 = (double*)malloc(sizeof(double) * (nk > 0 ? nk : 1));
+      double* t4 = (double*)malloc(sizeof(double) * (nk > 0 ? nk : 1));
+      double* xi = (double*)malloc(sizeof(double) * (D > 0 ? D : 1));
+      const double gl = -0.5 * (double)d * beta;
+      for(k = 0; k < nk; k++) t3[k] = 0.0;
+      for(i = 0; i < N; i++) {
+        for(j = 0; j < D; j++) xi[j] = X[i + j * N];
+        orc_kern_grad_sym(ks, xi, 1, D, &gl, t4);
+        for(k = 0; k < nk; k++) t3[k] += t4[k];
+      }
+      orc_grad_to_trans(ks, D, t3);
+      for(k = 0; k < nk; k++) t2[k] += t3[k];
+      free(t3); free(t4); free(xi);
+    }
     /* d/dX_u (CGp.cpp:1160-1182) */
     orc_kern_diag_gradx(ks, Xu, M, D, dg);
     for(i = 0; i < M; i++) {
@@ -1065,6 +1100,7 @@ double orc_gp_dtc(const orc_kspec* ks, const double* X, long N, long D, const do
     free(t1); free(t2); free(gKX); free(gKXuf); free(dg);
   }
 done:
+  free(iKK);
   free(Kuu); free(Kuf); free(U); free(invKuu); free(A); free(LA); free(Ainv); free(e); free(invAe);
   return L;
 }

@@ -99,5 +99,6 @@ double orc_gplvm_loglik_grad(const orc_kspec* ks, const double* m, long N, long 
 void orc_kern_gradx_row2(const orc_kspec* ks, const double* X, long ldx, long row, const double* X2, long N2, long D,
                          double* gX);
 double orc_gp_dtc(const orc_kspec* ks, const double* X, long N, long D, const double* m, long d, const double* Xu, long M,
-                  double beta, double* g, double* alpha, const double* Xs, long Ns, double* mu, double* var, int* info);
+                  double beta, int dtcvar, double* g, double* alpha, const double* Xs, long Ns, double* mu, double* var,
+                  int* info);   /* dtcvar != 0: the DTCVAR variant (extra diagonal terms, CGp.cpp:766-774, 955, 1275-1317) */
 #endif

@@ -237,7 +237,7 @@ static int run_gplvm(const gpcb_file* in, const char* out)
 static int run_dtc(const gpcb_file* in, const char* out)
 {
   const gpcb_array *X = gpcb_need(in, "X"), *y = gpcb_need(in, "y"), *Xu = gpcb_need(in, "X_u"),
-                   *xs = gpcb_find(in, "Xstar"), *ex = gpcb_find(in, "exact_trans");
+                   *xs = gpcb_find(in, "Xstar"), *ex = gpcb_find(in, "exact_trans"), *ap = gpcb_find(in, "approx");
   const double beta = gpcb_need(in, "beta")->data[0];
   const long N = X->rows, D = X->cols, d = y->cols, M = Xu->rows, Ns = xs ? xs->rows : 0;
   orc_kspec ks;
@@ -263,7 +263,8 @@ static int run_dtc(const gpcb_file* in, const char* out)
     mu = malloc(sizeof(double) * Ns * d);
     var = malloc(sizeof(double) * Ns);
   }
-  ll = orc_gp_dtc(&ks, X->data, N, D, m, d, Xu->data, M, beta, g, alpha, xs ? xs->data : 0, Ns, mu, var, &info);
+  ll = orc_gp_dtc(&ks, X->data, N, D, m, d, Xu->data, M, beta, (ap && ap->data[0] == 4.0) ? 1 : 0, g, alpha,
+                  xs ? xs->data : 0, Ns, mu, var, &info);
   for(j = 0; j < d && Ns; j++)   /* _posteriorMean adds the output bias (CGp.cpp:566-573) */
     for(i = 0; i < Ns; i++) mu[i + j * Ns] += means[j];
   infod = (double)info;

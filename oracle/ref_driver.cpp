@@ -243,6 +243,8 @@ static int runDtc(const gpcb_file& in, const char* outPath)
   const double beta = gpcb_need(&in, "beta")->data[0];
   const gpcb_array* xs = gpcb_find(&in, "Xstar");
   const gpcb_array* it = gpcb_find(&in, "iters");
+  const gpcb_array* ap = gpcb_find(&in, "approx");   // 1 = DTC (default), 4 = DTCVAR (the enum of CGp.h:12-19)
+  const int approx = ap ? (int)ap->data[0] : (int)CGp::DTC;
   CCmpndKern kern(X);
   buildKern(kern, X, in);
   CGaussianNoise noise(&y);
@@ -250,7 +252,7 @@ static int runDtc(const gpcb_file& in, const char* outPath)
   CMatrix scale(1, y.getCols(), 1.0);
   CMatrix bias(1, y.getCols(), 0.0);
   bias.deepCopy(meanCol(y));
-  CGp model(&kern, &noise, &X, CGp::DTC, Xu.getRows(), 0);
+  CGp model(&kern, &noise, &X, approx, Xu.getRows(), 0);
   model.setBetaVal(beta);
   model.setScale(scale);
   model.setBias(bias);

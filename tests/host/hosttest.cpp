@@ -169,7 +169,8 @@ static int testGp(int argc, char** argv)
 // sparse approximation DTC: gp_hosttest dtc X y Xs kernspec Xu beta [iters]
 static int testDtc(int argc, char** argv)
 {
-  if(argc < 8) { std::fprintf(stderr, "usage: gp_hosttest dtc X y Xs kernspec Xu beta [iters]\n"); return 2; }
+  if(argc < 8) { std::fprintf(stderr, "usage: gp_hosttest dtc X y Xs kernspec Xu beta [iters] [dtcvar]\n"); return 2; }
+  const int approx = (argc > 9 && std::string(argv[9]) == "dtcvar") ? (int)CGp::DTCVAR : (int)CGp::DTC;
   CMatrix X, y, Xs, Xu;
   X.fromUnheadedFile(argv[2]);
   y.fromUnheadedFile(argv[3]);
@@ -181,7 +182,7 @@ static int testDtc(int argc, char** argv)
   noise.setBias(0.0);
   CMatrix scale(1, y.getCols(), 1.0), bias(1, y.getCols(), 0.0);
   bias.deepCopy(meanCol(y));
-  CGp model(&kern, &noise, &X, CGp::DTC, Xu.getRows(), 0);
+  CGp model(&kern, &noise, &X, approx, Xu.getRows(), 0);
   model.setBetaVal(std::atof(argv[7]));
   model.setScale(scale);
   model.setBias(bias);
