@@ -5,6 +5,7 @@
 //   gp_hosttest gp X.txt y.txt Xs.txt "rbf:1,1;bias:0.135;white:0.135" [exact]
 #include <cmath>
 #include <cstdio>
+#include <time.h>
 #include <cstdlib>
 #include <iostream>
 #include <sstream>
@@ -191,7 +192,21 @@ static int testDtc(int argc, char** argv)
   CMatrix g(1, model.getOptNumParams()), params(1, model.getOptNumParams());
   model.getOptParams(params);
   model.setOptParams(params);   // marks K dirty with the given inducing inputs
-  const double ll = model.logLikelihoodGradient(g);
+  double ll = model.logLikelihoodGradient(g);
+  {
+    // second evaluation at a perturbed point, timed (buffers are allocated, the library is warm)
+    CMatrix p2(params);
+    p2.setVal(p2.getVal(p2.getCols() - 1) + 1e-9, p2.getCols() - 1);
+    model.setOptParams(p2);
+    struct timespec t0, t1;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    CMatrix g2(1, model.getOptNumParams());
+    (void)model.logLikelihoodGradient(g2);
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    std::printf("time_llgrad_ms %.3f\n", (t1.tv_sec - t0.tv_sec) * 1e3 + (t1.tv_nsec - t0.tv_nsec) * 1e-6);
+    model.setOptParams(params);
+    ll = model.logLikelihoodGradient(g);
+  }
   std::printf("ll %.17g\n", ll);
   printMat("grads", g);
   printMat("opt_params", params);
