@@ -552,3 +552,33 @@ def test_gradient_reuses_the_factor_of_the_objective(api, golden):
     g2, _ = m.logLikelihoodGradient()                        # must NOT be derived from the rounded factor
     assert np.array_equal(g2, g0)
     assert rel(g0, g["grads"].ravel()) < 1e-8
+
+
+def test_error_behaviour_of_the_c_abi(api):
+    """bad arguments come back as status codes with a message (the C++ layer turns them into the reference's exception
+    types); nothing throws across the boundary, nothing falls back"""
+    import ctypes
+    from gpc_amd import _lib
+    lib = api.lib()
+    A = api.from_host(np.eye(4))
+    info = ctypes.c_int(0)
+    rc = lib.gpc_potrf_f64(ctypes.c_char(b"X"), 4, api.ptr(A), 4, ctypes.byref(info), api.stream())
+    assert rc == _lib.GPC_EINVAL and b"uplo" in lib.gpc_last_error().lower()
+    rc = lib.gpc_potrf_f64(ctypes.c_char(b"L"), 4, api.ptr(A), 2, ctypes.byref(info), api.stream())   # lda < N
+    assert rc == _lib.GPC_EINVAL
+    with pytest.raises(_lib.GpcError):
+        api.trsm(A, api.from_host(np.ones((4, 2))), side="Q")
+    ks = api.kspec([("rbf", [1.0, 1.0])])
+    ks.types[0] = 99                                              # a kernel type outside the accelerated set
+    with pytest.raises(_lib.GpcError) as e:
+        api.gram_sym(ks, api.from_host(np.zeros((3, 2))))
+    assert e.value.rc == _lib.GPC_EUNSUPPORTED
+    ks5 = api.kspec([("rbf", [1.0, 1.0])] * 5)                    # more rbf terms than one pass handles
+    with pytest.raises(_lib.GpcError):
+        api.gram_sym(ks5, api.from_host(np.zeros((3, 2))))
+    X17 = api.from_host(np.zeros((8, 17)))                        # latent-gradient passes cover D <= 16
+    with pytest.raises(_lib.GpcError) as e:
+        api.kern_gradx(api.kspec([("rbf", [1.0, 1.0])]), X17, api.from_host(np.zeros((8, 8))))
+    assert e.value.rc == _lib.GPC_EUNSUPPORTED
+    # a failed call leaves the library usable
+    assert api.potrf(api.from_host(np.eye(4) * 4.0), "L") == 0
