@@ -118,7 +118,30 @@ def main():
     X, _ = synth.make_xy(N, D, seed=1234 + (rank if replicas else 0))
     if distributed:
         from gpc_amd import dist as gdist
-        g = gdist.DistGp(cfg["kern"], X)
+        dist_mode = "overlapped"
+        if world > 1 and os.environ.get("GPC_BENCH_SELFCHECK", "1") == "1":
+            # Start-up self-check (untimed): the block-cyclic factorisation of a small problem must give the log-determinant
+            # a single-GPU factorisation gives, on every rank.  The overlapped mode (second stream, asynchronous RCCL
+            # broadcasts ordered by events) is checked first; if it disagrees the run falls back to the serialised mode.
+            Xc, _ = synth.make_xy(8192, D, seed=99)
+            _, ref_ld, _, info0 = api.gp_update_k(api.kspec(cfg["kern"]), api.from_host(Xc))
+            for mode in ("overlapped", "serialised"):
+                ok = 0.0
+                try:
+                    gc = gdist.DistGp(cfg["kern"], Xc, sync=(mode == "serialised"))
+                    ld = gc.update_k()
+                    ok = 1.0 if (info0 == 0 and abs(ld - ref_ld) <= 1e-8 * abs(ref_ld)) else 0.0
+                    del gc
+                except Exception as e:     # noqa: BLE001 -- any failure of the check means "do not use this mode"
+                    sys.stderr.write("rank %d: distributed self-check (%s) failed: %r\n" % (rank, mode, e))
+                flag = torch.tensor([ok], dtype=torch.float64, device="cuda")
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                if float(flag.item()) == 1.0:
+                    dist_mode = mode
+                    break
+            else:
+                raise SystemExit("distributed factorisation failed its self-check in both modes")
+        g = gdist.DistGp(cfg["kern"], X, sync=(dist_mode == "serialised"))
 
         def step():
             return g.update_k()
@@ -242,8 +265,9 @@ def main():
                                       % (args.workload, N, D, "+".join(t for t, _ in cfg["kern"])),
                           "parallelism": "1 GPU" if world == 1 else
                           ("%d independent replicas" % world if replicas else
-                           "1-D block-cyclic column panels over %d GPUs (nb=%d), RCCL panel broadcast, look-ahead 1"
-                           % (world, g.nb)),
+                           "1-D block-cyclic column panels over %d GPUs (nb=%d), RCCL panel broadcast, %s"
+                           % (world, g.nb, "look-ahead 1, slab-pipelined" if dist_mode == "overlapped" else
+                              "serialised collectives (the overlapped mode failed the start-up self-check)")),
                           "logdet": logdet},
                "roofline": roof}
         if phases is not None:

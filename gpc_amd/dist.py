@@ -110,12 +110,15 @@ class _NoStream(object):
 
 
 class _Streams(object):
-    def __init__(self, device):
+    def __init__(self, device, single_stream=False):
         self.cuda = device.type == "cuda"
         if self.cuda:
             self.main = torch.cuda.current_stream(device)
-            self.panel = torch.cuda.Stream(device=device, priority=-1)
-            self.panel.wait_stream(self.main)
+            if single_stream:          # safe mode: panel work and collectives are serialised on the main stream
+                self.panel = self.main
+            else:
+                self.panel = torch.cuda.Stream(device=device, priority=-1)
+                self.panel.wait_stream(self.main)
         else:
             self.main = self.panel = _NoStream()
 
@@ -159,7 +162,11 @@ class DistGp(object):
     Xstar (optional, Ns x D): test inputs whose predictive variance is wanted (carried as extra rows).
     """
 
-    def __init__(self, terms, X, y=None, Xstar=None, nb=None, ops=None, group=None):
+    def __init__(self, terms, X, y=None, Xstar=None, nb=None, ops=None, group=None, sync=None):
+        # sync (default: env GPC_DIST_SYNC): no second stream, blocking collectives -- no look-ahead, but nothing about
+        # the ordering is left to events.  bench.py falls back to it if its start-up self-check of the overlapped
+        # mode disagrees with a single-GPU factorisation.
+        self.sync = (os.environ.get("GPC_DIST_SYNC", "0") == "1") if sync is None else bool(sync)
         self.ops = ops if ops is not None else HipOps()
         self.group = group
         self.P = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -190,7 +197,7 @@ class DistGp(object):
         self.ncols = sum(self.width(j) for j in self.mine)
         self.A = self.ops.empty(self.Mtot, max(self.ncols, 1))
         self.A[self.N:, :].zero_()
-        self.st = _Streams(self.A.device)
+        self.st = _Streams(self.A.device, single_stream=self.sync)
         # two receive buffers (panel k uses k % 2); flat so that every step's M x w panel is one contiguous message
         self.buf = [torch.empty(self.Mtot * self.nb, dtype=torch.float64, device=self.A.device) for _ in range(2)]
         self.info = self.ops.info_word()
@@ -244,6 +251,9 @@ class DistGp(object):
             return None
         gsrc = src if self.group is None else dist.get_global_rank(self.group, src)
         if self.backend == "nccl":
+            if self.sync:
+                dist.broadcast(flat, gsrc, group=self.group)       # the current stream waits for it
+                return None
             return dist.broadcast(flat, gsrc, group=self.group, async_op=True)
         if flat.is_cuda:
             h = flat.cpu() if self.rank == src else torch.empty(flat.shape, dtype=flat.dtype)

@@ -24,6 +24,10 @@ def make_problem(N, D, d, Ns, seed):
 def run(rank, world, port, flavour, N, D, d, Ns, nb, terms, outdir):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    sync = flavour.endswith("-sync")               # the serialised fall-back mode of gpc_amd.dist
+    if sync:
+        flavour = flavour[:-5]
+        os.environ["GPC_DIST_SYNC"] = "1"
     if flavour == "hip-rccl":                      # real RCCL; one rank per GPU (a 1-GPU box can only run world = 1)
         torch.cuda.set_device(rank)
         os.environ["GPC_DIST_FORCE_COMM"] = "1"

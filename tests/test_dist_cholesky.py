@@ -129,15 +129,17 @@ def test_hipops_fails_loudly_without_gpu():
 @pytest.mark.parametrize("world,N,Ns,d,nb", [(1, 1500, 33, 2, 128), (2, 1500, 33, 2, 128), (2, 4096, 0, 1, 512),
                                              (2, 2049, 7, 1, 256)])
 def test_blockcyclic_hip(world, N, Ns, d, nb, tmp_path):
-    res = _run(world, "hip", N, 3, d, Ns, nb, tmp_path)
+    res = _run(world, "hip" if nb != 256 else "hip-sync", N, 3, d, Ns, nb, tmp_path)
     _check(res, _expected(N, 3, d, Ns), Ns, 1e-9)
 
 
 @pytest.mark.gpu
-def test_blockcyclic_rccl_calls_single_rank(tmp_path):
+@pytest.mark.parametrize("flavour", ["hip-rccl", "hip-rccl-sync"])
+def test_blockcyclic_rccl_calls_single_rank(flavour, tmp_path):
     """The RCCL code path (async broadcast on the panel stream, work.wait(), int64 MIN / fp64 SUM all-reduce,
-    high-priority communicator) in a 1-rank job: all a 1-GPU box can run of it."""
-    res = _run(1, "hip-rccl", 1500, 3, 2, 33, 128, tmp_path)
+    high-priority communicator) in a 1-rank job: all a 1-GPU box can run of it -- and the serialised fall-back mode
+    (blocking broadcasts on the main stream) bench.py switches to if its start-up self-check fails."""
+    res = _run(1, flavour, 1500, 3, 2, 33, 128, tmp_path)
     _check(res, _expected(1500, 3, 2, 33), 33, 1e-9)
 
 
