@@ -347,3 +347,9 @@ def axpby_(alpha, X, beta, Y):
     """Y := alpha X + beta Y (elementwise)."""
     check(lib().gpc_axpby_f64(Y.shape[0], Y.shape[1], alpha, ptr(X), ld(X), beta, ptr(Y), ld(Y), stream()))
     return Y
+
+
+def scale_vec_(A, v, by_rows=False):
+    """A(i,j) *= v[i] (by_rows) or v[j]: CMatrix::scaleRow / scaleCol against a device vector (CGp.cpp:812-820)."""
+    check(lib().gpc_scale_vec_f64(A.shape[0], A.shape[1], ptr(A), ld(A), ptr(v), 1 if by_rows else 0, stream()))
+    return A

@@ -129,18 +129,19 @@ __global__ void __launch_bounds__(256) diag_reduce_kernel(const double* __restri
   if(threadIdx.x == 0) partial[blockIdx.x] = r;
 }
 
-// out[j*gridDim.x + b] = partial sum over rows of A(i,j)*B(i,j)
+// out[j*gridDim.y + b] = partial sum over rows of A(i,j)*B(i,j); columns along grid x (no 65 535 limit: the sparse
+// approximations take column sums over N data points), row blocks along grid y
 __global__ void __launch_bounds__(256) coldot_kernel(const double* __restrict__ A, int64_t lda,
                                                      const double* __restrict__ B, int64_t ldb, int64_t M,
                                                      double* __restrict__ partial)
 {
   __shared__ double sh[4];
-  const int64_t j = blockIdx.y;
+  const int64_t j = blockIdx.x;
   double v = 0.0;
-  for(int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < M; i += (int64_t)gridDim.x * 256)
+  for(int64_t i = (int64_t)blockIdx.y * 256 + threadIdx.x; i < M; i += (int64_t)gridDim.y * 256)
     v += A[i + j * lda] * B[i + j * ldb];
   const double r = block_sum_256(v, sh);
-  if(threadIdx.x == 0) partial[j * gridDim.x + blockIdx.x] = r;
+  if(threadIdx.x == 0) partial[j * gridDim.y + blockIdx.y] = r;
 }
 
 // out[j] = sum_i A(i,j)^2 : one workgroup per column (columns are independent test points)
@@ -212,6 +213,15 @@ __global__ void __launch_bounds__(256) axpby_kernel(int64_t M, double alpha, con
   if(i >= M) return;
   const double x = (alpha == 0.0) ? 0.0 : alpha * X[i + j * ldx];
   Y[i + j * ldy] = (beta == 0.0) ? x : fma(beta, Y[i + j * ldy], x);
+}
+
+// A(i,j) *= v[j] (by_rows == 0: CMatrix::scaleCol for every column) or A(i,j) *= v[i] (by_rows != 0: scaleRow)
+__global__ void __launch_bounds__(256) scale_vec_kernel(int64_t M, double* __restrict__ A, int64_t lda,
+                                                        const double* __restrict__ v, int by_rows, int64_t j0)
+{
+  const int64_t j = j0 + blockIdx.y;
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if(i < M) A[i + j * lda] *= by_rows ? v[i] : v[j];
 }
 
 int reduce_partials_to_host(const double* d_partial, int64_t ncols, int64_t nb, double* out_host, hipStream_t s)
@@ -314,7 +324,7 @@ extern "C" int gpc_coldot_f64(int64_t M, int64_t ncols, const double* A, int64_t
                               double* out, void* stream)
 {
   GPC_CHECK(ensure_device());
-  GPC_REQUIRE(M >= 0 && ncols >= 0 && ncols <= 65535, "coldot dims");
+  GPC_REQUIRE(M >= 0 && ncols >= 0 && ncols <= 0x7fffffffLL, "coldot dims");
   if(ncols == 0) return GPC_OK;
   hipStream_t s = as_stream(stream);
   int64_t nb = (M + 255) / 256;
@@ -322,7 +332,7 @@ extern "C" int gpc_coldot_f64(int64_t M, int64_t ncols, const double* A, int64_t
   if(nb < 1) nb = 1;
   void* ws = nullptr;
   GPC_CHECK(workspace(WS_REDUCE, sizeof(double) * (size_t)(nb * ncols), &ws));
-  hipLaunchKernelGGL(coldot_kernel, dim3((unsigned)nb, (unsigned)ncols), dim3(256), 0, s, A, lda, B, ldb, M,
+  hipLaunchKernelGGL(coldot_kernel, dim3((unsigned)ncols, (unsigned)nb), dim3(256), 0, s, A, lda, B, ldb, M,
                      static_cast<double*>(ws));
   GPC_HIP_CHECK(hipGetLastError());
   return reduce_partials_to_host(static_cast<double*>(ws), ncols, nb, out, s);
@@ -393,6 +403,21 @@ extern "C" int gpc_axpby_f64(int64_t M, int64_t N, double alpha, const double* X
     const int64_t nc = (N - j0 < 32768) ? (N - j0) : 32768;
     hipLaunchKernelGGL(axpby_kernel, dim3((unsigned)((M + 255) / 256), (unsigned)nc), dim3(256), 0, s, M, alpha, X, ldx,
                        beta, Y, ldy, j0);
+  }
+  GPC_HIP_CHECK(hipGetLastError());
+  return GPC_OK;
+}
+
+extern "C" int gpc_scale_vec_f64(int64_t M, int64_t N, double* A, int64_t lda, const double* v_dev, int by_rows, void* stream)
+{
+  GPC_CHECK(ensure_device());
+  GPC_REQUIRE(M >= 0 && N >= 0 && lda >= (M > 1 ? M : 1) && v_dev != nullptr, "scale_vec args");
+  if(M == 0 || N == 0) return GPC_OK;
+  hipStream_t s = as_stream(stream);
+  for(int64_t j0 = 0; j0 < N; j0 += 32768) {
+    const int64_t nc = (N - j0 < 32768) ? (N - j0) : 32768;
+    hipLaunchKernelGGL(scale_vec_kernel, dim3((unsigned)((M + 255) / 256), (unsigned)nc), dim3(256), 0, s, M, A, lda, v_dev,
+                       by_rows, j0);
   }
   GPC_HIP_CHECK(hipGetLastError());
   return GPC_OK;

@@ -33,12 +33,12 @@ CGp::CGp(CKern* kernel, CNoise* nois, CMatrix* Xin, int approx, unsigned int act
       AlphaUpToDate(false), invKupToDate(false), LcholRounded(false), dX(0), dM(0), dL(0), dInvKm(0), dAlpha(0), dInvK(0),
       dCovGrad(0), logDetK(0.0), lastJitter(0.0), needInverse(false), approxType(approx), betaVal(1e3),
       inducingFixed(false), dXu(0), dKuu(0), dKuf(0), dInvKuu(0), dA(0), dAinv(0), dLA(0), dE(0), dAlphaU(0), dIKK(0),
-      logDetKuu(0.0), logDetA(0.0), sumDiagD(0.0), LArounded(false)
+      logDetKuu(0.0), logDetA(0.0), sumDiagD(0.0), LArounded(false), dVf(0), dBet(0), sumLogDiagD(0.0), sumLogLm(0.0), sMsM(0.0)
 {
   if(Xin->getRows() != nois->getNumData())
     throw ndlexceptions::MatrixError("CGp: X and the targets disagree on the number of data");   // CGp.cpp:60
-  if(approxType != FTC && approxType != DTC && approxType != DTCVAR)
-    throw ndlexceptions::NotImplementedError("of the sparse approximations DTC and DTCVAR run on the accelerated path (FITC/PITC do not)");
+  if(approxType != FTC && approxType != DTC && approxType != DTCVAR && approxType != FITC)
+    throw ndlexceptions::NotImplementedError("the PITC approximation is not implemented (nor is it in the reference, CGp.cpp:857-866)");
   setVerbosity(verbos);
   const char* e = std::getenv("GPC_EXACT_TRANS");
   if(e && e[0] == '1') refTransRounding = false;
@@ -57,7 +57,8 @@ CGp::CGp()
       bias(1, 1, 0.0), refTransRounding(true), MupToDate(false), KupToDate(false), AlphaUpToDate(false),
       invKupToDate(false), LcholRounded(false), dX(0), dM(0), dL(0), dInvKm(0), dAlpha(0), dInvK(0), dCovGrad(0), logDetK(0.0), lastJitter(0.0),
       needInverse(false), approxType(FTC), betaVal(1e3), inducingFixed(false), dXu(0), dKuu(0), dKuf(0), dInvKuu(0), dA(0),
-      dAinv(0), dLA(0), dE(0), dAlphaU(0), dIKK(0), logDetKuu(0.0), logDetA(0.0), sumDiagD(0.0), LArounded(false)
+      dAinv(0), dLA(0), dE(0), dAlphaU(0), dIKK(0), logDetKuu(0.0), logDetA(0.0), sumDiagD(0.0), LArounded(false), dVf(0), dBet(0), sumLogDiagD(0.0),
+      sumLogLm(0.0), sMsM(0.0)
 {
   const char* e = std::getenv("GPC_EXACT_TRANS");
   if(e && e[0] == '1') refTransRounding = false;
@@ -79,6 +80,7 @@ void CGp::setData(CMatrix* Xin, CMatrix* yin)
   devFree(dKuf);
   devFree(dE);
   devFree(dIKK);
+  devFree(dVf);
   MupToDate = KupToDate = AlphaUpToDate = invKupToDate = false;
 }
 CGp::~CGp()
@@ -104,6 +106,8 @@ CGp::~CGp()
   devFree(dE);
   devFree(dAlphaU);
   devFree(dIKK);
+  devFree(dVf);
+  devFree(dBet);
 }
 
 void CGp::updateM() const
@@ -192,6 +196,11 @@ void CGp::updateAlpha() const
     if(refTransRounding && !LArounded) {
       gpcCheck(gpc_ref_trans_rounding_f64(M, dLA, M, 0));
       LArounded = true;
+    }
+    if(approxType == FITC) {
+      // Alpha = LcholA^-T LcholA^-1 K_uf (m ./ diagD)  (CGp.cpp:500-512) = ... V m with V = K_uf D^-1
+      const int64_t NN = getNumData();
+      gpcCheck(gpc_gemm_f64('N', 'N', M, dd, NN, 1.0, dVf, M, dM, NN, 0.0, dE, M, 0));
     }
     gpcCheck(gpc_gp_alpha_f64(M, dd, dLA, M, dE, M, dAlphaU, M, 0));
     AlphaUpToDate = true;
@@ -417,6 +426,15 @@ void CGp::updateKdtc() const
   if(jit > 0.0) gpcCheck(gpc_add_diag_f64(M, dKuu, M, jit, 0));
   if(jit > 1e-2 && getVerbosity() > 2)
     std::cout << "Warning: jitter of " << jit << " added to K_uu in _updateInvK()." << std::endl;
+  if(approxType == FITC) {
+    // FITC needs LcholK (the factor of K_uu) itself: keep it in dLA's storage until updateFitc has used it
+    gpcCheck(gpc_memcpy_d2d(dLA, dInvKuu, sizeof(double) * (size_t)M * M, 0));
+    gpcCheck(gpc_potri_f64('L', M, dInvKuu, M, 0));
+    updateFitc();
+    KupToDate = true;
+    AlphaUpToDate = false;
+    return;
+  }
   gpcCheck(gpc_potri_f64('L', M, dInvKuu, M, 0));
   // updateAD, CGp.cpp:751-776: A = K_uf K_uf' + K_uu / beta; LcholA, logDetA, Ainv
   gpcCheck(gpc_memcpy_d2d(dA, dKuu, sizeof(double) * (size_t)M * M, 0));
@@ -456,6 +474,22 @@ double CGp::logLikelihoodDtc() const
 {
   updateK();
   const int64_t N = getNumData(), d = getOutputDim(), M = numActive;
+  if(approxType == FITC) {
+    // CGp.cpp:963-990 (+ the common tail 1002-1013)
+    std::vector<double> bb((size_t)d);
+    gpcCheck(gpc_coldot_f64(M, d, dBet, M, dBet, M, &bb[0], 0));
+    double L = ((double)M - (double)N) * std::log(betaVal) + (double)N * 1.8378770664093454836;   // ndlutil::LOGTWOPI
+    L += sumLogDiagD;
+    L += sumLogLm * 2.0;
+    L *= (double)d;
+    double bsum = 0.0;
+    for(int64_t j = 0; j < d; j++) bsum += bb[j];
+    L += betaVal * (sMsM - bsum);
+    L *= -0.5;
+    L += pkern->priorLogProb();
+    L -= (double)d * (double)N * HALFLOGTWOPI;
+    return L;
+  }
   double* dInvAe = devAlloc((size_t)M * d);
   std::vector<double> eAe((size_t)d), mm((size_t)d);
   try {
@@ -480,6 +514,10 @@ double CGp::logLikelihoodDtc() const
 void CGp::gradientDtc(CMatrix& g) const
 {
   updateK();
+  if(approxType == FITC) {
+    gradientFitc(g);
+    return;
+  }
   const int64_t N = getNumData(), D = getInputDim(), d = getOutputDim(), M = numActive;
   const unsigned int nk = pkern->getNumParams();
   if(g.getRows() != 1 || g.getCols() != getOptNumParams())
@@ -579,6 +617,192 @@ void CGp::gradientDtc(CMatrix& g) const
   g.setVal(gb * beta, 0, counter++);   // gBeta * gradfact(beta), CGp.cpp:1071-1074
 }
 
+// ---- FITC ------------------------------------------------------------------------------------------------------------
+static void uploadVec(double* dst, const std::vector<double>& v)
+{
+  gpcCheck(gpc_memcpy_h2d(dst, &v[0], sizeof(double) * v.size(), 0));
+}
+
+// updateAD for FITC (CGp.cpp:798-856).  On entry dKuu, dKuf, dInvKuu are current and dLA holds LcholK (lower factor of K_uu).
+void CGp::updateFitc() const
+{
+  const int64_t N = getNumData(), D = getInputDim(), d = getOutputDim(), M = numActive;
+  gpc_kspec ks;
+  pkern->toKspec(ks);
+  if(!dIKK) dIKK = devAlloc((size_t)M * N);
+  if(!dVf) dVf = devAlloc((size_t)M * N);
+  if(!dBet) dBet = devAlloc((size_t)M * d);
+  double *dLuu = devAlloc((size_t)M * M), *dV2 = devAlloc((size_t)M * N), *dAm = devAlloc((size_t)M * M),
+         *dLm = devAlloc((size_t)M * M), *dVec = devAlloc((size_t)N), *dSM = devAlloc((size_t)N * d), *dDiag = devAlloc((size_t)N);
+  try {
+    gpcCheck(gpc_memcpy_d2d(dLuu, dLA, sizeof(double) * (size_t)M * M, 0));
+    if(refTransRounding) gpcCheck(gpc_ref_trans_rounding_f64(M, dLuu, M, 0));   // LcholK.trans(), CGp.cpp:908
+    // diagD = 1 + beta (diagK - column sums of (invK_uu K_uf) .* K_uf), in the reference's order of operations
+    gpcCheck(gpc_gemm_f64('N', 'N', M, N, M, 1.0, dInvKuu, M, dKuf, M, 0.0, dIKK, M, 0));
+    std::vector<double> cs((size_t)N), dk((size_t)N), v1((size_t)N), v2((size_t)N);
+    gpcCheck(gpc_coldot_f64(M, N, dIKK, M, dKuf, M, &cs[0], 0));
+    gpcCheck(gpc_gram_diag_f64(&ks, dX, N, D, N, dDiag, 0));
+    gpcCheck(gpc_memcpy_d2h(&dk[0], dDiag, sizeof(double) * dk.size(), 0));
+    diagD.assign((size_t)N, 0.0);
+    sumLogDiagD = 0.0;
+    for(int64_t n = 0; n < N; n++) {
+      double dd = -dk[n];
+      dd = cs[n] + dd;
+      dd *= betaVal;
+      dd = -dd;
+      diagD[n] = dd + 1.0;
+      sumLogDiagD += std::log(diagD[n]);
+      v1[n] = 1 / diagD[n];
+      v2[n] = std::sqrt(v1[n]);
+    }
+    // V = K_uf D^-1; scaledM = D^-1/2 m
+    gpcCheck(gpc_memcpy_d2d(dVf, dKuf, sizeof(double) * (size_t)M * N, 0));
+    uploadVec(dVec, v1);
+    gpcCheck(gpc_scale_vec_f64(M, N, dVf, M, dVec, 0, 0));
+    gpcCheck(gpc_memcpy_d2d(dSM, dM, sizeof(double) * (size_t)N * d, 0));
+    uploadVec(dVec, v2);
+    gpcCheck(gpc_scale_vec_f64(N, d, dSM, N, dVec, 1, 0));
+    std::vector<double> ss((size_t)d);
+    gpcCheck(gpc_coldot_f64(N, d, dSM, N, dSM, N, &ss[0], 0));
+    sMsM = 0.0;
+    for(int64_t j = 0; j < d; j++) sMsM += ss[j];
+    // A = K_uf V' + K_uu / beta; LcholA, logDetA, Ainv
+    gpcCheck(gpc_memcpy_d2d(dA, dKuu, sizeof(double) * (size_t)M * M, 0));
+    gpcCheck(gpc_gemm_f64('N', 'T', M, M, N, 1.0, dKuf, M, dVf, M, 1.0 / betaVal, dA, M, 0));
+    (void)devJitChol(M, dA, dLA);
+    gpcCheck(gpc_logdet_chol_f64(M, dLA, M, &logDetA, 0));
+    gpcCheck(gpc_memcpy_d2d(dAinv, dLA, sizeof(double) * (size_t)M * M, 0));
+    gpcCheck(gpc_potri_f64('L', M, dAinv, M, 0));
+    LArounded = false;
+    // V2 = LcholK^-1 K_uf D^-1/2; Am = I / beta + V2 V2'; Lm; bet = Lm^-1 V2 scaledM
+    gpcCheck(gpc_memcpy_d2d(dV2, dKuf, sizeof(double) * (size_t)M * N, 0));
+    gpcCheck(gpc_trsm_f64('L', 'L', 'N', 'N', M, N, 1.0, dLuu, M, dV2, M, 0));
+    gpcCheck(gpc_scale_vec_f64(M, N, dV2, M, dVec, 0, 0));   // dVec still holds D^-1/2
+    gpcCheck(gpc_memset(dAm, 0, sizeof(double) * (size_t)M * M, 0));
+    gpcCheck(gpc_add_diag_f64(M, dAm, M, 1 / betaVal, 0));
+    gpcCheck(gpc_gemm_f64('N', 'T', M, M, N, 1.0, dV2, M, dV2, M, 1.0, dAm, M, 0));
+    (void)devJitChol(M, dAm, dLm);
+    double ld = 0.0;
+    gpcCheck(gpc_logdet_chol_f64(M, dLm, M, &ld, 0));
+    sumLogLm = 0.5 * ld;                                                         // sum_i log Lm(i,i)
+    if(refTransRounding) gpcCheck(gpc_ref_trans_rounding_f64(M, dLm, M, 0));    // Lm.trans(), CGp.cpp:849
+    gpcCheck(gpc_trsm_f64('L', 'L', 'N', 'N', M, N, 1.0, dLm, M, dV2, M, 0));
+    gpcCheck(gpc_gemm_f64('N', 'N', M, d, N, 1.0, dV2, M, dSM, N, 0.0, dBet, M, 0));
+    // E = V m: what Alpha and the gradient start from
+    if(!dE) dE = devAlloc((size_t)M * d);
+    gpcCheck(gpc_gemm_f64('N', 'N', M, d, N, 1.0, dVf, M, dM, N, 0.0, dE, M, 0));
+  } catch(...) {
+    devFree(dLuu); devFree(dV2); devFree(dAm); devFree(dLm); devFree(dVec); devFree(dSM); devFree(dDiag);
+    throw;
+  }
+  devFree(dLuu); devFree(dV2); devFree(dAm); devFree(dLm); devFree(dVec); devFree(dSM); devFree(dDiag);
+}
+
+// gpCovGrads + updateG for FITC (CGp.cpp:1320-1399, 1146-1218)
+void CGp::gradientFitc(CMatrix& g) const
+{
+  const int64_t N = getNumData(), D = getInputDim(), d = getOutputDim(), M = numActive;
+  const unsigned int nk = pkern->getNumParams();
+  if(g.getRows() != 1 || g.getCols() != getOptNumParams())
+    throw ndlexceptions::MatrixError("logLikelihoodGradient: g must be 1 x nParams");
+  const double beta = betaVal, dd = (double)d;
+  gpc_kspec ks;
+  pkern->toKspec(ks);
+  double *dAinvE = devAlloc((size_t)M * d), *dAinvEMT = devAlloc((size_t)M * N), *dAEA = devAlloc((size_t)M * M),
+         *dAm2 = devAlloc((size_t)M * M), *dV3 = devAlloc((size_t)M * N), *dIKKD = devAlloc((size_t)M * N),
+         *dIKKDQ = devAlloc((size_t)M * N), *dGKuu = devAlloc((size_t)M * M), *dGKuf = devAlloc((size_t)M * N),
+         *dVec = devAlloc((size_t)N), *dGXa = devAlloc((size_t)M * D), *dGXb = devAlloc((size_t)M * D);
+  std::vector<double> t1(nk > 0 ? nk : 1), t2(nk > 0 ? nk : 1), t3(nk > 0 ? nk : 1, 0.0), gxa((size_t)M * D), gxb((size_t)M * D),
+      kae((size_t)N), kda((size_t)N), v((size_t)N), diagQ((size_t)N), gLambda((size_t)N);
+  double gb = 0.0;
+  try {
+    // E = V m is in dE (updateFitc).  AinvE, AinvEMT = (Ainv E) m', AinvEETAinv = AinvE AinvE'
+    gpcCheck(gpc_gemm_f64('N', 'N', M, d, M, 1.0, dAinv, M, dE, M, 0.0, dAinvE, M, 0));
+    gpcCheck(gpc_gemm_f64('N', 'T', M, N, d, 1.0, dAinvE, M, dM, N, 0.0, dAinvEMT, M, 0));
+    gpcCheck(gpc_gemm_f64('N', 'T', M, M, d, 1.0, dAinvE, M, dAinvE, M, 0.0, dAEA, M, 0));
+    gpcCheck(gpc_coldot_f64(M, N, dAinvEMT, M, dKuf, M, &kae[0], 0));            // diagK_ufAinvEMT
+    // (d Ainv + beta AinvEETAinv) K_uf, then its column-wise products with K_uf
+    gpcCheck(gpc_axpby_f64(M, M, dd, dAinv, M, 0.0, dAm2, M, 0));
+    gpcCheck(gpc_axpby_f64(M, M, beta, dAEA, M, 1.0, dAm2, M, 0));
+    gpcCheck(gpc_gemm_f64('N', 'N', M, N, M, 1.0, dAm2, M, dKuf, M, 0.0, dV3, M, 0));
+    gpcCheck(gpc_coldot_f64(M, N, dV3, M, dKuf, M, &kda[0], 0));
+    for(int64_t n = 0; n < N; n++) {
+      double mmt = 0.0;
+      for(int64_t j = 0; j < d; j++) mmt += m.getVal((unsigned int)n, (unsigned int)j) * m.getVal((unsigned int)n, (unsigned int)j);
+      diagQ[n] = kda[n] - dd * diagD[n] + beta * mmt - 2.0 * beta * kae[n];
+      gLambda[n] = ((diagQ[n] / diagD[n]) * (0.5 * beta)) / diagD[n];
+      gb += gLambda[n];
+    }
+    gb = -gb / (beta * beta);
+    // invK_uuK_ufDinv and ...DinvQ
+    gpcCheck(gpc_memcpy_d2d(dIKKD, dIKK, sizeof(double) * (size_t)M * N, 0));
+    for(int64_t n = 0; n < N; n++) v[n] = 1 / diagD[n];
+    uploadVec(dVec, v);
+    gpcCheck(gpc_scale_vec_f64(M, N, dIKKD, M, dVec, 0, 0));
+    gpcCheck(gpc_memcpy_d2d(dIKKDQ, dIKKD, sizeof(double) * (size_t)M * N, 0));
+    double* dQ = dV3;   // reuse (N doubles at its start are enough; V3 is consumed)
+    uploadVec(dQ, diagQ);
+    gpcCheck(gpc_scale_vec_f64(M, N, dIKKDQ, M, dQ, 0, 0));
+    // gK_uu = 0.5 (d (invK_uu - Ainv / beta) - AinvEETAinv + beta invK_uuK_ufDinvQ invK_uuK_ufDinv')
+    gpcCheck(gpc_axpby_f64(M, M, 0.5 * dd, dInvKuu, M, 0.0, dGKuu, M, 0));
+    gpcCheck(gpc_axpby_f64(M, M, -0.5 * dd / beta, dAinv, M, 1.0, dGKuu, M, 0));
+    gpcCheck(gpc_axpby_f64(M, M, -0.5, dAEA, M, 1.0, dGKuu, M, 0));
+    gpcCheck(gpc_gemm_f64('N', 'T', M, M, N, 0.5 * beta, dIKKDQ, M, dIKKD, M, 1.0, dGKuu, M, 0));
+    // gK_uf = (-beta invK_uuK_ufDinvQ - d Ainv K_uf - beta AinvEETAinv K_uf + beta AinvEMT) D^-1
+    gpcCheck(gpc_axpby_f64(M, N, -beta, dIKKDQ, M, 0.0, dGKuf, M, 0));
+    gpcCheck(gpc_gemm_f64('N', 'N', M, N, M, -dd, dAinv, M, dKuf, M, 1.0, dGKuf, M, 0));
+    gpcCheck(gpc_gemm_f64('N', 'N', M, N, M, -beta, dAEA, M, dKuf, M, 1.0, dGKuf, M, 0));
+    gpcCheck(gpc_axpby_f64(M, N, beta, dAinvEMT, M, 1.0, dGKuf, M, 0));
+    gpcCheck(gpc_scale_vec_f64(M, N, dGKuf, M, dVec, 0, 0));
+    // kernel parameters and inducing inputs
+    gpcCheck(gpc_kern_grad_f64(&ks, dXu, M, D, M, dGKuu, M, &t1[0], 0));
+    gpcCheck(gpc_kern_grad_cross_f64(&ks, dXu, M, M, dX, N, N, D, dGKuf, M, &t2[0], 0));
+    if(!inducingFixed) {
+      gpcCheck(gpc_kern_gradx_f64(&ks, dXu, M, D, M, dGKuu, M, dGXa, M, 0));
+      gpcCheck(gpc_kern_gradx_cross_f64(&ks, dXu, M, M, dX, N, N, D, dGKuf, M, dGXb, M, 0));
+      gpcCheck(gpc_memcpy_d2h(&gxa[0], dGXa, sizeof(double) * gxa.size(), 0));
+      gpcCheck(gpc_memcpy_d2h(&gxb[0], dGXb, sizeof(double) * gxb.size(), 0));
+    }
+  } catch(...) {
+    devFree(dAinvE); devFree(dAinvEMT); devFree(dAEA); devFree(dAm2); devFree(dV3); devFree(dIKKD); devFree(dIKKDQ);
+    devFree(dGKuu); devFree(dGKuf); devFree(dVec); devFree(dGXa); devFree(dGXb);
+    throw;
+  }
+  devFree(dAinvE); devFree(dAinvEMT); devFree(dAEA); devFree(dAm2); devFree(dV3); devFree(dIKKD); devFree(dIKKDQ);
+  devFree(dGKuu); devFree(dGKuf); devFree(dVec); devFree(dGXa); devFree(dGXb);
+  // the diagonal term against gLambda (CGp.cpp:1196-1203): dk(x_n,x_n)/dtheta is 1 for the variance-type parameters and
+  // |x_n|^2 for the linear kernel's
+  double sumL = 0.0, sumLx2 = 0.0;
+  for(int64_t n = 0; n < N; n++) {
+    sumL += gLambda[n];
+    double x2 = 0.0;
+    for(int64_t q = 0; q < D; q++) x2 += pX->getVal((unsigned int)n, (unsigned int)q) * pX->getVal((unsigned int)n, (unsigned int)q);
+    sumLx2 += gLambda[n] * x2;
+  }
+  for(int t = 0; t < ks.n_terms; t++) {
+    const int off = ks.offs[t];
+    switch(ks.types[t]) {
+    case GPC_KERN_RBF:
+    case GPC_KERN_RBFARD: t3[off + 1] += sumL; break;
+    case GPC_KERN_WHITE:
+    case GPC_KERN_BIAS: t3[off] += sumL; break;
+    case GPC_KERN_LIN: t3[off] += sumLx2; break;
+    default: break;
+    }
+  }
+  for(unsigned int i = 0; i < nk; i++) t1[i] += t2[i] + t3[i];
+  for(unsigned int t = 0; t < pkern->getNumTransforms(); t++) {
+    const unsigned int idx = pkern->getTransformIndex(t);
+    t1[idx] *= pkern->getTransformGradFact(pkern->getParam(idx), t);
+  }
+  unsigned int counter = 0;
+  if(!inducingFixed)
+    for(int64_t j = 0; j < D; j++)
+      for(int64_t i = 0; i < M; i++) g.setVal(gxa[i + j * M] + gxb[i + j * M], 0, counter++);
+  for(unsigned int i = 0; i < nk; i++) g.setVal(t1[i], 0, counter++);
+  g.setVal(gb * beta, 0, counter++);
+}
+
 void CGp::posteriorDtc(CMatrix& mu, CMatrix& varSigma, const CMatrix& Xin) const
 {
   // CGp.cpp:540-599 with the sparse branches: kX = k(X_u, X*), mu = kX' Alpha, var = k** - kX' (invK_uu - Ainv/beta) kX + 1/beta
@@ -660,8 +884,8 @@ void CGp::readParamsFromStream(std::istream& in)
   const unsigned int outDim = (unsigned int)ndlstream::readInt(in, "outputDim");
   fileInputDim = (unsigned int)ndlstream::readInt(in, "inputDim");
   const long approx = ndlstream::readInt(in, "sparseApproximation");
-  if(approx != FTC && approx != DTC && approx != DTCVAR)
-    throw ndlexceptions::NotImplementedError("of the sparse approximations DTC and DTCVAR run on the accelerated path");
+  if(approx != FTC && approx != DTC && approx != DTCVAR && approx != FITC)
+    throw ndlexceptions::NotImplementedError("the PITC approximation is not implemented");
   approxType = (int)approx;
   numActive = (unsigned int)std::strtoul(ndlstream::readField(in, "numActive").c_str(), 0, 10);
   if(isSparseApproximation()) {

@@ -6,10 +6,10 @@
 // reference's four resident N x N matrices (CGp.cpp:171-174) this model keeps one (the factor, in K's storage) for
 // likelihood / prediction and three only while a gradient is being evaluated.
 //
-// The sparse approximations DTC and DTCVAR (CGp.cpp:713-776, 939-961, 1146-1316) are provided as well: numActive inducing inputs
+// The sparse approximations DTC, DTCVAR and FITC (CGp.cpp:713-856, 939-990, 1146-1399) are provided as well: numActive inducing inputs
 // X_u (a random subset of X, optimised unless setInducingFixed(true)), noise precision beta; everything of size
 // M x N (K_uf, its gradient) lives in HBM, M = numActive.
-// Not provided: FITC, PITC, GP-LVM through CGp (optimiseX; see CGplvm) and learnt output scales; asking for
+// Not provided: PITC (not implemented in the reference either), GP-LVM through CGp (optimiseX; see CGplvm) and learnt output scales; asking for
 // them throws ndlexceptions::NotImplementedError.
 #ifndef GPC_AMD_CGP_H
 #define GPC_AMD_CGP_H
@@ -103,7 +103,13 @@ class CGp : public CProbabilisticOptimisable {
   double betaVal;
   bool inducingFixed;
   mutable double *dXu, *dKuu, *dKuf, *dInvKuu, *dA, *dAinv, *dLA, *dE, *dAlphaU;
-  mutable double* dIKK;        // invK_uu * K_uf (M x N), DTCVAR only
+  mutable double* dIKK;        // invK_uu * K_uf (M x N), DTCVAR and FITC
+  // FITC (CGp.cpp:798-856): V = K_uf D^-1, D = 1 + beta (diag K - diag K_fu invK_uu K_uf); bet, Lm for the likelihood
+  mutable double *dVf, *dBet;
+  mutable std::vector<double> diagD;
+  mutable double sumLogDiagD, sumLogLm, sMsM;
+  void updateFitc() const;
+  void gradientFitc(CMatrix& g) const;
   mutable double logDetKuu, logDetA, sumDiagD;
   mutable bool LArounded;
   CKern* pkern;

@@ -27,7 +27,7 @@ void CClgp::helpInfo()
   std::cout << "gp [-v verbosity] [-s seed] relearn [-# iterations] trainData.svml [modelFile] [newModelFile]\n"
                "gp display [modelFile]\n"
                "gp [-v verbosity] [-s seed] learn [-k kernel [-g gamma] [-v variance] [-i 0|1]]... [-C 0|1] [-S 0|1]\n"
-               "   [-# iterations] [-O scg] [-A ftc|dtc|dtcvar [-a activeSetSize]] trainData.svml [modelFile]\n"
+               "   [-# iterations] [-O scg] [-A ftc|dtc|dtcvar|fitc [-a activeSetSize]] trainData.svml [modelFile]\n"
                "kernels: rbf (with -i 1: rbfard), lin, bias, white.  bias and white terms are always appended.\n";
 }
 
@@ -93,8 +93,11 @@ void CClgp::learn()
   } else if(approxTypeStr == "dtcvar") {
     approxType = CGp::DTCVAR;
     if(activeSetSize == -1) exitError("You must choose an active set size (option -a) for the command learn.");
+  } else if(approxTypeStr == "fitc") {
+    approxType = CGp::FITC;
+    if(activeSetSize == -1) exitError("You must choose an active set size (option -a) for the command learn.");
   } else {
-    exitError("Of the sparse approximations dtc and dtcvar run on the accelerated path: " + approxTypeStr + ".");
+    exitError("Unknown or unimplemented sparse approximation type: " + approxTypeStr + " (ftc, dtc, dtcvar, fitc).");
   }
   if(optimiser != "scg") exitError("Unrecognised optimiser type: " + optimiser + " (scg is the one provided).");
 

@@ -155,6 +155,11 @@ int gpc_syrk_blockcyclic_f64(int64_t M, int64_t ncols, int64_t K, double alpha, 
 int gpc_axpby_f64(int64_t M, int64_t N, double alpha, const double* X, int64_t ldx, double beta, double* Y, int64_t ldy,
                   void* stream);
 
+/* A(i,j) *= v[j] (by_rows == 0; CMatrix::scaleCol, CMatrix.h:408-420, applied to every column) or A(i,j) *= v[i]
+ * (by_rows != 0; scaleRow): the diagonal scalings of the FITC approximation (CGp.cpp:812-820, 1327-1388).  v is a DEVICE
+ * vector of N (resp. M) doubles. */
+int gpc_scale_vec_f64(int64_t M, int64_t N, double* A, int64_t lda, const double* v_dev, int by_rows, void* stream);
+
 /* ---- vectors / reductions used by CGp's FTC branches ------------------------------------------------------------ */
 /* out[j] = sum_i A(i,j)*B(i,j), j < ncols (ddot per column: CGp.cpp:553-559, 928-930).  out is host. */
 int gpc_coldot_f64(int64_t M, int64_t ncols, const double* A, int64_t lda, const double* B, int64_t ldb,

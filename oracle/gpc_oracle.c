@@ -938,6 +938,220 @@ static void mm(int ta, int tb, long M, long N, long K, double alpha, const doubl
     }
 }
 
+/* per-point diagonal kernel gradient against an N-vector gLambda: CKern::getDiagGradParams (CKern.h:198-213) =
+ * getGradParams on every single point with a 1 x 1 covGrad, summed; natural parameters */
+static void diag_grad_params(const orc_kspec* ks, const double* X, long N, long D, const double* gl, double* out)
+{
+  const int nk = ks->offs[ks->n_terms];
+  double* t4 = (double*)malloc(sizeof(double) * (nk > 0 ? nk : 1));
+  double* xi = (double*)malloc(sizeof(double) * (D > 0 ? D : 1));
+  long i, j;
+  int k;
+  for(k = 0; k < nk; k++) out[k] = 0.0;
+  for(i = 0; i < N; i++) {
+    for(j = 0; j < D; j++) xi[j] = X[i + j * N];
+    orc_kern_grad_sym(ks, xi, 1, D, gl + i, t4);
+    for(k = 0; k < nk; k++) out[k] += t4[k];
+  }
+  free(t4);
+  free(xi);
+}
+
+/* CGp with approximationType FITC (CGp.cpp:798-856 updateAD, 963-990 logLikelihood, 500-512 updateAlpha, 1320-1399
+ * gpCovGrads, 1146-1218 updateG); arguments and gradient layout as orc_gp_dtc.  LcholK (the factor of K_uu) and Lm are
+ * used AFTER their trans(), so a reference built from ndlfortran.f feeds single-precision lower triangles into these
+ * solves (orc_trans reproduces that unless orc_exact_trans is set). */
+double orc_gp_fitc(const orc_kspec* ks, const double* X, long N, long D, const double* m, long d, const double* Xu, long M,
+                   double beta, double* g, double* alpha, const double* Xs, long Ns, double* mu, double* var, int* info)
+{
+  const int nk = ks->offs[ks->n_terms];
+  const size_t MM = (size_t)M * M, MN = (size_t)M * N;
+  double* Kuu = (double*)malloc(sizeof(double) * MM);
+  double* Kuf = (double*)malloc(sizeof(double) * MN);
+  double* Luu = (double*)malloc(sizeof(double) * MM);
+  double* invKuu = (double*)malloc(sizeof(double) * MM);
+  double* A = (double*)malloc(sizeof(double) * MM);
+  double* LA = (double*)malloc(sizeof(double) * MM);
+  double* Ainv = (double*)malloc(sizeof(double) * MM);
+  double* Am = (double*)malloc(sizeof(double) * MM);
+  double* Lm = (double*)malloc(sizeof(double) * MM);
+  double* V = (double*)malloc(sizeof(double) * MN);
+  double* V2 = (double*)malloc(sizeof(double) * MN);
+  double* iKK = (double*)malloc(sizeof(double) * MN);
+  double* diagD = (double*)malloc(sizeof(double) * N);
+  double* sM = (double*)malloc(sizeof(double) * N * d);
+  double* bet = (double*)malloc(sizeof(double) * M * d);
+  double logDetKuu, logDetA, L = 0.0, tmp;
+  long i, j, k, n;
+  *info = 0;
+  orc_gram_sym(ks, Xu, M, D, Kuu);
+  for(n = 0; n < N; n++)
+    for(i = 0; i < M; i++) Kuf[i + (size_t)n * M] = orc_kern_element(ks, Xu, M, i, X, N, n, D);
+  orc_jitchol(M, Kuu, Luu, 20, info);                                 /* _updateInvK */
+  if(*info != 0) goto done;
+  logDetKuu = orc_logdet(M, Luu, M);
+  (void)logDetKuu;
+  orc_pdinv_upper(M, Luu, invKuu);
+  orc_trans(M, Luu);                                                  /* LcholK.trans(): lower */
+  /* updateAD, FITC */
+  mm(0, 0, M, N, M, 1.0, invKuu, M, Kuf, M, 0.0, iKK, M);
+  for(n = 0; n < N; n++) {
+    double cs = 0.0, dd;
+    for(i = 0; i < M; i++) cs += iKK[i + (size_t)n * M] * Kuf[i + (size_t)n * M];
+    dd = -orc_kern_diag_element(ks, X, N, n, D);                      /* diagD = diagK; negate; += colsum; *= beta; negate; += 1 */
+    dd = cs + dd;
+    dd *= beta;
+    dd = -dd;
+    diagD[n] = dd + 1.0;
+  }
+  for(n = 0; n < N; n++) {
+    const double di = 1 / diagD[n];
+    for(i = 0; i < M; i++) V[i + (size_t)n * M] = Kuf[i + (size_t)n * M] * di;
+    for(j = 0; j < d; j++) sM[n + (size_t)j * N] = m[n + (size_t)j * N] * sqrt(di);
+  }
+  memcpy(A, Kuu, sizeof(double) * MM);
+  mm(0, 1, M, M, N, 1.0, Kuf, M, V, M, 1.0 / beta, A, M);
+  orc_jitchol(M, A, LA, 20, info);
+  if(*info != 0) goto done;
+  logDetA = orc_logdet(M, LA, M);
+  (void)logDetA;
+  orc_pdinv_upper(M, LA, Ainv);
+  orc_trans(M, LA);
+  memcpy(V2, Kuf, sizeof(double) * MN);
+  orc_trsm('l', 'l', 'n', 'n', M, N, 1.0, Luu, M, V2, M);
+  for(n = 0; n < N; n++) {
+    const double sc = 1 / sqrt(diagD[n]);
+    for(i = 0; i < M; i++) V2[i + (size_t)n * M] *= sc;
+  }
+  for(k = 0; k < (long)MM; k++) Am[k] = 0.0;
+  for(i = 0; i < M; i++) Am[i + i * M] = 1 / beta;
+  mm(0, 1, M, M, N, 1.0, V2, M, V2, M, 1.0, Am, M);
+  orc_jitchol(M, Am, Lm, 20, info);
+  if(*info != 0) goto done;
+  orc_trans(M, Lm);
+  orc_trsm('l', 'l', 'n', 'n', M, N, 1.0, Lm, M, V2, M);              /* invLmV */
+  mm(0, 0, M, d, N, 1.0, V2, M, sM, N, 0.0, bet, M);
+  /* logLikelihood, CGp.cpp:963-990 */
+  L += ((double)M - (double)N) * log(beta) + (double)N * 1.8378770664093454836;   /* ndlutil::LOGTWOPI */
+  for(n = 0; n < N; n++) L += log(diagD[n]);
+  tmp = 0.0;
+  for(i = 0; i < M; i++) tmp += log(Lm[i + i * M]);
+  L += tmp * 2.0;
+  L *= (double)d;
+  for(j = 0; j < d; j++)
+    L += beta * (dot(N, sM + (size_t)j * N, 1, sM + (size_t)j * N, 1) - dot(M, bet + (size_t)j * M, 1, bet + (size_t)j * M, 1));
+  L *= -0.5;
+  L -= (double)d * (double)N * HALFLOGTWOPI;
+  if(alpha) {                                                         /* updateAlpha, CGp.cpp:500-512 */
+    double* s2 = (double*)malloc(sizeof(double) * N * d);
+    for(n = 0; n < N; n++)
+      for(j = 0; j < d; j++) s2[n + (size_t)j * N] = m[n + (size_t)j * N] * (1 / diagD[n]);
+    mm(0, 0, M, d, N, 1.0, Kuf, M, s2, N, 0.0, alpha, M);
+    orc_trsm('l', 'l', 'n', 'n', M, d, 1.0, LA, M, alpha, M);
+    orc_trsm('l', 'l', 't', 'n', M, d, 1.0, LA, M, alpha, M);
+    free(s2);
+  }
+  if(Xs && Ns > 0) {                                                  /* posterior: the sparse branch of _posteriorVar */
+    double* kX = (double*)malloc(sizeof(double) * M * Ns);
+    double* W = (double*)malloc(sizeof(double) * MM);
+    double* st = (double*)malloc(sizeof(double) * M * Ns);
+    for(n = 0; n < Ns; n++)
+      for(i = 0; i < M; i++) kX[i + n * M] = orc_kern_element(ks, Xu, M, i, Xs, Ns, n, D);
+    for(k = 0; k < (long)MM; k++) W[k] = invKuu[k] - Ainv[k] / beta;
+    mm(0, 0, M, Ns, M, 1.0, W, M, kX, M, 0.0, st, M);
+    for(n = 0; n < Ns; n++) {
+      if(var) var[n] = orc_kern_diag_element(ks, Xs, Ns, n, D) - dot(M, kX + n * M, 1, st + n * M, 1) + 1.0 / beta;
+      if(mu && alpha)
+        for(j = 0; j < d; j++) mu[n + j * Ns] = dot(M, alpha + (size_t)j * M, 1, kX + n * M, 1);
+    }
+    free(kX); free(W); free(st);
+  }
+  if(g) {                                                             /* gpCovGrads FITC, CGp.cpp:1320-1399 */
+    double* E = (double*)malloc(sizeof(double) * M * d);
+    double* AinvE = (double*)malloc(sizeof(double) * M * d);
+    double* EMT = (double*)malloc(sizeof(double) * MN);
+    double* AinvEMT = (double*)malloc(sizeof(double) * MN);
+    double* AEA = (double*)malloc(sizeof(double) * MM);
+    double* Am2 = (double*)malloc(sizeof(double) * MM);
+    double* V3 = (double*)malloc(sizeof(double) * MN);
+    double* iKKD = (double*)malloc(sizeof(double) * MN);
+    double* iKKDQ = (double*)malloc(sizeof(double) * MN);
+    double* gKuu = (double*)malloc(sizeof(double) * MM);
+    double* gKuf = (double*)malloc(sizeof(double) * MN);
+    double* diagQ = (double*)malloc(sizeof(double) * N);
+    double* gLambda = (double*)malloc(sizeof(double) * N);
+    double* t1 = (double*)malloc(sizeof(double) * (nk > 0 ? nk : 1));
+    double* t2 = (double*)malloc(sizeof(double) * (nk > 0 ? nk : 1));
+    double* t3 = (double*)malloc(sizeof(double) * (nk > 0 ? nk : 1));
+    double* gKX = (double*)malloc(sizeof(double) * M * D);
+    double* gKXuf = (double*)malloc(sizeof(double) * N * D);
+    double* dg = (double*)malloc(sizeof(double) * M * D);
+    double gb;
+    mm(0, 0, M, d, N, 1.0, V, M, m, N, 0.0, E, M);                    /* V = K_uf D^-1 (still from updateAD) */
+    mm(0, 0, M, d, M, 1.0, Ainv, M, E, M, 0.0, AinvE, M);
+    mm(0, 1, M, N, d, 1.0, E, M, m, N, 0.0, EMT, M);
+    mm(0, 0, M, N, M, 1.0, Ainv, M, EMT, M, 0.0, AinvEMT, M);
+    mm(0, 1, M, M, d, 1.0, AinvE, M, AinvE, M, 0.0, AEA, M);
+    for(k = 0; k < (long)MM; k++) Am2[k] = (double)d * Ainv[k] + beta * AEA[k];
+    mm(0, 0, M, N, M, 1.0, Am2, M, Kuf, M, 0.0, V3, M);
+    for(n = 0; n < N; n++) {
+      double kae = 0.0, kda = 0.0, mmt = 0.0;
+      for(i = 0; i < M; i++) {
+        kae += AinvEMT[i + (size_t)n * M] * Kuf[i + (size_t)n * M];
+        kda += V3[i + (size_t)n * M] * Kuf[i + (size_t)n * M];
+      }
+      for(j = 0; j < d; j++) mmt += m[n + (size_t)j * N] * m[n + (size_t)j * N];
+      diagQ[n] = kda - (double)d * diagD[n] + beta * mmt - 2.0 * beta * kae;
+    }
+    for(n = 0; n < N; n++)
+      for(i = 0; i < M; i++) {
+        iKKD[i + (size_t)n * M] = iKK[i + (size_t)n * M] * (1 / diagD[n]);
+        iKKDQ[i + (size_t)n * M] = iKKD[i + (size_t)n * M] * diagQ[n];
+      }
+    for(k = 0; k < (long)MM; k++) gKuu[k] = (double)d * (invKuu[k] - Ainv[k] / beta) - AEA[k];
+    mm(0, 1, M, M, N, beta, iKKDQ, M, iKKD, M, 1.0, gKuu, M);
+    for(k = 0; k < (long)MM; k++) gKuu[k] *= 0.5;
+    memcpy(gKuf, iKKDQ, sizeof(double) * MN);
+    mm(0, 0, M, N, M, -(double)d, Ainv, M, Kuf, M, -beta, gKuf, M);
+    mm(0, 0, M, N, M, -beta, AEA, M, Kuf, M, 1.0, gKuf, M);
+    for(k = 0; k < (long)MN; k++) gKuf[k] += beta * AinvEMT[k];
+    for(n = 0; n < N; n++)
+      for(i = 0; i < M; i++) gKuf[i + (size_t)n * M] *= 1 / diagD[n];
+    gb = 0.0;
+    for(n = 0; n < N; n++) {
+      gLambda[n] = ((diagQ[n] / diagD[n]) * (0.5 * beta)) / diagD[n];
+      gb += gLambda[n];
+    }
+    gb = -gb / (beta * beta);
+    orc_kern_grad_sym(ks, Xu, M, D, gKuu, t1);
+    orc_grad_to_trans(ks, D, t1);
+    orc_kern_grad_cross(ks, Xu, M, X, N, D, gKuf, t2);
+    orc_grad_to_trans(ks, D, t2);
+    diag_grad_params(ks, X, N, D, gLambda, t3);
+    orc_grad_to_trans(ks, D, t3);
+    orc_kern_diag_gradx(ks, Xu, M, D, dg);
+    for(i = 0; i < M; i++) {
+      orc_kern_gradx_row2(ks, Xu, M, i, X, N, D, gKXuf);
+      orc_kern_gradx_row2(ks, Xu, M, i, Xu, M, D, gKX);
+      for(k = 0; k < M * D; k++) gKX[k] *= 2.0;
+      for(j = 0; j < D; j++) gKX[i + j * M] = dg[i + j * M];
+      for(j = 0; j < D; j++) {
+        double s = dot(M, gKX + (size_t)j * M, 1, gKuu + (size_t)i * M, 1);
+        s += dot(N, gKXuf + (size_t)j * N, 1, gKuf + i, M);
+        g[i + j * M] = s;
+      }
+    }
+    for(k = 0; k < nk; k++) g[M * D + k] = t1[k] + t2[k] + t3[k];
+    g[M * D + nk] = gb * beta;
+    free(E); free(AinvE); free(EMT); free(AinvEMT); free(AEA); free(Am2); free(V3); free(iKKD); free(iKKDQ); free(gKuu);
+    free(gKuf); free(diagQ); free(gLambda); free(t1); free(t2); free(t3); free(gKX); free(gKXuf); free(dg);
+  }
+done:
+  free(Kuu); free(Kuf); free(Luu); free(invKuu); free(A); free(LA); free(Ainv); free(Am); free(Lm); free(V); free(V2);
+  free(iKK); free(diagD); free(sM); free(bet);
+  return L;
+}
+
 /* CGp with approximationType DTC: updateK (CGp.cpp:713-735), _updateInvK (896-909), updateAD (751-776), logLikelihood
  * (939-961, 1002-1013), gpCovGrads (1252-1316), updateG (1146-1190), logLikelihoodGradient (1016-1079), updateAlpha
  * (490-497), _posteriorMean / _posteriorVar (548-599).

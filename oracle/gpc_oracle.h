@@ -101,4 +101,6 @@ void orc_kern_gradx_row2(const orc_kspec* ks, const double* X, long ldx, long ro
 double orc_gp_dtc(const orc_kspec* ks, const double* X, long N, long D, const double* m, long d, const double* Xu, long M,
                   double beta, int dtcvar, double* g, double* alpha, const double* Xs, long Ns, double* mu, double* var,
                   int* info);   /* dtcvar != 0: the DTCVAR variant (extra diagonal terms, CGp.cpp:766-774, 955, 1275-1317) */
+double orc_gp_fitc(const orc_kspec* ks, const double* X, long N, long D, const double* m, long d, const double* Xu, long M,
+                   double beta, double* g, double* alpha, const double* Xs, long Ns, double* mu, double* var, int* info);
 #endif

@@ -263,8 +263,11 @@ static int run_dtc(const gpcb_file* in, const char* out)
     mu = malloc(sizeof(double) * Ns * d);
     var = malloc(sizeof(double) * Ns);
   }
-  ll = orc_gp_dtc(&ks, X->data, N, D, m, d, Xu->data, M, beta, (ap && ap->data[0] == 4.0) ? 1 : 0, g, alpha,
-                  xs ? xs->data : 0, Ns, mu, var, &info);
+  if(ap && ap->data[0] == 2.0)   /* CGp::FITC */
+    ll = orc_gp_fitc(&ks, X->data, N, D, m, d, Xu->data, M, beta, g, alpha, xs ? xs->data : 0, Ns, mu, var, &info);
+  else
+    ll = orc_gp_dtc(&ks, X->data, N, D, m, d, Xu->data, M, beta, (ap && ap->data[0] == 4.0) ? 1 : 0, g, alpha,
+                    xs ? xs->data : 0, Ns, mu, var, &info);
   for(j = 0; j < d && Ns; j++)   /* _posteriorMean adds the output bias (CGp.cpp:566-573) */
     for(i = 0; i < Ns; i++) mu[i + j * Ns] += means[j];
   infod = (double)info;

@@ -210,7 +210,12 @@ def dtc_golden():
              "c": (2000, 8, 128, 1000.0, [("rbf", [0.25, 1.0]), ("white", [0.01])], 0),
              # DTCVAR (the variational variant: extra diagonal terms), same problems as a and b
              "va": (300, 3, 20, 100.0, [("rbf", [1.0, 1.0]), ("bias", [e2]), ("white", [e2])], 0),
-             "vb": (300, 3, 20, 50.0, [("rbfard", [1.3, 0.8, 0.3, 0.9, 0.5]), ("lin", [0.2]), ("white", [0.05])], 0)}
+             "vb": (300, 3, 20, 50.0, [("rbfard", [1.3, 0.8, 0.3, 0.9, 0.5]), ("lin", [0.2]), ("white", [0.05])], 0),
+             # FITC (per-point diagonal correction D), same problems as a, b and c
+             "fa": (300, 3, 20, 100.0, [("rbf", [1.0, 1.0]), ("bias", [e2]), ("white", [e2])], 15),
+             "fb": (300, 3, 20, 50.0, [("rbfard", [1.3, 0.8, 0.3, 0.9, 0.5]), ("lin", [0.2]), ("white", [0.05])], 0),
+             "fc": (2000, 8, 128, 1000.0, [("rbf", [0.25, 1.0]), ("white", [0.01])], 0)}
+    approx_of = {"v": 4.0, "f": 2.0}
     out = {}
     for name, (N, D, M, beta, terms, iters) in cases.items():
         X, y = synth.make_xy(N, D, seed=5)
@@ -219,7 +224,7 @@ def dtc_golden():
         Xs = synth.make_xstar(16, D, seed=5)
         arr = dict(refrun.kern_arrays(terms))
         arr.update({"X": X, "y": y, "X_u": Xu, "beta": beta, "Xstar": Xs, "iters": float(iters),
-                    "approx": 4.0 if name.startswith("v") else 1.0})
+                    "approx": approx_of.get(name[0], 1.0)})
         r = refrun.run_ref("dtc", arr)
         out.update({name + "_N": N, name + "_D": D, name + "_M": M, name + "_beta": beta, name + "_Xu": Xu,
                     name + "_Xstar": Xs, name + "_ll": r["ll"], name + "_grads": r["grads"], name + "_alpha": r["alpha"],

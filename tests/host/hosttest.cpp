@@ -171,7 +171,8 @@ static int testGp(int argc, char** argv)
 static int testDtc(int argc, char** argv)
 {
   if(argc < 8) { std::fprintf(stderr, "usage: gp_hosttest dtc X y Xs kernspec Xu beta [iters] [dtcvar]\n"); return 2; }
-  const int approx = (argc > 9 && std::string(argv[9]) == "dtcvar") ? (int)CGp::DTCVAR : (int)CGp::DTC;
+  const int approx = (argc > 9 && std::string(argv[9]) == "dtcvar") ? (int)CGp::DTCVAR
+                     : (argc > 9 && std::string(argv[9]) == "fitc") ? (int)CGp::FITC : (int)CGp::DTC;
   CMatrix X, y, Xs, Xu;
   X.fromUnheadedFile(argv[2]);
   y.fromUnheadedFile(argv[3]);

@@ -15,6 +15,9 @@ CASES = {"a": [("rbf", [1.0, 1.0]), ("bias", [E2]), ("white", [E2])],
          "b": [("rbfard", [1.3, 0.8, 0.3, 0.9, 0.5]), ("lin", [0.2]), ("white", [0.05])],
          "c": [("rbf", [0.25, 1.0]), ("white", [0.01])]}
 CASES["va"], CASES["vb"] = CASES["a"], CASES["b"]        # the DTCVAR variant on the same problems
+CASES["fa"], CASES["fb"], CASES["fc"] = CASES["a"], CASES["b"], CASES["c"]   # FITC on the same problems
+NAMES = ["a", "b", "c", "va", "vb", "fa", "fb", "fc"]
+APPROX = {"v": (4.0, "dtcvar"), "f": (2.0, "fitc")}
 
 
 def problem(g, name):
@@ -28,13 +31,13 @@ def close(a, b, tol):
     return np.abs(a - b).max() <= tol * max(1.0, np.abs(b).max())
 
 
-@pytest.mark.parametrize("name", ["a", "b", "c", "va", "vb"])
+@pytest.mark.parametrize("name", NAMES)
 def test_oracle_dtc(golden, name):
     from oracle import refrun
     g = golden("gp_dtc")
     X, y, Xu, beta, Xs = problem(g, name)
     arr = dict(refrun.kern_arrays(CASES[name]))
-    arr.update({"X": X, "y": y, "X_u": Xu, "beta": beta, "Xstar": Xs, "approx": 4.0 if name.startswith("v") else 1.0})
+    arr.update({"X": X, "y": y, "X_u": Xu, "beta": beta, "Xstar": Xs, "approx": APPROX.get(name[0], (1.0, ""))[0]})
     r = refrun.run_port("dtc", arr)
     assert r["info"][0, 0] == 0
     assert abs(r["ll"][0, 0] - g[name + "_ll"][0, 0]) <= 1e-8 * abs(g[name + "_ll"][0, 0])
@@ -67,7 +70,7 @@ def _spec(terms):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["a", "b", "c", "va", "vb"])
+@pytest.mark.parametrize("name", NAMES)
 def test_hip_dtc_through_the_cpp_cgp(golden, name, tmp_path):
     """the C++ CGp(approxType = DTC) on the HIP kernels against the compiled reference: log-likelihood, the full gradient
     (inducing inputs, kernel parameters, log beta), predictive mean / variance; for case a also an SCG run"""
@@ -80,7 +83,7 @@ def test_hip_dtc_through_the_cpp_cgp(golden, name, tmp_path):
     exe = os.path.join(ROOT, "gpc_amd", "host", "gp_hosttest")
     r = subprocess.run([exe, "dtc", str(tmp_path / "X.txt"), str(tmp_path / "y.txt"), str(tmp_path / "Xs.txt"),
                         _spec(CASES[name]), str(tmp_path / "Xu.txt"), "%.17g" % beta, iters] +
-                       (["dtcvar"] if name.startswith("v") else []),
+                       ([APPROX[name[0]][1]] if name[0] in APPROX else []),
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, stdin=subprocess.DEVNULL, timeout=600)
     assert r.returncode == 0, r.stderr.decode()[-2000:]
     v = _parse(r.stdout.decode())

@@ -475,6 +475,31 @@ def test_empty_and_degenerate_sizes(api):
     assert np.array_equal(api.kern_grad(ks, X0, K0), np.zeros(3))
 
 
+def test_scale_vec_and_axpby_are_exact(api):
+    """the elementwise helpers the sparse approximations use (CMatrix::scaleCol / scaleRow / axpy) are single roundings:
+    bit-equal to numpy, on ragged shapes and on sub-views (ld > rows)"""
+    rng = np.random.RandomState(3)
+    for M, N in ((1, 1), (37, 5), (128, 301), (1000, 3)):
+        A, v, w = rng.randn(M + 3, N), rng.randn(N), rng.randn(M)
+        Ad = api.from_host(A)[:M, :]
+        api.scale_vec_(Ad, api.from_host(v.reshape(-1, 1)))
+        assert np.array_equal(api.to_host(Ad), A[:M] * v[None, :])
+        api.scale_vec_(Ad, api.from_host(w.reshape(-1, 1)), by_rows=True)
+        assert np.array_equal(api.to_host(Ad), (A[:M] * v[None, :]) * w[:, None])
+        B = rng.randn(M, N)
+        Bd = api.from_host(B)
+        api.axpby_(0.5, Ad, 1.0, Bd)
+        assert np.array_equal(api.to_host(Bd), 0.5 * ((A[:M] * v[None, :]) * w[:, None]) + B)
+
+
+def test_coldot_over_many_columns(api):
+    """column sums over N > 65 535 data points (the diagonal terms of DTCVAR / FITC at BASELINE sizes)"""
+    rng = np.random.RandomState(4)
+    A, B = rng.randn(40, 70001), rng.randn(40, 70001)
+    got = api.coldot(api.from_host(A), api.from_host(B))
+    assert np.abs(got - (A * B).sum(0)).max() < 1e-13
+
+
 def test_gram_symmetric_build_is_bitwise_the_block_build(api):
     """the mirrored symmetric kernel and the generic block kernel produce the same bits (ragged N, D not a multiple of 4)"""
     import torch
