@@ -46,6 +46,7 @@ enum WorkspaceSlot {
   WS_KERN = 4,        // kernel-gradient partials
   WS_POTRI = 5,       // trtri scratch
   WS_XSCALED = 6,     // reserved
+  WS_PANEL_REF = 7,   // potrf panel chain: copy of the 64 rows under the diagonal block (panel_step_kernel)
   WS_NSLOTS = 8
 };
 int workspace(int slot, size_t bytes, void** out);

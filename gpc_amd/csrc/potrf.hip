@@ -120,6 +120,159 @@ __global__ void __launch_bounds__(256) potf2_kernel(double* __restrict__ A, int6
   }
 }
 
+__device__ __forceinline__ double lane_f64(double v, int lane)   // v of lane `lane` (wave-uniform index) as a scalar
+{
+  union { double d; int i[2]; } u;
+  u.d = v;
+  u.i[0] = __builtin_amdgcn_readlane(u.i[0], lane);
+  u.i[1] = __builtin_amdgcn_readlane(u.i[1], lane);
+  return u.d;
+}
+
+// The same factorisation with 64 / PW barriers instead of 64.  Columns are taken PW at a time: the four waves exchange
+// their shares of the next PW columns through LDS once, then EVERY wave factors that 64 x PW block redundantly in its
+// own registers (lane = row; the pivot and the multipliers a(c,j) travel as scalars through v_readlane: no LDS, no
+// barrier on the column-to-column chain) and applies it to the columns it owns further right, with the multipliers
+// read back as wave-uniform LDS operands (T, written once per block).  The kernel is issue-bound (one wave per SIMD,
+// ~4 cycles per instruction), so what counts is instructions per column: a v_readlane operand costs 7 instructions per
+// term, an LDS-broadcast operand 1.5 -- hence a narrow block (few in-block terms) and everything else through T.
+// Same operations in the same order per element as potf2_kernel: the factor is bitwise the same.
+constexpr int TSTR = 18;   // row stride of T (16-byte aligned rows, 4-way bank conflicts on the transposing store at worst)
+template <int PW, int DBG>
+__global__ void __launch_bounds__(256) potf2_blk_kernel(double* __restrict__ A, int64_t lda, int n,
+                                                        int* __restrict__ info, int64_t col0, long long* dbg,
+                                                        int nref, double* __restrict__ refcopy)
+{
+#define POTF2_STAMP(i) do { if(DBG && threadIdx.x == 0) dbg[i] = wall_clock64(); } while(0)
+  POTF2_STAMP(0);
+  __shared__ __attribute__((aligned(16))) double P[2][PW * JB];   // P[.][i*64 + r]: column i of the block being exchanged
+  __shared__ __attribute__((aligned(16))) double T[JB * TSTR];    // T[c*TSTR + j] = raw a(c, j) of the current block
+  __shared__ double Lout[JB * JB];                                // raw finished columns
+  __shared__ double piv[JB];
+  const int t = threadIdx.x;
+  if(*info != 0) return;
+  const int r = t & 63, g = __builtin_amdgcn_readfirstlane(t >> 6);
+  constexpr int SPB = PW / 4;   // register slots (columns per wave) per block
+
+  double a[16];
+#pragma unroll
+  for(int q = 0; q < 16; q++) {
+    const int c = 4 * q + g;
+    double v = 0.0;
+    if(r < n && c < n) {
+      if(r >= c) v = A[r + (int64_t)c * lda];
+    } else if(r == c) {
+      v = 1.0;
+    }
+    a[q] = v;
+  }
+  // The nref (<= 64) rows right under this block are copied aside (64 x 64 image, zero padded) before anything in the
+  // panel is overwritten: panel_step_kernel<true> solves them redundantly in every workgroup while workgroup 0 stores
+  // their solution in place.
+  if(refcopy) {
+    double cp[16];
+#pragma unroll
+    for(int q = 0; q < 16; q++) {
+      const int c = 4 * q + g;
+      cp[q] = (r < nref && c < n) ? A[n + r + (int64_t)c * lda] : 0.0;
+    }
+#pragma unroll
+    for(int q = 0; q < 16; q++) refcopy[r + (4 * q + g) * JB] = cp[q];
+  }
+  if(DBG) { double z = 0; for(int q = 0; q < 16; q++) z += a[q]; if(z == 1.2345e300) dbg[9] = 1; }   // force the loads
+  POTF2_STAMP(1);
+
+#pragma unroll 1
+  for(int b = 0; b < JB / PW; b++) {
+    double* Pb = P[b & 1];
+#pragma unroll
+    for(int i = 0; i < SPB; i++) Pb[(4 * i + g) * JB + r] = a[i];   // my columns PW b + 4 i + g (slots 0..SPB-1)
+    __syncthreads();
+    double p[PW], w[PW];
+#pragma unroll
+    for(int j = 0; j < PW; j++) p[j] = Pb[j * JB + r];
+#pragma unroll
+    for(int j = 0; j < PW; j++) {
+      const int cj = PW * b + j;
+      const double pj = lane_f64(p[j], cj);
+      double rp;
+      if(pj > 1e-280 && pj < 1e280) {   // uniform; the usual case: v_rcp_f64 seed + two Newton steps
+        double xx = __builtin_amdgcn_rcp(pj);
+        double e = fma(-pj, xx, 1.0);
+        xx = fma(xx, e, xx);
+        e = fma(-pj, xx, 1.0);
+        rp = fma(xx, e, xx);
+      } else {
+        if(!(pj > 0.0)) {   // non-positive or NaN pivot: LAPACK info
+          if(t == 0) atomicCAS(info, 0, (int)(col0 + cj + 1));
+          return;
+        }
+        rp = 1.0 / pj;
+      }
+      w[j] = p[j] * rp;
+#pragma unroll
+      for(int c = j + 1; c < PW; c++) p[c] -= w[j] * lane_f64(p[j], PW * b + c);
+    }
+    // every wave holds the same finished block: all of them record it (identical values, no branches)
+#pragma unroll
+    for(int j = 0; j < PW; j++) Lout[(PW * b + j) * JB + r] = p[j];
+    if(b + 1 < JB / PW) {
+#pragma unroll
+      for(int j = 0; j < PW; j++) T[r * TSTR + j] = p[j];
+      // the columns I own right of this block: slot q <-> column PW b + 4 q + g
+#pragma unroll
+      for(int q = SPB; q < 16; q++) {
+        const int c = PW * b + 4 * q + g;
+        if(c < JB) {   // wave-uniform
+          const double* tc = &T[c * TSTR];
+          double s = a[q];
+#pragma unroll
+          for(int j = 0; j < PW; j++) s -= w[j] * tc[j];
+          a[q] = s;
+        }
+      }
+#pragma unroll
+      for(int q = 0; q < 16 - SPB; q++) a[q] = a[q + SPB];
+    }
+    POTF2_STAMP(2 + (b * PW) / 16);
+  }
+  __syncthreads();
+  // L(j,j) = sqrt(pivot), L(r,j) = a(r,j) * (1 / L(j,j)): dpotf2's own DSCAL by ONE / AJJ
+  if(t < JB) {
+    const double d = sqrt(Lout[t * JB + t]);
+    piv[t] = d;
+    T[t] = 1.0 / d;   // T is free by now
+  }
+  __syncthreads();
+#pragma unroll
+  for(int q = 0; q < 16; q++) {
+    const int c = 4 * q + g;
+    if(r < n && c < n && r >= c) A[r + (int64_t)c * lda] = (r == c) ? piv[c] : Lout[c * JB + r] * T[c];
+  }
+  POTF2_STAMP(6);
+#undef POTF2_STAMP
+}
+
+static int g_potf2_variant = -1;
+inline int potf2_variant()
+{
+  if(g_potf2_variant < 0) {
+    const char* e = getenv("GPC_POTF2");
+    g_potf2_variant = e ? atoi(e) : 1;
+  }
+  return g_potf2_variant;
+}
+// nref > 0: also copy the nref rows under the block to refcopy (see potf2_blk_kernel)
+inline void launch_potf2(double* Ajj, int64_t lda, int jb, int* d_info, int64_t col, hipStream_t s, int nref = 0,
+                         double* refcopy = nullptr)
+{
+  if(potf2_variant() == 0)
+    hipLaunchKernelGGL(potf2_kernel, dim3(1), dim3(256), 0, s, Ajj, lda, jb, d_info, col);
+  else
+    hipLaunchKernelGGL((potf2_blk_kernel<8, 0>), dim3(1), dim3(256), 0, s, Ajj, lda, jb, d_info, col, (long long*)nullptr, nref,
+                       nref > 0 ? refcopy : (double*)nullptr);
+}
+
 // X := B * L^-T in place for B (M x n, n <= 64) and the lower-triangular n x n block L: one wave per 64 rows.
 // Row x solves  x L' = b  by forward substitution over 16-wide blocks held in registers.
 constexpr int LSTR = 66;  // row stride of the L image (even: 16-byte aligned broadcast reads)
@@ -188,6 +341,174 @@ __global__ void __launch_bounds__(64) panel_trsm_kernel(const double* __restrict
   }
 }
 
+// One 64-column step of a slab in ONE launch: X := B L^-T for 64 rows per workgroup (four waves share a row block: the
+// 16 x 16 diagonal solve of each column block is done redundantly by all four, the rank-16 update of the columns still
+// to be solved is split between them) and, when UPD, the rank-64 update of the slab's next 64 columns
+//   C(rows, 0:nc) -= X(rows, :) X(ref rows, :)'      ref rows = the first 64 rows of B (they become the next diagonal block),
+// for which every workgroup solves the ref rows as well (waves 4..7, from the copy the potf2 launch left): it replaces the latency-bound GEMM launch that
+// used to follow every first trsm of a slab (42 us on the critical path of the panel chain, N / 128 times).
+// Dynamic LDS: Ls[64 * LSTR] | Dinv[64] | V[halves][64 * 64].
+template <bool UPD, int DBG = 0>
+__global__ void __launch_bounds__(UPD ? 512 : 256)
+    panel_step_kernel(const double* __restrict__ L, int64_t ldl, int n, double* __restrict__ B, int64_t ldb, int64_t M,
+                      double* __restrict__ C, int64_t ldc, int nc, const double* __restrict__ refcopy, long long* dbg = nullptr)
+{
+#define STEP_STAMP(i) do { if(DBG && threadIdx.x == 0 && blockIdx.x == 0) dbg[i] = wall_clock64(); } while(0)
+  STEP_STAMP(0);
+  extern __shared__ __attribute__((aligned(16))) double step_lds[];
+  double* Ls = step_lds;
+  double* Dinv = Ls + JB * LSTR;
+  double* Vall = Dinv + JB;
+  const int t = threadIdx.x, lane = t & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int half = UPD ? (wv >> 2) : 0, w = wv & 3;
+  double* V = Vall + half * (JB * JB);
+  const int64_t rowrel = (half ? 0 : (int64_t)blockIdx.x * JB) + lane;   // row of B this thread solves
+
+  // every global load of the kernel is issued here, before anything is consumed
+  double b[16], v[16], cacc[8];
+#pragma unroll
+  for(int u = 0; u < 16; u++) {
+    const int k = w * 16 + u;
+    // ref rows come from the copy potf2 made: workgroup 0 overwrites them in B while other workgroups still need them
+    b[u] = half ? refcopy[lane + k * JB] : ((k < n && rowrel < M) ? B[rowrel + (int64_t)k * ldb] : 0.0);
+  }
+  if(half == 0) {
+#pragma unroll
+    for(int u = 0; u < 16; u++) {
+      const int k = w * 16 + u;
+      v[u] = (lane < n && k < n && k <= lane) ? L[lane + (int64_t)k * ldl] : ((lane == k && lane >= n) ? 1.0 : 0.0);
+    }
+  }
+  const int64_t crow = (int64_t)blockIdx.x * JB + lane;
+  if(UPD) {
+#pragma unroll
+    for(int i = 0; i < 8; i++) {
+      const int cc = wv * 8 + i;
+      cacc[i] = (crow < M && cc < nc) ? C[crow + (int64_t)cc * ldc] : 0.0;
+    }
+  }
+  double dl = 1.0;
+  if(half == 0 && w == 0 && lane < n) dl = L[lane + (int64_t)lane * ldl];
+#pragma unroll
+  for(int u = 0; u < 16; u++) V[(w * 16 + u) * JB + lane] = b[u];
+  if(half == 0) {
+#pragma unroll
+    for(int u = 0; u < 16; u++) Ls[lane * LSTR + w * 16 + u] = v[u];
+    if(w == 0) Dinv[lane] = 1.0 / dl;
+  }
+  __syncthreads();
+  STEP_STAMP(1);
+
+  double x[16];
+#pragma unroll 1
+  for(int blk = 0; blk < 4; blk++) {
+    const int o = blk * 16;
+#pragma unroll
+    for(int i = 0; i < 16; i++) x[i] = V[(o + i) * JB + lane];
+#pragma unroll
+    for(int i = 0; i < 16; i++) {
+      double s = x[i];
+#pragma unroll
+      for(int k = 0; k < i; k++) s -= x[k] * Ls[(o + i) * LSTR + o + k];
+      x[i] = s * Dinv[o + i];
+    }
+    // rank-16 update of the columns still to be solved: this wave takes c = o + 16 + w, + 4, ...
+#pragma unroll 2
+    for(int c = o + 16 + w; c < JB; c += 4) {
+      const double* lc = &Ls[c * LSTR + o];
+      double s0 = V[c * JB + lane], s1 = 0.0, s2 = 0.0, s3 = 0.0;
+#pragma unroll
+      for(int k = 0; k < 16; k += 4) {
+        s0 -= x[k] * lc[k];
+        s1 -= x[k + 1] * lc[k + 1];
+        s2 -= x[k + 2] * lc[k + 2];
+        s3 -= x[k + 3] * lc[k + 3];
+      }
+      V[c * JB + lane] = (s0 + s1) + (s2 + s3);
+    }
+    __syncthreads();   // every wave has read this block's right-hand sides; the next block's columns are complete
+    if(w == 0) {
+#pragma unroll
+      for(int i = 0; i < 16; i++) V[(o + i) * JB + lane] = x[i];
+    }
+    STEP_STAMP(2 + blk);
+  }
+  __syncthreads();
+
+  if(half == 0 && rowrel < M) {
+#pragma unroll
+    for(int u = 0; u < 16; u++) {
+      const int k = w * 16 + u;
+      if(k < n) B[rowrel + (int64_t)k * ldb] = V[k * JB + lane];
+    }
+  }
+  if(UPD) {
+    const double* Xo = Vall;              // own rows
+    const double* Xr = Vall + JB * JB;    // ref rows
+    const int c0 = wv * 8;
+#pragma unroll 4
+    for(int k = 0; k < JB; k++) {
+      const double xr = Xo[k * JB + lane];
+      // X(ref row c, k) sits at Xr[k * 64 + c]: eight consecutive doubles, wave-uniform address
+#pragma unroll
+      for(int i = 0; i < 8; i++) cacc[i] -= xr * Xr[k * JB + c0 + i];
+    }
+    if(crow < M) {
+#pragma unroll
+      for(int i = 0; i < 8; i++) {
+        const int cc = c0 + i;
+        if(cc < nc && crow >= cc) C[crow + (int64_t)cc * ldc] = cacc[i];   // lower trapezoid only
+      }
+    }
+  }
+  STEP_STAMP(6);
+#undef STEP_STAMP
+}
+
+constexpr size_t STEP_LDS_1 = sizeof(double) * (JB * LSTR + JB + JB * JB);
+constexpr size_t STEP_LDS_2 = sizeof(double) * (JB * LSTR + JB + 2 * JB * JB);
+static int g_panel_step = -1;
+inline int panel_step_variant()
+{
+  if(g_panel_step < 0) {
+    const char* e = getenv("GPC_PANEL_STEP");
+    g_panel_step = e ? atoi(e) : 1;
+    if(g_panel_step) {
+      if(hipFuncSetAttribute(reinterpret_cast<const void*>(panel_step_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                             (int)STEP_LDS_1) != hipSuccess ||
+         hipFuncSetAttribute(reinterpret_cast<const void*>(panel_step_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                             (int)STEP_LDS_2) != hipSuccess)
+        g_panel_step = 0;
+    }
+  }
+  return g_panel_step;
+}
+
+// L21 := A21 L11^-T for the `below` rows under the diagonal block, and (nc > 0) the update of the next nc <= 64 columns
+int panel_step(const double* Ajj, int64_t lda, int jb, double* A21, int64_t below, double* A22, int nc, hipStream_t s,
+               const double* refcopy, bool newkernels)
+{
+  const unsigned nblk = (unsigned)((below + JB - 1) / JB);
+  if(!newkernels) {
+    hipLaunchKernelGGL(panel_trsm_kernel, dim3(nblk), dim3(64), 0, s, Ajj, lda, jb, A21, lda, below);
+    GPC_HIP_CHECK(hipGetLastError());
+    if(nc > 0) GPC_CHECK(gemm(false, true, below, nc, jb, -1.0, A21, lda, A21, lda, 1.0, A22, lda, 3, s));
+    return GPC_OK;
+  }
+  if(refcopy != nullptr)
+    hipLaunchKernelGGL(panel_step_kernel<true>, dim3(nblk), dim3(512), STEP_LDS_2, s, Ajj, lda, jb, A21, lda, below, A22, lda, nc,
+                       refcopy);
+  else {
+    hipLaunchKernelGGL(panel_step_kernel<false>, dim3(nblk), dim3(256), STEP_LDS_1, s, Ajj, lda, jb, A21, lda, below,
+                       (double*)nullptr, (int64_t)0, 0, (const double*)nullptr);
+    GPC_HIP_CHECK(hipGetLastError());
+    if(nc > 0) GPC_CHECK(gemm(false, true, below, nc, jb, -1.0, A21, lda, A21, lda, 1.0, A22, lda, 3, s));
+  }
+  GPC_HIP_CHECK(hipGetLastError());
+  return GPC_OK;
+}
+
 // second stream + event pool for the look-ahead (created once per process and device)
 struct LookAhead {
   hipStream_t panel = nullptr;
@@ -225,29 +546,45 @@ int ensure_lookahead()
 // the whole remaining panel after every 64 columns this moves 1.75x fewer bytes of the panel through HBM (the
 // 64-deep updates are memory-bound) in half as many GEMM launches: 1.51 -> 1.29 ms for a 65 536 x 512 panel.
 constexpr int64_t SLAB = 128;
-int factor_panel(int64_t N, double* A, int64_t lda, int64_t k0, int64_t nbk, int* d_info, hipStream_t s)
+int factor_panel(int64_t N, double* A, int64_t lda, int64_t k0, int64_t nbk, int* d_info, hipStream_t s, int64_t col0 = 0)
 {
   const int64_t kend = k0 + nbk;
+  // the four-wave / fused step kernels win while the panel is short (the chain is latency-bound: 0.65 -> 0.57 ms for a
+  // 16 384 x 512 panel, 13.5 -> 12.4 ms for the whole N = 8192 factorisation); on a tall panel the one-wave solve +
+  // GEMM pair is as fast and leaves more of each CU to the trailing update running beside it
+  static int64_t step_max_rows = -1;
+  if(step_max_rows < 0) {
+    const char* e = getenv("GPC_STEP_MAXROWS");
+    step_max_rows = e ? atoll(e) : 24576;
+  }
+  const bool use_step = panel_step_variant() != 0 && potf2_variant() != 0 && (N - k0) <= step_max_rows;
+  double* refbuf = nullptr;
+  if(use_step) {
+    void* ws = nullptr;
+    GPC_CHECK(workspace(WS_PANEL_REF, sizeof(double) * JB * JB, &ws));
+    refbuf = static_cast<double*>(ws);
+  }
   for(int64_t s0 = k0; s0 < kend; s0 += SLAB) {
     const int64_t send = (s0 + SLAB < kend) ? (s0 + SLAB) : kend;
     for(int64_t j0 = s0; j0 < send; j0 += JB) {
       const int64_t jb = (send - j0 < JB) ? (send - j0) : JB;
       double* Ajj = A + j0 + j0 * lda;
-      hipLaunchKernelGGL(potf2_kernel, dim3(1), dim3(256), 0, s, Ajj, lda, (int)jb, d_info, j0);
-      GPC_HIP_CHECK(hipGetLastError());
       const int64_t below = N - (j0 + jb);
+      const int64_t nc = send - (j0 + jb);
+      // the fused step (solve + update of the slab's next columns) needs the rows under the block copied aside
+      const bool fused = use_step && nc > 0 && jb == JB && below > 0;
+      launch_potf2(Ajj, lda, (int)jb, d_info, col0 + j0, s, fused ? (int)(below < JB ? below : JB) : 0, refbuf);
+      GPC_HIP_CHECK(hipGetLastError());
       if(below <= 0) continue;
       double* A21 = A + (j0 + jb) + j0 * lda;
-      // L21 := A21 * L11^-T by substitution
-      hipLaunchKernelGGL(panel_trsm_kernel, dim3((unsigned)((below + JB - 1) / JB)), dim3(64), 0, s, Ajj, lda, (int)jb,
-                         A21, lda, below);
-      GPC_HIP_CHECK(hipGetLastError());
-      // update the not-yet-factored columns of this SLAB: lower trapezoid below the diagonal
-      const int64_t nc = send - (j0 + jb);
-      if(nc > 0) {
-        double* A22 = A + (j0 + jb) + (j0 + jb) * lda;
-        GPC_CHECK(gemm(false, true, below, nc, jb, -1.0, A21, lda, A21, lda, 1.0, A22, lda, 3, s));
-      }
+      // L21 := A21 * L11^-T by substitution, fused with the update of the not-yet-factored columns of this SLAB
+      // (lower trapezoid below the diagonal)
+      if(use_step)
+        GPC_CHECK(panel_step(Ajj, lda, (int)jb, A21, below, A + (j0 + jb) + (j0 + jb) * lda, (int)(nc > 0 ? nc : 0), s,
+                             fused ? refbuf : nullptr, true));
+      else
+        GPC_CHECK(panel_step(Ajj, lda, (int)jb, A21, below, A + (j0 + jb) + (j0 + jb) * lda, (int)(nc > 0 ? nc : 0), s,
+                             nullptr, false));
     }
     // the finished slab updates the rest of the panel
     const int64_t nc = kend - send, below = N - send;
@@ -267,27 +604,8 @@ int factor_panel(int64_t N, double* A, int64_t lda, int64_t k0, int64_t nbk, int
 int potrf_panel(int64_t M, int64_t nb, double* A, int64_t lda, int* d_info, int64_t col0, hipStream_t s)
 {
   if(M <= 0 || nb <= 0) return GPC_OK;
-  // factor_panel reports `info` relative to column 0 of the matrix it is given; shift by col0 through a tiny offset:
-  // the kernels take the global column index, so pass A as if it started col0 columns earlier in index space only.
-  const int64_t kend = nb;
-  for(int64_t j0 = 0; j0 < kend; j0 += JB) {
-    const int64_t jb = (kend - j0 < JB) ? (kend - j0) : JB;
-    double* Ajj = A + j0 + j0 * lda;
-    hipLaunchKernelGGL(potf2_kernel, dim3(1), dim3(256), 0, s, Ajj, lda, (int)jb, d_info, col0 + j0);
-    GPC_HIP_CHECK(hipGetLastError());
-    const int64_t below = M - (j0 + jb);
-    if(below <= 0) continue;
-    double* A21 = A + (j0 + jb) + j0 * lda;
-    hipLaunchKernelGGL(panel_trsm_kernel, dim3((unsigned)((below + JB - 1) / JB)), dim3(64), 0, s, Ajj, lda, (int)jb,
-                       A21, lda, below);
-    GPC_HIP_CHECK(hipGetLastError());
-    const int64_t nc = kend - (j0 + jb);
-    if(nc > 0) {
-      double* A22 = A + (j0 + jb) + (j0 + jb) * lda;
-      GPC_CHECK(gemm(false, true, below, nc, jb, -1.0, A21, lda, A21, lda, 1.0, A22, lda, 3, s));
-    }
-  }
-  return GPC_OK;
+  // the same two-level chain as the panels of potrf_lower; `info` is reported relative to the caller's column col0
+  return factor_panel(M, A, lda, 0, nb, d_info, s, col0);
 }
 
 // Width of the panel that starts with `rem` columns still to factor.  Fixed when GPC_NB / gpc_set_potrf_blocking says
