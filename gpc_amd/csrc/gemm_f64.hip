@@ -476,6 +476,7 @@ int launch_fast_role(const GemmArgs& g, unsigned grid, hipStream_t s)
 template <int NWN>
 int launch_fast(const GemmArgs& g, unsigned grid, hipStream_t s)
 {
+  if(g_gemm_trailing == 2) return launch_fast_role<NWN, 2>(g, grid, s);   // slab update inside a Cholesky panel
   return g_gemm_trailing ? launch_fast_role<NWN, 1>(g, grid, s) : launch_fast_role<NWN, 0>(g, grid, s);
 }
 

@@ -59,6 +59,11 @@ int gemm(bool transa, bool transb, int64_t M, int64_t N, int64_t K, double alpha
          const double* B, int64_t ldb, double beta, double* C, int64_t ldc, int tri, hipStream_t s);
 // While one of these is alive the fast GEMM launches under its "trailing update" kernel name (see gemm_f64.hip, ROLE).
 extern int g_gemm_trailing;
+struct PanelScope {   // ... and under its "panel slab update" name (ROLE 2)
+  int saved;
+  PanelScope() : saved(g_gemm_trailing) { g_gemm_trailing = 2; }
+  ~PanelScope() { g_gemm_trailing = saved; }
+};
 struct TrailingScope {
   TrailingScope() { g_gemm_trailing = 1; }
   ~TrailingScope() { g_gemm_trailing = 0; }

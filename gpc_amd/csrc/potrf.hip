@@ -591,6 +591,7 @@ int factor_panel(int64_t N, double* A, int64_t lda, int64_t k0, int64_t nbk, int
     if(nc > 0 && below > 0) {
       const double* L21 = A + send + s0 * lda;
       double* A22 = A + send + send * lda;
+      PanelScope role;
       GPC_CHECK(gemm(false, true, below, nc, send - s0, -1.0, L21, lda, L21, lda, 1.0, A22, lda, 3, s));
     }
   }
@@ -609,33 +610,32 @@ int potrf_panel(int64_t M, int64_t nb, double* A, int64_t lda, int* d_info, int6
 }
 
 // Width of the panel that starts with `rem` columns still to factor.  Fixed when GPC_NB / gpc_set_potrf_blocking says
-// so; otherwise 1024 while the trailing matrix is large (the update kernel's per-tile start-up and C read-modify-write
-// are amortised over a K twice as deep: 58.4 -> 61.1 TF at N = 65 536, and the longer panel still hides behind U2)
-// and 512 once it is small enough for the panel chain to show (measured cross-over between N = 16 384 and 32 768).
+// so; otherwise 1024: the update kernel's per-tile start-up and C read-modify-write are amortised over a K twice as
+// deep as with 512 (58.4 -> 61.1 TF at N = 65 536), and since the panel chain became short (blocked potf2, fused step)
+// the wider panel is the faster choice at every size measured (N = 2048 ... 65 536: 1-4 %).
 static int64_t panel_width(int64_t rem)
 {
+  (void)rem;
   if(g_nb_outer == 0) {
     const char* e = getenv("GPC_NB");
     const int64_t v = e ? atoll(e) : 0;
-    g_nb_outer = (v >= JB) ? (v / JB) * JB : -1;   // -1 = adaptive
+    g_nb_outer = (v >= JB) ? (v / JB) * JB : -1;   // -1 = default
   }
-  if(g_nb_outer > 0) return g_nb_outer;
-  static int64_t sw = -1;
-  if(sw < 0) {
-    const char* e = getenv("GPC_NB_SWITCH");
-    sw = e ? atoll(e) : 12288;
-  }
-  return rem >= sw ? 1024 : 512;
+  return g_nb_outer > 0 ? g_nb_outer : 1024;
 }
 
 int potrf_lower(int64_t N, double* A, int64_t lda, int* d_info, hipStream_t s)
 {
   if(N <= 0) return GPC_OK;
+  // Look-ahead pays only on large matrices: the panel kernels of a tall panel fill the chip themselves, so running them
+  // beside U2 mostly moves time around (N = 65 536: 1.497 -> 1.477 s), and below N ~ 32 768 the contention for CU
+  // slots (a panel workgroup has to wait for trailing-update workgroups to retire) costs more than the overlap wins
+  // (N = 8192: 10.65 ms without, 11.06 ms with).  GPC_LOOKAHEAD = 0 / 1 forces it off / on, unset = by size.
   if(g_lookahead < 0) {
     const char* e = getenv("GPC_LOOKAHEAD");
-    g_lookahead = e ? (atoi(e) != 0) : 1;
+    g_lookahead = e ? (atoi(e) != 0 ? 1 : 0) : 2;
   }
-  const bool la = g_lookahead && N > 2 * panel_width(N);
+  const bool la = (g_lookahead == 1 || (g_lookahead == 2 && N >= 28672)) && N > 2 * panel_width(N);
 
   if(!la) {
     int64_t nbk = 0;
