@@ -59,6 +59,10 @@ int gemm(bool transa, bool transb, int64_t M, int64_t N, int64_t K, double alpha
          const double* B, int64_t ldb, double beta, double* C, int64_t ldc, int tri, hipStream_t s);
 // While one of these is alive the fast GEMM launches under its "trailing update" kernel name (see gemm_f64.hip, ROLE).
 extern int g_gemm_trailing;
+// potrf.hip: the panel chain's substitution step, shared with trsm.hip (see its definition)
+int panel_solve_rt(const double* Lbb, int64_t lda, int nb, double* B, int64_t ldb, int64_t M, double* C, int64_t ldc, int nc,
+                   const double* Lnext, hipStream_t s);
+
 struct PanelScope {   // ... and under its "panel slab update" name (ROLE 2)
   int saved;
   PanelScope() : saved(g_gemm_trailing) { g_gemm_trailing = 2; }

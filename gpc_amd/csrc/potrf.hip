@@ -348,10 +348,13 @@ __global__ void __launch_bounds__(64) panel_trsm_kernel(const double* __restrict
 // for which every workgroup solves the ref rows as well (waves 4..7, from the copy the potf2 launch left): it replaces the latency-bound GEMM launch that
 // used to follow every first trsm of a slab (42 us on the critical path of the panel chain, N / 128 times).
 // Dynamic LDS: Ls[64 * LSTR] | Dinv[64] | V[halves][64 * 64].
-template <bool UPD, int DBG = 0>
+// REFSOLVE = false: the ref block is given solved (ldref its leading dimension) -- the triangular solve X L' = B of
+// trsm.hip, where it is the block L(next 64 rows, these 64 columns) of the factor itself.
+template <bool UPD, bool REFSOLVE, int DBG = 0>
 __global__ void __launch_bounds__(UPD ? 512 : 256)
     panel_step_kernel(const double* __restrict__ L, int64_t ldl, int n, double* __restrict__ B, int64_t ldb, int64_t M,
-                      double* __restrict__ C, int64_t ldc, int nc, const double* __restrict__ refcopy, long long* dbg = nullptr)
+                      double* __restrict__ C, int64_t ldc, int nc, const double* __restrict__ refcopy, int64_t ldref,
+                      long long* dbg = nullptr)
 {
 #define STEP_STAMP(i) do { if(DBG && threadIdx.x == 0 && blockIdx.x == 0) dbg[i] = wall_clock64(); } while(0)
   STEP_STAMP(0);
@@ -371,7 +374,8 @@ __global__ void __launch_bounds__(UPD ? 512 : 256)
   for(int u = 0; u < 16; u++) {
     const int k = w * 16 + u;
     // ref rows come from the copy potf2 made: workgroup 0 overwrites them in B while other workgroups still need them
-    b[u] = half ? refcopy[lane + k * JB] : ((k < n && rowrel < M) ? B[rowrel + (int64_t)k * ldb] : 0.0);
+    b[u] = half ? ((REFSOLVE || lane < nc) ? refcopy[lane + k * ldref] : 0.0)
+                : ((k < n && rowrel < M) ? B[rowrel + (int64_t)k * ldb] : 0.0);
   }
   if(half == 0) {
 #pragma unroll
@@ -401,9 +405,11 @@ __global__ void __launch_bounds__(UPD ? 512 : 256)
   STEP_STAMP(1);
 
   double x[16];
+  const bool do_solve = REFSOLVE || half == 0;   // wave-uniform
 #pragma unroll 1
   for(int blk = 0; blk < 4; blk++) {
     const int o = blk * 16;
+    if(do_solve) {
 #pragma unroll
     for(int i = 0; i < 16; i++) x[i] = V[(o + i) * JB + lane];
 #pragma unroll
@@ -427,8 +433,9 @@ __global__ void __launch_bounds__(UPD ? 512 : 256)
       }
       V[c * JB + lane] = (s0 + s1) + (s2 + s3);
     }
+    }
     __syncthreads();   // every wave has read this block's right-hand sides; the next block's columns are complete
-    if(w == 0) {
+    if(do_solve && w == 0) {
 #pragma unroll
       for(int i = 0; i < 16; i++) V[(o + i) * JB + lane] = x[i];
     }
@@ -458,7 +465,7 @@ __global__ void __launch_bounds__(UPD ? 512 : 256)
 #pragma unroll
       for(int i = 0; i < 8; i++) {
         const int cc = c0 + i;
-        if(cc < nc && crow >= cc) C[crow + (int64_t)cc * ldc] = cacc[i];   // lower trapezoid only
+        if(cc < nc && (!REFSOLVE || crow >= cc)) C[crow + (int64_t)cc * ldc] = cacc[i];   // Cholesky: lower trapezoid only
       }
     }
   }
@@ -466,6 +473,8 @@ __global__ void __launch_bounds__(UPD ? 512 : 256)
 #undef STEP_STAMP
 }
 
+}  // namespace (the step kernels are shared with trsm.hip through panel_solve_rt below)
+namespace {
 constexpr size_t STEP_LDS_1 = sizeof(double) * (JB * LSTR + JB + JB * JB);
 constexpr size_t STEP_LDS_2 = sizeof(double) * (JB * LSTR + JB + 2 * JB * JB);
 static int g_panel_step = -1;
@@ -475,10 +484,12 @@ inline int panel_step_variant()
     const char* e = getenv("GPC_PANEL_STEP");
     g_panel_step = e ? atoi(e) : 1;
     if(g_panel_step) {
-      if(hipFuncSetAttribute(reinterpret_cast<const void*>(panel_step_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                             (int)STEP_LDS_1) != hipSuccess ||
-         hipFuncSetAttribute(reinterpret_cast<const void*>(panel_step_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                             (int)STEP_LDS_2) != hipSuccess)
+      if(hipFuncSetAttribute(reinterpret_cast<const void*>(panel_step_kernel<false, true>),
+                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)STEP_LDS_1) != hipSuccess ||
+         hipFuncSetAttribute(reinterpret_cast<const void*>(panel_step_kernel<true, true>),
+                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)STEP_LDS_2) != hipSuccess ||
+         hipFuncSetAttribute(reinterpret_cast<const void*>(panel_step_kernel<true, false>),
+                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)STEP_LDS_2) != hipSuccess)
         g_panel_step = 0;
     }
   }
@@ -497,17 +508,41 @@ int panel_step(const double* Ajj, int64_t lda, int jb, double* A21, int64_t belo
     return GPC_OK;
   }
   if(refcopy != nullptr)
-    hipLaunchKernelGGL(panel_step_kernel<true>, dim3(nblk), dim3(512), STEP_LDS_2, s, Ajj, lda, jb, A21, lda, below, A22, lda, nc,
-                       refcopy);
+    hipLaunchKernelGGL((panel_step_kernel<true, true>), dim3(nblk), dim3(512), STEP_LDS_2, s, Ajj, lda, jb, A21, lda, below, A22,
+                       lda, nc, refcopy, (int64_t)JB);
   else {
-    hipLaunchKernelGGL(panel_step_kernel<false>, dim3(nblk), dim3(256), STEP_LDS_1, s, Ajj, lda, jb, A21, lda, below,
-                       (double*)nullptr, (int64_t)0, 0, (const double*)nullptr);
+    hipLaunchKernelGGL((panel_step_kernel<false, true>), dim3(nblk), dim3(256), STEP_LDS_1, s, Ajj, lda, jb, A21, lda, below,
+                       (double*)nullptr, (int64_t)0, 0, (const double*)nullptr, (int64_t)0);
     GPC_HIP_CHECK(hipGetLastError());
     if(nc > 0) GPC_CHECK(gemm(false, true, below, nc, jb, -1.0, A21, lda, A21, lda, 1.0, A22, lda, 3, s));
   }
   GPC_HIP_CHECK(hipGetLastError());
   return GPC_OK;
 }
+
+}  // namespace
+
+// X := B L^-T for the M rows of B (nb <= 64 columns, L = the nb x nb lower block at Lbb), optionally fused with
+// C(:, 0:nc) -= X Lnext(0:nc, 0:nb)'  (nc <= 64; Lnext = the block of the factor under Lbb).  The diagonal step of
+// trsm_impl's side-R / transposed / lower sweep (dpotri's V = L^-T), sharing the panel chain's kernels.  Returns
+// GPC_EUNSUPPORTED when those kernels are switched off (the caller keeps its own path).  nc > 0 requires nb == 64.
+int panel_solve_rt(const double* Lbb, int64_t lda, int nb, double* B, int64_t ldb, int64_t M, double* C, int64_t ldc, int nc,
+                   const double* Lnext, hipStream_t s)
+{
+  if(panel_step_variant() == 0 || (nc > 0 && nb != JB) || nc > JB) return GPC_EUNSUPPORTED;
+  const unsigned nblk = (unsigned)((M + JB - 1) / JB);
+  if(nblk == 0) return GPC_OK;
+  if(nc > 0)
+    hipLaunchKernelGGL((panel_step_kernel<true, false>), dim3(nblk), dim3(512), STEP_LDS_2, s, Lbb, lda, nb, B, ldb, M, C, ldc, nc,
+                       Lnext, lda);
+  else
+    hipLaunchKernelGGL((panel_step_kernel<false, true>), dim3(nblk), dim3(256), STEP_LDS_1, s, Lbb, lda, nb, B, ldb, M,
+                       (double*)nullptr, (int64_t)0, 0, (const double*)nullptr, (int64_t)0);
+  GPC_HIP_CHECK(hipGetLastError());
+  return GPC_OK;
+}
+
+namespace {
 
 // second stream + event pool for the look-ahead (created once per process and device)
 struct LookAhead {

@@ -412,6 +412,43 @@ int trsm_sweep(bool left, bool eff_lower, bool tr, bool unit, int64_t lo, int64_
 {
   const bool forward = left ? eff_lower : !eff_lower;
   const int64_t nblk = (hi - lo + JB - 1) / JB;
+  // X L' = B (side R, transposed lower factor: dpotri's V = L^-T and the right-side solves of the sparse paths): the
+  // Cholesky panel chain's four-wave substitution kernel, in 128-column slabs whose first step also updates the slab's
+  // other 64 columns (one launch instead of solve + 64-deep GEMM), then one 128-deep GEMM for the rest of the range
+  static int use_chain = -1;
+  if(use_chain < 0) {
+    const char* e = getenv("GPC_TRSM_CHAIN");
+    use_chain = e ? atoi(e) : 1;
+  }
+  if(use_chain && !left && tr && !eff_lower && !unit) {
+    bool ok = true;
+    for(int64_t s0 = lo; s0 < hi && ok; s0 += 2 * JB) {
+      const int64_t send = (s0 + 2 * JB < hi) ? (s0 + 2 * JB) : hi;
+      for(int64_t b0 = s0; b0 < send; b0 += JB) {
+        const int64_t nb = (send - b0 < JB) ? (send - b0) : JB;
+        const int64_t nc = send - (b0 + nb);   // the slab's columns still to solve (<= 64)
+        const bool fuse = nc > 0 && nb == JB;
+        const int rc = panel_solve_rt(A + b0 + b0 * lda, lda, (int)nb, B + b0 * ldb, ldb, nvec, B + (b0 + nb) * ldb, ldb,
+                                      fuse ? (int)nc : 0, A + (b0 + nb) + b0 * lda, s);
+        if(rc == GPC_EUNSUPPORTED) {
+          ok = false;
+          break;
+        }
+        GPC_CHECK(rc);
+        if(nc > 0 && !fuse)
+          GPC_CHECK(gemm(false, true, nvec, nc, nb, -1.0, B + b0 * ldb, ldb, A + (b0 + nb) + b0 * lda, lda, 1.0,
+                         B + (b0 + nb) * ldb, ldb, 0, s));
+      }
+      if(!ok) break;
+      const int64_t nrest = hi - send;
+      if(nrest > 0)
+        GPC_CHECK(gemm(false, true, nvec, nrest, send - s0, -1.0, B + s0 * ldb, ldb, A + send + s0 * lda, lda, 1.0,
+                       B + send * ldb, ldb, 0, s));
+    }
+    if(ok) return GPC_OK;
+    // the chain kernels are switched off: fall through to the generic sweep (nothing has been launched: the first
+    // call is the one that reports it)
+  }
   for(int64_t step = 0; step < nblk; step++) {
     const int64_t b0 = lo + (forward ? step : (nblk - 1 - step)) * JB;
     const int64_t nb = (hi - b0 < JB) ? (hi - b0) : JB;

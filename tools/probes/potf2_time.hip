@@ -45,13 +45,13 @@ int main()
     for(int j = 0; j < 64; j++) for(int i = 0; i < 64; i++) hp[i + (size_t)j * ld] = (i >= j) ? h[i + j * 64] / 65.0 + (i == j) : 0.0;
     hipMemcpy(P, hp.data(), sizeof(double) * hp.size(), hipMemcpyHostToDevice);
     hipMemset(ref, 0, sizeof(double) * 4096);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(panel_step_kernel<false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)STEP_LDS_1);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(panel_step_kernel<true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)STEP_LDS_2);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(panel_step_kernel<false, true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)STEP_LDS_1);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(panel_step_kernel<true, true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)STEP_LDS_2);
     for(int rep = 0; rep < 2; rep++) {
-      hipLaunchKernelGGL((panel_step_kernel<false, 1>), dim3(128), dim3(256), STEP_LDS_1, 0, P, ld, 64, P + 64, ld, M, (double*)nullptr, (int64_t)0, 0, (const double*)nullptr, dbg);
+      hipLaunchKernelGGL((panel_step_kernel<false, true, 1>), dim3(128), dim3(256), STEP_LDS_1, 0, P, ld, 64, P + 64, ld, M, (double*)nullptr, (int64_t)0, 0, (const double*)nullptr, (int64_t)0, dbg);
       hipMemcpy(st, dbg, sizeof(st), hipMemcpyDeviceToHost);
       printf("step<false> (10 ns ticks): loads %lld | blocks %lld %lld %lld %lld | end %lld\n", st[1] - st[0], st[2] - st[0], st[3] - st[0], st[4] - st[0], st[5] - st[0], st[6] - st[0]);
-      hipLaunchKernelGGL((panel_step_kernel<true, 1>), dim3(128), dim3(512), STEP_LDS_2, 0, P, ld, 64, P + 64, ld, M, P + 64 + 64 * ld, ld, 64, ref, dbg);
+      hipLaunchKernelGGL((panel_step_kernel<true, true, 1>), dim3(128), dim3(512), STEP_LDS_2, 0, P, ld, 64, P + 64, ld, M, P + 64 + 64 * ld, ld, 64, ref, (int64_t)64, dbg);
       hipMemcpy(st, dbg, sizeof(st), hipMemcpyDeviceToHost);
       printf("step<true>  (10 ns ticks): loads %lld | blocks %lld %lld %lld %lld | end %lld\n", st[1] - st[0], st[2] - st[0], st[3] - st[0], st[4] - st[0], st[5] - st[0], st[6] - st[0]);
     }
