@@ -360,13 +360,227 @@ __global__ void __launch_bounds__(256) trsv_step_t_kernel(const double* __restri
   }
 }
 
+// ---- dataflow trsv: the whole solve in ONE launch -----------------------------------------------------------------
+// One workgroup per 64-row block.  Block i accumulates L_ij x_j (forward) or L_ji' x_j (backward) over the blocks j it
+// depends on IN THE ORDER they become final, then solves its own 64 x 64 diagonal system and publishes x_i.  There is
+// no flag and no fence: the solution buffer Xf starts filled with a sentinel NaN payload that arithmetic never
+// produces, a consumer polls the VALUES it needs with device-scope atomic loads until they stop being the sentinel,
+// a producer publishes with device-scope atomic stores -- one memory round trip per dependency instead of two.
+// Block ids come from a ticket counter, so a workgroup only ever waits for workgroups that are already running:
+// deadlock-free whatever the dispatch order and however few of them are resident.  A poll that is not answered after
+// ~2^20 tries poisons the solution with NaN (and sets ctl[1]) instead of hanging the device.
+// Per 64-step launch sequence this replaces: N / 64 dependent launches of 11.5 us (forward) / 17 us (backward).
+constexpr unsigned long long FLOW_SENT = 0xFFF8C0DEFACE0001ull;
+constexpr int FLOW_MAXRHS = 4;
+
+__global__ void __launch_bounds__(256) flow_init_kernel(unsigned long long* __restrict__ Xf, int64_t n, int* __restrict__ ctl)
+{
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if(i < n) Xf[i] = FLOW_SENT;
+  if(i < 2) ctl[i] = 0;
+}
+
+__device__ __forceinline__ double flow_poll(const double* p, int* ctl)
+{
+  const unsigned long long* q = reinterpret_cast<const unsigned long long*>(p);
+  for(int it = 0; it < (1 << 20); it++) {
+    const unsigned long long v = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if(v != FLOW_SENT) return __longlong_as_double((long long)v);
+    __builtin_amdgcn_s_sleep(1);
+  }
+  atomicExch(&ctl[1], 1);
+  return __longlong_as_double(0x7FF8000000000000ll);
+}
+
+__device__ __forceinline__ void flow_publish(double* p, double x)
+{
+  __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), (unsigned long long)__double_as_longlong(x), __ATOMIC_RELAXED,
+                     __HIP_MEMORY_SCOPE_AGENT);
+}
+
+template <bool FWD>
+__global__ void __launch_bounds__(256) trsv_flow_kernel(const double* __restrict__ L, int64_t ldl, double* __restrict__ B,
+                                                        int64_t ldb, int64_t M, int d, int unit, double* __restrict__ Xf,
+                                                        int* __restrict__ ctl)
+{
+  __shared__ double P[64 * 65];
+  __shared__ double Dinv[64];
+  __shared__ double Y[FLOW_MAXRHS * 64];
+  __shared__ double Xs[2][FLOW_MAXRHS][64];
+  __shared__ double Red[3][FLOW_MAXRHS][64];
+  __shared__ int tk_s;
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  if(t == 0) tk_s = atomicAdd(&ctl[0], 1);
+  __syncthreads();
+  const int64_t nblk = (M + 63) / 64;
+  const int64_t ib = FWD ? (int64_t)tk_s : nblk - 1 - (int64_t)tk_s;
+  const int64_t b0 = ib * 64;
+  const int nb = (int)((M - b0 < 64) ? (M - b0) : 64);
+
+  // my diagonal block and right-hand side: nothing here depends on other blocks
+  {
+    double pa[16];
+#pragma unroll
+    for(int u = 0; u < 16; u++) {
+      const int c = w + 4 * u;
+      const bool in = (c < nb && lane < nb && lane >= c);
+      const double x = L[(b0 + (in ? lane : 0)) + (b0 + (in ? c : 0)) * ldl];   // L(b0+lane, b0+c)
+      pa[u] = in ? x : ((lane == c) ? 1.0 : 0.0);
+    }
+#pragma unroll
+    for(int u = 0; u < 16; u++) {
+      const int c = w + 4 * u;
+      if(FWD) P[c * 65 + lane] = pa[u];    // unknown c couples to equation lane > c through L(lane, c)
+      else P[lane * 65 + c] = pa[u];       // L': unknown lane couples to equation c < lane through L(lane, c)
+      if(lane == c) Dinv[c] = 1.0 / pa[u];
+    }
+  }
+  if(w < d) Y[w * 64 + lane] = (lane < nb) ? B[(b0 + lane) + (int64_t)w * ldb] : 0.0;
+
+  double tot[FLOW_MAXRHS];   // (wave 0) sum over the dependencies, per right-hand side, for row / column `lane` of my block
+#pragma unroll
+  for(int v = 0; v < FLOW_MAXRHS; v++) tot[v] = 0.0;
+
+  if(FWD) {
+    // L_ij (rows of my block, 64 columns of block j): lane = row, this wave takes columns 16 w .. 16 w + 15
+    const int64_t row = b0 + ((lane < nb) ? lane : 0);
+    const double* Lrow = L + row + (int64_t)(16 * w) * ldl;
+    double a[16], an[16], acc[FLOW_MAXRHS];
+#pragma unroll
+    for(int v = 0; v < FLOW_MAXRHS; v++) acc[v] = 0.0;
+    if(ib > 0) {
+#pragma unroll
+      for(int u = 0; u < 16; u++) a[u] = Lrow[(int64_t)u * ldl];
+    }
+    for(int64_t j = 0; j < ib; j++) {
+      if(j + 1 < ib) {
+#pragma unroll
+        for(int u = 0; u < 16; u++) an[u] = Lrow[((j + 1) * 64 + u) * ldl];
+      }
+      if(w < d) Xs[j & 1][w][lane] = flow_poll(&Xf[j * 64 + lane + (int64_t)w * M], ctl);
+      __syncthreads();
+#pragma unroll
+      for(int u = 0; u < 16; u++)
+#pragma unroll
+        for(int v = 0; v < FLOW_MAXRHS; v++)
+          if(v < d) acc[v] += a[u] * Xs[j & 1][v][16 * w + u];
+#pragma unroll
+      for(int u = 0; u < 16; u++) a[u] = an[u];
+    }
+    if(w > 0) {
+#pragma unroll
+      for(int v = 0; v < FLOW_MAXRHS; v++)
+        if(v < d) Red[w - 1][v][lane] = acc[v];
+    }
+    __syncthreads();
+    if(w == 0) {
+#pragma unroll
+      for(int v = 0; v < FLOW_MAXRHS; v++)
+        if(v < d) tot[v] = ((acc[v] + Red[0][v][lane]) + Red[1][v][lane]) + Red[2][v][lane];
+    }
+  } else {
+    // L_ji (rows of block j, my 64 columns): lane = row of block j, this wave takes my columns 16 w .. 16 w + 15; every
+    // lane polls the x_j element of its own row, so the loop has no barrier; the per-lane partial sums are reduced
+    // across lanes once, after the last dependency
+    const double* Lcol = L + (b0 + (int64_t)(16 * w)) * ldl;
+    double a[16], an[16], acc[FLOW_MAXRHS][16];
+#pragma unroll
+    for(int v = 0; v < FLOW_MAXRHS; v++)
+#pragma unroll
+      for(int u = 0; u < 16; u++) acc[v][u] = 0.0;
+    auto load_blk = [&](int64_t j, double (&r)[16]) {
+      const int64_t rr = j * 64 + lane;
+      const int64_t rc = (rr < M) ? rr : (M - 1);
+#pragma unroll
+      for(int u = 0; u < 16; u++) {
+        const double x = Lcol[rc + (int64_t)u * ldl];
+        r[u] = (rr < M) ? x : 0.0;
+      }
+    };
+    if(ib + 1 < nblk) load_blk(nblk - 1, a);
+    for(int64_t j = nblk - 1; j > ib; j--) {
+      if(j - 1 > ib) load_blk(j - 1, an);
+      double xj[FLOW_MAXRHS];
+#pragma unroll
+      for(int v = 0; v < FLOW_MAXRHS; v++)
+        xj[v] = (v < d && j * 64 + lane < M) ? flow_poll(&Xf[j * 64 + lane + (int64_t)v * M], ctl) : 0.0;
+#pragma unroll
+      for(int v = 0; v < FLOW_MAXRHS; v++)
+        if(v < d) {
+#pragma unroll
+          for(int u = 0; u < 16; u++) acc[v][u] += a[u] * xj[v];
+        }
+#pragma unroll
+      for(int u = 0; u < 16; u++) a[u] = an[u];
+    }
+    // cross-lane reduction through LDS: Tr[c * 65 + lane], then a thread owns column c = lane and a quarter of the 64
+    // partial sums
+    __shared__ double Tr[64 * 65];
+    for(int v = 0; v < d; v++) {
+      __syncthreads();
+#pragma unroll
+      for(int u = 0; u < 16; u++) {
+        double val = 0.0;
+#pragma unroll
+        for(int vv = 0; vv < FLOW_MAXRHS; vv++) val = (vv == v) ? acc[vv][u] : val;
+        Tr[(16 * w + u) * 65 + lane] = val;
+      }
+      __syncthreads();
+      double sacc = 0.0;
+#pragma unroll
+      for(int k = 0; k < 16; k++) sacc += Tr[lane * 65 + 16 * w + k];
+      if(w > 0) Red[w - 1][0][lane] = sacc;
+      __syncthreads();
+      if(w == 0) {
+        const double tv = ((sacc + Red[0][0][lane]) + Red[1][0][lane]) + Red[2][0][lane];
+#pragma unroll
+        for(int vv = 0; vv < FLOW_MAXRHS; vv++) tot[vv] = (vv == v) ? tv : tot[vv];
+      }
+    }
+  }
+  __syncthreads();
+  if(w == 0) {
+#pragma unroll
+    for(int v = 0; v < FLOW_MAXRHS; v++)
+      if(v < d) Y[v * 64 + lane] -= tot[v];
+  }
+  __syncthreads();
+  tv_solve64(P, Dinv, Y, nb, d, FWD, unit != 0);
+  __syncthreads();
+  if(w < d && lane < nb) {
+    const double x = Y[w * 64 + lane];
+    flow_publish(&Xf[b0 + lane + (int64_t)w * M], x);
+    B[(b0 + lane) + (int64_t)w * ldb] = x;
+  }
+}
+
+static int g_trsv_flow = -1;
+
 int trsv_lower(bool tr, bool unit, int64_t M, int64_t d, const double* L, int64_t ldl, double* B, int64_t ldb,
                hipStream_t s)
 {
   void* ws = nullptr;
-  GPC_CHECK(workspace(WS_TRSM_TMP, sizeof(double) * (size_t)M * (size_t)d, &ws));
+  GPC_CHECK(workspace(WS_TRSM_TMP, sizeof(double) * (size_t)M * (size_t)d + 256, &ws));
   double* Xout = static_cast<double*>(ws);
   const int64_t nblk = (M + JB - 1) / JB;
+  if(g_trsv_flow < 0) {
+    const char* e = getenv("GPC_TRSV_FLOW");
+    g_trsv_flow = e ? atoi(e) : 1;
+  }
+  if(g_trsv_flow && d <= FLOW_MAXRHS && nblk > 1) {
+    const int64_t n = M * d;
+    int* ctl = reinterpret_cast<int*>(Xout + n);
+    hipLaunchKernelGGL(flow_init_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s,
+                       reinterpret_cast<unsigned long long*>(Xout), n, ctl);
+    if(!tr)
+      hipLaunchKernelGGL(trsv_flow_kernel<true>, dim3((unsigned)nblk), dim3(256), 0, s, L, ldl, B, ldb, M, (int)d, unit ? 1 : 0,
+                         Xout, ctl);
+    else
+      hipLaunchKernelGGL(trsv_flow_kernel<false>, dim3((unsigned)nblk), dim3(256), 0, s, L, ldl, B, ldb, M, (int)d, unit ? 1 : 0,
+                         Xout, ctl);
+    GPC_HIP_CHECK(hipGetLastError());
+    return GPC_OK;
+  }
   for(int64_t step = 0; step < nblk; step++) {
     const int64_t b = tr ? (nblk - 1 - step) : step;
     const int64_t b0 = b * JB;
