@@ -408,41 +408,25 @@ int gpc_gp_posterior_f64(const gpc_kspec* ks, const double* X, int64_t N, int64_
               "gp_posterior dims");
   hipStream_t s = as_stream(stream);
   if(Ns == 0) return GPC_OK;
-  // kX = k(X, X*)  (CGp::_testComputeKx, CGp.cpp:540-547)
-  GPC_CHECK(gpc_gram_cross_f64(ks, X, N, ldx, Xs, Ns, ldxs, D, kX, ldkx, stream));
-  // mu = kX' Alpha   (CGp::_posteriorMean, CGp.cpp:548-560)
-  GPC_CHECK(gemm(true, false, Ns, d, N, 1.0, kX, ldkx, Alpha, lda, 0.0, mu, ldmu, 0, s));
+  // Everything is done on the TRANSPOSE kX' = k(X*, X) (Ns x N, stored in the caller's scratch with leading dimension
+  // Ns): the solve becomes the right-side transposed form X L' = B, which runs on the Cholesky panel chain's kernels
+  // (trsm.hip), and the test points sit along the coalesced dimension of every pass.
+  //   kX' = k(X*, X)                       (CGp::_testComputeKx, CGp.cpp:540-547)
+  double* kXt = kX;
+  GPC_CHECK(gpc_gram_cross_f64(ks, Xs, Ns, ldxs, X, N, ldx, D, kXt, Ns, stream));
+  //   mu = kX' Alpha                        (CGp::_posteriorMean, CGp.cpp:548-560)
+  GPC_CHECK(gemm(false, false, Ns, d, N, 1.0, kXt, Ns, Alpha, lda, 0.0, mu, ldmu, 0, s));
   if(var) {
-    // var = k(x*,x*) - |L^-1 kX_col|^2   (CGp::_posteriorVar, CGp.cpp:601-612)
-    GPC_CHECK(trsm('L', 'L', 'N', 'N', N, Ns, 1.0, L, ldl, kX, ldkx, s));
+    //   var = k(x*,x*) - |L^-1 kX_col|^2   (CGp::_posteriorVar, CGp.cpp:601-612): rows of kX' L^-T
+    GPC_CHECK(trsm('R', 'L', 'T', 'N', Ns, N, 1.0, L, ldl, kXt, Ns, s));
     void* ws = nullptr;
-    GPC_CHECK(workspace(WS_REDUCE, sizeof(double) * (size_t)(2 * Ns), &ws));
-    double* nrm = static_cast<double*>(ws);
-    double* kd = nrm + Ns;
-    GPC_CHECK(gpc_colnorm2_f64(N, Ns, kX, ldkx, nrm, stream));
+    GPC_CHECK(workspace(WS_KERN, sizeof(double) * (size_t)Ns, &ws));
+    double* kd = static_cast<double*>(ws);
     GPC_CHECK(gpc_gram_diag_f64(ks, Xs, Ns, D, ldxs, kd, stream));
-    // var = kd - nrm : reuse gemm-free path with a tiny kernel via hipMemcpy + host? keep it on device:
-    extern int gpc_internal_sub_vec(int64_t n, const double* a, const double* b, double* out, hipStream_t s);
-    GPC_CHECK(gpc_internal_sub_vec(Ns, kd, nrm, var, s));
+    GPC_CHECK(rownorm2_sub(Ns, N, kXt, Ns, kd, var, s));
   }
   return GPC_OK;
 }
 
 }  // extern "C"
 
-namespace {
-__global__ void __launch_bounds__(256) sub_vec_kernel(int64_t n, const double* __restrict__ a,
-                                                      const double* __restrict__ b, double* __restrict__ out)
-{
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if(i < n) out[i] = a[i] - b[i];
-}
-}  // namespace
-
-extern "C" int gpc_internal_sub_vec(int64_t n, const double* a, const double* b, double* out, hipStream_t s)
-{
-  if(n <= 0) return GPC_OK;
-  hipLaunchKernelGGL(sub_vec_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, n, a, b, out);
-  GPC_HIP_CHECK(hipGetLastError());
-  return GPC_OK;
-}

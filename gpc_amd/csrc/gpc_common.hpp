@@ -63,6 +63,9 @@ extern int g_gemm_trailing;
 int panel_solve_rt(const double* Lbb, int64_t lda, int nb, double* B, int64_t ldb, int64_t M, double* C, int64_t ldc, int nc,
                    const double* Lnext, hipStream_t s);
 
+// misc.hip: out[j] = base[j] - sum_i A(j,i)^2 over the N columns of the M x N matrix A (deterministic order)
+int rownorm2_sub(int64_t M, int64_t N, const double* A, int64_t lda, const double* base, double* out, hipStream_t s);
+
 struct PanelScope {   // ... and under its "panel slab update" name (ROLE 2)
   int saved;
   PanelScope() : saved(g_gemm_trailing) { g_gemm_trailing = 2; }

@@ -246,6 +246,37 @@ int reduce_partials_to_host(const double* d_partial, int64_t ncols, int64_t nb, 
   return GPC_OK;
 }
 
+// partial[by * M + j] = sum over the columns of chunk by of A(j,i)^2: lane = row (coalesced), the four waves stride
+// the chunk's columns
+__global__ void __launch_bounds__(256) rownorm2_partial_kernel(const double* __restrict__ A, int64_t lda, int64_t M, int64_t N,
+                                                               int64_t chunk, double* __restrict__ partial)
+{
+  __shared__ double red[3][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int64_t j = (int64_t)blockIdx.x * 64 + lane;
+  const int64_t jc = (j < M) ? j : (M - 1);
+  const int64_t c0 = (int64_t)blockIdx.y * chunk;
+  const int64_t c1 = (c0 + chunk < N) ? (c0 + chunk) : N;
+  double acc = 0.0;
+  for(int64_t c = c0 + w; c < c1; c += 4) {
+    const double a = A[jc + c * lda];
+    acc = fma(a, a, acc);
+  }
+  if(w > 0) red[w - 1][lane] = acc;
+  __syncthreads();
+  if(w == 0 && j < M) partial[(int64_t)blockIdx.y * M + j] = ((acc + red[0][lane]) + red[1][lane]) + red[2][lane];
+}
+
+__global__ void __launch_bounds__(256) rownorm2_final_kernel(const double* __restrict__ partial, int64_t M, int nch,
+                                                             const double* __restrict__ base, double* __restrict__ out)
+{
+  const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if(j >= M) return;
+  double acc = 0.0;
+  for(int c = 0; c < nch; c++) acc += partial[(int64_t)c * M + j];
+  out[j] = base[j] - acc;
+}
+
 inline unsigned tri_count(int64_t nt) { return (unsigned)(nt * (nt + 1) / 2); }
 
 }  // namespace
@@ -300,6 +331,23 @@ int diag_reduce(int what, int64_t N, const double* A, int64_t lda, double* out_h
                      static_cast<double*>(ws));
   GPC_HIP_CHECK(hipGetLastError());
   return reduce_partials_to_host(static_cast<double*>(ws), 1, nb, out_host, s);
+}
+
+int rownorm2_sub(int64_t M, int64_t N, const double* A, int64_t lda, const double* base, double* out, hipStream_t s)
+{
+  if(M <= 0) return GPC_OK;
+  int64_t nch = (N + 255) / 256;
+  if(nch > 64) nch = 64;
+  if(nch < 1) nch = 1;
+  const int64_t chunk = (N + nch - 1) / nch;
+  void* ws = nullptr;
+  GPC_CHECK(workspace(WS_REDUCE, sizeof(double) * (size_t)(nch * M), &ws));
+  double* partial = static_cast<double*>(ws);
+  hipLaunchKernelGGL(rownorm2_partial_kernel, dim3((unsigned)((M + 63) / 64), (unsigned)nch), dim3(256), 0, s, A, lda, M, N, chunk,
+                     partial);
+  hipLaunchKernelGGL(rownorm2_final_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, s, partial, M, (int)nch, base, out);
+  GPC_HIP_CHECK(hipGetLastError());
+  return GPC_OK;
 }
 
 }  // namespace gpc

@@ -194,7 +194,7 @@ int gpc_gp_alpha_f64(int64_t N, int64_t d, const double* L, int64_t ldl, const d
 int gpc_gp_loglik_f64(int64_t N, int64_t d, const double* m, int64_t ldm, const double* Alpha, int64_t lda,
                       double logdet, double* ll, void* stream);
 /* CGp::posteriorMeanVar FTC (CGp.cpp:642-663, 548-625) before output scale/bias: mu(Ns x d) = kX' Alpha,
- * var(Ns) = k(x*,x*) - |L^-1 kX_col|^2.  kX_work is an N x Ns device scratch (destroyed, as in the reference).
+ * var(Ns) = k(x*,x*) - |L^-1 kX_col|^2.  kX_work is a device scratch of N x Ns doubles (destroyed; the library keeps k(X*, X), Ns x N, in it).
  * mu and var are DEVICE buffers. */
 int gpc_gp_posterior_f64(const gpc_kspec* ks, const double* X, int64_t N, int64_t D, int64_t ldx,
                          const double* L, int64_t ldl, const double* Alpha, int64_t lda, int64_t d,
