@@ -4,6 +4,7 @@
 // path covers (rbf, lin, bias, white, `-i 1` for rbfard): kernel = cmpnd{ <-k kernels, default rbf>, bias, white },
 // Gaussian noise, bias = mean(y) unless -C 0, FTC only.  `relearn` and `display` read the reference's text model files
 // (and the ones this tool writes); `gnuplot` and the sparse approximations are outside the hot path.
+#include <fstream>
 #include <cstdlib>
 #include <iostream>
 #include <string>
@@ -19,6 +20,7 @@ class CClgp : public CClctrl {
   void learn();
   void relearn();
   void display();
+  void gnuplot();
   void helpInfo();
 };
 
@@ -26,6 +28,7 @@ void CClgp::helpInfo()
 {
   std::cout << "gp [-v verbosity] [-s seed] relearn [-# iterations] trainData.svml [modelFile] [newModelFile]\n"
                "gp display [modelFile]\n"
+               "gp gnuplot [-r resolution] [-p pointSize] trainData.svml [modelFile] [name]\n"
                "gp [-v verbosity] [-s seed] learn [-k kernel [-g gamma] [-v variance] [-i 0|1]]... [-C 0|1] [-S 0|1]\n"
                "   [-# iterations] [-O scg] [-A ftc|dtc|dtcvar|fitc [-a activeSetSize]] trainData.svml [modelFile]\n"
                "kernels: rbf (with -i 1: rbfard), lin, bias, white.  bias and white terms are always appended.\n";
@@ -229,6 +232,145 @@ void CClgp::display()
   delete pmodel;
 }
 
+// gp gnuplot data [modelFile] [name]  (gp.cpp:567-905, Gaussian noise): the CLI's route to predictions.  Writes
+//   name_scatter_data.dat (inputs | target), name_active_set.dat (sparse models: X_u | mean there),
+//   1-D inputs: name_line_data.dat (x | mean), name_error_bar_data.dat (x | mean + 2 std, blank line, x | mean - 2 std)
+//               over the data range extended by a quarter on both sides, `resolution` points;
+//   2-D inputs: name_output_matrix.dat, `resolution` blocks of (x | y | mean) rows;
+//   name_plot.gp, the gnuplot script that shows them.
+// The grid runs from CMatrix::minRow's values, which hold the column MAXIMA as in the reference, i.e. downwards.
+void CClgp::gnuplot()
+{
+  incrementArgument();
+  setMode("gnuplot");
+  double pointSize = 2, lineWidth = 2;
+  int resolution = 80;
+  std::string name = "gp", modelFileName = "gp_model";
+  while(isFlags()) {
+    if(isCurrentArgumentFlag()) {
+      if(isCurrentArg("-?", "--?") || isCurrentArg("-h", "--help")) { helpInfo(); exitNormal(); }
+      else if(isCurrentArg("-l", "--labels")) { incrementArgument(); }   // label file: accepted, unused (as in the reference)
+      else if(isCurrentArg("-p", "--point-size")) { incrementArgument(); pointSize = getDoubleFromCurrentArgument(); }
+      else if(isCurrentArg("-r", "--resolution")) { incrementArgument(); resolution = getIntFromCurrentArgument(); }
+      else unrecognisedFlag();
+      incrementArgument();
+    } else {
+      setFlags(false);
+    }
+  }
+  if(getCurrentArgumentNo() >= argc) exitError("There are not enough input parameters.");
+  if(resolution < 2) exitError("The resolution must be at least 2.");
+  const std::string dataFileName = getCurrentArgument();
+  if(getCurrentArgumentNo() + 1 < argc) modelFileName = argv[getCurrentArgumentNo() + 1];
+  if(getCurrentArgumentNo() + 2 < argc) name = argv[getCurrentArgumentNo() + 2];
+  CMatrix X, y;
+  readData(X, y, dataFileName);
+  CGp* pmodel = readGpFromFile(modelFileName, getVerbosity());
+  pmodel->setData(&X, &y);
+  if(pmodel->getNoiseType() != "gaussian") exitError("Unknown noise model for gnuplot output.");
+  if(pmodel->getInputDim() > 2) exitError("Incorrect number of model inputs.");
+  if(X.getCols() != pmodel->getInputDim()) exitError("Incorrect dimension of input data.");
+  const unsigned int D = X.getCols();
+  if(pmodel->isSparseApproximation()) {
+    const CMatrix& Xu = pmodel->X_u;
+    CMatrix scatterActive(Xu.getRows(), Xu.getCols() + 1), scatterOut(Xu.getRows(), pmodel->getOutputDim());
+    pmodel->out(scatterOut, Xu);
+    for(unsigned int i = 0; i < Xu.getRows(); i++) {
+      for(unsigned int j = 0; j < Xu.getCols(); j++) scatterActive.setVal(Xu.getVal(i, j), i, j);
+      scatterActive.setVal(scatterOut.getVal(i, 0), i, Xu.getCols());
+    }
+    scatterActive.toUnheadedFile(name + "_active_set.dat");
+  }
+  CMatrix scatterData(X.getRows(), D + 1);
+  for(unsigned int i = 0; i < X.getRows(); i++) {
+    for(unsigned int j = 0; j < D; j++) scatterData.setVal(X.getVal(i, j), i, j);
+    scatterData.setVal(y.getVal(i, 0), i, D);
+  }
+  scatterData.toUnheadedFile(name + "_scatter_data.dat");
+  CMatrix minVals(1, D), maxVals(1, D);
+  X.maxRow(maxVals);
+  X.minRow(minVals);
+  const std::string plotFileName = name + "_plot.gp";
+  if(D == 2) {
+    const int numx = resolution, numy = resolution;
+    const double xdiff = (maxVals.getVal(0, 0) - minVals.getVal(0, 0)) / (numx - 1);
+    const double ydiff = (maxVals.getVal(0, 1) - minVals.getVal(0, 1)) / (numy - 1);
+    CMatrix Xgrid(numx * numy, 2);
+    double yy = minVals.getVal(0, 1);
+    for(int i = 0; i < numy; yy += ydiff, i++) {
+      double xx = minVals.getVal(0, 0);
+      for(int j = 0; j < numx; xx += xdiff, j++) {
+        Xgrid.setVal(xx, i * numy + j, 0);
+        Xgrid.setVal(yy, i * numy + j, 1);
+      }
+    }
+    CMatrix outVals(Xgrid.getRows(), pmodel->getOutputDim());
+    pmodel->out(outVals, Xgrid);
+    const std::string matrixFile = name + "_output_matrix.dat";
+    std::ofstream out(matrixFile.c_str());
+    if(!out) throw ndlexceptions::FileWriteError(matrixFile);
+    out << "# Prepared plot of model file " << std::endl;
+    for(int i = 0; i < numy; i++) {
+      CMatrix block(numx, 3);
+      for(int j = 0; j < numx; j++) {
+        block.setVal(Xgrid.getVal(i * numy + j, 0), j, 0);
+        block.setVal(Xgrid.getVal(i * numy + j, 1), j, 1);
+        block.setVal(outVals.getVal(i * numy + j, 0), j, 2);
+      }
+      block.toUnheadedStream(out);
+      out << std::endl;
+    }
+    out.close();
+    std::ofstream gp(plotFileName.c_str());
+    if(!gp) throw ndlexceptions::FileWriteError(plotFileName);
+    gp << "splot \"" << name << "_output_matrix.dat\"  with lines lw " << lineWidth;
+    gp << ", \"" << name << "_scatter_data.dat\" with points ps " << pointSize;
+    if(pmodel->isSparseApproximation()) gp << ", \"" << name << "_active_set.dat\" with points ps " << pointSize << std::endl;
+    gp << "pause -1";
+  } else {
+    const double outLap = 0.25;
+    const int numx = resolution;
+    double xspan = maxVals.getVal(0, 0) - minVals.getVal(0, 0);
+    maxVals.setVal(maxVals.getVal(0, 0) + outLap * xspan, 0, 0);
+    minVals.setVal(minVals.getVal(0, 0) - outLap * xspan, 0, 0);
+    xspan = maxVals.getVal(0, 0) - minVals.getVal(0, 0);
+    const double xdiff = xspan / (numx - 1);
+    CMatrix Xinvals(numx, 1), regressOut(numx, 2), errorBarPlus(numx, 2), errorBarMinus(numx, 2);
+    double xx = minVals.getVal(0, 0);
+    for(int j = 0; j < numx; xx += xdiff, j++) {
+      Xinvals.setVal(xx, j, 0);
+      regressOut.setVal(xx, j, 0);
+      errorBarPlus.setVal(xx, j, 0);
+      errorBarMinus.setVal(xx, j, 0);
+    }
+    CMatrix outVals(numx, pmodel->getOutputDim()), stdVals(numx, pmodel->getOutputDim());
+    pmodel->out(outVals, stdVals, Xinvals);
+    for(int j = 0; j < numx; j++) {
+      const double val = outVals.getVal(j, 0);
+      regressOut.setVal(val, j, 1);
+      errorBarPlus.setVal(val + 2 * stdVals.getVal(j, 0), j, 1);
+      errorBarMinus.setVal(val - 2 * stdVals.getVal(j, 0), j, 1);
+    }
+    regressOut.toUnheadedFile(name + "_line_data.dat");
+    const std::string errorFile = name + "_error_bar_data.dat";
+    std::ofstream out(errorFile.c_str());
+    if(!out) throw ndlexceptions::FileWriteError(errorFile);
+    out << "# Prepared plot of model file " << std::endl;
+    errorBarPlus.toUnheadedStream(out);
+    out << std::endl;
+    errorBarMinus.toUnheadedStream(out);
+    out.close();
+    std::ofstream gp(plotFileName.c_str());
+    if(!gp) throw ndlexceptions::FileWriteError(plotFileName);
+    gp << "plot \"" << name << "_line_data.dat\" with lines lw " << lineWidth;
+    gp << ", \"" << name << "_scatter_data.dat\" with points ps " << pointSize;
+    if(pmodel->isSparseApproximation()) gp << ", \"" << name << "_active_set.dat\" with points ps " << pointSize;
+    gp << ", \"" << name << "_error_bar_data.dat\" with lines lw " << lineWidth << std::endl;
+    gp << "pause -1";
+  }
+  delete pmodel;
+}
+
 int main(int argc, char* argv[])
 {
   CClgp command(argc, argv);
@@ -253,8 +395,11 @@ int main(int argc, char* argv[])
       } else if(command.getCurrentArgumentNo() < argc && command.getCurrentArgument() == "display") {
         command.display();
         return 0;
+      } else if(command.getCurrentArgumentNo() < argc && command.getCurrentArgument() == "gnuplot") {
+        command.gnuplot();
+        return 0;
       } else {
-        command.exitError("Invalid gp command provided (this build implements learn, relearn and display).");
+        command.exitError("Invalid gp command provided (learn, relearn, display, gnuplot).");
       }
     }
   } catch(ndlexceptions::Error& err) {

@@ -322,6 +322,37 @@ def gplvm_golden():
     save("gplvm_oil", **out)
 
 
+def gnuplot_golden():
+    """`gp gnuplot` of the compiled reference (the CLI's route to predictions, gp.cpp:567-905) on the sinc data: for the
+    FTC model sinc_ref_final.model at the default resolution, and for a DTC model the reference learns here
+    (`gp -s 3 learn -A dtc -a 10 -# 40`, kept as sinc_ref_dtc40.model) at resolution 33.  The .dat files it writes
+    are stored as arrays: line data (x | mean; the reference prints these with 6 significant digits), error-bar data
+    (x | mean +- 2 std; 17 digits), active set (X_u | mean there)."""
+    import shutil
+    import subprocess
+    import tempfile
+    ref_gp = os.path.join(ROOT, "oracle", "_ref", "gp")
+    svml = os.path.join(OUT, "sinc.svml")
+    env = dict(os.environ, LD_PRELOAD=refrun.MKL)
+
+    def table(path):
+        return np.array([[float(t) for t in ln.split()] for ln in open(path) if ln.strip() and not ln.startswith("#")])
+
+    with tempfile.TemporaryDirectory() as td:
+        def run(args):
+            subprocess.run([ref_gp] + args, env=env, stdin=subprocess.DEVNULL, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                           check=True, cwd=td)
+        run(["gnuplot", svml, os.path.join(OUT, "sinc_ref_final.model"), "f"])
+        run(["-s", "3", "learn", "-A", "dtc", "-a", "10", "-#", "40", svml, "dtc.model"])
+        run(["gnuplot", "-r", "33", svml, "dtc.model", "s"])
+        shutil.copy(os.path.join(td, "dtc.model"), os.path.join(OUT, "sinc_ref_dtc40.model"))
+        arrays = {k: table(os.path.join(td, k + ".dat")) for k in
+                  ("f_line_data", "f_error_bar_data", "f_scatter_data", "s_line_data", "s_error_bar_data", "s_active_set")}
+        arrays["f_plot"] = np.frombuffer(open(os.path.join(td, "f_plot.gp"), "rb").read(), dtype=np.uint8)
+        arrays["s_plot"] = np.frombuffer(open(os.path.join(td, "s_plot.gp"), "rb").read(), dtype=np.uint8)
+    save("sinc_gnuplot", **arrays)
+
+
 if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "all"
     if what in ("all", "main"):
@@ -335,3 +366,5 @@ if __name__ == "__main__":
     if what in ("all", "dtc"):
         dtc_golden()
         sinc_dtc_golden()
+    if what in ("all", "gnuplot"):
+        gnuplot_golden()

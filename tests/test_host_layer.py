@@ -194,3 +194,33 @@ def test_gp_relearn_continues_like_the_reference(tmp_path):
     keep = os.path.join(ROOT, "gpurun_out")
     if os.path.isdir(keep):
         shutil.copyfile(str(new), os.path.join(keep, "sinc_relearn_written_by_this_build.model"))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("prefix,model,flags", [("f", "sinc_ref_final.model", []), ("s", "sinc_ref_dtc40.model", ["-r", "33"])])
+def test_gp_gnuplot_predictions_match_the_reference(tmp_path, prefix, model, flags):
+    """`gp gnuplot` (the CLI's route to CGp::out): predictive mean and mean +- 2 std over the extended data range, from
+    model files written by the reference (FTC and DTC), against the files the reference's own `gp gnuplot` wrote."""
+    g = dict(np.load(os.path.join(GOLDEN, "sinc_gnuplot.npz")))
+    _run([os.path.join(HOST, "gp"), "gnuplot"] + flags + [os.path.join(GOLDEN, "sinc.svml"), os.path.join(GOLDEN, model), prefix],
+         cwd=str(tmp_path))
+
+    def table(name):
+        return np.array([[float(t) for t in ln.split()] for ln in open(tmp_path / (prefix + "_" + name + ".dat"))
+                         if ln.strip() and not ln.startswith("#")])
+    eb, want = table("error_bar_data"), g[prefix + "_error_bar_data"]
+    assert eb.shape == want.shape
+    assert np.abs(eb[:, 0] - want[:, 0]).max() <= 1e-12 * np.abs(want[:, 0]).max()      # the grid itself (runs downwards)
+    assert np.abs(eb[:, 1] - want[:, 1]).max() <= 1e-8 * np.abs(want[:, 1]).max()       # mean +- 2 std
+    line, wline = table("line_data"), g[prefix + "_line_data"]
+    assert line.shape == wline.shape
+    assert np.abs(line - wline).max() <= 1e-5 * np.abs(wline).max()                     # the reference prints 6 digits here
+    n = line.shape[0]
+    assert np.abs(0.5 * (eb[:n, 1] + eb[n:, 1]) - line[:, 1]).max() <= 1e-12            # the two files agree with each other
+    if prefix == "s":
+        act, wact = table("active_set"), g["s_active_set"]
+        assert act.shape == wact.shape and np.abs(act - wact).max() <= 1e-5 * np.abs(wact).max()
+    else:
+        sc = table("scatter_data")
+        assert sc.shape == g["f_scatter_data"].shape and np.abs(sc - g["f_scatter_data"]).max() <= 1e-5 * np.abs(sc).max()
+    assert open(tmp_path / (prefix + "_plot.gp"), "rb").read() == g[prefix + "_plot"].tobytes()

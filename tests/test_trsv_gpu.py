@@ -5,7 +5,7 @@ import scipy.linalg as sla
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("M,d", [(1, 1), (63, 1), (64, 3), (65, 16), (200, 2), (1000, 12), (4096, 1), (4133, 5)])
+@pytest.mark.parametrize("M,d", [(1, 1), (63, 1), (64, 3), (65, 16), (200, 2), (1000, 12), (4096, 1), (4133, 5), (4133, 4), (8200, 3), (129, 2)])
 @pytest.mark.parametrize("trans", ["N", "T"])
 @pytest.mark.parametrize("diag", ["N", "U"])
 def test_trsv_lower_vs_scipy(M, d, trans, diag):
