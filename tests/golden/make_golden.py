@@ -322,6 +322,35 @@ def gplvm_golden():
     save("gplvm_oil", **out)
 
 
+def readme_golden():
+    """The README's GP tutorial on its "larger data set" (README.md:136-142, 112-134): `gp -v 3 learn -# 100
+    examples/spgp1d.svml` then `gp gnuplot -r 100`, by the compiled reference: per-iteration SCG objective, final
+    kernel parameters (exact, from the model file), printed log-likelihood, and the prediction files."""
+    import re
+    import subprocess
+    import tempfile
+    ref_gp = os.path.join(ROOT, "oracle", "_ref", "gp")
+    svml = os.path.join(OUT, "spgp1d.svml")        # copy of the reference's examples/spgp1d.svml (a data file)
+    env = dict(os.environ, LD_PRELOAD=refrun.MKL)
+
+    def table(path):
+        return np.array([[float(t) for t in ln.split()] for ln in open(path) if ln.strip() and not ln.startswith("#")])
+
+    with tempfile.TemporaryDirectory() as td:
+        r = subprocess.run([ref_gp, "-v", "3", "learn", "-#", "100", svml, "spgp1d.model"], env=env, cwd=td,
+                           stdin=subprocess.DEVNULL, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, check=True)
+        log = r.stdout.decode()
+        its = re.findall(r"^Iteration: (\d+) Error: (\S+) Scale: (\S+)$", log, flags=re.M)
+        ll = float(re.findall(r"^Log likelihood: (\S+)$", log, flags=re.M)[-1])
+        rows = [ln.split() for ln in open(os.path.join(td, "spgp1d.model")) if ln.startswith("0x") or re.match(r"^-?\d", ln)]
+        flat = [float.fromhex(t) if "x" in t else float(t) for row in rows for t in row]
+        subprocess.run([ref_gp, "gnuplot", "-r", "100", svml, "spgp1d.model", "sp"], env=env, cwd=td, stdin=subprocess.DEVNULL,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, check=True)
+        line, eb = table(os.path.join(td, "sp_line_data.dat")), table(os.path.join(td, "sp_error_bar_data.dat"))
+    save("spgp1d_readme", errors=np.array([float(e) for _, e, _ in its]), n_iters=len(its), ll_printed=ll, model_scale=flat[0],
+         model_bias=flat[1], kern_params=np.array(flat[2:6]), line_data=line, error_bar_data=eb)
+
+
 def gnuplot_golden():
     """`gp gnuplot` of the compiled reference (the CLI's route to predictions, gp.cpp:567-905) on the sinc data: for the
     FTC model sinc_ref_final.model at the default resolution, and for a DTC model the reference learns here
@@ -368,3 +397,5 @@ if __name__ == "__main__":
         sinc_dtc_golden()
     if what in ("all", "gnuplot"):
         gnuplot_golden()
+    if what in ("all", "readme"):
+        readme_golden()
