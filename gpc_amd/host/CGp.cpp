@@ -363,18 +363,39 @@ void CGp::optimise(unsigned int iters)
   if(getVerbosity() > 1) std::cout << "... done. " << std::endl;
   if(getVerbosity() > 0) display(std::cout);
 }
+// a 1 x n matrix the way `cout << matrix` shows it in the reference: the stream's own (6 digit) formatting, a space after
+// every value, a newline after the row
+static void showRow(std::ostream& os, const CMatrix& A)
+{
+  for(unsigned int i = 0; i < A.getRows(); i++) {
+    for(unsigned int j = 0; j < A.getCols(); j++) os << A.getVal(i, j) << " ";
+    os << std::endl;
+  }
+}
 void CGp::display(std::ostream& os) const
 {
-  os << "Standard GP Model: " << std::endl;
+  // CGp.cpp:1583-1604
+  if(isSparseApproximation())
+    os << "Sparse Approximation GP Model:" << std::endl << "Approx type: " << getApproximationStr() << std::endl;
+  else
+    os << "Standard GP Model: " << std::endl;
   os << "Optimiser: " << getDefaultOptimiserStr() << std::endl;
   os << "Data Set Size: " << getNumData() << std::endl;
   os << "Kernel Type: " << std::endl;
   os << "Scales learnt: " << isOutputScaleLearnt() << std::endl;
   os << "X learnt: " << isOptimiseX() << std::endl;
-  os << "Bias: " << bias << std::endl;
-  os << "Scale: " << scale << std::endl;
+  os << "Bias: ";
+  showRow(os, bias);
+  os << std::endl;
+  os << "Scale: ";
+  showRow(os, scale);
+  os << std::endl;
   pnoise->display(os);
   pkern->display(os);
+  if(isSparseApproximation()) {
+    os << "Inducing fixed: " << isInducingFixed() << std::endl;
+    os << "Beta Value: " << getBetaVal() << std::endl;
+  }
   if(py && pX) os << "Log likelihood: " << logLikelihood() << std::endl;   // a model read from a file has no data yet
 }
 

@@ -55,6 +55,17 @@ class CGp : public CProbabilisticOptimisable {
   double getBiasVal(unsigned int j) const { return bias.getVal(j); }
   void setBetaVal(double v) { betaVal = v; KupToDate = false; AlphaUpToDate = false; }   // noise precision (DTC)
   double getBetaVal() const { return betaVal; }
+  std::string getApproximationStr() const   // CGp.h:209-224
+  {
+    switch(approxType) {
+    case FTC: return "ftc";
+    case DTC: return "dtc";
+    case DTCVAR: return "dtcvar";
+    case FITC: return "fitc";
+    case PITC: return "pitc";
+    default: throw ndlexceptions::Error("Unknown approximation type");
+    }
+  }
   void setInducingFixed(bool v) { inducingFixed = v; }
   bool isInducingFixed() const { return inducingFixed; }
   void setOutputScaleLearnt(bool v)

@@ -1,6 +1,10 @@
 // CGplvm.cpp -- see CGplvm.h.  Host side: parameter vector, PCA start, dirty flag; everything O(N^2) and up is a call
 // into libgpc_hip.so.
+#include <sstream>
+#include <fstream>
+#include <cstdlib>
 #include "CGplvm.h"
+#include "ndlstream.h"
 #include <cmath>
 #include <cstdlib>
 #include <fstream>
@@ -72,7 +76,7 @@ void jacobiEig(std::vector<double>& a, int n, std::vector<double>& w, std::vecto
 }  // namespace
 
 CGplvm::CGplvm(CKern* kernel, CScaleNoise* nois, int latDim, int verbos)
-    : pX(new CMatrix()), pkern(kernel), pnoise(nois), latentDim((unsigned int)latDim), dataDim(nois->getOutputDim()),
+    : pX(new CMatrix()), pkern(kernel), pnoise(nois), pYown(0), latentDim((unsigned int)latDim), dataDim(nois->getOutputDim()),
       numData(nois->getNumData()), regulariseLatent(true), KupToDate(false), dX(0), dM(0), dK(0), dA(0), dG(0), dGX(0),
       logDetK(0.0)
 {
@@ -82,10 +86,21 @@ CGplvm::CGplvm(CKern* kernel, CScaleNoise* nois, int latDim, int verbos)
   initXpca();
 }
 
+CGplvm::CGplvm()
+    : pX(new CMatrix()), pkern(0), pnoise(0), pYown(0), latentDim(0), dataDim(0), numData(0), regulariseLatent(true),
+      KupToDate(false), dX(0), dM(0), dK(0), dA(0), dG(0), dGX(0), logDetK(0.0)
+{
+}
+
 CGplvm::~CGplvm()
 {
   releaseDevice();
   delete pX;
+  if(pYown) {
+    delete pkern;
+    delete pnoise;
+    delete pYown;
+  }
 }
 
 void CGplvm::releaseDevice()
@@ -285,6 +300,105 @@ void CGplvm::toStream(std::ostream& out) const
   out << "version=0.200000" << std::endl;
   writeParamsToStream(out);
 }
+// CGplvm::readParamsFromStream (CGplvm.cpp:802-899): header fields, kernel, noise, then one row per data point
+// "Y:<d>,X:<q>[,labels:1]" = d targets, q latent coordinates and the optional integer label.
+void CGplvm::readParamsFromStream(std::istream& in)
+{
+  using namespace ndlstream;
+  const std::string tbase = readField(in, "baseType");
+  if(tbase != "dataModel")
+    throw ndlexceptions::StreamFormatError("baseType", "Error mismatch between saved base type, " + tbase + ", and Class base type, dataModel.");
+  const std::string ttype = readField(in, "type");
+  if(ttype != "gplvm")
+    throw ndlexceptions::StreamFormatError("type", "Error mismatch between saved type, " + ttype + ", and Class type, gplvm.");
+  numData = (unsigned int)readInt(in, "numData");
+  dataDim = (unsigned int)readInt(in, "outputDim");
+  latentDim = (unsigned int)readInt(in, "inputDim");
+  regulariseLatent = readBool(in, "latentRegularised");
+  if(readBool(in, "backConstrained"))
+    throw ndlexceptions::NotImplementedError("back-constrained GP-LVM models are outside the accelerated path");
+  if(readBool(in, "dynamicsLearnt"))
+    throw ndlexceptions::NotImplementedError("GP-LVM models with dynamics are outside the accelerated path");
+  pkern = readKernFromStream(in);
+  // the noise block: CScaleNoise, parameters [bias..., scale...]
+  readVersion(in);
+  if(readField(in, "baseType") != "noise") throw ndlexceptions::StreamFormatError("baseType", "noise block expected");
+  const std::string ntype = readField(in, "type");
+  if(ntype != "scale") throw ndlexceptions::StreamFormatError("type", "Noise type " + ntype + " is outside the GP-LVM path (scale)");
+  const unsigned int outDim = (unsigned int)readInt(in, "outputDim"), numPar = (unsigned int)readInt(in, "numParams");
+  if(outDim != dataDim || numPar != 2 * outDim)
+    throw ndlexceptions::StreamFormatError("numParams", "Number of parameters in file does not match computed number.");
+  CMatrix par(1, numPar);
+  par.fromStream(in);
+  // data rows
+  std::string line;
+  if(!ndlstream::getline(in, line)) throw ndlexceptions::StreamFormatError("Y", "data header missing");
+  bool labelsPresent = false;
+  {
+    std::stringstream hs(line);
+    std::string tok;
+    while(std::getline(hs, tok, ',')) {
+      const size_t c = tok.find(':');
+      if(c == std::string::npos) throw ndlexceptions::StreamFormatError("Y", "bad data header: " + line);
+      const std::string key = tok.substr(0, c);
+      const long val = std::atol(tok.substr(c + 1).c_str());
+      if(key == "Y" && (unsigned int)val != dataDim) throw ndlexceptions::StreamFormatError("Y", "data dimension mismatch");
+      if(key == "X" && (unsigned int)val != latentDim) throw ndlexceptions::StreamFormatError("X", "latent dimension mismatch");
+      if(key == "labels") labelsPresent = (val != 0);
+    }
+  }
+  pYown = new CMatrix(numData, dataDim);
+  pX->resize(numData, latentDim);
+  labels.clear();
+  for(unsigned int i = 0; i < numData; i++) {
+    if(!ndlstream::getline(in, line)) throw ndlexceptions::StreamFormatError("Y", "Incorrect number of data rows.");
+    std::istringstream ss(line);
+    std::string tok;
+    for(unsigned int j = 0; j < dataDim; j++) {
+      if(!(ss >> tok)) throw ndlexceptions::StreamFormatError("Y", "short data row");
+      pYown->setVal(std::strtod(tok.c_str(), 0), i, j);
+    }
+    for(unsigned int j = 0; j < latentDim; j++) {
+      if(!(ss >> tok)) throw ndlexceptions::StreamFormatError("X", "short data row");
+      pX->setVal(std::strtod(tok.c_str(), 0), i, j);
+    }
+    if(labelsPresent) {
+      if(!(ss >> tok)) throw ndlexceptions::StreamFormatError("labels", "short data row");
+      labels.push_back(std::atoi(tok.c_str()));
+    }
+  }
+  pnoise = new CScaleNoise(pYown);
+  pnoise->setParams(par);
+  pnoise->computeM(m);
+  releaseDevice();
+  KupToDate = false;
+}
+void CGplvm::fromStream(std::istream& in)
+{
+  ndlstream::readVersion(in);
+  readParamsFromStream(in);
+}
+CGplvm* readGplvmFromStream(std::istream& in)
+{
+  CGplvm* pmodel = new CGplvm();
+  try {
+    pmodel->fromStream(in);
+  } catch(...) {
+    delete pmodel;
+    throw;
+  }
+  return pmodel;
+}
+CGplvm* readGplvmFromFile(const std::string modelFileName, int verbosity)
+{
+  if(verbosity > 0) std::cout << "Loading model file." << std::endl;
+  std::ifstream in(modelFileName.c_str());
+  if(!in.is_open()) throw ndlexceptions::FileReadError(modelFileName);
+  CGplvm* pmodel = readGplvmFromStream(in);
+  if(verbosity > 0) std::cout << "... done." << std::endl;
+  return pmodel;
+}
+
 void writeGplvmToStream(const CGplvm& model, std::ostream& out) { model.toStream(out); }
 void writeGplvmToFile(const CGplvm& model, const std::string modelFileName, const std::string comment)
 {

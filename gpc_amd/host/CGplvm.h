@@ -23,6 +23,7 @@
 class CGplvm : public CProbabilisticOptimisable {
  public:
   CGplvm(CKern* kernel, CScaleNoise* nois, int latDim = 2, int verbos = 2);   // CGplvm.cpp:17-36 (runs initXpca)
+  CGplvm();   // empty model for readGplvmFromStream (CGplvm.cpp:905-910): owns the kernel, noise and Y it reads
   ~CGplvm();
 
   void initXpca();                              // CGplvm.cpp:157-192
@@ -54,6 +55,8 @@ class CGplvm : public CProbabilisticOptimisable {
   // text model file (CGplvm.cpp:761-800)
   void writeParamsToStream(std::ostream& out) const;
   void toStream(std::ostream& out) const;
+  void readParamsFromStream(std::istream& in);   // CGplvm.cpp:802-899
+  void fromStream(std::istream& in);
 
   CMatrix* pX;    // latent points (owned; public in the reference as well, CGplvm.h:260)
   CMatrix m;      // centred / scaled targets (CGplvm.h:263)
@@ -63,6 +66,7 @@ class CGplvm : public CProbabilisticOptimisable {
   void releaseDevice();
   CKern* pkern;
   CScaleNoise* pnoise;
+  CMatrix* pYown;   // non-null when the model was read from a stream: Y, the kernel and the noise model are its own
   unsigned int latentDim, dataDim, numData;
   bool regulariseLatent;
   std::vector<int> labels;
@@ -79,4 +83,6 @@ class CGplvm : public CProbabilisticOptimisable {
 
 void writeGplvmToStream(const CGplvm& model, std::ostream& out);
 void writeGplvmToFile(const CGplvm& model, const std::string modelFileName, const std::string comment = "");
+CGplvm* readGplvmFromStream(std::istream& in);
+CGplvm* readGplvmFromFile(const std::string modelFileName, int verbosity = 2);
 #endif

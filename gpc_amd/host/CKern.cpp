@@ -408,9 +408,9 @@ void CCmpndKern::writeParamsToStream(std::ostream& out) const
 }
 std::ostream& CCmpndKern::display(std::ostream& os) const
 {
-  os << "Compound kernel:" << std::endl;
-  for(size_t i = 0; i < components.size(); i++) components[i]->display(os);
-  return os;
+  // the reference has no override: CKern::display lists the concatenated parameters under their compound names
+  // ("rbfinverseWidth: ...", CKern.cpp:66-74, CKern.h:402-414)
+  return CKern::display(os);
 }
 
 // ---- model-file reader (reference CKern.cpp:100-112, 125-140, 4192-4260) ----------------------------------------------

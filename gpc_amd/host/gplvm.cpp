@@ -18,12 +18,14 @@ class CClgplvm : public CClctrl {
  public:
   CClgplvm(int argc, char** argv) : CClctrl(argc, argv) {}
   void learn();
+  void display();
   void helpInfo();
 };
 
 void CClgplvm::helpInfo()
 {
-  std::cout << "gplvm [-v verbosity] [-s seed] learn [-x latentDim] [-k kernel [-g gamma] [-v variance] [-i 0|1]]...\n"
+  std::cout << "gplvm display [modelFile]\n"
+               "gplvm [-v verbosity] [-s seed] learn [-x latentDim] [-k kernel [-g gamma] [-v variance] [-i 0|1]]...\n"
                "      [-C 0|1] [-S 0|1] [-R 0|1] [-# iterations] [-O scg] trainData.svml [modelFile]\n"
                "kernels: rbf (with -i 1: rbfard), lin.  bias and white terms are always appended.\n";
 }
@@ -174,6 +176,26 @@ void CClgplvm::learn()
   }
 }
 
+// gplvm display [modelFile]  (gplvm.cpp:562-590)
+void CClgplvm::display()
+{
+  incrementArgument();
+  setMode("display");
+  while(isFlags()) {
+    if(isCurrentArgumentFlag()) {
+      if(isCurrentArg("-?", "--?") || isCurrentArg("-h", "--help")) { helpInfo(); exitNormal(); }
+      else unrecognisedFlag();
+      incrementArgument();
+    } else {
+      setFlags(false);
+    }
+  }
+  const std::string modelFileName = (getCurrentArgumentNo() >= argc) ? "gplvm_model" : getCurrentArgument();
+  CGplvm* pmodel = readGplvmFromFile(modelFileName, getVerbosity());
+  pmodel->display(std::cout);
+  delete pmodel;
+}
+
 int main(int argc, char* argv[])
 {
   CClgplvm command(argc, argv);
@@ -192,8 +214,11 @@ int main(int argc, char* argv[])
       } else if(command.getCurrentArgumentNo() < argc && command.getCurrentArgument() == "learn") {
         command.learn();
         return 0;
+      } else if(command.getCurrentArgumentNo() < argc && command.getCurrentArgument() == "display") {
+        command.display();
+        return 0;
       } else {
-        command.exitError("Invalid gplvm command provided (this build implements `learn`).");
+        command.exitError("Invalid gplvm command provided (learn, display).");
       }
     }
   } catch(ndlexceptions::Error& err) {

@@ -351,6 +351,34 @@ def readme_golden():
          model_bias=flat[1], kern_params=np.array(flat[2:6]), line_data=line, error_bar_data=eb)
 
 
+def gplvm_readme_golden():
+    """The README's GP-LVM tutorial (README.md:512-560): `gplvm -v 3 learn -# 100 examples/oilTrain100.svml oil100.model`
+    then `gplvm display oil100.model`, by the compiled reference: SCG trajectory, final kernel parameters, the model
+    file it wrote (kept as oil100_ref.model: an OUTPUT of the reference, the reader's fixture) and what its display
+    printed for it."""
+    import re
+    import shutil
+    import subprocess
+    import tempfile
+    ref = os.path.join(ROOT, "oracle", "_ref", "gplvm")
+    svml = os.path.join(OUT, "oilTrain100.svml")       # copy of the reference's examples/oilTrain100.svml (a data file)
+    env = dict(os.environ, LD_PRELOAD=refrun.MKL)
+    with tempfile.TemporaryDirectory() as td:
+        r = subprocess.run([ref, "-v", "3", "learn", "-#", "100", svml, "oil100.model"], env=env, cwd=td, stdin=subprocess.DEVNULL,
+                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT, check=True)
+        log = r.stdout.decode()
+        its = re.findall(r"^Iteration: (\d+) Error: (\S+) Scale: (\S+)$", log, flags=re.M)
+        r = subprocess.run([ref, "display", "oil100.model"], env=env, cwd=td, stdin=subprocess.DEVNULL, stdout=subprocess.PIPE,
+                           stderr=subprocess.STDOUT, check=True)
+        shown = r.stdout.decode()
+        lines = [ln for ln in open(os.path.join(td, "oil100.model")) if not ln.startswith("#")]   # drop the command-line comment
+        open(os.path.join(OUT, "oil100_ref.model"), "w").writelines(lines)
+        rows = [ln.split() for ln in lines if ln.startswith("0x") or re.match(r"^-?\d", ln)]
+        kern = [float.fromhex(t) if "x" in t else float(t) for row in rows[:3] for t in row]
+    save("oil100_readme", errors=np.array([float(e) for _, e, _ in its]), n_iters=len(its), kern_params=np.array(kern),
+         display=np.frombuffer(shown.encode(), dtype=np.uint8))
+
+
 def gnuplot_golden():
     """`gp gnuplot` of the compiled reference (the CLI's route to predictions, gp.cpp:567-905) on the sinc data: for the
     FTC model sinc_ref_final.model at the default resolution, and for a DTC model the reference learns here
@@ -377,6 +405,10 @@ def gnuplot_golden():
         shutil.copy(os.path.join(td, "dtc.model"), os.path.join(OUT, "sinc_ref_dtc40.model"))
         arrays = {k: table(os.path.join(td, k + ".dat")) for k in
                   ("f_line_data", "f_error_bar_data", "f_scatter_data", "s_line_data", "s_error_bar_data", "s_active_set")}
+        for key, mf in (("f_display", os.path.join(OUT, "sinc_ref_final.model")), ("s_display", os.path.join(td, "dtc.model"))):
+            r = subprocess.run([ref_gp, "display", mf], env=env, stdin=subprocess.DEVNULL, stdout=subprocess.PIPE,
+                               stderr=subprocess.STDOUT, check=True, cwd=td)
+            arrays[key] = np.frombuffer(r.stdout, dtype=np.uint8)       # what the reference's `gp display` prints
         arrays["f_plot"] = np.frombuffer(open(os.path.join(td, "f_plot.gp"), "rb").read(), dtype=np.uint8)
         arrays["s_plot"] = np.frombuffer(open(os.path.join(td, "s_plot.gp"), "rb").read(), dtype=np.uint8)
     save("sinc_gnuplot", **arrays)
@@ -399,3 +431,4 @@ if __name__ == "__main__":
         gnuplot_golden()
     if what in ("all", "readme"):
         readme_golden()
+        gplvm_readme_golden()

@@ -128,6 +128,6 @@ def test_gp_learn_dtc_cli_on_sinc(golden, tmp_path):
     ll = float(re.findall(r"^Log likelihood: (\S+)$", out, flags=re.M)[-1])
     assert abs(ll - float(g["ll40_printed"])) <= 2e-2 * abs(float(g["ll40_printed"]))
     shown = run(["display", m40])
-    assert "Compound kernel:" in shown
+    assert "compound kernel:" in shown
     txt = open(m40).read()
     assert "sparseApproximation=1" in txt and "numActive=10" in txt and "fixInducing=0" in txt

@@ -170,10 +170,10 @@ def test_gp_display_reads_the_reference_model_file():
         pytest.skip("host layer not built")
     g = dict(np.load(os.path.join(GOLDEN, "sinc_relearn.npz")))
     out = _run([os.path.join(HOST, "gp"), "display", os.path.join(GOLDEN, "sinc_ref_final.model")])
-    vals = [float(v) for v in re.findall(r"^(?:inverseWidth|variance): (\S+)$", out, flags=re.M)]
+    vals = [float(v) for v in re.findall(r"^(?:rbfinverseWidth|rbfvariance|biasvariance|whitevariance): (\S+)$", out, flags=re.M)]
     assert len(vals) == 4
     assert np.allclose(vals, g["final"][2:6], rtol=2e-6)          # printed with 6 significant digits
-    assert "Data Set Size: 40" in out and "Compound kernel:" in out
+    assert "Data Set Size: 40" in out and "compound kernel:" in out
 
 
 @pytest.mark.gpu
@@ -189,7 +189,7 @@ def test_gp_relearn_continues_like_the_reference(tmp_path):
     assert rel(got[2:6], g["relearn30"][2:6]) < 1e-6
     assert abs(got[1] - g["relearn30"][1]) < 1e-15 and got[0] == 1.0
     out = _run([os.path.join(HOST, "gp"), "display", str(new)])
-    assert "Compound kernel:" in out
+    assert "compound kernel:" in out
     import shutil
     keep = os.path.join(ROOT, "gpurun_out")
     if os.path.isdir(keep):
@@ -260,3 +260,34 @@ def test_readme_tutorial_on_the_larger_data_set(tmp_path):
     # predictions of two models from neighbouring points of that ridge: inside the data they agree to 1e-2 of the range
     inside = slice(len(line) // 6, -len(line) // 6)
     assert np.abs(line[inside, 1] - g["line_data"][inside, 1]).max() <= 1e-2 * (np.abs(g["line_data"][:, 1]).max() + 1.0)
+
+
+@pytest.mark.parametrize("exe,model,npz,key", [("gp", "sinc_ref_final.model", "sinc_gnuplot", "f_display"),
+                                               ("gp", "sinc_ref_dtc40.model", "sinc_gnuplot", "s_display"),
+                                               ("gplvm", "oil100_ref.model", "oil100_readme", "display")])
+def test_display_prints_what_the_reference_prints(exe, model, npz, key):
+    """`gp display` / `gplvm display` on model files written by the reference: byte for byte the text the reference's
+    own display command prints for them (FTC, DTC and GP-LVM models).  Host-only: no kernel is launched."""
+    want = np.load(os.path.join(GOLDEN, npz + ".npz"))[key].tobytes().decode()
+    got = _run([os.path.join(HOST, exe), "display", os.path.join(GOLDEN, model)])
+    assert got == want
+
+
+@pytest.mark.gpu
+def test_readme_gplvm_tutorial(tmp_path):
+    """README.md:512-560: `gplvm -v 3 learn -# 100 examples/oilTrain100.svml oil100.model` (default rbf + bias + white
+    kernel, N = 100, 12 outputs, 2 latent dimensions; all 100 iterations are used) then `gplvm display`: the SCG
+    trajectory of the compiled reference, then its end state."""
+    g = dict(np.load(os.path.join(GOLDEN, "oil100_readme.npz")))
+    out = _run([os.path.join(HOST, "gplvm"), "-v", "3", "learn", "-#", "100", os.path.join(GOLDEN, "oilTrain100.svml"),
+                "oil100.model"], cwd=str(tmp_path))
+    its = re.findall(r"^Iteration: (\d+) Error: (\S+) Scale: (\S+)$", out, flags=re.M)
+    errs = np.array([float(e) for _, e, _ in its])
+    assert len(errs) == int(g["n_iters"]) == 100
+    # 204 optimised variables, -ll from -674 to -2023: 6 printed digits for the first 30 iterations, 1e-3 relative at the end
+    assert np.all(np.abs(errs[:30] - g["errors"][:30]) <= 2e-5 * np.abs(g["errors"][:30]))
+    assert np.all(np.abs(errs - g["errors"]) <= 1e-3 * np.abs(g["errors"]))
+    shown = _run([os.path.join(HOST, "gplvm"), "display", "oil100.model"], cwd=str(tmp_path))
+    vals = [float(v) for v in re.findall(r"^(?:rbfinverseWidth|rbfvariance|biasvariance|whitevariance): (\S+)$", shown, flags=re.M)]
+    assert len(vals) == 4 and rel(vals, g["kern_params"]) < 5e-2
+    assert "Data Set Size: 100" in shown and "Latent space regularised: 1" in shown
