@@ -108,7 +108,7 @@ def test_chol_fixture(api, golden):
         assert np.abs(api.to_host(A) - g[key]).max() < MATCHTOL
 
 
-@pytest.mark.parametrize("N", [1, 2, 63, 64, 65, 200, 513, 1000, 2500])
+@pytest.mark.parametrize("N", [1, 2, 63, 64, 65, 127, 129, 200, 513, 1000, 1089, 2500, 4133])
 @pytest.mark.parametrize("uplo", ["L", "U"])
 def test_potrf_vs_numpy(api, N, uplo):
     A = spd(N, N)
@@ -161,7 +161,7 @@ def test_logdet_and_trace(api):
     assert abs(api.logdet_chol(Ad) - ld) < 1e-9 * abs(ld)
 
 
-@pytest.mark.parametrize("N", [5, 64, 100, 333, 1024])
+@pytest.mark.parametrize("N", [5, 64, 100, 129, 333, 1024, 2500])
 @pytest.mark.parametrize("uplo", ["L", "U"])
 def test_potri_vs_numpy(api, N, uplo):
     A = spd(N, N + 1)
@@ -209,7 +209,7 @@ def test_trsm_fixture_all_16_variants(api, golden):
 
 @pytest.mark.parametrize("side,uplo,trans,diag", [("L", "L", "N", "N"), ("L", "L", "T", "N"), ("L", "U", "N", "U"),
                                                   ("R", "L", "T", "N"), ("R", "U", "N", "N"), ("R", "L", "N", "U")])
-@pytest.mark.parametrize("M,Nrhs", [(300, 1), (200, 300), (1000, 65)])
+@pytest.mark.parametrize("M,Nrhs", [(300, 1), (200, 300), (1000, 65), (700, 1100), (130, 129)])
 def test_trsm_vs_numpy(api, side, uplo, trans, diag, M, Nrhs):
     rng = np.random.RandomState(M + Nrhs)
     nt = M if side == "L" else Nrhs
@@ -554,6 +554,31 @@ def test_cfg3_full_size_properties(api):
     Z = Kfull @ (inv @ E)
     assert float((Z - E).abs().max()) < 1e-9
     assert torch.equal(inv[idx, :], inv[:, idx].t())
+
+
+@pytest.mark.parametrize("N", [24000, 24700, 28700, 33000])
+def test_potrf_across_the_panel_chain_switches(api, N):
+    """Sizes either side of the points where the factorisation changes kernels (fused four-wave panel steps up to
+    24 576 rows, look-ahead from 28 672 columns), ragged (N % 64 != 0): L L' against the Gram matrix on sampled
+    columns, log-determinant against the sum over the factor's diagonal, and the triangular solves through the factor."""
+    import torch
+    from gpc_amd import synth
+    X, y = synth.make_xy(N, 8, N)
+    ks = api.kspec([("rbf", [0.5, 1.0]), ("white", [0.05])])
+    Xd = api.from_host(X)
+    K = api.gram_sym(ks, Xd)
+    idx = [0, 63, 64, 1023, 1024, 12345, N - 65, N - 1]
+    Kcols = K[:, idx].clone()
+    L, logdet, jit, info = api.gp_update_k(ks, Xd, K)
+    assert info == 0 and jit == 0.0
+    for q, j in enumerate(idx):
+        col = L[j:, :j + 1] @ L[j, :j + 1]
+        assert float((col - Kcols[j:, q]).abs().max()) < 1e-11
+    assert abs(logdet - 2.0 * float(torch.log(torch.diagonal(L)).sum())) <= 1e-9 * abs(logdet)
+    m = api.from_host(y - y.mean())
+    alpha = api.gp_alpha(L, m)
+    Kfull = api.gram_sym(ks, Xd)
+    assert float((Kfull @ alpha - m).abs().max()) < 1e-9 * max(1.0, float(alpha.abs().max()))
 
 
 def test_gradient_reuses_the_factor_of_the_objective(api, golden):
