@@ -194,7 +194,7 @@ def main():
     fixed_nb = int(os.environ.get("GPC_NB", "0"))
     while k0 < N:
         rem = N - k0
-        nbp = fixed_nb if fixed_nb >= 64 else (1024 if rem >= 12288 else 512)   # potrf.hip panel_width()
+        nbp = fixed_nb if fixed_nb >= 64 else 1024   # potrf.hip panel_width()
         nbp = min(nbp, rem)
         m = rem - nbp
         if m > 0:
@@ -227,6 +227,9 @@ def main():
             inv.copy_(K)
             t_potri, _ = timed(lambda: api.potri(inv, "L"))                # CMatrix::pdinv for the gradient
             phases.update({"potri_ms": t_potri, "potri_tflops_at_2N3_over_3": 2.0 * N ** 3 / 3.0 / (t_potri * 1e-3) * 1e-12})
+            # CKern::getGradParams over a symmetric N x N covGrad (the inverse stands in for it: same bytes, same work)
+            t_kg, _ = timed(lambda: api.kern_grad(ks, Xd, inv))
+            phases.update({"kern_grad_ms": t_kg, "kern_grad_GBs_of_4N2_bytes": 4.0 * N * N / (t_kg * 1e-3) * 1e-9})
             del inv
         except (RuntimeError, api._lib.GpcError) as e:                      # not enough HBM for the two extra N x N buffers
             phases["potri_ms"] = None

@@ -169,6 +169,213 @@ __global__ void __launch_bounds__(256) kern_grad_kernel(const KSpecDev ks, const
   }
 }
 
+// ---- symmetric fast path: kernels without an ARD term, D <= 32 -----------------------------------------------------------
+// covGrad is symmetric (CGp::updateCovGradient mirrors it, CGp.cpp:666-679), so only the tiles left of and inside a row
+// block's diagonal block are visited: half the covGrad bytes, half the dot products and exponentials, tiles strictly
+// left of the diagonal block counting twice.  The structure is gram_sym_kernel's (gram.hip): the row block's MFMA
+// operand fragments stay in registers for the whole walk, the 64-column tile is double-buffered in LDS with the next
+// one's rows in flight, x_i.x_j comes out of v_mfma_f64_16x16x4 -- and where that kernel stores K(i,j), this one loads
+// covGrad(i,j) (same access pattern: 128-byte runs along i) and accumulates the per-parameter sums.
+// HBM-read bound: 4 N^2 bytes.  Partial sums per workgroup in the NP_MAIN layout of kern_grad_kernel, added on the host
+// in a fixed order (deterministic).
+constexpr int GMI = 128, GMJ = 64, GSJ = 80, GMDC = 32, GSI = 144;
+typedef double gdouble4 __attribute__((ext_vector_type(4)));
+
+template <int NRBF, int NK>
+__global__ void __launch_bounds__(256, 2) kern_grad_sym_kernel(const KSpecDev ks, const GradArgs g, int jt_per_block,
+                                                               double* __restrict__ partial)
+{
+  __shared__ double Xj[2][GMDC * GSJ];
+  __shared__ double Nj[2][GMJ];
+  __shared__ double Xi[NK > 2 ? GMDC * GSI : 1];
+  __shared__ double sh[4];
+  const int t = threadIdx.x;
+  const int lane = t & 63, w = t >> 6;
+  const int wm = w & 1, wn = w >> 1;
+  const int64_t i0 = (int64_t)blockIdx.x * GMI;
+  double* mypartial = partial + ((int64_t)blockIdx.x * gridDim.y + blockIdx.y) * NP_MAIN;
+  int64_t tiles_j = (g.N + GMJ - 1) / GMJ;
+  if(tiles_j > 2 * ((int64_t)blockIdx.x + 1)) tiles_j = 2 * ((int64_t)blockIdx.x + 1);
+  const int64_t jt0 = (int64_t)blockIdx.y * jt_per_block;
+  int64_t jt1 = jt0 + jt_per_block;
+  if(jt1 > tiles_j) jt1 = tiles_j;
+  if(jt0 >= jt1) {
+    if(t < NP_MAIN) mypartial[t] = 0.0;
+    return;
+  }
+  const int dc = (int)g.D;   // <= 4 NK
+
+  // the row block's MFMA operand fragments: in registers for D <= 8; beyond that they would push the kernel into scratch
+  // (32 doubles per lane), so there they live in LDS (Xi[k * GSI + row], the Gram kernel's conflict-free stride)
+  constexpr bool AF_LDS = (NK > 2);
+  double af[AF_LDS ? 1 : NK][4];
+  if(AF_LDS) {
+#pragma unroll
+    for(int u = 0; u < (GMDC * GMI) / 256; u++) {
+      const int idx = t + 256 * u;
+      const int kr = idx >> 7, row = idx & 127;
+      int64_t gi = i0 + row;
+      if(gi > g.N - 1) gi = g.N - 1;
+      Xi[kr * GSI + row] = (kr < dc) ? g.X[gi + (int64_t)kr * g.ldx] : 0.0;
+    }
+  } else {
+#pragma unroll
+    for(int kk = 0; kk < (AF_LDS ? 1 : NK); kk++)
+#pragma unroll
+      for(int tm = 0; tm < 4; tm++) {
+        int64_t gi = i0 + wm * 64 + tm * 16 + (lane & 15);
+        if(gi > g.N - 1) gi = g.N - 1;
+        int kr = kk * 4 + (lane >> 4);
+        if(kr > dc - 1) kr = dc - 1;
+        af[kk][tm] = g.X[gi + (int64_t)kr * g.ldx];
+      }
+  }
+  double ni[4];
+#pragma unroll
+  for(int tm = 0; tm < 4; tm++) {
+    int64_t gi = i0 + wm * 64 + tm * 16 + (lane & 15);
+    if(gi > g.N - 1) gi = g.N - 1;
+    ni[tm] = g.n1[gi];
+  }
+
+  const int ws = __builtin_amdgcn_readfirstlane(w);
+  double vj[8], vn;
+  auto prefetch = [&](int64_t jt) {
+    int64_t gj = jt * GMJ + lane;
+    if(gj > g.N - 1) gj = g.N - 1;
+#pragma unroll
+    for(int u = 0; u < 8; u++) {
+      const int d = ws + 4 * u;
+      vj[u] = 0.0;
+      if(d < dc) vj[u] = (g.X + (int64_t)d * g.ldx)[gj];
+    }
+    vn = g.n1[gj];
+  };
+  prefetch(jt0);
+
+  double s_d2e[NRBF > 0 ? NRBF : 1], s_e[NRBF > 0 ? NRBF : 1], s_lin = 0.0, s_all = 0.0, s_tr = 0.0;
+#pragma unroll
+  for(int q = 0; q < (NRBF > 0 ? NRBF : 1); q++) s_d2e[q] = s_e[q] = 0.0;
+
+  for(int64_t jt = jt0; jt < jt1; jt++) {
+    double* Xjb = Xj[(jt - jt0) & 1];
+    double* Njb = Nj[(jt - jt0) & 1];
+    const int64_t j0 = jt * GMJ;
+#pragma unroll
+    for(int u = 0; u < 8; u++) {
+      const int idx = t + 256 * u;
+      Xjb[(idx >> 6) * GSJ + (idx & 63)] = vj[u];
+    }
+    if(t < GMJ) Njb[t] = vn;
+    __syncthreads();
+    if(jt + 1 < jt1) prefetch(jt + 1);
+
+    // One 16-column half of the wave's patch at a time (products, then sums), so that only 16 accumulators and 16 + 16
+    // covGrad values are live: the full 64 x 32 patch at once needs more registers than a wave has at D = 32.  The
+    // covGrad values of a half are requested one half ahead: their latency hides behind the other half's work.
+    const bool full = (i0 + GMI <= g.N) && (j0 + GMJ <= g.N);
+    const bool mirror = (j0 + GMJ <= i0);   // strictly left of the diagonal block: every element stands for two
+    const double wgt = mirror ? 2.0 : 1.0;
+    double c[2][4][4];
+    auto load_cg = [&](int tn) {
+#pragma unroll
+      for(int r = 0; r < 4; r++) {
+        const int64_t gj = j0 + wn * 32 + tn * 16 + (lane >> 4) + 4 * r;
+        const int64_t gjc = (gj < g.N) ? gj : (g.N - 1);
+#pragma unroll
+        for(int tm = 0; tm < 4; tm++) {
+          const int64_t gi = i0 + wm * 64 + tm * 16 + (lane & 15);
+          const int64_t gic = (gi < g.N) ? gi : (g.N - 1);
+          const double v = g.cg[gic + gjc * g.ldc];
+          c[tn][r][tm] = (full || (gi < g.N && gj < g.N)) ? v : 0.0;
+        }
+      }
+    };
+    load_cg(0);
+#pragma unroll
+    for(int tn = 0; tn < 2; tn++) {
+      gdouble4 acc[4];
+#pragma unroll
+      for(int a = 0; a < 4; a++) acc[a] = (gdouble4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll(NK > 2 ? 2 : NK)
+      for(int kk = 0; kk < NK; kk++) {
+        const int kr = kk * 4 + (lane >> 4);
+        const double b = Xjb[kr * GSJ + wn * 32 + tn * 16 + (lane & 15)];
+#pragma unroll
+        for(int tm = 0; tm < 4; tm++) {
+          const double a = AF_LDS ? Xi[kr * GSI + wm * 64 + tm * 16 + (lane & 15)] : af[AF_LDS ? 0 : kk][tm];
+          acc[tm] = __builtin_amdgcn_mfma_f64_16x16x4f64(b, a, acc[tm], 0, 0, 0);
+        }
+      }
+      if(tn == 0) load_cg(1);
+#pragma unroll
+      for(int r = 0; r < 4; r++) {
+        const int jl = wn * 32 + tn * 16 + (lane >> 4) + 4 * r;
+        const int64_t gj = j0 + jl;
+        const double nj = Njb[jl];
+        // two rows at a time: enough independent exp chains to overlap, few enough to stay in registers
+#pragma unroll
+        for(int th = 0; th < 4; th += 2) {
+#pragma unroll
+          for(int u = 0; u < 2; u++) {
+            const int tm = th + u;
+            const int64_t gi = i0 + wm * 64 + tm * 16 + (lane & 15);
+            const double cw = c[tn][r][tm] * wgt;
+            const bool isdiag = (gi == gj);            // only inside the diagonal block (wgt = 1)
+            const double cm = isdiag ? 0.0 : cw;       // the diagonal takes no part in the rbf sums
+            const double dot = acc[tm][r];
+            const double d2 = fma(-2.0, dot, ni[tm] + nj);
+            s_all += cw;
+            s_tr += isdiag ? cw : 0.0;
+            s_lin = fma(cw, isdiag ? ni[tm] : dot, s_lin);
+#pragma unroll
+            for(int q = 0; q < NRBF; q++) {
+              const double e = cm * exp(-(ks.rbf_hiw[q] * d2));
+              s_d2e[q] = fma(d2, e, s_d2e[q]);
+              s_e[q] += e;
+            }
+          }
+        }
+      }
+    }
+  }
+  double out[NP_MAIN];
+#pragma unroll
+  for(int p = 0; p < NP_MAIN; p++) out[p] = 0.0;
+#pragma unroll
+  for(int q = 0; q < NRBF; q++) {
+    out[2 * q] = s_d2e[q];
+    out[2 * q + 1] = s_e[q];
+  }
+  out[11] = s_lin;
+  out[12] = s_all;
+  out[13] = s_tr;
+#pragma unroll
+  for(int p = 0; p < NP_MAIN; p++) {
+    if(p < 2 * NRBF || (p >= 11 && p <= 13)) {
+      const double rsum = block_sum(out[p], sh);
+      if(t == 0) mypartial[p] = rsum;
+    } else if(t == 0) {
+      mypartial[p] = 0.0;
+    }
+  }
+}
+
+template <int NRBF>
+int launch_grad_sym(const KSpecDev& ks, const GradArgs& g, int per, dim3 grid, double* partial, hipStream_t s)
+{
+  if(g.D <= 4)
+    hipLaunchKernelGGL((kern_grad_sym_kernel<NRBF, 1>), grid, dim3(256), 0, s, ks, g, per, partial);
+  else if(g.D <= 8)
+    hipLaunchKernelGGL((kern_grad_sym_kernel<NRBF, 2>), grid, dim3(256), 0, s, ks, g, per, partial);
+  else if(g.D <= 16)
+    hipLaunchKernelGGL((kern_grad_sym_kernel<NRBF, 4>), grid, dim3(256), 0, s, ks, g, per, partial);
+  else
+    hipLaunchKernelGGL((kern_grad_sym_kernel<NRBF, 8>), grid, dim3(256), 0, s, ks, g, per, partial);
+  GPC_HIP_CHECK(hipGetLastError());
+  return GPC_OK;
+}
+
 // per-dimension ARD sums: S_k = sum_{i != j} cg(i,j) k~(i,j) (x_ik - x_jk)^2 for k in [dim0, dim0 + 32)
 __global__ void __launch_bounds__(256) ard_dim_grad_kernel(const KSpecDev ks, const GradArgs g, int64_t dim0,
                                                            double* __restrict__ partial)
@@ -305,7 +512,15 @@ extern "C" int gpc_kern_grad_f64(const gpc_kspec* ksp, const double* X, int64_t 
   const int64_t nblk = total < 2048 ? total : 2048;
 
   void* ws = nullptr;
-  const size_t pbytes = sizeof(double) * (size_t)nblk * (NP_MAIN > ARD_PASS ? NP_MAIN : ARD_PASS);
+  // column tiles per workgroup: enough workgroups to fill the chip on a small matrix, long walks (operand fragments and
+  // the final reductions amortised) on a large one
+  const int64_t sym_nrb = (N + GMI - 1) / GMI;
+  int64_t sym_per = sym_nrb * (sym_nrb + 1) / 768;
+  if(sym_per < 4) sym_per = 4;
+  if(sym_per > 48) sym_per = 48;
+  const int64_t sym_ny = (2 * sym_nrb + sym_per - 1) / sym_per, sym_nwg = sym_nrb * sym_ny;
+  size_t pbytes = sizeof(double) * (size_t)nblk * (NP_MAIN > ARD_PASS ? NP_MAIN : ARD_PASS);
+  if(pbytes < sizeof(double) * (size_t)sym_nwg * NP_MAIN) pbytes = sizeof(double) * (size_t)sym_nwg * NP_MAIN;
   GPC_CHECK(workspace(WS_KERN, sizeof(double) * (size_t)N + pbytes, &ws));
   double* nrm = static_cast<double*>(ws);
   double* partial = nrm + N;
@@ -314,6 +529,37 @@ extern "C" int gpc_kern_grad_f64(const gpc_kspec* ksp, const double* X, int64_t 
     hipLaunchKernelGGL(row_norms_kernel2, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, X, ldx, N, D, nrm);
   }
   const bool dot = ks.need_dot != 0, ard = ks.n_ard > 0;
+  static int use_sym = -1;
+  if(use_sym < 0) {
+    const char* e = getenv("GPC_KGRAD_SYM");
+    use_sym = e ? atoi(e) : 1;
+  }
+  if(use_sym && !ard && D >= 1 && D <= GMDC && ks.n_rbf <= 2) {
+    const int64_t nrb = sym_nrb, per = sym_per, ny = sym_ny, nwg = sym_nwg;
+    const dim3 grid((unsigned)nrb, (unsigned)ny);
+    if(ks.n_rbf == 0) GPC_CHECK(launch_grad_sym<0>(ks, g, (int)per, grid, partial, s));
+    else if(ks.n_rbf == 1) GPC_CHECK(launch_grad_sym<1>(ks, g, (int)per, grid, partial, s));
+    else GPC_CHECK(launch_grad_sym<2>(ks, g, (int)per, grid, partial, s));
+    double S2[NP_MAIN];
+    GPC_CHECK(fetch_partials(partial, nwg, NP_MAIN, S2, s));
+    int ir = 0;
+    for(int t = 0; t < ksp->n_terms; t++) {
+      double* gt = gout + ksp->offs[t];
+      const double* p = ksp->params + ksp->offs[t];
+      switch(ksp->types[t]) {
+      case GPC_KERN_RBF:
+        gt[0] = -0.5 * p[1] * S2[2 * ir];
+        gt[1] = S2[13] + S2[2 * ir + 1];
+        ir++;
+        break;
+      case GPC_KERN_WHITE: gt[0] = S2[13]; break;
+      case GPC_KERN_BIAS: gt[0] = S2[12]; break;
+      case GPC_KERN_LIN: gt[0] = S2[11]; break;
+      default: break;
+      }
+    }
+    return GPC_OK;
+  }
   if(dot && ard)
     hipLaunchKernelGGL((kern_grad_kernel<true, true>), dim3((unsigned)nblk), dim3(256), 0, s, ks, g, partial);
   else if(dot)
