@@ -2,8 +2,9 @@
 //     gp [-v verbosity] [-s seed] learn [flags] trainData.svml [modelFile]
 // Same flags, defaults and model construction as the reference's `learn` (gp.cpp:86-437) for the kernels the HIP
 // path covers (rbf, lin, bias, white, `-i 1` for rbfard): kernel = cmpnd{ <-k kernels, default rbf>, bias, white },
-// Gaussian noise, bias = mean(y) unless -C 0, FTC only.  `relearn` and `display` read the reference's text model files
-// (and the ones this tool writes); `gnuplot` and the sparse approximations are outside the hot path.
+// Gaussian noise, bias = mean(y) unless -C 0; -A ftc | dtc | dtcvar | fitc with -a inducing inputs.  `relearn`, `display`
+// and `gnuplot` read the reference's text model files (and the ones this tool writes) and print / plot what the
+// reference's commands print / plot.
 #include <fstream>
 #include <cstdlib>
 #include <iostream>

@@ -1,5 +1,6 @@
 // gplvm.cpp -- the `gplvm` command line (reference gplvm.cpp:3-933) for the accelerated GP-LVM path:
 //     gplvm [-v verbosity] [-s seed] learn [flags] trainData.svml [modelFile]
+//     gplvm display [modelFile]
 // Same flags, defaults and model construction as the reference's `learn` (gplvm.cpp:86-560) for what the HIP path
 // covers: kernel = cmpnd{ <-k kernels, default rbf>, bias, white } on a q-dimensional latent space (-x, default 2),
 // CScaleNoise centred (-C) and optionally scaled (-S), PCA initialisation, latent regulariser (-R), SCG.
