@@ -293,6 +293,35 @@ def test_kern_grad_fixtures(api, golden, name):
         assert np.abs(got - want).max() < 1e-9 * max(1.0, np.abs(want).max())
 
 
+@pytest.mark.parametrize("N,D", [(1, 1), (63, 3), (129, 4), (300, 5), (517, 8), (640, 9), (700, 16), (333, 17), (900, 32), (200, 40)])
+def test_kern_grad_vs_numpy(api, N, D):
+    """the symmetric MFMA gradient kernel (D <= 32) and the generic one (D = 40) against the defining double sums, on
+    ragged sizes either side of every tile / fragment boundary: two rbf terms, lin, bias and white"""
+    rng = np.random.RandomState(N + D)
+    X = rng.randn(N, D) / np.sqrt(D)
+    cg = rng.randn(N, N)
+    cg = cg + cg.T
+    terms = [("rbf", [1.3, 0.7]), ("lin", [0.4]), ("rbf", [0.2, 1.9]), ("bias", [0.3]), ("white", [0.05])]
+    got = api.kern_grad(api.kspec(terms), api.from_host(X), api.from_host(cg))
+    G = X @ X.T
+    n = np.diag(G)
+    d2 = n[:, None] + n[None, :] - 2.0 * G
+    off = ~np.eye(N, dtype=bool)
+    want = []
+    for term in ((1.3, 0.7), None, (0.2, 1.9)):
+        if term is None:
+            want.append(float((cg * G).sum()))                                   # lin: sum cg x_i.x_j
+            continue
+        iw, var = term
+        kt = np.exp(-0.5 * iw * d2)
+        want += [float(-0.5 * var * (cg * d2 * kt)[off].sum()), float(np.trace(cg) + (cg * kt)[off].sum())]
+    want += [float(cg.sum()), float(np.trace(cg))]
+    want = np.array(want)
+    assert np.abs(got - want).max() <= 1e-11 * max(1.0, np.abs(want).max()) * max(1.0, N / 10.0)
+    again = api.kern_grad(api.kspec(terms), api.from_host(X), api.from_host(cg))
+    assert np.array_equal(got, again)                                            # fixed-order reduction
+
+
 @pytest.mark.parametrize("name", KERN_FIXTURES)
 def test_kern_grad_cross_fixtures(api, golden, name):
     """testKern.cpp:280-304: getGradTransParams(g, X, X2, covGrad2) -- the cross-Gram parameter gradient (g4)"""
