@@ -386,6 +386,8 @@ __device__ __forceinline__ double flow_poll(const double* p, int* ctl)
   for(int it = 0; it < (1 << 20); it++) {
     const unsigned long long v = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if(v != FLOW_SENT) return __longlong_as_double((long long)v);
+    // somebody else already gave up: do not wait out another timeout per dependency (bounds a failure to ~1 s in all)
+    if((it & 1023) == 1023 && __hip_atomic_load(&ctl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
     __builtin_amdgcn_s_sleep(1);
   }
   atomicExch(&ctl[1], 1);
