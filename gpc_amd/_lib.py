@@ -91,6 +91,45 @@ SIGNATURES = {
     "gpc_probe_mfma_f64": (c_int, [POINTER(c_double), POINTER(c_double), POINTER(c_double), VP]),
 }
 
+
+
+class GridTransport(Structure):
+    """struct gpc_grid_transport (include/gpc_hip.h): the caller's own exchange behind a grid."""
+    BCAST = ctypes.CFUNCTYPE(c_int, c_void_p, c_void_p, c_int64, c_int, c_int)
+    ALLREDUCE_SUM = ctypes.CFUNCTYPE(c_int, c_void_p, c_void_p, c_int64, c_int, c_int)
+    ALLREDUCE_MIN = ctypes.CFUNCTYPE(c_int, c_void_p, POINTER(c_int64))
+    _fields_ = [("ctx", c_void_p), ("bcast", BCAST), ("allreduce_sum", ALLREDUCE_SUM), ("allreduce_min_i64", ALLREDUCE_MIN)]
+
+
+GP = c_void_p   # gpc_grid*
+# the 2-D block-cyclic grid; `name -> signature` with the prefix left off, so that the CPU tests can bind the same table
+# to their host stand-in (tests/host/libgridhost.so exports gridtest_* with identical signatures)
+GRID_SIGNATURES = {
+    "unique_id": (c_int, [c_void_p]),
+    "create": (c_int, [POINTER(GP), c_int, c_int, c_int, c_int, I64, c_void_p]),
+    "create_local": (c_int, [POINTER(GP), c_int, c_int, I64, POINTER(c_int)]),
+    "create_transport": (c_int, [POINTER(GP), c_int, c_int, c_int, I64, POINTER(GridTransport)]),
+    "destroy": (c_int, [GP]),
+    "last_error": (c_char_p, [GP]),
+    "set_problem": (c_int, [GP, POINTER(KSpec), DP, I64, I64, I64, DP, I64, I64, DP, I64, I64]),
+    "set_kernel": (c_int, [GP, POINTER(KSpec)]),
+    "update_k": (c_int, [GP, POINTER(c_double), POINTER(c_double), POINTER(c_int)]),
+    "fill": (c_int, [GP]),
+    "factor": (c_int, [GP, POINTER(c_int)]),
+    "loglik": (c_int, [GP, POINTER(c_double)]),
+    "alpha": (c_int, [GP, DP, I64]),
+    "posterior": (c_int, [GP, DP, I64, DP]),
+    "sync": (c_int, [GP]),
+    "barrier": (c_int, [GP]),
+    "set_lookahead": (c_int, [GP, c_int]),
+    "info": (c_int, [GP, POINTER(c_int64)]),
+    "stats": (c_int, [GP, POINTER(c_double), c_int]),
+    "copy_tile": (c_int, [GP, I64, I64, DP, POINTER(c_int)]),
+}
+for _n, _sig in GRID_SIGNATURES.items():
+    SIGNATURES["gpc_grid_" + _n] = _sig
+SIGNATURES["gpc_grid_rccl_path"] = (c_char_p, [])
+
 _lib = None
 
 

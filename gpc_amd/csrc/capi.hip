@@ -7,6 +7,7 @@
 #include <string.h>
 #include <ctype.h>
 #include <math.h>
+#include <thread>
 
 namespace gpc {
 
@@ -38,12 +39,29 @@ int ensure_device()
   return GPC_OK;
 }
 
+// Scratch is owned per HOST THREAD (like gpc_last_error): two models driven from two threads -- or the rank threads of a
+// single-process multi-GPU grid (grid.hip) -- never share a buffer.  Within one thread the slots are shared by every
+// stream that thread launches on; the library itself only ever uses them from one stream at a time (the look-ahead
+// panel stream owns WS_PANEL_REF / WS_INFO, the trailing updates need no scratch).
 struct WsBuf {
   void* p;
   size_t bytes;
   int dev;
 };
-static WsBuf g_ws[WS_NSLOTS] = {};
+static const std::thread::id g_loader_thread = std::this_thread::get_id();
+struct WsSet {
+  WsBuf b[WS_NSLOTS] = {};
+  ~WsSet()
+  {
+    // worker threads give their scratch back when they end; the loading thread's set lives as long as the process
+    // (its destructor would run after the HIP runtime has been torn down)
+    if(std::this_thread::get_id() == g_loader_thread) return;
+    for(int i = 0; i < WS_NSLOTS; i++)
+      if(b[i].p) (void)hipFree(b[i].p);
+  }
+};
+static thread_local WsSet g_wsset;
+#define g_ws g_wsset.b
 
 int workspace(int slot, size_t bytes, void** out)
 {

@@ -22,13 +22,14 @@
 #include "gpc_common.hpp"
 #include <math.h>
 #include <stdlib.h>
+#include <atomic>
 
 namespace gpc {
 
-int g_gemm_trailing = 0;  // TrailingScope (gpc_common.hpp)
-int g_gemm_kstart = 0;    // KStartScope (gpc_common.hpp)
-extern int g_stair_args_set;
-extern int64_t g_stair[4];
+thread_local int g_gemm_trailing = 0;  // TrailingScope (gpc_common.hpp); per host thread
+thread_local int g_gemm_kstart = 0;    // KStartScope (gpc_common.hpp)
+extern thread_local int g_stair_args_set;
+extern thread_local int64_t g_stair[4];
 int g_gemm_variant = -1;  // -1: read GPC_GEMM_VARIANT on first use; 0 generic only; 1 fast 4-wave; 2 fast 8-wave
 
 namespace {
@@ -62,7 +63,14 @@ struct GemmArgs {
                          //   gcol(c) = (stair_j0 + (c / stair_nb) * stair_pstride) * stair_nb + c % stair_nb,
                          //   row m of A / C is global row stair_row0 + m, the B operand row for column c is
                          //   gcol(c) - stair_row0, and only global_row >= global_col is written
+                         // 5 2-D block-cyclic staircase (fast NT kernel only; grid.hip): C is the local block of a pr x pc
+                         //   grid.  nb-row-tile t of A / C is GLOBAL tile st_I0 + t * st_pr, nb-column-tile u is GLOBAL
+                         //   tile st_J0 + u * st_pc; tiles with I < J are skipped, I == J writes its lower triangle.
+                         //   The B operand of column tile u starts at B + voff[st_jl0 + u] (leading dimension ldb): the
+                         //   column panel is kept tile by tile in the order it arrives from the process column
   int64_t stair_nb, stair_pstride, stair_j0, stair_row0;
+  int64_t st_I0, st_pr, st_J0, st_pc, st_jl0;
+  const int64_t* voff;
 };
 
 // ---- global -> registers -------------------------------------------------------------------------------------
@@ -152,7 +160,7 @@ __device__ __forceinline__ bool map_tile(const GemmArgs& g, int& ti, int& tj)
   // tiles.  Deal groups of 64 consecutive ids (about one super-tile: the L2 locality survives) round-robin instead.
   if(g.kstart) L = (((b >> 3) >> 6) * 8u + (b & 7u)) * 64u + ((b >> 3) & 63u);
   int si, sj, di, dj;
-  if(g.tri == 4) {
+  if(g.tri == 4 || g.tri == 5) {
     // Block-cyclic staircase: which super-tiles are empty depends on the panel owner pattern, so contiguous chunks
     // would leave some XCDs with nothing but skipped tiles.  Deal whole super-tiles round-robin instead (super-tile s
     // -> XCD s % 8): each one still lives in a single L2 and the empty ones spread evenly.
@@ -344,9 +352,23 @@ __global__ void __launch_bounds__(128 * NWN, NWN) gemm_nt_fast_kernel(const Gemm
     gcol0 = (g.stair_j0 + (n0 / g.stair_nb) * g.stair_pstride) * g.stair_nb + (n0 % g.stair_nb);
     if(g.stair_row0 + m0 + BM - 1 < gcol0) return;
   }
+  // 2-D staircase: global tile coordinates of this 128 x 128 tile; roff / coff = its offsets inside the nb x nb tile
+  const double* Bop = g.B;
+  int roff = 0, coff = 0;
+  bool diag5 = false;
+  if(g.tri == 5) {
+    const int64_t rt = m0 / g.stair_nb, ct = n0 / g.stair_nb;
+    const int64_t I = g.st_I0 + rt * g.st_pr, J = g.st_J0 + ct * g.st_pc;
+    if(I < J) return;
+    roff = (int)(m0 - rt * g.stair_nb);
+    coff = (int)(n0 - ct * g.stair_nb);
+    diag5 = (I == J);
+    if(diag5 && roff + BM - 1 < coff) return;
+    Bop = g.B + g.voff[g.st_jl0 + ct] + coff;
+  }
   // staging pointers (rows clamped into the matrix; M, N are even and >= 2 on this path)
-  int64_t ra = m0 + 2 * lane, rb = (g.tri == 4 ? gcol0 - g.stair_row0 : n0) + 2 * lane;
-  const int64_t rbmax = (g.tri == 4 ? g.M : g.N) - 2;
+  int64_t ra = m0 + 2 * lane, rb = (g.tri == 4 ? gcol0 - g.stair_row0 : (g.tri == 5 ? 0 : n0)) + 2 * lane;
+  const int64_t rbmax = (g.tri == 4 ? g.M : (g.tri == 5 ? BN : g.N)) - 2;
   if(g.debug_same_rows) {  // ablation: every tile reads operand rows 0..127 (all L2 hits); results are wrong
     ra = 2 * lane;
     rb = 2 * lane;
@@ -357,7 +379,7 @@ __global__ void __launch_bounds__(128 * NWN, NWN) gemm_nt_fast_kernel(const Gemm
   // upper-triangular operands (potri's V V'): rows >= m0 of A are zero left of column m0, so the product starts there
   const int64_t kfirst = g.kstart ? (m0 / BK) * BK : 0;
   const double* pa = g.A + ra + ((int64_t)(t >> 6) + kfirst) * g.lda;
-  const double* pb = g.B + rb + ((int64_t)(t >> 6) + kfirst) * g.ldb;
+  const double* pb = Bop + rb + ((int64_t)(t >> 6) + kfirst) * g.ldb;
   const int64_t stepa = (int64_t)KROWS * g.lda, stepb = (int64_t)KROWS * g.ldb;
   const int64_t stagea = (int64_t)BK * g.lda, stageb = (int64_t)BK * g.ldb;
   const int lds_w = (t >> 6) * STRIDE_MC + 2 * lane;  // [k][m] image, k = (t>>6) + KROWS*i
@@ -427,7 +449,7 @@ __global__ void __launch_bounds__(128 * NWN, NWN) gemm_nt_fast_kernel(const Gemm
 
   const double alpha = g.alpha, beta = g.beta;
   const bool full_mn = (m0 + BM <= g.M) && (n0 + BN <= g.N);
-  const bool diag_tile = (g.tri != 0) && (ti == tj);
+  const bool diag_tile = (g.tri != 0 && g.tri < 4) && (ti == tj);
 #pragma unroll
   for(int tn = 0; tn < NT; tn++) {
 #pragma unroll
@@ -438,6 +460,7 @@ __global__ void __launch_bounds__(128 * NWN, NWN) gemm_nt_fast_kernel(const Gemm
         const int64_t n = n0 + wn * (16 * NT) + tn * 16 + (lane >> 4) + 4 * r;
         bool ok = full_mn || (m < g.M && n < g.N);
         if(g.tri == 4) ok = ok && (g.stair_row0 + m >= gcol0 + (n - n0));
+        else if(g.tri == 5) ok = ok && (!diag5 || roff + (int)(m - m0) >= coff + (int)(n - n0));
         else if(diag_tile) ok = ok && (g.tri == 2 ? (m <= n) : (m >= n));
         if(ok) {
           double* p = g.C + m + n * g.ldc;
@@ -461,12 +484,14 @@ __global__ void __launch_bounds__(128 * NWN, NWN) gemm_nt_fast_kernel(const Gemm
 template <int NWN, int ROLE>
 int launch_fast_role(const GemmArgs& g, unsigned grid, hipStream_t s)
 {
-  static bool attr_set = false;
+  static std::atomic<uint64_t> attr_set{0};   // one bit per device: the attribute is per device and per function
   auto kern = gemm_nt_fast_kernel<NWN, ROLE>;
-  if(!attr_set) {
+  int dev = 0;
+  GPC_HIP_CHECK(hipGetDevice(&dev));
+  if(!(attr_set.load() >> (dev & 63) & 1)) {
     GPC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES));
-    attr_set = true;
+    attr_set.fetch_or(1ull << (dev & 63));
   }
   hipLaunchKernelGGL(kern, dim3(grid), dim3(128 * NWN), GEMM_LDS_BYTES, s, g);
   GPC_HIP_CHECK(hipGetLastError());
@@ -483,12 +508,14 @@ int launch_fast(const GemmArgs& g, unsigned grid, hipStream_t s)
 template <bool A_KC, bool B_KC, bool VEC>
 int launch(const GemmArgs& g, unsigned grid, hipStream_t s)
 {
-  static bool attr_set = false;
+  static std::atomic<uint64_t> attr_set{0};
   auto kern = gemm_f64_kernel<A_KC, B_KC, VEC>;
-  if(!attr_set) {
+  int dev = 0;
+  GPC_HIP_CHECK(hipGetDevice(&dev));
+  if(!(attr_set.load() >> (dev & 63) & 1)) {
     GPC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES));
-    attr_set = true;
+    attr_set.fetch_or(1ull << (dev & 63));
   }
   hipLaunchKernelGGL(kern, dim3(grid), dim3(256), GEMM_LDS_BYTES, s, g);
   GPC_HIP_CHECK(hipGetLastError());
@@ -497,8 +524,38 @@ int launch(const GemmArgs& g, unsigned grid, hipStream_t s)
 
 }  // namespace
 
+static int gemm_ex(bool transa, bool transb, int64_t M, int64_t N, int64_t K, double alpha, const double* A, int64_t lda,
+                   const double* B, int64_t ldb, double beta, double* C, int64_t ldc, int tri, const Stair2D* st2,
+                   hipStream_t s);
+
 int gemm(bool transa, bool transb, int64_t M, int64_t N, int64_t K, double alpha, const double* A, int64_t lda,
          const double* B, int64_t ldb, double beta, double* C, int64_t ldc, int tri, hipStream_t s)
+{
+  if(tri == 5) {
+    set_error("2-D staircase gemm must be called through gemm_stair2d");
+    return GPC_EINVAL;
+  }
+  return gemm_ex(transa, transb, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, tri, nullptr, s);
+}
+
+// C(local block) -= / += alpha * W * V' on the 2-D block-cyclic staircase (GemmArgs::tri == 5).  M need not be a multiple
+// of nb (the extra rows of the distributed right-hand sides hang below the last tile row); N must be.
+int gemm_stair2d(int64_t M, int64_t N, int64_t K, double alpha, const double* W, int64_t ldw, const double* Vbase,
+                 int64_t ldv, double* C, int64_t ldc, const Stair2D& st, hipStream_t s)
+{
+  if(M <= 0 || N <= 0) return GPC_OK;
+  if(st.nb <= 0 || st.nb % BN != 0 || N % st.nb != 0 || K <= 0 || K % BK != 0 || (M & 1) || (ldw & 1) || (ldv & 1) ||
+     ((reinterpret_cast<uintptr_t>(W) | reinterpret_cast<uintptr_t>(Vbase)) & 15) != 0 || st.voff == nullptr) {
+    set_error("gemm_stair2d: needs nb %% 128 == 0, N %% nb == 0, K %% 16 == 0, even M / leading dimensions, 16-byte "
+              "aligned panels and an offset table");
+    return GPC_EINVAL;
+  }
+  return gemm_ex(false, true, M, N, K, alpha, W, ldw, Vbase, ldv, 1.0, C, ldc, 5, &st, s);
+}
+
+static int gemm_ex(bool transa, bool transb, int64_t M, int64_t N, int64_t K, double alpha, const double* A, int64_t lda,
+                   const double* B, int64_t ldb, double beta, double* C, int64_t ldc, int tri, const Stair2D* st2,
+                   hipStream_t s)
 {
   if(M <= 0 || N <= 0) return GPC_OK;
   GemmArgs g;
@@ -526,6 +583,17 @@ int gemm(bool transa, bool transb, int64_t M, int64_t N, int64_t K, double alpha
   g.super_n = (g.tiles_n + SUPER - 1) / SUPER;
   g.tri = tri;
   g.stair_nb = g.stair_pstride = g.stair_j0 = g.stair_row0 = 0;
+  g.st_I0 = g.st_pr = g.st_J0 = g.st_pc = g.st_jl0 = 0;
+  g.voff = nullptr;
+  if(tri == 5) {
+    g.stair_nb = st2->nb;
+    g.st_I0 = st2->I0;
+    g.st_pr = st2->pr;
+    g.st_J0 = st2->J0;
+    g.st_pc = st2->pc;
+    g.st_jl0 = st2->jl0;
+    g.voff = st2->voff;
+  }
   if(tri == 4) {
     if(!g_stair_args_set) {
       set_error("staircase gemm must be called through syrk_blockcyclic");
@@ -550,7 +618,7 @@ int gemm(bool transa, bool transb, int64_t M, int64_t N, int64_t K, double alpha
     return GPC_EINVAL;
   }
   uint64_t slots;
-  if(tri == 4)
+  if(tri == 4 || tri == 5)
     slots = (((uint64_t)g.super_m * g.super_n + 7) / 8) * 8 * SUPER * SUPER;
   else if(tri == 0 || tri == 3)
     slots = (uint64_t)g.super_m * g.super_n * SUPER * SUPER;
@@ -573,7 +641,7 @@ int gemm(bool transa, bool transb, int64_t M, int64_t N, int64_t K, double alpha
     g_gemm_variant = e ? atoi(e) : 2;
     if(g_gemm_variant < 0 || g_gemm_variant > 2) g_gemm_variant = 2;
   }
-  if(tri == 4) return g_gemm_variant == 1 ? launch_fast<2>(g, grid, s) : launch_fast<4>(g, grid, s);
+  if(tri == 4 || tri == 5) return g_gemm_variant == 1 ? launch_fast<2>(g, grid, s) : launch_fast<4>(g, grid, s);
   if(g_gemm_variant > 0 && !a_kc && !b_kc && vec && g.K > 0 && (g.K % BK) == 0 && (M % 2) == 0 && (N % 2) == 0) {
     return g_gemm_variant == 2 ? launch_fast<4>(g, grid, s) : launch_fast<2>(g, grid, s);
   }
@@ -589,8 +657,8 @@ int gemm(bool transa, bool transb, int64_t M, int64_t N, int64_t K, double alpha
   return GPC_EINVAL;
 }
 
-int g_stair_args_set = 0;
-int64_t g_stair[4];
+thread_local int g_stair_args_set = 0;
+thread_local int64_t g_stair[4];
 
 int syrk_blockcyclic(int64_t M, int64_t ncols, int64_t K, double alpha, const double* P, int64_t ldp, double beta,
                      double* C, int64_t ldc, int64_t row0, int64_t j0, int64_t pstride, int64_t nb, hipStream_t s)

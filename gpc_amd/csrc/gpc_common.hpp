@@ -57,8 +57,18 @@ int ensure_device();
 // 3 = only i>=j for a tall C (M >= N) whose (0,0) sits on the diagonal.
 int gemm(bool transa, bool transb, int64_t M, int64_t N, int64_t K, double alpha, const double* A, int64_t lda,
          const double* B, int64_t ldb, double beta, double* C, int64_t ldc, int tri, hipStream_t s);
+// 2-D block-cyclic staircase update (grid.hip); see GemmArgs::tri == 5 in gemm_f64.hip
+struct Stair2D {
+  int64_t nb;            // tile size (multiple of 128)
+  int64_t I0, pr;        // global tile row of C's first nb-row-tile, and the stride between consecutive local tile rows
+  int64_t J0, pc;        // same for columns
+  int64_t jl0;           // absolute local column-tile index of C's first column tile (index into voff)
+  const int64_t* voff;   // DEVICE table: offset (in doubles, from Vbase) of the B operand of every local column tile
+};
+int gemm_stair2d(int64_t M, int64_t N, int64_t K, double alpha, const double* W, int64_t ldw, const double* Vbase,
+                 int64_t ldv, double* C, int64_t ldc, const Stair2D& st, hipStream_t s);
 // While one of these is alive the fast GEMM launches under its "trailing update" kernel name (see gemm_f64.hip, ROLE).
-extern int g_gemm_trailing;
+extern thread_local int g_gemm_trailing;
 // potrf.hip: the panel chain's substitution step, shared with trsm.hip (see its definition)
 int panel_solve_rt(const double* Lbb, int64_t lda, int nb, double* B, int64_t ldb, int64_t M, double* C, int64_t ldc, int nc,
                    const double* Lnext, hipStream_t s);
@@ -76,12 +86,13 @@ struct TrailingScope {
   ~TrailingScope() { g_gemm_trailing = 0; }
 };
 // While alive: A * B' products whose operands are UPPER triangular start each tile's k-loop at the tile's first row.
-extern int g_gemm_kstart;
+extern thread_local int g_gemm_kstart;
 struct KStartScope {
   KStartScope() { g_gemm_kstart = 1; }
   ~KStartScope() { g_gemm_kstart = 0; }
 };
-int potrf_lower(int64_t N, double* A, int64_t lda, int* d_info, hipStream_t s);
+// col0: global index of A's first column, added to the `info` a failing pivot reports
+int potrf_lower(int64_t N, double* A, int64_t lda, int* d_info, hipStream_t s, int64_t col0 = 0);
 int potrf_panel(int64_t M, int64_t nb, double* A, int64_t lda, int* d_info, int64_t col0, hipStream_t s);
 int syrk_blockcyclic(int64_t M, int64_t ncols, int64_t K, double alpha, const double* P, int64_t ldp, double beta,
                      double* C, int64_t ldc, int64_t row0, int64_t j0, int64_t pstride, int64_t nb, hipStream_t s);

@@ -1,0 +1,625 @@
+// grid.hip -- the 2-D block-cyclic multi-GPU factorisation behind gpc_grid_* (include/gpc_hip.h):
+// the HIP implementation of grid_sched.hpp's GridOps (the library's own Gram / potrf / trsm / MFMA staircase kernels plus
+// a few layout kernels) and the RCCL implementation of GridComm (panel broadcasts along process rows and columns over
+// xGMI; librccl is opened at run time, only when a grid with more than one process is created).
+//
+// Distributes /root/reference/CGp.cpp:698-712 (Gram) + 877-891 (jitChol -> logDet) and what CGp reads off the factor
+// (469-489, 913-938, 548-663).  One rank per GPU: one process per GPU (gpc_grid_create, RCCL) or one host thread per GPU
+// inside one process (gpc_grid_create_local).
+#include "gpc_common.hpp"
+#include "grid_sched.hpp"
+#include <rccl/rccl.h>   // types and enums only: the entry points are resolved with dlsym (no link-time dependency)
+#include <dlfcn.h>
+#include <stdlib.h>
+
+namespace gpc {
+int diag_reduce(int what, int64_t N, const double* A, int64_t lda, double* out_host, hipStream_t s);
+}
+
+namespace {
+using namespace gpc;
+using namespace gpc::grid;
+
+#define HIPOPS_CHECK(expr)                                                                            \
+  do {                                                                                                \
+    hipError_t e__ = (expr);                                                                          \
+    if(e__ != hipSuccess) {                                                                           \
+      gpc::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), __FILE__, __LINE__);     \
+      return GPC_EHIP;                                                                                \
+    }                                                                                                 \
+  } while(0)
+
+// ---- layout kernels ----------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) gather_rows_kernel(const double* __restrict__ X, int64_t N, int64_t ldx, int64_t first,
+                                                          int64_t stride, int64_t nb, int64_t rows, double* __restrict__ out,
+                                                          int64_t ldo)
+{
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if(i >= rows) return;
+  const int64_t t = i / nb;
+  int64_t g = (first + t * stride) * nb + (i - t * nb);
+  if(g > N - 1) g = N - 1;
+  out[i + (int64_t)blockIdx.y * ldo] = X[g + (int64_t)blockIdx.y * ldx];
+}
+
+__global__ void __launch_bounds__(256) add_scalar_kernel(double* v, int64_t n, double c)
+{
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if(i < n) v[i] += c;
+}
+
+// zero the rows of local tile row `il` from in-tile offset r0 on, over all ncols columns (identity padding)
+__global__ void __launch_bounds__(256) zero_rows_kernel(double* __restrict__ A, int64_t lld, int64_t row0, int64_t nrows,
+                                                        int64_t ncols)
+{
+  const int64_t i = threadIdx.x;
+  const int64_t j = (int64_t)blockIdx.x;
+  for(int64_t jj = j; jj < ncols; jj += gridDim.x)
+    for(int64_t ii = i; ii < nrows; ii += 256) A[row0 + ii + jj * lld] = 0.0;
+}
+
+// one workgroup per local tile row: the nb entries of the GLOBAL diagonal it holds (if any)
+__global__ void __launch_bounds__(256) set_diag_kernel(double* __restrict__ A, int64_t lld, int64_t nb, int r, int pr, int c,
+                                                       int pc, int64_t T, int64_t N, const double* __restrict__ dg)
+{
+  const int64_t il = blockIdx.x;
+  const int64_t I = r + (int64_t)pr * il;
+  if(I >= T || (I - c) % pc != 0 || I < c) return;
+  const int64_t jl = (I - c) / pc;
+  for(int64_t i = threadIdx.x; i < nb; i += 256) {
+    const int64_t g = I * nb + i;
+    A[il * nb + i + (jl * nb + i) * lld] = g < N ? dg[g] : 1.0;
+  }
+}
+
+__global__ void __launch_bounds__(256) put_rhs_kernel(double* __restrict__ Aex, int64_t lld, const double* __restrict__ Y,
+                                                      int64_t ldy, int64_t d, int64_t nloc, int64_t nb, int c, int pc, int64_t N)
+{
+  const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if(n >= nloc) return;
+  const int64_t jl = n / nb;
+  const int64_t g = (c + (int64_t)pc * jl) * nb + (n - jl * nb);
+  for(int64_t e = 0; e < d; e++) Aex[e + n * lld] = g < N ? Y[g + e * ldy] : 0.0;
+}
+
+__global__ void __launch_bounds__(256) pack_tiles_kernel(double* __restrict__ dst, const double* __restrict__ src, int64_t lds,
+                                                         int64_t first, int64_t step, int64_t nb)
+{
+  const int64_t t = blockIdx.y;
+  const int64_t j = blockIdx.x;           // column of the tile
+  const double* s = src + (first + t * step) * nb + j * lds;
+  double* d = dst + t * nb * nb + j * nb;
+  for(int64_t i = 2 * threadIdx.x; i < nb; i += 512)
+    *reinterpret_cast<double2_t*>(d + i) = *reinterpret_cast<const double2_t*>(s + i);
+}
+
+__device__ __forceinline__ double block_sum(double v, double* sh)
+{
+  for(int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if(lane == 0) sh[w] = v;
+  __syncthreads();
+  double r = 0.0;
+  if(threadIdx.x == 0) r = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+  __syncthreads();
+  return r;
+}
+
+__global__ void __launch_bounds__(256) diag_logsum_kernel(const double* __restrict__ A, int64_t lld, int64_t nb, int r, int pr,
+                                                          int c, int pc, int64_t T, double* __restrict__ partial)
+{
+  __shared__ double sh[4];
+  const int64_t il = blockIdx.x;
+  const int64_t I = r + (int64_t)pr * il;
+  double v = 0.0;
+  if(I < T && I >= c && (I - c) % pc == 0) {
+    const int64_t jl = (I - c) / pc;
+    for(int64_t i = threadIdx.x; i < nb; i += 256) v += log(A[il * nb + i + (jl * nb + i) * lld]);
+  }
+  const double s = block_sum(v, sh);
+  if(threadIdx.x == 0) partial[il] = s;
+}
+
+// partial[chunk * nrows + e] = sum over the chunk's columns of A(e, n)^2; threads along the rows (coalesced)
+__global__ void __launch_bounds__(256) rows_sumsq_kernel(const double* __restrict__ A, int64_t lld, int64_t nrows,
+                                                         int64_t ncols, double* __restrict__ partial)
+{
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if(e >= nrows) return;
+  const int64_t per = (ncols + gridDim.y - 1) / gridDim.y;
+  const int64_t n0 = (int64_t)blockIdx.y * per, n1 = (n0 + per < ncols) ? n0 + per : ncols;
+  double s = 0.0;
+  for(int64_t n = n0; n < n1; n++) {
+    const double a = A[e + n * lld];
+    s = fma(a, a, s);
+  }
+  partial[(int64_t)blockIdx.y * nrows + e] = s;
+}
+
+__global__ void __launch_bounds__(256) add_transposed_kernel(double* __restrict__ dst, int64_t ldd, const double* __restrict__ src,
+                                                             int64_t lds, int64_t n, int64_t d)
+{
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if(i >= n) return;
+  for(int64_t e = 0; e < d; e++) dst[i + e * ldd] += src[e + i * lds];
+}
+
+// ---- GridOps on HIP ------------------------------------------------------------------------------------------------------
+struct HipOps : GridOps {
+  int dev;
+  hipStream_t st[2] = {nullptr, nullptr};
+  double* red = nullptr;   // reduction partials
+  size_t red_bytes = 0;
+  explicit HipOps(int d) : dev(d) {}
+  int init()
+  {
+    int lo = 0, hi = 0;
+    HIPOPS_CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+    HIPOPS_CHECK(hipStreamCreateWithPriority(&st[ST_MAIN], hipStreamNonBlocking, lo));
+    HIPOPS_CHECK(hipStreamCreateWithPriority(&st[ST_PANEL], hipStreamNonBlocking, hi));
+    return GPC_OK;
+  }
+  ~HipOps() override
+  {
+    (void)hipSetDevice(dev);
+    if(st[0]) (void)hipStreamDestroy(st[0]);
+    if(st[1]) (void)hipStreamDestroy(st[1]);
+    if(red) (void)hipFree(red);
+  }
+  int scratch(size_t bytes, double** out)
+  {
+    if(red_bytes < bytes) {
+      if(red) HIPOPS_CHECK(hipFree(red));
+      red = nullptr;
+      red_bytes = 0;
+      HIPOPS_CHECK(hipMalloc((void**)&red, bytes));
+      red_bytes = bytes;
+    }
+    *out = red;
+    return GPC_OK;
+  }
+  int alloc(void** p, size_t bytes) override
+  {
+    hipError_t e = hipMalloc(p, bytes ? bytes : 16);
+    if(e != hipSuccess) {
+      *p = nullptr;
+      set_error("grid: hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+      (void)hipGetLastError();
+      return GPC_ENOMEM;
+    }
+    return GPC_OK;
+  }
+  int release(void* p) override
+  {
+    if(p) HIPOPS_CHECK(hipFree(p));
+    return GPC_OK;
+  }
+  int upload(void* dst, const void* src, size_t bytes) override
+  {
+    HIPOPS_CHECK(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
+    return GPC_OK;
+  }
+  int download(void* dst, const void* src, size_t bytes, int s) override
+  {
+    HIPOPS_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, st[s]));
+    HIPOPS_CHECK(hipStreamSynchronize(st[s]));
+    return GPC_OK;
+  }
+  int zero(void* p, size_t bytes, int s) override
+  {
+    HIPOPS_CHECK(hipMemsetAsync(p, 0, bytes, st[s]));
+    return GPC_OK;
+  }
+  int zero2d(double* A, int64_t lda, int64_t m, int64_t n, int s) override
+  {
+    if(m <= 0 || n <= 0) return GPC_OK;
+    HIPOPS_CHECK(hipMemset2DAsync(A, sizeof(double) * (size_t)lda, 0, sizeof(double) * (size_t)m, (size_t)n, st[s]));
+    return GPC_OK;
+  }
+  int copy(void* dst, const void* src, size_t bytes, int s) override
+  {
+    HIPOPS_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDefault, st[s]));   // same device or a peer (xGMI)
+    return GPC_OK;
+  }
+  void* event_create() override
+  {
+    hipEvent_t e = nullptr;
+    if(hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
+    return e;
+  }
+  void event_destroy(void* ev) override
+  {
+    if(ev) (void)hipEventDestroy((hipEvent_t)ev);
+  }
+  int record(void* ev, int s) override
+  {
+    HIPOPS_CHECK(hipEventRecord((hipEvent_t)ev, st[s]));
+    return GPC_OK;
+  }
+  int wait(int s, void* ev) override
+  {
+    HIPOPS_CHECK(hipStreamWaitEvent(st[s], (hipEvent_t)ev, 0));
+    return GPC_OK;
+  }
+  int sync(int s) override
+  {
+    HIPOPS_CHECK(hipStreamSynchronize(st[s]));
+    return GPC_OK;
+  }
+  void* native_stream(int s) override { return st[s]; }
+
+  int gather_rows(const double* X, int64_t N, int64_t D, int64_t ldx, int64_t first, int64_t stride, int64_t ntiles,
+                  int64_t nb, double* out, int64_t ldo, int s) override
+  {
+    const int64_t rows = ntiles * nb;
+    if(rows <= 0) return GPC_OK;
+    hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)((rows + 255) / 256), (unsigned)D), dim3(256), 0, st[s], X, N, ldx,
+                       first, stride, nb, rows, out, ldo);
+    HIPOPS_CHECK(hipGetLastError());
+    return GPC_OK;
+  }
+  int gram_cross(const gpc_kspec* ks, const double* Xa, int64_t Na, int64_t lda, const double* Xb, int64_t Nb, int64_t ldb,
+                 int64_t D, double* K, int64_t ldk, int s) override
+  {
+    return gpc_gram_cross_f64(ks, Xa, Na, lda, Xb, Nb, ldb, D, K, ldk, st[s]);
+  }
+  int gram_diag(const gpc_kspec* ks, const double* X, int64_t N, int64_t D, int64_t ldx, double shift, double* dg, int s) override
+  {
+    GPC_CHECK(gpc_gram_diag_f64(ks, X, N, D, ldx, dg, st[s]));
+    if(shift != 0.0) {
+      hipLaunchKernelGGL(add_scalar_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st[s], dg, N, shift);
+      HIPOPS_CHECK(hipGetLastError());
+    }
+    return GPC_OK;
+  }
+  int sum_host(const double* v, int64_t n, double* out, int s) override
+  {
+    return gpc::diag_reduce(0, n, v, 0, out, st[s]);   // "diagonal" of a matrix with leading dimension 0 = the vector
+  }
+  int fix_diag_pad(double* A, const Layout& L, const double* dg, int s) override
+  {
+    const int64_t pad0 = L.N - (L.T - 1) * L.nb;   // rows of the last tile that are real
+    if(pad0 < L.nb) {
+      if((int)((L.T - 1) % L.pr) == L.r && L.nloc > 0) {
+        const int64_t il = (L.T - 1) / L.pr;
+        hipLaunchKernelGGL(zero_rows_kernel, dim3((unsigned)(L.nloc < 1024 ? L.nloc : 1024)), dim3(256), 0, st[s], A, L.lld,
+                           il * L.nb + pad0, L.nb - pad0, L.nloc);
+      }
+      if((int)((L.T - 1) % L.pc) == L.c && L.mloc > 0) {
+        const int64_t jl = (L.T - 1) / L.pc;
+        GPC_CHECK(zero2d(A + (jl * L.nb + pad0) * L.lld, L.lld, L.mloc, L.nb - pad0, s));
+      }
+    }
+    if(L.Lr > 0 && L.Lc > 0)
+      hipLaunchKernelGGL(set_diag_kernel, dim3((unsigned)L.Lr), dim3(256), 0, st[s], A, L.lld, L.nb, L.r, L.pr, L.c, L.pc, L.T,
+                         L.N, dg);
+    HIPOPS_CHECK(hipGetLastError());
+    return GPC_OK;
+  }
+  int put_rhs_rows(double* Aex, int64_t lld, const double* Y, int64_t ldy, int64_t d, const Layout& L, int s) override
+  {
+    if(L.nloc <= 0 || d <= 0) return GPC_OK;
+    hipLaunchKernelGGL(put_rhs_kernel, dim3((unsigned)((L.nloc + 255) / 256)), dim3(256), 0, st[s], Aex, lld, Y, ldy, d, L.nloc,
+                       L.nb, L.c, L.pc, L.N);
+    HIPOPS_CHECK(hipGetLastError());
+    return GPC_OK;
+  }
+  int potrf_tile(double* A, int64_t lda, int64_t n, int64_t col0, int* info, int s) override
+  {
+    return gpc::potrf_lower(n, A, lda, info, st[s], col0);
+  }
+  int potrf_panel(int64_t M, int64_t nb, double* A, int64_t lda, int64_t col0, int* info, int s) override
+  {
+    return gpc::potrf_panel(M, nb, A, lda, info, col0, st[s]);
+  }
+  int trsm_rlt(const double* Lkk, int64_t ldl, int64_t n, double* B, int64_t ldb, int64_t M, int s) override
+  {
+    return gpc::trsm('R', 'L', 'T', 'N', M, n, 1.0, Lkk, ldl, B, ldb, st[s]);
+  }
+  int copy2d(double* dst, int64_t ldd, const double* src, int64_t lds, int64_t m, int64_t n, int s) override
+  {
+    if(m <= 0 || n <= 0) return GPC_OK;
+    HIPOPS_CHECK(hipMemcpy2DAsync(dst, sizeof(double) * (size_t)ldd, src, sizeof(double) * (size_t)lds,
+                                  sizeof(double) * (size_t)m, (size_t)n, hipMemcpyDeviceToDevice, st[s]));
+    return GPC_OK;
+  }
+  int pack_tiles(double* dst, const double* src, int64_t lds, int64_t first, int64_t step, int64_t count, int64_t nb,
+                 int s) override
+  {
+    if(count <= 0) return GPC_OK;
+    for(int64_t t0 = 0; t0 < count; t0 += 65535) {
+      const int64_t nt = count - t0 < 65535 ? count - t0 : 65535;
+      hipLaunchKernelGGL(pack_tiles_kernel, dim3((unsigned)nb, (unsigned)nt), dim3(256), 0, st[s], dst + t0 * nb * nb, src, lds,
+                         first + t0 * step, step, nb);
+    }
+    HIPOPS_CHECK(hipGetLastError());
+    return GPC_OK;
+  }
+  int update(const UpdateArgs& u, int s) override
+  {
+    Stair2D sd;
+    sd.nb = u.nb;
+    sd.I0 = u.I0;
+    sd.pr = u.pr;
+    sd.J0 = u.J0;
+    sd.pc = u.pc;
+    sd.jl0 = u.jl0;
+    sd.voff = u.voff_dev;
+    TrailingScope role;
+    return gpc::gemm_stair2d(u.M, u.Ncols, u.K, -1.0, u.W, u.ldw, u.Vbase, u.ldv, u.C, u.ldc, sd, st[s]);
+  }
+  int diag_logsum(const double* A, const Layout& L, double* out, int s) override
+  {
+    *out = 0.0;
+    if(L.Lr <= 0 || L.Lc <= 0) return GPC_OK;
+    double* part = nullptr;
+    GPC_CHECK(scratch(sizeof(double) * (size_t)L.Lr, &part));
+    hipLaunchKernelGGL(diag_logsum_kernel, dim3((unsigned)L.Lr), dim3(256), 0, st[s], A, L.lld, L.nb, L.r, L.pr, L.c, L.pc, L.T,
+                       part);
+    HIPOPS_CHECK(hipGetLastError());
+    std::vector<double> h((size_t)L.Lr);
+    GPC_CHECK(download(h.data(), part, sizeof(double) * h.size(), s));
+    double t = 0.0;
+    for(double v : h) t += v;
+    *out = 2.0 * t;
+    return GPC_OK;
+  }
+  int rows_sumsq(const double* Arow, int64_t lld, int64_t nrows, int64_t ncols, double* out, int s) override
+  {
+    const unsigned chunks = (unsigned)(ncols < 64 ? (ncols > 0 ? ncols : 1) : 64);
+    double* part = nullptr;
+    GPC_CHECK(scratch(sizeof(double) * (size_t)(chunks * nrows), &part));
+    hipLaunchKernelGGL(rows_sumsq_kernel, dim3((unsigned)((nrows + 255) / 256), chunks), dim3(256), 0, st[s], Arow, lld, nrows,
+                       ncols, part);
+    HIPOPS_CHECK(hipGetLastError());
+    std::vector<double> h((size_t)(chunks * nrows));
+    GPC_CHECK(download(h.data(), part, sizeof(double) * h.size(), s));
+    for(int64_t e = 0; e < nrows; e++) {
+      double t = 0.0;
+      for(unsigned ch = 0; ch < chunks; ch++) t += h[(size_t)(ch * nrows + e)];
+      out[e] = t;
+    }
+    return GPC_OK;
+  }
+  int gemm(char ta, char tb, int64_t M, int64_t N, int64_t K, double alpha, const double* A, int64_t lda, const double* B,
+           int64_t ldb, double beta, double* C, int64_t ldc, int s) override
+  {
+    return gpc::gemm(ta == 'T', tb == 'T', M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, 0, st[s]);
+  }
+  int trsm_llt(const double* Lkk, int64_t ldl, int64_t n, double* B, int64_t ldb, int64_t nrhs, int s) override
+  {
+    return gpc::trsm('L', 'L', 'T', 'N', n, nrhs, 1.0, Lkk, ldl, B, ldb, st[s]);
+  }
+  int add_transposed(double* dst, int64_t ldd, const double* src, int64_t lds, int64_t n, int64_t d, int s) override
+  {
+    hipLaunchKernelGGL(add_transposed_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st[s], dst, ldd, src, lds, n, d);
+    HIPOPS_CHECK(hipGetLastError());
+    return GPC_OK;
+  }
+  int read_info(const int* info_dev, int* out, int s) override { return download(out, info_dev, sizeof(int), s); }
+  void prof_update_begin(double flops, int s) override { gpc::prof_begin(PROF_SYRK, flops, st[s]); }
+  void prof_update_end(int s) override { gpc::prof_end(PROF_SYRK, st[s]); }
+};
+
+// ---- RCCL -------------------------------------------------------------------------------------------------------------------
+struct RcclApi {
+  void* handle = nullptr;
+  decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+  decltype(&ncclCommInitRank) CommInitRank = nullptr;
+  decltype(&ncclCommSplit) CommSplit = nullptr;
+  decltype(&ncclCommDestroy) CommDestroy = nullptr;
+  decltype(&ncclBroadcast) Broadcast = nullptr;
+  decltype(&ncclAllReduce) AllReduce = nullptr;
+  decltype(&ncclGetErrorString) GetErrorString = nullptr;
+  std::string where;
+};
+
+RcclApi* rccl_api()
+{
+  static RcclApi api;
+  static std::once_flag once;
+  std::call_once(once, [] {
+    const char* env = getenv("GPC_RCCL_LIB");
+    // a copy already mapped into the process first (e.g. the one PyTorch ships), then the ROCm installation's
+    const char* names[] = {env, "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
+    for(int pass = 0; pass < 2 && !api.handle; pass++)
+      for(const char* n : names) {
+        if(!n || !*n) continue;
+        api.handle = dlopen(n, RTLD_NOW | RTLD_LOCAL | (pass == 0 ? RTLD_NOLOAD : 0));
+        if(api.handle) {
+          api.where = n;
+          break;
+        }
+      }
+    if(!api.handle) return;
+#define GPC_RCCL_SYM(name) api.name = reinterpret_cast<decltype(api.name)>(dlsym(api.handle, "nccl" #name))
+    GPC_RCCL_SYM(GetUniqueId);
+    GPC_RCCL_SYM(CommInitRank);
+    GPC_RCCL_SYM(CommSplit);
+    GPC_RCCL_SYM(CommDestroy);
+    GPC_RCCL_SYM(Broadcast);
+    GPC_RCCL_SYM(AllReduce);
+    GPC_RCCL_SYM(GetErrorString);
+#undef GPC_RCCL_SYM
+    if(!api.GetUniqueId || !api.CommInitRank || !api.CommSplit || !api.CommDestroy || !api.Broadcast || !api.AllReduce ||
+       !api.GetErrorString) {
+      dlclose(api.handle);
+      api.handle = nullptr;
+    }
+  });
+  return api.handle ? &api : nullptr;
+}
+
+#define RCCL_CHECK(expr)                                                                                  \
+  do {                                                                                                    \
+    ncclResult_t r__ = (expr);                                                                            \
+    if(r__ != ncclSuccess) {                                                                              \
+      gpc::set_error("%s failed: %s (%s:%d)", #expr, api->GetErrorString(r__), __FILE__, __LINE__);       \
+      return GPC_EHIP;                                                                                    \
+    }                                                                                                     \
+  } while(0)
+
+struct RcclComm : GridComm {
+  RcclApi* api;
+  ncclComm_t comm[3] = {nullptr, nullptr, nullptr};   // by axis; null = a group of one
+  int size[3] = {1, 1, 1};
+  double* scratch = nullptr;                           // device words for the host-valued reductions
+  hipStream_t main = nullptr;
+  static constexpr int SCRATCH = 512;
+  bool force = false;   // GPC_GRID_FORCE_RCCL=1: issue the collectives even in groups of one (exercises the RCCL calls on one GPU)
+  explicit RcclComm(RcclApi* a) : api(a)
+  {
+    const char* e = getenv("GPC_GRID_FORCE_RCCL");
+    force = e && atoi(e) != 0;
+  }
+  int init(int rank, int nranks, int pr, int pc, const void* uid, GridOps* ops)
+  {
+    ncclUniqueId id;
+    static_assert(sizeof(id) == GPC_GRID_UID_BYTES, "ncclUniqueId size");
+    memcpy(&id, uid, sizeof(id));
+    main = (hipStream_t)ops->native_stream(ST_MAIN);
+    RCCL_CHECK(api->CommInitRank(&comm[AX_WORLD], nranks, id, rank));
+    size[AX_WORLD] = nranks;
+    const int r = rank / pc, c = rank % pc;
+    if(pc > 1 || force) RCCL_CHECK(api->CommSplit(comm[AX_WORLD], r, c, &comm[AX_ROW], nullptr));
+    if(pr > 1 || force) RCCL_CHECK(api->CommSplit(comm[AX_WORLD], c, r, &comm[AX_COL], nullptr));
+    size[AX_ROW] = pc;
+    size[AX_COL] = pr;
+    HIPOPS_CHECK(hipMalloc((void**)&scratch, sizeof(double) * SCRATCH));
+    return GPC_OK;
+  }
+  ~RcclComm() override
+  {
+    if(scratch) (void)hipFree(scratch);
+    for(int a = 0; a < 3; a++)
+      if(comm[a] && a != AX_WORLD) (void)api->CommDestroy(comm[a]);
+    if(comm[AX_WORLD]) (void)api->CommDestroy(comm[AX_WORLD]);
+  }
+  int bcast(void* buf, int64_t count, int root, int axis, GridOps* ops, int st) override
+  {
+    if((size[axis] == 1 && !force) || count <= 0) return GPC_OK;
+    RCCL_CHECK(api->Broadcast(buf, buf, (size_t)count, ncclDouble, root, comm[axis], (hipStream_t)ops->native_stream(st)));
+    return GPC_OK;
+  }
+  int allreduce_dev(double* buf, int64_t count, int axis, GridOps* ops, int st) override
+  {
+    if((size[axis] == 1 && !force) || count <= 0) return GPC_OK;
+    RCCL_CHECK(api->AllReduce(buf, buf, (size_t)count, ncclDouble, ncclSum, comm[axis], (hipStream_t)ops->native_stream(st)));
+    return GPC_OK;
+  }
+  int allreduce_host(double* v, int n, int axis) override
+  {
+    if(size[axis] == 1 && !force) return GPC_OK;
+    for(int o = 0; o < n; o += SCRATCH) {
+      const int m = n - o < SCRATCH ? n - o : SCRATCH;
+      HIPOPS_CHECK(hipMemcpyAsync(scratch, v + o, sizeof(double) * (size_t)m, hipMemcpyHostToDevice, main));
+      RCCL_CHECK(api->AllReduce(scratch, scratch, (size_t)m, ncclDouble, ncclSum, comm[axis], main));
+      HIPOPS_CHECK(hipMemcpyAsync(v + o, scratch, sizeof(double) * (size_t)m, hipMemcpyDeviceToHost, main));
+      HIPOPS_CHECK(hipStreamSynchronize(main));
+    }
+    return GPC_OK;
+  }
+  int allmin_host(int64_t* v) override
+  {
+    if(size[AX_WORLD] == 1 && !force) return GPC_OK;
+    HIPOPS_CHECK(hipMemcpyAsync(scratch, v, sizeof(int64_t), hipMemcpyHostToDevice, main));
+    RCCL_CHECK(api->AllReduce(scratch, scratch, 1, ncclInt64, ncclMin, comm[AX_WORLD], main));
+    HIPOPS_CHECK(hipMemcpyAsync(v, scratch, sizeof(int64_t), hipMemcpyDeviceToHost, main));
+    HIPOPS_CHECK(hipStreamSynchronize(main));
+    return GPC_OK;
+  }
+  int barrier() override
+  {
+    double z = 0.0;
+    return allreduce_host(&z, 1, AX_WORLD);
+  }
+};
+
+// ---- hooks of grid_capi_impl.hpp ---------------------------------------------------------------------------------------------
+int grid_current_device(int* dev)
+{
+  GPC_CHECK(gpc::ensure_device());
+  HIPOPS_CHECK(hipGetDevice(dev));
+  return GPC_OK;
+}
+
+int grid_enter(int dev)
+{
+  HIPOPS_CHECK(hipSetDevice(dev));
+  return GPC_OK;
+}
+
+std::unique_ptr<GridOps> grid_make_ops(int dev)
+{
+  std::unique_ptr<HipOps> o(new HipOps(dev));
+  if(o->init() != GPC_OK) return nullptr;
+  return std::unique_ptr<GridOps>(o.release());
+}
+
+int grid_enable_peers(const int* devices, int n)
+{
+  int cur = 0;
+  HIPOPS_CHECK(hipGetDevice(&cur));
+  for(int i = 0; i < n; i++)
+    for(int j = 0; j < n; j++) {
+      if(devices[i] == devices[j]) continue;
+      int can = 0;
+      HIPOPS_CHECK(hipDeviceCanAccessPeer(&can, devices[i], devices[j]));
+      if(!can) continue;
+      HIPOPS_CHECK(hipSetDevice(devices[i]));
+      const hipError_t e = hipDeviceEnablePeerAccess(devices[j], 0);
+      if(e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) {
+        gpc::set_error("hipDeviceEnablePeerAccess(%d -> %d) failed: %s", devices[i], devices[j], hipGetErrorString(e));
+        (void)hipSetDevice(cur);
+        return GPC_EHIP;
+      }
+      (void)hipGetLastError();
+    }
+  HIPOPS_CHECK(hipSetDevice(cur));
+  return GPC_OK;
+}
+
+bool grid_force_collectives()
+{
+  const char* e = getenv("GPC_GRID_FORCE_RCCL");
+  return e && atoi(e) != 0;
+}
+
+int grid_unique_id(void* uid)
+{
+  RcclApi* api = rccl_api();
+  if(!api) {
+    gpc::set_error("librccl could not be opened (set GPC_RCCL_LIB): a multi-process grid needs RCCL");
+    return GPC_EUNSUPPORTED;
+  }
+  ncclUniqueId id;
+  RCCL_CHECK(api->GetUniqueId(&id));
+  memcpy(uid, &id, sizeof(id));
+  return GPC_OK;
+}
+
+int grid_make_collective_comm(std::unique_ptr<GridComm>& out, int rank, int nranks, int pr, int pc, const void* uid,
+                              GridOps* ops)
+{
+  RcclApi* api = rccl_api();
+  if(!api) {
+    gpc::set_error("librccl could not be opened (set GPC_RCCL_LIB): a multi-process grid needs RCCL");
+    return GPC_EUNSUPPORTED;
+  }
+  std::unique_ptr<RcclComm> c(new RcclComm(api));
+  GPC_CHECK(c->init(rank, nranks, pr, pc, uid, ops));
+  out.reset(c.release());
+  return GPC_OK;
+}
+
+}  // namespace
+
+#define GRID_API(name) gpc_grid_##name
+#include "grid_capi_impl.hpp"
+
+// which librccl the grid resolved ("" before the first multi-process grid / when none could be opened)
+extern "C" const char* gpc_grid_rccl_path(void)
+{
+  RcclApi* api = rccl_api();
+  return api ? api->where.c_str() : "";
+}

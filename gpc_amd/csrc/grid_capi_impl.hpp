@@ -1,0 +1,234 @@
+// grid_capi_impl.hpp -- bodies of the gpc_grid_* entry points (include/gpc_hip.h), written once against the GridOps /
+// GridComm seams of grid_sched.hpp.  grid.hip instantiates them over the HIP kernels + RCCL as libgpc_hip.so's
+// gpc_grid_*; the CPU test-suite instantiates the same text over its host stand-in (tests/host/grid_host.cpp) as
+// gridtest_*, so the gloo / thread-rank tests exercise exactly this code.
+//
+// The includer defines, before including this file:
+//   GRID_API(name)                         the exported symbol for entry point `name`
+//   grid_make_ops(int device)              -> std::unique_ptr<GridOps>
+//   grid_enter(int device)                 make `device` current on the calling thread (status code)
+//   grid_make_collective_comm(...)         the RCCL communicator (or GPC_EUNSUPPORTED)
+//   grid_unique_id(void* uid)              fill GPC_GRID_UID_BYTES
+#include <new>
+
+struct gpc_grid {
+  std::unique_ptr<gpc::grid::GridGp> gp;
+  int device = 0;
+  std::string err;
+};
+
+namespace {
+using namespace gpc::grid;
+
+int grid_fail(gpc_grid* g, int rc)
+{
+  if(g && rc != GPC_OK && !g->gp->error().empty()) g->err = g->gp->error();
+  return rc;
+}
+
+int grid_check_shape(int rank, int pr, int pc, int64_t nb)
+{
+  if(pr < 1 || pc < 1 || pr * pc > 4096 || rank < 0 || rank >= pr * pc || nb <= 0 || nb % 128 != 0) return GPC_EINVAL;
+  return GPC_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int GRID_API(unique_id)(void* uid) { return uid ? grid_unique_id(uid) : GPC_EINVAL; }
+
+int GRID_API(create)(gpc_grid** out, int rank, int nranks, int pr, int pc, int64_t nb, const void* uid)
+{
+  if(!out || nranks != pr * pc || grid_check_shape(rank, pr, pc, nb) != GPC_OK || (nranks > 1 && !uid)) return GPC_EINVAL;
+  int dev = 0;
+  GRID_CHECK(grid_current_device(&dev));
+  std::unique_ptr<GridOps> ops = grid_make_ops(dev);
+  if(!ops) return GPC_ENODEV;
+  std::unique_ptr<GridComm> comm;
+  if(nranks == 1 && !grid_force_collectives())
+    comm.reset(new SelfComm());
+  else
+    GRID_CHECK(grid_make_collective_comm(comm, rank, nranks, pr, pc, uid, ops.get()));
+  gpc_grid* g = new(std::nothrow) gpc_grid();
+  if(!g) return GPC_ENOMEM;
+  g->device = dev;
+  g->gp.reset(new GridGp(std::move(ops), std::move(comm), pr, pc, rank / pc, rank % pc, nb));
+  *out = g;
+  return GPC_OK;
+}
+
+int GRID_API(create_local)(gpc_grid** out, int pr, int pc, int64_t nb, const int* devices)
+{
+  if(!out || grid_check_shape(0, pr, pc, nb) != GPC_OK) return GPC_EINVAL;
+  const int P = pr * pc;
+  int cur = 0;
+  GRID_CHECK(grid_current_device(&cur));
+  std::shared_ptr<LocalBoard> board(new LocalBoard(pr, pc));
+  std::vector<gpc_grid*> made;
+  for(int rank = 0; rank < P; rank++) {
+    const int dev = devices ? devices[rank] : cur;
+    int rc = grid_enter(dev);
+    std::unique_ptr<GridOps> ops;
+    if(rc == GPC_OK) {
+      ops = grid_make_ops(dev);
+      if(!ops) rc = GPC_ENODEV;
+    }
+    if(rc != GPC_OK) {
+      for(gpc_grid* g : made) delete g;
+      (void)grid_enter(cur);
+      return rc;
+    }
+    gpc_grid* g = new gpc_grid();
+    g->device = dev;
+    std::unique_ptr<GridComm> comm;
+    if(P == 1) comm.reset(new SelfComm());
+    else comm.reset(new LocalComm(board, rank / pc, rank % pc));
+    g->gp.reset(new GridGp(std::move(ops), std::move(comm), pr, pc, rank / pc, rank % pc, nb));
+    made.push_back(g);
+  }
+  (void)grid_enter(cur);
+  if(devices) GRID_CHECK(grid_enable_peers(devices, P));
+  for(int rank = 0; rank < P; rank++) out[rank] = made[(size_t)rank];
+  return GPC_OK;
+}
+
+int GRID_API(create_transport)(gpc_grid** out, int rank, int pr, int pc, int64_t nb, const gpc_grid_transport* t)
+{
+  if(!out || !t || !t->bcast || !t->allreduce_sum || !t->allreduce_min_i64 || grid_check_shape(rank, pr, pc, nb) != GPC_OK)
+    return GPC_EINVAL;
+  int dev = 0;
+  GRID_CHECK(grid_current_device(&dev));
+  std::unique_ptr<GridOps> ops = grid_make_ops(dev);
+  if(!ops) return GPC_ENODEV;
+  gpc_grid* g = new(std::nothrow) gpc_grid();
+  if(!g) return GPC_ENOMEM;
+  g->device = dev;
+  std::unique_ptr<GridComm> comm(new CallbackComm(*t));
+  g->gp.reset(new GridGp(std::move(ops), std::move(comm), pr, pc, rank / pc, rank % pc, nb));
+  *out = g;
+  return GPC_OK;
+}
+
+int GRID_API(destroy)(gpc_grid* g)
+{
+  if(!g) return GPC_OK;
+  (void)grid_enter(g->device);
+  delete g;
+  return GPC_OK;
+}
+
+const char* GRID_API(last_error)(gpc_grid* g) { return g ? g->err.c_str() : ""; }
+
+int GRID_API(set_problem)(gpc_grid* g, const gpc_kspec* ks, const double* X, int64_t N, int64_t D, int64_t ldx,
+                          const double* Y, int64_t d, int64_t ldy, const double* Xs, int64_t Ns, int64_t ldxs)
+{
+  if(!g) return GPC_EINVAL;
+  GRID_CHECK(grid_enter(g->device));
+  return grid_fail(g, g->gp->set_problem(ks, X, N, D, ldx, Y, d, ldy, Xs, Ns, ldxs));
+}
+
+int GRID_API(set_kernel)(gpc_grid* g, const gpc_kspec* ks)
+{
+  if(!g) return GPC_EINVAL;
+  return grid_fail(g, g->gp->set_kernel(ks));
+}
+
+int GRID_API(set_lookahead)(gpc_grid* g, int on)
+{
+  if(!g) return GPC_EINVAL;
+  g->gp->lookahead = on ? 1 : 0;
+  return GPC_OK;
+}
+
+int GRID_API(update_k)(gpc_grid* g, double* logdet, double* jitter_added, int* info)
+{
+  if(!g || !info) return GPC_EINVAL;
+  GRID_CHECK(grid_enter(g->device));
+  return grid_fail(g, g->gp->update_k(logdet, jitter_added, info));
+}
+
+int GRID_API(fill)(gpc_grid* g)
+{
+  if(!g) return GPC_EINVAL;
+  GRID_CHECK(grid_enter(g->device));
+  return grid_fail(g, g->gp->fill(0.0));
+}
+
+int GRID_API(factor)(gpc_grid* g, int* info)
+{
+  if(!g || !info) return GPC_EINVAL;
+  GRID_CHECK(grid_enter(g->device));
+  return grid_fail(g, g->gp->factor(info));
+}
+
+int GRID_API(loglik)(gpc_grid* g, double* ll)
+{
+  if(!g || !ll) return GPC_EINVAL;
+  GRID_CHECK(grid_enter(g->device));
+  return grid_fail(g, g->gp->loglik(ll));
+}
+
+int GRID_API(alpha)(gpc_grid* g, double* alpha_host, int64_t lda)
+{
+  if(!g) return GPC_EINVAL;
+  GRID_CHECK(grid_enter(g->device));
+  return grid_fail(g, g->gp->alpha(alpha_host, lda));
+}
+
+int GRID_API(posterior)(gpc_grid* g, double* mu_host, int64_t ldmu, double* var_host)
+{
+  if(!g || !mu_host || !var_host) return GPC_EINVAL;
+  GRID_CHECK(grid_enter(g->device));
+  return grid_fail(g, g->gp->posterior(mu_host, ldmu, var_host));
+}
+
+int GRID_API(copy_tile)(gpc_grid* g, int64_t I, int64_t J, double* host, int* owned)
+{
+  if(!g || !host) return GPC_EINVAL;
+  GRID_CHECK(grid_enter(g->device));
+  return grid_fail(g, g->gp->copy_tile(I, J, host, owned));
+}
+
+int GRID_API(sync)(gpc_grid* g)
+{
+  if(!g) return GPC_EINVAL;
+  GRID_CHECK(grid_enter(g->device));
+  GRID_CHECK(g->gp->ops()->sync(ST_PANEL));
+  return g->gp->ops()->sync(ST_MAIN);
+}
+
+int GRID_API(barrier)(gpc_grid* g)
+{
+  if(!g) return GPC_EINVAL;
+  GRID_CHECK(grid_enter(g->device));
+  return g->gp->comm()->barrier();
+}
+
+// out[0..11] = N, nb, T, pr, pc, r, c, mloc, nloc, extra rows, local tile rows, local tile columns
+int GRID_API(info)(gpc_grid* g, int64_t* out)
+{
+  if(!g || !out) return GPC_EINVAL;
+  const Layout& L = g->gp->layout();
+  const int64_t v[12] = {L.N, L.nb, L.T, L.pr, L.pc, L.r, L.c, L.mloc, L.nloc, L.E, L.Lr, L.Lc};
+  for(int i = 0; i < 12; i++) out[i] = v[i];
+  return GPC_OK;
+}
+
+// out[0..7] = bytes received along process rows / columns / world, collectives entered, algorithmic flops of this
+// rank's trailing updates, their launches, 0, 0 -- since the last reset
+int GRID_API(stats)(gpc_grid* g, double* out, int reset)
+{
+  if(!g || !out) return GPC_EINVAL;
+  const GridStats& s = g->gp->stats();
+  out[0] = s.bytes_recv[0];
+  out[1] = s.bytes_recv[1];
+  out[2] = s.bytes_recv[2];
+  out[3] = (double)s.collectives;
+  out[4] = s.update_flops;
+  out[5] = (double)s.update_launches;
+  out[6] = out[7] = 0.0;
+  if(reset) g->gp->reset_stats();
+  return GPC_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,835 @@
+// grid_sched.hpp -- the exact-GP factorisation on a 2-D block-cyclic process grid.
+//
+// What is distributed is CGp::updateK() of the reference (/root/reference/CGp.cpp:698-712: the Gram loop; 877-891:
+// jitChol -> logDet -> pdinv) and what CGp reads off the factor (updateAlpha 469-489, logLikelihood 913-938,
+// posteriorMeanVar 548-663).  The reference has no multi-device path; the algorithm is the classical right-looking
+// block Cholesky over a pr x pc grid of ranks, one rank per GPU:
+//
+//   layout   global nb x nb tile (I, J), I >= J, lives on rank (I mod pr, J mod pc); a rank keeps its tiles in ONE
+//            column-major array (local row tile il <-> I = r + pr*il, local column tile jl <-> J = c + pc*jl).  N is
+//            padded to T*nb with an identity block (log 1 = 0: nothing changes).  Right-hand sides ride below the
+//            matrix rows as one more tile row ("extra rows": y' and K(X*, X)); the factorisation turns them into
+//            (L^-1 y)' and (L^-1 K(X, X*))', so the forward substitutions of updateAlpha / posteriorMeanVar are free.
+//   step k   (1) rank (k mod pr, k mod pc) factors the diagonal tile and sends it down its process COLUMN;
+//            (2) the ranks of that column solve their rows of the panel, L(I,k) = A(I,k) L(k,k)^-T;
+//            (3) row panel W: every rank of the column sends its rows ALONG ITS PROCESS ROW;
+//            (4) column panel V: inside each process column c the tiles L(J,k), J = c (mod pc), are exchanged
+//                (rank (J mod pr, c) holds L(J,k) after (3)) -- the "transposed" panel;
+//            (5) everyone: A(I,J) -= W(I) V(J)' for its tiles with I >= J > k  (MFMA staircase GEMM).
+//   overlap  look-ahead 1: the column that owns panel k+1 updates it first (U1); steps (1)-(4) of k+1 run on a second,
+//            high-priority stream while the rest of update k (U2) keeps the CUs busy.  W / V / diagonal buffers alternate.
+//   volume   a rank receives 8 * N^2/2 * ((pc-1)/pc / pr + (pr-1)/pr / pc) bytes over a factorisation.
+//
+// This header is plain C++ (no HIP): the arithmetic goes through GridOps (HIP kernels in grid.hip; the CPU test-suite
+// supplies a host stand-in under tests/host/), the exchange through GridComm (RCCL in grid.hip; the in-process
+// thread-rank board and the caller-supplied transport below).  Nothing here falls back to a CPU path by itself.
+#pragma once
+#include <stdint.h>
+#include <stddef.h>
+#include <stdio.h>
+#include <math.h>
+#include <string.h>
+#include <vector>
+#include <mutex>
+#include <condition_variable>
+#include <memory>
+#include <string>
+#include "gpc_hip.h"
+
+namespace gpc {
+namespace grid {
+
+enum { ST_MAIN = 0, ST_PANEL = 1 };
+enum { AX_ROW = 0, AX_COL = 1, AX_WORLD = 2 };
+
+#define GRID_CHECK(expr)              \
+  do {                                \
+    int rc__ = (expr);                \
+    if(rc__ != GPC_OK) return rc__;   \
+  } while(0)
+
+// ---- layout --------------------------------------------------------------------------------------------------------
+struct Layout {
+  int64_t N = 0, nb = 0, T = 0, Np = 0;
+  int pr = 1, pc = 1, r = 0, c = 0;
+  int64_t E = 0, E2 = 0;        // extra rows (right-hand sides), E2 = E rounded up to even
+  int64_t Lr = 0, Lc = 0;       // local tile rows / columns of the matrix proper
+  bool has_extra = false;       // this rank's process row carries the extra rows (tile row T)
+  int64_t mloc = 0, nloc = 0, lld = 0;
+
+  void init(int64_t N_, int64_t nb_, int pr_, int pc_, int r_, int c_, int64_t E_)
+  {
+    N = N_; nb = nb_; pr = pr_; pc = pc_; r = r_; c = c_; E = E_;
+    T = (N + nb - 1) / nb;
+    Np = T * nb;
+    E2 = (E + 1) & ~(int64_t)1;
+    Lr = ntiles(T, r, pr);
+    Lc = ntiles(T, c, pc);
+    has_extra = E > 0 && (int)(T % pr) == r;
+    mloc = Lr * nb + (has_extra ? E2 : 0);
+    nloc = Lc * nb;
+    lld = mloc > 2 ? mloc : 2;
+  }
+  static int64_t ntiles(int64_t T, int first, int stride) { return first >= T ? 0 : (T - first + stride - 1) / stride; }
+  // first local tile index whose global index exceeds k (first = r or c, stride = pr or pc)
+  static int64_t first_after(int64_t k, int first, int stride) { return k < first ? 0 : (k - first) / stride + 1; }
+  int64_t il0(int64_t k) const { return first_after(k, r, pr); }
+  int64_t jl0(int64_t k) const { return first_after(k, c, pc); }
+  int extra_row() const { return (int)(T % pr); }
+  int rank() const { return r * pc + c; }
+  static int64_t gcd(int64_t a, int64_t b) { while(b) { int64_t t = a % b; a = b; b = t; } return a; }
+};
+
+// ---- local arithmetic ------------------------------------------------------------------------------------------------
+// Every pointer is a pointer in the memory the implementation owns (HBM for the HIP implementation); `st` is ST_MAIN or
+// ST_PANEL; everything is asynchronous on that stream unless it returns a host value.
+struct UpdateArgs {
+  int64_t M, Ncols, K;          // C is M x Ncols (Ncols a multiple of nb), depth K = nb
+  const double* W; int64_t ldw; // row panel: row m of C <-> row m of W
+  const double* Vbase; int64_t ldv; const int64_t* voff_dev;   // column panel, see Stair2D in gpc_common.hpp
+  const int64_t* voff_host;     // the same table on the host (for implementations that run there)
+  double* C; int64_t ldc;
+  int64_t nb, I0, J0, jl0; int pr, pc;
+};
+
+struct GridOps {
+  virtual ~GridOps() {}
+  virtual int alloc(void** p, size_t bytes) = 0;
+  virtual int release(void* p) = 0;
+  virtual int upload(void* dst, const void* src_host, size_t bytes) = 0;             // synchronous
+  virtual int download(void* dst_host, const void* src, size_t bytes, int st) = 0;   // waits for stream st first
+  virtual int zero(void* p, size_t bytes, int st) = 0;
+  virtual int zero2d(double* A, int64_t lda, int64_t m, int64_t n, int st) = 0;
+  virtual int copy(void* dst, const void* src, size_t bytes, int st) = 0;            // between buffers of THIS process
+  virtual void* event_create() = 0;
+  virtual void event_destroy(void* ev) = 0;
+  virtual int record(void* ev, int st) = 0;
+  virtual int wait(int st, void* ev) = 0;          // ev may belong to another rank of the same process
+  virtual int sync(int st) = 0;
+  virtual void* native_stream(int st) = 0;
+  // ---- Gram generation
+  // out(t*nb + i, q) = X(min((first + t*stride)*nb + i, N-1), q): the inputs of this rank's tile rows / columns
+  virtual int gather_rows(const double* X, int64_t N, int64_t D, int64_t ldx, int64_t first, int64_t stride,
+                          int64_t ntiles, int64_t nb, double* out, int64_t ldo, int st) = 0;
+  // K(i,j) = k(Xa_i, Xb_j), white excluded (CKern::compute(K, X, X2), CKern.h:146-157)
+  virtual int gram_cross(const gpc_kspec* ks, const double* Xa, int64_t Na, int64_t lda, const double* Xb, int64_t Nb,
+                         int64_t ldb, int64_t D, double* K, int64_t ldk, int st) = 0;
+  // dg(i) = k(X_i, X_i) + shift  (diagComputeElement incl. white; shift = accumulated jitter)
+  virtual int gram_diag(const gpc_kspec* ks, const double* X, int64_t N, int64_t D, int64_t ldx, double shift,
+                        double* dg, int st) = 0;
+  virtual int sum_host(const double* v, int64_t n, double* out_host, int st) = 0;
+  // entries of the local block on the GLOBAL diagonal := dg[g] (g < N) or 1 (padding); padding rows / columns := 0
+  virtual int fix_diag_pad(double* A, const Layout& L, const double* dg, int st) = 0;
+  // extra rows e = 0..d-1: A(e, n) = Y(gcol(n), e) for gcol < N else 0;  Aex points at the first extra row
+  virtual int put_rhs_rows(double* Aex, int64_t lld, const double* Y, int64_t ldy, int64_t d, const Layout& L, int st) = 0;
+  // ---- factorisation
+  virtual int potrf_tile(double* A, int64_t lda, int64_t n, int64_t col0, int* info_dev, int st) = 0;
+  virtual int potrf_panel(int64_t M, int64_t nb, double* A, int64_t lda, int64_t col0, int* info_dev, int st) = 0;
+  virtual int trsm_rlt(const double* Lkk, int64_t ldl, int64_t n, double* B, int64_t ldb, int64_t M, int st) = 0;
+  virtual int copy2d(double* dst, int64_t ldd, const double* src, int64_t lds, int64_t m, int64_t n, int st) = 0;
+  // dst tile t (nb x nb, contiguous) = src rows (first + t*step)*nb .. +nb, all nb columns
+  virtual int pack_tiles(double* dst, const double* src, int64_t lds, int64_t first, int64_t step, int64_t count,
+                         int64_t nb, int st) = 0;
+  virtual int update(const UpdateArgs& u, int st) = 0;
+  // ---- reductions over the local block
+  virtual int diag_logsum(const double* A, const Layout& L, double* out_host, int st) = 0;   // sum 2 log A(g,g)
+  virtual int rows_sumsq(const double* Arow, int64_t lld, int64_t nrows, int64_t ncols, double* out_host, int st) = 0;
+  // ---- small dense pieces of the back substitution / prediction
+  virtual int gemm(char ta, char tb, int64_t M, int64_t N, int64_t K, double alpha, const double* A, int64_t lda,
+                   const double* B, int64_t ldb, double beta, double* C, int64_t ldc, int st) = 0;
+  virtual int trsm_llt(const double* Lkk, int64_t ldl, int64_t n, double* B, int64_t ldb, int64_t nrhs, int st) = 0;
+  // dst(i, e) += src(e, i): the extra rows of a tile, transposed (nb x d)
+  virtual int add_transposed(double* dst, int64_t ldd, const double* src, int64_t lds, int64_t n, int64_t d, int st) = 0;
+  virtual int read_info(const int* info_dev, int* out_host, int st) = 0;
+  // HIP events around the trailing updates (bench.py's roofline leg); the host stand-in ignores them
+  virtual void prof_update_begin(double flops, int st) { (void)flops; (void)st; }
+  virtual void prof_update_end(int st) { (void)st; }
+};
+
+// ---- exchange ---------------------------------------------------------------------------------------------------------
+// Collectives are entered by every rank of the axis group in the same order.  bcast / allreduce_dev are ordered on stream
+// `st` of the calling rank; the host reductions synchronise.
+struct GridComm {
+  virtual ~GridComm() {}
+  virtual int bcast(void* buf, int64_t count, int root, int axis, GridOps* ops, int st) = 0;     // count doubles
+  virtual int allreduce_dev(double* buf, int64_t count, int axis, GridOps* ops, int st) = 0;     // sum, in place
+  virtual int allreduce_host(double* v, int n, int axis) = 0;                                     // sum
+  virtual int allmin_host(int64_t* v) = 0;                                                        // world
+  virtual int barrier() = 0;
+};
+
+// Caller-supplied transport (MPI, gloo, ...): plain C callbacks.  The library synchronises stream `st` before a call, the
+// callback returns when buf holds the result.  Pointers are whatever the GridOps implementation allocates (device
+// pointers for the HIP library).
+struct CallbackComm : GridComm {
+  gpc_grid_transport t;
+  explicit CallbackComm(const gpc_grid_transport& tt) : t(tt) {}
+  int bcast(void* buf, int64_t count, int root, int axis, GridOps* ops, int st) override
+  {
+    GRID_CHECK(ops->sync(st));
+    return t.bcast(t.ctx, buf, count, root, axis) == 0 ? GPC_OK : GPC_EHIP;
+  }
+  int allreduce_dev(double* buf, int64_t count, int axis, GridOps* ops, int st) override
+  {
+    GRID_CHECK(ops->sync(st));
+    return t.allreduce_sum(t.ctx, buf, count, axis, 1) == 0 ? GPC_OK : GPC_EHIP;
+  }
+  int allreduce_host(double* v, int n, int axis) override { return t.allreduce_sum(t.ctx, v, n, axis, 0) == 0 ? GPC_OK : GPC_EHIP; }
+  int allmin_host(int64_t* v) override { return t.allreduce_min_i64(t.ctx, v) == 0 ? GPC_OK : GPC_EHIP; }
+  int barrier() override
+  {
+    double z = 0.0;
+    return allreduce_host(&z, 1, AX_WORLD);
+  }
+};
+
+// In-process ranks (one host thread each; single-process multi-GPU, and the way a single GPU runs pr x pc > 1 in the
+// tests): a shared board with a reusable barrier per axis group.  A broadcast is the receivers copying out of the root's
+// buffer on their own streams once the root's event has fired; the root's stream then waits for their copies.
+struct LocalBoard {
+  int pr, pc;
+  struct Group {
+    std::mutex m;
+    std::condition_variable cv;
+    int n = 0, arrived = 0;
+    uint64_t gen = 0;
+    const void* src = nullptr;
+    void* src_event = nullptr;
+    std::vector<void*> done_events;
+    std::vector<double> acc;
+    std::vector<std::vector<double>> parts;
+    std::vector<int64_t> imin;
+  };
+  std::vector<std::unique_ptr<Group>> rows, cols;
+  Group world;
+  bool failed = false;
+  LocalBoard(int pr_, int pc_) : pr(pr_), pc(pc_)
+  {
+    for(int i = 0; i < pr; i++) { rows.emplace_back(new Group()); init(*rows.back(), pc); }
+    for(int i = 0; i < pc; i++) { cols.emplace_back(new Group()); init(*cols.back(), pr); }
+    init(world, pr * pc);
+  }
+  static void init(Group& g, int n)
+  {
+    g.n = n;
+    g.done_events.assign(n, nullptr);
+    g.parts.resize(n);
+    g.imin.assign(n, 0);
+  }
+  Group& group(int axis, int r, int c) { return axis == AX_ROW ? *rows[r] : (axis == AX_COL ? *cols[c] : world); }
+  static void sync(Group& g)
+  {
+    std::unique_lock<std::mutex> lk(g.m);
+    const uint64_t my = g.gen;
+    if(++g.arrived == g.n) {
+      g.arrived = 0;
+      g.gen++;
+      g.cv.notify_all();
+    } else {
+      g.cv.wait(lk, [&] { return g.gen != my; });
+    }
+  }
+};
+
+struct LocalComm : GridComm {
+  std::shared_ptr<LocalBoard> board;
+  int r, c;
+  std::vector<void*> my_done;   // events this rank records after copying out of a root's buffer, one per axis
+  GridOps* ops0 = nullptr;
+  LocalComm(std::shared_ptr<LocalBoard> b, int r_, int c_) : board(b), r(r_), c(c_) { my_done.assign(3, nullptr); }
+  int index(int axis) const { return axis == AX_ROW ? c : (axis == AX_COL ? r : r * board->pc + c); }
+  int bcast(void* buf, int64_t count, int root, int axis, GridOps* ops, int st) override
+  {
+    LocalBoard::Group& g = board->group(axis, r, c);
+    if(g.n == 1) return GPC_OK;
+    const int me = index(axis);
+    if(!my_done[axis]) my_done[axis] = ops->event_create();
+    if(me == root) {
+      if(!g.src_event) g.src_event = ops->event_create();
+      GRID_CHECK(ops->record(g.src_event, st));
+      g.src = buf;
+    }
+    LocalBoard::sync(g);
+    int rc = GPC_OK;
+    if(me != root) {
+      rc = ops->wait(st, g.src_event);
+      if(rc == GPC_OK) rc = ops->copy(buf, g.src, sizeof(double) * (size_t)count, st);
+      if(rc == GPC_OK) rc = ops->record(my_done[axis], st);
+      g.done_events[me] = my_done[axis];
+    }
+    LocalBoard::sync(g);
+    if(me == root)
+      for(int i = 0; i < g.n && rc == GPC_OK; i++)
+        if(i != root) rc = ops->wait(st, g.done_events[i]);
+    LocalBoard::sync(g);
+    return rc;
+  }
+  int allreduce_dev(double* buf, int64_t count, int axis, GridOps* ops, int st) override
+  {
+    LocalBoard::Group& g = board->group(axis, r, c);
+    if(g.n == 1) return GPC_OK;
+    const int me = index(axis);
+    g.parts[me].resize((size_t)count);
+    GRID_CHECK(ops->download(g.parts[me].data(), buf, sizeof(double) * (size_t)count, st));
+    LocalBoard::sync(g);
+    std::vector<double> sum((size_t)count, 0.0);
+    for(int i = 0; i < g.n; i++)
+      for(int64_t j = 0; j < count; j++) sum[(size_t)j] += g.parts[i][(size_t)j];   // rank order: same bits everywhere
+    LocalBoard::sync(g);
+    GRID_CHECK(ops->upload(buf, sum.data(), sizeof(double) * (size_t)count));
+    return GPC_OK;
+  }
+  int allreduce_host(double* v, int n, int axis) override
+  {
+    LocalBoard::Group& g = board->group(axis, r, c);
+    if(g.n == 1) return GPC_OK;
+    const int me = index(axis);
+    g.parts[me].assign(v, v + n);
+    LocalBoard::sync(g);
+    for(int j = 0; j < n; j++) {
+      double s = 0.0;
+      for(int i = 0; i < g.n; i++) s += g.parts[i][(size_t)j];
+      v[j] = s;
+    }
+    LocalBoard::sync(g);
+    return GPC_OK;
+  }
+  int allmin_host(int64_t* v) override
+  {
+    LocalBoard::Group& g = board->world;
+    if(g.n == 1) return GPC_OK;
+    g.imin[index(AX_WORLD)] = *v;
+    LocalBoard::sync(g);
+    int64_t m = g.imin[0];
+    for(int i = 1; i < g.n; i++) m = g.imin[i] < m ? g.imin[i] : m;
+    LocalBoard::sync(g);
+    *v = m;
+    return GPC_OK;
+  }
+  int barrier() override
+  {
+    LocalBoard::sync(board->world);
+    return GPC_OK;
+  }
+};
+
+struct SelfComm : GridComm {   // a 1 x 1 grid: nothing to exchange
+  int bcast(void*, int64_t, int, int, GridOps*, int) override { return GPC_OK; }
+  int allreduce_dev(double*, int64_t, int, GridOps*, int) override { return GPC_OK; }
+  int allreduce_host(double*, int, int) override { return GPC_OK; }
+  int allmin_host(int64_t*) override { return GPC_OK; }
+  int barrier() override { return GPC_OK; }
+};
+
+// ---- one rank of the distributed CGp state ------------------------------------------------------------------------------
+struct GridStats {
+  double bytes_recv[3] = {0, 0, 0};   // per axis, this rank, since the last reset
+  double bytes_sent[3] = {0, 0, 0};
+  int64_t collectives = 0;
+  double update_flops = 0;            // algorithmic flops of this rank's trailing updates
+  int64_t update_launches = 0;
+};
+
+class GridGp {
+ public:
+  GridGp(std::unique_ptr<GridOps> ops, std::unique_ptr<GridComm> comm, int pr, int pc, int r, int c, int64_t nb)
+      : ops_(std::move(ops)), comm_(std::move(comm)), pr_(pr), pc_(pc), r_(r), c_(c), nb_(nb)
+  {
+  }
+  ~GridGp() { free_all(); }
+
+  GridOps* ops() { return ops_.get(); }
+  GridComm* comm() { return comm_.get(); }
+  const Layout& layout() const { return L_; }
+  const GridStats& stats() const { return stats_; }
+  void reset_stats() { stats_ = GridStats(); }
+  const std::string& error() const { return err_; }
+  double logdet() const { return logdet_; }
+  double jitter() const { return jitter_; }
+  const double* local_block() const { return A_; }
+  int lookahead = 1;   // 0: everything on one stream, no overlap (debugging / A-B measurements)
+
+  // Problem definition: X (N x D), Y (N x d, may be null), Xstar (Ns x D, may be null) are HOST arrays, column-major,
+  // identical on every rank.  (Re)allocates the local block when the shape changes.
+  int set_problem(const gpc_kspec* ks, const double* X, int64_t N, int64_t D, int64_t ldx, const double* Y, int64_t d,
+                  int64_t ldy, const double* Xs, int64_t Ns, int64_t ldxs)
+  {
+    if(!ks || !X || N <= 0 || D <= 0 || ldx < N || d < 0 || Ns < 0 || (d > 0 && (!Y || ldy < N)) ||
+       (Ns > 0 && (!Xs || ldxs < Ns)))
+      return fail(GPC_EINVAL, "grid problem: bad dimensions");
+    if(nb_ <= 0 || nb_ % 128 != 0) return fail(GPC_EINVAL, "grid tile size must be a positive multiple of 128");
+    ks_ = *ks;
+    const bool reshape = !(N == L_.N && D == D_ && d == d_ && Ns == Ns_ && A_ != nullptr);
+    if(reshape) {
+      free_all();
+      D_ = D; d_ = d; Ns_ = Ns;
+      L_.init(N, nb_, pr_, pc_, r_, c_, d + Ns);
+      GRID_CHECK(allocate());
+    }
+    // replicated inputs
+    GRID_CHECK(upload_matrix(X_, X, N, D, ldx));
+    if(d > 0) GRID_CHECK(upload_matrix(Y_, Y, N, d, ldy));
+    if(Ns > 0) GRID_CHECK(upload_matrix(Xs_, Xs, Ns, D, ldxs));
+    GRID_CHECK(ops_->gather_rows(X_, N, D, N, r_, pr_, L_.Lr, nb_, Xr_, imax(L_.Lr * nb_, 1), ST_MAIN));
+    GRID_CHECK(ops_->gather_rows(X_, N, D, N, c_, pc_, L_.Lc, nb_, Xc_, imax(L_.Lc * nb_, 1), ST_MAIN));
+    factored_ = false;
+    return GPC_OK;
+  }
+  // kernel parameters only (an optimiser's inner loop): the inputs stay where they are
+  int set_kernel(const gpc_kspec* ks)
+  {
+    if(!ks || !A_) return fail(GPC_EINVAL, "grid: set_kernel before set_problem");
+    ks_ = *ks;
+    factored_ = false;
+    return GPC_OK;
+  }
+
+  // Every rank builds its own tiles of K from X (CGp::_updateK, CGp.cpp:698-712), then the right-hand-side rows.
+  int fill(double diag_shift)
+  {
+    const Layout& L = L_;
+    if(L.Lr > 0 && L.Lc > 0)
+      GRID_CHECK(ops_->gram_cross(&ks_, Xr_, L.Lr * nb_, L.Lr * nb_, Xc_, L.Lc * nb_, L.Lc * nb_, D_, A_, L.lld, ST_MAIN));
+    GRID_CHECK(ops_->gram_diag(&ks_, X_, L.N, D_, L.N, diag_shift, dg_, ST_MAIN));
+    if(L.has_extra && L.Lc > 0) {
+      double* Aex = A_ + L.Lr * nb_;
+      GRID_CHECK(ops_->zero2d(Aex, L.lld, L.E2, L.nloc, ST_MAIN));
+      if(d_ > 0) GRID_CHECK(ops_->put_rhs_rows(Aex, L.lld, Y_, L.N, d_, L, ST_MAIN));
+      if(Ns_ > 0) GRID_CHECK(ops_->gram_cross(&ks_, Xs_, Ns_, Ns_, Xc_, L.Lc * nb_, L.Lc * nb_, D_, Aex + d_, L.lld, ST_MAIN));
+    }
+    GRID_CHECK(ops_->fix_diag_pad(A_, L, dg_, ST_MAIN));
+    factored_ = false;
+    return GPC_OK;
+  }
+
+  // CGp::updateK (FTC) on the distributed matrix: Gram, factor, log|K|, with CMatrix::jitChol's jitter schedule
+  // (CMatrix.cpp:767-804) when a pivot fails: first candidate 1e-6 * trace(K) / N, x10 per retry, accumulated on the
+  // diagonal of a regenerated K; gives up when the candidate exceeds 10 or after maxTries.
+  int update_k(double* logdet, double* jitter_added, int* info, int max_tries = 20)
+  {
+    GRID_CHECK(fill(0.0));
+    double jitter = -1.0, total = 0.0;
+    int tries = 0, inf = 0;
+    for(;;) {
+      if(jitter < 0.0) {
+        double tr = 0.0;   // trace(K) = sum of the replicated diagonal values: no exchange needed
+        GRID_CHECK(ops_->sum_host(dg_, L_.N, &tr, ST_MAIN));
+        jitter = 1e-6 * tr / (double)L_.N;
+      }
+      GRID_CHECK(factor(&inf));
+      if(inf == 0) break;
+      total += jitter;
+      jitter *= 10.0;
+      tries++;
+      if(jitter > 10.0 || tries >= max_tries) break;
+      GRID_CHECK(fill(total));
+    }
+    jitter_ = total;
+    if(info) *info = inf;
+    if(jitter_added) *jitter_added = total;
+    if(inf != 0) return GPC_OK;   // like gpc_gp_update_k_f64: the status is in *info
+    double s = 0.0;
+    GRID_CHECK(ops_->diag_logsum(A_, L_, &s, ST_MAIN));
+    GRID_CHECK(comm_->allreduce_host(&s, 1, AX_WORLD));
+    logdet_ = s;
+    if(logdet) *logdet = s;
+    return GPC_OK;
+  }
+
+  // Right-looking block Cholesky of the local blocks, look-ahead 1.  *info: LAPACK's (smallest failing minor, 0 = ok).
+  int factor(int* info)
+  {
+    const Layout& L = L_;
+    GRID_CHECK(ops_->zero(info_dev_, sizeof(int) * 2, ST_MAIN));
+    const int SP = lookahead ? ST_PANEL : ST_MAIN;
+    GRID_CHECK(ops_->record(ev_ready_, ST_MAIN));
+    if(SP != ST_MAIN) GRID_CHECK(ops_->wait(SP, ev_ready_));
+    GRID_CHECK(panel_phase(0, SP));
+    for(int64_t k = 0; k < L.T; k++) {
+      const int b = (int)(k & 1);
+      if(SP != ST_MAIN) GRID_CHECK(ops_->wait(ST_MAIN, ev_panel_[b]));
+      const int64_t il0 = L.il0(k), jl0 = L.jl0(k);
+      const int64_t M = L.mloc - il0 * nb_;
+      int64_t jfirst = jl0;
+      if(k + 1 < L.T) {
+        const bool next_col = (int)((k + 1) % pc_) == c_;
+        if(next_col && M > 0 && jl0 < L.Lc) {
+          // U1: the tiles of panel k+1 first, so that its factorisation overlaps the rest of this update
+          GRID_CHECK(update(k, il0, jl0, 1, ST_MAIN));
+          jfirst = jl0 + 1;
+        }
+        if(SP != ST_MAIN) {
+          GRID_CHECK(ops_->record(ev_u1_, ST_MAIN));
+          GRID_CHECK(ops_->wait(SP, ev_u1_));
+          if(free_valid_[b ^ 1]) GRID_CHECK(ops_->wait(SP, ev_free_[b ^ 1]));   // update k-1 has released W/V[(k+1)&1]
+        }
+        GRID_CHECK(panel_phase(k + 1, SP));
+      }
+      if(M > 0 && jfirst < L.Lc) GRID_CHECK(update(k, il0, jfirst, L.Lc - jfirst, ST_MAIN));
+      if(SP != ST_MAIN) {
+        GRID_CHECK(ops_->record(ev_free_[b], ST_MAIN));
+        free_valid_[b] = true;
+      }
+    }
+    if(SP != ST_MAIN) {
+      GRID_CHECK(ops_->record(ev_u1_, SP));
+      GRID_CHECK(ops_->wait(ST_MAIN, ev_u1_));
+    }
+    free_valid_[0] = free_valid_[1] = false;
+    int inf = 0;
+    GRID_CHECK(ops_->read_info(info_dev_, &inf, ST_MAIN));
+    int64_t v = inf > 0 ? (int64_t)inf : ((int64_t)1 << 60);
+    GRID_CHECK(comm_->allmin_host(&v));
+    inf = v < ((int64_t)1 << 60) ? (int)v : 0;
+    if(inf > L.N) inf = (int)L.N;   // (cannot happen: the padding is the identity)
+    factored_ = inf == 0;
+    if(info) *info = inf;
+    return GPC_OK;
+  }
+
+  // CGp::logLikelihood, FTC (CGp.cpp:913-938, 1002-1013): -0.5 (sum_j |L^-1 y_j|^2 + d log|K|) - d N/2 log 2 pi
+  int loglik(double* ll)
+  {
+    if(!factored_ || d_ <= 0) return fail(GPC_EINVAL, "grid loglik: no factor / no targets");
+    std::vector<double> q((size_t)d_, 0.0);
+    GRID_CHECK(extra_sumsq(0, d_, q.data()));
+    double quad = 0.0;
+    for(int64_t j = 0; j < d_; j++) quad += q[(size_t)j];
+    *ll = -0.5 * (quad + (double)d_ * logdet_) - (double)d_ * (double)L_.N * 0.5 * log(2.0 * M_PI);
+    return GPC_OK;
+  }
+
+  // CGp::updateAlpha (CGp.cpp:469-489): alpha = K^-1 y, N x d, replicated; alpha_host may be null (kept on the device).
+  // Column-oriented back substitution L' alpha = z over the tiles, last to first: the ranks of process column k mod pc
+  // form sum_{I>k} L(I,k)' alpha_I for their rows, one reduction down the column, the diagonal owner solves and sends.
+  int alpha(double* alpha_host, int64_t lda)
+  {
+    const Layout& L = L_;
+    if(!factored_ || d_ <= 0) return fail(GPC_EINVAL, "grid alpha: no factor / no targets");
+    const int er = L.extra_row();
+    GRID_CHECK(ops_->zero(al_, sizeof(double) * (size_t)(L.Np * d_), ST_MAIN));
+    GRID_CHECK(ops_->zero(alr_, sizeof(double) * (size_t)(imax(L.Lr, 1) * nb_ * d_), ST_MAIN));
+    const int64_t ldr = imax(L.Lr, 1) * nb_;
+    for(int64_t k = L.T - 1; k >= 0; k--) {
+      const int kr = (int)(k % pr_), kc = (int)(k % pc_);
+      if(c_ == kc) {
+        const int64_t jl = k / pc_, il0 = L.il0(k);
+        const int64_t Mb = (L.Lr - il0) * nb_;   // matrix rows below tile k on this rank
+        GRID_CHECK(ops_->zero(t_, sizeof(double) * (size_t)(nb_ * d_), ST_MAIN));
+        if(Mb > 0)
+          GRID_CHECK(ops_->gemm('T', 'N', nb_, d_, Mb, -1.0, A_ + il0 * nb_ + jl * nb_ * L.lld, L.lld, alr_ + il0 * nb_, ldr,
+                                0.0, t_, nb_, ST_MAIN));
+        if(r_ == er)
+          GRID_CHECK(ops_->add_transposed(t_, nb_, A_ + L.Lr * nb_ + jl * nb_ * L.lld, L.lld, nb_, d_, ST_MAIN));
+        GRID_CHECK(comm_->allreduce_dev(t_, nb_ * d_, AX_COL, ops_.get(), ST_MAIN));
+        count_coll(AX_COL, 8.0 * (double)(nb_ * d_), pr_);
+        if(r_ == kr) {
+          const int64_t il = k / pr_;
+          GRID_CHECK(ops_->trsm_llt(A_ + il * nb_ + jl * nb_ * L.lld, L.lld, nb_, t_, nb_, d_, ST_MAIN));
+        }
+      }
+      GRID_CHECK(comm_->bcast(t_, nb_ * d_, kr * pc_ + kc, AX_WORLD, ops_.get(), ST_MAIN));
+      count_coll(AX_WORLD, 8.0 * (double)(nb_ * d_), (kr == r_ && kc == c_) ? 0 : 1);
+      GRID_CHECK(ops_->copy2d(al_ + k * nb_, L.Np, t_, nb_, nb_, d_, ST_MAIN));
+      if(r_ == kr) GRID_CHECK(ops_->copy2d(alr_ + (k / pr_) * nb_, ldr, t_, nb_, nb_, d_, ST_MAIN));
+    }
+    alpha_valid_ = true;
+    if(alpha_host) {
+      std::vector<double> h((size_t)(L.Np * d_));
+      GRID_CHECK(ops_->download(h.data(), al_, sizeof(double) * h.size(), ST_MAIN));
+      for(int64_t j = 0; j < d_; j++) memcpy(alpha_host + j * lda, h.data() + j * L.Np, sizeof(double) * (size_t)L.N);
+    }
+    return GPC_OK;
+  }
+
+  // CGp::posteriorMeanVar before output scale / bias (CGp.cpp:548-625, 642-663) at the test inputs given to set_problem:
+  // mu = K(X*, X) alpha (Ns x d), var = k(x*, x*) - |L^-1 K(X, x*)|^2 (Ns).  Host outputs.
+  int posterior(double* mu_host, int64_t ldmu, double* var_host)
+  {
+    const Layout& L = L_;
+    if(!factored_ || Ns_ <= 0 || d_ <= 0) return fail(GPC_EINVAL, "grid posterior: no factor / no test inputs");
+    if(!alpha_valid_) GRID_CHECK(alpha(nullptr, 0));
+    double *kx = nullptr, *mu = nullptr, *kss = nullptr;
+    GRID_CHECK(ops_->alloc((void**)&kx, sizeof(double) * (size_t)(Ns_ * L.N)));
+    GRID_CHECK(ops_->alloc((void**)&mu, sizeof(double) * (size_t)(Ns_ * d_)));
+    GRID_CHECK(ops_->alloc((void**)&kss, sizeof(double) * (size_t)Ns_));
+    int rc = ops_->gram_cross(&ks_, Xs_, Ns_, Ns_, X_, L.N, L.N, D_, kx, Ns_, ST_MAIN);
+    if(rc == GPC_OK) rc = ops_->gemm('N', 'N', Ns_, d_, L.N, 1.0, kx, Ns_, al_, L.Np, 0.0, mu, Ns_, ST_MAIN);
+    if(rc == GPC_OK) rc = ops_->gram_diag(&ks_, Xs_, Ns_, D_, Ns_, 0.0, kss, ST_MAIN);
+    std::vector<double> hm((size_t)(Ns_ * d_)), hk((size_t)Ns_), q((size_t)Ns_, 0.0);
+    if(rc == GPC_OK) rc = ops_->download(hm.data(), mu, sizeof(double) * hm.size(), ST_MAIN);
+    if(rc == GPC_OK) rc = ops_->download(hk.data(), kss, sizeof(double) * hk.size(), ST_MAIN);
+    ops_->release(kx);
+    ops_->release(mu);
+    ops_->release(kss);
+    GRID_CHECK(rc);
+    GRID_CHECK(extra_sumsq(d_, d_ + Ns_, q.data()));
+    for(int64_t j = 0; j < d_; j++)
+      for(int64_t i = 0; i < Ns_; i++) mu_host[i + j * ldmu] = hm[(size_t)(i + j * Ns_)];
+    for(int64_t i = 0; i < Ns_; i++) var_host[i] = hk[(size_t)i] - q[(size_t)i];
+    return GPC_OK;
+  }
+
+  // tests / debugging: tile (I, J) of the local block to the host (nb x nb, ld nb); *owned = 0 if it lives elsewhere
+  int copy_tile(int64_t I, int64_t J, double* host, int* owned)
+  {
+    const Layout& L = L_;
+    const bool extra = (I == L.T);
+    const bool mine = (extra ? L.has_extra : (int)(I % pr_) == r_) && (int)(J % pc_) == c_ && J < L.T && I <= L.T;
+    if(owned) *owned = mine ? 1 : 0;
+    if(!mine) return GPC_OK;
+    const int64_t il = extra ? L.Lr : I / pr_, jl = J / pc_;
+    const int64_t rows = extra ? L.E : nb_;
+    std::vector<double> col((size_t)rows);
+    GRID_CHECK(ops_->sync(ST_MAIN));
+    for(int64_t j = 0; j < nb_; j++) {
+      GRID_CHECK(ops_->download(col.data(), A_ + il * nb_ + (jl * nb_ + j) * L.lld, sizeof(double) * (size_t)rows, ST_MAIN));
+      memcpy(host + j * nb_, col.data(), sizeof(double) * (size_t)rows);
+    }
+    return GPC_OK;
+  }
+
+ private:
+  static int64_t imax(int64_t a, int64_t b) { return a > b ? a : b; }
+  int fail(int rc, const char* msg)
+  {
+    err_ = msg;
+    return rc;
+  }
+  void count_coll(int axis, double bytes, int receivers_or_flag)
+  {
+    stats_.collectives++;
+    if(receivers_or_flag) stats_.bytes_recv[axis] += bytes;
+  }
+
+  int upload_matrix(double* dst, const double* src, int64_t rows, int64_t cols, int64_t ld)
+  {
+    if(ld == rows) return ops_->upload(dst, src, sizeof(double) * (size_t)(rows * cols));
+    for(int64_t j = 0; j < cols; j++)
+      GRID_CHECK(ops_->upload(dst + j * rows, src + j * ld, sizeof(double) * (size_t)rows));
+    return GPC_OK;
+  }
+
+  int allocate()
+  {
+    const Layout& L = L_;
+    auto A = [&](double*& p, int64_t n) { return ops_->alloc((void**)&p, sizeof(double) * (size_t)imax(n, 2)); };
+    GRID_CHECK(A(A_, L.lld * imax(L.nloc, 1)));
+    GRID_CHECK(A(X_, L.N * D_));
+    GRID_CHECK(A(Xr_, imax(L.Lr, 1) * nb_ * D_));
+    GRID_CHECK(A(Xc_, imax(L.Lc, 1) * nb_ * D_));
+    GRID_CHECK(A(dg_, L.N));
+    if(d_ > 0) {
+      GRID_CHECK(A(Y_, L.N * d_));
+      GRID_CHECK(A(al_, L.Np * d_));
+      GRID_CHECK(A(alr_, imax(L.Lr, 1) * nb_ * d_));
+      GRID_CHECK(A(t_, nb_ * d_));
+    }
+    if(Ns_ > 0) GRID_CHECK(A(Xs_, Ns_ * D_));
+    // exchange buffers (only the ones this grid shape needs)
+    for(int b = 0; b < 2; b++) {
+      if(pc_ > 1) GRID_CHECK(A(W_[b], L.lld * nb_));
+      if(pr_ > 1) {
+        GRID_CHECK(A(V_[b], imax(L.nloc, nb_) * nb_));
+        GRID_CHECK(A(Dg_[b], nb_ * nb_));
+      }
+      ev_panel_[b] = ops_->event_create();
+      ev_free_[b] = ops_->event_create();
+    }
+    ev_ready_ = ops_->event_create();
+    ev_u1_ = ops_->event_create();
+    GRID_CHECK(ops_->alloc((void**)&info_dev_, 64));
+    // column-panel offset table (see Stair2D): tile-major slots ordered by source process row when pr > 1, else the
+    // rows of the row panel itself
+    voff_host_.assign((size_t)imax(L.Lc, 1), 0);
+    region_start_.assign((size_t)pr_ + 1, 0);
+    if(pr_ > 1) {
+      std::vector<int64_t> cnt((size_t)pr_, 0);
+      for(int64_t jl = 0; jl < L.Lc; jl++) cnt[(size_t)((c_ + pc_ * jl) % pr_)]++;
+      for(int s = 0; s < pr_; s++) region_start_[(size_t)s + 1] = region_start_[(size_t)s] + cnt[(size_t)s];
+      std::vector<int64_t> seen((size_t)pr_, 0);
+      slot_.assign((size_t)imax(L.Lc, 1), 0);
+      for(int64_t jl = 0; jl < L.Lc; jl++) {
+        const int s = (int)((c_ + pc_ * jl) % pr_);
+        slot_[(size_t)jl] = region_start_[(size_t)s] + seen[(size_t)s]++;
+        voff_host_[(size_t)jl] = slot_[(size_t)jl] * nb_ * nb_;
+      }
+    } else {
+      for(int64_t jl = 0; jl < L.Lc; jl++) voff_host_[(size_t)jl] = (c_ + pc_ * jl) * nb_;   // row tile J of the row panel
+    }
+    GRID_CHECK(ops_->alloc((void**)&voff_dev_, sizeof(int64_t) * voff_host_.size()));
+    GRID_CHECK(ops_->upload(voff_dev_, voff_host_.data(), sizeof(int64_t) * voff_host_.size()));
+    return GPC_OK;
+  }
+
+  void free_all()
+  {
+    if(!ops_) return;
+    double** ps[] = {&A_, &X_, &Xr_, &Xc_, &dg_, &Y_, &al_, &alr_, &t_, &Xs_, &W_[0], &W_[1], &V_[0], &V_[1], &Dg_[0], &Dg_[1]};
+    for(double** p : ps)
+      if(*p) {
+        ops_->release(*p);
+        *p = nullptr;
+      }
+    if(info_dev_) ops_->release(info_dev_);
+    if(voff_dev_) ops_->release(voff_dev_);
+    info_dev_ = nullptr;
+    voff_dev_ = nullptr;
+    void** evs[] = {&ev_panel_[0], &ev_panel_[1], &ev_free_[0], &ev_free_[1], &ev_ready_, &ev_u1_};
+    for(void** e : evs)
+      if(*e) {
+        ops_->event_destroy(*e);
+        *e = nullptr;
+      }
+    alpha_valid_ = factored_ = false;
+  }
+
+  // The row panel of step k as this rank sees it after panel_phase(k): pointer to the rows below tile k, leading dimension.
+  void row_panel(int64_t k, const double*& W, int64_t& ldw) const
+  {
+    const Layout& L = L_;
+    const int64_t il0 = L.il0(k);
+    if(pc_ > 1) {
+      W = W_[k & 1];
+      ldw = imax(L.mloc - il0 * nb_, 2);
+    } else {   // one process column: the panel is read where it was computed
+      W = A_ + il0 * nb_ + (k / pc_) * nb_ * L.lld;
+      ldw = L.lld;
+    }
+  }
+
+  // steps (1)-(4) of panel k on stream st; leaves W / V of parity k&1 complete and records ev_panel_[k&1]
+  int panel_phase(int64_t k, int st)
+  {
+    const Layout& L = L_;
+    const int b = (int)(k & 1);
+    const int kr = (int)(k % pr_), kc = (int)(k % pc_);
+    const int64_t il0 = L.il0(k), jl0 = L.jl0(k);
+    const int64_t M = L.mloc - il0 * nb_;          // rows below tile k on this rank (extra rows included)
+    const double* W = nullptr;
+    int64_t ldw = 0;
+    row_panel(k, W, ldw);
+    if(c_ == kc) {
+      const int64_t jl = k / pc_;
+      double* col = A_ + jl * nb_ * L.lld;
+      if(pr_ == 1) {
+        // the whole panel is local: diagonal block + the rows below it in one chain (dpotrf + dtrsm)
+        GRID_CHECK(ops_->potrf_panel(L.mloc - k * nb_, nb_, col + k * nb_, L.lld, k * nb_, info_dev_, st));
+      } else {
+        if(r_ == kr) {
+          const int64_t il = k / pr_;
+          GRID_CHECK(ops_->potrf_tile(col + il * nb_, L.lld, nb_, k * nb_, info_dev_, st));
+          GRID_CHECK(ops_->copy2d(Dg_[b], nb_, col + il * nb_, L.lld, nb_, nb_, st));
+        }
+        GRID_CHECK(comm_->bcast(Dg_[b], nb_ * nb_, kr, AX_COL, ops_.get(), st));
+        count_coll(AX_COL, 8.0 * (double)(nb_ * nb_), r_ != kr);
+        if(M > 0) GRID_CHECK(ops_->trsm_rlt(Dg_[b], nb_, nb_, col + il0 * nb_, L.lld, M, st));
+      }
+      if(pc_ > 1 && M > 0) GRID_CHECK(ops_->copy2d(W_[b], ldw, col + il0 * nb_, L.lld, M, nb_, st));
+    }
+    if(pc_ > 1 && M > 0) {
+      GRID_CHECK(comm_->bcast(W_[b], ldw * nb_, kc, AX_ROW, ops_.get(), st));
+      count_coll(AX_ROW, 8.0 * (double)(ldw * nb_), c_ != kc);
+    }
+    if(pr_ > 1 && jl0 < L.Lc) {
+      // column panel: tiles L(J,k), J = c + pc*jl > k, grouped by the process row that holds them (J mod pr)
+      const int64_t g = Layout::gcd(pr_, pc_);
+      const int64_t q = pr_ / g;          // consecutive tiles of one source are q local column tiles apart
+      for(int s = 0; s < pr_; s++) {
+        // first jl >= jl0 with (c + pc*jl) mod pr == s
+        int64_t jf = -1;
+        for(int64_t jl = jl0; jl < jl0 + q && jl < L.Lc; jl++)
+          if((int)((c_ + pc_ * jl) % pr_) == s) { jf = jl; break; }
+        if(jf < 0) continue;
+        const int64_t count = (L.Lc - 1 - jf) / q + 1;
+        double* dst = V_[b] + slot_[(size_t)jf] * nb_ * nb_;
+        if(r_ == s) {
+          const int64_t J = c_ + pc_ * jf;
+          const int64_t first = J / pr_ - il0;                 // row tile of W that holds L(J,k)
+          GRID_CHECK(ops_->pack_tiles(dst, W, ldw, first, pc_ / g, count, nb_, st));
+        }
+        GRID_CHECK(comm_->bcast(dst, count * nb_ * nb_, s, AX_COL, ops_.get(), st));
+        count_coll(AX_COL, 8.0 * (double)(count * nb_ * nb_), r_ != s);
+      }
+    }
+    if(st != ST_MAIN) GRID_CHECK(ops_->record(ev_panel_[b], st));
+    return GPC_OK;
+  }
+
+  // A(I,J) -= W(I) V(J)' for local column tiles jl_first .. jl_first + ncolt - 1 and all rows below tile k
+  int update(int64_t k, int64_t il0, int64_t jl_first, int64_t ncolt, int st)
+  {
+    const Layout& L = L_;
+    UpdateArgs u;
+    u.M = L.mloc - il0 * nb_;
+    u.Ncols = ncolt * nb_;
+    u.K = nb_;
+    row_panel(k, u.W, u.ldw);
+    if(pr_ > 1) {
+      u.Vbase = V_[k & 1];
+      u.ldv = nb_;
+    } else {
+      u.Vbase = u.W - il0 * nb_;     // row tile J of the row panel; voff = J * nb
+      u.ldv = u.ldw;
+    }
+    u.voff_dev = voff_dev_;
+    u.voff_host = voff_host_.data();
+    u.C = A_ + il0 * nb_ + jl_first * nb_ * L.lld;
+    u.ldc = L.lld;
+    u.nb = nb_;
+    u.I0 = r_ + pr_ * il0;
+    u.J0 = c_ + pc_ * jl_first;
+    u.jl0 = jl_first;
+    u.pr = pr_;
+    u.pc = pc_;
+    // algorithmic flops: 2 nb per entry on or below the global diagonal
+    double entries = 0.0;
+    for(int64_t jl = jl_first; jl < jl_first + ncolt; jl++) {
+      const int64_t J = c_ + pc_ * jl;
+      const int64_t ilf = Layout::first_after(J - 1, r_, pr_);   // first local row tile with I >= J
+      double rows = (double)(L.mloc - ilf * nb_);
+      if(rows <= 0) continue;
+      entries += rows * (double)nb_;
+      if(ilf < L.Lr && r_ + pr_ * ilf == J) entries -= 0.5 * (double)nb_ * (double)(nb_ - 1);
+    }
+    stats_.update_flops += 2.0 * (double)nb_ * entries;
+    stats_.update_launches++;
+    ops_->prof_update_begin(2.0 * (double)nb_ * entries, st);
+    const int rc = ops_->update(u, st);
+    ops_->prof_update_end(st);
+    return rc;
+  }
+
+  // sum over ALL columns (all ranks) of the squares of extra rows e0 .. e1-1
+  int extra_sumsq(int64_t e0, int64_t e1, double* out)
+  {
+    const Layout& L = L_;
+    const int64_t ne = e1 - e0;
+    for(int64_t i = 0; i < ne; i++) out[i] = 0.0;
+    if(L.has_extra && L.nloc > 0) GRID_CHECK(ops_->rows_sumsq(A_ + L.Lr * nb_ + e0, L.lld, ne, L.nloc, out, ST_MAIN));
+    return comm_->allreduce_host(out, (int)ne, AX_WORLD);
+  }
+
+  std::unique_ptr<GridOps> ops_;
+  std::unique_ptr<GridComm> comm_;
+  int pr_, pc_, r_, c_;
+  int64_t nb_;
+  Layout L_;
+  gpc_kspec ks_;
+  int64_t D_ = 0, d_ = 0, Ns_ = 0;
+  double *A_ = nullptr, *X_ = nullptr, *Xr_ = nullptr, *Xc_ = nullptr, *dg_ = nullptr, *Y_ = nullptr, *al_ = nullptr,
+         *alr_ = nullptr, *t_ = nullptr, *Xs_ = nullptr;
+  double *W_[2] = {nullptr, nullptr}, *V_[2] = {nullptr, nullptr}, *Dg_[2] = {nullptr, nullptr};
+  int* info_dev_ = nullptr;
+  int64_t* voff_dev_ = nullptr;
+  std::vector<int64_t> voff_host_, slot_, region_start_;
+  void *ev_panel_[2] = {nullptr, nullptr}, *ev_free_[2] = {nullptr, nullptr}, *ev_ready_ = nullptr, *ev_u1_ = nullptr;
+  bool free_valid_[2] = {false, false};
+  bool factored_ = false, alpha_valid_ = false;
+  double logdet_ = 0.0, jitter_ = 0.0;
+  GridStats stats_;
+  std::string err_;
+};
+
+}  // namespace grid
+}  // namespace gpc

@@ -560,7 +560,7 @@ struct LookAhead {
     return ev[next++];
   }
 };
-LookAhead g_la;
+thread_local LookAhead g_la;   // per host thread, like the scratch buffers (capi.hip)
 
 int ensure_lookahead()
 {
@@ -659,7 +659,7 @@ static int64_t panel_width(int64_t rem)
   return g_nb_outer > 0 ? g_nb_outer : 1024;
 }
 
-int potrf_lower(int64_t N, double* A, int64_t lda, int* d_info, hipStream_t s)
+int potrf_lower(int64_t N, double* A, int64_t lda, int* d_info, hipStream_t s, int64_t col0)
 {
   if(N <= 0) return GPC_OK;
   // Look-ahead pays only on large matrices: the panel kernels of a tall panel fill the chip themselves, so running them
@@ -678,7 +678,7 @@ int potrf_lower(int64_t N, double* A, int64_t lda, int* d_info, hipStream_t s)
       const int64_t NB = panel_width(N - k0);
       nbk = (N - k0 < NB) ? (N - k0) : NB;
       const int64_t kend = k0 + nbk;
-      GPC_CHECK(factor_panel(N, A, lda, k0, nbk, d_info, s));
+      GPC_CHECK(factor_panel(N, A, lda, k0, nbk, d_info, s, col0));
       const int64_t mt = N - kend;
       if(mt > 0) {
         const double* L21 = A + kend + k0 * lda;
@@ -701,7 +701,7 @@ int potrf_lower(int64_t N, double* A, int64_t lda, int* d_info, hipStream_t s)
   GPC_HIP_CHECK(hipEventRecord(e0, s));           // everything queued before this call (the Gram build, memset of info)
   GPC_HIP_CHECK(hipStreamWaitEvent(sp, e0, 0));
   int64_t nbk = (N < panel_width(N)) ? N : panel_width(N), nb_next = 0;
-  GPC_CHECK(factor_panel(N, A, lda, 0, nbk, d_info, sp));
+  GPC_CHECK(factor_panel(N, A, lda, 0, nbk, d_info, sp, col0));
   hipEvent_t e_panel = g_la.get();
   if(!e_panel) return GPC_EHIP;
   GPC_HIP_CHECK(hipEventRecord(e_panel, sp));
@@ -728,7 +728,7 @@ int potrf_lower(int64_t N, double* A, int64_t lda, int* d_info, hipStream_t s)
     GPC_HIP_CHECK(hipEventRecord(e_u1, s));
     // panel k+1 on the panel stream, concurrently with U2(k)
     GPC_HIP_CHECK(hipStreamWaitEvent(sp, e_u1, 0));
-    GPC_CHECK(factor_panel(N, A, lda, kend, nb1, d_info, sp));
+    GPC_CHECK(factor_panel(N, A, lda, kend, nb1, d_info, sp, col0));
     e_panel = g_la.get();
     if(!e_panel) return GPC_EHIP;
     GPC_HIP_CHECK(hipEventRecord(e_panel, sp));

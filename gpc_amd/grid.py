@@ -1,0 +1,296 @@
+"""ctypes front end of the 2-D block-cyclic multi-GPU factorisation (gpc_grid_* in include/gpc_hip.h).
+
+The driver itself is C++ below the C-ABI (gpc_amd/csrc/grid_sched.hpp: scheduler, look-ahead; grid.hip: HIP kernels + RCCL);
+this module only marshals host numpy arrays in and out and, for the single-process form, runs one Python thread per rank
+(ctypes releases the GIL for the duration of a call).  It distributes CGp::updateK / logLikelihood / updateAlpha /
+posteriorMeanVar of the reference (/root/reference/CGp.cpp:698-712, 877-891, 913-938, 469-489, 548-663).
+
+`binding` selects the shared library: the default is libgpc_hip.so (no CPU fallback: it needs a gfx950 GPU); the CPU
+test-suite passes a binding of its host stand-in, which exports the same entry points under another prefix.
+"""
+import ctypes
+import threading
+from ctypes import byref, c_double, c_int, c_int64, c_void_p
+
+import numpy as np
+
+from . import _lib
+from ._lib import GRID_SIGNATURES, GpcError, GridTransport, KSpec
+
+UID_BYTES = 128
+AXIS_ROW, AXIS_COL, AXIS_WORLD = 0, 1, 2
+
+
+class Binding(object):
+    """The gpc_grid_* entry points of one shared library."""
+
+    def __init__(self, cdll, prefix, last_error=None):
+        self.cdll = cdll
+        for name, (res, args) in GRID_SIGNATURES.items():
+            fn = getattr(cdll, prefix + name)
+            fn.restype = res
+            fn.argtypes = args
+            setattr(self, name, fn)
+        self._global_error = last_error
+
+    def check(self, rc, handle=None):
+        if rc != _lib.GPC_OK:
+            msg = b""
+            if handle is not None:
+                msg = self.last_error(handle) or b""
+            if not msg and self._global_error is not None:
+                msg = self._global_error() or b""
+            raise GpcError(rc, msg.decode() if msg else "")
+        return rc
+
+
+_product = None
+
+
+def product_binding():
+    global _product
+    if _product is None:
+        lib = _lib.load()
+        _product = Binding(lib, "gpc_grid_", lib.gpc_last_error)
+    return _product
+
+
+def default_shape(nranks):
+    """pr x pc for a node's GPU count (1x1, 1x2, 2x2, 2x4); pr <= pc keeps the row panels --
+    the larger of the two exchanged pieces -- spread over more senders."""
+    pr = 1
+    while (pr * 2) * (pr * 2) <= nranks and nranks % (pr * 2) == 0:
+        pr *= 2
+    return pr, nranks // pr
+
+
+def _kspec(terms_or_ks):
+    if isinstance(terms_or_ks, KSpec):
+        return terms_or_ks
+    from .api import kspec
+    return kspec(terms_or_ks)
+
+
+def _f(a):
+    """host array -> Fortran-ordered float64 (column-major like CMatrix), kept alive by the caller"""
+    a = np.asarray(a, dtype=np.float64)
+    if a.ndim == 1:
+        a = a.reshape(-1, 1)
+    return np.asfortranarray(a)
+
+
+class Grid(object):
+    """One rank of a pr x pc grid."""
+
+    def __init__(self, handle, binding):
+        self.h = handle
+        self.b = binding
+        self._keep = None
+
+    def destroy(self):
+        if self.h:
+            self.b.destroy(self.h)
+            self.h = None
+
+    def info(self):
+        out = (c_int64 * 12)()
+        self.b.check(self.b.info(self.h, out), self.h)
+        keys = ["N", "nb", "T", "pr", "pc", "r", "c", "mloc", "nloc", "E", "Lr", "Lc"]
+        return dict(zip(keys, [int(v) for v in out]))
+
+    def stats(self, reset=False):
+        out = (c_double * 8)()
+        self.b.check(self.b.stats(self.h, out, 1 if reset else 0), self.h)
+        return {"bytes_row": out[0], "bytes_col": out[1], "bytes_world": out[2], "collectives": int(out[3]),
+                "update_flops": out[4], "update_launches": int(out[5])}
+
+    def set_lookahead(self, on):
+        self.b.check(self.b.set_lookahead(self.h, 1 if on else 0), self.h)
+
+    def set_problem(self, terms, X, Y=None, Xstar=None):
+        ks = _kspec(terms)
+        X = _f(X)
+        N, D = X.shape
+        Y = None if Y is None else _f(Y)
+        Xs = None if Xstar is None else _f(Xstar)
+        d = 0 if Y is None else Y.shape[1]
+        Ns = 0 if Xs is None else Xs.shape[0]
+        self.N, self.D, self.d, self.Ns = N, D, d, Ns
+        self.b.check(self.b.set_problem(self.h, byref(ks), X.ctypes.data, N, D, N,
+                                        None if Y is None else Y.ctypes.data, d, N,
+                                        None if Xs is None else Xs.ctypes.data, Ns, max(Ns, 1)), self.h)
+
+    def set_kernel(self, terms):
+        ks = _kspec(terms)
+        self.b.check(self.b.set_kernel(self.h, byref(ks)), self.h)
+
+    def update_k(self):
+        """-> (logdet, jitter_added, info)"""
+        ld, jit, info = c_double(0.0), c_double(0.0), c_int(0)
+        self.b.check(self.b.update_k(self.h, byref(ld), byref(jit), byref(info)), self.h)
+        return ld.value, jit.value, info.value
+
+    def fill(self):
+        self.b.check(self.b.fill(self.h), self.h)
+
+    def factor(self):
+        info = c_int(0)
+        self.b.check(self.b.factor(self.h, byref(info)), self.h)
+        return info.value
+
+    def sync(self):
+        self.b.check(self.b.sync(self.h), self.h)
+
+    def barrier(self):
+        self.b.check(self.b.barrier(self.h), self.h)
+
+    def loglik(self):
+        ll = c_double(0.0)
+        self.b.check(self.b.loglik(self.h, byref(ll)), self.h)
+        return ll.value
+
+    def alpha(self):
+        out = np.zeros((self.N, self.d), order="F")
+        self.b.check(self.b.alpha(self.h, out.ctypes.data, self.N), self.h)
+        return out
+
+    def posterior(self):
+        mu = np.zeros((self.Ns, self.d), order="F")
+        var = np.zeros(self.Ns)
+        self.b.check(self.b.posterior(self.h, mu.ctypes.data, max(self.Ns, 1), var.ctypes.data), self.h)
+        return mu, var
+
+    def copy_tile(self, I, J):
+        """tile (I, J) of the local block as an nb x nb array, or None when it lives on another rank"""
+        nb = self.info()["nb"]
+        buf = np.zeros((nb, nb), order="F")
+        owned = c_int(0)
+        self.b.check(self.b.copy_tile(self.h, I, J, buf.ctypes.data, byref(owned)), self.h)
+        return buf if owned.value else None
+
+    def local_tiles(self, lower_only=True, extras=False):
+        """{(I, J): tile} for every tile this rank owns (tests)."""
+        inf = self.info()
+        T, pr, pc, r, c = inf["T"], inf["pr"], inf["pc"], inf["r"], inf["c"]
+        out = {}
+        rows = list(range(r, T, pr))
+        if extras and inf["E"] > 0 and T % pr == r:
+            rows.append(T)
+        for I in rows:
+            for J in range(c, T, pc):
+                if lower_only and J > I:
+                    continue
+                out[(I, J)] = self.copy_tile(I, J)
+        return out
+
+
+def create(rank, nranks, pr, pc, nb, uid, binding=None):
+    """One process per GPU over RCCL; uid = unique_id() of rank 0, shipped by the launcher."""
+    b = binding or product_binding()
+    h = c_void_p()
+    buf = None
+    if uid is not None:
+        buf = ctypes.create_string_buffer(bytes(uid), UID_BYTES)
+    b.check(b.create(byref(h), rank, nranks, pr, pc, nb, buf))
+    return Grid(h, b)
+
+
+def unique_id(binding=None):
+    b = binding or product_binding()
+    buf = ctypes.create_string_buffer(UID_BYTES)
+    b.check(b.unique_id(buf))
+    return buf.raw
+
+
+def create_local(pr, pc, nb, devices=None, binding=None):
+    """pr*pc ranks in THIS process (rank order); drive them with run_local."""
+    b = binding or product_binding()
+    P = pr * pc
+    hs = (c_void_p * P)()
+    dev = None
+    if devices is not None:
+        dev = (c_int * P)(*[int(x) for x in devices])
+    b.check(b.create_local(hs, pr, pc, nb, dev))
+    return [Grid(c_void_p(hs[i]), b) for i in range(P)]
+
+
+def run_local(grids, fn):
+    """fn(grid, rank) on one thread per rank, concurrently (the entry points are collective); returns the results in
+    rank order and re-raises the first exception."""
+    out = [None] * len(grids)
+    err = [None] * len(grids)
+
+    def work(i):
+        try:
+            out[i] = fn(grids[i], i)
+        except BaseException as e:   # noqa: B902 -- re-raised below
+            err[i] = e
+
+    if len(grids) == 1:
+        work(0)
+    else:
+        ts = [threading.Thread(target=work, args=(i,)) for i in range(len(grids))]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+    for e in err:
+        if e is not None:
+            raise e
+    return out
+
+
+class Transport(object):
+    """A gpc_grid_transport built from three Python callables (MPI / gloo / anything):
+    bcast(ptr, count, root, axis), allreduce_sum(ptr, count, axis, on_device), allreduce_min(value) -> value."""
+
+    def __init__(self, bcast, allreduce_sum, allreduce_min):
+        def _b(ctx, buf, count, root, axis):
+            try:
+                bcast(buf, count, root, axis)
+                return 0
+            except Exception:   # the C side turns a non-zero status into GPC_EHIP
+                import traceback
+                traceback.print_exc()
+                return 1
+
+        def _s(ctx, buf, count, axis, on_device):
+            try:
+                allreduce_sum(buf, count, axis, on_device)
+                return 0
+            except Exception:
+                import traceback
+                traceback.print_exc()
+                return 1
+
+        def _m(ctx, p):
+            try:
+                p[0] = int(allreduce_min(int(p[0])))
+                return 0
+            except Exception:
+                import traceback
+                traceback.print_exc()
+                return 1
+
+        self.struct = GridTransport(None, GridTransport.BCAST(_b), GridTransport.ALLREDUCE_SUM(_s),
+                                    GridTransport.ALLREDUCE_MIN(_m))
+
+
+def create_transport(rank, pr, pc, nb, transport, binding=None):
+    b = binding or product_binding()
+    h = c_void_p()
+    b.check(b.create_transport(byref(h), rank, pr, pc, nb, byref(transport.struct)))
+    g = Grid(h, b)
+    g._keep = transport     # the callbacks must outlive the handle
+    return g
+
+
+def assemble_factor(tile_dicts, N, nb):
+    """tests: the N x N lower factor from the ranks' {(I, J): tile} dictionaries"""
+    T = (N + nb - 1) // nb
+    L = np.zeros((T * nb, T * nb))
+    for tiles in tile_dicts:
+        for (I, J), t in tiles.items():
+            if I < T:
+                L[I * nb:(I + 1) * nb, J * nb:(J + 1) * nb] = t
+    return np.tril(L)[:N, :N]

@@ -150,6 +150,70 @@ int gpc_syrk_blockcyclic_f64(int64_t M, int64_t ncols, int64_t K, double alpha, 
                              double beta, double* C, int64_t ldc, int64_t row0, int64_t j0, int64_t pstride,
                              int64_t nb, void* stream);
 
+/* ---- 2-D block-cyclic multi-GPU factorisation ---------------------------------------------------
+ * CGp::updateK() -- the Gram loop of CGp.cpp:698-712 and jitChol -> logDet of CGp.cpp:877-891 -- and what CGp reads off
+ * the factor (updateAlpha 469-489, logLikelihood 913-938, posteriorMeanVar 548-663) for a matrix spread over a pr x pc
+ * grid of GPUs: nb x nb tile (I, J) on rank (I mod pr, J mod pc), rank = r * pc + c.  Right-looking block Cholesky;
+ * per step the diagonal tile goes down its process column, the solved panel along the process rows and, transposed,
+ * along the process columns (RCCL broadcasts over xGMI on sub-communicators), the trailing update is local MFMA work,
+ * look-ahead 1.  The driver is C++ below this boundary (csrc/grid_sched.hpp); K never exists in one place.
+ *
+ * One rank per GPU, three ways to make one:
+ *   gpc_grid_create           one PROCESS (or thread) per GPU over RCCL; `uid` (GPC_GRID_UID_BYTES, from gpc_grid_unique_id
+ *                             on rank 0) is shipped to the other ranks by the launcher (file, socket, MPI, torch store);
+ *                             uses the calling thread's current device;
+ *   gpc_grid_create_local     pr*pc ranks inside ONE process, handles returned in rank order; every collective entry point
+ *                             below must then be called for all of them concurrently, one host thread per handle.
+ *                             devices == NULL puts all ranks on the current device (how one GPU tests a grid);
+ *   gpc_grid_create_transport the caller's own transport (MPI, gloo, ...) through plain C callbacks.
+ * X, Y, Xstar and all results are HOST arrays (column-major), identical on every rank; every entry point except
+ * gpc_grid_info / stats / copy_tile / set_lookahead / destroy is collective. */
+typedef struct gpc_grid gpc_grid;
+#define GPC_GRID_UID_BYTES 128
+#define GPC_GRID_AXIS_ROW 0      /* the ranks of my process row    (index in the group = my column c) */
+#define GPC_GRID_AXIS_COL 1      /* the ranks of my process column (index = my row r) */
+#define GPC_GRID_AXIS_WORLD 2    /* everyone (index = rank) */
+typedef struct gpc_grid_transport {
+  void* ctx;
+  /* buf holds `count` doubles in the memory the library allocates (device memory); root = index inside the axis group.
+   * The library has synchronised its stream before the call; return 0 when buf is final. */
+  int (*bcast)(void* ctx, void* buf, int64_t count, int root, int axis);
+  int (*allreduce_sum)(void* ctx, double* buf, int64_t count, int axis, int buf_on_device);
+  int (*allreduce_min_i64)(void* ctx, int64_t* host_value);   /* world */
+} gpc_grid_transport;
+
+int gpc_grid_unique_id(void* uid);
+int gpc_grid_create(gpc_grid** g, int rank, int nranks, int pr, int pc, int64_t nb, const void* uid);
+int gpc_grid_create_local(gpc_grid** handles, int pr, int pc, int64_t nb, const int* devices);
+int gpc_grid_create_transport(gpc_grid** g, int rank, int pr, int pc, int64_t nb, const gpc_grid_transport* t);
+int gpc_grid_destroy(gpc_grid* g);
+const char* gpc_grid_last_error(gpc_grid* g);
+const char* gpc_grid_rccl_path(void);
+/* The model: kernel, inputs X (N x D), targets Y (N x d; the reference's m = (y - bias) / scale; may be NULL with d = 0)
+ * and test inputs Xstar (Ns x D; may be NULL).  Y and K(Xstar, X) ride through the factorisation as extra rows. */
+int gpc_grid_set_problem(gpc_grid* g, const gpc_kspec* ks, const double* X, int64_t N, int64_t D, int64_t ldx,
+                         const double* Y, int64_t d, int64_t ldy, const double* Xstar, int64_t Ns, int64_t ldxs);
+int gpc_grid_set_kernel(gpc_grid* g, const gpc_kspec* ks);   /* new hyper-parameters, same data */
+/* CGp::updateK (FTC): Gram + Cholesky + log|K| with jitChol's schedule (CMatrix.cpp:767-804); outputs as
+ * gpc_gp_update_k_f64, identical on every rank. */
+int gpc_grid_update_k(gpc_grid* g, double* logdet, double* jitter_added, int* info);
+int gpc_grid_fill(gpc_grid* g);                 /* the two halves of update_k, for measurements */
+int gpc_grid_factor(gpc_grid* g, int* info);
+int gpc_grid_loglik(gpc_grid* g, double* ll);                                  /* CGp::logLikelihood */
+int gpc_grid_alpha(gpc_grid* g, double* alpha_host, int64_t lda);              /* CGp::updateAlpha: K^-1 Y, N x d */
+int gpc_grid_posterior(gpc_grid* g, double* mu_host, int64_t ldmu, double* var_host);   /* before output scale / bias */
+int gpc_grid_sync(gpc_grid* g);
+int gpc_grid_barrier(gpc_grid* g);
+int gpc_grid_set_lookahead(gpc_grid* g, int on);
+/* out[12] = N, nb, T (tiles per side), pr, pc, r, c, local rows, local columns, extra rows, local tile rows, columns */
+int gpc_grid_info(gpc_grid* g, int64_t* out);
+/* out[8] = bytes received along the process row / column / world, collectives entered, algorithmic flops of this rank's
+ * trailing updates, their launches, 0, 0 -- since the last reset */
+int gpc_grid_stats(gpc_grid* g, double* out, int reset);
+/* tests: tile (I, J) of the factor to the host (nb x nb, leading dimension nb; I == T addresses the extra rows);
+ * *owned = 0 and nothing copied when the tile lives on another rank */
+int gpc_grid_copy_tile(gpc_grid* g, int64_t I, int64_t J, double* host, int* owned);
+
 /* Y := alpha*X + beta*Y elementwise, M x N (CMatrix::axpy / scale / deepCopy: daxpy_, dscal_, dcopy_, lapack.h:78-111).
  * alpha == 0 ignores X's contents, beta == 0 ignores Y's (no NaN propagation from uninitialised storage). */
 int gpc_axpby_f64(int64_t M, int64_t N, double alpha, const double* X, int64_t ldx, double beta, double* Y, int64_t ldy,

@@ -1,0 +1,108 @@
+"""Shared pieces of the grid tests (tests/test_grid_cpu.py, tests/test_grid_gpu.py, tests/grid_worker.py): the host
+stand-in's binding, a seeded problem and its dense numpy solution."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+import scipy.linalg as sla
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+HOSTLIB = os.path.join(HERE, "host", "libgridhost.so")
+
+TERMS = [("rbf", [1.3, 0.9]), ("bias", [0.2]), ("white", [0.05])]
+
+
+def host_binding():
+    """gridtest_* of tests/host/libgridhost.so (the scheduler over the host stand-in of its GridOps seam)."""
+    from gpc_amd import grid
+    if not os.path.exists(HOSTLIB):
+        subprocess.check_call(["make", "-C", os.path.join(HERE, "host"), "libgridhost.so"])
+    return grid.Binding(ctypes.CDLL(HOSTLIB), "gridtest_")
+
+
+def make_problem(N, D, d, Ns, seed):
+    rng = np.random.RandomState(seed)
+    X = rng.randn(N, D)
+    Y = np.sin(X.sum(1, keepdims=True) / np.sqrt(D) + np.arange(d)[None, :]) + 0.1 * rng.randn(N, d)
+    Xs = rng.randn(Ns, D) if Ns else None
+    return X, Y, Xs
+
+
+def kern(terms, A, B, sym):
+    K = np.zeros((A.shape[0], B.shape[0]))
+    for name, p in terms:
+        if name == "rbf":
+            d2 = (A * A).sum(1)[:, None] + (B * B).sum(1)[None, :] - 2.0 * A @ B.T
+            K += p[1] * np.exp(-0.5 * p[0] * np.maximum(d2, 0.0))
+        elif name == "rbfard":
+            s = np.asarray(p[2:])
+            d2 = ((A[:, None, :] - B[None, :, :]) ** 2 * s[None, None, :]).sum(-1)
+            K += p[1] * np.exp(-0.5 * p[0] * d2)
+        elif name == "bias":
+            K += p[0]
+        elif name == "lin":
+            K += p[0] * A @ B.T
+        elif name == "white" and sym:
+            K += p[0] * np.eye(A.shape[0])
+    if sym:
+        K = 0.5 * (K + K.T)
+        np.fill_diagonal(K, kdiag(terms, A))
+    return K
+
+
+def kdiag(terms, A):
+    d = np.zeros(A.shape[0])
+    for name, p in terms:
+        if name in ("rbf", "rbfard"):
+            d += p[1]
+        elif name in ("bias", "white"):
+            d += p[0]
+        elif name == "lin":
+            d += p[0] * (A * A).sum(1)
+    return d
+
+
+def expected(terms, X, Y, Xs):
+    N, d = Y.shape
+    K = kern(terms, X, X, True)
+    L = np.linalg.cholesky(K)
+    z = sla.solve_triangular(L, Y, lower=True)
+    al = sla.solve_triangular(L, z, lower=True, trans=1)
+    logdet = 2.0 * np.log(np.diag(L)).sum()
+    out = {"L": L, "alpha": al, "logdet": logdet,
+           "ll": -0.5 * ((z * z).sum() + d * logdet) - d * N * 0.5 * np.log(2 * np.pi)}
+    if Xs is not None:
+        ks = kern(terms, Xs, X, False)
+        v = sla.solve_triangular(L, ks.T, lower=True)
+        out["mu"] = ks @ al
+        out["var"] = kdiag(terms, Xs) - (v * v).sum(0)
+    return out
+
+
+def rel(a, b):
+    a, b = np.asarray(a, dtype=float), np.asarray(b, dtype=float)
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-300))
+
+
+def recv_bytes_model(N, nb, pr, pc, r, c, E2_rows_on=None):
+    """Bytes rank (r, c) receives over one factorisation (matrix rows only), by the counting the scheduler does:
+    diagonal tiles down the column, row panels along the row, column-panel tiles inside the column."""
+    T = (N + nb - 1) // nb
+    row = col = 0.0
+    for k in range(T):
+        kr, kc = k % pr, k % pc
+        il0 = 0 if k < r else (k - r) // pr + 1
+        jl0 = 0 if k < c else (k - c) // pc + 1
+        Lr = 0 if r >= T else (T - r + pr - 1) // pr
+        Lc = 0 if c >= T else (T - c + pc - 1) // pc
+        M = (Lr - il0) * nb + (E2_rows_on or 0)
+        if pr > 1 and c == kc and r != kr:
+            col += 8.0 * nb * nb
+        if pc > 1 and M > 0 and c != kc:
+            row += 8.0 * max(M, 2) * nb
+        if pr > 1:
+            for jl in range(jl0, Lc):
+                if (c + pc * jl) % pr != r:
+                    col += 8.0 * nb * nb
+    return row, col

@@ -1,0 +1,238 @@
+// grid_host.cpp -- TEST INFRASTRUCTURE: a host stand-in for the GridOps seam of gpc_amd/csrc/grid_sched.hpp, so that the
+// CPU test-suite (no GPU here) can run the REAL 2-D block-cyclic scheduler, its in-process thread-rank exchange and its
+// caller-transport exchange (gloo from tests/grid_worker.py) at world sizes 2 / 4 / 8.  The arithmetic is the oracle's
+// (oracle/gpc_oracle.c: Gram elements, dpotrf, dtrsm) plus plain loops.  Built as tests/host/libgridhost.so exporting
+// gridtest_* with the signatures of libgpc_hip.so's gpc_grid_*; nothing under gpc_amd/ links or loads it.
+#include <stdlib.h>
+#include <string.h>
+#include <math.h>
+#include "../../gpc_amd/csrc/grid_sched.hpp"
+extern "C" {
+#include "../../oracle/gpc_oracle.h"
+}
+
+namespace {
+using namespace gpc::grid;
+
+static_assert(sizeof(orc_kspec) == sizeof(gpc_kspec), "kspec layouts must agree");
+
+struct HostOps : GridOps {
+  int alloc(void** p, size_t bytes) override
+  {
+    *p = nullptr;
+    if(posix_memalign(p, 64, bytes ? bytes : 64) != 0) return GPC_ENOMEM;
+    memset(*p, 0xff, bytes);   // NaN pattern: reading an entry nobody wrote shows up in the results
+    return GPC_OK;
+  }
+  int release(void* p) override
+  {
+    free(p);
+    return GPC_OK;
+  }
+  int upload(void* dst, const void* src, size_t bytes) override
+  {
+    memcpy(dst, src, bytes);
+    return GPC_OK;
+  }
+  int download(void* dst, const void* src, size_t bytes, int) override
+  {
+    memcpy(dst, src, bytes);
+    return GPC_OK;
+  }
+  int zero(void* p, size_t bytes, int) override
+  {
+    memset(p, 0, bytes);
+    return GPC_OK;
+  }
+  int zero2d(double* A, int64_t lda, int64_t m, int64_t n, int) override
+  {
+    for(int64_t j = 0; j < n; j++)
+      for(int64_t i = 0; i < m; i++) A[i + j * lda] = 0.0;
+    return GPC_OK;
+  }
+  int copy(void* dst, const void* src, size_t bytes, int) override
+  {
+    memcpy(dst, src, bytes);
+    return GPC_OK;
+  }
+  void* event_create() override { return malloc(1); }
+  void event_destroy(void* ev) override { free(ev); }
+  int record(void*, int) override { return GPC_OK; }
+  int wait(int, void*) override { return GPC_OK; }
+  int sync(int) override { return GPC_OK; }
+  void* native_stream(int) override { return nullptr; }
+
+  int gather_rows(const double* X, int64_t N, int64_t D, int64_t ldx, int64_t first, int64_t stride, int64_t ntiles,
+                  int64_t nb, double* out, int64_t ldo, int) override
+  {
+    for(int64_t t = 0; t < ntiles; t++)
+      for(int64_t i = 0; i < nb; i++) {
+        int64_t g = (first + t * stride) * nb + i;
+        if(g > N - 1) g = N - 1;
+        for(int64_t q = 0; q < D; q++) out[t * nb + i + q * ldo] = X[g + q * ldx];
+      }
+    return GPC_OK;
+  }
+  int gram_cross(const gpc_kspec* ks, const double* Xa, int64_t Na, int64_t lda, const double* Xb, int64_t Nb, int64_t ldb,
+                 int64_t D, double* K, int64_t ldk, int) override
+  {
+    const orc_kspec* o = reinterpret_cast<const orc_kspec*>(ks);
+    // orc_kern_element on the rows of two different matrices is the cross-Gram element (white excluded), CKern.h:146-157
+    for(int64_t j = 0; j < Nb; j++)
+      for(int64_t i = 0; i < Na; i++) K[i + j * ldk] = orc_kern_element(o, Xa, (long)lda, (long)i, Xb, (long)ldb, (long)j, (long)D);
+    return GPC_OK;
+  }
+  int gram_diag(const gpc_kspec* ks, const double* X, int64_t N, int64_t D, int64_t ldx, double shift, double* dg, int) override
+  {
+    const orc_kspec* o = reinterpret_cast<const orc_kspec*>(ks);
+    for(int64_t i = 0; i < N; i++) dg[i] = orc_kern_diag_element(o, X, (long)ldx, (long)i, (long)D) + shift;
+    return GPC_OK;
+  }
+  int sum_host(const double* v, int64_t n, double* out, int) override
+  {
+    double s = 0.0;
+    for(int64_t i = 0; i < n; i++) s += v[i];
+    *out = s;
+    return GPC_OK;
+  }
+  int fix_diag_pad(double* A, const Layout& L, const double* dg, int) override
+  {
+    for(int64_t jl = 0; jl < L.Lc; jl++)
+      for(int64_t j = 0; j < L.nb; j++) {
+        const int64_t gj = (L.c + L.pc * jl) * L.nb + j;
+        double* col = A + (jl * L.nb + j) * L.lld;
+        if(gj >= L.N)
+          for(int64_t i = 0; i < L.mloc; i++) col[i] = 0.0;
+        for(int64_t il = 0; il < L.Lr; il++)
+          for(int64_t i = 0; i < L.nb; i++) {
+            const int64_t gi = (L.r + L.pr * il) * L.nb + i;
+            if(gi == gj) col[il * L.nb + i] = gi < L.N ? dg[gi] : 1.0;
+            else if(gi >= L.N) col[il * L.nb + i] = 0.0;
+          }
+      }
+    return GPC_OK;
+  }
+  int put_rhs_rows(double* Aex, int64_t lld, const double* Y, int64_t ldy, int64_t d, const Layout& L, int) override
+  {
+    for(int64_t n = 0; n < L.nloc; n++) {
+      const int64_t jl = n / L.nb;
+      const int64_t g = (L.c + L.pc * jl) * L.nb + (n - jl * L.nb);
+      for(int64_t e = 0; e < d; e++) Aex[e + n * lld] = g < L.N ? Y[g + e * ldy] : 0.0;
+    }
+    return GPC_OK;
+  }
+  int potrf_tile(double* A, int64_t lda, int64_t n, int64_t col0, int* info, int) override
+  {
+    if(*info != 0) return GPC_OK;
+    const int rc = orc_potrf('L', (long)n, A, (long)lda);
+    if(rc > 0) *info = (int)(col0 + rc);
+    return GPC_OK;
+  }
+  int potrf_panel(int64_t M, int64_t nb, double* A, int64_t lda, int64_t col0, int* info, int st) override
+  {
+    GRID_CHECK(potrf_tile(A, lda, nb, col0, info, st));
+    if(*info == 0 && M > nb) orc_trsm('R', 'L', 'T', 'N', (long)(M - nb), (long)nb, 1.0, A, (long)lda, A + nb, (long)lda);
+    return GPC_OK;
+  }
+  int trsm_rlt(const double* Lkk, int64_t ldl, int64_t n, double* B, int64_t ldb, int64_t M, int) override
+  {
+    orc_trsm('R', 'L', 'T', 'N', (long)M, (long)n, 1.0, Lkk, (long)ldl, B, (long)ldb);
+    return GPC_OK;
+  }
+  int copy2d(double* dst, int64_t ldd, const double* src, int64_t lds, int64_t m, int64_t n, int) override
+  {
+    for(int64_t j = 0; j < n; j++) memcpy(dst + j * ldd, src + j * lds, sizeof(double) * (size_t)m);
+    return GPC_OK;
+  }
+  int pack_tiles(double* dst, const double* src, int64_t lds, int64_t first, int64_t step, int64_t count, int64_t nb, int) override
+  {
+    for(int64_t t = 0; t < count; t++)
+      for(int64_t j = 0; j < nb; j++)
+        memcpy(dst + t * nb * nb + j * nb, src + (first + t * step) * nb + j * lds, sizeof(double) * (size_t)nb);
+    return GPC_OK;
+  }
+  int update(const UpdateArgs& u, int) override
+  {
+    const int64_t nb = u.nb;
+    for(int64_t n = 0; n < u.Ncols; n++) {
+      const int64_t ct = n / nb, cn = n - ct * nb;
+      const int64_t J = u.J0 + ct * u.pc;
+      const double* vrow = u.Vbase + u.voff_host[u.jl0 + ct] + cn;   // V(J)(cn, :) with stride ldv
+      for(int64_t m = 0; m < u.M; m++) {
+        const int64_t rt = m / nb, rm = m - rt * nb;
+        const int64_t I = u.I0 + rt * u.pr;
+        if(I < J || (I == J && rm < cn)) continue;
+        double s = 0.0;
+        for(int64_t k = 0; k < u.K; k++) s += u.W[m + k * u.ldw] * vrow[k * u.ldv];
+        u.C[m + n * u.ldc] -= s;
+      }
+    }
+    return GPC_OK;
+  }
+  int diag_logsum(const double* A, const Layout& L, double* out, int) override
+  {
+    double s = 0.0;
+    for(int64_t il = 0; il < L.Lr; il++) {
+      const int64_t I = L.r + L.pr * il;
+      if(I < L.c || (I - L.c) % L.pc != 0) continue;
+      const int64_t jl = (I - L.c) / L.pc;
+      for(int64_t i = 0; i < L.nb; i++) s += log(A[il * L.nb + i + (jl * L.nb + i) * L.lld]);
+    }
+    *out = 2.0 * s;
+    return GPC_OK;
+  }
+  int rows_sumsq(const double* Arow, int64_t lld, int64_t nrows, int64_t ncols, double* out, int) override
+  {
+    for(int64_t e = 0; e < nrows; e++) {
+      double s = 0.0;
+      for(int64_t n = 0; n < ncols; n++) s += Arow[e + n * lld] * Arow[e + n * lld];
+      out[e] = s;
+    }
+    return GPC_OK;
+  }
+  int gemm(char ta, char tb, int64_t M, int64_t N, int64_t K, double alpha, const double* A, int64_t lda, const double* B,
+           int64_t ldb, double beta, double* C, int64_t ldc, int) override
+  {
+    for(int64_t j = 0; j < N; j++)
+      for(int64_t i = 0; i < M; i++) {
+        double s = 0.0;
+        for(int64_t k = 0; k < K; k++)
+          s += (ta == 'T' ? A[k + i * lda] : A[i + k * lda]) * (tb == 'T' ? B[j + k * ldb] : B[k + j * ldb]);
+        C[i + j * ldc] = alpha * s + (beta == 0.0 ? 0.0 : beta * C[i + j * ldc]);
+      }
+    return GPC_OK;
+  }
+  int trsm_llt(const double* Lkk, int64_t ldl, int64_t n, double* B, int64_t ldb, int64_t nrhs, int) override
+  {
+    orc_trsm('L', 'L', 'T', 'N', (long)n, (long)nrhs, 1.0, Lkk, (long)ldl, B, (long)ldb);
+    return GPC_OK;
+  }
+  int add_transposed(double* dst, int64_t ldd, const double* src, int64_t lds, int64_t n, int64_t d, int) override
+  {
+    for(int64_t i = 0; i < n; i++)
+      for(int64_t e = 0; e < d; e++) dst[i + e * ldd] += src[e + i * lds];
+    return GPC_OK;
+  }
+  int read_info(const int* info_dev, int* out, int) override
+  {
+    *out = *info_dev;
+    return GPC_OK;
+  }
+};
+
+int grid_current_device(int* dev)
+{
+  *dev = 0;
+  return GPC_OK;
+}
+int grid_enter(int) { return GPC_OK; }
+std::unique_ptr<GridOps> grid_make_ops(int) { return std::unique_ptr<GridOps>(new HostOps()); }
+int grid_enable_peers(const int*, int) { return GPC_OK; }
+bool grid_force_collectives() { return false; }
+int grid_unique_id(void*) { return GPC_EUNSUPPORTED; }   // RCCL lives in libgpc_hip.so only
+int grid_make_collective_comm(std::unique_ptr<GridComm>&, int, int, int, int, const void*, GridOps*) { return GPC_EUNSUPPORTED; }
+
+}  // namespace
+
+#define GRID_API(name) gridtest_##name
+#include "../../gpc_amd/csrc/grid_capi_impl.hpp"

@@ -1,0 +1,207 @@
+"""The 2-D block-cyclic factorisation (gpc_amd/csrc/grid_sched.hpp behind gpc_grid_*) on CPU.
+
+No GPU here, so the scheduler -- ownership, the staircase, the three exchanges per step, look-ahead bookkeeping, the
+extra-row forward substitution, the back substitution -- runs over the host stand-in of its GridOps seam
+(tests/host/grid_host.cpp: the oracle's arithmetic) with
+  * thread ranks on the in-process board (the LocalComm the single-process multi-GPU mode uses), pr x pc up to 8 ranks,
+  * one process per rank over gloo through the caller-transport entry point (world 2 and 4), tests/grid_worker.py.
+Everything is compared with a dense numpy solution of the same problem.
+"""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import grid_common as gc  # noqa: E402
+from gpc_amd import grid  # noqa: E402
+
+TOL = 1e-10
+
+
+@pytest.fixture(scope="module")
+def hb():
+    return gc.host_binding()
+
+
+def _solve_local(hb, pr, pc, nb, terms, X, Y, Xs, lookahead=True):
+    grids = grid.create_local(pr, pc, nb, binding=hb)
+
+    def work(g, rank):
+        g.set_lookahead(lookahead)
+        g.set_problem(terms, X, Y, Xs)
+        logdet, jit, info = g.update_k()
+        out = {"logdet": logdet, "jitter": jit, "info": info, "stats": g.stats(), "inf": g.info()}
+        if info == 0:
+            out["ll"] = g.loglik()
+            out["alpha"] = g.alpha()
+            if Xs is not None:
+                out["mu"], out["var"] = g.posterior()
+            out["tiles"] = g.local_tiles()
+        return out
+
+    try:
+        return grid.run_local(grids, work)
+    finally:
+        for g in grids:
+            g.destroy()
+
+
+def _check(res, exp, N, nb, Xs):
+    L = grid.assemble_factor([r["tiles"] for r in res], N, nb)
+    assert gc.rel(L, exp["L"]) < TOL
+    for r in res:
+        assert r["info"] == 0 and r["jitter"] == 0.0
+        assert abs(r["logdet"] - exp["logdet"]) <= TOL * abs(exp["logdet"])
+        assert abs(r["ll"] - exp["ll"]) <= TOL * abs(exp["ll"])
+        assert gc.rel(r["alpha"], exp["alpha"]) < 1e-8
+        if Xs is not None:
+            assert gc.rel(r["mu"], exp["mu"]) < 1e-8
+            assert gc.rel(r["var"], exp["var"]) < 1e-8
+    # replicated results are bit-identical on every rank
+    for r in res[1:]:
+        assert r["logdet"] == res[0]["logdet"] and r["ll"] == res[0]["ll"]
+        assert np.array_equal(r["alpha"], res[0]["alpha"])
+
+
+@pytest.mark.parametrize("pr,pc", [(1, 1), (1, 2), (2, 1), (2, 2), (2, 4), (4, 2), (1, 4), (3, 2), (2, 3), (1, 8)])
+def test_grid_shapes_against_numpy(hb, pr, pc):
+    N, D, d, Ns, nb = 700, 3, 2, 5, 128        # T = 6 tiles, ragged last tile (60 real rows), odd extra-row count
+    X, Y, Xs = gc.make_problem(N, D, d, Ns, 7)
+    exp = gc.expected(gc.TERMS, X, Y, Xs)
+    res = _solve_local(hb, pr, pc, nb, gc.TERMS, X, Y, Xs)
+    _check(res, exp, N, nb, Xs)
+
+
+@pytest.mark.parametrize("N", [128, 129, 255, 384, 1000])
+def test_ragged_sizes_on_2x2(hb, N):
+    X, Y, Xs = gc.make_problem(N, 2, 1, 3, N)
+    exp = gc.expected(gc.TERMS, X, Y, Xs)
+    _check(_solve_local(hb, 2, 2, 128, gc.TERMS, X, Y, Xs), exp, N, 128, Xs)
+
+
+def test_more_ranks_than_tiles(hb):
+    X, Y, Xs = gc.make_problem(200, 2, 1, 0, 3)       # T = 2 on a 2 x 4 grid: most ranks own nothing
+    exp = gc.expected(gc.TERMS, X, Y, None)
+    _check(_solve_local(hb, 2, 4, 128, gc.TERMS, X, Y, None), exp, 200, 128, None)
+
+
+def test_lookahead_off_gives_the_same_bits(hb):
+    X, Y, Xs = gc.make_problem(640, 3, 1, 4, 11)
+    a = _solve_local(hb, 2, 2, 128, gc.TERMS, X, Y, Xs, lookahead=True)
+    b = _solve_local(hb, 2, 2, 128, gc.TERMS, X, Y, Xs, lookahead=False)
+    for ra, rb in zip(a, b):
+        assert ra["logdet"] == rb["logdet"] and np.array_equal(ra["alpha"], rb["alpha"])
+        for key in ra["tiles"]:
+            assert np.array_equal(ra["tiles"][key], rb["tiles"][key])
+
+
+def test_jitter_schedule_on_a_singular_gram(hb):
+    """CMatrix::jitChol (CMatrix.cpp:767-804) on the distributed matrix: duplicated inputs, no white term."""
+    X, Y, _ = gc.make_problem(300, 2, 1, 0, 5)
+    X[150:] = X[:150]
+    terms = [("rbf", [1.0, 1.0])]
+    res = _solve_local(hb, 2, 2, 128, terms, X, Y, None)
+    K = gc.kern(terms, X, X, True)
+    jitter, total = 1e-6 * np.trace(K) / 300.0, 0.0
+    for _ in range(20):
+        try:
+            np.linalg.cholesky(K + total * np.eye(300))
+            break
+        except np.linalg.LinAlgError:
+            total += jitter
+            jitter *= 10.0
+    assert total > 0.0
+    for r in res:
+        assert r["info"] == 0
+        assert r["jitter"] == pytest.approx(total, rel=1e-12)
+        Lref = np.linalg.cholesky(K + r["jitter"] * np.eye(300))
+        assert abs(r["logdet"] - 2.0 * np.log(np.diag(Lref)).sum()) < 1e-6 * abs(r["logdet"])
+
+
+def test_not_positive_definite_reports_lapack_info(hb):
+    # rbf on well separated points (close to the identity) minus a rank-one "lin" term with a NEGATIVE variance: the
+    # leading minors stop being positive definite at a definite order, with a clearly negative pivot
+    X = 3.0 * np.arange(300, dtype=float).reshape(-1, 1)
+    Y = np.zeros((300, 1))
+    terms = [("rbf", [1.0, 1.0]), ("lin", [-1.0 / (9.0 * 1500.0 ** 2)])]
+    K = gc.kern(terms, X, X, True)
+    first = next(m for m in range(1, 301) if np.linalg.eigvalsh(K[:m, :m]).min() <= 0.0)
+    assert 128 < first < 300 and np.linalg.eigvalsh(K[:first, :first]).min() < -1e-6
+    grids = grid.create_local(2, 2, 128, binding=hb)
+
+    def work(g, rank):
+        g.set_problem(terms, X, Y, None)
+        g.fill()
+        return g.factor()
+
+    try:
+        infos = grid.run_local(grids, work)
+    finally:
+        for g in grids:
+            g.destroy()
+    assert len(set(infos)) == 1 and infos[0] > 0
+    assert infos[0] == first                             # LAPACK's info: the order of the first failing minor
+
+
+@pytest.mark.parametrize("pr,pc", [(1, 2), (2, 2), (2, 4), (4, 2)])
+def test_received_bytes_fall_as_one_over_pr_plus_one_over_pc(hb, pr, pc):
+    """The scheduler's own count of what every rank receives equals the closed-form count of the layout."""
+    N, nb = 2048, 128
+    X, Y, _ = gc.make_problem(N, 2, 1, 0, 1)
+    grids = grid.create_local(pr, pc, nb, binding=hb)
+
+    def work(g, rank):
+        g.set_problem(gc.TERMS, X, None, None)
+        g.fill()
+        g.stats(reset=True)
+        assert g.factor() == 0
+        return g.stats(), g.info()
+
+    try:
+        res = grid.run_local(grids, work)
+    finally:
+        for g in grids:
+            g.destroy()
+    tot = 0.0
+    for st, inf in res:
+        row, col = gc.recv_bytes_model(N, nb, pr, pc, inf["r"], inf["c"])
+        assert st["bytes_row"] == row and st["bytes_col"] == col
+        tot += row + col
+    # ... and the average per rank is close to 8 N^2/2 ((pc-1)/pc/pr + (pr-1)/pr/pc)
+    model = 8.0 * N * N / 2.0 * ((pc - 1.0) / pc / pr + (pr - 1.0) / pr / pc)
+    assert abs(tot / (pr * pc) - model) < 0.15 * model
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.parametrize("pr,pc", [(1, 2), (2, 1), (2, 2)])
+def test_one_process_per_rank_over_gloo(pr, pc, tmp_path):
+    """world_size 2 / 4 over gloo: the grid's exchange goes through gpc_grid_create_transport callbacks that call
+    torch.distributed (the same entry point an MPI launcher would use)."""
+    import torch.multiprocessing as mp
+    import grid_worker
+    N, D, d, Ns, nb = 520, 3, 2, 4, 128
+    world = pr * pc
+    mp.spawn(grid_worker.run, args=(world, _free_port(), pr, pc, nb, N, D, d, Ns, str(tmp_path), "host"), nprocs=world,
+             join=True)
+    X, Y, Xs = gc.make_problem(N, D, d, Ns, 7)
+    exp = gc.expected(gc.TERMS, X, Y, Xs)
+    res = []
+    for r in range(world):
+        z = dict(np.load(os.path.join(str(tmp_path), "rank%d.npz" % r), allow_pickle=True))
+        z["tiles"] = z["tiles"].item()
+        for k in ("logdet", "ll", "jitter"):
+            z[k] = float(z[k])
+        z["info"] = int(z["info"])
+        res.append(z)
+    _check(res, exp, N, nb, Xs)

@@ -1,0 +1,200 @@
+"""The 2-D block-cyclic factorisation on the GPU: the REAL HIP kernels (gpc_grid_* of libgpc_hip.so) under
+  * thread ranks sharing the box's single GPU (gpc_grid_create_local; every rank has its own streams, the exchange is
+    device-to-device copies ordered by events -- exactly what the single-process multi-GPU mode runs),
+  * one process per rank over gloo behind gpc_grid_create_transport (2 processes sharing the GPU),
+  * RCCL on a one-rank communicator with the collectives forced on (GPC_GRID_FORCE_RCCL=1): every RCCL entry point the grid
+    uses is called on hardware,
+against numpy, the single-GPU library path and the compiled reference's golden vectors (cfg 4's kernel, D = 16, gamma = 1).
+"""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, HERE)
+import grid_common as gc  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-9
+
+
+def _solve(pr, pc, nb, terms, X, Y, Xs, lookahead=True):
+    from gpc_amd import grid
+    grids = grid.create_local(pr, pc, nb)
+
+    def work(g, rank):
+        g.set_lookahead(lookahead)
+        g.set_problem(terms, X, Y, Xs)
+        logdet, jit, info = g.update_k()
+        out = {"logdet": logdet, "jitter": jit, "info": info, "ll": g.loglik(), "alpha": g.alpha()}
+        if Xs is not None:
+            out["mu"], out["var"] = g.posterior()
+        out["tiles"] = g.local_tiles()
+        out["stats"] = g.stats()
+        return out
+
+    try:
+        return grid.run_local(grids, work)
+    finally:
+        for g in grids:
+            g.destroy()
+
+
+def _check(res, exp, N, nb, Xs, tol=TOL):
+    from gpc_amd import grid
+    L = grid.assemble_factor([r["tiles"] for r in res], N, nb)
+    assert gc.rel(L, exp["L"]) < tol
+    for r in res:
+        assert r["info"] == 0 and r["jitter"] == 0.0
+        assert abs(r["logdet"] - exp["logdet"]) <= tol * abs(exp["logdet"])
+        assert abs(r["ll"] - exp["ll"]) <= tol * abs(exp["ll"])
+        assert gc.rel(r["alpha"], exp["alpha"]) < 1e-8
+        if Xs is not None:
+            assert gc.rel(r["mu"], exp["mu"]) < 1e-8
+            assert gc.rel(r["var"], exp["var"]) < 1e-8
+    for r in res[1:]:
+        assert r["logdet"] == res[0]["logdet"] and r["ll"] == res[0]["ll"]
+        assert np.array_equal(r["alpha"], res[0]["alpha"])
+
+
+@pytest.mark.parametrize("pr,pc", [(1, 1), (1, 2), (2, 1), (2, 2), (2, 4), (4, 2), (1, 8), (3, 2)])
+def test_grid_shapes_against_numpy(pr, pc):
+    N, D, d, Ns, nb = 1500, 3, 2, 5, 128     # T = 12 tiles, ragged last tile, odd extra-row count
+    X, Y, Xs = gc.make_problem(N, D, d, Ns, 7)
+    exp = gc.expected(gc.TERMS, X, Y, Xs)
+    _check(_solve(pr, pc, nb, gc.TERMS, X, Y, Xs), exp, N, nb, Xs)
+
+
+@pytest.mark.parametrize("N,nb", [(128, 128), (129, 128), (1000, 256), (2048, 512), (2500, 512)])
+def test_ragged_sizes_and_tile_widths_on_2x2(N, nb):
+    X, Y, Xs = gc.make_problem(N, 4, 1, 3, N)
+    exp = gc.expected(gc.TERMS, X, Y, Xs)
+    _check(_solve(2, 2, nb, gc.TERMS, X, Y, Xs), exp, N, nb, Xs)
+
+
+def test_lookahead_off_gives_the_same_bits():
+    X, Y, Xs = gc.make_problem(1900, 3, 1, 4, 11)
+    a = _solve(2, 2, 128, gc.TERMS, X, Y, Xs, lookahead=True)
+    b = _solve(2, 2, 128, gc.TERMS, X, Y, Xs, lookahead=False)
+    for ra, rb in zip(a, b):
+        assert ra["logdet"] == rb["logdet"] and np.array_equal(ra["alpha"], rb["alpha"])
+        for key in ra["tiles"]:
+            assert np.array_equal(ra["tiles"][key], rb["tiles"][key])
+
+
+def test_gram_tiles_match_the_single_gpu_gram_bit_for_bit():
+    """Every rank generates its own tiles; they must be the entries gpc_gram_sym_f64 produces on one GPU."""
+    from gpc_amd import api, grid
+    N, nb = 1000, 128
+    X, _, _ = gc.make_problem(N, 5, 1, 0, 3)
+    K = api.to_host(api.gram_sym(api.kspec(gc.TERMS), api.from_host(X)))
+    grids = grid.create_local(2, 2, nb)
+
+    def work(g, rank):
+        g.set_problem(gc.TERMS, X, None, None)
+        g.fill()
+        return g.local_tiles()
+
+    try:
+        res = grid.run_local(grids, work)
+    finally:
+        for g in grids:
+            g.destroy()
+    T = (N + nb - 1) // nb
+    Kp = np.eye(T * nb)
+    Kp[:N, :N] = K
+    for tiles in res:
+        for (I, J), t in tiles.items():
+            ref = Kp[I * nb:(I + 1) * nb, J * nb:(J + 1) * nb]
+            assert np.array_equal(np.tril(t) if I == J else t, np.tril(ref) if I == J else ref), (I, J)
+
+
+@pytest.mark.parametrize("pr,pc,nb", [(1, 1, 256), (2, 2, 128), (2, 4, 128)])
+def test_cfg4_kernel_against_the_reference_golden(golden, pr, pc, nb):
+    """BASELINE config 4's kernel (D = 16, rbf, gamma = 1) at the golden's N = 1024 through the grid path, against the
+    outputs of the compiled reference (tests/golden/synth_cfg4_1024.npz).  ll / log|K| at 1e-8; Alpha and the predictions
+    of the reference carry its single-precision LcholK, so they are held to 1e-6 there and to 1e-8
+    against the single-GPU library path, which is exact."""
+    from gpc_amd import synth
+    from gpc_amd.gp import CGp
+    g = golden("synth_cfg4_1024")
+    c = synth.CONFIGS["cfg4"]
+    X, y = synth.make_xy(1024, c["D"], int(g["seed"]))
+    assert X.sum() == g["x_checksum"]
+    res = _solve(pr, pc, nb, c["kern"], X, g["m"], g["Xstar"])
+    from gpc_amd import api
+    one = CGp(c["kern"], X, y, ref_trans_rounding=False)        # the single-GPU library path, plain fp64
+    ll1 = one.logLikelihood()
+    mu1, var1 = one.posteriorMeanVar(g["Xstar"])
+    al1 = api.to_host(one.invKm)
+    for r in res:
+        assert r["info"] == 0
+        assert abs(r["ll"] - g["ll"].ravel()[0]) <= 1e-8 * abs(g["ll"].ravel()[0])
+        assert abs(r["logdet"] - g["logdet"].ravel()[0]) <= 1e-8 * abs(g["logdet"].ravel()[0])
+        assert gc.rel(r["alpha"], g["alpha"]) < 1e-6
+        assert gc.rel(r["var"], g["var"].ravel()) < 1e-6
+        assert gc.rel(r["mu"] + one.bias[None, :], g["mu"]) < 1e-6
+        assert abs(r["ll"] - ll1) <= 1e-10 * abs(ll1)
+        assert gc.rel(r["alpha"], al1) < 1e-8
+        assert gc.rel(r["var"], var1.ravel()) < 1e-8
+        assert gc.rel(r["mu"] + one.bias[None, :], mu1) < 1e-8
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_two_processes_sharing_the_gpu_over_gloo(tmp_path):
+    import torch.multiprocessing as mp
+    import grid_worker
+    N, D, d, Ns, nb, pr, pc = 900, 3, 1, 4, 128, 1, 2
+    mp.spawn(grid_worker.run, args=(2, _free_port(), pr, pc, nb, N, D, d, Ns, str(tmp_path), "hip"), nprocs=2, join=True)
+    X, Y, Xs = gc.make_problem(N, D, d, Ns, 7)
+    exp = gc.expected(gc.TERMS, X, Y, Xs)
+    res = []
+    for r in range(2):
+        z = dict(np.load(os.path.join(str(tmp_path), "rank%d.npz" % r), allow_pickle=True))
+        z["tiles"] = z["tiles"].item()
+        for k in ("logdet", "ll", "jitter"):
+            z[k] = float(z[k])
+        z["info"] = int(z["info"])
+        res.append(z)
+    _check(res, exp, N, nb, Xs)
+
+
+def test_rccl_entry_points_on_one_rank():
+    """ncclCommInitRank / ncclCommSplit / ncclBroadcast / ncclAllReduce as the grid calls them, on a communicator of
+    one rank (RCCL refuses two ranks on one device, and the box has one GPU)."""
+    code = r"""
+import os, sys, numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+os.environ["GPC_GRID_FORCE_RCCL"] = "1"
+import grid_common as gc
+from gpc_amd import grid, _lib
+uid = grid.unique_id()
+g = grid.create(0, 1, 1, 1, 128, uid)
+X, Y, Xs = gc.make_problem(700, 3, 2, 3, 7)
+g.set_problem(gc.TERMS, X, Y, Xs)
+logdet, jit, info = g.update_k()
+exp = gc.expected(gc.TERMS, X, Y, Xs)
+assert info == 0 and abs(logdet - exp["logdet"]) < 1e-9 * abs(exp["logdet"])
+assert abs(g.loglik() - exp["ll"]) < 1e-9 * abs(exp["ll"])
+assert gc.rel(g.alpha(), exp["alpha"]) < 1e-8
+mu, var = g.posterior()
+assert gc.rel(var, exp["var"]) < 1e-8
+path = _lib.load().gpc_grid_rccl_path().decode()
+assert "rccl" in path, path
+print("RCCL-OK", path, g.stats()["collectives"])
+""" % (HERE, ROOT)
+    r = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    out = r.stdout.decode()
+    assert r.returncode == 0 and "RCCL-OK" in out, out
