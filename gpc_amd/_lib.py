@@ -141,6 +141,14 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise ImportError("gpc_amd: %s not found -- build it with `python -c 'import __graft_entry__ as g; "
                           "g.build()'` (hipcc --offload-arch=gfx950); there is no CPU fallback" % LIB_PATH)
+    # PyTorch's ROCm wheels bundle their own HIP runtime.  Two runtimes in one process fight over the device (whichever
+    # starts second reports "no GPUs"), so when torch is going to be used in this process it has to be mapped first: the
+    # library then resolves its libamdhip64 dependency to the copy already loaded.  (C++ hosts link the library directly
+    # and never see torch.)
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = ctypes.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)   # AttributeError here = header/library mismatch: fail loudly

@@ -353,3 +353,16 @@ def scale_vec_(A, v, by_rows=False):
     """A(i,j) *= v[i] (by_rows) or v[j]: CMatrix::scaleRow / scaleCol against a device vector (CGp.cpp:812-820)."""
     check(lib().gpc_scale_vec_f64(A.shape[0], A.shape[1], ptr(A), ld(A), ptr(v), 1 if by_rows else 0, stream()))
     return A
+
+
+# ---- measurement hooks (include/gpc_hip.h: gpc_profile_*) ----------------------------------------------------------
+
+def profile_enable(on):
+    check(lib().gpc_profile_enable(1 if on else 0))
+
+
+def profile_read(kind, reset=True):
+    """(launches, total ms, algorithmic work) of kind 0 = trailing updates (flops) / 1 = Gram kernels (bytes)."""
+    n, ms, work = ctypes.c_int64(0), c_double(0.0), c_double(0.0)
+    check(lib().gpc_profile_read(kind, byref(n), byref(ms), byref(work), 1 if reset else 0))
+    return n.value, ms.value, work.value

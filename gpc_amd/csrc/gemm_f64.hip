@@ -43,6 +43,7 @@ constexpr int OP_ELEMS = 2304;  // 16*144 == 128*18 doubles per operand per stag
 constexpr int STAGE_ELEMS = 2 * OP_ELEMS;
 constexpr int GEMM_LDS_BYTES = 2 * STAGE_ELEMS * 8;  // 73,728 B -> two workgroups per CU
 constexpr int SUPER = 8;
+constexpr int MAX_SUPER_COLS = 128;   // 2-D staircase launches: at most 131 072 local columns per launch
 
 struct GemmArgs {
   const double* A;
@@ -71,6 +72,12 @@ struct GemmArgs {
   int64_t stair_nb, stair_pstride, stair_j0, stair_row0;
   int64_t st_I0, st_pr, st_J0, st_pc, st_jl0;
   const int64_t* voff;
+  // tri == 5: compact enumeration of the super-tiles that hold at least one valid tile.  Super-column sj holds the
+  // super-rows st_first[sj] .. super_m-1; st_cum[sj] = how many such super-tiles lie in columns < sj.  (Launching the
+  // empty ones is not free: a workgroup that exits at once still has to wait for 73 KB of LDS, i.e. for a working
+  // workgroup to retire -- with half the grid empty that cost 8 % of the update.)
+  uint32_t st_cum[MAX_SUPER_COLS + 1];
+  uint16_t st_first[MAX_SUPER_COLS];
 };
 
 // ---- global -> registers -------------------------------------------------------------------------------------
@@ -160,16 +167,31 @@ __device__ __forceinline__ bool map_tile(const GemmArgs& g, int& ti, int& tj)
   // tiles.  Deal groups of 64 consecutive ids (about one super-tile: the L2 locality survives) round-robin instead.
   if(g.kstart) L = (((b >> 3) >> 6) * 8u + (b & 7u)) * 64u + ((b >> 3) & 63u);
   int si, sj, di, dj;
-  if(g.tri == 4 || g.tri == 5) {
-    // Block-cyclic staircase: which super-tiles are empty depends on the panel owner pattern, so contiguous chunks
-    // would leave some XCDs with nothing but skipped tiles.  Deal whole super-tiles round-robin instead (super-tile s
-    // -> XCD s % 8): each one still lives in a single L2 and the empty ones spread evenly.
-    const unsigned i = b >> 3;
-    const unsigned s = (i / (SUPER * SUPER)) * 8u + (b & 7u);
-    const unsigned w = i % (SUPER * SUPER);
-    if(s >= (unsigned)(g.super_m * g.super_n)) return false;
-    si = s % g.super_m;
-    sj = s / g.super_m;
+  if(g.tri == 5) {
+    // 2-D block-cyclic staircase: the super-tiles with at least one valid tile, column by column, dealt round-robin to
+    // the XCDs (super-tile number L runs on XCD L mod 8: every XCD gets the same count to within one, each super-tile
+    // lives in a single L2, and the 8 an XCD handles in a row share their column operand).
+    const unsigned i = b >> 3, x = b & 7u;
+    const unsigned L5 = (i / (SUPER * SUPER)) * 8u + x, w = i % (SUPER * SUPER);
+    if(L5 >= g.st_cum[g.super_n]) return false;
+    int lo = 0, hi = g.super_n;
+    while(hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if(g.st_cum[mid] <= L5) lo = mid;
+      else hi = mid;
+    }
+    sj = lo;
+    si = (int)g.st_first[lo] + (int)(L5 - g.st_cum[lo]);
+    di = (int)(w % SUPER);
+    dj = (int)(w / SUPER);
+  } else if(g.tri == 4) {
+    // 1-D block-cyclic staircase: whole super-tiles dealt so that super-tile (si, sj) runs on XCD (si + sj) mod 8
+    const unsigned i = b >> 3, x = b & 7u;
+    const unsigned q = i / (SUPER * SUPER), w = i % (SUPER * SUPER);
+    const unsigned rows8 = ((unsigned)g.super_m + 7u) >> 3;
+    sj = (int)(q / rows8);
+    si = (int)(((x + 8u - ((unsigned)sj & 7u)) & 7u) + 8u * (q % rows8));
+    if(sj >= g.super_n || si >= g.super_m) return false;
     di = (int)(w % SUPER);
     dj = (int)(w / SUPER);
   } else if(g.tri == 0 || g.tri == 3) {
@@ -618,8 +640,31 @@ static int gemm_ex(bool transa, bool transb, int64_t M, int64_t N, int64_t K, do
     return GPC_EINVAL;
   }
   uint64_t slots;
-  if(tri == 4 || tri == 5)
-    slots = (((uint64_t)g.super_m * g.super_n + 7) / 8) * 8 * SUPER * SUPER;
+  if(tri == 5) {
+    if(g.super_n > MAX_SUPER_COLS) {
+      set_error("gemm_stair2d: more than %d local columns in one launch", MAX_SUPER_COLS * SUPER * BN);
+      return GPC_EINVAL;
+    }
+    // first super-row of every super-column that holds a valid tile (the staircase only moves down to the right)
+    const int64_t R = g.stair_nb / BN;   // 128-tiles per nb-tile
+    uint32_t cum = 0;
+    for(int sj = 0; sj < g.super_n; sj++) {
+      const int64_t tj = (int64_t)sj * SUPER;            // first 128-tile column of the super-column
+      const int64_t ct = tj / R;
+      const int64_t J = g.st_J0 + ct * g.st_pc;
+      int64_t rt = J > g.st_I0 ? (J - g.st_I0 + g.st_pr - 1) / g.st_pr : 0;   // first nb-tile row with I >= J
+      int64_t f = rt * R;
+      if(g.st_I0 + rt * g.st_pr == J) f += tj % R;        // inside the diagonal nb-tile: 128-tiles on or below its diagonal
+      int64_t sf = f / SUPER;
+      if(sf > g.super_m) sf = g.super_m;
+      g.st_first[sj] = (uint16_t)sf;
+      g.st_cum[sj] = cum;
+      cum += (uint32_t)(g.super_m - sf);
+    }
+    g.st_cum[g.super_n] = cum;
+    slots = (((uint64_t)cum + 7) / 8) * 8 * SUPER * SUPER;
+  } else if(tri == 4)
+    slots = 8ull * (uint64_t)((g.super_m + 7) / 8) * (uint64_t)g.super_n * SUPER * SUPER;
   else if(tri == 0 || tri == 3)
     slots = (uint64_t)g.super_m * g.super_n * SUPER * SUPER;
   else

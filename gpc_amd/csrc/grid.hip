@@ -346,6 +346,14 @@ struct HipOps : GridOps {
     sd.jl0 = u.jl0;
     sd.voff = u.voff_dev;
     TrailingScope role;
+    static int p1 = -1;
+    if(p1 < 0) { const char* e = getenv("GPC_GRID_P1_TRI"); p1 = e ? atoi(e) : 0; }
+    if(p1 && u.pr == 1 && u.pc == 1) {
+      // experiment: on a 1 x 1 grid the staircase is the plain lower trapezoid of the single-GPU factorisation
+      const int64_t skip = (u.J0 - u.I0) * u.nb;     // rows of C above its first diagonal element
+      const double* Wd = u.W + skip;
+      return gpc::gemm(false, true, u.M - skip, u.Ncols, u.K, -1.0, Wd, u.ldw, Wd, u.ldw, 1.0, u.C + skip, u.ldc, 3, st[s]);
+    }
     return gpc::gemm_stair2d(u.M, u.Ncols, u.K, -1.0, u.W, u.ldw, u.Vbase, u.ldv, u.C, u.ldc, sd, st[s]);
   }
   int diag_logsum(const double* A, const Layout& L, double* out, int s) override
@@ -622,4 +630,98 @@ extern "C" const char* gpc_grid_rccl_path(void)
 {
   RcclApi* api = rccl_api();
   return api ? api->where.c_str() : "";
+}
+
+__global__ void __launch_bounds__(256) bench_fill_kernel(double* p, int64_t n, double scale)
+{
+  for(int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    unsigned long long z = (unsigned long long)i * 0x9E3779B97F4A7C15ull + 0x1234567ull;
+    z ^= z >> 29;
+    z *= 0xBF58476D1CE4E5B9ull;
+    z ^= z >> 32;
+    p[i] = scale * ((double)(z >> 11) * (1.0 / 9007199254740992.0) - 0.5);
+  }
+}
+
+// Measurement aid (tools/stair_bench.py; not part of the declared C-ABI): average time of one trailing-update launch over an
+// m x m lower triangle of depth K, as the single-GPU factorisation issues it (mode 1: compact triangle) and as a pr x pc
+// grid's rank (r, c) issues it (mode 5: 2-D staircase over that rank's share of an m_glob matrix).
+extern "C" int gpc_bench_update(int mode, int64_t m, int64_t nb, int pr, int pc, int r, int c, int reps, double* ms,
+                                double* flops)
+{
+  GPC_CHECK(gpc::ensure_device());
+  gpc::grid::Layout L;
+  L.init(m, nb, pr, pc, r, c, 0);
+  const int64_t mloc = mode == 1 ? m : L.mloc, nloc = mode == 1 ? m : L.nloc;
+  if(mloc <= 0 || nloc <= 0) return GPC_EINVAL;
+  double *W = nullptr, *V = nullptr, *C = nullptr;
+  int64_t* voff = nullptr;
+  HIPOPS_CHECK(hipMalloc((void**)&W, sizeof(double) * (size_t)(mloc * nb)));
+  HIPOPS_CHECK(hipMalloc((void**)&V, sizeof(double) * (size_t)(nloc * nb)));
+  HIPOPS_CHECK(hipMalloc((void**)&C, sizeof(double) * (size_t)(mloc * nloc)));
+  // random operands: an all-zero product draws less power and clocks higher than the factorisation's real data
+  hipLaunchKernelGGL(bench_fill_kernel, dim3(2048), dim3(256), 0, nullptr, W, mloc * nb, 1e-3);
+  hipLaunchKernelGGL(bench_fill_kernel, dim3(2048), dim3(256), 0, nullptr, V, nloc * nb, 1e-3);
+  hipLaunchKernelGGL(bench_fill_kernel, dim3(2048), dim3(256), 0, nullptr, C, mloc * nloc, 1.0);
+  std::vector<int64_t> vh((size_t)(L.Lc > 0 ? L.Lc : 1));
+  for(int64_t jl = 0; jl < L.Lc; jl++) vh[(size_t)jl] = jl * nb * nb;
+  HIPOPS_CHECK(hipMalloc((void**)&voff, sizeof(int64_t) * vh.size()));
+  HIPOPS_CHECK(hipMemcpy(voff, vh.data(), sizeof(int64_t) * vh.size(), hipMemcpyHostToDevice));
+  hipEvent_t e0, e1;
+  HIPOPS_CHECK(hipEventCreate(&e0));
+  HIPOPS_CHECK(hipEventCreate(&e1));
+  gpc::Stair2D sd;
+  sd.nb = nb; sd.I0 = r; sd.pr = pr; sd.J0 = c; sd.pc = pc; sd.jl0 = 0; sd.voff = voff;
+  double fl = 0.0;
+  for(int64_t jl = 0; jl < L.Lc; jl++) {
+    const int64_t J = c + (int64_t)pc * jl;
+    const int64_t ilf = gpc::grid::Layout::first_after(J - 1, r, pr);
+    const double rows = (double)(L.mloc - ilf * nb);
+    if(rows <= 0) continue;
+    fl += rows * (double)nb;
+    if(ilf < L.Lr && r + pr * ilf == J) fl -= 0.5 * (double)nb * (double)(nb - 1);
+  }
+  fl *= 2.0 * (double)nb;
+  if(mode == 1) fl = (double)m * (double)(m + 1) * (double)nb;
+  int rc = GPC_OK;
+  // mode 6 / 7: the operands where the factorisation has them -- panel and trailing matrix inside ONE array of leading
+  // dimension lld = m + nb + 16 (mode 6: compact triangle, 7: the 1 x 1 staircase reading its column panel from the row panel)
+  double* A6 = nullptr;
+  const int64_t lld6 = m + nb + 16;
+  std::vector<int64_t> v6((size_t)(m / nb + 2));
+  int64_t* voff6 = nullptr;
+  if(mode >= 6) {
+    HIPOPS_CHECK(hipMalloc((void**)&A6, sizeof(double) * (size_t)(lld6 * (m + nb))));
+    hipLaunchKernelGGL(bench_fill_kernel, dim3(4096), dim3(256), 0, nullptr, A6, lld6 * (m + nb), 1e-3);
+    for(size_t j = 0; j < v6.size(); j++) v6[j] = (int64_t)j * nb;
+    HIPOPS_CHECK(hipMalloc((void**)&voff6, sizeof(int64_t) * v6.size()));
+    HIPOPS_CHECK(hipMemcpy(voff6, v6.data(), sizeof(int64_t) * v6.size(), hipMemcpyHostToDevice));
+    fl = (double)m * (double)(m + 1) * (double)nb;
+  }
+  for(int it = 0; it < reps + 1 && rc == GPC_OK; it++) {
+    if(it == 1) HIPOPS_CHECK(hipEventRecord(e0, nullptr));
+    gpc::TrailingScope role;
+    if(mode == 6) {
+      const double* P = A6 + nb;
+      rc = gpc::gemm(false, true, m, m, nb, -1.0, P, lld6, P, lld6, 1.0, A6 + nb + nb * lld6, lld6, 1, nullptr);
+    } else if(mode == 7) {
+      gpc::Stair2D s7;
+      s7.nb = nb; s7.I0 = 1; s7.pr = 1; s7.J0 = 1; s7.pc = 1; s7.jl0 = 1; s7.voff = voff6;
+      const double* P = A6 + nb;   // rows below tile 0; V base = P - 1 * nb so that voff[J] = J * nb
+      rc = gpc::gemm_stair2d(m + 16, m, nb, -1.0, P, lld6, P - nb, lld6, A6 + nb + nb * lld6, lld6, s7, nullptr);
+    } else
+    if(mode == 1) rc = gpc::gemm(false, true, m, m, nb, -1.0, W, m, W, m, 1.0, C, m, 1, nullptr);
+    else rc = gpc::gemm_stair2d(mloc, nloc, nb, -1.0, W, mloc, V, nb, C, mloc, sd, nullptr);
+  }
+  HIPOPS_CHECK(hipEventRecord(e1, nullptr));
+  HIPOPS_CHECK(hipEventSynchronize(e1));
+  float t = 0.f;
+  HIPOPS_CHECK(hipEventElapsedTime(&t, e0, e1));
+  *ms = (double)t / reps;
+  *flops = fl;
+  (void)hipFree(W); (void)hipFree(V); (void)hipFree(C); (void)hipFree(voff);
+  if(A6) (void)hipFree(A6);
+  if(voff6) (void)hipFree(voff6);
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  return rc;
 }

@@ -52,7 +52,9 @@ enum { AX_ROW = 0, AX_COL = 1, AX_WORLD = 2 };
 struct Layout {
   int64_t N = 0, nb = 0, T = 0, Np = 0;
   int pr = 1, pc = 1, r = 0, c = 0;
-  int64_t E = 0, E2 = 0;        // extra rows (right-hand sides), E2 = E rounded up to even
+  int64_t E = 0, E2 = 0;        // extra rows (right-hand sides); E2 = E rounded up to 16, so that every column of the local
+                                // block and of the row panels starts on a 128-byte line (misaligned columns cost the
+                                // trailing update 10 %: every 128-byte run of its stores straddles two lines)
   int64_t Lr = 0, Lc = 0;       // local tile rows / columns of the matrix proper
   bool has_extra = false;       // this rank's process row carries the extra rows (tile row T)
   int64_t mloc = 0, nloc = 0, lld = 0;
@@ -62,7 +64,7 @@ struct Layout {
     N = N_; nb = nb_; pr = pr_; pc = pc_; r = r_; c = c_; E = E_;
     T = (N + nb - 1) / nb;
     Np = T * nb;
-    E2 = (E + 1) & ~(int64_t)1;
+    E2 = (E + 15) & ~(int64_t)15;
     Lr = ntiles(T, r, pr);
     Lc = ntiles(T, c, pc);
     has_extra = E > 0 && (int)(T % pr) == r;
