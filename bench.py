@@ -1,24 +1,30 @@
 #!/usr/bin/env python
 """bench.py -- N x N RBF Gram build + Cholesky factors/sec on MI355X (BASELINE.json's metric).
 
-One "step" = one CGp::updateK()-equivalent (FTC): Gram build of the config's kernel from X resident in HBM, blocked
-Cholesky in place, log-determinant (gpc_gp_update_k_f64).  Default workload = BASELINE config 3 (N = 65 536, D = 32,
-rbf + white, the configuration the north-star target is quoted on; K is 34.4 GB and fits one 288 GB GPU).
-`--workload cfg2` runs config 2 (N = 8 192, D = 8, rbf).
+One "step" = one CGp::updateK()-equivalent (FTC; /root/reference/CGp.cpp:698-712 + 877-891): Gram build of the config's
+kernel from X resident in HBM, blocked Cholesky in place, log-determinant.  Default workload = BASELINE config 3
+(N = 65 536, D = 32, rbf + white: the configuration the north-star target is quoted on; K is 34.4 GB and fits one 288 GB GPU).
+`--workload cfg2` = N = 8 192, D = 8; `--workload cfg4` = N = 131 072, D = 16 (137 GB: still one GPU).
 
-N > 1 GPUs (launched by torch.distributed.run, one process per GPU): ONE factorisation of the same workload spread
-over the ranks by gpc_amd/dist.py (1-D block-cyclic column panels, panel broadcasts over RCCL/xGMI, look-ahead), so
-the total work is fixed ("scaling": "strong") and `value` is still whole-job factors/s.  GPC_BENCH_REPLICAS=1 runs
-independent replicas instead (weak scaling, no collective).
+`--gpus N`, N > 1: ONE factorisation of the same workload spread over N ranks, one process per GPU, by the C++ grid
+driver below the C-ABI (gpc_grid_*: 2-D block-cyclic pr x pc tiles, RCCL broadcasts of the diagonal tile / row panel /
+column panel over xGMI sub-communicators, look-ahead 1), so the total work is fixed ("scaling": "strong") and `value` is
+whole-job factors/s.  Started without a launcher (WORLD_SIZE unset) the script re-executes itself under
+torch.distributed.run with N ranks; started by one, it checks that the launcher's world size is the N it was asked for.
+torch.distributed (gloo, CPU) only carries the RCCL unique id, the barriers and the max-over-ranks of the timing.
+Before the timed region every rank factors a small problem both ways (grid and single GPU) and compares log-determinants:
+a mismatch is an error (exit status 3, `value` null, "dist_selfcheck_failed": true), never a silent change of what is measured.
+GPC_BENCH_REPLICAS=1 (explicit only) runs N independent single-GPU replicas instead ("scaling": "weak").
 
-Prints ONE JSON line on rank 0.  The `roofline` object is measured live with HIP events bracketing the dominant
-kernel (the trailing SYRK update on fp64 MFMA) on the stream it is launched on; `cpu_baseline` times the compiled
-reference (oracle/_ref, kind "reference") or, when that binary or MKL is absent, the C restatement (kind "port")
-on a bounded sample of the same workload.
+Prints ONE JSON line on rank 0.  `roofline` is measured live with HIP events bracketing the dominant kernel (the trailing
+update on fp64 MFMA) on the stream it is launched on; `cpu_baseline` times LAPACK dpotrf_ (the reference's CPU path,
+lapack.h:59-65) plus a vectorised host Gram on the host cores at the largest sample of the workload that fits its time budget.
 """
 import argparse
+import ctypes
 import json
 import os
+import socket
 import sys
 import time
 
@@ -29,37 +35,155 @@ sys.path.insert(0, ROOT)
 
 FP64_MFMA_PEAK_TFLOPS = 78.6      # 256 CU x 4 SIMD x 2.4 GHz x 32 flop/clk (AMD MI355X fp64 matrix)
 HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: 8 TB/s HBM3E
+MKL = os.environ.get("GPC_ORACLE_MKL", "/opt/conda/lib/libmkl_rt.so.1")
 
 
-def cpu_baseline(cfg, sample_n, seed):
-    """Reference semantics of one updateK (scalar Gram loop + jitChol) on a bounded sample, on the host cores."""
+# ---- CPU baseline -------------------------------------------------------------------------------------------------------------
+
+def _host_lapack():
+    """(dpotrf(n, a) -> info, gram(kern, X) -> K, vendor string, threads).  MKL's Fortran-ABI dpotrf_ / dgemm_ and its VML
+    vdExp when the image has MKL (the library the compiled reference links, oracle/Makefile), else SciPy's OpenBLAS + numpy.
+    Everything BLAS-like goes through ONE library: MKL's and numpy's thread pools in one process spin against each other."""
+    if os.path.exists(MKL):
+        mkl = ctypes.CDLL(MKL)
+        threads = int(mkl.mkl_get_max_threads())
+        for f in (mkl.dpotrf_, mkl.dgemm_, mkl.vdExp):
+            f.restype = None
+
+        def potrf(n, a):
+            info, nn, lda, uplo = ctypes.c_int(0), ctypes.c_int(n), ctypes.c_int(n), ctypes.c_char(b"L")
+            mkl.dpotrf_(ctypes.byref(uplo), ctypes.byref(nn), ctypes.c_void_p(a.ctypes.data), ctypes.byref(lda), ctypes.byref(info))
+            return info.value
+
+        def gram(kern, X, K):
+            """K = sum_t var_t exp(-gamma_t/2 (|x|^2 + |x'|^2 - 2 x.x')) + white on the diagonal; column-major, in place."""
+            N, D = X.shape
+            Xt = np.ascontiguousarray(X)                       # C-ordered N x D == column-major D x N
+            tT, tN = ctypes.c_char(b"T"), ctypes.c_char(b"N")
+            n, d = ctypes.c_int(N), ctypes.c_int(D)
+            alpha, beta = ctypes.c_double(-2.0), ctypes.c_double(0.0)
+            mkl.dgemm_(ctypes.byref(tT), ctypes.byref(tN), ctypes.byref(n), ctypes.byref(n), ctypes.byref(d), ctypes.byref(alpha),
+                       ctypes.c_void_p(Xt.ctypes.data), ctypes.byref(d), ctypes.c_void_p(Xt.ctypes.data), ctypes.byref(d),
+                       ctypes.byref(beta), ctypes.c_void_p(K.ctypes.data), ctypes.byref(n))
+            n2 = (X * X).sum(1)
+            rbf = [(p[0], p[1]) for name, p in kern if name == "rbf"]
+            assert len(rbf) == 1, "host Gram: one rbf term"
+            gamma, var = rbf[0]
+            for j0 in range(0, N, 512):                        # cache-sized column blocks, all in place
+                blk = K[:, j0:j0 + 512]
+                blk += n2[:, None]
+                blk += n2[None, j0:j0 + 512]
+                np.maximum(blk, 0.0, out=blk)
+                blk *= -0.5 * gamma
+                mkl.vdExp(ctypes.c_int(blk.size), ctypes.c_void_p(blk.ctypes.data), ctypes.c_void_p(blk.ctypes.data))
+                if var != 1.0:
+                    blk *= var
+            K[np.diag_indices_from(K)] = var + sum(p[0] for name, p in kern if name in ("white", "bias"))
+            return K
+        return potrf, gram, "MKL dpotrf_ (%s)" % MKL, threads
+    from scipy.linalg import lapack
+
+    def potrf(n, a):
+        _, info = lapack.dpotrf(a, lower=1, overwrite_a=1)
+        return info
+
+    def gram(kern, X, K):
+        N = X.shape[0]
+        n2 = (X * X).sum(1)
+        gamma, var = [(p[0], p[1]) for name, p in kern if name == "rbf"][0]
+        for j0 in range(0, N, 512):
+            d2 = X @ X[j0:j0 + 512].T
+            d2 *= -2.0
+            d2 += n2[:, None]
+            d2 += n2[None, j0:j0 + 512]
+            np.maximum(d2, 0.0, out=d2)
+            d2 *= -0.5 * gamma
+            np.exp(d2, out=d2)
+            K[:, j0:j0 + 512] = var * d2
+        K[np.diag_indices_from(K)] = var + sum(p[0] for name, p in kern if name in ("white", "bias"))
+        return K
+    return potrf, gram, "SciPy OpenBLAS dpotrf", os.cpu_count() or 1
+
+
+def cpu_baseline(cfg, budget_s):
+    """LAPACK dpotrf_ + vectorised Gram on the host cores: the largest sample size of {N, N/2, N/4, ...} whose
+    2 warm-ups + 5 timed factorisations fit `budget_s` (calibrated on N = 2048), median of 5."""
     from gpc_amd import synth
-    from oracle import refrun, portrun
-    X, _ = synth.make_xy(sample_n, cfg["D"], seed)
-    cores = min(os.cpu_count() or 1, 64)     # BLAS threads; more than 64 only slow a factorisation of this size down
-    t0 = time.time()
-    if refrun.have_ref():
+    potrf, gram, vendor, threads = _host_lapack()
+    N, D, kern = cfg["N"], cfg["D"], cfg["kern"]
+    t_wall = time.time()
+    Xc, _ = synth.make_xy(2048, D, 77)
+    Kc = gram(kern, Xc, np.zeros((2048, 2048), order="F"))
+    A = np.zeros((2048, 2048), order="F")
+    tc = 1e30
+    for _ in range(4):
+        A[...] = Kc
+        t0 = time.perf_counter()
+        potrf(2048, A)
+        tc = min(tc, time.perf_counter() - t0)
+    try:
+        avail = os.sysconf("SC_AVPHYS_PAGES") * os.sysconf("SC_PAGE_SIZE")
+    except (ValueError, OSError):
+        avail = 32 << 30
+    ns = N
+    while ns > 2048:
+        # large factorisations run ~3x closer to the BLAS peak than N = 2048 does; stay on the safe side with 2x
+        pred = 7.0 * tc * (ns / 2048.0) ** 3 / 2.0
+        if pred <= budget_s and 2 * 8 * ns * ns < 0.6 * avail:
+            break
+        ns //= 2
+    X, _ = synth.make_xy(ns, D, 1234)
+    K, A = np.zeros((ns, ns), order="F"), np.zeros((ns, ns), order="F")   # touched once, outside the timed regions: a fresh
+    gram(kern, X, K)                                                       # page costs more here than the arithmetic on it
+    t0 = time.perf_counter()
+    gram(kern, X, K)
+    t_gram = time.perf_counter() - t0
+    times = []
+    for it in range(7):
+        A[...] = K
+        t0 = time.perf_counter()
+        info = potrf(ns, A)
+        dt = time.perf_counter() - t0
+        assert info == 0, "host dpotrf failed (info=%d)" % info
+        if it >= 2:
+            times.append(dt)
+    t_potrf = float(np.median(times))
+    out = {"value": 1.0 / (t_gram + t_potrf), "unit": "factors/s at the sample size", "cores": threads, "kind": "reference",
+           "sample": "N=%d of the workload's N=%d, D=%d, same kernel: vectorised host Gram %.2f s (second of two builds into touched memory) + %s %.3f s (median of 5 "
+                     "after 2 warm-ups, %d threads; %.0f GFLOP/s); wall %.1f s"
+                     % (ns, N, D, t_gram, vendor, t_potrf, threads, ns ** 3 / 3.0 / t_potrf * 1e-9, time.time() - t_wall),
+           "sample_n": ns, "potrf_s": t_potrf, "gram_s": t_gram}
+    if ns != N:
+        full = t_gram * (N / ns) ** 2 + t_potrf * (N / ns) ** 3
+        out["extrapolated_to_workload"] = {"value": 1.0 / full, "unit": "factors/s", "note": "N^3 (dpotrf) and N^2 (Gram) "
+                                           "scaling of the sample; labelled extrapolation, not a measurement"}
+    return out
+
+
+def cpu_reference_binary(cfg, sample_n):
+    """Second, labelled entry: the compiled, unmodified reference's own updateK (scalar Gram loop + jitChol) at a small N."""
+    try:
+        from gpc_amd import synth
+        from oracle import refrun
+        if not refrun.have_ref():
+            return None
+        X, _ = synth.make_xy(sample_n, cfg["D"], 1234)
+        cores = min(os.cpu_count() or 1, 64)
         arrays = dict(refrun.kern_arrays(cfg["kern"]))
         arrays.update({"X": X, "reps": 1.0})
+        refrun.run_ref("time", arrays, threads=cores)            # warm-up (MKL start-up is most of a cold N = 4096 run)
         r = refrun.run_ref("time", arrays, threads=cores)
-        kind, used = "reference", cores
-    elif refrun.have_port():
-        sample_n = min(sample_n, 2048)
-        X = X[:sample_n]
-        r = portrun.time_update_k(cfg["kern"], X, reps=1)
-        kind, used = "port", 1
-    else:
-        return None
-    tg, tc = float(r["t_gram"][0, 0]), float(r["t_chol"][0, 0])
-    return {"value": 1.0 / (tg + tc), "unit": "factors/s at the sample size", "cores": used, "kind": kind,
-            "sample": "N=%d D=%d same kernel, one CGp::updateK (scalar Gram loop %.2f s + jitChol %.2f s; "
-                      "BLAS threads = cores for the reference, the Gram loop is single-threaded); wall %.1f s"
-                      % (sample_n, cfg["D"], tg, tc, time.time() - t0)}
+        tg, tc = float(r["t_gram"][0, 0]), float(r["t_chol"][0, 0])
+        return {"value": 1.0 / (tg + tc), "unit": "factors/s at N=%d" % sample_n, "cores": cores, "kind": "reference",
+                "sample": "oracle/_ref/ref_driver: CGp::updateK of the compiled reference, scalar Gram loop %.2f s (one thread) "
+                          "+ jitChol %.2f s (MKL, %d threads), second of two runs" % (tg, tc, cores)}
+    except Exception as e:   # noqa: BLE001 -- the baseline is a report, never a reason to lose the GPU measurement
+        return {"value": None, "error": str(e)[:200]}
 
 
 def pmc_traffic(workload, single_gpu_path):
-    """HBM bytes per trailing-update launch from the committed PMC passes of THIS command (tools/pmc_bench_traffic.sh ->
-    profiles/rNN_pmc_bench_traffic.json); None when no such profile exists for the workload being run."""
+    """HBM bytes per trailing-update launch from the committed PMC passes of this command (tools/pmc_bench_traffic.sh ->
+    profiles/rNN_pmc_bench_traffic.json).  REPLAYED, not collected in this run: counters need a rocprofv3 wrapper."""
     import glob
     if workload != "cfg3" or not single_gpu_path:
         return None, None
@@ -74,8 +198,12 @@ def pmc_traffic(workload, single_gpu_path):
         return None, None
 
 
-def jobs_flops(world, replicas):
-    return world if replicas else 1
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
 
 
 def main():
@@ -85,73 +213,96 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default=os.environ.get("GPC_BENCH_WORKLOAD", "cfg3"))
     ap.add_argument("--n", type=int, default=0, help="override N (debug)")
-    ap.add_argument("--cpu-sample-n", type=int, default=4096)
+    ap.add_argument("--cpu-budget-s", type=float, default=25.0, help="time budget of the host dpotrf_ baseline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
+    if args.gpus < 1:
+        sys.exit("bench.py: --gpus must be >= 1")
+
+    launched = "WORLD_SIZE" in os.environ
+    if args.gpus > 1 and not launched:
+        # no launcher: become one.  One process per GPU, rendezvous on 127.0.0.1 (the container hostname may not resolve).
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+        os.execv(sys.executable, cmd)
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        sys.exit("bench.py: --gpus %d but the launcher started %d ranks; refusing to report one as the other"
+                 % (args.gpus, world))
 
     import torch
     import torch.distributed as dist
-    if not os.path.exists(os.path.join(ROOT, "gpc_amd", "lib", "libgpc_hip.so")) and \
-            int(os.environ.get("LOCAL_RANK", "0")) == 0 and int(os.environ.get("WORLD_SIZE", "1")) == 1:
+    if not os.path.exists(os.path.join(ROOT, "gpc_amd", "lib", "libgpc_hip.so")) and world == 1:
         import __graft_entry__           # a checkout without the built library: build it (single-process runs only)
         __graft_entry__.build()
     from gpc_amd import api, synth
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
+    if local_rank >= torch.cuda.device_count():
+        sys.exit("bench.py: rank %d has no GPU (%d visible); refusing to share devices" % (rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
+    api.lib()
+    api.check(api.lib().gpc_set_device(local_rank))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        opts = dist.ProcessGroupNCCL.Options(is_high_priority_stream=True)   # panel broadcasts overtake the SYRK
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), pg_options=opts)
-    api.lib()
+        dist.init_process_group("gloo")      # control plane only; the data path is RCCL inside libgpc_hip.so
     replicas = world > 1 and os.environ.get("GPC_BENCH_REPLICAS", "0") == "1"
-    # GPC_BENCH_DIST=1: drive the block-cyclic code path on ONE GPU too (P = 1, no collective) to price its overhead
-    distributed = (world > 1 and not replicas) or os.environ.get("GPC_BENCH_DIST", "0") == "1"
+    # GPC_BENCH_GRID=1: drive the grid code path on ONE GPU too (1 x 1, no exchange) to price its overhead
+    gridded = (world > 1 and not replicas) or os.environ.get("GPC_BENCH_GRID", "0") == "1"
 
     cfg = dict(synth.CONFIGS[args.workload])
     if args.n:
         cfg["N"] = args.n
     N, D = cfg["N"], cfg["D"]
     X, _ = synth.make_xy(N, D, seed=1234 + (rank if replicas else 0))
-    dist_fallback = False
-    if distributed:
-        from gpc_amd import dist as gdist
-        dist_mode = "overlapped"
+
+    def fail(msg, **extra):
+        if rank == 0:
+            line = {"metric": "N x N RBF Gram build + Cholesky factors/sec", "value": None, "unit": "factors/s",
+                    "n_gpus": world, "error": msg}
+            line.update(extra)
+            print(json.dumps(line))
+        sys.stdout.flush()
+        if world > 1:
+            dist.destroy_process_group()
+        sys.exit(3)
+
+    g = None
+    if gridded:
+        from gpc_amd import grid
+        shape = os.environ.get("GPC_GRID", "")
+        pr, pc = (int(v) for v in shape.lower().split("x")) if shape else grid.default_shape(world)
+        if pr * pc != world:
+            sys.exit("bench.py: GPC_GRID=%s does not have %d ranks" % (shape, world))
+        nb = int(os.environ.get("GPC_GRID_NB", "1024" if N >= 49152 else "512"))
+        uid = [grid.unique_id() if (rank == 0 and world > 1) else None]
+        if world > 1:
+            dist.broadcast_object_list(uid, src=0)
+        g = grid.create(rank, world, pr, pc, nb, uid[0])
         if world > 1 and os.environ.get("GPC_BENCH_SELFCHECK", "1") == "1":
-            # Start-up self-check (untimed): the block-cyclic factorisation of a small problem must give the log-determinant
-            # a single-GPU factorisation gives, on every rank.  The overlapped mode (second stream, asynchronous RCCL
-            # broadcasts ordered by events) is checked first; if it disagrees the run falls back to the serialised mode.
+            # untimed: the grid must reproduce the single-GPU log-determinant of a small problem on every rank
             Xc, _ = synth.make_xy(8192, D, seed=99)
             _, ref_ld, _, info0 = api.gp_update_k(api.kspec(cfg["kern"]), api.from_host(Xc))
-            for mode in ("overlapped", "serialised"):
-                ok = 0.0
-                try:
-                    gc = gdist.DistGp(cfg["kern"], Xc, sync=(mode == "serialised"))
-                    ld = gc.update_k()
-                    ok = 1.0 if (info0 == 0 and abs(ld - ref_ld) <= 1e-8 * abs(ref_ld)) else 0.0
-                    del gc
-                except Exception as e:     # noqa: BLE001 -- any failure of the check means "do not use this mode"
-                    sys.stderr.write("rank %d: distributed self-check (%s) failed: %r\n" % (rank, mode, e))
-                flag = torch.tensor([ok], dtype=torch.float64, device="cuda")
-                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-                if float(flag.item()) == 1.0:
-                    dist_mode = mode
-                    break
-            else:
-                # neither mode reproduces the single-GPU factor on this node: report what the GPUs do independently
-                # rather than nothing (every rank reaches this branch together: the flags were all-reduced)
-                sys.stderr.write("rank %d: block-cyclic factorisation failed its self-check in both modes; "
-                                 "running %d independent replicas instead\n" % (rank, world))
-                distributed, replicas, dist_fallback = False, True, True
-                X, _ = synth.make_xy(N, D, seed=1234 + rank)
-    if distributed:
-        g = gdist.DistGp(cfg["kern"], X, sync=(dist_mode == "serialised"))
+            torch.cuda.synchronize()
+            g.set_problem(cfg["kern"], Xc, None, None)
+            ld, _, info1 = g.update_k()
+            ok = info0 == 0 and info1 == 0 and abs(ld - ref_ld) <= 1e-8 * abs(ref_ld)
+            flag = torch.tensor([1.0 if ok else 0.0], dtype=torch.float64)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if float(flag.item()) != 1.0:
+                sys.stderr.write("rank %d: grid self-check: log|K| %.17g (info %d) vs single GPU %.17g (info %d)\n"
+                                 % (rank, ld, info1, ref_ld, info0))
+                fail("the %d x %d grid does not reproduce the single-GPU factorisation of the N = 8192 check problem"
+                     % (pr, pc), dist_selfcheck_failed=True)
+        g.set_problem(cfg["kern"], X, None, None)
+        g.stats(reset=True)
 
         def step():
-            return g.update_k()
+            logdet, _, info = g.update_k()
+            assert info == 0, "factorisation failed (info=%d)" % info
+            return logdet
     else:
         Xd = api.from_host(X)
         ks = api.kspec(cfg["kern"])
@@ -166,16 +317,20 @@ def main():
             return logdet
 
     def sync():
+        if g is not None:
+            g.sync()
+        torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
         step()
-    api.check(api.lib().gpc_profile_enable(1))
-    import ctypes
+    api.profile_enable(True)
     for kind in (0, 1):
-        api.check(api.lib().gpc_profile_read(kind, None, None, None, 1))
+        api.profile_read(kind, reset=True)
+    if g is not None:
+        g.stats(reset=True)
     sync()
     t0 = time.perf_counter()
     logdet = 0.0
@@ -183,35 +338,33 @@ def main():
         logdet = step()
     sync()
     dt = time.perf_counter() - t0
-    api.check(api.lib().gpc_profile_enable(0))
+    api.profile_enable(False)
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([dt], dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
-    def prof(kind):
-        n, ms, w = ctypes.c_int64(0), ctypes.c_double(0.0), ctypes.c_double(0.0)
-        api.check(api.lib().gpc_profile_read(kind, ctypes.byref(n), ctypes.byref(ms), ctypes.byref(w), 1))
-        return n.value, ms.value, w.value
-
-    syrk_n, syrk_ms, syrk_flops = prof(0)
-    # algorithmic HBM bytes of the trailing updates of one factor: each reads its panel rows once (8*m*NB) and reads +
-    # writes the lower triangle it updates (2 * 8 * m(m+1)/2); summed over the panels
-    syrk_bytes, k0 = 0.0, 0
-    fixed_nb = int(os.environ.get("GPC_NB", "0"))
-    while k0 < N:
-        rem = N - k0
-        nbp = fixed_nb if fixed_nb >= 64 else 1024   # potrf.hip panel_width()
-        nbp = min(nbp, rem)
-        m = rem - nbp
-        if m > 0:
-            syrk_bytes += 8.0 * m * nbp + 8.0 * m * (m + 1)
-        k0 += nbp
-    syrk_bytes *= args.steps
-    gram_n, gram_ms, gram_bytes = prof(1)
+    syrk_n, syrk_ms, syrk_flops = api.profile_read(0, reset=True)
+    gram_n, gram_ms, gram_bytes = api.profile_read(1, reset=True)
+    gstats = g.stats() if g is not None else None
+    if g is not None:
+        syrk_bytes = gstats["update_bytes"]
+    else:
+        # algorithmic HBM bytes of the trailing updates of one factor: each reads its panel rows once (8*m*NB) and reads +
+        # writes the lower triangle it updates (2 * 8 * m(m+1)/2); summed over the panels
+        syrk_bytes, k0 = 0.0, 0
+        fixed_nb = int(os.environ.get("GPC_NB", "0"))
+        while k0 < N:
+            rem = N - k0
+            nbp = min(fixed_nb if fixed_nb >= 64 else 1024, rem)   # potrf.hip panel_width()
+            m = rem - nbp
+            if m > 0:
+                syrk_bytes += 8.0 * m * nbp + 8.0 * m * (m + 1)
+            k0 += nbp
+        syrk_bytes *= args.steps
 
     phases = None
-    if rank == 0 and not distributed and not replicas and os.environ.get("GPC_BENCH_PHASES", "1") == "1":
+    if rank == 0 and g is None and not replicas and os.environ.get("GPC_BENCH_PHASES", "1") == "1":
         # The other phases of one likelihood / gradient evaluation on the factor just computed, timed with events on
         # torch's current stream (the stream every C-ABI call above ran on).  NOT part of `value`.
         def timed(fn):
@@ -243,53 +396,72 @@ def main():
             phases["potri_skipped"] = str(e)[:100]
 
     if rank == 0:
-        probe, pcyc, pclk = ctypes.c_double(0.0), ctypes.c_double(0.0), ctypes.c_double(0.0)
-        api.check(api.lib().gpc_probe_mfma_f64(ctypes.byref(probe), ctypes.byref(pcyc), ctypes.byref(pclk),
-                                               api.stream()))
+        probe, ticks, tick_ghz = ctypes.c_double(0.0), ctypes.c_double(0.0), ctypes.c_double(0.0)
+        api.check(api.lib().gpc_probe_mfma_f64(ctypes.byref(probe), ctypes.byref(ticks), ctypes.byref(tick_ghz), api.stream()))
+        cus = torch.cuda.get_device_properties(local_rank).multi_processor_count
         achieved = syrk_flops / (syrk_ms * 1e-3) * 1e-12 if syrk_ms > 0 else 0.0
         potrf_flops = N ** 3 / 3.0
-        traffic, traffic_src = pmc_traffic(args.workload if not args.n else "custom", not distributed)
-        roof = {"bound": "mfma", "kernel": "gemm_nt_fast_kernel<4, 1> (trailing SYRK launches U1+U2 of %s)"
-                                           % ("gpc_syrk_blockcyclic_f64, rank 0" if distributed else "gpc_potrf_f64"),
+        traffic, traffic_src = pmc_traffic(args.workload if not args.n else "custom", g is None)
+        jobs = world if replicas else 1
+        roof = {"bound": "mfma",
+                "kernel": "gemm_nt_fast_kernel<4, 1> (trailing updates U1+U2 of %s)"
+                          % ("the grid's rank 0, 2-D staircase" if g is not None else "gpc_potrf_f64"),
                 "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": traffic,
-                "traffic_unit": "HBM bytes per launch = (2 x FETCH_SIZE + WRITE_SIZE) x 1024, rocprofv3 --pmc passes of "
-                                "this command", "traffic_source": traffic_src,
+                "traffic_unit": "HBM bytes per launch = (2 x FETCH_SIZE + WRITE_SIZE) x 1024",
+                "traffic_source": None if traffic is None else
+                "REPLAYED from %s (separate rocprofv3 --pmc passes of this command; not collected in this run)" % traffic_src,
                 "algorithmic_bytes_per_launch": syrk_bytes / max(1, syrk_n),
                 "launches_per_step": syrk_n / max(1, args.steps),
                 "avg_launch_ms": syrk_ms / max(1, syrk_n),
                 "algorithmic_flops_per_launch": syrk_flops / max(1, syrk_n),
-                "mfma_f64_probe_tflops": probe.value, "mfma_f64_probe_cycles_per_mfma": pcyc.value,
-                "mfma_f64_probe_clock_ghz": pclk.value,
-                "whole_factor_tflops": jobs_flops(world, replicas) * potrf_flops * args.steps / dt * 1e-12,
+                "mfma_f64_probe_tflops": probe.value,
+                # a v_mfma_f64_16x16x4 occupies a SIMD's matrix pipe for 64 shader cycles (PMC: SQ_VALU_MFMA_BUSY_CYCLES), so
+                # the probe's rate IS the shader clock under MFMA load; s_memtime ticks at half of it on gfx950
+                "mfma_f64_probe_shader_clock_ghz": probe.value * 1e12 / (cus * 4 * 32.0) * 1e-9,
+                "mfma_f64_probe_shader_cycles_per_mfma": 64.0,
+                "mfma_f64_probe_s_memtime_ticks_per_mfma": ticks.value, "s_memtime_ghz": tick_ghz.value,
+                "whole_factor_tflops": jobs * potrf_flops * args.steps / dt * 1e-12,
+                "whole_factor_frac_of_n_gpu_peak": jobs * potrf_flops * args.steps / dt * 1e-12 / (FP64_MFMA_PEAK_TFLOPS * world),
                 "gram": {"bound": "hbm", "achieved": gram_bytes / (gram_ms * 1e-3) * 1e-9 if gram_ms > 0 else 0.0,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "avg_launch_ms": gram_ms / max(1, gram_n)}}
         roof["gram"]["frac"] = roof["gram"]["achieved"] / HBM_PEAK_GBS
-        jobs = world if replicas else 1
+        if g is not None:
+            inf = g.info()
+            par = "%d x %d block-cyclic grid (nb=%d) over %d GPU%s, C++ driver below the C-ABI, %s, look-ahead 1" % (
+                inf["pr"], inf["pc"], inf["nb"], world, "" if world == 1 else "s",
+                "RCCL broadcasts of diagonal tile / row panel / column panel" if world > 1 else "no exchange")
+        else:
+            par = "1 GPU" if world == 1 else "%d independent replicas (GPC_BENCH_REPLICAS=1)" % world
         out = {"metric": "N x N RBF Gram build + Cholesky factors/sec", "value": jobs * args.steps / dt,
                "unit": "factors/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
-               "scaling": "strong" if distributed else "weak",
+               "scaling": "weak" if replicas else "strong",
                "vs_baseline": None, "dtype": "f64", "data": "synthetic",
                "config": {"workload": "%s: N=%d D=%d kernel=%s, one CGp::updateK (Gram + dpotrf + logdet) per step"
                                       % (args.workload, N, D, "+".join(t for t, _ in cfg["kern"])),
-                          "parallelism": "1 GPU" if world == 1 else
-                          ("%d independent replicas%s" % (world, " (the block-cyclic factorisation failed its start-up "
-                                                          "self-check on this node)" if dist_fallback else "")
-                           if replicas else
-                           "1-D block-cyclic column panels over %d GPUs (nb=%d), RCCL panel broadcast, %s"
-                           % (world, g.nb, "look-ahead 1, slab-pipelined" if dist_mode == "overlapped" else
-                              "serialised collectives (the overlapped mode failed the start-up self-check)")),
-                          "logdet": logdet},
+                          "parallelism": par, "logdet": logdet},
                "roofline": roof}
+        if gstats is not None:
+            out["grid"] = {"rank0_bytes_received_per_step": {"along_row": gstats["bytes_row"] / args.steps,
+                                                             "along_column": gstats["bytes_col"] / args.steps},
+                           "rank0_collectives_per_step": gstats["collectives"] / args.steps,
+                           "rank0_update_tflops": achieved}
         if phases is not None:
             phases["gram_ms"] = gram_ms / max(1, gram_n)
             phases["potrf_logdet_ms"] = dt / args.steps * 1e3 - phases["gram_ms"]
             out["phases"] = phases
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(cfg, min(args.cpu_sample_n, N), 1234)
+            out["cpu_baseline"] = cpu_baseline(cfg, args.cpu_budget_s)
+            ref = cpu_reference_binary(cfg, min(4096, N))
+            if ref is not None:
+                out["cpu_baseline_reference_binary"] = ref
         print(json.dumps(out))
+    sys.stdout.flush()
+    if g is not None:
+        g.destroy()
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 

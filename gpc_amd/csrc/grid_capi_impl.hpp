@@ -226,7 +226,8 @@ int GRID_API(stats)(gpc_grid* g, double* out, int reset)
   out[3] = (double)s.collectives;
   out[4] = s.update_flops;
   out[5] = (double)s.update_launches;
-  out[6] = out[7] = 0.0;
+  out[6] = s.update_bytes;
+  out[7] = 0.0;
   if(reset) g->gp->reset_stats();
   return GPC_OK;
 }

@@ -329,6 +329,7 @@ struct GridStats {
   double bytes_sent[3] = {0, 0, 0};
   int64_t collectives = 0;
   double update_flops = 0;            // algorithmic flops of this rank's trailing updates
+  double update_bytes = 0;            // ... and their algorithmic HBM bytes: both panels once + read and write of the entries updated
   int64_t update_launches = 0;
 };
 
@@ -795,6 +796,7 @@ class GridGp {
       if(ilf < L.Lr && r_ + pr_ * ilf == J) entries -= 0.5 * (double)nb_ * (double)(nb_ - 1);
     }
     stats_.update_flops += 2.0 * (double)nb_ * entries;
+    stats_.update_bytes += 8.0 * (double)nb_ * (double)(u.M + u.Ncols) + 16.0 * entries;
     stats_.update_launches++;
     ops_->prof_update_begin(2.0 * (double)nb_ * entries, st);
     const int rc = ops_->update(u, st);

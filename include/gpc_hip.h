@@ -208,7 +208,7 @@ int gpc_grid_set_lookahead(gpc_grid* g, int on);
 /* out[12] = N, nb, T (tiles per side), pr, pc, r, c, local rows, local columns, extra rows, local tile rows, columns */
 int gpc_grid_info(gpc_grid* g, int64_t* out);
 /* out[8] = bytes received along the process row / column / world, collectives entered, algorithmic flops of this rank's
- * trailing updates, their launches, 0, 0 -- since the last reset */
+ * trailing updates, their launches, their algorithmic HBM bytes, 0 -- since the last reset */
 int gpc_grid_stats(gpc_grid* g, double* out, int reset);
 /* tests: tile (I, J) of the factor to the host (nb x nb, leading dimension nb; I == T addresses the extra rows);
  * *owned = 0 and nothing copied when the tile lives on another rank */
