@@ -107,28 +107,29 @@ def _host_lapack():
 
 def cpu_baseline(cfg, budget_s):
     """LAPACK dpotrf_ + vectorised Gram on the host cores: the largest sample size of {N, N/2, N/4, ...} whose
-    2 warm-ups + 5 timed factorisations fit `budget_s` (calibrated on N = 2048), median of 5."""
+    2 warm-ups + 5 timed factorisations fit `budget_s` (calibrated on N = 4096), median of 5."""
     from gpc_amd import synth
     potrf, gram, vendor, threads = _host_lapack()
     N, D, kern = cfg["N"], cfg["D"], cfg["kern"]
     t_wall = time.time()
-    Xc, _ = synth.make_xy(2048, D, 77)
-    Kc = gram(kern, Xc, np.zeros((2048, 2048), order="F"))
-    A = np.zeros((2048, 2048), order="F")
+    n0 = min(4096, N)
+    Xc, _ = synth.make_xy(n0, D, 77)
+    Kc = gram(kern, Xc, np.zeros((n0, n0), order="F"))
+    A = np.zeros((n0, n0), order="F")
     tc = 1e30
     for _ in range(4):
         A[...] = Kc
         t0 = time.perf_counter()
-        potrf(2048, A)
+        potrf(n0, A)
         tc = min(tc, time.perf_counter() - t0)
     try:
         avail = os.sysconf("SC_AVPHYS_PAGES") * os.sysconf("SC_PAGE_SIZE")
     except (ValueError, OSError):
         avail = 32 << 30
     ns = N
-    while ns > 2048:
-        # large factorisations run ~3x closer to the BLAS peak than N = 2048 does; stay on the safe side with 2x
-        pred = 7.0 * tc * (ns / 2048.0) ** 3 / 2.0
+    while ns > n0:
+        # larger factorisations run somewhat closer to the BLAS peak than the calibration size does
+        pred = 7.0 * tc * (ns / float(n0)) ** 3 / 1.5
         if pred <= budget_s and 2 * 8 * ns * ns < 0.6 * avail:
             break
         ns //= 2
@@ -158,6 +159,20 @@ def cpu_baseline(cfg, budget_s):
         out["extrapolated_to_workload"] = {"value": 1.0 / full, "unit": "factors/s", "note": "N^3 (dpotrf) and N^2 (Gram) "
                                            "scaling of the sample; labelled extrapolation, not a measurement"}
     return out
+
+
+def cpu_baseline_subprocess(args):
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--workload", args.workload,
+           "--cpu-budget-s", str(args.cpu_budget_s)] + (["--n", str(args.n)] if args.n else [])
+    try:
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, stdin=subprocess.DEVNULL,
+                           timeout=6.0 * args.cpu_budget_s + 60.0)
+        if r.returncode != 0:
+            return {"value": None, "error": "host baseline failed: %s" % r.stderr.decode()[-300:]}
+        return json.loads(r.stdout.decode().strip().splitlines()[-1])
+    except subprocess.TimeoutExpired:
+        return {"value": None, "error": "host baseline exceeded %.0f s and was stopped" % (6.0 * args.cpu_budget_s + 60.0)}
 
 
 def cpu_reference_binary(cfg, sample_n):
@@ -215,7 +230,17 @@ def main():
     ap.add_argument("--n", type=int, default=0, help="override N (debug)")
     ap.add_argument("--cpu-budget-s", type=float, default=25.0, help="time budget of the host dpotrf_ baseline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.cpu_baseline_only:
+        # child process of the N = 1 run: MKL's OpenMP runtime and the one PyTorch brings deadlock in one process, so the
+        # host baseline runs in a process of its own (numpy + MKL only) and hands its JSON back on stdout
+        from gpc_amd import synth
+        cfg = dict(synth.CONFIGS[args.workload])
+        if args.n:
+            cfg["N"] = args.n
+        print(json.dumps(cpu_baseline(cfg, args.cpu_budget_s)))
+        return
     if args.gpus < 1:
         sys.exit("bench.py: --gpus must be >= 1")
 
@@ -452,7 +477,7 @@ def main():
             phases["potrf_logdet_ms"] = dt / args.steps * 1e3 - phases["gram_ms"]
             out["phases"] = phases
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(cfg, args.cpu_budget_s)
+            out["cpu_baseline"] = cpu_baseline_subprocess(args)
             ref = cpu_reference_binary(cfg, min(4096, N))
             if ref is not None:
                 out["cpu_baseline_reference_binary"] = ref
