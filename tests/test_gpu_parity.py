@@ -585,6 +585,47 @@ def test_cfg3_full_size_properties(api):
     assert torch.equal(inv[idx, :], inv[:, idx].t())
 
 
+def test_cfg4_full_size_properties(api):
+    """BASELINE config 4 at its full size on ONE GPU (N = 131 072, D = 16, rbf, gamma = 1; K is 137 GB, so there is room
+    for one N x N matrix only): sampled columns of L L' against the Gram columns saved before the factorisation,
+    log|K| against the factor's diagonal, K alpha = m with K regenerated in row blocks, and the tiles a 2 x 4 grid would
+    hold (gpc_gram_block_f64) against the single matrix."""
+    import torch
+    from gpc_amd import synth
+    if torch.cuda.get_device_properties(0).total_memory < 200e9:
+        pytest.skip("needs 140 GB of HBM")
+    c = synth.CONFIGS["cfg4"]
+    N, D = c["N"], c["D"]
+    X, y = synth.make_xy(N, D, 1234)
+    ks = api.kspec(c["kern"])
+    Xd = api.from_host(X)
+    K = api.gram_sym(ks, Xd)
+    idx = [0, 1, 4095, 65536, 100000, N - 1]
+    tidx = torch.tensor(idx, device="cuda")
+    assert torch.equal(K[tidx, :], K[:, tidx].t())                               # the mirrored build is exactly symmetric
+    blk = api.gram_block(ks, Xd, 70000, 300, 100, 200)
+    assert torch.equal(blk, K[70000:70300, 100:300])
+    del blk
+    Kcols = K[:, tidx].clone()
+    L, logdet, jit, info = api.gp_update_k(ks, Xd, K)
+    assert info == 0 and jit == 0.0 and np.isfinite(logdet)
+    assert abs(logdet - 2.0 * float(torch.log(torch.diagonal(L)).sum())) <= 1e-9 * abs(logdet)
+    # (L L')(i, j) for the sampled columns j and all rows i >= j, through the library's GEMM on views of the factor (a
+    # torch matmul would copy the strided slices: 34 GB for j = 65 536)
+    for q, j in enumerate(idx):
+        col = api.empty(N - j, 1)
+        api.gemm(L[j:, :j + 1], L[j:j + 1, :j + 1], col, "N", "T", 1.0, 0.0)
+        assert float((col[:, 0] - Kcols[j:, q]).abs().max()) < 1e-10
+    m = api.from_host(y - y.mean())
+    alpha = api.gp_alpha(L, m)
+    worst, step = 0.0, 4096
+    for i0 in range(0, N, step):                                                 # K alpha = m, K one row block at a time
+        rows = api.gram_block(ks, Xd, i0, step, 0, N)
+        worst = max(worst, float((rows @ alpha - m[i0:i0 + step]).abs().max()))
+        del rows
+    assert worst < 1e-9 * max(1.0, float(alpha.abs().max()))
+
+
 @pytest.mark.parametrize("N", [24000, 24700, 28700, 33000])
 def test_potrf_across_the_panel_chain_switches(api, N):
     """Sizes either side of the points where the factorisation changes kernels (fused four-wave panel steps up to
