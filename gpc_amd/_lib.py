@@ -117,6 +117,7 @@ GRID_SIGNATURES = {
     "fill": (c_int, [GP]),
     "factor": (c_int, [GP, POINTER(c_int)]),
     "loglik": (c_int, [GP, POINTER(c_double)]),
+    "quadform": (c_int, [GP, DP]),
     "alpha": (c_int, [GP, DP, I64]),
     "posterior": (c_int, [GP, DP, I64, DP]),
     "sync": (c_int, [GP]),

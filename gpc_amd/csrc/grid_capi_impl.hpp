@@ -168,6 +168,13 @@ int GRID_API(loglik)(gpc_grid* g, double* ll)
   return grid_fail(g, g->gp->loglik(ll));
 }
 
+int GRID_API(quadform)(gpc_grid* g, double* q)
+{
+  if(!g || !q) return GPC_EINVAL;
+  GRID_CHECK(grid_enter(g->device));
+  return grid_fail(g, g->gp->quadform(q));
+}
+
 int GRID_API(alpha)(gpc_grid* g, double* alpha_host, int64_t lda)
 {
   if(!g) return GPC_EINVAL;

@@ -502,6 +502,13 @@ class GridGp {
     return GPC_OK;
   }
 
+  // q[j] = m_j' K^-1 m_j = |L^-1 y_j|^2, j < d: the quadratic forms of CGp::logLikelihood (CGp.cpp:923-932)
+  int quadform(double* q)
+  {
+    if(!factored_ || d_ <= 0) return fail(GPC_EINVAL, "grid quadform: no factor / no targets");
+    return extra_sumsq(0, d_, q);
+  }
+
   // CGp::updateAlpha (CGp.cpp:469-489): alpha = K^-1 y, N x d, replicated; alpha_host may be null (kept on the device).
   // Column-oriented back substitution L' alpha = z over the tiles, last to first: the ranks of process column k mod pc
   // form sum_{I>k} L(I,k)' alpha_I for their rows, one reduction down the column, the diagonal owner solves and sends.

@@ -149,6 +149,11 @@ class Grid(object):
         self.b.check(self.b.loglik(self.h, byref(ll)), self.h)
         return ll.value
 
+    def quadform(self):
+        q = np.zeros(self.d)
+        self.b.check(self.b.quadform(self.h, q.ctypes.data), self.h)
+        return q
+
     def alpha(self):
         out = np.zeros((self.N, self.d), order="F")
         self.b.check(self.b.alpha(self.h, out.ctypes.data, self.N), self.h)

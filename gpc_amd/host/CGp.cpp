@@ -5,6 +5,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <fstream>
+#include <thread>
 #include <vector>
 #include "gpc_hip.h"
 #include "ndlstream.h"
@@ -33,7 +34,8 @@ CGp::CGp(CKern* kernel, CNoise* nois, CMatrix* Xin, int approx, unsigned int act
       AlphaUpToDate(false), invKupToDate(false), LcholRounded(false), dX(0), dM(0), dL(0), dInvKm(0), dAlpha(0), dInvK(0),
       dCovGrad(0), logDetK(0.0), lastJitter(0.0), needInverse(false), approxType(approx), betaVal(1e3),
       inducingFixed(false), dXu(0), dKuu(0), dKuf(0), dInvKuu(0), dA(0), dAinv(0), dLA(0), dE(0), dAlphaU(0), dIKK(0),
-      logDetKuu(0.0), logDetA(0.0), sumDiagD(0.0), LArounded(false), dVf(0), dBet(0), sumLogDiagD(0.0), sumLogLm(0.0), sMsM(0.0)
+      logDetKuu(0.0), logDetA(0.0), sumDiagD(0.0), LArounded(false), dVf(0), dBet(0), sumLogDiagD(0.0), sumLogLm(0.0), sMsM(0.0),
+      gridPr(1), gridPc(1), gridDecided(0), gridNs(-1)
 {
   if(Xin->getRows() != nois->getNumData())
     throw ndlexceptions::MatrixError("CGp: X and the targets disagree on the number of data");   // CGp.cpp:60
@@ -58,7 +60,7 @@ CGp::CGp()
       invKupToDate(false), LcholRounded(false), dX(0), dM(0), dL(0), dInvKm(0), dAlpha(0), dInvK(0), dCovGrad(0), logDetK(0.0), lastJitter(0.0),
       needInverse(false), approxType(FTC), betaVal(1e3), inducingFixed(false), dXu(0), dKuu(0), dKuf(0), dInvKuu(0), dA(0),
       dAinv(0), dLA(0), dE(0), dAlphaU(0), dIKK(0), logDetKuu(0.0), logDetA(0.0), sumDiagD(0.0), LArounded(false), dVf(0), dBet(0), sumLogDiagD(0.0),
-      sumLogLm(0.0), sMsM(0.0)
+      sumLogLm(0.0), sMsM(0.0), gridPr(1), gridPc(1), gridDecided(0), gridNs(-1)
 {
   const char* e = std::getenv("GPC_EXACT_TRANS");
   if(e && e[0] == '1') refTransRounding = false;
@@ -82,9 +84,11 @@ void CGp::setData(CMatrix* Xin, CMatrix* yin)
   devFree(dIKK);
   devFree(dVf);
   MupToDate = KupToDate = AlphaUpToDate = invKupToDate = false;
+  gridNs = -1;
 }
 CGp::~CGp()
 {
+  gridRelease();
   if(ownsKernNoise) {
     delete pkern;
     delete pnoise;
@@ -133,10 +137,138 @@ void CGp::ensureDeviceInputs() const
   if(!MupToDate) updateM();
 }
 
+// ---- multi-GPU ---------------------------------------------------------------------------------------------------------
+namespace {
+// f(rank) on one host thread per rank, concurrently: the grid's entry points are collective.  The first failure is rethrown.
+template <class F>
+void onRanks(size_t n, F f)
+{
+  std::vector<int> rc(n, GPC_OK);
+  if(n == 1) {
+    rc[0] = f(0);
+  } else {
+    std::vector<std::thread> th;
+    for(size_t i = 0; i < n; i++) th.push_back(std::thread([&rc, &f, i] { rc[i] = f(i); }));
+    for(size_t i = 0; i < n; i++) th[i].join();
+  }
+  for(size_t i = 0; i < n; i++) gpcCheck(rc[i]);
+}
+}  // namespace
+
+bool CGp::useGrid() const
+{
+  if(gridDecided) return gridDecided > 0;
+  gridDecided = -1;
+  if(isSparseApproximation()) return false;
+  int ndev = 0;
+  gpcCheck(gpc_device_count(&ndev));
+  const char* shape = std::getenv("GPC_GRID");
+  int pr = 0, pc = 0;
+  if(shape && std::sscanf(shape, "%dx%d", &pr, &pc) == 2 && pr >= 1 && pc >= 1) {
+    if(pr * pc == 1) return false;
+  } else {
+    // by itself: only when the factor cannot live on the current GPU (K, N x N doubles, with 15 % headroom)
+    size_t hbm = 0;
+    if(gpc_device_info(0, 0, 0, &hbm, 0) != GPC_OK || ndev < 2) return false;
+    const double need = 8.0 * (double)getNumData() * (double)getNumData();
+    if(need <= 0.85 * (double)hbm) return false;
+    pr = 1;
+    pc = 2;
+    if(ndev >= 4) pr = 2;
+    if(ndev >= 8) pc = 4;
+  }
+  const char* same = std::getenv("GPC_GRID_DEVICES");   // "same": every rank on the current device (tests on a 1-GPU box)
+  const bool one_device = same && std::string(same) == "same";
+  if(!one_device && pr * pc > ndev)
+    throw ndlexceptions::Error("GPC_GRID asks for more ranks than the node has GPUs");
+  const char* nbs = std::getenv("GPC_GRID_NB");
+  const long nb = nbs ? std::atol(nbs) : (getNumData() >= 49152 ? 1024 : 512);
+  grids.assign((size_t)pr * pc, (gpc_grid*)0);
+  std::vector<int> dev((size_t)pr * pc);
+  for(size_t i = 0; i < dev.size(); i++) dev[i] = (int)i;
+  gpcCheck(gpc_grid_create_local(&grids[0], pr, pc, nb, one_device ? (const int*)0 : &dev[0]));
+  gridPr = pr;
+  gridPc = pc;
+  gridDecided = 1;
+  if(getVerbosity() > 1)
+    std::cout << "CGp: factorising on a " << pr << " x " << pc << " grid of GPUs (tile " << nb << ")." << std::endl;
+  return true;
+}
+
+void CGp::gridRelease() const
+{
+  for(size_t i = 0; i < grids.size(); i++)
+    if(grids[i]) (void)gpc_grid_destroy(grids[i]);
+  grids.clear();
+}
+
+// CGp::updateK on the grid: Gram + Cholesky + log|K| + the quadratic forms; with Xstar the test inputs ride through the
+// factorisation as extra rows and the predictive mean / variance are collected as well (one factorisation per call).
+void CGp::gridUpdateK(const CMatrix* Xstar) const
+{
+  updateM();
+  const int64_t N = getNumData(), D = getInputDim(), d = getOutputDim();
+  const int64_t Ns = Xstar ? (int64_t)Xstar->getRows() : 0;
+  gpc_kspec ks;
+  pkern->toKspec(ks);
+  const bool fresh = gridNs != (long)Ns || Ns > 0;     // new data / new test inputs: restage; else only the kernel changed
+  std::vector<double> ld(grids.size(), 0.0), jit(grids.size(), 0.0);
+  std::vector<int> info(grids.size(), 0);
+  quad.assign((size_t)d, 0.0);
+  if(Ns > 0) {
+    gridMu.assign((size_t)(Ns * d), 0.0);
+    gridVar.assign((size_t)Ns, 0.0);
+    gridAlpha.assign((size_t)(N * d), 0.0);
+  }
+  const double* Xh = pX->getVals();
+  const double* Mh = m.getVals();
+  const double* Xsh = Xstar ? Xstar->getVals() : (const double*)0;
+  std::vector<gpc_grid*>& gs = grids;
+  std::vector<double>& q = quad;
+  std::vector<double>&mu = gridMu, &var = gridVar, &al = gridAlpha;
+  onRanks(gs.size(), [&](size_t r) -> int {
+    int rc = fresh ? gpc_grid_set_problem(gs[r], &ks, Xh, N, D, N, Mh, d, N, Xsh, Ns, Ns > 0 ? Ns : 1) : gpc_grid_set_kernel(gs[r], &ks);
+    if(rc != GPC_OK) return rc;
+    rc = gpc_grid_update_k(gs[r], &ld[r], &jit[r], &info[r]);
+    if(rc != GPC_OK || info[r] != 0) return rc;
+    std::vector<double> qq((size_t)d, 0.0);
+    rc = gpc_grid_quadform(gs[r], &qq[0]);
+    if(rc == GPC_OK && r == 0) q = qq;
+    if(rc == GPC_OK && Ns > 0) {
+      std::vector<double> m2((size_t)(Ns * d)), v2((size_t)Ns), a2;
+      if(r == 0) a2.resize((size_t)(N * d));
+      rc = gpc_grid_alpha(gs[r], r == 0 ? &a2[0] : (double*)0, N);
+      if(rc == GPC_OK) rc = gpc_grid_posterior(gs[r], &m2[0], Ns, &v2[0]);
+      if(rc == GPC_OK && r == 0) {
+        mu = m2;
+        var = v2;
+        al = a2;
+      }
+    }
+    return rc;
+  });
+  gridNs = (long)Ns;
+  logDetK = ld[0];
+  lastJitter = jit[0];
+  if(info[0] != 0) throw ndlexceptions::MatrixNonPosDef();
+  if(lastJitter > 1e-2 && getVerbosity() > 2)
+    std::cout << "Warning: jitter of " << lastJitter << " added to K in _updateInvK()." << std::endl;
+  invKupToDate = false;
+  KupToDate = true;
+  AlphaUpToDate = Ns > 0;
+}
+
 void CGp::updateK() const
 {
   if(isSparseApproximation()) {
     updateKdtc();
+    return;
+  }
+  if(useGrid()) {
+    if(needInverse)
+      throw ndlexceptions::NotImplementedError("the gradient needs the explicit inverse, which is not distributed yet: "
+                                               "on a multi-GPU grid the model gives likelihood, Alpha and predictions");
+    if(!KupToDate) gridUpdateK(0);
     return;
   }
   if(KupToDate && (invKupToDate || !needInverse)) return;
@@ -207,6 +339,15 @@ void CGp::updateAlpha() const
     return;
   }
   const int64_t N = getNumData(), d = getOutputDim();
+  if(useGrid()) {
+    // plain fp64: the grid never materialises the reference's single-precision LcholK
+    gridAlpha.assign((size_t)(N * d), 0.0);
+    std::vector<gpc_grid*>& gs = grids;
+    std::vector<double>& al = gridAlpha;
+    onRanks(gs.size(), [&](size_t r) -> int { return gpc_grid_alpha(gs[r], r == 0 ? &al[0] : (double*)0, N); });
+    AlphaUpToDate = true;
+    return;
+  }
   if(!dAlpha) dAlpha = devAlloc((size_t)N * d);
   if(refTransRounding && !LcholRounded) {
     gpcCheck(gpc_ref_trans_rounding_f64(N, dL, N, 0));
@@ -306,6 +447,21 @@ void CGp::posteriorMeanVar(CMatrix& mu, CMatrix& varSigma, const CMatrix& Xin) c
   if(Xin.getCols() != D) throw ndlexceptions::MatrixError("posteriorMeanVar: input dimension");
   if(isSparseApproximation()) {
     posteriorDtc(mu, varSigma, Xin);
+    return;
+  }
+  if(useGrid()) {
+    gridUpdateK(&Xin);
+    for(int64_t i = 0; i < Ns; i++) {
+      if(!(gridVar[(size_t)i] >= 0.0)) throw ndlexceptions::Error("posterior variance is negative");
+      for(int64_t j = 0; j < d; j++) {
+        double muv = gridMu[(size_t)(i + j * Ns)], vs = gridVar[(size_t)i];
+        const double sc = scale.getVal((unsigned int)j), bi = bias.getVal((unsigned int)j);
+        if(sc != 1.0) { muv *= sc; vs *= sc * sc; }
+        if(bi != 0.0) muv += bi;
+        mu.setVal(muv, (unsigned int)i, (unsigned int)j);
+        varSigma.setVal(vs, (unsigned int)i, (unsigned int)j);
+      }
+    }
     return;
   }
   updateAlpha();

@@ -20,6 +20,8 @@
 #include "CNoise.h"
 #include "COptimisable.h"
 
+struct gpc_grid;   // include/gpc_hip.h: one rank of the 2-D block-cyclic multi-GPU factorisation
+
 class CGp : public CProbabilisticOptimisable {
  public:
   enum { FTC, DTC, FITC, PITC, DTCVAR };
@@ -145,6 +147,17 @@ class CGp : public CProbabilisticOptimisable {
   mutable double logDetK;
   mutable double lastJitter;
   mutable bool needInverse;
+  // Multi-GPU (FTC): the N x N matrix spread over a pr x pc grid of GPUs, one host thread per rank inside this process
+  // (gpc_grid_create_local; the C++ driver and RCCL-free peer copies live below the C-ABI).  Chosen by GPC_GRID=PRxPC in
+  // the environment, or by itself when one N x N matrix does not fit the current GPU and the node has more of them.
+  // Likelihood, Alpha and predictions run on the grid; the gradient still needs the explicit inverse on one GPU.
+  bool useGrid() const;
+  void gridUpdateK(const CMatrix* Xstar) const;
+  void gridRelease() const;
+  mutable std::vector<gpc_grid*> grids;
+  mutable int gridPr, gridPc, gridDecided;
+  mutable long gridNs;                   // test inputs carried by the grid's current problem (-1: no problem set)
+  mutable std::vector<double> gridAlpha, gridMu, gridVar;
 };
 
 void writeGpToStream(const CGp& model, std::ostream& out);

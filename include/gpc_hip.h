@@ -200,6 +200,7 @@ int gpc_grid_update_k(gpc_grid* g, double* logdet, double* jitter_added, int* in
 int gpc_grid_fill(gpc_grid* g);                 /* the two halves of update_k, for measurements */
 int gpc_grid_factor(gpc_grid* g, int* info);
 int gpc_grid_loglik(gpc_grid* g, double* ll);                                  /* CGp::logLikelihood */
+int gpc_grid_quadform(gpc_grid* g, double* q);                                /* q[j] = m_j' K^-1 m_j, j < d (CGp.cpp:923-932) */
 int gpc_grid_alpha(gpc_grid* g, double* alpha_host, int64_t lda);              /* CGp::updateAlpha: K^-1 Y, N x d */
 int gpc_grid_posterior(gpc_grid* g, double* mu_host, int64_t ldmu, double* var_host);   /* before output scale / bias */
 int gpc_grid_sync(gpc_grid* g);

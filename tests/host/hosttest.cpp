@@ -167,6 +167,48 @@ static int testGp(int argc, char** argv)
   return 0;
 }
 
+// the model on a multi-GPU grid (GPC_GRID=PRxPC in the environment): what CGp gives there -- likelihood, Alpha through the
+// predictions, log|K| -- plus the refusal of the gradient.  gp_hosttest gpgrid X y Xs kernspec
+static int testGpGrid(int argc, char** argv)
+{
+  if(argc < 6) { std::fprintf(stderr, "usage: gp_hosttest gpgrid X y Xs kernspec\n"); return 2; }
+  CMatrix X, y, Xs;
+  X.fromUnheadedFile(argv[2]);
+  y.fromUnheadedFile(argv[3]);
+  Xs.fromUnheadedFile(argv[4]);
+  CCmpndKern kern(X);
+  buildKern(kern, X, argv[5]);
+  CGaussianNoise noise(&y);
+  noise.setBias(0.0);
+  CMatrix scale(1, y.getCols(), 1.0), bias(1, y.getCols(), 0.0);
+  bias.deepCopy(meanCol(y));
+  CGp model(&kern, &noise, &X, CGp::FTC, (unsigned int)-1, 0);
+  model.setReferenceTransRounding(false);
+  model.setScale(scale);
+  model.setBias(bias);
+  model.updateM();
+  std::printf("ll %.17g\n", model.logLikelihood());
+  std::printf("logdet %.17g\n", model.getLogDetK());
+  CMatrix mu(Xs.getRows(), y.getCols()), var(Xs.getRows(), y.getCols());
+  model.posteriorMeanVar(mu, var, Xs);
+  printMat("mu", mu);
+  printMat("var", var);
+  std::printf("ll_after_predict %.17g\n", model.logLikelihood());
+  CMatrix params(1, model.getOptNumParams());
+  model.getOptParams(params);
+  model.setOptParams(params);
+  std::printf("ll_roundtrip %.17g\n", model.logLikelihood());
+  int refused = 0;
+  try {
+    CMatrix g(1, model.getOptNumParams());
+    model.logLikelihoodGradient(g);
+  } catch(ndlexceptions::NotImplementedError&) {
+    refused = 1;
+  }
+  std::printf("gradient_refused %d\n", refused);
+  return 0;
+}
+
 // sparse approximation DTC: gp_hosttest dtc X y Xs kernspec Xu beta [iters]
 static int testDtc(int argc, char** argv)
 {
@@ -230,6 +272,7 @@ int main(int argc, char** argv)
   try {
     if(argc >= 2 && std::string(argv[1]) == "matrix") return testMatrix();
     if(argc >= 2 && std::string(argv[1]) == "gp") return testGp(argc, argv);
+    if(argc >= 2 && std::string(argv[1]) == "gpgrid") return testGpGrid(argc, argv);
     if(argc >= 2 && std::string(argv[1]) == "dtc") return testDtc(argc, argv);
     std::fprintf(stderr, "usage: gp_hosttest matrix | gp ...\n");
     return 2;

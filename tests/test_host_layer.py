@@ -75,6 +75,29 @@ def _write_txt(path, A):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("shape", ["1x2", "2x2", "2x4"])
+def test_cgp_on_a_multi_gpu_grid(tmp_path, shape):
+    """The C++ CGp with GPC_GRID=PRxPC: the model factors on the 2-D block-cyclic grid (one host thread per rank; here all
+    ranks on the box's one GPU) and must give the numbers the single-GPU model gives (plain fp64 on both sides), and the
+    compiled reference's ll / log|K| (cfg 4's kernel, tests/golden/synth_cfg4_1024.npz)."""
+    from gpc_amd import synth
+    g = dict(np.load(os.path.join(GOLDEN, "synth_cfg4_1024.npz")))
+    X, y = synth.make_xy(1024, 16, 1234)
+    _write_txt(tmp_path / "X.txt", X)
+    _write_txt(tmp_path / "y.txt", y)
+    _write_txt(tmp_path / "Xs.txt", g["Xstar"])
+    args = [str(tmp_path / "X.txt"), str(tmp_path / "y.txt"), str(tmp_path / "Xs.txt"), "rbf:1,1"]
+    one = _parse(_run([os.path.join(HOST, "gp_hosttest"), "gp"] + args + ["exact"]))
+    env = dict(os.environ, GPC_GRID=shape, GPC_GRID_DEVICES="same", GPC_GRID_NB="128")
+    v = _parse(_run([os.path.join(HOST, "gp_hosttest"), "gpgrid"] + args, env=env))
+    assert rel(v["ll"], g["ll"]) < 1e-8 and rel(v["logdet"], g["logdet"]) < 1e-8
+    assert rel(v["ll"], one["ll"]) < 1e-10 and rel(v["logdet"], one["logdet"]) < 1e-10
+    assert rel(v["mu"], one["mu"]) < 1e-8 and rel(v["var"], one["var"]) < 1e-8
+    assert rel(v["ll_after_predict"], one["ll"]) < 1e-10 and rel(v["ll_roundtrip"], one["ll"]) < 1e-10
+    assert v["gradient_refused"][0] == 1
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("name,spec,seed,N,D", [
     ("synth_cfg2_256", "rbf:1,1", 1234, 256, 8),
     ("synth_cfg3_1024", "rbf:0.0625,1;white:%.17g" % np.exp(-2.0), 1234, 1024, 32),
