@@ -81,8 +81,6 @@ SIGNATURES = {
     "gpc_kern_gradx_cross_f64": (c_int, [POINTER(KSpec), DP, I64, I64, DP, I64, I64, I64, DP, I64, DP, I64, VP]),
     "gpc_axpby_f64": (c_int, [I64, I64, c_double, DP, I64, c_double, DP, I64, VP]),
     "gpc_scale_vec_f64": (c_int, [I64, I64, DP, I64, DP, c_int, VP]),
-    "gpc_potrf_panel_f64": (c_int, [I64, I64, DP, I64, I64, DP, VP]),
-    "gpc_syrk_blockcyclic_f64": (c_int, [I64, I64, I64, c_double, DP, I64, c_double, DP, I64, I64, I64, I64, I64, VP]),
     "gpc_set_potrf_blocking": (c_int, [I64, I64]),
     "gpc_set_gemm_variant": (c_int, [c_int]),
     "gpc_set_potrf_lookahead": (c_int, [c_int]),

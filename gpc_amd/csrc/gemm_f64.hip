@@ -28,8 +28,6 @@ namespace gpc {
 
 thread_local int g_gemm_trailing = 0;  // TrailingScope (gpc_common.hpp); per host thread
 thread_local int g_gemm_kstart = 0;    // KStartScope (gpc_common.hpp)
-extern thread_local int g_stair_args_set;
-extern thread_local int64_t g_stair[4];
 int g_gemm_variant = -1;  // -1: read GPC_GEMM_VARIANT on first use; 0 generic only; 1 fast 4-wave; 2 fast 8-wave
 
 namespace {
@@ -60,16 +58,12 @@ struct GemmArgs {
   int atomic_c;          // beta == 1: accumulate into C with no-return fp64 atomics instead of load + add + store
   int tri;               // 0 full, 1 lower (i >= j, C square), 2 upper (i <= j, C square),
                          // 3 lower trapezoid (i >= j, M >= N, full enumeration with skipped tiles)
-                         // 4 block-cyclic staircase (fast NT kernel only): local column c of C is GLOBAL column
-                         //   gcol(c) = (stair_j0 + (c / stair_nb) * stair_pstride) * stair_nb + c % stair_nb,
-                         //   row m of A / C is global row stair_row0 + m, the B operand row for column c is
-                         //   gcol(c) - stair_row0, and only global_row >= global_col is written
                          // 5 2-D block-cyclic staircase (fast NT kernel only; grid.hip): C is the local block of a pr x pc
                          //   grid.  nb-row-tile t of A / C is GLOBAL tile st_I0 + t * st_pr, nb-column-tile u is GLOBAL
                          //   tile st_J0 + u * st_pc; tiles with I < J are skipped, I == J writes its lower triangle.
                          //   The B operand of column tile u starts at B + voff[st_jl0 + u] (leading dimension ldb): the
                          //   column panel is kept tile by tile in the order it arrives from the process column
-  int64_t stair_nb, stair_pstride, stair_j0, stair_row0;
+  int64_t stair_nb;
   int64_t st_I0, st_pr, st_J0, st_pc, st_jl0;
   const int64_t* voff;
   // tri == 5: compact enumeration of the super-tiles that hold at least one valid tile.  Super-column sj holds the
@@ -182,16 +176,6 @@ __device__ __forceinline__ bool map_tile(const GemmArgs& g, int& ti, int& tj)
     }
     sj = lo;
     si = (int)g.st_first[lo] + (int)(L5 - g.st_cum[lo]);
-    di = (int)(w % SUPER);
-    dj = (int)(w / SUPER);
-  } else if(g.tri == 4) {
-    // 1-D block-cyclic staircase: whole super-tiles dealt so that super-tile (si, sj) runs on XCD (si + sj) mod 8
-    const unsigned i = b >> 3, x = b & 7u;
-    const unsigned q = i / (SUPER * SUPER), w = i % (SUPER * SUPER);
-    const unsigned rows8 = ((unsigned)g.super_m + 7u) >> 3;
-    sj = (int)(q / rows8);
-    si = (int)(((x + 8u - ((unsigned)sj & 7u)) & 7u) + 8u * (q % rows8));
-    if(sj >= g.super_n || si >= g.super_m) return false;
     di = (int)(w % SUPER);
     dj = (int)(w / SUPER);
   } else if(g.tri == 0 || g.tri == 3) {
@@ -368,12 +352,6 @@ __global__ void __launch_bounds__(128 * NWN, NWN) gemm_nt_fast_kernel(const Gemm
   const int64_t m0 = (int64_t)ti * BM;
   const int64_t n0 = (int64_t)tj * BN;
 
-  // block-cyclic staircase: global column of this tile's first column; tiles entirely above the diagonal are skipped
-  int64_t gcol0 = 0;
-  if(g.tri == 4) {
-    gcol0 = (g.stair_j0 + (n0 / g.stair_nb) * g.stair_pstride) * g.stair_nb + (n0 % g.stair_nb);
-    if(g.stair_row0 + m0 + BM - 1 < gcol0) return;
-  }
   // 2-D staircase: global tile coordinates of this 128 x 128 tile; roff / coff = its offsets inside the nb x nb tile
   const double* Bop = g.B;
   int roff = 0, coff = 0;
@@ -389,8 +367,8 @@ __global__ void __launch_bounds__(128 * NWN, NWN) gemm_nt_fast_kernel(const Gemm
     Bop = g.B + g.voff[g.st_jl0 + ct] + coff;
   }
   // staging pointers (rows clamped into the matrix; M, N are even and >= 2 on this path)
-  int64_t ra = m0 + 2 * lane, rb = (g.tri == 4 ? gcol0 - g.stair_row0 : (g.tri == 5 ? 0 : n0)) + 2 * lane;
-  const int64_t rbmax = (g.tri == 4 ? g.M : (g.tri == 5 ? BN : g.N)) - 2;
+  int64_t ra = m0 + 2 * lane, rb = (g.tri == 5 ? 0 : n0) + 2 * lane;
+  const int64_t rbmax = (g.tri == 5 ? BN : g.N) - 2;
   if(g.debug_same_rows) {  // ablation: every tile reads operand rows 0..127 (all L2 hits); results are wrong
     ra = 2 * lane;
     rb = 2 * lane;
@@ -481,8 +459,7 @@ __global__ void __launch_bounds__(128 * NWN, NWN) gemm_nt_fast_kernel(const Gemm
       for(int r = 0; r < 4; r++) {
         const int64_t n = n0 + wn * (16 * NT) + tn * 16 + (lane >> 4) + 4 * r;
         bool ok = full_mn || (m < g.M && n < g.N);
-        if(g.tri == 4) ok = ok && (g.stair_row0 + m >= gcol0 + (n - n0));
-        else if(g.tri == 5) ok = ok && (!diag5 || roff + (int)(m - m0) >= coff + (int)(n - n0));
+        if(g.tri == 5) ok = ok && (!diag5 || roff + (int)(m - m0) >= coff + (int)(n - n0));
         else if(diag_tile) ok = ok && (g.tri == 2 ? (m <= n) : (m >= n));
         if(ok) {
           double* p = g.C + m + n * g.ldc;
@@ -604,7 +581,7 @@ static int gemm_ex(bool transa, bool transb, int64_t M, int64_t N, int64_t K, do
   g.super_m = (g.tiles_m + SUPER - 1) / SUPER;
   g.super_n = (g.tiles_n + SUPER - 1) / SUPER;
   g.tri = tri;
-  g.stair_nb = g.stair_pstride = g.stair_j0 = g.stair_row0 = 0;
+  g.stair_nb = 0;
   g.st_I0 = g.st_pr = g.st_J0 = g.st_pc = g.st_jl0 = 0;
   g.voff = nullptr;
   if(tri == 5) {
@@ -615,16 +592,6 @@ static int gemm_ex(bool transa, bool transb, int64_t M, int64_t N, int64_t K, do
     g.st_pc = st2->pc;
     g.st_jl0 = st2->jl0;
     g.voff = st2->voff;
-  }
-  if(tri == 4) {
-    if(!g_stair_args_set) {
-      set_error("staircase gemm must be called through syrk_blockcyclic");
-      return GPC_EINVAL;
-    }
-    g.stair_nb = g_stair[0];
-    g.stair_pstride = g_stair[1];
-    g.stair_j0 = g_stair[2];
-    g.stair_row0 = g_stair[3];
   }
   {
     static int dbg = -1;
@@ -663,9 +630,7 @@ static int gemm_ex(bool transa, bool transb, int64_t M, int64_t N, int64_t K, do
     }
     g.st_cum[g.super_n] = cum;
     slots = (((uint64_t)cum + 7) / 8) * 8 * SUPER * SUPER;
-  } else if(tri == 4)
-    slots = 8ull * (uint64_t)((g.super_m + 7) / 8) * (uint64_t)g.super_n * SUPER * SUPER;
-  else if(tri == 0 || tri == 3)
+  } else if(tri == 0 || tri == 3)
     slots = (uint64_t)g.super_m * g.super_n * SUPER * SUPER;
   else
     slots = 32ull * g.super_m * g.super_m + 4ull * g.super_m;  // valid lower tiles of full 8 x 8 super-tiles
@@ -686,7 +651,7 @@ static int gemm_ex(bool transa, bool transb, int64_t M, int64_t N, int64_t K, do
     g_gemm_variant = e ? atoi(e) : 2;
     if(g_gemm_variant < 0 || g_gemm_variant > 2) g_gemm_variant = 2;
   }
-  if(tri == 4 || tri == 5) return g_gemm_variant == 1 ? launch_fast<2>(g, grid, s) : launch_fast<4>(g, grid, s);
+  if(tri == 5) return g_gemm_variant == 1 ? launch_fast<2>(g, grid, s) : launch_fast<4>(g, grid, s);
   if(g_gemm_variant > 0 && !a_kc && !b_kc && vec && g.K > 0 && (g.K % BK) == 0 && (M % 2) == 0 && (N % 2) == 0) {
     return g_gemm_variant == 2 ? launch_fast<4>(g, grid, s) : launch_fast<2>(g, grid, s);
   }
@@ -700,28 +665,6 @@ static int gemm_ex(bool transa, bool transb, int64_t M, int64_t N, int64_t K, do
   GPC_GEMM_CASE(true, true)
 #undef GPC_GEMM_CASE
   return GPC_EINVAL;
-}
-
-thread_local int g_stair_args_set = 0;
-thread_local int64_t g_stair[4];
-
-int syrk_blockcyclic(int64_t M, int64_t ncols, int64_t K, double alpha, const double* P, int64_t ldp, double beta,
-                     double* C, int64_t ldc, int64_t row0, int64_t j0, int64_t pstride, int64_t nb, hipStream_t s)
-{
-  if(M <= 0 || ncols <= 0) return GPC_OK;
-  if(nb <= 0 || nb % BN != 0 || K % BK != 0 || K <= 0 || (M & 1) || (ldp & 1) ||
-     (reinterpret_cast<uintptr_t>(P) & 15) != 0) {
-    set_error("syrk_blockcyclic: needs nb %% 128 == 0, K %% 16 == 0, even M / ldp and a 16-byte aligned panel");
-    return GPC_EINVAL;
-  }
-  g_stair[0] = nb;
-  g_stair[1] = pstride;
-  g_stair[2] = j0;
-  g_stair[3] = row0;
-  g_stair_args_set = 1;
-  const int rc = gemm(false, true, M, ncols, K, alpha, P, ldp, P, ldp, beta, C, ldc, 4, s);
-  g_stair_args_set = 0;
-  return rc;
 }
 
 }  // namespace gpc

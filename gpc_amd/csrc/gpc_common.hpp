@@ -94,8 +94,6 @@ struct KStartScope {
 // col0: global index of A's first column, added to the `info` a failing pivot reports
 int potrf_lower(int64_t N, double* A, int64_t lda, int* d_info, hipStream_t s, int64_t col0 = 0);
 int potrf_panel(int64_t M, int64_t nb, double* A, int64_t lda, int* d_info, int64_t col0, hipStream_t s);
-int syrk_blockcyclic(int64_t M, int64_t ncols, int64_t K, double alpha, const double* P, int64_t ldp, double beta,
-                     double* C, int64_t ldc, int64_t row0, int64_t j0, int64_t pstride, int64_t nb, hipStream_t s);
 int trsm(char side, char uplo, char trans, char diag, int64_t M, int64_t Nrhs, double alpha, const double* A,
          int64_t lda, double* B, int64_t ldb, hipStream_t s);
 int potri_full(bool lower, int64_t N, double* A, int64_t lda, hipStream_t s);

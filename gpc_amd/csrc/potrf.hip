@@ -636,7 +636,7 @@ int factor_panel(int64_t N, double* A, int64_t lda, int64_t k0, int64_t nbk, int
 }  // namespace
 
 // Factor one tall panel (M x nb, M >= nb): diagonal blocks + substitution solve + in-panel updates.  Used by the
-// block-cyclic multi-GPU driver, whose panel owner factors its panel locally (gpc_potrf_panel_f64).
+// multi-GPU grid when one rank holds the whole panel (grid.hip: a 1 x pc grid).
 int potrf_panel(int64_t M, int64_t nb, double* A, int64_t lda, int* d_info, int64_t col0, hipStream_t s)
 {
   if(M <= 0 || nb <= 0) return GPC_OK;
@@ -761,41 +761,6 @@ extern "C" int gpc_set_potrf_blocking(int64_t nb_outer, int64_t jb_inner)
   }
   gpc::g_nb_outer = nb_outer;   // fixed from now on (adaptive widths only when never set and GPC_NB is absent)
   return GPC_OK;
-}
-
-extern "C" int gpc_potrf_panel_f64(int64_t M, int64_t nb, double* A, int64_t lda, int64_t col0, int* d_info, void* stream)
-{
-  GPC_CHECK(gpc::ensure_device());
-  GPC_REQUIRE(M >= nb && nb >= 0 && lda >= (M > 1 ? M : 1) && d_info != nullptr, "potrf_panel args");
-  return gpc::potrf_panel(M, nb, A, lda, d_info, col0, gpc::as_stream(stream));
-}
-
-extern "C" int gpc_syrk_blockcyclic_f64(int64_t M, int64_t ncols, int64_t K, double alpha, const double* P, int64_t ldp,
-                                        double beta, double* C, int64_t ldc, int64_t row0, int64_t j0, int64_t pstride,
-                                        int64_t nb, void* stream)
-{
-  GPC_CHECK(gpc::ensure_device());
-  GPC_REQUIRE(M >= 0 && ncols >= 0 && K >= 0 && ldp >= (M > 1 ? M : 1) && ldc >= (M > 1 ? M : 1) && pstride >= 1 &&
-                  j0 >= 0 && row0 >= 0,
-              "syrk_blockcyclic args");
-  // algorithmic flops: 2*K per entry on or below the global diagonal
-  double entries = 0.0;
-  for(int64_t c0 = 0; c0 < ncols && nb > 0; c0 += nb) {
-    const int64_t w = (ncols - c0 < nb) ? (ncols - c0) : nb;
-    const int64_t g0 = (j0 + (c0 / nb) * pstride) * nb;
-    const int64_t top = (g0 > row0) ? g0 : row0;           // first global row the panel's first column touches
-    const double rows = (double)(row0 + M - top);
-    if(rows > 0) entries += rows * (double)w - 0.5 * (double)w * (double)(w - 1);
-  }
-  hipStream_t s = gpc::as_stream(stream);
-  gpc::prof_begin(gpc::PROF_SYRK, 2.0 * (double)K * entries, s);
-  int rc;
-  {
-    gpc::TrailingScope role;
-    rc = gpc::syrk_blockcyclic(M, ncols, K, alpha, P, ldp, beta, C, ldc, row0, j0, pstride, nb, s);
-  }
-  gpc::prof_end(gpc::PROF_SYRK, s);
-  return rc;
 }
 
 extern "C" int gpc_set_potrf_lookahead(int on)

@@ -87,8 +87,8 @@ int gpc_gram_cross_f64(const gpc_kspec* ks, const double* X, int64_t N, int64_t 
 /* Diagonal d(i)=k(X_i,X_i): CKern::diagCompute CKern.h:49-55. */
 int gpc_gram_diag_f64(const gpc_kspec* ks, const double* X, int64_t N, int64_t D, int64_t ldx,
                       double* d, void* stream);
-/* An m x n block K(i0+i, j0+j) of the SYMMETRIC Gram of X (white lands where i0+i == j0+j).  Used to generate a
- * 2-D block-cyclic distribution in place; same arithmetic as gpc_gram_sym_f64. */
+/* An m x n block K(i0+i, j0+j) of the SYMMETRIC Gram of X (white lands where i0+i == j0+j): K in pieces, for callers
+ * that cannot hold N x N doubles at once; same arithmetic as gpc_gram_sym_f64. */
 int gpc_gram_block_f64(const gpc_kspec* ks, const double* X, int64_t N, int64_t D, int64_t ldx,
                        int64_t i0, int64_t m, int64_t j0, int64_t n, double* Kblk, int64_t ldk, void* stream);
 
@@ -133,22 +133,6 @@ int gpc_add_diag_f64(int64_t N, double* A, int64_t lda, double c, void* stream);
 int gpc_ref_trans_rounding_f64(int64_t N, double* A, int64_t lda, void* stream);
 /* trace(A) to a host double (jitChol's 1e-6*tr/N). */
 int gpc_trace_f64(int64_t N, const double* A, int64_t lda, double* out, void* stream);
-
-/* ---- building blocks of the 1-D block-cyclic multi-GPU factorisation (gpc_amd/dist.py) ------
- * Panel j (nb columns) of the N x N matrix lives on rank j % P.  A rank stores its panels side by side, every local
- * column holding all N rows. */
-
-/* Factor one tall panel in place (dpotrf of the nb x nb diagonal block + dtrsm of the M-nb rows below it; the
- * owner-local part of a right-looking step).  Fully asynchronous: a non-positive pivot writes the LAPACK info
- * (col0 + its 1-based column) into the DEVICE word *d_info, which the caller zeroes once and reads at the end. */
-int gpc_potrf_panel_f64(int64_t M, int64_t nb, double* A, int64_t lda, int64_t col0, int* d_info, void* stream);
-/* Trailing update of ALL local panels with one received panel, in one launch:
- *   C(m, c) += alpha * sum_k P(m, k) * P(gcol(c) - row0, k)   for global_row = row0 + m >= gcol(c) (beta scales C),
- * where local column c of the M x ncols view C is GLOBAL column gcol(c) = (j0 + (c / nb) * pstride) * nb + c % nb
- * and row m of C and of the panel P (M x K) is global row row0 + m.  nb must be a multiple of 128, K of 16. */
-int gpc_syrk_blockcyclic_f64(int64_t M, int64_t ncols, int64_t K, double alpha, const double* P, int64_t ldp,
-                             double beta, double* C, int64_t ldc, int64_t row0, int64_t j0, int64_t pstride,
-                             int64_t nb, void* stream);
 
 /* ---- 2-D block-cyclic multi-GPU factorisation ---------------------------------------------------
  * CGp::updateK() -- the Gram loop of CGp.cpp:698-712 and jitChol -> logDet of CGp.cpp:877-891 -- and what CGp reads off
