@@ -85,6 +85,7 @@ int workspace(int slot, size_t bytes, void** out)
     }
     w.bytes = want;
     w.dev = dev;
+    if(slot == WS_INFO) GPC_HIP_CHECK(hipMemset(w.p, 0, want));   // holds a sticky flag (gpc_common.hpp)
   }
   *out = w.p;
   return GPC_OK;

@@ -50,6 +50,10 @@ enum WorkspaceSlot {
   WS_NSLOTS = 8
 };
 int workspace(int slot, size_t bytes, void** out);
+// WS_INFO layout (64 bytes, zeroed when allocated): int[0] = LAPACK info of the running factorisation, int[4] = sticky
+// "a dataflow triangular solve timed out" flag (trsm.hip), read and cleared by take_solve_fault
+constexpr int SOLVE_FAULT_WORD = 4;
+int take_solve_fault(hipStream_t s, int* fault);
 int ensure_device();
 
 // ---- internal (device-pointer) building blocks; all asynchronous on `s` ----------------------------------------

@@ -163,7 +163,7 @@ __global__ void __launch_bounds__(256) colnorm2_kernel(const double* __restrict_
 // One thread per row i, loop over j in chunks staged through LDS for x.
 __global__ void __launch_bounds__(256) symv_kernel(const double* __restrict__ A, int64_t lda, int64_t N,
                                                    double alpha, const double* __restrict__ x, double beta,
-                                                   double* __restrict__ y, int64_t jchunk)
+                                                   double* __restrict__ y, int64_t jchunk, double* __restrict__ partial)
 {
   __shared__ double xs[256];
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -180,12 +180,23 @@ __global__ void __launch_bounds__(256) symv_kernel(const double* __restrict__ A,
     __syncthreads();
   }
   if(i < N) {
-    // blockIdx.y == 0 applies beta; other chunks accumulate (y pre-scaled by the host wrapper when gridDim.y > 1)
+    // several column chunks: each leaves its partial sum, symv_combine_kernel adds them in chunk order -- the same bits
+    // on every run (an fp64 atomicAdd into y would let the hardware pick the order)
     if(gridDim.y == 1)
       y[i] = alpha * acc + (beta != 0.0 ? beta * y[i] : 0.0);
     else
-      atomicAdd(&y[i], alpha * acc);
+      partial[(int64_t)blockIdx.y * N + i] = acc;
   }
+}
+
+__global__ void __launch_bounds__(256) symv_combine_kernel(const double* __restrict__ partial, int nchunks, int64_t N,
+                                                           double alpha, double beta, double* __restrict__ y)
+{
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if(i >= N) return;
+  double acc = 0.0;
+  for(int c = 0; c < nchunks; c++) acc += partial[(int64_t)c * N + i];
+  y[i] = alpha * acc + (beta != 0.0 ? beta * y[i] : 0.0);
 }
 
 __global__ void __launch_bounds__(256) scale_vec_kernel(double* __restrict__ y, int64_t N, double beta)
@@ -383,7 +394,17 @@ extern "C" int gpc_coldot_f64(int64_t M, int64_t ncols, const double* A, int64_t
   hipLaunchKernelGGL(coldot_kernel, dim3((unsigned)ncols, (unsigned)nb), dim3(256), 0, s, A, lda, B, ldb, M,
                      static_cast<double*>(ws));
   GPC_HIP_CHECK(hipGetLastError());
-  return reduce_partials_to_host(static_cast<double*>(ws), ncols, nb, out, s);
+  GPC_CHECK(reduce_partials_to_host(static_cast<double*>(ws), ncols, nb, out, s));
+  // the column dots of CGp (m' K^-1 m, CGp.cpp:928-930) follow the dataflow solves: this is where a solve that gave up
+  // (poisoned with NaN) is reported instead of being handed back as GPC_OK
+  int fault = 0;
+  GPC_CHECK(take_solve_fault(s, &fault));
+  if(fault) {
+    set_error("a dataflow triangular solve timed out (device shared or pre-empted?); its result is NaN -- repeat the call, or "
+              "set GPC_TRSV_FLOW=0 for the stepped kernels");
+    return GPC_EHIP;
+  }
+  return GPC_OK;
 }
 
 extern "C" int gpc_colnorm2_f64(int64_t M, int64_t ncols, const double* A, int64_t lda, double* out_dev,
@@ -416,10 +437,14 @@ extern "C" int gpc_symv_f64(int64_t N, double alpha, const double* A, int64_t ld
   int64_t jchunk = (N + gy - 1) / gy;
   jchunk = ((jchunk + 255) / 256) * 256;
   gy = (unsigned)((N + jchunk - 1) / jchunk);
+  double* partial = nullptr;
   if(gy > 1) {
-    hipLaunchKernelGGL(scale_vec_kernel, dim3(gx), dim3(256), 0, s, y, N, beta);
+    void* ws = nullptr;
+    GPC_CHECK(workspace(WS_REDUCE, sizeof(double) * (size_t)gy * (size_t)N, &ws));
+    partial = static_cast<double*>(ws);
   }
-  hipLaunchKernelGGL(symv_kernel, dim3(gx, gy), dim3(256), 0, s, A, lda, N, alpha, x, beta, y, jchunk);
+  hipLaunchKernelGGL(symv_kernel, dim3(gx, gy), dim3(256), 0, s, A, lda, N, alpha, x, beta, y, jchunk, partial);
+  if(gy > 1) hipLaunchKernelGGL(symv_combine_kernel, dim3(gx), dim3(256), 0, s, partial, (int)gy, N, alpha, beta, y);
   GPC_HIP_CHECK(hipGetLastError());
   return GPC_OK;
 }

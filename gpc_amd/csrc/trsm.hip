@@ -380,7 +380,7 @@ __global__ void __launch_bounds__(256) flow_init_kernel(unsigned long long* __re
   if(i < 2) ctl[i] = 0;
 }
 
-__device__ __forceinline__ double flow_poll(const double* p, int* ctl)
+__device__ __forceinline__ double flow_poll(const double* p, int* ctl, int* sticky)
 {
   const unsigned long long* q = reinterpret_cast<const unsigned long long*>(p);
   for(int it = 0; it < (1 << 20); it++) {
@@ -391,6 +391,7 @@ __device__ __forceinline__ double flow_poll(const double* p, int* ctl)
     __builtin_amdgcn_s_sleep(1);
   }
   atomicExch(&ctl[1], 1);
+  atomicExch(sticky, 1);   // survives the next solve's flow_init: the host reads and clears it at its next synchronising call
   return __longlong_as_double(0x7FF8000000000000ll);
 }
 
@@ -403,7 +404,7 @@ __device__ __forceinline__ void flow_publish(double* p, double x)
 template <bool FWD>
 __global__ void __launch_bounds__(256) trsv_flow_kernel(const double* __restrict__ L, int64_t ldl, double* __restrict__ B,
                                                         int64_t ldb, int64_t M, int d, int unit, double* __restrict__ Xf,
-                                                        int* __restrict__ ctl)
+                                                        int* __restrict__ ctl, int* __restrict__ sticky)
 {
   __shared__ double P[64 * 65];
   __shared__ double Dinv[64];
@@ -459,7 +460,7 @@ __global__ void __launch_bounds__(256) trsv_flow_kernel(const double* __restrict
 #pragma unroll
         for(int u = 0; u < 16; u++) an[u] = Lrow[((j + 1) * 64 + u) * ldl];
       }
-      if(w < d) Xs[j & 1][w][lane] = flow_poll(&Xf[j * 64 + lane + (int64_t)w * M], ctl);
+      if(w < d) Xs[j & 1][w][lane] = flow_poll(&Xf[j * 64 + lane + (int64_t)w * M], ctl, sticky);
       __syncthreads();
 #pragma unroll
       for(int u = 0; u < 16; u++)
@@ -505,7 +506,7 @@ __global__ void __launch_bounds__(256) trsv_flow_kernel(const double* __restrict
       double xj[FLOW_MAXRHS];
 #pragma unroll
       for(int v = 0; v < FLOW_MAXRHS; v++)
-        xj[v] = (v < d && j * 64 + lane < M) ? flow_poll(&Xf[j * 64 + lane + (int64_t)v * M], ctl) : 0.0;
+        xj[v] = (v < d && j * 64 + lane < M) ? flow_poll(&Xf[j * 64 + lane + (int64_t)v * M], ctl, sticky) : 0.0;
 #pragma unroll
       for(int v = 0; v < FLOW_MAXRHS; v++)
         if(v < d) {
@@ -558,6 +559,24 @@ __global__ void __launch_bounds__(256) trsv_flow_kernel(const double* __restrict
 
 static int g_trsv_flow = -1;
 
+}  // namespace
+
+// Has a dataflow solve on this thread's streams given up since the last call (a poll unanswered after ~1 s: the device was
+// shared or pre-empted)?  Its result is NaN-poisoned; callers that are about to hand a host scalar back report it.
+int take_solve_fault(hipStream_t s, int* fault)
+{
+  void* wi = nullptr;
+  GPC_CHECK(workspace(WS_INFO, 64, &wi));
+  int* sticky = static_cast<int*>(wi) + SOLVE_FAULT_WORD;
+  *fault = 0;
+  GPC_HIP_CHECK(hipMemcpyAsync(fault, sticky, sizeof(int), hipMemcpyDeviceToHost, s));
+  GPC_HIP_CHECK(hipStreamSynchronize(s));
+  if(*fault) GPC_HIP_CHECK(hipMemsetAsync(sticky, 0, sizeof(int), s));
+  return GPC_OK;
+}
+
+namespace {
+
 int trsv_lower(bool tr, bool unit, int64_t M, int64_t d, const double* L, int64_t ldl, double* B, int64_t ldb,
                hipStream_t s)
 {
@@ -572,14 +591,17 @@ int trsv_lower(bool tr, bool unit, int64_t M, int64_t d, const double* L, int64_
   if(g_trsv_flow && d <= FLOW_MAXRHS && nblk > 1) {
     const int64_t n = M * d;
     int* ctl = reinterpret_cast<int*>(Xout + n);
+    void* wi = nullptr;
+    GPC_CHECK(workspace(WS_INFO, 64, &wi));
+    int* sticky = static_cast<int*>(wi) + SOLVE_FAULT_WORD;
     hipLaunchKernelGGL(flow_init_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s,
                        reinterpret_cast<unsigned long long*>(Xout), n, ctl);
     if(!tr)
       hipLaunchKernelGGL(trsv_flow_kernel<true>, dim3((unsigned)nblk), dim3(256), 0, s, L, ldl, B, ldb, M, (int)d, unit ? 1 : 0,
-                         Xout, ctl);
+                         Xout, ctl, sticky);
     else
       hipLaunchKernelGGL(trsv_flow_kernel<false>, dim3((unsigned)nblk), dim3(256), 0, s, L, ldl, B, ldb, M, (int)d, unit ? 1 : 0,
-                         Xout, ctl);
+                         Xout, ctl, sticky);
     GPC_HIP_CHECK(hipGetLastError());
     return GPC_OK;
   }

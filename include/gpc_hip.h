@@ -12,6 +12,12 @@
  *   - `stream` is a hipStream_t passed as void* (NULL = the default stream).  Calls that return a host scalar
  *     (info, logdet, dot products, gradients) synchronise that stream before returning; all others are asynchronous.
  * There is no CPU fallback behind any of these symbols: without a gfx950 device they return GPC_ENODEV.
+ *
+ * Threads and streams.  The library's mutable state -- scratch buffers, the look-ahead stream of gpc_potrf_f64, the text
+ * of gpc_last_error -- is kept PER HOST THREAD: different threads may drive different models (or the ranks of a
+ * gpc_grid_create_local grid) concurrently.  Within one thread, calls share that thread's scratch: issue them on ONE
+ * stream at a time (finish, or gpc_stream_sync, before switching streams).  The tuning setters (gpc_set_*) and the
+ * gpc_profile_* hooks are process-wide; set them before the threads start.
  */
 #ifndef GPC_HIP_H
 #define GPC_HIP_H
