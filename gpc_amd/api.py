@@ -288,6 +288,56 @@ def gp_posterior(ks, X, L, Alpha, Xs, want_var=True):
     return mu, var
 
 
+# ---- GP-LVM passes (gpc_amd/gplvm.py) --------------------------------------------------------------------------------
+
+def covgrad_multi(invK, A, out=None):
+    """G = -0.5 * (d * invK - A A'), A = invK m (N x d)."""
+    N, d = A.shape
+    cg = out if out is not None else empty(N, N, invK.device)
+    check(lib().gpc_covgrad_multi_f64(N, d, ptr(invK), ld(invK), ptr(A), ld(A), ptr(cg), ld(cg), stream()))
+    return cg
+
+
+def kern_gradx(ks, X, covGrad, out=None):
+    """dL/dX contribution of the kernel: gX(i,q) = sum_n covGrad(n,i) dk(x_i,x_n)/dx_iq (CGplvm.cpp:573-604)."""
+    N, D = X.shape
+    gX = out if out is not None else empty(N, D, X.device)
+    check(lib().gpc_kern_gradx_f64(byref(ks), ptr(X), N, D, ld(X), ptr(covGrad), ld(covGrad), ptr(gX), ld(gX), stream()))
+    return gX
+
+
+# ---- cross-Gram gradient passes (sparse approximations) ----------------------------------------------------------------
+
+def kern_grad_cross(ks, X, X2, covGrad):
+    """Natural-parameter gradient of a cross Gram: sum_{i,n} covGrad(i,n) dk(x_i, x2_n)/dtheta (covGrad is N x N2)."""
+    N, D = X.shape
+    g = (c_double * max(n_params(ks), 1))()
+    check(lib().gpc_kern_grad_cross_f64(byref(ks), ptr(X), N, ld(X), ptr(X2), X2.shape[0], ld(X2), D, ptr(covGrad),
+                                        ld(covGrad), g, stream()))
+    return np.array(g[:n_params(ks)])
+
+
+def kern_gradx_cross(ks, X, X2, covGrad, out=None):
+    """gX(i,q) = sum_n covGrad(i,n) dk(x_i, x2_n)/dx_iq (N x D)."""
+    N, D = X.shape
+    gX = out if out is not None else empty(N, D, X.device)
+    check(lib().gpc_kern_gradx_cross_f64(byref(ks), ptr(X), N, ld(X), ptr(X2), X2.shape[0], ld(X2), D, ptr(covGrad),
+                                         ld(covGrad), ptr(gX), ld(gX), stream()))
+    return gX
+
+
+def axpby_(alpha, X, beta, Y):
+    """Y := alpha X + beta Y (elementwise)."""
+    check(lib().gpc_axpby_f64(Y.shape[0], Y.shape[1], alpha, ptr(X), ld(X), beta, ptr(Y), ld(Y), stream()))
+    return Y
+
+
+def scale_vec_(A, v, by_rows=False):
+    """A(i,j) *= v[i] (by_rows) or v[j]: CMatrix::scaleRow / scaleCol against a device vector (CGp.cpp:812-820)."""
+    check(lib().gpc_scale_vec_f64(A.shape[0], A.shape[1], ptr(A), ld(A), ptr(v), 1 if by_rows else 0, stream()))
+    return A
+
+
 # ---- measurement hooks (include/gpc_hip.h: gpc_profile_*) ----------------------------------------------------------
 
 def profile_enable(on):
