@@ -458,7 +458,7 @@ __global__ void __launch_bounds__(256) gram_diag_kernel(const KSpecDev ks, const
 //     like the direct store (writing it straight from the accumulator layout -- 32-byte runs -- was slower than not
 //     exploiting symmetry at all).
 constexpr int TS = 17;   // row stride of the mirror staging patch (doubles)
-template <int NRBF, int NK>
+template <int NRBF, int NK, bool SPLIT = false>
 __global__ void __launch_bounds__(256, 2) gram_sym_kernel(const KSpecDev ks, const GramArgs g, int jt_per_block)
 {
   __shared__ double Xj[2][MDC * SJ];
@@ -532,27 +532,38 @@ __global__ void __launch_bounds__(256, 2) gram_sym_kernel(const KSpecDev ks, con
     __syncthreads();   // tile jt is visible; every wave is past its reads of the other buffer (tile jt-1)
     if(jt + 1 < jt1) prefetch(jt + 1);
 
+    // SPLIT: one 16-column half of the wave's patch at a time (its products, then its epilogue), so that only 4
+    // accumulator tiles are live while the exponentials run: the whole 64 x 32 patch at once leaves the D = 32 instance
+    // short of registers (256 VGPRs + scratch)
     double4_t acc[4][2];
+    auto products = [&](int tn_lo, int tn_hi) {
 #pragma unroll
-    for(int a = 0; a < 4; a++)
+      for(int a = 0; a < 4; a++)
 #pragma unroll
-      for(int b = 0; b < 2; b++) acc[a][b] = (double4_t){0.0, 0.0, 0.0, 0.0};
+        for(int b = 0; b < 2; b++)
+          if(b >= tn_lo && b < tn_hi) acc[a][b] = (double4_t){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-    for(int kk = 0; kk < NK; kk++) {
-      double b[2];
-      const int kr = kk * 4 + (lane >> 4);
+      for(int kk = 0; kk < NK; kk++) {
+        const int kr = kk * 4 + (lane >> 4);
 #pragma unroll
-      for(int s2 = 0; s2 < 2; s2++) b[s2] = Xjb[kr * SJ + wn * 32 + s2 * 16 + (lane & 15)];
+        for(int tn = 0; tn < 2; tn++) {
+          if(tn < tn_lo || tn >= tn_hi) continue;
+          const double b = Xjb[kr * SJ + wn * 32 + tn * 16 + (lane & 15)];
 #pragma unroll
-      for(int tn = 0; tn < 2; tn++)
-#pragma unroll
-        for(int tm = 0; tm < 4; tm++)
-          acc[tm][tn] = __builtin_amdgcn_mfma_f64_16x16x4f64(b[tn], af[kk][tm], acc[tm][tn], 0, 0, 0);
-    }
+          for(int tm = 0; tm < 4; tm++)
+            acc[tm][tn] = __builtin_amdgcn_mfma_f64_16x16x4f64(b, af[kk][tm], acc[tm][tn], 0, 0, 0);
+        }
+      }
+    };
+    if(!SPLIT) products(0, 2);
     const bool full = (i0 + MI <= g.N) && (j0 + MJ <= g.N);
     const bool mirror = (j0 + MJ <= i0);   // strictly left of the diagonal block (workgroup-uniform)
 #pragma unroll
     for(int tn = 0; tn < 2; tn++) {
+      if(SPLIT) {
+        __builtin_amdgcn_sched_barrier(0);
+        products(tn, tn + 1);
+      }
 #pragma unroll
       for(int r = 0; r < 4; r++) {
         __builtin_amdgcn_sched_barrier(0);   // keep the unrolled (tn, r) bodies apart: interleaved they spill
@@ -626,7 +637,11 @@ int launch_gram(const KSpecDev& ks, const GramArgs& g, hipStream_t s)
       const dim3 grid((unsigned)tiles_i, (unsigned)nsplit), block(256);
       if(g.mirror && (ks.n_rbf == 1 || ks.n_rbf == 2)) {
         const int nkk = (int)((g.D + 3) / 4);
-#define GPC_SYM_LAUNCH(R, K) hipLaunchKernelGGL((gram_sym_kernel<R, K>), grid, block, 0, s, ks, g, (int)per)
+#define GPC_SYM_LAUNCH(R, K)                                                                                         \
+  do {                                                                                                             \
+    if(K >= 8 && g.debug != 8) hipLaunchKernelGGL((gram_sym_kernel<R, K, true>), grid, block, 0, s, ks, g, (int)per); \
+    else hipLaunchKernelGGL((gram_sym_kernel<R, K, false>), grid, block, 0, s, ks, g, (int)per);                     \
+  } while(0)
         if(ks.n_rbf == 1) {
           if(nkk <= 1) GPC_SYM_LAUNCH(1, 1);
           else if(nkk <= 2) GPC_SYM_LAUNCH(1, 2);
