@@ -69,6 +69,7 @@ SIGNATURES = {
     "gpc_symv_f64": (c_int, [I64, c_double, DP, I64, DP, c_double, DP, VP]),
     "gpc_covgrad_f64": (c_int, [I64, DP, I64, DP, DP, I64, VP]),
     "gpc_kern_grad_f64": (c_int, [POINTER(KSpec), DP, I64, I64, I64, DP, I64, POINTER(c_double), VP]),
+    "gpc_kern_grad_fused_f64": (c_int, [POINTER(KSpec), DP, I64, I64, I64, DP, I64, DP, I64, I64, POINTER(c_double), VP]),
     "gpc_gp_update_k_f64": (c_int, [POINTER(KSpec), DP, I64, I64, I64, DP, I64, POINTER(c_double),
                                     POINTER(c_double), POINTER(c_int), VP]),
     "gpc_gp_alpha_f64": (c_int, [I64, I64, DP, I64, DP, I64, DP, I64, VP]),

@@ -248,6 +248,19 @@ def kern_grad(ks, X, covGrad):
     return np.array(g[:n_params(ks)])
 
 
+def kern_grad_fused(ks, X, invK, A):
+    """Kernel-parameter gradient straight from invK and A = invK m (no covGrad matrix); None when the kernel / sizes are
+    outside the fused pass (GPC_EUNSUPPORTED)."""
+    N, D = X.shape
+    g = (c_double * n_params(ks))()
+    rc = lib().gpc_kern_grad_fused_f64(byref(ks), ptr(X), N, D, ld(X), ptr(invK), ld(invK), ptr(A), ld(A), A.shape[1], g,
+                                       stream())
+    if rc == _lib.GPC_EUNSUPPORTED:
+        return None
+    check(rc)
+    return np.array(list(g))
+
+
 # ---- fused CGp (FTC) drivers ----------------------------------------------------------------------------------------
 
 def gp_update_k(ks, X, K=None):

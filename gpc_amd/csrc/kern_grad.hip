@@ -31,6 +31,12 @@ struct GradArgs {
   const double* cg;
   int64_t ldx, ldc, N, D;
   int64_t tiles_i, tiles_j;
+  // fused covGrad (kern_grad_sym_kernel only): cg points at invK and the kernel forms
+  //   covGrad(i,j) = -0.5 * (nd * invK(i,j) - sum_o A(i,o) A(j,o))      (CGp::updateCovGradient, CGp.cpp:666-679, summed
+  // over the nd outputs) on the fly, so the N x N covGrad is never written or read
+  const double* A;
+  int64_t lda;
+  int nd;
 };
 
 __device__ __forceinline__ double block_sum(double v, double* sh)
@@ -181,7 +187,7 @@ __global__ void __launch_bounds__(256) kern_grad_kernel(const KSpecDev ks, const
 constexpr int GMI = 128, GMJ = 64, GSJ = 80, GMDC = 32, GSI = 144;
 typedef double gdouble4 __attribute__((ext_vector_type(4)));
 
-template <int NRBF, int NK>
+template <int NRBF, int NK, int ND = 0>
 __global__ void __launch_bounds__(256, 2) kern_grad_sym_kernel(const KSpecDev ks, const GradArgs g, int jt_per_block,
                                                                double* __restrict__ partial)
 {
@@ -231,11 +237,14 @@ __global__ void __launch_bounds__(256, 2) kern_grad_sym_kernel(const KSpecDev ks
       }
   }
   double ni[4];
+  double ai[ND > 0 ? ND : 1][4];   // fused covGrad: A(i, o) of this lane's four rows
 #pragma unroll
   for(int tm = 0; tm < 4; tm++) {
     int64_t gi = i0 + wm * 64 + tm * 16 + (lane & 15);
     if(gi > g.N - 1) gi = g.N - 1;
     ni[tm] = g.n1[gi];
+#pragma unroll
+    for(int o = 0; o < ND; o++) ai[o][tm] = g.A[gi + (int64_t)o * g.lda];
   }
 
   const int ws = __builtin_amdgcn_readfirstlane(w);
@@ -282,11 +291,20 @@ __global__ void __launch_bounds__(256, 2) kern_grad_sym_kernel(const KSpecDev ks
       for(int r = 0; r < 4; r++) {
         const int64_t gj = j0 + wn * 32 + tn * 16 + (lane >> 4) + 4 * r;
         const int64_t gjc = (gj < g.N) ? gj : (g.N - 1);
+        double aj[ND > 0 ? ND : 1];
+#pragma unroll
+        for(int o = 0; o < ND; o++) aj[o] = g.A[gjc + (int64_t)o * g.lda];
 #pragma unroll
         for(int tm = 0; tm < 4; tm++) {
           const int64_t gi = i0 + wm * 64 + tm * 16 + (lane & 15);
           const int64_t gic = (gi < g.N) ? gi : (g.N - 1);
-          const double v = g.cg[gic + gjc * g.ldc];
+          double v = g.cg[gic + gjc * g.ldc];
+          if(ND > 0) {   // covGrad from invK: same operations as covgrad_kernel / covgrad_multi_kernel, element by element
+            double aa = 0.0;
+#pragma unroll
+            for(int o = 0; o < ND; o++) aa = fma(ai[o][tm], aj[o], aa);
+            v = -0.5 * ((double)ND * v - aa);
+          }
           c[tn][r][tm] = (full || (gi < g.N && gj < g.N)) ? v : 0.0;
         }
       }
@@ -361,19 +379,27 @@ __global__ void __launch_bounds__(256, 2) kern_grad_sym_kernel(const KSpecDev ks
   }
 }
 
+template <int NRBF, int ND>
+int launch_grad_sym_nd(const KSpecDev& ks, const GradArgs& g, int per, dim3 grid, double* partial, hipStream_t s)
+{
+  if(g.D <= 4)
+    hipLaunchKernelGGL((kern_grad_sym_kernel<NRBF, 1, ND>), grid, dim3(256), 0, s, ks, g, per, partial);
+  else if(g.D <= 8)
+    hipLaunchKernelGGL((kern_grad_sym_kernel<NRBF, 2, ND>), grid, dim3(256), 0, s, ks, g, per, partial);
+  else if(g.D <= 16)
+    hipLaunchKernelGGL((kern_grad_sym_kernel<NRBF, 4, ND>), grid, dim3(256), 0, s, ks, g, per, partial);
+  else
+    hipLaunchKernelGGL((kern_grad_sym_kernel<NRBF, 8, ND>), grid, dim3(256), 0, s, ks, g, per, partial);
+  GPC_HIP_CHECK(hipGetLastError());
+  return GPC_OK;
+}
+
 template <int NRBF>
 int launch_grad_sym(const KSpecDev& ks, const GradArgs& g, int per, dim3 grid, double* partial, hipStream_t s)
 {
-  if(g.D <= 4)
-    hipLaunchKernelGGL((kern_grad_sym_kernel<NRBF, 1>), grid, dim3(256), 0, s, ks, g, per, partial);
-  else if(g.D <= 8)
-    hipLaunchKernelGGL((kern_grad_sym_kernel<NRBF, 2>), grid, dim3(256), 0, s, ks, g, per, partial);
-  else if(g.D <= 16)
-    hipLaunchKernelGGL((kern_grad_sym_kernel<NRBF, 4>), grid, dim3(256), 0, s, ks, g, per, partial);
-  else
-    hipLaunchKernelGGL((kern_grad_sym_kernel<NRBF, 8>), grid, dim3(256), 0, s, ks, g, per, partial);
-  GPC_HIP_CHECK(hipGetLastError());
-  return GPC_OK;
+  if(g.nd == 0) return launch_grad_sym_nd<NRBF, 0>(ks, g, per, grid, partial, s);
+  if(g.nd == 1) return launch_grad_sym_nd<NRBF, 1>(ks, g, per, grid, partial, s);
+  return launch_grad_sym_nd<NRBF, 2>(ks, g, per, grid, partial, s);
 }
 
 // per-dimension ARD sums: S_k = sum_{i != j} cg(i,j) k~(i,j) (x_ik - x_jk)^2 for k in [dim0, dim0 + 32)
@@ -487,12 +513,37 @@ int fetch_partials(const double* d_p, int64_t nblk, int np, double* sums, hipStr
 
 using namespace gpc;
 
+static int kern_grad_impl(const gpc_kspec* ksp, const double* X, int64_t N, int64_t D, int64_t ldx, const double* covGrad,
+                          int64_t ldc, const double* A, int64_t lda, int nd, double* gout, hipStream_t s, bool* took_fused);
+
 extern "C" int gpc_kern_grad_f64(const gpc_kspec* ksp, const double* X, int64_t N, int64_t D, int64_t ldx,
                                  const double* covGrad, int64_t ldc, double* gout, void* stream)
 {
   GPC_CHECK(ensure_device());
   GPC_REQUIRE(ksp && gout && N >= 0 && D >= 0 && ldx >= (N > 1 ? N : 1) && ldc >= (N > 1 ? N : 1), "kern_grad args");
-  hipStream_t s = as_stream(stream);
+  return kern_grad_impl(ksp, X, N, D, ldx, covGrad, ldc, nullptr, 0, 0, gout, as_stream(stream), nullptr);
+}
+
+// CGp::updateG without the covGrad matrix (CGp.cpp:666-679 + 1096-1117 in one pass): the kernel reads invK and the
+// N x d matrix A = invK * m and forms covGrad(i,j) = -0.5 (d invK(i,j) - sum_o A(i,o) A(j,o)) in registers.  Taken when the
+// kernel has no rbfard term, D <= 32 and d <= 2; otherwise GPC_EUNSUPPORTED (the caller materialises covGrad as before).
+extern "C" int gpc_kern_grad_fused_f64(const gpc_kspec* ksp, const double* X, int64_t N, int64_t D, int64_t ldx,
+                                       const double* invK, int64_t ldi, const double* A, int64_t lda, int64_t d, double* gout,
+                                       void* stream)
+{
+  GPC_CHECK(ensure_device());
+  GPC_REQUIRE(ksp && gout && invK && A && N >= 0 && D >= 0 && d >= 1 && ldx >= (N > 1 ? N : 1) && ldi >= (N > 1 ? N : 1) &&
+                  lda >= (N > 1 ? N : 1),
+              "kern_grad_fused args");
+  if(d > 2) return GPC_EUNSUPPORTED;
+  bool took = false;
+  GPC_CHECK(kern_grad_impl(ksp, X, N, D, ldx, invK, ldi, A, lda, (int)d, gout, as_stream(stream), &took));
+  return took ? GPC_OK : GPC_EUNSUPPORTED;
+}
+
+static int kern_grad_impl(const gpc_kspec* ksp, const double* X, int64_t N, int64_t D, int64_t ldx, const double* covGrad,
+                          int64_t ldc, const double* A, int64_t lda, int nd, double* gout, hipStream_t s, bool* took_fused)
+{
   KSpecDev ks;
   GPC_CHECK(collapse_kspec(ksp, D, &ks));
   const int nparams = ksp->offs[ksp->n_terms];
@@ -508,6 +559,9 @@ extern "C" int gpc_kern_grad_f64(const gpc_kspec* ksp, const double* X, int64_t 
   g.D = D;
   g.tiles_i = (N + TI - 1) / TI;
   g.tiles_j = (N + TJ - 1) / TJ;
+  g.A = A;
+  g.lda = lda;
+  g.nd = nd;
   const int64_t total = g.tiles_i * g.tiles_j;
   const int64_t nblk = total < 2048 ? total : 2048;
 
@@ -542,6 +596,7 @@ extern "C" int gpc_kern_grad_f64(const gpc_kspec* ksp, const double* X, int64_t 
     else GPC_CHECK(launch_grad_sym<2>(ks, g, (int)per, grid, partial, s));
     double S2[NP_MAIN];
     GPC_CHECK(fetch_partials(partial, nwg, NP_MAIN, S2, s));
+    if(took_fused) *took_fused = true;
     int ir = 0;
     for(int t = 0; t < ksp->n_terms; t++) {
       double* gt = gout + ksp->offs[t];
@@ -560,6 +615,7 @@ extern "C" int gpc_kern_grad_f64(const gpc_kspec* ksp, const double* X, int64_t 
     }
     return GPC_OK;
   }
+  if(nd > 0) return GPC_OK;   // fused request outside the symmetric kernel's domain: nothing launched, *took_fused stays false
   if(dot && ard)
     hipLaunchKernelGGL((kern_grad_kernel<true, true>), dim3((unsigned)nblk), dim3(256), 0, s, ks, g, partial);
   else if(dot)

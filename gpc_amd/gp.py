@@ -154,12 +154,16 @@ class CGp:
         """Returns (g wrt transformed kernel parameters, logLikelihood) like CGp::logLikelihoodGradient."""
         self.updateK(need_inverse=True)
         ks = self.kspec()
-        g = np.zeros(self.getOptNumParams())
-        cg = api.empty(self.N, self.N, self.device)
-        for j in range(self.d):
-            a = self.invKm[:, j:j + 1]
-            api.covgrad(self.invK, a, out=cg)          # CGp::updateCovGradient, CGp.cpp:666-679
-            g += api.kern_grad(ks, self.X, cg)         # CKern::getGradParams
+        # one pass over half of invK, covGrad = -0.5 (d invK - invKm invKm') formed in registers (no N x N covGrad buffer)
+        g = api.kern_grad_fused(ks, self.X, self.invK, self.invKm) if self.d <= 2 else None
+        if g is None:
+            # rbfard terms, D > 32 or d > 2: covGrad is materialised, one output at a time
+            g = np.zeros(self.getOptNumParams())
+            cg = api.empty(self.N, self.N, self.device)
+            for j in range(self.d):
+                a = self.invKm[:, j:j + 1]
+                api.covgrad(self.invK, a, out=cg)          # CGp::updateCovGradient, CGp.cpp:666-679
+                g += api.kern_grad(ks, self.X, cg)         # CKern::getGradParams
         # CKern::getGradTransParams (CKern.cpp:50-63): chain rule through the transforms
         g *= np.array([_gradfact(k, x) for k, x in zip(self.kinds, self._flat())])
         return g, self.logLikelihood()

@@ -391,14 +391,23 @@ double CGp::logLikelihoodGradient(CMatrix& g) const
   const int64_t N = getNumData(), D = getInputDim();
   const unsigned int np = pkern->getNumParams();
   if(g.getRows() != 1 || g.getCols() != np) throw ndlexceptions::MatrixError("logLikelihoodGradient: g must be 1 x nParams");
-  if(!dCovGrad) dCovGrad = devAlloc((size_t)N * N);
   gpc_kspec ks;
   pkern->toKspec(ks);
-  std::vector<double> acc(np, 0.0), tmp(np > 0 ? np : 1, 0.0);
-  for(unsigned int j = 0; j < getOutputDim(); j++) {
-    gpcCheck(gpc_covgrad_f64(N, dInvK, N, dInvKm + (size_t)j * N, dCovGrad, N, 0));   // updateCovGradient, CGp.cpp:666-679
-    gpcCheck(gpc_kern_grad_f64(&ks, dX, N, D, N, dCovGrad, N, &tmp[0], 0));
-    for(unsigned int i = 0; i < np; i++) acc[i] += tmp[i];
+  std::vector<double> acc(np > 0 ? np : 1, 0.0), tmp(np > 0 ? np : 1, 0.0);
+  // One pass over half of invK that forms covGrad = -0.5 (d invK - invKm invKm') in registers: no N x N covGrad buffer, no
+  // pass to write it and read it back (the gradient is linear in covGrad, so the outputs are summed inside the pass).
+  const int fused = gpc_kern_grad_fused_f64(&ks, dX, N, D, N, dInvK, N, dInvKm, N, (int64_t)getOutputDim(), &acc[0], 0);
+  if(fused == GPC_EUNSUPPORTED) {
+    // kernels with an rbfard term, D > 32 or more than two outputs: covGrad is materialised, one output at a time
+    if(!dCovGrad) dCovGrad = devAlloc((size_t)N * N);
+    std::fill(acc.begin(), acc.end(), 0.0);
+    for(unsigned int j = 0; j < getOutputDim(); j++) {
+      gpcCheck(gpc_covgrad_f64(N, dInvK, N, dInvKm + (size_t)j * N, dCovGrad, N, 0));   // updateCovGradient, CGp.cpp:666-679
+      gpcCheck(gpc_kern_grad_f64(&ks, dX, N, D, N, dCovGrad, N, &tmp[0], 0));
+      for(unsigned int i = 0; i < np; i++) acc[i] += tmp[i];
+    }
+  } else {
+    gpcCheck(fused);
   }
   // chain rule into the optimiser space (CKern::getGradTransParams, CKern.cpp:50-63); linear in g, so once at the end
   for(unsigned int t = 0; t < pkern->getNumTransforms(); t++) {

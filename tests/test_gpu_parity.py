@@ -322,6 +322,29 @@ def test_kern_grad_vs_numpy(api, N, D):
     assert np.array_equal(got, again)                                            # fixed-order reduction
 
 
+@pytest.mark.parametrize("N,D,d", [(63, 3, 1), (300, 5, 2), (700, 16, 1), (900, 32, 2), (517, 8, 1)])
+def test_kern_grad_fused_covgrad(api, N, D, d):
+    """gpc_kern_grad_fused_f64 (covGrad = -0.5 (d invK - A A') formed inside the pass, CGp.cpp:666-679) against the two-step
+    route it replaces (gpc_covgrad_multi_f64 + gpc_kern_grad_f64) and the refusals outside its domain."""
+    rng = np.random.RandomState(N * d + D)
+    X = rng.randn(N, D) / np.sqrt(D)
+    B = rng.randn(N, N)
+    invK = B @ B.T / N + np.eye(N)
+    A = rng.randn(N, d)
+    terms = [("rbf", [1.3, 0.7]), ("bias", [0.3]), ("white", [0.05])]
+    ks = api.kspec(terms)
+    Xd, Id, Ad = api.from_host(X), api.from_host(invK), api.from_host(A)
+    got = api.kern_grad_fused(ks, Xd, Id, Ad)
+    assert got is not None
+    cg = api.covgrad_multi(Id, Ad)
+    want = api.kern_grad(ks, Xd, cg)
+    assert np.abs(got - want).max() <= 1e-12 * max(1.0, np.abs(want).max())
+    assert np.array_equal(got, api.kern_grad_fused(ks, Xd, Id, Ad))                      # fixed-order reduction
+    ard = api.kspec([("rbfard", [1.0, 1.0] + [0.5] * D), ("white", [0.1])])
+    assert api.kern_grad_fused(ard, Xd, Id, Ad) is None                                 # outside the fused pass: refused
+    assert api.kern_grad_fused(ks, Xd, Id, api.from_host(rng.randn(N, 3))) is None
+
+
 @pytest.mark.parametrize("name", KERN_FIXTURES)
 def test_kern_grad_cross_fixtures(api, golden, name):
     """testKern.cpp:280-304: getGradTransParams(g, X, X2, covGrad2) -- the cross-Gram parameter gradient (g4)"""
