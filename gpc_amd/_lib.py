@@ -119,6 +119,7 @@ GRID_SIGNATURES = {
     "quadform": (c_int, [GP, DP]),
     "alpha": (c_int, [GP, DP, I64]),
     "posterior": (c_int, [GP, DP, I64, DP]),
+    "gradient": (c_int, [GP, DP]),
     "sync": (c_int, [GP]),
     "barrier": (c_int, [GP]),
     "set_lookahead": (c_int, [GP, c_int]),

@@ -114,7 +114,7 @@ __global__ void __launch_bounds__(256) kern_gradx_kernel(const KSpecDev ks, cons
 //   [2t], [2t+1]  rbf term t: sum cg k~ d2, sum cg k~      [8], [9] rbfard: the same with the scaled distance
 //   [10] sum cg (bias)   [11] sum cg x_i.x2_n (lin)   [12 + q] rbfard: sum cg k~ (x_iq - x2_nq)^2
 constexpr int NPC = 12 + 16;
-template <int DMAX>
+template <int DMAX, bool ARD = true>
 __global__ void __launch_bounds__(256) kern_grad_cross_kernel(const KSpecDev ks, const GradXArgs g, double* __restrict__ partial)
 {
   __shared__ double red[4];
@@ -125,26 +125,27 @@ __global__ void __launch_bounds__(256) kern_grad_cross_kernel(const KSpecDev ks,
   const int64_t nbeg = (int64_t)blockIdx.y * g.cols_per_split;
   int64_t nend = nbeg + g.cols_per_split;
   if(nend > g.N2) nend = g.N2;
-  double xi[DMAX], sdim[DMAX], srbf[8], sard1 = 0.0, sard2 = 0.0, sbias = 0.0, slin = 0.0;
+  double xi[DMAX], sdim[ARD ? DMAX : 1], srbf[8], sard1 = 0.0, sard2 = 0.0, sbias = 0.0, slin = 0.0;
 #pragma unroll
   for(int q = 0; q < DMAX; q++) {
     xi[q] = (q < g.D) ? g.X[ic + (int64_t)q * g.ldx] : 0.0;
-    sdim[q] = 0.0;
+    if(ARD) sdim[q] = 0.0;
   }
 #pragma unroll
   for(int q = 0; q < 8; q++) srbf[q] = 0.0;
-  const bool has_ard = ks.n_ard > 0;
+  const bool has_ard = ARD && ks.n_ard > 0;
   for(int64_t n = nbeg + w; n < nend; n += 4) {
     const double cg = row_ok ? g.G[ic + n * g.ldg] : 0.0;
-    double d2 = 0.0, d2a = 0.0, dot = 0.0, dq[DMAX];
+    double d2 = 0.0, d2a = 0.0, dot = 0.0, dq[ARD ? DMAX : 1];
 #pragma unroll
     for(int q = 0; q < DMAX; q++) {
       const double xn = (q < g.D) ? g.X2[n + (int64_t)q * g.ldx2] : 0.0;   // wave-uniform address
       const double dx = xi[q] - xn;
-      dq[q] = dx * dx;
-      d2 += dq[q];
+      const double dxx = dx * dx;
+      if(ARD) dq[q] = dxx;
+      d2 += dxx;
       dot += xi[q] * xn;
-      if(has_ard) d2a += ks.ard_scale[0][q < GPC_MAX_ARD_DIM ? q : 0] * dq[q];
+      if(has_ard) d2a += ks.ard_scale[0][q < GPC_MAX_ARD_DIM ? q : 0] * dxx;
     }
     for(int t = 0; t < ks.n_rbf; t++) {
       const double kcg = exp(-ks.rbf_hiw[t] * d2) * cg;
@@ -156,7 +157,8 @@ __global__ void __launch_bounds__(256) kern_grad_cross_kernel(const KSpecDev ks,
       sard1 += kcg * d2a;
       sard2 += kcg;
 #pragma unroll
-      for(int q = 0; q < DMAX; q++) sdim[q] += kcg * dq[q];
+      for(int q = 0; q < DMAX; q++)
+        if(ARD) sdim[q] += kcg * dq[q];
     }
     sbias += cg;
     slin += cg * dot;
@@ -177,7 +179,7 @@ __global__ void __launch_bounds__(256) kern_grad_cross_kernel(const KSpecDev ks,
   block_store(sbias, 10);
   block_store(slin, 11);
 #pragma unroll
-  for(int q = 0; q < 16; q++) block_store(q < DMAX ? sdim[q < DMAX ? q : 0] : 0.0, 12 + q);
+  for(int q = 0; q < 16; q++) block_store((ARD && q < DMAX) ? sdim[(ARD && q < DMAX) ? q : 0] : 0.0, 12 + q);
 }
 
 __global__ void __launch_bounds__(256) gradx_reduce_kernel(const double* __restrict__ part, int nsplit, int D, int64_t N,
@@ -299,13 +301,13 @@ extern "C" int gpc_kern_grad_cross_f64(const gpc_kspec* ksp, const double* X, in
   GPC_REQUIRE(ksp && gout && N >= 0 && N2 >= 0 && D >= 0 && ldx >= (N > 1 ? N : 1) && ldx2 >= (N2 > 1 ? N2 : 1) &&
                   ldc >= (N > 1 ? N : 1),
               "kern_grad_cross args");
-  if(D > 16) {
-    set_error("kern_grad_cross: input dimension %lld > 16 is outside the accelerated set", (long long)D);
-    return GPC_EUNSUPPORTED;
-  }
   hipStream_t s = as_stream(stream);
   KSpecDev ks;
   GPC_CHECK(collapse_kspec(ksp, D, &ks));
+  if(D > 32 || (D > 16 && ks.n_ard > 0)) {
+    set_error("kern_grad_cross: input dimension %lld is outside the accelerated set (32; 16 with an rbfard term)", (long long)D);
+    return GPC_EUNSUPPORTED;
+  }
   const int nparams = ksp->offs[ksp->n_terms];
   for(int p = 0; p < nparams; p++) gout[p] = 0.0;
   if(N == 0 || N2 == 0) return GPC_OK;
@@ -337,8 +339,10 @@ extern "C" int gpc_kern_grad_cross_f64(const gpc_kspec* ksp, const double* X, in
   const dim3 grid((unsigned)rb, (unsigned)nsplit);
   if(D <= 4)
     hipLaunchKernelGGL(kern_grad_cross_kernel<4>, grid, dim3(256), 0, s, ks, g, partial);
-  else
+  else if(D <= 16)
     hipLaunchKernelGGL(kern_grad_cross_kernel<16>, grid, dim3(256), 0, s, ks, g, partial);
+  else
+    hipLaunchKernelGGL((kern_grad_cross_kernel<32, false>), grid, dim3(256), 0, s, ks, g, partial);
   GPC_HIP_CHECK(hipGetLastError());
   std::vector<double> h((size_t)nblk * NPC);
   GPC_HIP_CHECK(hipMemcpyAsync(h.data(), partial, sizeof(double) * h.size(), hipMemcpyDeviceToHost, s));

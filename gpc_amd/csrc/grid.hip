@@ -144,6 +144,35 @@ __global__ void __launch_bounds__(256) add_transposed_kernel(double* __restrict_
   for(int64_t e = 0; e < d; e++) dst[i + e * ldd] += src[e + i * lds];
 }
 
+__global__ void __launch_bounds__(256) scatter_row_tiles_kernel(double* __restrict__ dst, int64_t ldd, int64_t first, int64_t step,
+                                                                const double* __restrict__ src, int64_t lds, int64_t nb)
+{
+  const int64_t t = blockIdx.y, j = blockIdx.x;
+  const double* s = src + t * nb + j * lds;
+  double* d = dst + (first + t * step) * nb + j * ldd;
+  for(int64_t i = 2 * threadIdx.x; i < nb; i += 512)
+    *reinterpret_cast<double2_t*>(d + i) = *reinterpret_cast<const double2_t*>(s + i);
+}
+
+__global__ void __launch_bounds__(256) set_identity_diag_kernel(double* A, int64_t lda, int64_t n)
+{
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if(i < n) A[i + i * lda] = 1.0;
+}
+
+// see GridOps::covgrad_block
+__global__ void __launch_bounds__(256) covgrad_block_kernel(double* __restrict__ S, int64_t lds, int64_t M, const double* __restrict__ Al,
+                                                            int64_t lda, int nd, int64_t g0)
+{
+  const int64_t j = blockIdx.y;
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if(i >= M) return;
+  double aa = 0.0;
+  for(int o = 0; o < nd; o++) aa = fma(Al[g0 + i + (int64_t)o * lda], Al[g0 + j + (int64_t)o * lda], aa);
+  const double c = -0.5 * ((double)nd * S[i + j * lds] - aa);
+  S[i + j * lds] = i > j ? 2.0 * c : (i == j ? c : 0.0);
+}
+
 // ---- GridOps on HIP ------------------------------------------------------------------------------------------------------
 struct HipOps : GridOps {
   int dev;
@@ -397,6 +426,47 @@ struct HipOps : GridOps {
   int trsm_llt(const double* Lkk, int64_t ldl, int64_t n, double* B, int64_t ldb, int64_t nrhs, int s) override
   {
     return gpc::trsm('L', 'L', 'T', 'N', n, nrhs, 1.0, Lkk, ldl, B, ldb, st[s]);
+  }
+  int trsm_lln(const double* L, int64_t ldl, int64_t n, double* B, int64_t ldb, int64_t nrhs, int s) override
+  {
+    return gpc::trsm('L', 'L', 'N', 'N', n, nrhs, 1.0, L, ldl, B, ldb, st[s]);
+  }
+  int scatter_row_tiles(double* dst, int64_t ldd, int64_t first, int64_t step, const double* src, int64_t lds, int64_t count,
+                        int64_t nb, int64_t ncols, int s) override
+  {
+    if(count <= 0 || ncols <= 0) return GPC_OK;
+    for(int64_t t0 = 0; t0 < count; t0 += 65535) {
+      const int64_t nt = count - t0 < 65535 ? count - t0 : 65535;
+      hipLaunchKernelGGL(scatter_row_tiles_kernel, dim3((unsigned)ncols, (unsigned)nt), dim3(256), 0, st[s], dst, ldd,
+                         first + t0 * step, step, src + t0 * nb, lds, nb);
+    }
+    HIPOPS_CHECK(hipGetLastError());
+    return GPC_OK;
+  }
+  int set_identity(double* A, int64_t lda, int64_t n, int s) override
+  {
+    GPC_CHECK(zero2d(A, lda, n, n, s));
+    hipLaunchKernelGGL(set_identity_diag_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st[s], A, lda, n);
+    HIPOPS_CHECK(hipGetLastError());
+    return GPC_OK;
+  }
+  int sum_diag(const double* A, int64_t lda, int64_t n, double* out, int s) override
+  {
+    return gpc::diag_reduce(0, n, A, lda, out, st[s]);
+  }
+  int covgrad_block(double* S, int64_t lds, int64_t M, int64_t nbc, const double* Al, int64_t lda, int64_t nd, int64_t g0,
+                    int s) override
+  {
+    if(M <= 0 || nbc <= 0) return GPC_OK;
+    hipLaunchKernelGGL(covgrad_block_kernel, dim3((unsigned)((M + 255) / 256), (unsigned)nbc), dim3(256), 0, st[s], S, lds, M, Al,
+                       lda, (int)nd, g0);
+    HIPOPS_CHECK(hipGetLastError());
+    return GPC_OK;
+  }
+  int kern_grad_block(const gpc_kspec* ks, const double* Xa, int64_t Na, int64_t lda, const double* Xb, int64_t Nb, int64_t ldb,
+                      int64_t D, const double* C, int64_t ldc, double* g, int s) override
+  {
+    return gpc_kern_grad_cross_f64(ks, Xa, Na, lda, Xb, Nb, ldb, D, C, ldc, g, st[s]);
   }
   int add_transposed(double* dst, int64_t ldd, const double* src, int64_t lds, int64_t n, int64_t d, int s) override
   {

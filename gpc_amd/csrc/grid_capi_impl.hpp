@@ -182,6 +182,13 @@ int GRID_API(alpha)(gpc_grid* g, double* alpha_host, int64_t lda)
   return grid_fail(g, g->gp->alpha(alpha_host, lda));
 }
 
+int GRID_API(gradient)(gpc_grid* g, double* g_host)
+{
+  if(!g || !g_host) return GPC_EINVAL;
+  GRID_CHECK(grid_enter(g->device));
+  return grid_fail(g, g->gp->gradient(g_host));
+}
+
 int GRID_API(posterior)(gpc_grid* g, double* mu_host, int64_t ldmu, double* var_host)
 {
   if(!g || !mu_host || !var_host) return GPC_EINVAL;

@@ -140,6 +140,22 @@ struct GridOps {
   virtual int gemm(char ta, char tb, int64_t M, int64_t N, int64_t K, double alpha, const double* A, int64_t lda,
                    const double* B, int64_t ldb, double beta, double* C, int64_t ldc, int st) = 0;
   virtual int trsm_llt(const double* Lkk, int64_t ldl, int64_t n, double* B, int64_t ldb, int64_t nrhs, int st) = 0;
+  // ---- gradient (see GridGp::gradient)
+  virtual int trsm_lln(const double* L, int64_t ldl, int64_t n, double* B, int64_t ldb, int64_t nrhs, int st) = 0;   // B := L^-1 B
+  // dst row tile (first + t*step), all ncols columns := src row tile t (src is count*nb x ncols, leading dimension lds)
+  virtual int scatter_row_tiles(double* dst, int64_t ldd, int64_t first, int64_t step, const double* src, int64_t lds,
+                                int64_t count, int64_t nb, int64_t ncols, int st) = 0;
+  virtual int set_identity(double* A, int64_t lda, int64_t n, int st) = 0;      // the n x n block at A := I
+  virtual int sum_diag(const double* A, int64_t lda, int64_t n, double* out_host, int st) = 0;
+  // In place on the M x nb block S = K^-1(g0 + i, g0 + j):  C(i,j) = w * -0.5 (nd S(i,j) - sum_o Al(g0+i,o) Al(g0+j,o)) with
+  // w = 2 below the block's diagonal, 1 on it, 0 above it (CGp::updateCovGradient, CGp.cpp:666-679, summed over outputs; the
+  // weight 2 stands for the mirrored element the lower-triangular sweep never forms)
+  virtual int covgrad_block(double* S, int64_t lds, int64_t M, int64_t nbc, const double* Al, int64_t lda, int64_t nd,
+                            int64_t g0, int st) = 0;
+  // g[p] = sum over the block of C(i,n) dk(Xa_i, Xb_n)/dtheta_p, natural parameters in spec order, white = 0
+  // (CKern::getGradParams(g, X, X2, covGrad)); g is a host array of ks->offs[n_terms] doubles
+  virtual int kern_grad_block(const gpc_kspec* ks, const double* Xa, int64_t Na, int64_t lda, const double* Xb, int64_t Nb,
+                              int64_t ldb, int64_t D, const double* C, int64_t ldc, double* g_host, int st) = 0;
   // dst(i, e) += src(e, i): the extra rows of a tile, transposed (nb x d)
   virtual int add_transposed(double* dst, int64_t ldd, const double* src, int64_t lds, int64_t n, int64_t d, int st) = 0;
   virtual int read_info(const int* info_dev, int* out_host, int st) = 0;
@@ -375,7 +391,7 @@ class GridGp {
     if(Ns > 0) GRID_CHECK(upload_matrix(Xs_, Xs, Ns, D, ldxs));
     GRID_CHECK(ops_->gather_rows(X_, N, D, N, r_, pr_, L_.Lr, nb_, Xr_, imax(L_.Lr * nb_, 1), ST_MAIN));
     GRID_CHECK(ops_->gather_rows(X_, N, D, N, c_, pc_, L_.Lc, nb_, Xc_, imax(L_.Lc * nb_, 1), ST_MAIN));
-    factored_ = false;
+    factored_ = alpha_valid_ = false;
     return GPC_OK;
   }
   // kernel parameters only (an optimiser's inner loop): the inputs stay where they are
@@ -383,7 +399,7 @@ class GridGp {
   {
     if(!ks || !A_) return fail(GPC_EINVAL, "grid: set_kernel before set_problem");
     ks_ = *ks;
-    factored_ = false;
+    factored_ = alpha_valid_ = false;
     return GPC_OK;
   }
 
@@ -401,7 +417,7 @@ class GridGp {
       if(Ns_ > 0) GRID_CHECK(ops_->gram_cross(&ks_, Xs_, Ns_, Ns_, Xc_, L.Lc * nb_, L.Lc * nb_, D_, Aex + d_, L.lld, ST_MAIN));
     }
     GRID_CHECK(ops_->fix_diag_pad(A_, L, dg_, ST_MAIN));
-    factored_ = false;
+    factored_ = alpha_valid_ = false;
     return GPC_OK;
   }
 
@@ -577,6 +593,71 @@ class GridGp {
     for(int64_t j = 0; j < d_; j++)
       for(int64_t i = 0; i < Ns_; i++) mu_host[i + j * ldmu] = hm[(size_t)(i + j * Ns_)];
     for(int64_t i = 0; i < Ns_; i++) var_host[i] = hk[(size_t)i] - q[(size_t)i];
+    return GPC_OK;
+  }
+
+  // CGp::updateG (CGp.cpp:1080-1117) for the distributed model: g[p] = sum_ij covGrad(i,j) dK(i,j)/dtheta_p for the natural
+  // kernel parameters in spec order (the transform chain rule stays with the caller), identical on every rank.
+  // K^-1 is not formed by a distributed dpotri.  The factor is replicated instead (one broadcast per tile-column strip; it
+  // has to fit beside the local block: 8 N^2 bytes, 137 GB at N = 131 072), and every rank then solves for ITS tile columns
+  // of the lower triangle of K^-1 on its own --  S(J:, J) = L(J:, J:)^-T L(J:, J:)^-1 E_J, two triangular solves on the
+  // trailing block, (2/3) N^3 / P flops per rank like a distributed dpotri, no exchange -- and runs the kernel-gradient
+  // pass over that block column.  One all-reduce of the parameter sums at the end.
+  int gradient(double* g_host)
+  {
+    const Layout& L = L_;
+    if(!factored_ || d_ <= 0) return fail(GPC_EINVAL, "grid gradient: no factor / no targets");
+    if(!alpha_valid_) GRID_CHECK(alpha(nullptr, 0));
+    const int np = ks_.offs[ks_.n_terms];
+    const int P = pr_ * pc_, me = r_ * pc_ + c_;
+    double* Lf = nullptr;
+    double* strip = nullptr;
+    double* Z = nullptr;
+    GRID_CHECK(ops_->alloc((void**)&Lf, sizeof(double) * (size_t)(L.Np * L.Np)));
+    int rc = ops_->alloc((void**)&strip, sizeof(double) * (size_t)(((L.T + pr_ - 1) / pr_) * nb_ * nb_ + 16));   // any row's strip
+    if(rc == GPC_OK) rc = ops_->alloc((void**)&Z, sizeof(double) * (size_t)(L.Np * nb_));
+    // 1. replicate the lower tiles of the factor
+    for(int64_t J = 0; J < L.T && rc == GPC_OK; J++) {
+      const int jc = (int)(J % pc_);
+      for(int s = 0; s < pr_ && rc == GPC_OK; s++) {
+        const int64_t ilf = Layout::first_after(J - 1, s, pr_);          // first local tile row of process row s with I >= J
+        const int64_t cnt = Layout::ntiles(L.T, s, pr_) - ilf;
+        if(cnt <= 0) continue;
+        if(r_ == s && c_ == jc)
+          rc = ops_->copy2d(strip, cnt * nb_, A_ + ilf * nb_ + (J / pc_) * nb_ * L.lld, L.lld, cnt * nb_, nb_, ST_MAIN);
+        if(rc == GPC_OK) rc = comm_->bcast(strip, cnt * nb_ * nb_, s * pc_ + jc, AX_WORLD, ops_.get(), ST_MAIN);
+        count_coll(AX_WORLD, 8.0 * (double)(cnt * nb_ * nb_), !(r_ == s && c_ == jc));
+        if(rc == GPC_OK)
+          rc = ops_->scatter_row_tiles(Lf + J * nb_ * L.Np, L.Np, s + pr_ * ilf, pr_, strip, cnt * nb_, cnt, nb_, nb_, ST_MAIN);
+      }
+    }
+    // 2. my tile columns of K^-1 and their share of the gradient
+    std::vector<double> acc((size_t)imax(np, 1), 0.0), part((size_t)imax(np, 1), 0.0);
+    double trace = 0.0;
+    for(int64_t J = me; J < L.T && rc == GPC_OK; J += P) {
+      const int64_t g0 = J * nb_, M = L.Np - g0;
+      const int64_t Mv = L.N - g0, nv = Mv < nb_ ? Mv : nb_;             // rows / columns that are data, not padding
+      rc = ops_->zero(Z, sizeof(double) * (size_t)(M * nb_), ST_MAIN);
+      if(rc == GPC_OK) rc = ops_->set_identity(Z, M, nb_, ST_MAIN);
+      const double* Lt = Lf + g0 + g0 * L.Np;
+      if(rc == GPC_OK) rc = ops_->trsm_lln(Lt, L.Np, M, Z, M, nb_, ST_MAIN);
+      if(rc == GPC_OK) rc = ops_->trsm_llt(Lt, L.Np, M, Z, M, nb_, ST_MAIN);
+      if(rc == GPC_OK) rc = ops_->covgrad_block(Z, M, Mv, nv, al_, L.Np, d_, g0, ST_MAIN);
+      double tr = 0.0;
+      if(rc == GPC_OK) rc = ops_->sum_diag(Z, M, nv, &tr, ST_MAIN);
+      if(rc == GPC_OK) rc = ops_->kern_grad_block(&ks_, X_ + g0, Mv, L.N, X_ + g0, nv, L.N, D_, Z, M, part.data(), ST_MAIN);
+      trace += tr;
+      for(int p = 0; p < np; p++) acc[(size_t)p] += part[(size_t)p];
+    }
+    ops_->release(Lf);
+    ops_->release(strip);
+    ops_->release(Z);
+    GRID_CHECK(rc);
+    // the white terms see only the diagonal of covGrad (CWhiteKern::getGradParams, CKern.cpp:735-739)
+    for(int t = 0; t < ks_.n_terms; t++)
+      if(ks_.types[t] == GPC_KERN_WHITE) acc[(size_t)ks_.offs[t]] += trace;
+    GRID_CHECK(comm_->allreduce_host(acc.data(), np, AX_WORLD));
+    for(int p = 0; p < np; p++) g_host[p] = acc[(size_t)p];
     return GPC_OK;
   }
 

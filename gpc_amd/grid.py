@@ -165,6 +165,12 @@ class Grid(object):
         self.b.check(self.b.posterior(self.h, mu.ctypes.data, max(self.Ns, 1), var.ctypes.data), self.h)
         return mu, var
 
+    def gradient(self, n_params):
+        """natural-space kernel-parameter gradient of the log-likelihood's covGrad sums (CGp::updateG)"""
+        g = np.zeros(n_params)
+        self.b.check(self.b.gradient(self.h, g.ctypes.data), self.h)
+        return g
+
     def copy_tile(self, I, J):
         """tile (I, J) of the local block as an nb x nb array, or None when it lives on another rank"""
         nb = self.info()["nb"]

@@ -265,10 +265,7 @@ void CGp::updateK() const
     return;
   }
   if(useGrid()) {
-    if(needInverse)
-      throw ndlexceptions::NotImplementedError("the gradient needs the explicit inverse, which is not distributed yet: "
-                                               "on a multi-GPU grid the model gives likelihood, Alpha and predictions");
-    if(!KupToDate) gridUpdateK(0);
+    if(!KupToDate) gridUpdateK(0);   // the grid never forms invK: its gradient solves for block columns of it (gpc_grid_gradient)
     return;
   }
   if(KupToDate && (invKupToDate || !needInverse)) return;
@@ -386,11 +383,25 @@ double CGp::logLikelihoodGradient(CMatrix& g) const
     gradientDtc(g);
     return logLikelihood();
   }
+  const unsigned int np = pkern->getNumParams();
+  if(g.getRows() != 1 || g.getCols() != np) throw ndlexceptions::MatrixError("logLikelihoodGradient: g must be 1 x nParams");
+  if(useGrid()) {
+    // updateG on the grid: every rank solves for its tile columns of K^-1 from the replicated factor and runs the
+    // kernel-gradient pass over them; the parameter sums come back all-reduced (natural space, spec order)
+    updateK();
+    std::vector<std::vector<double> > gr(grids.size(), std::vector<double>(np > 0 ? np : 1, 0.0));
+    std::vector<gpc_grid*>& gs = grids;
+    onRanks(gs.size(), [&](size_t r) -> int { return gpc_grid_gradient(gs[r], &gr[r][0]); });
+    for(unsigned int t = 0; t < pkern->getNumTransforms(); t++) {
+      const unsigned int idx = pkern->getTransformIndex(t);
+      gr[0][idx] *= pkern->getTransformGradFact(pkern->getParam(idx), t);
+    }
+    for(unsigned int i = 0; i < np; i++) g.setVal(gr[0][i], 0, i);
+    return logLikelihood();
+  }
   needInverse = true;
   updateK();
   const int64_t N = getNumData(), D = getInputDim();
-  const unsigned int np = pkern->getNumParams();
-  if(g.getRows() != 1 || g.getCols() != np) throw ndlexceptions::MatrixError("logLikelihoodGradient: g must be 1 x nParams");
   gpc_kspec ks;
   pkern->toKspec(ks);
   std::vector<double> acc(np > 0 ? np : 1, 0.0), tmp(np > 0 ? np : 1, 0.0);

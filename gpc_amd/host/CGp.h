@@ -150,7 +150,7 @@ class CGp : public CProbabilisticOptimisable {
   // Multi-GPU (FTC): the N x N matrix spread over a pr x pc grid of GPUs, one host thread per rank inside this process
   // (gpc_grid_create_local; the C++ driver and RCCL-free peer copies live below the C-ABI).  Chosen by GPC_GRID=PRxPC in
   // the environment, or by itself when one N x N matrix does not fit the current GPU and the node has more of them.
-  // Likelihood, Alpha and predictions run on the grid; the gradient still needs the explicit inverse on one GPU.
+  // Likelihood, gradient, Alpha and predictions all run on the grid (the gradient from a replicated factor, gpc_grid_gradient).
   bool useGrid() const;
   void gridUpdateK(const CMatrix* Xstar) const;
   void gridRelease() const;

@@ -193,6 +193,11 @@ int gpc_grid_loglik(gpc_grid* g, double* ll);                                  /
 int gpc_grid_quadform(gpc_grid* g, double* q);                                /* q[j] = m_j' K^-1 m_j, j < d (CGp.cpp:923-932) */
 int gpc_grid_alpha(gpc_grid* g, double* alpha_host, int64_t lda);              /* CGp::updateAlpha: K^-1 Y, N x d */
 int gpc_grid_posterior(gpc_grid* g, double* mu_host, int64_t ldmu, double* var_host);   /* before output scale / bias */
+/* CGp::updateG (CGp.cpp:1080-1117): g[p] = sum_ij covGrad(i,j) dK(i,j)/dtheta_p, natural kernel parameters in spec order
+ * (offs[n_terms] doubles), covGrad = -0.5 (d K^-1 - Alpha Alpha').  The factor is replicated (it must fit one GPU next to
+ * the local block: N <= ~170 000 on 288 GB) and every rank solves for its own tile columns of K^-1: (2/3) N^3 / P flops per
+ * rank, no distributed dpotri.  Cross-block kernel pass: D <= 32 without an rbfard term, D <= 16 with one. */
+int gpc_grid_gradient(gpc_grid* g, double* g_host);
 int gpc_grid_sync(gpc_grid* g);
 int gpc_grid_barrier(gpc_grid* g);
 int gpc_grid_set_lookahead(gpc_grid* g, int on);

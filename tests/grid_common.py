@@ -80,6 +80,36 @@ def expected(terms, X, Y, Xs):
     return out
 
 
+def expected_gradient(terms, X, Y):
+    """natural-space kernel-parameter sums of CGp::updateG: g_p = sum_ij covGrad(i,j) dK(i,j)/dtheta_p with
+    covGrad = -0.5 (d K^-1 - alpha alpha') (CGp.cpp:666-679, 1096-1117), in spec order"""
+    N, d = Y.shape
+    K = kern(terms, X, X, True)
+    Ki = np.linalg.inv(K)
+    al = Ki @ Y
+    C = -0.5 * (d * Ki - al @ al.T)
+    d2 = (X * X).sum(1)[:, None] + (X * X).sum(1)[None, :] - 2.0 * X @ X.T
+    np.fill_diagonal(d2, 0.0)
+    g = []
+    for name, p in terms:
+        if name == "rbf":
+            kt = np.exp(-0.5 * p[0] * d2)
+            g += [float((C * (-0.5 * p[1] * d2 * kt)).sum()), float((C * kt).sum())]
+        elif name == "rbfard":
+            s = np.asarray(p[2:])
+            dq = (X[:, None, :] - X[None, :, :]) ** 2
+            kt = np.exp(-0.5 * p[0] * (dq * s).sum(-1))
+            g += [float((C * (-0.5 * p[1] * (dq * s).sum(-1) * kt)).sum()), float((C * kt).sum())]
+            g += [float((C * (-0.5 * p[0] * p[1] * dq[:, :, q] * kt)).sum()) for q in range(X.shape[1])]
+        elif name == "bias":
+            g.append(float(C.sum()))
+        elif name == "white":
+            g.append(float(np.trace(C)))
+        elif name == "lin":
+            g.append(float((C * (X @ X.T)).sum()))
+    return np.array(g)
+
+
 def rel(a, b):
     a, b = np.asarray(a, dtype=float), np.asarray(b, dtype=float)
     return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-300))

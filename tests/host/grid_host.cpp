@@ -6,6 +6,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <math.h>
+#include <vector>
 #include "../../gpc_amd/csrc/grid_sched.hpp"
 extern "C" {
 #include "../../oracle/gpc_oracle.h"
@@ -205,6 +206,57 @@ struct HostOps : GridOps {
   int trsm_llt(const double* Lkk, int64_t ldl, int64_t n, double* B, int64_t ldb, int64_t nrhs, int) override
   {
     orc_trsm('L', 'L', 'T', 'N', (long)n, (long)nrhs, 1.0, Lkk, (long)ldl, B, (long)ldb);
+    return GPC_OK;
+  }
+  int trsm_lln(const double* L, int64_t ldl, int64_t n, double* B, int64_t ldb, int64_t nrhs, int) override
+  {
+    orc_trsm('L', 'L', 'N', 'N', (long)n, (long)nrhs, 1.0, L, (long)ldl, B, (long)ldb);
+    return GPC_OK;
+  }
+  int scatter_row_tiles(double* dst, int64_t ldd, int64_t first, int64_t step, const double* src, int64_t lds, int64_t count,
+                        int64_t nb, int64_t ncols, int) override
+  {
+    for(int64_t t = 0; t < count; t++)
+      for(int64_t j = 0; j < ncols; j++)
+        memcpy(dst + (first + t * step) * nb + j * ldd, src + t * nb + j * lds, sizeof(double) * (size_t)nb);
+    return GPC_OK;
+  }
+  int set_identity(double* A, int64_t lda, int64_t n, int) override
+  {
+    for(int64_t j = 0; j < n; j++)
+      for(int64_t i = 0; i < n; i++) A[i + j * lda] = i == j ? 1.0 : 0.0;
+    return GPC_OK;
+  }
+  int sum_diag(const double* A, int64_t lda, int64_t n, double* out, int) override
+  {
+    double s = 0.0;
+    for(int64_t i = 0; i < n; i++) s += A[i + i * lda];
+    *out = s;
+    return GPC_OK;
+  }
+  int covgrad_block(double* S, int64_t lds, int64_t M, int64_t nbc, const double* Al, int64_t lda, int64_t nd, int64_t g0,
+                    int) override
+  {
+    for(int64_t j = 0; j < nbc; j++)
+      for(int64_t i = 0; i < M; i++) {
+        double aa = 0.0;
+        for(int64_t o = 0; o < nd; o++) aa += Al[g0 + i + o * lda] * Al[g0 + j + o * lda];
+        const double c = -0.5 * ((double)nd * S[i + j * lds] - aa);
+        S[i + j * lds] = i > j ? 2.0 * c : (i == j ? c : 0.0);
+      }
+    return GPC_OK;
+  }
+  int kern_grad_block(const gpc_kspec* ks, const double* Xa, int64_t Na, int64_t lda, const double* Xb, int64_t Nb, int64_t ldb,
+                      int64_t D, const double* C, int64_t ldc, double* g, int) override
+  {
+    // the oracle's CKern::getGradParams(g, X, X2, covGrad) takes densely stored arguments
+    std::vector<double> xa((size_t)(Na * D)), xb((size_t)(Nb * D)), cg((size_t)(Na * Nb));
+    for(int64_t q = 0; q < D; q++) {
+      memcpy(&xa[(size_t)(q * Na)], Xa + q * lda, sizeof(double) * (size_t)Na);
+      memcpy(&xb[(size_t)(q * Nb)], Xb + q * ldb, sizeof(double) * (size_t)Nb);
+    }
+    for(int64_t j = 0; j < Nb; j++) memcpy(&cg[(size_t)(j * Na)], C + j * ldc, sizeof(double) * (size_t)Na);
+    orc_kern_grad_cross(reinterpret_cast<const orc_kspec*>(ks), xa.data(), (long)Na, xb.data(), (long)Nb, (long)D, cg.data(), g);
     return GPC_OK;
   }
   int add_transposed(double* dst, int64_t ldd, const double* src, int64_t lds, int64_t n, int64_t d, int) override

@@ -171,7 +171,7 @@ static int testGp(int argc, char** argv)
 // predictions, log|K| -- plus the refusal of the gradient.  gp_hosttest gpgrid X y Xs kernspec
 static int testGpGrid(int argc, char** argv)
 {
-  if(argc < 6) { std::fprintf(stderr, "usage: gp_hosttest gpgrid X y Xs kernspec\n"); return 2; }
+  if(argc < 6) { std::fprintf(stderr, "usage: gp_hosttest gpgrid X y Xs kernspec [scg iterations]\n"); return 2; }
   CMatrix X, y, Xs;
   X.fromUnheadedFile(argv[2]);
   y.fromUnheadedFile(argv[3]);
@@ -198,14 +198,17 @@ static int testGpGrid(int argc, char** argv)
   model.getOptParams(params);
   model.setOptParams(params);
   std::printf("ll_roundtrip %.17g\n", model.logLikelihood());
-  int refused = 0;
-  try {
-    CMatrix g(1, model.getOptNumParams());
-    model.logLikelihoodGradient(g);
-  } catch(ndlexceptions::NotImplementedError&) {
-    refused = 1;
+  CMatrix g(1, model.getOptNumParams());
+  std::printf("ll_with_grad %.17g\n", model.logLikelihoodGradient(g));
+  printMat("grads", g);
+  if(argc > 6) {   // a few SCG iterations on the grid: `gp learn` beyond one GPU
+    model.setVerbosity(0);
+    model.optimise((unsigned int)std::atoi(argv[6]));
+    CMatrix p2(1, model.getOptNumParams());
+    model.getOptParams(p2);
+    printMat("opt_params_after", p2);
+    std::printf("ll_after %.17g\n", model.logLikelihood());
   }
-  std::printf("gradient_refused %d\n", refused);
   return 0;
 }
 

@@ -83,6 +83,76 @@ def test_ragged_sizes_on_2x2(hb, N):
     _check(_solve_local(hb, 2, 2, 128, gc.TERMS, X, Y, Xs), exp, N, 128, Xs)
 
 
+@pytest.mark.parametrize("pr,pc", [(1, 1), (1, 2), (2, 2), (2, 4), (3, 2)])
+def test_gradient_against_numpy(hb, pr, pc):
+    """CGp::updateG on the grid (replicated factor, every rank its own tile columns of K^-1, one all-reduce) against the
+    defining sums: rbf + lin + bias + white, ragged last tile, two outputs."""
+    N, D, d, nb = 600, 3, 2, 128
+    terms = [("rbf", [1.3, 0.9]), ("lin", [0.15]), ("bias", [0.2]), ("white", [0.05])]
+    X, Y, _ = gc.make_problem(N, D, d, 0, 13)
+    want = gc.expected_gradient(terms, X, Y)
+    grids = grid.create_local(pr, pc, nb, binding=hb)
+
+    def work(g, rank):
+        g.set_problem(terms, X, Y, None)
+        assert g.update_k()[2] == 0
+        return g.gradient(len(want)), g.loglik()
+
+    try:
+        res = grid.run_local(grids, work)
+    finally:
+        for g in grids:
+            g.destroy()
+    for got, _ in res:
+        assert gc.rel(got, want) < 1e-8
+        assert np.array_equal(got, res[0][0])
+
+
+def test_new_kernel_parameters_invalidate_everything(hb):
+    """set_kernel between evaluations (an optimiser's inner loop): factor, Alpha and gradient all follow the new parameters"""
+    X, Y, _ = gc.make_problem(300, 2, 1, 0, 3)
+    t1 = [("rbf", [1.3, 0.9]), ("white", [0.05])]
+    t2 = [("rbf", [0.6, 1.4]), ("white", [0.11])]
+    want = gc.expected_gradient(t2, X, Y)
+    exp = gc.expected(t2, X, Y, None)
+    grids = grid.create_local(2, 2, 128, binding=hb)
+
+    def work(g, rank):
+        g.set_problem(t1, X, Y, None)
+        g.update_k()
+        g.gradient(3)
+        g.set_kernel(t2)
+        assert g.update_k()[2] == 0
+        return g.gradient(3), g.loglik(), g.alpha()
+
+    try:
+        res = grid.run_local(grids, work)
+    finally:
+        for g in grids:
+            g.destroy()
+    assert gc.rel(res[0][0], want) < 1e-8 and abs(res[0][1] - exp["ll"]) < 1e-10 * abs(exp["ll"])
+    assert gc.rel(res[0][2], exp["alpha"]) < 1e-8
+
+
+def test_gradient_with_an_ard_term(hb):
+    terms = [("rbfard", [1.1, 0.8, 0.7, 0.4, 0.55]), ("white", [0.05])]
+    X, Y, _ = gc.make_problem(400, 3, 1, 0, 5)
+    want = gc.expected_gradient(terms, X, Y)
+    grids = grid.create_local(2, 2, 128, binding=hb)
+
+    def work(g, rank):
+        g.set_problem(terms, X, Y, None)
+        assert g.update_k()[2] == 0
+        return g.gradient(len(want))
+
+    try:
+        res = grid.run_local(grids, work)
+    finally:
+        for g in grids:
+            g.destroy()
+    assert gc.rel(res[0], want) < 1e-8
+
+
 def test_more_ranks_than_tiles(hb):
     X, Y, Xs = gc.make_problem(200, 2, 1, 0, 3)       # T = 2 on a 2 x 4 grid: most ranks own nothing
     exp = gc.expected(gc.TERMS, X, Y, None)

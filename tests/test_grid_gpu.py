@@ -145,6 +145,41 @@ def test_cfg4_kernel_against_the_reference_golden(golden, pr, pc, nb):
         assert gc.rel(r["mu"] + one.bias[None, :], mu1) < 1e-8
 
 
+@pytest.mark.parametrize("pr,pc,D,terms", [
+    (1, 1, 3, [("rbf", [1.3, 0.9]), ("lin", [0.15]), ("bias", [0.2]), ("white", [0.05])]),
+    (2, 2, 3, [("rbf", [1.3, 0.9]), ("lin", [0.15]), ("bias", [0.2]), ("white", [0.05])]),
+    (2, 4, 16, [("rbf", [0.3, 0.9]), ("white", [0.05])]),
+    (2, 2, 32, [("rbf", [0.1, 1.1]), ("white", [0.1])]),                      # the D > 16 instance of the cross pass
+    (1, 2, 4, [("rbfard", [1.1, 0.8, 0.7, 0.4, 0.55, 0.3]), ("white", [0.05])])])
+def test_gradient_against_numpy_and_the_single_gpu_model(pr, pc, D, terms):
+    from gpc_amd import grid
+    from gpc_amd.gp import CGp
+    N, d, nb = 1100, 1, 128
+    X, Y, _ = gc.make_problem(N, D, d, 0, 13)
+    want = gc.expected_gradient(terms, X, Y)
+    grids = grid.create_local(pr, pc, nb)
+
+    def work(g, rank):
+        g.set_problem(terms, X, Y, None)
+        assert g.update_k()[2] == 0
+        return g.gradient(len(want))
+
+    try:
+        res = grid.run_local(grids, work)
+    finally:
+        for g in grids:
+            g.destroy()
+    for got in res:
+        assert gc.rel(got, want) < 1e-8
+        assert np.array_equal(got, res[0])
+    # the single-GPU model's gradient is in the transformed space: undo the chain rule factors to compare
+    one = CGp(terms, X, Y, bias=np.zeros(d), ref_trans_rounding=False)
+    g1, _ = one.logLikelihoodGradient()
+    from gpc_amd.gp import _gradfact
+    fac = np.array([_gradfact(k, x) for k, x in zip(one.kinds, one._flat())])
+    assert gc.rel(res[0] * fac, g1) < 1e-8
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))

@@ -94,7 +94,26 @@ def test_cgp_on_a_multi_gpu_grid(tmp_path, shape):
     assert rel(v["ll"], one["ll"]) < 1e-10 and rel(v["logdet"], one["logdet"]) < 1e-10
     assert rel(v["mu"], one["mu"]) < 1e-8 and rel(v["var"], one["var"]) < 1e-8
     assert rel(v["ll_after_predict"], one["ll"]) < 1e-10 and rel(v["ll_roundtrip"], one["ll"]) < 1e-10
-    assert v["gradient_refused"][0] == 1
+    assert rel(v["ll_with_grad"], one["ll"]) < 1e-10
+    assert rel(v["grads"], one["grads"]) < 1e-8 and rel(v["grads"], g["grads"]) < 1e-8
+
+
+@pytest.mark.gpu
+def test_gp_learn_on_a_grid_follows_the_single_gpu_run(tmp_path):
+    """15 SCG iterations with every likelihood / gradient evaluation on a 2 x 2 grid end where the single-GPU model ends."""
+    from gpc_amd import synth
+    X, y = synth.make_xy(700, 3, 5)
+    _write_txt(tmp_path / "X.txt", X)
+    _write_txt(tmp_path / "y.txt", y)
+    _write_txt(tmp_path / "Xs.txt", X[:4])
+    spec = "rbf:1,1;bias:0.135;white:0.135"
+    args = [str(tmp_path / "X.txt"), str(tmp_path / "y.txt"), str(tmp_path / "Xs.txt"), spec, "15"]
+    one = _parse(_run([os.path.join(HOST, "gp_hosttest"), "gpgrid"] + args, env=dict(os.environ, GPC_GRID="1x1")))
+    env = dict(os.environ, GPC_GRID="2x2", GPC_GRID_DEVICES="same", GPC_GRID_NB="128")
+    v = _parse(_run([os.path.join(HOST, "gp_hosttest"), "gpgrid"] + args, env=env))
+    assert rel(v["grads"], one["grads"]) < 1e-8
+    assert rel(v["opt_params_after"], one["opt_params_after"]) < 1e-5 and rel(v["ll_after"], one["ll_after"]) < 1e-7
+    assert v["ll_after"][0] > v["ll"][0] + 10.0
 
 
 @pytest.mark.gpu
