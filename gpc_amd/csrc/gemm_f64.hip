@@ -629,6 +629,7 @@ static int gemm_ex(bool transa, bool transb, int64_t M, int64_t N, int64_t K, do
       cum += (uint32_t)(g.super_m - sf);
     }
     g.st_cum[g.super_n] = cum;
+    if(cum == 0) return GPC_OK;   // this rank's share of the update lies entirely above the diagonal: nothing to launch
     slots = (((uint64_t)cum + 7) / 8) * 8 * SUPER * SUPER;
   } else if(tri == 0 || tri == 3)
     slots = (uint64_t)g.super_m * g.super_n * SUPER * SUPER;

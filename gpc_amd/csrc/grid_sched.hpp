@@ -34,6 +34,7 @@
 #include <condition_variable>
 #include <memory>
 #include <string>
+#include <stdlib.h>
 #include "gpc_hip.h"
 
 namespace gpc {
@@ -261,6 +262,8 @@ struct LocalComm : GridComm {
     LocalBoard::Group& g = board->group(axis, r, c);
     if(g.n == 1) return GPC_OK;
     const int me = index(axis);
+    static const bool trace = getenv("GPC_GRID_TRACE") != nullptr;
+    if(trace) fprintf(stderr, "[%d,%d] bcast axis %d root %d count %lld st %d\n", r, c, axis, root, (long long)count, st);
     if(!my_done[axis]) my_done[axis] = ops->event_create();
     if(me == root) {
       if(!g.src_event) g.src_event = ops->event_create();
@@ -464,8 +467,11 @@ class GridGp {
     GRID_CHECK(ops_->record(ev_ready_, ST_MAIN));
     if(SP != ST_MAIN) GRID_CHECK(ops_->wait(SP, ev_ready_));
     GRID_CHECK(panel_phase(0, SP));
+    static const bool trace = getenv("GPC_GRID_TRACE") != nullptr;
+#define GRID_TRACE(what) do { if(trace) fprintf(stderr, "[%d,%d] k=%lld %s\n", r_, c_, (long long)k, what); } while(0)
     for(int64_t k = 0; k < L.T; k++) {
       const int b = (int)(k & 1);
+      GRID_TRACE("top");
       if(SP != ST_MAIN) GRID_CHECK(ops_->wait(ST_MAIN, ev_panel_[b]));
       const int64_t il0 = L.il0(k), jl0 = L.jl0(k);
       const int64_t M = L.mloc - il0 * nb_;
@@ -474,17 +480,22 @@ class GridGp {
         const bool next_col = (int)((k + 1) % pc_) == c_;
         if(next_col && M > 0 && jl0 < L.Lc) {
           // U1: the tiles of panel k+1 first, so that its factorisation overlaps the rest of this update
+          GRID_TRACE("U1");
           GRID_CHECK(update(k, il0, jl0, 1, ST_MAIN));
           jfirst = jl0 + 1;
         }
+        GRID_TRACE("events");
         if(SP != ST_MAIN) {
           GRID_CHECK(ops_->record(ev_u1_, ST_MAIN));
           GRID_CHECK(ops_->wait(SP, ev_u1_));
           if(free_valid_[b ^ 1]) GRID_CHECK(ops_->wait(SP, ev_free_[b ^ 1]));   // update k-1 has released W/V[(k+1)&1]
         }
+        GRID_TRACE("panel");
         GRID_CHECK(panel_phase(k + 1, SP));
       }
+      GRID_TRACE("U2");
       if(M > 0 && jfirst < L.Lc) GRID_CHECK(update(k, il0, jfirst, L.Lc - jfirst, ST_MAIN));
+      GRID_TRACE("U2 done");
       if(SP != ST_MAIN) {
         GRID_CHECK(ops_->record(ev_free_[b], ST_MAIN));
         free_valid_[b] = true;
@@ -631,23 +642,38 @@ class GridGp {
           rc = ops_->scatter_row_tiles(Lf + J * nb_ * L.Np, L.Np, s + pr_ * ilf, pr_, strip, cnt * nb_, cnt, nb_, nb_, ST_MAIN);
       }
     }
-    // 2. my tile columns of K^-1 and their share of the gradient
+    // 2. my tile columns of K^-1 and their share of the gradient.  G of them are solved for at once (the triangular solves are
+    // chains of N/64 small dependent kernels whatever the number of right-hand sides: 4096 of them cost what 512 do), on the
+    // trailing block of the first; the columns of the later tiles just start with a few zero rows.
     std::vector<double> acc((size_t)imax(np, 1), 0.0), part((size_t)imax(np, 1), 0.0);
     double trace = 0.0;
-    for(int64_t J = me; J < L.T && rc == GPC_OK; J += P) {
-      const int64_t g0 = J * nb_, M = L.Np - g0;
-      const int64_t Mv = L.N - g0, nv = Mv < nb_ ? Mv : nb_;             // rows / columns that are data, not padding
-      rc = ops_->zero(Z, sizeof(double) * (size_t)(M * nb_), ST_MAIN);
-      if(rc == GPC_OK) rc = ops_->set_identity(Z, M, nb_, ST_MAIN);
-      const double* Lt = Lf + g0 + g0 * L.Np;
-      if(rc == GPC_OK) rc = ops_->trsm_lln(Lt, L.Np, M, Z, M, nb_, ST_MAIN);
-      if(rc == GPC_OK) rc = ops_->trsm_llt(Lt, L.Np, M, Z, M, nb_, ST_MAIN);
-      if(rc == GPC_OK) rc = ops_->covgrad_block(Z, M, Mv, nv, al_, L.Np, d_, g0, ST_MAIN);
-      double tr = 0.0;
-      if(rc == GPC_OK) rc = ops_->sum_diag(Z, M, nv, &tr, ST_MAIN);
-      if(rc == GPC_OK) rc = ops_->kern_grad_block(&ks_, X_ + g0, Mv, L.N, X_ + g0, nv, L.N, D_, Z, M, part.data(), ST_MAIN);
-      trace += tr;
-      for(int p = 0; p < np; p++) acc[(size_t)p] += part[(size_t)p];
+    const int64_t G = imax(1, 4096 / nb_);
+    if(rc == GPC_OK) {
+      ops_->release(Z);
+      Z = nullptr;
+      rc = ops_->alloc((void**)&Z, sizeof(double) * (size_t)(L.Np * nb_ * G));
+    }
+    for(int64_t J0 = me; J0 < L.T && rc == GPC_OK; J0 += P * G) {
+      int64_t cnt = 0;
+      while(cnt < G && J0 + cnt * P < L.T) cnt++;
+      const int64_t gmin = J0 * nb_, M = L.Np - gmin;
+      rc = ops_->zero(Z, sizeof(double) * (size_t)(M * nb_ * cnt), ST_MAIN);
+      for(int64_t t = 0; t < cnt && rc == GPC_OK; t++)
+        rc = ops_->set_identity(Z + t * P * nb_ + t * nb_ * M, M, nb_, ST_MAIN);      // E of tile column J0 + t P
+      const double* Lt = Lf + gmin + gmin * L.Np;
+      if(rc == GPC_OK) rc = ops_->trsm_lln(Lt, L.Np, M, Z, M, nb_ * cnt, ST_MAIN);
+      if(rc == GPC_OK) rc = ops_->trsm_llt(Lt, L.Np, M, Z, M, nb_ * cnt, ST_MAIN);
+      for(int64_t t = 0; t < cnt && rc == GPC_OK; t++) {
+        const int64_t g0 = (J0 + t * P) * nb_;
+        double* Zt = Z + (g0 - gmin) + t * nb_ * M;                                   // K^-1(g0:, g0:g0+nb)
+        const int64_t Mv = L.N - g0, nv = Mv < nb_ ? Mv : nb_;                        // rows / columns that are data, not padding
+        rc = ops_->covgrad_block(Zt, M, Mv, nv, al_, L.Np, d_, g0, ST_MAIN);
+        double tr = 0.0;
+        if(rc == GPC_OK) rc = ops_->sum_diag(Zt, M, nv, &tr, ST_MAIN);
+        if(rc == GPC_OK) rc = ops_->kern_grad_block(&ks_, X_ + g0, Mv, L.N, X_ + g0, nv, L.N, D_, Zt, M, part.data(), ST_MAIN);
+        trace += tr;
+        for(int p = 0; p < np; p++) acc[(size_t)p] += part[(size_t)p];
+      }
     }
     ops_->release(Lf);
     ops_->release(strip);

@@ -236,6 +236,11 @@ def run_local(grids, fn):
             out[i] = fn(grids[i], i)
         except BaseException as e:   # noqa: B902 -- re-raised below
             err[i] = e
+            # the other ranks are now waiting for this one inside a collective: say why before they are left hanging
+            import sys
+            import traceback
+            sys.stderr.write("gpc_amd.grid: rank %d failed: %r\n" % (i, e))
+            traceback.print_exc()
 
     if len(grids) == 1:
         work(0)

@@ -77,6 +77,31 @@ def test_ragged_sizes_and_tile_widths_on_2x2(N, nb):
     _check(_solve(2, 2, nb, gc.TERMS, X, Y, Xs), exp, N, nb, Xs)
 
 
+@pytest.mark.parametrize("pr,pc,N,nb", [(2, 4, 1500, 128), (2, 4, 4096, 512), (4, 2, 2000, 128), (1, 8, 1100, 128)])
+def test_factor_without_right_hand_sides(pr, pc, N, nb):
+    """No targets, no test inputs -- what bench.py times: near the end of the factorisation some ranks then hold nothing on
+    or below the diagonal, and their share of the trailing update is an empty launch."""
+    from gpc_amd import grid
+    X, _, _ = gc.make_problem(N, 3, 1, 0, N)
+    K = gc.kern(gc.TERMS, X, X, True)
+    L = np.linalg.cholesky(K)
+    grids = grid.create_local(pr, pc, nb)
+
+    def work(g, rank):
+        g.set_problem(gc.TERMS, X, None, None)
+        logdet, jit, info = g.update_k()
+        return logdet, info, g.local_tiles()
+
+    try:
+        res = grid.run_local(grids, work)
+    finally:
+        for g in grids:
+            g.destroy()
+    assert all(r[1] == 0 for r in res)
+    assert abs(res[0][0] - 2.0 * np.log(np.diag(L)).sum()) < 1e-9 * abs(res[0][0])
+    assert gc.rel(grid.assemble_factor([r[2] for r in res], N, nb), L) < TOL
+
+
 def test_lookahead_off_gives_the_same_bits():
     X, Y, Xs = gc.make_problem(1900, 3, 1, 4, 11)
     a = _solve(2, 2, 128, gc.TERMS, X, Y, Xs, lookahead=True)
