@@ -39,8 +39,8 @@ pmc tcc TCC_HIT_sum TCC_MISS_sum
 # 3. the Gram kernel alone (HBM bytes)
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmc_g$c
-  timeout 300 rocprofv3 --pmc $c -d /tmp/pmc_g$c -o p -- python $R/tools/gram_bench.py 32768 32 > /dev/null 2>&1
-  echo "# rocprofv3 --pmc $c -- python tools/gram_bench.py 32768 32" > $OUT/pmc_gram_$c.txt
-  python $R/tools/pmc_query.py /tmp/pmc_g$c gram_mfma >> $OUT/pmc_gram_$c.txt 2>&1
+  timeout 300 rocprofv3 --pmc $c -d /tmp/pmc_g$c -o p -- python $R/tools/gram_bench.py 65536 32 > /dev/null 2>&1
+  echo "# rocprofv3 --pmc $c -- python tools/gram_bench.py 65536 32   (cfg 3's Gram: gram_sym_kernel; counter values in KB summed over the XCDs)" > $OUT/pmc_gram_$c.txt
+  python $R/tools/pmc_query.py /tmp/pmc_g$c gram_sym >> $OUT/pmc_gram_$c.txt 2>&1
 done
 ls -la $OUT

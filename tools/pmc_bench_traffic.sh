@@ -17,21 +17,29 @@ python - $OUT/pmc_bench_traffic.json <<'PY'
 import sqlite3, glob, json, sys, collections
 res = {"command": "rocprofv3 --pmc <C> -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline  (C = FETCH_SIZE, WRITE_SIZE; separate passes)",
        "kernel": "gemm_nt_fast_kernel<4, 1> (the trailing-update launches only)", "units": "counter values are KB summed over the 8 XCDs per dispatch"}
-for c in ("FETCH_SIZE", "WRITE_SIZE"):
-    tot, n, dur = 0.0, 0, 0.0
-    for f in glob.glob("/tmp/pmcb_%s/**/*.db" % c, recursive=True):
-        cur = sqlite3.connect(f).cursor()
-        byd = collections.defaultdict(lambda: [0.0, 0.0, ""])
-        for did, kn, cn, v, d in cur.execute("select dispatch_id, kernel_name, counter_name, value, duration from counters_collection"):
-            if cn == c and "gemm_nt_fast_kernel<4, 1>" in kn:
-                byd[did][0] += v; byd[did][1] = d
-        for did, (v, d, _) in byd.items():
-            tot += v; n += 1; dur += d
-    res[c] = {"dispatches": n, "sum_kb": tot, "avg_kb_per_dispatch": tot / max(n, 1), "sum_duration_ms_under_pmc": dur / 1e6}
+def collect(pattern):
+    out = {}
+    for c in ("FETCH_SIZE", "WRITE_SIZE"):
+        tot, n, dur = 0.0, 0, 0.0
+        for f in glob.glob("/tmp/pmcb_%s/**/*.db" % c, recursive=True):
+            cur = sqlite3.connect(f).cursor()
+            byd = collections.defaultdict(lambda: [0.0, 0.0, ""])
+            for did, kn, cn, v, d in cur.execute("select dispatch_id, kernel_name, counter_name, value, duration from counters_collection"):
+                if cn == c and pattern in kn:
+                    byd[did][0] += v; byd[did][1] = d
+            for did, (v, d, _) in byd.items():
+                tot += v; n += 1; dur += d
+        out[c] = {"dispatches": n, "sum_kb": tot, "avg_kb_per_dispatch": tot / max(n, 1), "sum_duration_ms_under_pmc": dur / 1e6}
+    return out
+res.update(collect("gemm_nt_fast_kernel<4, 1>"))
 f, w = res["FETCH_SIZE"], res["WRITE_SIZE"]
 # MI355X_MICROARCH.md "HBM": on gfx950 FETCH_SIZE reports half the bytes of wide coalesced reads -> double it; WRITE_SIZE taken as is
 res["hbm_bytes_per_launch"] = (2.0 * f["avg_kb_per_dispatch"] + w["avg_kb_per_dispatch"]) * 1024.0
 res["correction"] = "bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 (gfx950: FETCH_SIZE counts 128-B requests as 64 B)"
+# the O(N^2) kernel of the same command: the mirrored Gram build (algorithmic bytes 8 N^2 + 8 N D = 34.38 GB at cfg 3)
+g = collect("gram_sym_kernel")
+res["gram_sym_kernel"] = dict(g, hbm_bytes_per_launch=(2.0 * g["FETCH_SIZE"]["avg_kb_per_dispatch"] + g["WRITE_SIZE"]["avg_kb_per_dispatch"]) * 1024.0,
+                              algorithmic_bytes=8.0 * 65536.0 ** 2 + 8.0 * 65536.0 * 32.0)
 json.dump(res, open(sys.argv[1], "w"), indent=1)
 print(json.dumps(res))
 PY
