@@ -46,6 +46,9 @@ def _host_lapack():
     Everything BLAS-like goes through ONE library: MKL's and numpy's thread pools in one process spin against each other."""
     if os.path.exists(MKL):
         mkl = ctypes.CDLL(MKL)
+        # more threads than 64 (SMT siblings of a 2 x 64-thread host) only slow a factorisation of these sizes down
+        want = ctypes.c_int(min(int(mkl.mkl_get_max_threads()), 64))
+        mkl.mkl_set_num_threads(ctypes.byref(want))
         threads = int(mkl.mkl_get_max_threads())
         for f in (mkl.dpotrf_, mkl.dgemm_, mkl.vdExp):
             f.restype = None

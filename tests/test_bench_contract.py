@@ -1,4 +1,4 @@
-"""The committed bench line (profiles/r01_bench_default.json, the output of `python bench.py` on an MI355X) carries every
+"""The committed bench line (profiles/r02_bench_default.json, the output of `python bench.py` on an MI355X) carries every
 field the measurement contract names, with consistent values.  Host-only."""
 import json
 import os
@@ -7,7 +7,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_committed_bench_line_has_the_contract_fields():
-    line = json.load(open(os.path.join(ROOT, "profiles", "r01_bench_default.json")))
+    line = json.load(open(os.path.join(ROOT, "profiles", "r02_bench_default.json")))
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
                 "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert key in line, key
@@ -28,7 +28,7 @@ def test_committed_bench_line_has_the_contract_fields():
 
 
 def test_committed_traffic_file_matches_the_bench_line():
-    line = json.load(open(os.path.join(ROOT, "profiles", "r01_bench_default.json")))
-    t = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_bench_traffic.json")))
+    line = json.load(open(os.path.join(ROOT, "profiles", "r02_bench_default.json")))
+    t = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_bench_traffic.json")))
     assert abs(line["roofline"]["traffic"] - t["hbm_bytes_per_launch"]) <= 1e-6 * t["hbm_bytes_per_launch"]
     assert t["FETCH_SIZE"]["dispatches"] == t["WRITE_SIZE"]["dispatches"] == int(line["roofline"]["launches_per_step"])
