@@ -276,6 +276,17 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("gloo")      # control plane only; the data path is RCCL inside libgpc_hip.so
+        # a collective that never completes (a rank died, a mismatched exchange) must not hold the node: give up loudly
+        import threading
+        limit = float(os.environ.get("GPC_BENCH_WATCHDOG_S", "1500"))
+
+        def _give_up():
+            sys.stderr.write("bench.py: rank %d still running after %.0f s -- aborting the job\n" % (rank, limit))
+            sys.stderr.flush()
+            os._exit(4)
+        wd = threading.Timer(limit, _give_up)
+        wd.daemon = True
+        wd.start()
     replicas = world > 1 and os.environ.get("GPC_BENCH_REPLICAS", "0") == "1"
     # GPC_BENCH_GRID=1: drive the grid code path on ONE GPU too (1 x 1, no exchange) to price its overhead
     gridded = (world > 1 and not replicas) or os.environ.get("GPC_BENCH_GRID", "0") == "1"
