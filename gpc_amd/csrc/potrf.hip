@@ -2,22 +2,23 @@
 //
 // Replaces dpotrf_ as called by CMatrix::potrf / chol / jitChol (CMatrix.cpp:371-403, 767-804; lapack.h:59-65).
 //
-// Structure (SURVEY.md section 7 item 4):
-//   outer panels of NB columns (default 512).  After panel k is final its trailing update A22 -= L21 * L21' (depth NB,
-//   fp64 MFMA tiles of gemm_f64.hip, N^3/3 of the flops) is split in two launches:
+// Structure (DESIGN.md section 3.2):
+//   outer panels of NB = 1024 columns (panel_width()).  After panel k is final its trailing update A22 -= L21 * L21' (depth
+//   NB, the fp64 MFMA tiles of gemm_f64.hip, N^3/3 of the flops) is split in two launches:
 //       U1(k): the NB columns that form panel k+1 (lower trapezoid),   U2(k): everything to the right of them.
-//   LOOK-AHEAD: U1/U2 run on the caller's stream, the panels on a second, high-priority stream; panel k+1 starts as
-//   soon as U1(k) is done and is factored while U2(k) keeps every CU busy.  The chain of small latency-bound panel
-//   kernels (N/64 diagonal blocks) therefore disappears behind the SYRK as long as U2 is longer than a panel.
-//   inside a panel, JB = 64 columns at a time, three launches:
-//     1. potf2_kernel: one workgroup, the 64 x 64 diagonal block lives in REGISTERS (thread = one row x 16 columns,
-//        rotated so that the active column group is always register slot 0: the loop stays rolled and the code small,
-//        which matters more than anything else for a one-shot latency-bound kernel -- a fully unrolled version spent
-//        its time on instruction-cache misses); per column one LDS broadcast of the pivot column and one barrier;
-//     2. panel_trsm_kernel: L21 := A21 * L11^-T by true substitution, one wave per 64 rows, the 64-vector of a row
-//        handled in 16-wide register blocks (16 x 16 triangular solve in registers, rank-16 updates against LDS);
-//     3. the still-to-be-factored columns of the panel are updated with that 64-deep block column (MFMA GEMM, lower
-//        trapezoid).
+//   LOOK-AHEAD (N >= 28 672): U1/U2 run on the caller's stream, the panels on a second, high-priority stream (per host
+//   thread); panel k+1 starts as soon as U1(k) is done and is factored while U2(k) keeps every CU busy.
+//   Inside a panel, two levels: 128-column slabs of two 64-column steps, per slab
+//     potf2_blk_kernel          one workgroup, the 64 x 64 diagonal block in registers, columns 8 at a time (the four waves
+//                               exchange their shares through LDS once per 8 columns, every wave then factors the 64 x 8 block
+//                               redundantly with pivots and multipliers travelling through v_readlane);
+//     panel_step_kernel<UPD>    X = B L11^-T by true substitution for 64 rows per workgroup (four waves; 16 x 16 triangular
+//                               solves in registers, rank-16 updates against LDS), fused with the rank-64 update of the
+//                               slab's other 64 columns (every workgroup solves the 64 "ref" rows as well, from the copy
+//                               potf2 left aside);
+//     potf2 + panel_step_kernel the second 64 columns;
+//     one 128-deep MFMA product updates the rest of the panel (lower trapezoid).
+//   On panels taller than 24 576 rows the one-wave panel_trsm_kernel + GEMM pair replaces the fused step.
 //   A non-positive pivot writes the LAPACK `info` (1-based order of the failing minor) to a device word; later
 //   diagonal kernels turn into no-ops and the host reads the word once at the end.
 #include "gpc_common.hpp"
