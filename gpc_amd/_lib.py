@@ -54,6 +54,7 @@ SIGNATURES = {
     "gpc_potrf_f64": (c_int, [c_char, I64, DP, I64, POINTER(c_int), VP]),
     "gpc_chol_f64": (c_int, [c_char, I64, DP, I64, POINTER(c_int), VP]),
     "gpc_potri_f64": (c_int, [c_char, I64, DP, I64, VP]),
+    "gpc_chol_inverse_f64": (c_int, [I64, DP, I64, DP, I64, POINTER(c_double), POINTER(c_int), VP]),
     "gpc_trsm_f64": (c_int, [c_char, c_char, c_char, c_char, I64, I64, c_double, DP, I64, DP, I64, VP]),
     "gpc_logdet_chol_f64": (c_int, [I64, DP, I64, POINTER(c_double), VP]),
     "gpc_gemm_f64": (c_int, [c_char, c_char, I64, I64, I64, c_double, DP, I64, DP, I64, c_double, DP, I64, VP]),

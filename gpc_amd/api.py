@@ -148,6 +148,15 @@ def chol(A, uplo="U"):
     return info.value
 
 
+def chol_inverse(A, invK=None):
+    """A: K (lower read) -> L in its lower triangle; returns (invK full symmetric, logdet, info)."""
+    N = A.shape[0]
+    inv = invK if invK is not None else empty(N, N, A.device)
+    logdet, info = c_double(0.0), c_int(0)
+    check(lib().gpc_chol_inverse_f64(N, ptr(A), ld(A), ptr(inv), ld(inv), byref(logdet), byref(info), stream()))
+    return inv, logdet.value, info.value
+
+
 def potri(A, uplo="L"):
     check(lib().gpc_potri_f64(_c(uplo), A.shape[0], ptr(A), ld(A), stream()))
     return A

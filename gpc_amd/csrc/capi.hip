@@ -266,6 +266,60 @@ int gpc_potri_f64(char uplo, int64_t N, double* A, int64_t lda, void* stream)
   return potri_full(ul == 'L', N, A, lda, as_stream(stream));
 }
 
+int gpc_chol_inverse_f64(int64_t N, double* A, int64_t lda, double* invK, int64_t ldi, double* logdet, int* info, void* stream)
+{
+  GPC_CHECK(ensure_device());
+  GPC_REQUIRE(info != nullptr && invK != nullptr && N >= 0 && lda >= (N > 1 ? N : 1) && ldi >= (N > 1 ? N : 1), "chol_inverse args");
+  hipStream_t s = as_stream(stream);
+  *info = 0;
+  if(logdet) *logdet = 0.0;
+  if(N == 0) return GPC_OK;
+  void* wi = nullptr;
+  GPC_CHECK(workspace(WS_INFO, 64, &wi));
+  int* d_info = static_cast<int*>(wi);
+  GPC_HIP_CHECK(hipMemsetAsync(d_info, 0, sizeof(int), s));
+  if(N > 2048) {
+    // large matrices: the factorisation and dpotri as two calls (an augmented factorisation would triple the flops)
+    GPC_CHECK(potrf_lower(N, A, lda, d_info, s));
+    GPC_CHECK(read_info(d_info, info, s));
+    if(*info != 0) return GPC_OK;
+    if(logdet) {
+      double sl = 0.0;
+      GPC_CHECK(diag_reduce(1, N, A, lda, &sl, s));
+      *logdet = 2.0 * sl;
+    }
+    GPC_HIP_CHECK(hipMemcpy2DAsync(invK, sizeof(double) * (size_t)ldi, A, sizeof(double) * (size_t)lda, sizeof(double) * (size_t)N,
+                                   (size_t)N, hipMemcpyDeviceToDevice, s));
+    return potri_full(true, N, invK, ldi, s);
+  }
+  // Small matrices are bound by the N/64 dependent steps of the panel chain, not by flops: the inverse costs a second
+  // chain of the same length (dpotri's L^-T).  Factoring the 2N x N array [K; I] instead lets the identity ride through the
+  // SAME launches -- every panel solve and trailing update simply covers N more rows -- and leaves [L; L^-T]; the inverse
+  // is then one product, K^-1 = (L^-T)(L^-T)'.  Np = N rounded up to 16: the extra (zero) columns let that product take
+  // the fast MFMA kernel.
+  const int64_t Np = (N + 15) & ~(int64_t)15, ld2 = 2 * N + (2 * N) % 2;
+  void* wa = nullptr;
+  GPC_CHECK(workspace(WS_AUG, sizeof(double) * (size_t)ld2 * (size_t)Np, &wa));
+  double* W = static_cast<double*>(wa);
+  GPC_HIP_CHECK(hipMemcpy2DAsync(W, sizeof(double) * (size_t)ld2, A, sizeof(double) * (size_t)lda, sizeof(double) * (size_t)N,
+                                 (size_t)N, hipMemcpyDeviceToDevice, s));
+  GPC_CHECK(set_identity(N, N, W + N, ld2, s));
+  if(Np > N) GPC_HIP_CHECK(hipMemsetAsync(W + (size_t)N * ld2, 0, sizeof(double) * (size_t)ld2 * (size_t)(Np - N), s));
+  GPC_CHECK(potrf_lower_tall(2 * N, N, W, ld2, d_info, s));
+  GPC_CHECK(read_info(d_info, info, s));
+  if(*info != 0) return GPC_OK;
+  if(logdet) {
+    double sl = 0.0;
+    GPC_CHECK(diag_reduce(1, N, W, ld2, &sl, s));
+    *logdet = 2.0 * sl;
+  }
+  // L back into A.  (The whole block: W's upper triangle still holds the values it was given, i.e. A's own.)
+  GPC_HIP_CHECK(hipMemcpy2DAsync(A, sizeof(double) * (size_t)lda, W, sizeof(double) * (size_t)ld2, sizeof(double) * (size_t)N,
+                                 (size_t)N, hipMemcpyDeviceToDevice, s));
+  GPC_CHECK(gemm(false, true, N, N, Np, 1.0, W + N, ld2, W + N, ld2, 0.0, invK, ldi, 1, s));
+  return symmetrize(true, N, invK, ldi, s);
+}
+
 int gpc_trsm_f64(char side, char uplo, char trans, char diag, int64_t M, int64_t Nrhs, double alpha,
                  const double* A, int64_t lda, double* B, int64_t ldb, void* stream)
 {
@@ -300,6 +354,9 @@ int gpc_gemm_f64(char transa, char transb, int64_t M, int64_t N, int64_t K, doub
   GPC_REQUIRE(lda >= ((ta == 'N' ? M : K) > 1 ? (ta == 'N' ? M : K) : 1), "gemm lda");
   GPC_REQUIRE(ldb >= ((tb == 'N' ? K : N) > 1 ? (tb == 'N' ? K : N) : 1), "gemm ldb");
   GPC_REQUIRE(ldc >= (M > 1 ? M : 1), "gemm ldc");
+  // a tall matrix times a few columns (invK * m, K(X*, X) * Alpha): 128 x 128 MFMA tiles would leave most of the chip idle
+  if(ta == 'N' && tb == 'N' && N >= 1 && N <= 16 && M >= 256 && K >= 1)
+    return gemm_skinny(M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, as_stream(stream));
   return gemm(ta != 'N', tb != 'N', M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, 0, as_stream(stream));
 }
 

@@ -47,7 +47,8 @@ enum WorkspaceSlot {
   WS_POTRI = 5,       // trtri scratch
   WS_XSCALED = 6,     // reserved
   WS_PANEL_REF = 7,   // potrf panel chain: copy of the 64 rows under the diagonal block (panel_step_kernel)
-  WS_NSLOTS = 8
+  WS_AUG = 8,         // chol_inverse: the 2N x N array [K; I] -> [L; L^-T]
+  WS_NSLOTS = 9
 };
 int workspace(int slot, size_t bytes, void** out);
 // WS_INFO layout (64 bytes, zeroed when allocated): int[0] = LAPACK info of the running factorisation, int[4] = sticky
@@ -98,6 +99,11 @@ struct KStartScope {
 // col0: global index of A's first column, added to the `info` a failing pivot reports
 int potrf_lower(int64_t N, double* A, int64_t lda, int* d_info, hipStream_t s, int64_t col0 = 0);
 int potrf_panel(int64_t M, int64_t nb, double* A, int64_t lda, int* d_info, int64_t col0, hipStream_t s);
+int potrf_lower_tall(int64_t Nrows, int64_t Ncols, double* A, int64_t lda, int* d_info, hipStream_t s);
+// misc.hip: C (M x n, n <= 16) = alpha A (M x K) B (K x n) + beta C -- the skinny products of CGp / CGplvm (invK * m)
+int gemm_skinny(int64_t M, int64_t n, int64_t K, double alpha, const double* A, int64_t lda, const double* B, int64_t ldb,
+                double beta, double* C, int64_t ldc, hipStream_t s);
+int set_identity(int64_t M, int64_t N, double* B, int64_t ldb, hipStream_t s);   // trsm.hip: B(i,j) = (i == j)
 int trsm(char side, char uplo, char trans, char diag, int64_t M, int64_t Nrhs, double alpha, const double* A,
          int64_t lda, double* B, int64_t ldb, hipStream_t s);
 int potri_full(bool lower, int64_t N, double* A, int64_t lda, hipStream_t s);

@@ -159,6 +159,51 @@ __global__ void __launch_bounds__(256) colnorm2_kernel(const double* __restrict_
   if(threadIdx.x == 0) out[j] = r;
 }
 
+// C (M x n, n <= 16) = A (M x K) B (K x n): thread = row of A, B staged through LDS 64 k-rows at a time, K split over
+// grid.y with one partial per chunk (added in chunk order by skinny_combine_kernel: deterministic).
+constexpr int SK_N = 16, SK_KB = 64;
+__global__ void __launch_bounds__(256) gemm_skinny_kernel(const double* __restrict__ A, int64_t lda, const double* __restrict__ B,
+                                                          int64_t ldb, int64_t M, int n, int64_t K, int64_t kchunk,
+                                                          double* __restrict__ partial)
+{
+  __shared__ double Bs[SK_KB * SK_N];
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t kbeg = (int64_t)blockIdx.y * kchunk;
+  const int64_t kend = (kbeg + kchunk < K) ? (kbeg + kchunk) : K;
+  double acc[SK_N];
+#pragma unroll
+  for(int c = 0; c < SK_N; c++) acc[c] = 0.0;
+  for(int64_t k0 = kbeg; k0 < kend; k0 += SK_KB) {
+    const int lim = (int)((kend - k0 < SK_KB) ? (kend - k0) : SK_KB);
+    __syncthreads();
+    for(int idx = threadIdx.x; idx < SK_KB * SK_N; idx += 256) {
+      const int kk = idx % SK_KB, c = idx / SK_KB;
+      Bs[kk * SK_N + c] = (kk < lim && c < n) ? B[k0 + kk + (int64_t)c * ldb] : 0.0;
+    }
+    __syncthreads();
+    if(i < M) {
+      for(int kk = 0; kk < lim; kk++) {
+        const double a = A[i + (k0 + kk) * lda];
+#pragma unroll
+        for(int c = 0; c < SK_N; c++) acc[c] = fma(a, Bs[kk * SK_N + c], acc[c]);
+      }
+    }
+  }
+  if(i < M)
+    for(int c = 0; c < n; c++) partial[((int64_t)blockIdx.y * n + c) * M + i] = acc[c];
+}
+
+__global__ void __launch_bounds__(256) skinny_combine_kernel(const double* __restrict__ partial, int nchunks, int64_t M, int n,
+                                                             double alpha, double beta, double* __restrict__ C, int64_t ldc)
+{
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int c = blockIdx.y;
+  if(i >= M) return;
+  double acc = 0.0;
+  for(int q = 0; q < nchunks; q++) acc += partial[((int64_t)q * n + c) * M + i];
+  C[i + (int64_t)c * ldc] = alpha * acc + (beta != 0.0 ? beta * C[i + (int64_t)c * ldc] : 0.0);
+}
+
 // y := alpha*A*x + beta*y, A full symmetric storage: use columns (coalesced along i): y_i = sum_j A(i,j) x_j.
 // One thread per row i, loop over j in chunks staged through LDS for x.
 __global__ void __launch_bounds__(256) symv_kernel(const double* __restrict__ A, int64_t lda, int64_t N,
@@ -326,6 +371,30 @@ int add_diag(int64_t N, double* A, int64_t lda, double c, hipStream_t s)
 {
   if(N <= 0) return GPC_OK;
   hipLaunchKernelGGL(add_diag_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, A, lda, N, c);
+  GPC_HIP_CHECK(hipGetLastError());
+  return GPC_OK;
+}
+
+int gemm_skinny(int64_t M, int64_t n, int64_t K, double alpha, const double* A, int64_t lda, const double* B, int64_t ldb,
+                double beta, double* C, int64_t ldc, hipStream_t s)
+{
+  if(M <= 0 || n <= 0) return GPC_OK;
+  if(n > SK_N) return GPC_EINVAL;
+  const unsigned gx = (unsigned)((M + 255) / 256);
+  // enough column chunks for ~512 workgroups, each at least one staged block deep
+  int64_t ny = (512 + gx - 1) / gx;
+  const int64_t maxy = (K + SK_KB - 1) / SK_KB;
+  if(ny > maxy) ny = maxy;
+  if(ny < 1) ny = 1;
+  int64_t kchunk = ((K + ny - 1) / ny + SK_KB - 1) / SK_KB * SK_KB;
+  if(kchunk < SK_KB) kchunk = SK_KB;
+  ny = K > 0 ? (K + kchunk - 1) / kchunk : 1;
+  void* ws = nullptr;
+  GPC_CHECK(workspace(WS_REDUCE, sizeof(double) * (size_t)(ny * n * M), &ws));
+  double* partial = static_cast<double*>(ws);
+  hipLaunchKernelGGL(gemm_skinny_kernel, dim3(gx, (unsigned)ny), dim3(256), 0, s, A, lda, B, ldb, M, (int)n, K, kchunk, partial);
+  hipLaunchKernelGGL(skinny_combine_kernel, dim3(gx, (unsigned)n), dim3(256), 0, s, partial, (int)ny, M, (int)n, alpha, beta, C,
+                     ldc);
   GPC_HIP_CHECK(hipGetLastError());
   return GPC_OK;
 }

@@ -748,6 +748,27 @@ int potrf_lower(int64_t N, double* A, int64_t lda, int* d_info, hipStream_t s, i
   return GPC_OK;
 }
 
+// Right-looking Cholesky of the leading Ncols x Ncols block of a TALL array (Nrows >= Ncols rows): the rows below the
+// square take every panel solve and trailing update along, so an identity stored there comes out as L^-T (chol_inverse in
+// capi.hip).  Same panel chain, no look-ahead (small matrices only); the updates are lower trapezoids.
+int potrf_lower_tall(int64_t Nrows, int64_t Ncols, double* A, int64_t lda, int* d_info, hipStream_t s)
+{
+  int64_t nbk = 0;
+  for(int64_t k0 = 0; k0 < Ncols; k0 += nbk) {
+    const int64_t NB = panel_width(Ncols - k0);
+    nbk = (Ncols - k0 < NB) ? (Ncols - k0) : NB;
+    const int64_t kend = k0 + nbk;
+    GPC_CHECK(factor_panel(Nrows, A, lda, k0, nbk, d_info, s, 0));
+    const int64_t mc = Ncols - kend, mr = Nrows - kend;
+    if(mc > 0) {
+      const double* L21 = A + kend + k0 * lda;
+      TrailingScope role;
+      GPC_CHECK(gemm(false, true, mr, mc, nbk, -1.0, L21, lda, L21, lda, 1.0, A + kend + kend * lda, lda, 3, s));
+    }
+  }
+  return GPC_OK;
+}
+
 }  // namespace gpc
 
 extern "C" int gpc_set_potrf_blocking(int64_t nb_outer, int64_t jb_inner)

@@ -787,6 +787,16 @@ int trsm(char side, char uplo, char trans, char diag, int64_t M, int64_t Nrhs, d
   return trsm_impl(sd == 'L', ul == 'L', tc != 'N', dg == 'U', M, Nrhs, alpha, A, lda, B, ldb, false, s);
 }
 
+int set_identity(int64_t M, int64_t N, double* B, int64_t ldb, hipStream_t s)
+{
+  for(int64_t j0 = 0; j0 < N; j0 += 32768) {
+    const int64_t nc = (N - j0 < 32768) ? (N - j0) : 32768;
+    hipLaunchKernelGGL(set_identity_kernel, dim3((unsigned)((M + 255) / 256), (unsigned)nc), dim3(256), 0, s, B, ldb, M, j0);
+  }
+  GPC_HIP_CHECK(hipGetLastError());
+  return GPC_OK;
+}
+
 // A (factor in triangle uplo) -> full symmetric inverse of the factored matrix, in place (dpotri + mirror).
 //   lower: K^-1 = L^-T L^-1 = V V' with V = L^-T (upper triangular).
 //   1. V := I * L^-T by the right-side solve (side R, lower, transposed): its rank-512 updates X_b * L(rest, b)' are in

@@ -72,12 +72,10 @@ class CGplvm:
         ks = api.kspec(self.terms)
         N, d, q = self.N, self.d, self.q
         K = api.gram_sym(ks, self.X)                                  # _updateK, CGplvm.cpp:418-432
-        info = api.potrf(K, "L")                                      # _updateInvK: chol() -- no jitter here
+        # _updateInvK: chol() (no jitter here), logDet, pdinv in one pass (CGplvm.cpp:441-444)
+        invK, self.logDetK, info = api.chol_inverse(K)
         if info != 0:
             raise np.linalg.LinAlgError("MatrixNonPosDef: leading minor %d" % info)
-        self.logDetK = api.logdet_chol(K)
-        api.potri(K, "L")                                             # K now holds the full symmetric inverse
-        invK = K
         A = api.zeros(N, d, self.device)
         api.gemm(invK, self.m, A)                                     # invK * m  (dsymv per column in the reference)
         quad = api.coldot(A, self.m)

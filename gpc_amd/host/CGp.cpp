@@ -286,8 +286,17 @@ void CGp::updateK() const
   pkern->toKspec(ks);
   double jit = 0.0;
   int info = 0;
+  bool haveInverse = false;
+  if(needInverse && N <= 2048) {
+    // small model, gradient wanted: factor and inverse in ONE chain of launches (the identity rides through the
+    // factorisation, gpc_chol_inverse_f64); jitChol's schedule only if that attempt fails
+    if(!dInvK) dInvK = devAlloc((size_t)N * N);
+    gpcCheck(gpc_gram_sym_f64(&ks, dX, N, D, N, dL, N, 0));
+    gpcCheck(gpc_chol_inverse_f64(N, dL, N, dInvK, N, &logDetK, &info, 0));
+    haveInverse = info == 0;
+  }
   // _updateK + jitChol + logDet (CGp.cpp:698-712, 881-887) in one call: Gram, in-place lower Cholesky, log|K|
-  gpcCheck(gpc_gp_update_k_f64(&ks, dX, N, D, N, dL, N, &logDetK, &jit, &info, 0));
+  if(!haveInverse) gpcCheck(gpc_gp_update_k_f64(&ks, dX, N, D, N, dL, N, &logDetK, &jit, &info, 0));
   lastJitter = jit;
   if(info != 0) throw ndlexceptions::MatrixNonPosDef();
   if(jit > 1e-2 && getVerbosity() > 2)
@@ -296,7 +305,9 @@ void CGp::updateK() const
   gpcCheck(gpc_gp_alpha_f64(N, d, dL, N, dM, N, dInvKm, N, 0));
   quad.assign((size_t)d, 0.0);
   gpcCheck(gpc_coldot_f64(N, d, dM, N, dInvKm, N, &quad[0], 0));
-  if(needInverse) {
+  if(haveInverse) {
+    invKupToDate = true;
+  } else if(needInverse) {
     // invK.pdinv(LcholK) (CGp.cpp:889): only the gradient needs the explicit inverse
     if(!dInvK) dInvK = devAlloc((size_t)N * N);
     gpcCheck(gpc_memcpy_d2d(dInvK, dL, sizeof(double) * (size_t)N * N, 0));

@@ -77,7 +77,7 @@ void jacobiEig(std::vector<double>& a, int n, std::vector<double>& w, std::vecto
 
 CGplvm::CGplvm(CKern* kernel, CScaleNoise* nois, int latDim, int verbos)
     : pX(new CMatrix()), pkern(kernel), pnoise(nois), pYown(0), latentDim((unsigned int)latDim), dataDim(nois->getOutputDim()),
-      numData(nois->getNumData()), regulariseLatent(true), KupToDate(false), dX(0), dM(0), dK(0), dA(0), dG(0), dGX(0),
+      numData(nois->getNumData()), regulariseLatent(true), KupToDate(false), dX(0), dM(0), dK(0), dL(0), dA(0), dG(0), dGX(0),
       logDetK(0.0)
 {
   setVerbosity(verbos);
@@ -88,7 +88,7 @@ CGplvm::CGplvm(CKern* kernel, CScaleNoise* nois, int latDim, int verbos)
 
 CGplvm::CGplvm()
     : pX(new CMatrix()), pkern(0), pnoise(0), pYown(0), latentDim(0), dataDim(0), numData(0), regulariseLatent(true),
-      KupToDate(false), dX(0), dM(0), dK(0), dA(0), dG(0), dGX(0), logDetK(0.0)
+      KupToDate(false), dX(0), dM(0), dK(0), dL(0), dA(0), dG(0), dGX(0), logDetK(0.0)
 {
 }
 
@@ -108,6 +108,7 @@ void CGplvm::releaseDevice()
   devFree(dX);
   devFree(dM);
   devFree(dK);
+  devFree(dL);
   devFree(dA);
   devFree(dG);
   devFree(dGX);
@@ -190,12 +191,12 @@ void CGplvm::updateK() const
   gpcCheck(gpc_memcpy_h2d(dX, pX->getVals(), sizeof(double) * (size_t)N * q, 0));
   gpc_kspec ks;
   pkern->toKspec(ks);
-  gpcCheck(gpc_gram_sym_f64(&ks, dX, N, q, N, dK, N, 0));                 // _updateK, CGplvm.cpp:418-432
+  if(!dL) dL = devAlloc((size_t)N * N);
+  gpcCheck(gpc_gram_sym_f64(&ks, dX, N, q, N, dL, N, 0));                 // _updateK, CGplvm.cpp:418-432
   int info = 0;
-  gpcCheck(gpc_potrf_f64('L', N, dK, N, &info, 0));                       // LcholK.chol(), CGplvm.cpp:441
+  // LcholK.chol(), logDet(LcholK), invK.pdinv(LcholK) (CGplvm.cpp:441-444) in one pass: dL <- L, dK <- invK
+  gpcCheck(gpc_chol_inverse_f64(N, dL, N, dK, N, &logDetK, &info, 0));
   if(info != 0) throw ndlexceptions::MatrixNonPosDef();
-  gpcCheck(gpc_logdet_chol_f64(N, dK, N, &logDetK, 0));                   // logDet(LcholK), 442
-  gpcCheck(gpc_potri_f64('L', N, dK, N, 0));                              // invK.pdinv(LcholK), 444
   gpcCheck(gpc_gemm_f64('N', 'N', N, d, N, 1.0, dK, N, dM, N, 0.0, dA, N, 0));   // invK * m, column by column in 503 / 374
   quad.assign((size_t)d, 0.0);
   gpcCheck(gpc_coldot_f64(N, d, dA, N, dM, N, &quad[0], 0));

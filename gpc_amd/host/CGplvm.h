@@ -73,7 +73,8 @@ class CGplvm : public CProbabilisticOptimisable {
   mutable bool KupToDate;
   mutable double* dX;      // N x q
   mutable double* dM;      // N x d
-  mutable double* dK;      // N x N: K, then its factor, then invK (full symmetric)
+  mutable double* dK;      // N x N: invK (full symmetric)
+  mutable double* dL;      // N x N: K, then its lower factor
   mutable double* dA;      // N x d: invK * m
   mutable double* dG;      // N x N: summed covGrad
   mutable double* dGX;     // N x q

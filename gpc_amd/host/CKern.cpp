@@ -91,6 +91,47 @@ void CKern::compute(CMatrix& K, const CMatrix& X, const CMatrix& X2) const
   gpcCheck(gpc_gram_cross_f64(&ks, x.p, X.getRows(), ld(X), x2.p, X2.getRows(), ld(X2), X.getCols(), k.p, ld(K), 0));
   gpcCheck(gpc_stream_sync(0));
 }
+namespace {
+// the rows `idx` of X as a matrix of their own (BOUNDCHECK of the reference: an index past the data throws)
+void gatherRows(CMatrix& out, const CMatrix& X, const std::vector<unsigned int>& idx)
+{
+  out.resize((unsigned int)idx.size(), X.getCols());
+  for(unsigned int i = 0; i < idx.size(); i++) {
+    if(idx[i] >= X.getRows()) throw ndlexceptions::MatrixError("compute: row index outside the data");
+    out.copyRowRow(i, X, idx[i]);
+  }
+}
+}  // namespace
+
+void CKern::compute(CMatrix& K, const CMatrix& X1, const std::vector<unsigned int> indices1, const CMatrix& X2,
+                    const std::vector<unsigned int> indices2) const
+{
+  if(K.getRows() != indices1.size() || K.getCols() != indices2.size())
+    throw ndlexceptions::MatrixError("compute: K must be |indices1| x |indices2|");
+  if(indices1.empty() || indices2.empty()) return;
+  CMatrix A, B;
+  gatherRows(A, X1, indices1);
+  gatherRows(B, X2, indices2);
+  compute(K, A, B);
+}
+void CKern::compute(CMatrix& K, const CMatrix& X, const std::vector<unsigned int> indices) const
+{
+  if(K.getRows() != indices.size() || !K.isSquare()) throw ndlexceptions::MatrixError("compute: K must be |indices| x |indices|");
+  if(indices.empty()) return;
+  const bool wasSymmetric = K.isSymmetric();   // the reference's overload leaves the flag alone (CKern.h:111-126)
+  CMatrix A;
+  gatherRows(A, X, indices);
+  compute(K, A);
+  K.setSymmetric(wasSymmetric);
+}
+void CKern::compute(CMatrix& K, const CMatrix& X, const CMatrix& X2, unsigned int row) const
+{
+  if(!K.rowsMatch(X) || K.getCols() != 1) throw ndlexceptions::MatrixError("compute: K must be N x 1");
+  const std::vector<unsigned int> one(1, row);
+  CMatrix B;
+  gatherRows(B, X2, one);
+  compute(K, X, B);
+}
 void CKern::diagCompute(CMatrix& d, const CMatrix& X) const
 {
   if(!X.rowsMatch(d) || d.getCols() != 1) throw ndlexceptions::MatrixError("diagCompute: d must be N x 1");

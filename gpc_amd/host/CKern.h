@@ -35,6 +35,12 @@ class CKern : public CTransformable {
   // whole-matrix operations: libgpc_hip.so
   virtual void compute(CMatrix& K, const CMatrix& X) const;                       // CKern.h:128-144
   virtual void compute(CMatrix& K, const CMatrix& X, const CMatrix& X2) const;    // CKern.h:146-157
+  // selected rows / columns and a single column of the Gram matrix (CKern.h:94-126, 159-167): the rows are gathered on the
+  // host and go through the same device kernels
+  virtual void compute(CMatrix& K, const CMatrix& X1, const std::vector<unsigned int> indices1, const CMatrix& X2,
+                       const std::vector<unsigned int> indices2) const;
+  virtual void compute(CMatrix& K, const CMatrix& X, const std::vector<unsigned int> indices) const;
+  virtual void compute(CMatrix& K, const CMatrix& X, const CMatrix& X2, unsigned int row) const;
   virtual void diagCompute(CMatrix& d, const CMatrix& X) const;                   // CKern.h:49-55
   virtual void getGradParams(CMatrix& g, const CMatrix& X, const CMatrix& covGrad, bool regularise = true) const;
   void getGradTransParams(CMatrix& g, const CMatrix& X, const CMatrix& covGrad, bool regularise = true) const;

@@ -161,6 +161,26 @@ static int testGp(int argc, char** argv)
       worst = std::fmax(worst, std::fabs(e - K.getVal(i, j)));
     }
   std::printf("compute_vs_element %.3e\n", worst);
+  {
+    // the index / single-column overloads (CKern.h:94-126, 159-167) against whole-matrix entries
+    std::vector<unsigned int> a, b;
+    for(unsigned int i = 1; i < X.getRows(); i += 9) a.push_back(i);
+    for(unsigned int j = 0; j < X.getRows(); j += 13) b.push_back(X.getRows() - 1 - j);
+    CMatrix Kab((unsigned int)a.size(), (unsigned int)b.size()), Kaa((unsigned int)a.size(), (unsigned int)a.size()), kcol(X.getRows(), 1);
+    kern.compute(Kab, X, a, X, b);
+    kern.compute(Kaa, X, a);
+    kern.compute(kcol, X, X, 5);
+    double w2 = 0.0;
+    for(unsigned int i = 0; i < a.size(); i++) {
+      for(unsigned int j = 0; j < b.size(); j++) {
+        const double e = kern.computeElement(X, a[i], X, b[j]);   // cross form: white contributes nothing, also where a[i] == b[j]
+        w2 = std::fmax(w2, std::fabs(e - Kab.getVal(i, j)));
+      }
+      for(unsigned int j = 0; j < a.size(); j++) w2 = std::fmax(w2, std::fabs(K.getVal(a[i], a[j]) - Kaa.getVal(i, j)));
+    }
+    for(unsigned int i = 0; i < X.getRows(); i++) w2 = std::fmax(w2, std::fabs(kern.computeElement(X, i, X, 5) - kcol.getVal(i, 0)));
+    std::printf("index_overloads %.3e\n", w2);
+  }
   // setOptParams / getOptParams round trip marks K dirty and reproduces the likelihood
   model.setOptParams(params);
   std::printf("ll_roundtrip %.17g\n", model.logLikelihood());

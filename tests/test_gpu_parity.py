@@ -608,6 +608,50 @@ def test_cfg3_full_size_properties(api):
     assert torch.equal(inv[idx, :], inv[:, idx].t())
 
 
+@pytest.mark.parametrize("N", [1, 40, 64, 65, 500, 1000, 1023, 1100, 2048, 2049, 3000])
+def test_chol_inverse(api, N):
+    """gpc_chol_inverse_f64 (factor + log|K| + inverse in one pass; the augmented [K; I] factorisation up to N = 2048, the two
+    LAPACK steps beyond) against numpy and against gpc_potrf_f64 + gpc_potri_f64; a non-PD input reports LAPACK's info."""
+    import torch
+    rng = np.random.RandomState(N)
+    B = rng.randn(N, max(N // 2, 1))
+    K = B @ B.T / max(N // 2, 1) + np.eye(N) * (0.5 + rng.rand(N))
+    Kd = api.from_host(K)
+    inv, logdet, info = api.chol_inverse(Kd)
+    assert info == 0
+    Lref = np.linalg.cholesky(K)
+    assert abs(logdet - 2.0 * np.log(np.diag(Lref)).sum()) <= 1e-10 * max(1.0, abs(logdet))
+    L = np.tril(api.to_host(Kd))
+    assert np.abs(L - Lref).max() <= 1e-11 * np.abs(Lref).max()
+    assert np.array_equal(np.triu(api.to_host(Kd), 1), np.triu(K, 1))            # the other triangle is left alone, like dpotrf
+    invh = api.to_host(inv)
+    assert np.abs(invh @ K - np.eye(N)).max() < 1e-9
+    assert np.array_equal(invh, invh.T)
+    K2 = api.from_host(K)
+    assert api.potrf(K2, "L") == 0
+    api.potri(K2, "L")
+    assert np.abs(api.to_host(K2) - invh).max() <= 1e-10 * np.abs(invh).max()
+    if N >= 40:
+        Kbad = K.copy()
+        Kbad[30, 30] = -1.0
+        _, _, info = api.chol_inverse(api.from_host(Kbad))
+        assert info == 31
+
+
+@pytest.mark.parametrize("M,n,K", [(256, 1, 300), (1000, 12, 1000), (4096, 16, 777), (300, 3, 5000), (70000, 2, 64)])
+def test_skinny_products(api, M, n, K):
+    """gpc_gemm_f64 with a few right-hand columns takes the row-per-thread kernel (invK * m of CGp / CGplvm): against numpy,
+    with alpha / beta, and bitwise repeatable."""
+    rng = np.random.RandomState(M + n)
+    A, B, C = rng.randn(M, K), rng.randn(K, n), rng.randn(M, n)
+    Ad, Bd = api.from_host(A), api.from_host(B)
+    got = api.to_host(api.gemm(Ad, Bd, api.from_host(C), "N", "N", 0.7, -0.3))
+    want = 0.7 * A @ B - 0.3 * C
+    assert np.abs(got - want).max() <= 1e-12 * np.abs(want).max() * max(1.0, K / 100.0)
+    again = api.to_host(api.gemm(Ad, Bd, api.from_host(C), "N", "N", 0.7, -0.3))
+    assert np.array_equal(got, again)
+
+
 def test_cfg4_full_size_properties(api):
     """BASELINE config 4 at its full size on ONE GPU (N = 131 072, D = 16, rbf, gamma = 1; K is 137 GB, so there is room
     for one N x N matrix only): sampled columns of L L' against the Gram columns saved before the factorisation,

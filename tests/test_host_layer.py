@@ -139,6 +139,7 @@ def test_cgp_surface_against_reference_goldens(tmp_path, name, spec, seed, N, D)
     assert rel(v["var"], g["var"]) < 1e-8
     assert rel(v["errBar"], g["errBar"]) < 1e-8
     assert v["compute_vs_element"][0] < 1e-12
+    assert v["index_overloads"][0] < 1e-12
 
 
 @pytest.mark.gpu
