@@ -466,7 +466,7 @@ class GridGp {
     const int SP = lookahead ? ST_PANEL : ST_MAIN;
     GRID_CHECK(ops_->record(ev_ready_, ST_MAIN));
     if(SP != ST_MAIN) GRID_CHECK(ops_->wait(SP, ev_ready_));
-    GRID_CHECK(panel_phase(0, SP));
+    GRID_CHECK(panel_phase(0, SP, nullptr, nullptr));
     static const bool trace = getenv("GPC_GRID_TRACE") != nullptr;
 #define GRID_TRACE(what) do { if(trace) fprintf(stderr, "[%d,%d] k=%lld %s\n", r_, c_, (long long)k, what); } while(0)
     for(int64_t k = 0; k < L.T; k++) {
@@ -478,20 +478,29 @@ class GridGp {
       int64_t jfirst = jl0;
       if(k + 1 < L.T) {
         const bool next_col = (int)((k + 1) % pc_) == c_;
+        const bool next_diag = next_col && pr_ > 1 && (int)((k + 1) % pr_) == r_;   // this rank factors diagonal tile k+1
+        bool have_u1a = false;
         if(next_col && M > 0 && jl0 < L.Lc) {
-          // U1: the tiles of panel k+1 first, so that its factorisation overlaps the rest of this update
+          // U1: the tiles of panel k+1 first, so that its factorisation overlaps the rest of this update -- and of those
+          // the diagonal tile before the others (U1a): the next dpotrf waits for one tile, not for the whole tile column
           GRID_TRACE("U1");
-          GRID_CHECK(update(k, il0, jl0, 1, ST_MAIN));
+          if(next_diag && SP != ST_MAIN) {
+            GRID_CHECK(update(k, il0, jl0, 1, ST_MAIN, il0 + 1));
+            GRID_CHECK(ops_->record(ev_u1a_, ST_MAIN));
+            have_u1a = true;
+            GRID_CHECK(update(k, il0 + 1, jl0, 1, ST_MAIN));
+          } else {
+            GRID_CHECK(update(k, il0, jl0, 1, ST_MAIN));
+          }
           jfirst = jl0 + 1;
         }
         GRID_TRACE("events");
         if(SP != ST_MAIN) {
           GRID_CHECK(ops_->record(ev_u1_, ST_MAIN));
-          GRID_CHECK(ops_->wait(SP, ev_u1_));
           if(free_valid_[b ^ 1]) GRID_CHECK(ops_->wait(SP, ev_free_[b ^ 1]));   // update k-1 has released W/V[(k+1)&1]
         }
         GRID_TRACE("panel");
-        GRID_CHECK(panel_phase(k + 1, SP));
+        GRID_CHECK(panel_phase(k + 1, SP, have_u1a ? ev_u1a_ : (SP != ST_MAIN ? ev_u1_ : nullptr), SP != ST_MAIN ? ev_u1_ : nullptr));
       }
       GRID_TRACE("U2");
       if(M > 0 && jfirst < L.Lc) GRID_CHECK(update(k, il0, jfirst, L.Lc - jfirst, ST_MAIN));
@@ -755,6 +764,7 @@ class GridGp {
     }
     ev_ready_ = ops_->event_create();
     ev_u1_ = ops_->event_create();
+    ev_u1a_ = ops_->event_create();
     GRID_CHECK(ops_->alloc((void**)&info_dev_, 64));
     // column-panel offset table (see Stair2D): tile-major slots ordered by source process row when pr > 1, else the
     // rows of the row panel itself
@@ -792,7 +802,7 @@ class GridGp {
     if(voff_dev_) ops_->release(voff_dev_);
     info_dev_ = nullptr;
     voff_dev_ = nullptr;
-    void** evs[] = {&ev_panel_[0], &ev_panel_[1], &ev_free_[0], &ev_free_[1], &ev_ready_, &ev_u1_};
+    void** evs[] = {&ev_panel_[0], &ev_panel_[1], &ev_free_[0], &ev_free_[1], &ev_ready_, &ev_u1_, &ev_u1a_};
     for(void** e : evs)
       if(*e) {
         ops_->event_destroy(*e);
@@ -815,8 +825,10 @@ class GridGp {
     }
   }
 
-  // steps (1)-(4) of panel k on stream st; leaves W / V of parity k&1 complete and records ev_panel_[k&1]
-  int panel_phase(int64_t k, int st)
+  // steps (1)-(4) of panel k on stream st; leaves W / V of parity k&1 complete and records ev_panel_[k&1].
+  // before_potrf / before_solve: events of the update stream after which the diagonal tile / the whole tile column k carry
+  // the previous panel's update (null: same stream, nothing to wait for)
+  int panel_phase(int64_t k, int st, void* before_potrf, void* before_solve)
   {
     const Layout& L = L_;
     const int b = (int)(k & 1);
@@ -831,16 +843,21 @@ class GridGp {
       double* col = A_ + jl * nb_ * L.lld;
       if(pr_ == 1) {
         // the whole panel is local: diagonal block + the rows below it in one chain (dpotrf + dtrsm)
+        if(before_solve) GRID_CHECK(ops_->wait(st, before_solve));
         GRID_CHECK(ops_->potrf_panel(L.mloc - k * nb_, nb_, col + k * nb_, L.lld, k * nb_, info_dev_, st));
       } else {
         if(r_ == kr) {
           const int64_t il = k / pr_;
+          if(before_potrf) GRID_CHECK(ops_->wait(st, before_potrf));
           GRID_CHECK(ops_->potrf_tile(col + il * nb_, L.lld, nb_, k * nb_, info_dev_, st));
           GRID_CHECK(ops_->copy2d(Dg_[b], nb_, col + il * nb_, L.lld, nb_, nb_, st));
         }
         GRID_CHECK(comm_->bcast(Dg_[b], nb_ * nb_, kr, AX_COL, ops_.get(), st));
         count_coll(AX_COL, 8.0 * (double)(nb_ * nb_), r_ != kr);
-        if(M > 0) GRID_CHECK(ops_->trsm_rlt(Dg_[b], nb_, nb_, col + il0 * nb_, L.lld, M, st));
+        if(M > 0) {
+          if(before_solve) GRID_CHECK(ops_->wait(st, before_solve));
+          GRID_CHECK(ops_->trsm_rlt(Dg_[b], nb_, nb_, col + il0 * nb_, L.lld, M, st));
+        }
       }
       if(pc_ > 1 && M > 0) GRID_CHECK(ops_->copy2d(W_[b], ldw, col + il0 * nb_, L.lld, M, nb_, st));
     }
@@ -873,12 +890,15 @@ class GridGp {
     return GPC_OK;
   }
 
-  // A(I,J) -= W(I) V(J)' for local column tiles jl_first .. jl_first + ncolt - 1 and all rows below tile k
-  int update(int64_t k, int64_t il0, int64_t jl_first, int64_t ncolt, int st)
+  // A(I,J) -= W(I) V(J)' for local column tiles jl_first .. jl_first + ncolt - 1 and the rows below tile k -- all of them
+  // (il_begin = il0(k), il_end < 0) or the local row tiles il_begin .. il_end - 1 only
+  int update(int64_t k, int64_t il_begin, int64_t jl_first, int64_t ncolt, int st, int64_t il_end = -1)
   {
     const Layout& L = L_;
+    const int64_t il0 = L.il0(k);
     UpdateArgs u;
-    u.M = L.mloc - il0 * nb_;
+    u.M = (il_end < 0 ? L.mloc : il_end * nb_) - il_begin * nb_;
+    if(u.M <= 0) return GPC_OK;
     u.Ncols = ncolt * nb_;
     u.K = nb_;
     row_panel(k, u.W, u.ldw);
@@ -889,12 +909,14 @@ class GridGp {
       u.Vbase = u.W - il0 * nb_;     // row tile J of the row panel; voff = J * nb
       u.ldv = u.ldw;
     }
+    u.W += (il_begin - il0) * nb_;
+    il0_unused(il0);
     u.voff_dev = voff_dev_;
     u.voff_host = voff_host_.data();
-    u.C = A_ + il0 * nb_ + jl_first * nb_ * L.lld;
+    u.C = A_ + il_begin * nb_ + jl_first * nb_ * L.lld;
     u.ldc = L.lld;
     u.nb = nb_;
-    u.I0 = r_ + pr_ * il0;
+    u.I0 = r_ + pr_ * il_begin;
     u.J0 = c_ + pc_ * jl_first;
     u.jl0 = jl_first;
     u.pr = pr_;
@@ -903,11 +925,13 @@ class GridGp {
     double entries = 0.0;
     for(int64_t jl = jl_first; jl < jl_first + ncolt; jl++) {
       const int64_t J = c_ + pc_ * jl;
-      const int64_t ilf = Layout::first_after(J - 1, r_, pr_);   // first local row tile with I >= J
-      double rows = (double)(L.mloc - ilf * nb_);
+      int64_t ilf = Layout::first_after(J - 1, r_, pr_);   // first local row tile with I >= J
+      const bool diag_in_range = ilf >= il_begin && ilf < L.Lr && r_ + pr_ * ilf == J && (il_end < 0 || ilf < il_end);
+      if(ilf < il_begin) ilf = il_begin;
+      double rows = (double)((il_end < 0 ? L.mloc : il_end * nb_) - ilf * nb_);
       if(rows <= 0) continue;
       entries += rows * (double)nb_;
-      if(ilf < L.Lr && r_ + pr_ * ilf == J) entries -= 0.5 * (double)nb_ * (double)(nb_ - 1);
+      if(diag_in_range) entries -= 0.5 * (double)nb_ * (double)(nb_ - 1);
     }
     stats_.update_flops += 2.0 * (double)nb_ * entries;
     stats_.update_bytes += 8.0 * (double)nb_ * (double)(u.M + u.Ncols) + 16.0 * entries;
@@ -917,6 +941,8 @@ class GridGp {
     ops_->prof_update_end(st);
     return rc;
   }
+
+  static void il0_unused(int64_t) {}
 
   // sum over ALL columns (all ranks) of the squares of extra rows e0 .. e1-1
   int extra_sumsq(int64_t e0, int64_t e1, double* out)
@@ -941,7 +967,7 @@ class GridGp {
   int* info_dev_ = nullptr;
   int64_t* voff_dev_ = nullptr;
   std::vector<int64_t> voff_host_, slot_, region_start_;
-  void *ev_panel_[2] = {nullptr, nullptr}, *ev_free_[2] = {nullptr, nullptr}, *ev_ready_ = nullptr, *ev_u1_ = nullptr;
+  void *ev_panel_[2] = {nullptr, nullptr}, *ev_free_[2] = {nullptr, nullptr}, *ev_ready_ = nullptr, *ev_u1_ = nullptr, *ev_u1a_ = nullptr;
   bool free_valid_[2] = {false, false};
   bool factored_ = false, alpha_valid_ = false;
   double logdet_ = 0.0, jitter_ = 0.0;
