@@ -234,7 +234,10 @@ def main():
     ap.add_argument("--cpu-budget-s", type=float, default=25.0, help="time budget of the host dpotrf_ baseline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
-    args = ap.parse_args()
+    # the self-launched ranks get their arguments through the environment: torch.distributed.run's own parser claims
+    # anything after the script name that abbreviates one of ITS options (--n..., --no-...)
+    forwarded = os.environ.get("GPC_BENCH_ARGV")
+    args = ap.parse_args(json.loads(forwarded) if (forwarded and len(sys.argv) == 1) else None)
     if args.cpu_baseline_only:
         # child process of the N = 1 run: MKL's OpenMP runtime and the one PyTorch brings deadlock in one process, so the
         # host baseline runs in a process of its own (numpy + MKL only) and hands its JSON back on stdout
@@ -251,7 +254,8 @@ def main():
     if args.gpus > 1 and not launched:
         # no launcher: become one.  One process per GPU, rendezvous on 127.0.0.1 (the container hostname may not resolve).
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
-               "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+               "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)]
+        os.environ["GPC_BENCH_ARGV"] = json.dumps(sys.argv[1:])
         os.execv(sys.executable, cmd)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -268,11 +272,16 @@ def main():
     from gpc_amd import api, synth
 
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
-    if local_rank >= torch.cuda.device_count():
+    # GPC_BENCH_TRANSPORT=torch (a rehearsal of the multi-rank control flow where RCCL cannot run, e.g. N ranks on ONE GPU):
+    # the grid's exchange goes through torch.distributed (gloo, staged through the host) instead of RCCL, and ranks may
+    # share a device.  Never the default and labelled in the output: it is not the configuration the metric is about.
+    rehearsal = os.environ.get("GPC_BENCH_TRANSPORT", "rccl") == "torch"
+    if local_rank >= torch.cuda.device_count() and not rehearsal:
         sys.exit("bench.py: rank %d has no GPU (%d visible); refusing to share devices" % (rank, torch.cuda.device_count()))
-    torch.cuda.set_device(local_rank)
+    device = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(device)
     api.lib()
-    api.check(api.lib().gpc_set_device(local_rank))
+    api.check(api.lib().gpc_set_device(device))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("gloo")      # control plane only; the data path is RCCL inside libgpc_hip.so
@@ -316,10 +325,13 @@ def main():
         if pr * pc != world:
             sys.exit("bench.py: GPC_GRID=%s does not have %d ranks" % (shape, world))
         nb = int(os.environ.get("GPC_GRID_NB", "1024" if N >= 49152 else "512"))
-        uid = [grid.unique_id() if (rank == 0 and world > 1) else None]
-        if world > 1:
-            dist.broadcast_object_list(uid, src=0)
-        g = grid.create(rank, world, pr, pc, nb, uid[0])
+        if rehearsal and world > 1:
+            g = grid.create_transport(rank, pr, pc, nb, grid.torch_transport(rank, pr, pc))
+        else:
+            uid = [grid.unique_id() if (rank == 0 and world > 1) else None]
+            if world > 1:
+                dist.broadcast_object_list(uid, src=0)
+            g = grid.create(rank, world, pr, pc, nb, uid[0])
         if world > 1 and os.environ.get("GPC_BENCH_SELFCHECK", "1") == "1":
             # untimed: the grid must reproduce the single-GPU log-determinant of a small problem on every rank
             Xc, _ = synth.make_xy(8192, D, seed=99)
@@ -437,7 +449,7 @@ def main():
     if rank == 0:
         probe, ticks, tick_ghz = ctypes.c_double(0.0), ctypes.c_double(0.0), ctypes.c_double(0.0)
         api.check(api.lib().gpc_probe_mfma_f64(ctypes.byref(probe), ctypes.byref(ticks), ctypes.byref(tick_ghz), api.stream()))
-        cus = torch.cuda.get_device_properties(local_rank).multi_processor_count
+        cus = torch.cuda.get_device_properties(device).multi_processor_count
         achieved = syrk_flops / (syrk_ms * 1e-3) * 1e-12 if syrk_ms > 0 else 0.0
         potrf_flops = N ** 3 / 3.0
         traffic, traffic_src = pmc_traffic(args.workload if not args.n else "custom", g is None)
@@ -469,7 +481,8 @@ def main():
             inf = g.info()
             par = "%d x %d block-cyclic grid (nb=%d) over %d GPU%s, C++ driver below the C-ABI, %s, look-ahead 1" % (
                 inf["pr"], inf["pc"], inf["nb"], world, "" if world == 1 else "s",
-                "RCCL broadcasts of diagonal tile / row panel / column panel" if world > 1 else "no exchange")
+                ("REHEARSAL: exchange through torch.distributed/gloo, ranks may share a GPU -- not a measurement of the metric"
+                 if rehearsal else "RCCL broadcasts of diagonal tile / row panel / column panel") if world > 1 else "no exchange")
         else:
             par = "1 GPU" if world == 1 else "%d independent replicas (GPC_BENCH_REPLICAS=1)" % world
         out = {"metric": "N x N RBF Gram build + Cholesky factors/sec", "value": jobs * args.steps / dt,

@@ -292,6 +292,58 @@ class Transport(object):
                                     GridTransport.ALLREDUCE_MIN(_m))
 
 
+def torch_transport(rank, pr, pc, on_device=True):
+    """A Transport whose exchange is torch.distributed (whatever backend the default process group has; gloo stages
+    through the host).  Every process must call this (it creates the row / column groups collectively).  This is the
+    "bring your own transport" path of gpc_grid_create_transport; the RCCL path (create) needs none of it."""
+    import torch
+    import torch.distributed as dist
+    r, c = rank // pc, rank % pc
+    groups = {AXIS_WORLD: (None, list(range(pr * pc)))}
+    for rr in range(pr):                 # every process creates every group, in the same order
+        ranks = [rr * pc + cc for cc in range(pc)]
+        g = dist.new_group(ranks)
+        if rr == r:
+            groups[AXIS_ROW] = (g, ranks)
+    for cc in range(pc):
+        ranks = [rr * pc + cc for rr in range(pr)]
+        g = dist.new_group(ranks)
+        if cc == c:
+            groups[AXIS_COL] = (g, ranks)
+    lib = _lib.load() if on_device else None
+
+    def fetch(ptr, count, device_memory):
+        if not device_memory:
+            return torch.from_numpy(np.ctypeslib.as_array(ctypes.cast(ptr, ctypes.POINTER(ctypes.c_double)), shape=(count,)))
+        t = torch.empty(count, dtype=torch.float64)
+        _lib.check(lib.gpc_memcpy_d2h(t.data_ptr(), ptr, 8 * count, None))
+        return t
+
+    def store(ptr, t, count, device_memory):
+        if device_memory:
+            _lib.check(lib.gpc_memcpy_h2d(ptr, t.data_ptr(), 8 * count, None))
+
+    def bcast(ptr, count, root, axis):
+        g, ranks = groups[axis]
+        t = fetch(ptr, count, on_device)
+        dist.broadcast(t, ranks[root], group=g)
+        store(ptr, t, count, on_device)
+
+    def allreduce_sum(ptr, count, axis, buf_on_device):
+        g, ranks = groups[axis]
+        dev = bool(buf_on_device) and on_device
+        t = fetch(ptr, count, dev)
+        dist.all_reduce(t, group=g)
+        store(ptr, t, count, dev)
+
+    def allreduce_min(v):
+        t = torch.tensor([v], dtype=torch.int64)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return int(t.item())
+
+    return Transport(bcast, allreduce_sum, allreduce_min)
+
+
 def create_transport(rank, pr, pc, nb, transport, binding=None):
     b = binding or product_binding()
     h = c_void_p()

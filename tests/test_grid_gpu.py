@@ -258,3 +258,24 @@ print("RCCL-OK", path, g.stats()["collectives"])
     r = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
     out = r.stdout.decode()
     assert r.returncode == 0 and "RCCL-OK" in out, out
+
+
+def test_bench_multi_rank_control_flow_rehearsal():
+    """`bench.py --gpus 2` end to end where RCCL cannot run two ranks (one GPU): the self-launch under torch.distributed.run,
+    the start-up self-check, the barrier / max-over-ranks timing and the JSON line, with the grid's exchange routed through
+    torch.distributed (GPC_BENCH_TRANSPORT=torch) and the two ranks sharing the device.  The line says it is a rehearsal."""
+    import json
+    env = dict(os.environ, GPC_BENCH_TRANSPORT="torch")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "cfg2", "--steps", "2",
+                        "--warmup", "1", "--no-cpu-baseline"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    line = json.loads(r.stdout.decode().strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["value"] > 0
+    assert "REHEARSAL" in line["config"]["parallelism"] and "1 x 2" in line["config"]["parallelism"]
+    assert line["roofline"]["achieved"] > 0 and line["grid"]["rank0_collectives_per_step"] > 0
+    # without the rehearsal switch the second rank has no GPU of its own: the run must refuse, not degrade
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "cfg2", "--steps", "1",
+                        "--warmup", "0", "--no-cpu-baseline"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    import torch
+    if torch.cuda.device_count() < 2:
+        assert r.returncode != 0 and b"refusing to share devices" in r.stderr
