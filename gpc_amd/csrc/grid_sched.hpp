@@ -630,12 +630,16 @@ class GridGp {
     if(!alpha_valid_) GRID_CHECK(alpha(nullptr, 0));
     const int np = ks_.offs[ks_.n_terms];
     const int P = pr_ * pc_, me = r_ * pc_ + c_;
-    double* Lf = nullptr;
-    double* strip = nullptr;
-    double* Z = nullptr;
-    GRID_CHECK(ops_->alloc((void**)&Lf, sizeof(double) * (size_t)(L.Np * L.Np)));
-    int rc = ops_->alloc((void**)&strip, sizeof(double) * (size_t)(((L.T + pr_ - 1) / pr_) * nb_ * nb_ + 16));   // any row's strip
-    if(rc == GPC_OK) rc = ops_->alloc((void**)&Z, sizeof(double) * (size_t)(L.Np * nb_));
+    // the three gradient buffers live as long as the problem does (an optimiser calls this once per iteration; allocating
+    // 8 N^2 bytes each time would cost more than the solves)
+    const int64_t G = imax(1, 4096 / nb_);
+    int rc = GPC_OK;
+    if(!Lf_) rc = ops_->alloc((void**)&Lf_, sizeof(double) * (size_t)(L.Np * L.Np));
+    if(rc == GPC_OK && !strip_)
+      rc = ops_->alloc((void**)&strip_, sizeof(double) * (size_t)(((L.T + pr_ - 1) / pr_) * nb_ * nb_ + 16));   // any row's strip
+    if(rc == GPC_OK && !Zg_) rc = ops_->alloc((void**)&Zg_, sizeof(double) * (size_t)(L.Np * nb_ * G));
+    GRID_CHECK(rc);
+    double *Lf = Lf_, *strip = strip_, *Z = Zg_;
     // 1. replicate the lower tiles of the factor
     for(int64_t J = 0; J < L.T && rc == GPC_OK; J++) {
       const int jc = (int)(J % pc_);
@@ -656,12 +660,6 @@ class GridGp {
     // trailing block of the first; the columns of the later tiles just start with a few zero rows.
     std::vector<double> acc((size_t)imax(np, 1), 0.0), part((size_t)imax(np, 1), 0.0);
     double trace = 0.0;
-    const int64_t G = imax(1, 4096 / nb_);
-    if(rc == GPC_OK) {
-      ops_->release(Z);
-      Z = nullptr;
-      rc = ops_->alloc((void**)&Z, sizeof(double) * (size_t)(L.Np * nb_ * G));
-    }
     for(int64_t J0 = me; J0 < L.T && rc == GPC_OK; J0 += P * G) {
       int64_t cnt = 0;
       while(cnt < G && J0 + cnt * P < L.T) cnt++;
@@ -684,9 +682,6 @@ class GridGp {
         for(int p = 0; p < np; p++) acc[(size_t)p] += part[(size_t)p];
       }
     }
-    ops_->release(Lf);
-    ops_->release(strip);
-    ops_->release(Z);
     GRID_CHECK(rc);
     // the white terms see only the diagonal of covGrad (CWhiteKern::getGradParams, CKern.cpp:735-739)
     for(int t = 0; t < ks_.n_terms; t++)
@@ -792,7 +787,8 @@ class GridGp {
   void free_all()
   {
     if(!ops_) return;
-    double** ps[] = {&A_, &X_, &Xr_, &Xc_, &dg_, &Y_, &al_, &alr_, &t_, &Xs_, &W_[0], &W_[1], &V_[0], &V_[1], &Dg_[0], &Dg_[1]};
+    double** ps[] = {&A_, &X_, &Xr_, &Xc_, &dg_, &Y_, &al_, &alr_, &t_, &Xs_, &W_[0], &W_[1], &V_[0], &V_[1], &Dg_[0], &Dg_[1],
+                     &Lf_, &strip_, &Zg_};
     for(double** p : ps)
       if(*p) {
         ops_->release(*p);
@@ -910,7 +906,6 @@ class GridGp {
       u.ldv = u.ldw;
     }
     u.W += (il_begin - il0) * nb_;
-    il0_unused(il0);
     u.voff_dev = voff_dev_;
     u.voff_host = voff_host_.data();
     u.C = A_ + il_begin * nb_ + jl_first * nb_ * L.lld;
@@ -942,8 +937,6 @@ class GridGp {
     return rc;
   }
 
-  static void il0_unused(int64_t) {}
-
   // sum over ALL columns (all ranks) of the squares of extra rows e0 .. e1-1
   int extra_sumsq(int64_t e0, int64_t e1, double* out)
   {
@@ -964,6 +957,7 @@ class GridGp {
   double *A_ = nullptr, *X_ = nullptr, *Xr_ = nullptr, *Xc_ = nullptr, *dg_ = nullptr, *Y_ = nullptr, *al_ = nullptr,
          *alr_ = nullptr, *t_ = nullptr, *Xs_ = nullptr;
   double *W_[2] = {nullptr, nullptr}, *V_[2] = {nullptr, nullptr}, *Dg_[2] = {nullptr, nullptr};
+  double *Lf_ = nullptr, *strip_ = nullptr, *Zg_ = nullptr;   // gradient(): replicated factor, one strip in flight, the solves' block
   int* info_dev_ = nullptr;
   int64_t* voff_dev_ = nullptr;
   std::vector<int64_t> voff_host_, slot_, region_start_;
