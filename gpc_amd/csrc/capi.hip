@@ -97,6 +97,12 @@ static int read_info(int* d_info, int* info, hipStream_t s)
 {
   GPC_HIP_CHECK(hipMemcpyAsync(info, d_info, sizeof(int), hipMemcpyDeviceToHost, s));
   GPC_HIP_CHECK(hipStreamSynchronize(s));
+  if(*info == PANEL_FLOW_TIMEOUT) {
+    *info = 0;
+    set_error("the dataflow panel factorisation timed out (device shared or pre-empted?); the factor is unusable -- repeat the "
+              "call, or set GPC_PANEL_FLOW=0 for the launch chain");
+    return GPC_EHIP;
+  }
   return GPC_OK;
 }
 

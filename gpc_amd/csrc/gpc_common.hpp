@@ -45,10 +45,11 @@ enum WorkspaceSlot {
   WS_INFO = 3,        // device-side info / flags
   WS_KERN = 4,        // kernel-gradient partials
   WS_POTRI = 5,       // trtri scratch
-  WS_XSCALED = 6,     // reserved
+  WS_XSCALED = 6,     // Gram: inputs scaled by the ARD lengths
   WS_PANEL_REF = 7,   // potrf panel chain: copy of the 64 rows under the diagonal block (panel_step_kernel)
   WS_AUG = 8,         // chol_inverse: the 2N x N array [K; I] -> [L; L^-T]
-  WS_NSLOTS = 9
+  WS_FLOW = 9,        // panel_flow: exchange buffer + control words
+  WS_NSLOTS = 10
 };
 int workspace(int slot, size_t bytes, void** out);
 // WS_INFO layout (64 bytes, zeroed when allocated): int[0] = LAPACK info of the running factorisation, int[4] = sticky
@@ -99,6 +100,11 @@ struct KStartScope {
 // col0: global index of A's first column, added to the `info` a failing pivot reports
 int potrf_lower(int64_t N, double* A, int64_t lda, int* d_info, hipStream_t s, int64_t col0 = 0);
 int potrf_panel(int64_t M, int64_t nb, double* A, int64_t lda, int* d_info, int64_t col0, hipStream_t s);
+// panel_flow.hip: one panel (diagonal dpotrf + the rows below) as ONE dataflow launch; GPC_EUNSUPPORTED outside its domain
+int panel_flow(int64_t M, int64_t nbk, double* P, int64_t lda, int* d_info, int64_t col0, hipStream_t s);
+// ... and what it leaves in the info word when one of its polls was not answered within ~1 s (device shared or pre-empted):
+// not a LAPACK info, the factor is unusable.  Whoever reads the info word back reports an error.
+constexpr int PANEL_FLOW_TIMEOUT = (int)0x80000000;
 int potrf_lower_tall(int64_t Nrows, int64_t Ncols, double* A, int64_t lda, int* d_info, hipStream_t s);
 // misc.hip: C (M x n, n <= 16) = alpha A (M x K) B (K x n) + beta C -- the skinny products of CGp / CGplvm (invK * m)
 int gemm_skinny(int64_t M, int64_t n, int64_t K, double alpha, const double* A, int64_t lda, const double* B, int64_t ldb,

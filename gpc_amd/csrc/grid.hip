@@ -474,7 +474,12 @@ struct HipOps : GridOps {
     HIPOPS_CHECK(hipGetLastError());
     return GPC_OK;
   }
-  int read_info(const int* info_dev, int* out, int s) override { return download(out, info_dev, sizeof(int), s); }
+  int read_info(const int* info_dev, int* out, int s) override
+  {
+    const int rc = download(out, info_dev, sizeof(int), s);
+    if(rc == GPC_OK && *out == PANEL_FLOW_TIMEOUT) *out = -1;   // "this rank's factor is unusable" (GridGp::factor agrees on it)
+    return rc;
+  }
   void prof_update_begin(double flops, int s) override { gpc::prof_begin(PROF_SYRK, flops, st[s]); }
   void prof_update_end(int s) override { gpc::prof_end(PROF_SYRK, st[s]); }
 };

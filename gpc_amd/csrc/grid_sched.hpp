@@ -517,8 +517,12 @@ class GridGp {
     free_valid_[0] = free_valid_[1] = false;
     int inf = 0;
     GRID_CHECK(ops_->read_info(info_dev_, &inf, ST_MAIN));
-    int64_t v = inf > 0 ? (int64_t)inf : ((int64_t)1 << 60);
+    int64_t v = inf > 0 ? (int64_t)inf : (inf < 0 ? (int64_t)-1 : ((int64_t)1 << 60));
     GRID_CHECK(comm_->allmin_host(&v));
+    if(v < 0) {   // some rank's device-side factorisation gave up (a dataflow kernel's poll timed out): every rank reports it
+      factored_ = false;
+      return fail(GPC_EHIP, "factor: a rank's panel factorisation timed out (device shared or pre-empted?)");
+    }
     inf = v < ((int64_t)1 << 60) ? (int)v : 0;
     if(inf > L.N) inf = (int)L.N;   // (cannot happen: the padding is the identity)
     factored_ = inf == 0;

@@ -1,0 +1,452 @@
+// panel_flow.hip -- one Cholesky panel (dpotrf of the diagonal block + dtrsm of the rows below; CMatrix.cpp:371-403 via
+// lapack.h:59-65) as ONE dataflow launch instead of the five dependent launches per 128 columns of potrf.hip's chain.
+//
+// One workgroup per 64 x 64 block (b, c) of the panel's lower trapezoid, ids from a ticket counter in column-major order, so
+// that a workgroup only ever waits for blocks whose workgroups are already running or done: no deadlock whatever the
+// residency.  Block (b, c):
+//     C = A(b,c) - sum_{t<c} L(b,t) L(c,t)'       MFMA products, one 64-deep chunk per finished block pair, consumed AS THEY
+//                                                 APPEAR (so only the last chunk is ever on the critical path)
+//     b == c :  C = chol(C)                       the 64 x 64 block kernel of potrf.hip, published 8 columns at a time
+//     b >  c :  C = C L(c,c)^-T                   substitution as panel_step_kernel, consuming L(c,c) 16 columns at a time
+// Finished blocks are PUBLISHED into an exchange buffer that starts as a sentinel NaN payload arithmetic never produces;
+// consumers read it with device-scope atomic loads and poll the VALUES until they stop being the sentinel.  No flags and
+// no fences: the XCDs' L2s are not coherent with each other, so an agent-scope release / acquire fence costs an L2
+// write-back / invalidate per use (the first version of this kernel had two per column block and lost to the launch chain).
+// A poll that is not answered after ~1 s, or a non-positive pivot anywhere, raises ctl[1]; everybody then leaves (the host
+// sees LAPACK's info, or an error).  The critical path per 64 columns is chol(c,c) -> [the solve of (c+1,c) runs 16 columns
+// behind it] -> last product chunk of (c+1,c+1) -> chol(c+1,c+1).
+#include "gpc_common.hpp"
+
+namespace gpc {
+
+namespace {
+
+constexpr int PF_OS = 80;   // LDS stride of an operand stage [k][row] in doubles (= 16 mod 32: conflict-free fragment reads)
+constexpr int PF_SS = 65;   // LDS column stride of the working block S[c * PF_SS + r]
+constexpr int PF_LS = 66;   // row stride of the L image for the solve
+constexpr int PF_TS = 18;   // row stride of potf2's multiplier table
+
+struct PanelFlowArgs {
+  double* P;          // the panel: M rows x nbk columns, leading dimension lda
+  int64_t lda, M;
+  int nbk, ncb;       // columns, column blocks of 64 (the last one may be narrower)
+  int nrb;            // row blocks of 64
+  int64_t col0;       // global index of the panel's first column (for info)
+  int* info;          // LAPACK info word (device)
+  int* ctl;           // [0] ticket counter, [1] abort flag (1 = pivot failure, 2 = time-out)
+  int trace;          // measurement aid: stamp pf_trace
+  double* X;          // exchange buffer: every finished block, (64 nrb) x (64 ncb), leading dimension ldx
+  int64_t ldx;
+};
+
+constexpr unsigned long long PF_SENT = 0xFFF8C0DEFACE0002ull;
+
+__device__ __forceinline__ double pf_lane(double v, int lane)
+{
+  union { double d; int i[2]; } u;
+  u.d = v;
+  u.i[0] = __builtin_amdgcn_readlane(u.i[0], lane);
+  u.i[1] = __builtin_amdgcn_readlane(u.i[1], lane);
+  return u.d;
+}
+
+// one round of NV loads, `step` apart; true when none of this wave's values is the sentinel any more
+template <int NV>
+__device__ __forceinline__ bool pf_try(const double* p, int64_t step, double (&v)[NV])
+{
+  bool all = true;
+#pragma unroll
+  for(int i = 0; i < NV; i++) {
+    const unsigned long long u = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p + i * step), __ATOMIC_RELAXED,
+                                                   __HIP_MEMORY_SCOPE_AGENT);
+    all = all && (u != PF_SENT);
+    v[i] = __longlong_as_double((long long)u);
+  }
+  return __builtin_amdgcn_read_exec() == __builtin_amdgcn_ballot_w64(all);
+}
+
+// ... repeated until they are all there.  false = somebody raised the abort flag (or nobody answered).
+template <int NV>
+__device__ __forceinline__ bool pf_fetch(const PanelFlowArgs& g, const double* p, int64_t step, double (&v)[NV])
+{
+  for(int it = 0; it < (1 << 20); it++) {
+    if(pf_try<NV>(p, step, v)) return true;
+    if((it & 63) == 63 && __hip_atomic_load(&g.ctl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return false;
+    __builtin_amdgcn_s_sleep(1);
+  }
+  atomicCAS(&g.ctl[1], 0, 2);
+  atomicExch(g.info, PANEL_FLOW_TIMEOUT);   // the host turns this into an error (read_info)
+  return false;
+}
+
+__device__ __forceinline__ void pf_put(double* p, double x)
+{
+  __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), (unsigned long long)__double_as_longlong(x), __ATOMIC_RELAXED,
+                     __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__global__ void __launch_bounds__(256) panel_flow_init_kernel(int* ctl, unsigned long long* X, int64_t n)
+{
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if(i < 2) ctl[i] = 0;
+  if(i < n) X[i] = PF_SENT;
+}
+
+__device__ long long pf_trace[64 * 64 * 4];   // measurement aid (GPC_PANEL_FLOW_TRACE): per block (b < 64, c < 64) four stamps
+
+__global__ void __launch_bounds__(256) panel_flow_kernel(const PanelFlowArgs g)
+{
+  // one LDS arena, carved per phase:
+  //   products : As = arena[0 .. 64*OS), Bs = arena[64*OS .. 128*OS)
+  //   chol     : Pb = arena[0 .. 1024), T = arena[1024 .. 1024 + 64*TS)
+  //   solve    : Ls = arena[0 .. 64*LS), Dinv = next 64
+  __shared__ __attribute__((aligned(16))) double arena[2 * 64 * PF_OS];
+  __shared__ __attribute__((aligned(16))) double S[64 * PF_SS];
+  __shared__ int tk_s, giveup;
+  const int t = threadIdx.x, lane = t & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wm = wv & 1, wn = wv >> 1;
+  if(t == 0) {
+    tk_s = atomicAdd(&g.ctl[0], 1);
+    giveup = 0;
+  }
+  __syncthreads();
+  // ticket -> block, column-major over the trapezoid: column c holds row blocks c .. nrb-1
+  int c = 0, left = tk_s;
+  while(left >= g.nrb - c) {
+    left -= g.nrb - c;
+    c++;
+  }
+  const int b = c + left;
+  const int64_t r0 = (int64_t)b * 64;
+  const int nr = (int)((g.M - r0 < 64) ? (g.M - r0) : 64);        // real rows
+  const int ncol = (c == g.ncb - 1) ? (g.nbk - 64 * c) : 64;      // real columns
+  const bool diag = (b == c);
+  const bool tr = g.trace && b < 64 && t == 0;
+  if(tr) pf_trace[(b * 64 + c) * 4 + 0] = wall_clock64();
+
+  // my block of the input, S layout: thread (lane, wv) holds row `lane`, columns 16 wv + u
+  double a0[16];
+#pragma unroll
+  for(int u = 0; u < 16; u++) {
+    const int n = wv * 16 + u;
+    a0[u] = (lane < nr && n < ncol) ? g.P[r0 + lane + ((int64_t)c * 64 + n) * g.lda] : 0.0;
+  }
+
+  // ---- acc = sum_{t<c} L(b,t) L(c,t)' ------------------------------------------------------------------------------------------
+  double4_t acc[2][2];
+#pragma unroll
+  for(int i = 0; i < 2; i++)
+#pragma unroll
+    for(int j = 0; j < 2; j++) acc[i][j] = (double4_t){0.0, 0.0, 0.0, 0.0};
+  if(c > 0) {
+    double* As = arena;
+    double* Bs = arena + 64 * PF_OS;
+    const double* pa = g.X + r0 + lane + (int64_t)wv * g.ldx;                 // row `lane` of row block b, column wv + 4 i
+    const double* pb = g.X + (int64_t)c * 64 + lane + (int64_t)wv * g.ldx;    // ... of row block c
+    double va[16], vb[16];
+    bool lost = false;
+    auto fetch = [&](int tt) {
+      if(!pf_fetch<16>(g, pa + (int64_t)tt * 64 * g.ldx, 4 * g.ldx, va)) lost = true;
+      if(diag) {
+#pragma unroll
+        for(int i = 0; i < 16; i++) vb[i] = va[i];
+      } else if(!pf_fetch<16>(g, pb + (int64_t)tt * 64 * g.ldx, 4 * g.ldx, vb)) {
+        lost = true;
+      }
+    };
+    fetch(0);
+    for(int tt = 0; tt < c; tt++) {
+      __syncthreads();                                                   // the previous chunk's fragment reads are done
+#pragma unroll
+      for(int i = 0; i < 16; i++) {
+        As[(wv + 4 * i) * PF_OS + lane] = va[i];
+        Bs[(wv + 4 * i) * PF_OS + lane] = vb[i];
+      }
+      __syncthreads();
+      if(tt + 1 < c) fetch(tt + 1);
+#pragma unroll
+      for(int kk = 0; kk < 16; kk++) {
+        double a[2], bb[2];
+        const int kr = kk * 4 + (lane >> 4);
+#pragma unroll
+        for(int s = 0; s < 2; s++) {
+          a[s] = As[kr * PF_OS + wm * 32 + s * 16 + (lane & 15)];
+          bb[s] = Bs[kr * PF_OS + wn * 32 + s * 16 + (lane & 15)];
+        }
+#pragma unroll
+        for(int tn = 0; tn < 2; tn++)
+#pragma unroll
+          for(int tm = 0; tm < 2; tm++) acc[tm][tn] = __builtin_amdgcn_mfma_f64_16x16x4f64(bb[tn], a[tm], acc[tm][tn], 0, 0, 0);
+      }
+    }
+    if(lost) giveup = 1;
+  }
+  if(tr) pf_trace[(b * 64 + c) * 4 + 1] = wall_clock64();
+  // ---- S = A(b,c) - acc;  lane l, register r of acc[tm][tn]: m = wm*32 + tm*16 + (l & 15), n = wn*32 + tn*16 + (l >> 4) + 4 r
+#pragma unroll
+  for(int u = 0; u < 16; u++) S[(wv * 16 + u) * PF_SS + lane] = a0[u];
+  __syncthreads();   // (also: the arena is free, giveup is final)
+  if(giveup) return;
+  if(c > 0) {
+#pragma unroll
+    for(int tn = 0; tn < 2; tn++)
+#pragma unroll
+      for(int tm = 0; tm < 2; tm++)
+#pragma unroll
+        for(int r = 0; r < 4; r++) {
+          const int m = wm * 32 + tm * 16 + (lane & 15), n = wn * 32 + tn * 16 + (lane >> 4) + 4 * r;
+          if(m < nr && n < ncol) S[n * PF_SS + m] -= acc[tm][tn][r];
+        }
+    __syncthreads();
+  }
+  if(tr) pf_trace[(b * 64 + c) * 4 + 2] = wall_clock64();
+
+  if(diag) {
+    // ---- chol of the ncol x ncol block in S (potf2_blk_kernel of potrf.hip, columns 8 at a time), each group of 8 columns
+    //      normalised, stored and published as soon as it is final -------------------------------------------------------------
+    double* Pb = arena;
+    double* T = arena + 1024;
+    const int rr = lane, gq = wv;
+    const int n = ncol;
+    double a[16];          // column 4 q + gq of the block, row rr
+#pragma unroll
+    for(int q = 0; q < 16; q++) {
+      const int cc = 4 * q + gq;
+      double v = 0.0;
+      if(rr < n && cc < n) {
+        if(rr >= cc) v = S[cc * PF_SS + rr];
+      } else if(rr == cc) {
+        v = 1.0;
+      }
+      a[q] = v;
+    }
+    // normalise, store and publish this wave's two columns of a finished group: L(r, j) = w_j(r) sqrt(p_j(j))
+    auto publish = [&](int blk, const double (&p)[8], const double (&w)[8]) {
+#pragma unroll
+      for(int j = 0; j < 8; j++) {
+        if((j >> 1) == gq) {
+          const int cj = 8 * blk + j;
+          const double d = sqrt(pf_lane(p[j], cj));
+          const double lv = (rr == cj) ? d : ((rr > cj) ? w[j] * d : 0.0);        // (identity in the padding: p_j(j) = 1 there)
+          if(rr < nr && cj < n && rr >= cj) g.P[r0 + rr + ((int64_t)c * 64 + cj) * g.lda] = lv;
+          pf_put(&g.X[r0 + rr + ((int64_t)c * 64 + cj) * g.ldx], lv);
+        }
+      }
+    };
+    // fast path, everything static: no branch inside a group; a pivot outside [1e-280, 1e280] (or not positive) only
+    // clears `safe`, and the group is then redone by the careful loop below
+    int done = 0;
+    bool safe = true;
+#pragma unroll
+    for(int blk = 0; blk < 8; blk++) {
+      if(safe) {
+        double* Pc = Pb + (blk & 1) * 512;
+        const bool fine = (g.trace == 2) && b == 0 && t == 0;
+        if(fine) pf_trace[63 * 256 + blk * 8 + 0] = wall_clock64();
+        if(fine) pf_trace[63 * 256 + blk * 8 + 5] = clock64();
+        Pc[gq * 64 + rr] = a[2 * blk];
+        Pc[(4 + gq) * 64 + rr] = a[2 * blk + 1];
+        __syncthreads();
+        if(fine) pf_trace[63 * 256 + blk * 8 + 1] = wall_clock64();
+        double p[8], w[8];
+#pragma unroll
+        for(int j = 0; j < 8; j++) p[j] = Pc[j * 64 + rr];
+        bool ok = true;
+#pragma unroll
+        for(int j = 0; j < 8; j++) {
+          const double pj = pf_lane(p[j], 8 * blk + j);
+          ok = ok && (pj > 1e-280) && (pj < 1e280);
+          double xx = __builtin_amdgcn_rcp(pj);
+          double e = fma(-pj, xx, 1.0);
+          xx = fma(xx, e, xx);
+          e = fma(-pj, xx, 1.0);
+          const double rp = fma(xx, e, xx);
+          w[j] = p[j] * rp;
+#pragma unroll
+          for(int cc = j + 1; cc < 8; cc++) p[cc] -= w[j] * pf_lane(p[j], 8 * blk + cc);
+        }
+        if(fine) pf_trace[63 * 256 + blk * 8 + 2] = wall_clock64();
+        if(ok) {
+          publish(blk, p, w);
+          if(fine) pf_trace[63 * 256 + blk * 8 + 3] = wall_clock64();
+          if(blk + 1 < 8) {
+#pragma unroll
+            for(int j = 0; j < 8; j++) T[rr * PF_TS + j] = p[j];
+#pragma unroll
+            for(int q = 2 * blk + 2; q < 16; q++) {
+              const double* tc = &T[(4 * q + gq) * PF_TS];
+              double s0 = a[q], s1 = 0.0;
+#pragma unroll
+              for(int j = 0; j < 8; j += 2) {
+                s0 -= w[j] * tc[j];
+                s1 -= w[j + 1] * tc[j + 1];
+              }
+              a[q] = s0 + s1;
+            }
+          }
+          done = blk + 1;
+          if(fine) pf_trace[63 * 256 + blk * 8 + 4] = wall_clock64();
+        } else {
+          safe = false;
+        }
+      }
+    }
+    if(!safe) {
+      // the careful loop (exact division, LAPACK's info on a non-positive pivot), from the first group the fast path refused
+      for(int sh = 0; sh < done; sh++) {
+#pragma unroll
+        for(int q = 0; q < 14; q++) a[q] = a[q + 2];
+      }
+      __syncthreads();
+      bool failed = false;
+#pragma unroll 1
+      for(int blk = done; blk < 8; blk++) {
+        double* Pc = Pb + (blk & 1) * 512;
+#pragma unroll
+        for(int i = 0; i < 2; i++) Pc[(4 * i + gq) * 64 + rr] = a[i];
+        __syncthreads();
+        double p[8], w[8];
+#pragma unroll
+        for(int j = 0; j < 8; j++) p[j] = Pc[j * 64 + rr];
+#pragma unroll
+        for(int j = 0; j < 8; j++) {
+          const int cj = 8 * blk + j;
+          const double pj = pf_lane(p[j], cj);
+          if(!(pj > 0.0)) {
+            if(t == 0) {
+              atomicCAS(g.info, 0, (int)(g.col0 + 64 * c + cj + 1));
+              atomicCAS(&g.ctl[1], 0, 1);
+            }
+            failed = true;
+            break;
+          }
+          w[j] = p[j] * (1.0 / pj);
+#pragma unroll
+          for(int cc = j + 1; cc < 8; cc++) p[cc] -= w[j] * pf_lane(p[j], 8 * blk + cc);
+        }
+        if(failed) break;   // the pivot is wave-uniform and the same in all four waves: the whole workgroup leaves
+        publish(blk, p, w);
+        if(blk + 1 < 8) {
+#pragma unroll
+          for(int j = 0; j < 8; j++) T[rr * PF_TS + j] = p[j];
+#pragma unroll
+          for(int q = 2; q < 16; q++) {
+            const int cc = 8 * blk + 4 * q + gq;
+            if(cc < 64) {
+              const double* tc = &T[cc * PF_TS];
+              double s = a[q];
+#pragma unroll
+              for(int j = 0; j < 8; j++) s -= w[j] * tc[j];
+              a[q] = s;
+            }
+          }
+#pragma unroll
+          for(int q = 0; q < 14; q++) a[q] = a[q + 2];
+        }
+      }
+    }
+  } else {
+    // ---- C = C L(c,c)^-T by substitution (panel_step_kernel of potrf.hip: 16-column blocks, four waves), L(c,c) taken from
+    //      the exchange buffer 16 columns at a time, as its workgroup finishes them --------------------------------------------
+    double* Ls = arena;
+    double* Dinv = arena + 64 * PF_LS;
+    const double* Lx = g.X + (int64_t)c * 64 + lane + ((int64_t)c * 64 + wv * 4) * g.ldx;   // L(c,c)(lane, 16 blk + 4 wv + u)
+    const bool wanted = (c + 1 < g.ncb);                                                     // somebody's product operand
+    double lv[4];
+    bool have = pf_try<4>(Lx, g.ldx, lv);
+    double x[16];
+#pragma unroll 1
+    for(int blk = 0; blk < 4; blk++) {
+      const int o = blk * 16;
+      if(!have && !pf_fetch<4>(g, Lx + (int64_t)o * g.ldx, g.ldx, lv)) giveup = 1;
+#pragma unroll
+      for(int u = 0; u < 4; u++) Ls[lane * PF_LS + o + wv * 4 + u] = lv[u];
+      __syncthreads();
+      if(giveup) return;
+      if(t < 16) Dinv[o + t] = 1.0 / Ls[(o + t) * PF_LS + o + t];
+      if(blk + 1 < 4) have = pf_try<4>(Lx + (int64_t)(o + 16) * g.ldx, g.ldx, lv);          // in flight during this block's work
+      __syncthreads();
+#pragma unroll
+      for(int i = 0; i < 16; i++) x[i] = S[(o + i) * PF_SS + lane];
+#pragma unroll
+      for(int i = 0; i < 16; i++) {
+        double s = x[i];
+#pragma unroll
+        for(int k = 0; k < i; k++) s -= x[k] * Ls[(o + i) * PF_LS + o + k];
+        x[i] = s * Dinv[o + i];
+      }
+#pragma unroll 2
+      for(int cc = o + 16 + wv; cc < 64; cc += 4) {
+        const double* lc = &Ls[cc * PF_LS + o];
+        double s0 = S[cc * PF_SS + lane], s1 = 0.0, s2 = 0.0, s3 = 0.0;
+#pragma unroll
+        for(int k = 0; k < 16; k += 4) {
+          s0 -= x[k] * lc[k];
+          s1 -= x[k + 1] * lc[k + 1];
+          s2 -= x[k + 2] * lc[k + 2];
+          s3 -= x[k + 3] * lc[k + 3];
+        }
+        S[cc * PF_SS + lane] = (s0 + s1) + (s2 + s3);
+      }
+      // these 16 columns are final: store and publish them (wave wv: columns o + 4 wv + u)
+#pragma unroll
+      for(int i = 0; i < 16; i++) {
+        if((i >> 2) == wv) {
+          if(lane < nr) g.P[r0 + lane + ((int64_t)c * 64 + o + i) * g.lda] = x[i];
+          if(wanted) pf_put(&g.X[r0 + lane + ((int64_t)c * 64 + o + i) * g.ldx], x[i]);
+        }
+      }
+      __syncthreads();
+    }
+  }
+  if(tr) pf_trace[(b * 64 + c) * 4 + 3] = wall_clock64();
+}
+
+}  // namespace
+
+// Factor the nbk-column panel whose diagonal block starts at P (M rows, M >= nbk): one launch.  Returns GPC_EUNSUPPORTED
+// when the shape is outside what the kernel takes (the caller then runs the launch chain).
+int panel_flow(int64_t M, int64_t nbk, double* P, int64_t lda, int* d_info, int64_t col0, hipStream_t s)
+{
+  if(M < nbk || nbk <= 0 || nbk > 4096) return GPC_EUNSUPPORTED;
+  const int64_t nrb = (M + 63) / 64;
+  const int ncb = (int)((nbk + 63) / 64);
+  // the last diagonal block may be narrower than 64, but then it has to be the last ROW block too (a panel that ends the matrix)
+  if(nbk % 64 != 0 && M != nbk) return GPC_EUNSUPPORTED;
+  const int64_t ldx = 64 * nrb, nx = ldx * 64 * ncb;
+  void* ws = nullptr;
+  GPC_CHECK(workspace(WS_FLOW, sizeof(double) * (size_t)nx + 64, &ws));
+  double* X = static_cast<double*>(ws);
+  int* ctl = reinterpret_cast<int*>(X + nx);
+  hipLaunchKernelGGL(panel_flow_init_kernel, dim3((unsigned)((nx + 255) / 256)), dim3(256), 0, s, ctl,
+                     reinterpret_cast<unsigned long long*>(X), nx);
+  PanelFlowArgs g;
+  g.P = P;
+  g.lda = lda;
+  g.M = M;
+  g.nbk = (int)nbk;
+  g.ncb = ncb;
+  g.nrb = (int)nrb;
+  g.col0 = col0;
+  g.info = d_info;
+  g.ctl = ctl;
+  g.X = X;
+  g.ldx = ldx;
+  static const int trace = [] { const char* e = getenv("GPC_PANEL_FLOW_TRACE"); return e ? atoi(e) : 0; }();
+  g.trace = trace;
+  const int64_t nblocks = (int64_t)ncb * nrb - (int64_t)ncb * (ncb - 1) / 2;
+  hipLaunchKernelGGL(panel_flow_kernel, dim3((unsigned)nblocks), dim3(256), 0, s, g);
+  GPC_HIP_CHECK(hipGetLastError());
+  return GPC_OK;
+}
+
+}  // namespace gpc
+
+// measurement aid: the stamps of the last traced panel_flow launch (wall_clock64 ticks, 100 MHz), [row block][column block][4]
+extern "C" int gpc_debug_panel_flow_trace(long long* out, int64_t n)
+{
+  if(n > 64 * 64 * 4) n = 64 * 64 * 4;
+  GPC_HIP_CHECK(hipMemcpyFromSymbol(out, HIP_SYMBOL(gpc::pf_trace), sizeof(long long) * (size_t)n));
+  return GPC_OK;
+}

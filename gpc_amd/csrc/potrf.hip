@@ -584,6 +584,19 @@ int ensure_lookahead()
 constexpr int64_t SLAB = 128;
 int factor_panel(int64_t N, double* A, int64_t lda, int64_t k0, int64_t nbk, int* d_info, hipStream_t s, int64_t col0 = 0)
 {
+  // short panels: the whole panel as one dataflow launch (panel_flow.hip) instead of five launches per 128 columns
+  static int flow = -1;
+  static int64_t flow_maxrows = 0;
+  if(flow < 0) {
+    const char* e = getenv("GPC_PANEL_FLOW");
+    flow = e ? atoi(e) : 1;
+    const char* m = getenv("GPC_PANEL_FLOW_MAXROWS");
+    flow_maxrows = m ? atoll(m) : 16384;
+  }
+  if(flow && N - k0 <= flow_maxrows) {
+    const int rc = panel_flow(N - k0, nbk, A + k0 + k0 * lda, lda, d_info, col0 + k0, s);
+    if(rc != GPC_EUNSUPPORTED) return rc;
+  }
   const int64_t kend = k0 + nbk;
   // the four-wave / fused step kernels win while the panel is short (the chain is latency-bound: 0.65 -> 0.57 ms for a
   // 16 384 x 512 panel, 13.5 -> 12.4 ms for the whole N = 8192 factorisation); on a tall panel the one-wave solve +
