@@ -99,7 +99,7 @@ __global__ void __launch_bounds__(256) panel_flow_kernel(const PanelFlowArgs g)
   // one LDS arena, carved per phase:
   //   products : As = arena[0 .. 64*OS), Bs = arena[64*OS .. 128*OS)
   //   chol     : Pb = arena[0 .. 1024), T = arena[1024 .. 1024 + 64*TS)
-  //   solve    : Ls = arena[0 .. 64*LS), Dinv = next 64
+  //   solve    : Ls = arena[0 .. 64*LS), Xs = next 16*OS
   __shared__ __attribute__((aligned(16))) double arena[2 * 64 * PF_OS];
   __shared__ __attribute__((aligned(16))) double S[64 * PF_SS];
   __shared__ int tk_s, giveup;
@@ -125,13 +125,18 @@ __global__ void __launch_bounds__(256) panel_flow_kernel(const PanelFlowArgs g)
   const bool tr = g.trace && b < 64 && t == 0;
   if(tr) pf_trace[(b * 64 + c) * 4 + 0] = wall_clock64();
 
-  // my block of the input, S layout: thread (lane, wv) holds row `lane`, columns 16 wv + u
-  double a0[16];
+  // my block of the input, in the accumulator layout of the products below: lane l, register r of tile (tm, tn) holds
+  // row m = wm*32 + tm*16 + (l & 15), column n = wn*32 + tn*16 + (l >> 4) + 4 r
+  double4_t a0[2][2];
 #pragma unroll
-  for(int u = 0; u < 16; u++) {
-    const int n = wv * 16 + u;
-    a0[u] = (lane < nr && n < ncol) ? g.P[r0 + lane + ((int64_t)c * 64 + n) * g.lda] : 0.0;
-  }
+  for(int tn = 0; tn < 2; tn++)
+#pragma unroll
+    for(int tm = 0; tm < 2; tm++)
+#pragma unroll
+      for(int r = 0; r < 4; r++) {
+        const int m = wm * 32 + tm * 16 + (lane & 15), n = wn * 32 + tn * 16 + (lane >> 4) + 4 * r;
+        a0[tm][tn][r] = (m < nr && n < ncol) ? g.P[r0 + m + ((int64_t)c * 64 + n) * g.lda] : 0.0;
+      }
 
   // ---- acc = sum_{t<c} L(b,t) L(c,t)' ------------------------------------------------------------------------------------------
   double4_t acc[2][2];
@@ -155,8 +160,8 @@ __global__ void __launch_bounds__(256) panel_flow_kernel(const PanelFlowArgs g)
         lost = true;
       }
     };
-    fetch(0);
-    for(int tt = 0; tt < c; tt++) {
+    if(c > 1) fetch(0);
+    for(int tt = 0; tt + 1 < c; tt++) {
       __syncthreads();                                                   // the previous chunk's fragment reads are done
 #pragma unroll
       for(int i = 0; i < 16; i++) {
@@ -164,7 +169,7 @@ __global__ void __launch_bounds__(256) panel_flow_kernel(const PanelFlowArgs g)
         Bs[(wv + 4 * i) * PF_OS + lane] = vb[i];
       }
       __syncthreads();
-      if(tt + 1 < c) fetch(tt + 1);
+      if(tt + 2 < c) fetch(tt + 1);
 #pragma unroll
       for(int kk = 0; kk < 16; kk++) {
         double a[2], bb[2];
@@ -180,26 +185,60 @@ __global__ void __launch_bounds__(256) panel_flow_kernel(const PanelFlowArgs g)
           for(int tm = 0; tm < 2; tm++) acc[tm][tn] = __builtin_amdgcn_mfma_f64_16x16x4f64(bb[tn], a[tm], acc[tm][tn], 0, 0, 0);
       }
     }
+    // the last pair of blocks, (b, c-1) and (c, c-1), is the one still being solved when this block sits on the critical
+    // path: taken 16 columns at a time, as the solves publish them, so that only a 16-deep product follows the last piece
+    {
+      const double* qa = pa + (int64_t)(c - 1) * 64 * g.ldx;
+      const double* qb = pb + (int64_t)(c - 1) * 64 * g.ldx;
+#pragma unroll 1
+      for(int sub = 0; sub < 4; sub++) {
+        double ua[4], ub[4];
+        if(!pf_fetch<4>(g, qa + (int64_t)sub * 16 * g.ldx, 4 * g.ldx, ua)) lost = true;
+        if(diag) {
+#pragma unroll
+          for(int i = 0; i < 4; i++) ub[i] = ua[i];
+        } else if(!pf_fetch<4>(g, qb + (int64_t)sub * 16 * g.ldx, 4 * g.ldx, ub)) {
+          lost = true;
+        }
+        __syncthreads();
+#pragma unroll
+        for(int i = 0; i < 4; i++) {
+          As[(wv + 4 * i) * PF_OS + lane] = ua[i];
+          Bs[(wv + 4 * i) * PF_OS + lane] = ub[i];
+        }
+        __syncthreads();
+#pragma unroll
+        for(int kk = 0; kk < 4; kk++) {
+          double a[2], bb[2];
+          const int kr = kk * 4 + (lane >> 4);
+#pragma unroll
+          for(int s = 0; s < 2; s++) {
+            a[s] = As[kr * PF_OS + wm * 32 + s * 16 + (lane & 15)];
+            bb[s] = Bs[kr * PF_OS + wn * 32 + s * 16 + (lane & 15)];
+          }
+#pragma unroll
+          for(int tn = 0; tn < 2; tn++)
+#pragma unroll
+            for(int tm = 0; tm < 2; tm++) acc[tm][tn] = __builtin_amdgcn_mfma_f64_16x16x4f64(bb[tn], a[tm], acc[tm][tn], 0, 0, 0);
+        }
+      }
+    }
     if(lost) giveup = 1;
   }
   if(tr) pf_trace[(b * 64 + c) * 4 + 1] = wall_clock64();
-  // ---- S = A(b,c) - acc;  lane l, register r of acc[tm][tn]: m = wm*32 + tm*16 + (l & 15), n = wn*32 + tn*16 + (l >> 4) + 4 r
-#pragma unroll
-  for(int u = 0; u < 16; u++) S[(wv * 16 + u) * PF_SS + lane] = a0[u];
-  __syncthreads();   // (also: the arena is free, giveup is final)
+  // ---- S = A(b,c) - acc -------------------------------------------------------------------------------------------------
+  __syncthreads();   // the arena is free, giveup is final
   if(giveup) return;
-  if(c > 0) {
 #pragma unroll
-    for(int tn = 0; tn < 2; tn++)
+  for(int tn = 0; tn < 2; tn++)
 #pragma unroll
-      for(int tm = 0; tm < 2; tm++)
+    for(int tm = 0; tm < 2; tm++)
 #pragma unroll
-        for(int r = 0; r < 4; r++) {
-          const int m = wm * 32 + tm * 16 + (lane & 15), n = wn * 32 + tn * 16 + (lane >> 4) + 4 * r;
-          if(m < nr && n < ncol) S[n * PF_SS + m] -= acc[tm][tn][r];
-        }
-    __syncthreads();
-  }
+      for(int r = 0; r < 4; r++) {
+        const int m = wm * 32 + tm * 16 + (lane & 15), n = wn * 32 + tn * 16 + (lane >> 4) + 4 * r;
+        S[n * PF_SS + m] = a0[tm][tn][r] - acc[tm][tn][r];
+      }
+  __syncthreads();
   if(tr) pf_trace[(b * 64 + c) * 4 + 2] = wall_clock64();
 
   if(diag) {
@@ -221,18 +260,35 @@ __global__ void __launch_bounds__(256) panel_flow_kernel(const PanelFlowArgs g)
       }
       a[q] = v;
     }
-    // normalise, store and publish this wave's two columns of a finished group: L(r, j) = w_j(r) sqrt(p_j(j))
+    // normalise, store and publish this wave's two columns (8 blk + 2 gq, + 1) of a finished group: L(r, j) = w_j(r) sqrt(p_j(j)).
+    // The pivots are in [1e-280, 1e280] here (or exactly 1 in the padding), so the square root needs no rescaling:
+    // rsq + two Newton steps, the two columns' chains interleaved.
     auto publish = [&](int blk, const double (&p)[8], const double (&w)[8]) {
-#pragma unroll
-      for(int j = 0; j < 8; j++) {
-        if((j >> 1) == gq) {
-          const int cj = 8 * blk + j;
-          const double d = sqrt(pf_lane(p[j], cj));
-          const double lv = (rr == cj) ? d : ((rr > cj) ? w[j] * d : 0.0);        // (identity in the padding: p_j(j) = 1 there)
-          if(rr < nr && cj < n && rr >= cj) g.P[r0 + rr + ((int64_t)c * 64 + cj) * g.lda] = lv;
-          pf_put(&g.X[r0 + rr + ((int64_t)c * 64 + cj) * g.ldx], lv);
-        }
-      }
+      const double pa = (gq == 0) ? p[0] : (gq == 1) ? p[2] : (gq == 2) ? p[4] : p[6];
+      const double pb = (gq == 0) ? p[1] : (gq == 1) ? p[3] : (gq == 2) ? p[5] : p[7];
+      const double wa = (gq == 0) ? w[0] : (gq == 1) ? w[2] : (gq == 2) ? w[4] : w[6];
+      const double wb = (gq == 0) ? w[1] : (gq == 1) ? w[3] : (gq == 2) ? w[5] : w[7];
+      const int ca = 8 * blk + 2 * gq, cb = ca + 1;
+      const double xa = pf_lane(pa, ca), xb = pf_lane(pb, cb);
+      double ya = __builtin_amdgcn_rsq(xa), yb = __builtin_amdgcn_rsq(xb);
+      double ga = xa * ya, gb = xb * yb, ha = 0.5 * ya, hb = 0.5 * yb;
+      double ra = fma(-ha, ga, 0.5), rb = fma(-hb, gb, 0.5);
+      ga = fma(ga, ra, ga);
+      gb = fma(gb, rb, gb);
+      ha = fma(ha, ra, ha);
+      hb = fma(hb, rb, hb);
+      double ea = fma(-ga, ga, xa), eb = fma(-gb, gb, xb);
+      ga = fma(ea, ha, ga);
+      gb = fma(eb, hb, gb);
+      ea = fma(-ga, ga, xa);
+      eb = fma(-gb, gb, xb);
+      const double da = fma(ea, ha, ga), db = fma(eb, hb, gb);
+      const double la = (rr == ca) ? da : ((rr > ca) ? wa * da : 0.0);           // (identity in the padding: p_j(j) = 1 there)
+      const double lb = (rr == cb) ? db : ((rr > cb) ? wb * db : 0.0);
+      if(rr < nr && ca < n && rr >= ca) g.P[r0 + rr + ((int64_t)c * 64 + ca) * g.lda] = la;
+      if(rr < nr && cb < n && rr >= cb) g.P[r0 + rr + ((int64_t)c * 64 + cb) * g.lda] = lb;
+      pf_put(&g.X[r0 + rr + ((int64_t)c * 64 + ca) * g.ldx], la);
+      pf_put(&g.X[r0 + rr + ((int64_t)c * 64 + cb) * g.ldx], lb);
     };
     // fast path, everything static: no branch inside a group; a pivot outside [1e-280, 1e280] (or not positive) only
     // clears `safe`, and the group is then redone by the careful loop below
@@ -350,45 +406,65 @@ __global__ void __launch_bounds__(256) panel_flow_kernel(const PanelFlowArgs g)
     // ---- C = C L(c,c)^-T by substitution (panel_step_kernel of potrf.hip: 16-column blocks, four waves), L(c,c) taken from
     //      the exchange buffer 16 columns at a time, as its workgroup finishes them --------------------------------------------
     double* Ls = arena;
-    double* Dinv = arena + 64 * PF_LS;
+    double* Xs = arena + 64 * PF_LS;   // 16 x PF_OS: the group's solution as a product operand
     const double* Lx = g.X + (int64_t)c * 64 + lane + ((int64_t)c * 64 + wv * 4) * g.ldx;   // L(c,c)(lane, 16 blk + 4 wv + u)
     const bool wanted = (c + 1 < g.ncb);                                                     // somebody's product operand
     double lv[4];
     bool have = pf_try<4>(Lx, g.ldx, lv);
     double x[16];
-#pragma unroll 1
+#pragma unroll
     for(int blk = 0; blk < 4; blk++) {
       const int o = blk * 16;
+      const bool fine = (g.trace == 2) && b == 1 && c == 0 && t == 0;
+      if(fine) pf_trace[62 * 256 + blk * 8 + 0] = wall_clock64();
       if(!have && !pf_fetch<4>(g, Lx + (int64_t)o * g.ldx, g.ldx, lv)) giveup = 1;
+      if(fine) pf_trace[62 * 256 + blk * 8 + 1] = wall_clock64();
 #pragma unroll
       for(int u = 0; u < 4; u++) Ls[lane * PF_LS + o + wv * 4 + u] = lv[u];
       __syncthreads();
       if(giveup) return;
-      if(t < 16) Dinv[o + t] = 1.0 / Ls[(o + t) * PF_LS + o + t];
       if(blk + 1 < 4) have = pf_try<4>(Lx + (int64_t)(o + 16) * g.ldx, g.ldx, lv);          // in flight during this block's work
-      __syncthreads();
+      if(fine) pf_trace[62 * 256 + blk * 8 + 2] = wall_clock64();
+      // the 16 x 16 triangle, column-oriented: as soon as x_k is final every later x_i takes its share (independent updates)
 #pragma unroll
       for(int i = 0; i < 16; i++) x[i] = S[(o + i) * PF_SS + lane];
 #pragma unroll
-      for(int i = 0; i < 16; i++) {
-        double s = x[i];
+      for(int k = 0; k < 16; k++) {
+        const double dk = Ls[(o + k) * PF_LS + o + k];                    // in [1e-140, 1e140]: the fast path's pivot range
+        double xx = __builtin_amdgcn_rcp(dk);
+        double e = fma(-dk, xx, 1.0);
+        xx = fma(xx, e, xx);
+        e = fma(-dk, xx, 1.0);
+        xx = fma(xx, e, xx);
+        x[k] *= xx;
 #pragma unroll
-        for(int k = 0; k < i; k++) s -= x[k] * Ls[(o + i) * PF_LS + o + k];
-        x[i] = s * Dinv[o + i];
+        for(int i = k + 1; i < 16; i++) x[i] -= x[k] * Ls[(o + i) * PF_LS + o + k];
       }
-#pragma unroll 2
-      for(int cc = o + 16 + wv; cc < 64; cc += 4) {
-        const double* lc = &Ls[cc * PF_LS + o];
-        double s0 = S[cc * PF_SS + lane], s1 = 0.0, s2 = 0.0, s3 = 0.0;
+      if(fine) pf_trace[62 * 256 + blk * 8 + 3] = wall_clock64();
+      // the columns to the right, S(:, o+16:) -= X L(o+16:, o:o+16)', on the matrix cores (the same flops as the vector
+      // units, but no broadcast reads of L: those were LDS-bound): X goes through LDS as the [k][row] operand, wave wv
+      // owns rows 16 wv .. 16 wv + 15 of every 16-column tile
+      if(blk < 3) {
 #pragma unroll
-        for(int k = 0; k < 16; k += 4) {
-          s0 -= x[k] * lc[k];
-          s1 -= x[k + 1] * lc[k + 1];
-          s2 -= x[k + 2] * lc[k + 2];
-          s3 -= x[k + 3] * lc[k + 3];
+        for(int i = 0; i < 16; i++)
+          if((i >> 2) == wv) Xs[i * PF_OS + lane] = x[i];
+        __syncthreads();
+        double xa[4];
+#pragma unroll
+        for(int kk = 0; kk < 4; kk++) xa[kk] = Xs[(kk * 4 + (lane >> 4)) * PF_OS + wv * 16 + (lane & 15)];
+#pragma unroll
+        for(int n0 = o + 16; n0 < 64; n0 += 16) {
+          double4_t cf = (double4_t){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+          for(int kk = 0; kk < 4; kk++) {
+            const double lb = Ls[(n0 + (lane & 15)) * PF_LS + o + kk * 4 + (lane >> 4)];
+            cf = __builtin_amdgcn_mfma_f64_16x16x4f64(lb, xa[kk], cf, 0, 0, 0);
+          }
+#pragma unroll
+          for(int r = 0; r < 4; r++) S[(n0 + (lane >> 4) + 4 * r) * PF_SS + wv * 16 + (lane & 15)] -= cf[r];
         }
-        S[cc * PF_SS + lane] = (s0 + s1) + (s2 + s3);
       }
+      if(fine) pf_trace[62 * 256 + blk * 8 + 4] = wall_clock64();
       // these 16 columns are final: store and publish them (wave wv: columns o + 4 wv + u)
 #pragma unroll
       for(int i = 0; i < 16; i++) {
@@ -397,6 +473,7 @@ __global__ void __launch_bounds__(256) panel_flow_kernel(const PanelFlowArgs g)
           if(wanted) pf_put(&g.X[r0 + lane + ((int64_t)c * 64 + o + i) * g.ldx], x[i]);
         }
       }
+      if(fine) pf_trace[62 * 256 + blk * 8 + 5] = wall_clock64();
       __syncthreads();
     }
   }

@@ -136,6 +136,28 @@ def test_potrf_reports_failing_minor(api):
     assert api.potrf(Ad, "U") == 171
 
 
+@pytest.mark.parametrize("N,bad", [(1500, 1), (1500, 64), (1500, 65), (1500, 700), (1500, 1499), (1500, 1500), (1000, 961),
+                                   (70, 66)])
+def test_potrf_failing_minor_at_any_position(api, N, bad):
+    """The dataflow panel (panel_flow.hip) finds LAPACK's info wherever the first bad pivot sits: first / last column of a 64
+    block, a later panel, the ragged tail."""
+    A = spd(N, 5)
+    A[bad - 1, bad - 1] = -1.0
+    assert api.potrf(api.from_host(A), "L") == bad
+
+
+@pytest.mark.parametrize("scale", [1e-290, 1e290])
+def test_potrf_with_pivots_outside_the_fast_reciprocal_range(api, scale):
+    """Pivots below 1e-280 / above 1e280 leave the branch-free reciprocal of the 64 x 64 block kernels for the careful loop
+    (exact division); the factor is still the factor."""
+    N = 200
+    A = spd(N, 9)
+    Ad = api.from_host(A * scale)
+    assert api.potrf(Ad, "L") == 0
+    L = np.linalg.cholesky(A) * np.sqrt(scale)
+    assert rel(np.tril(api.to_host(Ad)), L) < 1e-12
+
+
 def test_potrf_blocking_invariance(api):
     # different outer panel widths give the same factor up to rounding
     N = 1500

@@ -35,6 +35,11 @@ if len(sys.argv) > 2 and sys.argv[2] == "child":
             print("   shader clock over blocks 0..7: %.0f MHz" % ((f[7,5]-f[0,5]) / ((f[7,0]-f[0,0]) / 100.)))
             for k in range(8):
                 print("   blk %d: %.2f %.2f %.2f %.2f" % (k, (f[k,1]-f[k,0])/100., (f[k,2]-f[k,1])/100., (f[k,3]-f[k,2])/100., (f[k,4]-f[k,3])/100.))
+        if os.environ.get("GPC_PANEL_FLOW_TRACE") == "2":
+            f = tr.reshape(-1)[62 * 256: 62 * 256 + 32].reshape(4, 8)
+            print("solve of block (1,0), per 16-column group (us since chol start): start | L there, staged+sync, triangle, trailing, publish")
+            for k in range(4):
+                print("   blk %d: %.2f | %.2f %.2f %.2f %.2f %.2f" % ((k, us(f[k, 0])) + tuple((f[k, i + 1] - f[k, i]) / 100. for i in range(5))))
         print("trace (us since start): block (b, c): start / products done / S ready / end")
         for c in range(nb):
             for b in (c, c + 1, nb - 1, min(63, (N + 63) // 64 - 1)):
