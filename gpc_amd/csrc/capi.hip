@@ -298,20 +298,27 @@ int gpc_chol_inverse_f64(int64_t N, double* A, int64_t lda, double* invK, int64_
                                    (size_t)N, hipMemcpyDeviceToDevice, s));
     return potri_full(true, N, invK, ldi, s);
   }
-  // Small matrices are bound by the N/64 dependent steps of the panel chain, not by flops: the inverse costs a second
-  // chain of the same length (dpotri's L^-T).  Factoring the 2N x N array [K; I] instead lets the identity ride through the
-  // SAME launches -- every panel solve and trailing update simply covers N more rows -- and leaves [L; L^-T]; the inverse
-  // is then one product, K^-1 = (L^-T)(L^-T)'.  Np = N rounded up to 16: the extra (zero) columns let that product take
-  // the fast MFMA kernel.
-  const int64_t Np = (N + 15) & ~(int64_t)15, ld2 = 2 * N + (2 * N) % 2;
+  // Small matrices are bound by the N/64 dependent steps of the panel factorisation, not by flops: the inverse costs a
+  // second chain of the same length (dpotri's L^-T).  Factoring the tall array [K; I] instead lets the identity ride through
+  // the SAME launches -- every panel solve and trailing update simply covers N more rows -- and leaves [L; L^-T]; the
+  // inverse is then one product, K^-1 = (L^-T)(L^-T)'.  K is padded with an identity block to Np = N rounded up to 64, so
+  // that every panel is whole 64-column blocks (the dataflow panel kernel's domain) and the product takes the MFMA kernel:
+  //     W = [ K 0 ]  N        after the factorisation   [ L     0 ]
+  //         [ 0 I ]  Np - N                             [ 0     I ]
+  //         [ I 0 ]  N                                  [ L^-T  0 ]
+  const int64_t Np = (N + 63) & ~(int64_t)63, rows = Np + N, ld2 = rows + (rows & 1);
   void* wa = nullptr;
   GPC_CHECK(workspace(WS_AUG, sizeof(double) * (size_t)ld2 * (size_t)Np, &wa));
   double* W = static_cast<double*>(wa);
   GPC_HIP_CHECK(hipMemcpy2DAsync(W, sizeof(double) * (size_t)ld2, A, sizeof(double) * (size_t)lda, sizeof(double) * (size_t)N,
                                  (size_t)N, hipMemcpyDeviceToDevice, s));
-  GPC_CHECK(set_identity(N, N, W + N, ld2, s));
-  if(Np > N) GPC_HIP_CHECK(hipMemsetAsync(W + (size_t)N * ld2, 0, sizeof(double) * (size_t)ld2 * (size_t)(Np - N), s));
-  GPC_CHECK(potrf_lower_tall(2 * N, N, W, ld2, d_info, s));
+  if(Np > N) {
+    GPC_HIP_CHECK(hipMemset2DAsync(W + N, sizeof(double) * (size_t)ld2, 0, sizeof(double) * (size_t)(Np - N), (size_t)N, s));
+    GPC_HIP_CHECK(hipMemsetAsync(W + (size_t)N * ld2, 0, sizeof(double) * (size_t)ld2 * (size_t)(Np - N), s));
+    GPC_CHECK(set_identity(Np - N, Np - N, W + N + (size_t)N * ld2, ld2, s));
+  }
+  GPC_CHECK(set_identity(N, N, W + Np, ld2, s));
+  GPC_CHECK(potrf_lower_tall(rows, Np, W, ld2, d_info, s));
   GPC_CHECK(read_info(d_info, info, s));
   if(*info != 0) return GPC_OK;
   if(logdet) {
@@ -322,7 +329,7 @@ int gpc_chol_inverse_f64(int64_t N, double* A, int64_t lda, double* invK, int64_
   // L back into A.  (The whole block: W's upper triangle still holds the values it was given, i.e. A's own.)
   GPC_HIP_CHECK(hipMemcpy2DAsync(A, sizeof(double) * (size_t)lda, W, sizeof(double) * (size_t)ld2, sizeof(double) * (size_t)N,
                                  (size_t)N, hipMemcpyDeviceToDevice, s));
-  GPC_CHECK(gemm(false, true, N, N, Np, 1.0, W + N, ld2, W + N, ld2, 0.0, invK, ldi, 1, s));
+  GPC_CHECK(gemm(false, true, N, N, Np, 1.0, W + Np, ld2, W + Np, ld2, 0.0, invK, ldi, 1, s));
   return symmetrize(true, N, invK, ldi, s);
 }
 

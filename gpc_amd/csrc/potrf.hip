@@ -576,6 +576,21 @@ int ensure_lookahead()
   return GPC_OK;
 }
 
+// Is the dataflow panel kernel (panel_flow.hip) in use, and up to how many rows?  GPC_PANEL_FLOW=0 turns it off (the launch
+// chain below then factors every panel), GPC_PANEL_FLOW_MAXROWS moves the height above which the chain takes over (on a tall
+// panel the chain's products are chip-wide GEMMs, the dataflow blocks' are one CU each: 1504 vs 1474 ms at N = 65 536 when
+// every panel goes through the dataflow kernel).
+static int64_t panel_flow_maxrows()
+{
+  static int64_t maxrows = -1;
+  if(maxrows < 0) {
+    const char* e = getenv("GPC_PANEL_FLOW");
+    const char* m = getenv("GPC_PANEL_FLOW_MAXROWS");
+    maxrows = (e && atoi(e) == 0) ? 0 : (m ? atoll(m) : 16384);
+  }
+  return maxrows;
+}
+
 // factor the NB-wide panel starting at column k0 (all rows below it), on stream s.
 // Two levels inside the panel: 128-column slabs, 64-column steps inside a slab.  A 64-deep update only touches the
 // rest of its slab; the rest of the PANEL is updated once per slab with a 128-deep product.  Compared with updating
@@ -585,15 +600,7 @@ constexpr int64_t SLAB = 128;
 int factor_panel(int64_t N, double* A, int64_t lda, int64_t k0, int64_t nbk, int* d_info, hipStream_t s, int64_t col0 = 0)
 {
   // short panels: the whole panel as one dataflow launch (panel_flow.hip) instead of five launches per 128 columns
-  static int flow = -1;
-  static int64_t flow_maxrows = 0;
-  if(flow < 0) {
-    const char* e = getenv("GPC_PANEL_FLOW");
-    flow = e ? atoi(e) : 1;
-    const char* m = getenv("GPC_PANEL_FLOW_MAXROWS");
-    flow_maxrows = m ? atoll(m) : 16384;
-  }
-  if(flow && N - k0 <= flow_maxrows) {
+  if(N - k0 <= panel_flow_maxrows()) {
     const int rc = panel_flow(N - k0, nbk, A + k0 + k0 * lda, lda, d_info, col0 + k0, s);
     if(rc != GPC_EUNSUPPORTED) return rc;
   }
@@ -662,15 +669,23 @@ int potrf_panel(int64_t M, int64_t nb, double* A, int64_t lda, int* d_info, int6
 // so; otherwise 1024: the update kernel's per-tile start-up and C read-modify-write are amortised over a K twice as
 // deep as with 512 (58.4 -> 61.1 TF at N = 65 536), and since the panel chain became short (blocked potf2, fused step)
 // the wider panel is the faster choice at every size measured (N = 2048 ... 65 536: 1-4 %).
+// Width of the next panel when `rem` columns are left.  The dataflow kernel does its own trailing updates (left-looking, in
+// the same launch), so near the end one launch replaces several panel + GEMM rounds: measured with N = rem, 1024 -> 2048 ->
+// 4096 wide: 0.855 -> 0.708 ms at 2048, 1.97 -> 1.71 -> 1.38 ms at 4096, 3.69 -> 3.52 -> 3.65 ms at 6144; from 8192 up 1024
+// and 2048 tie and wider loses.  A width set by the caller (gpc_set_potrf_blocking) or GPC_NB is used as given.
 static int64_t panel_width(int64_t rem)
 {
-  (void)rem;
   if(g_nb_outer == 0) {
     const char* e = getenv("GPC_NB");
     const int64_t v = e ? atoll(e) : 0;
     g_nb_outer = (v >= JB) ? (v / JB) * JB : -1;   // -1 = default
   }
-  return g_nb_outer > 0 ? g_nb_outer : 1024;
+  if(g_nb_outer > 0) return g_nb_outer;
+  if(panel_flow_maxrows() >= 8192) {
+    if(rem <= 4096) return 4096;
+    if(rem <= 8192) return 2048;
+  }
+  return 1024;
 }
 
 int potrf_lower(int64_t N, double* A, int64_t lda, int* d_info, hipStream_t s, int64_t col0)
