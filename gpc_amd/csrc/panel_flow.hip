@@ -98,7 +98,7 @@ __global__ void __launch_bounds__(256) panel_flow_kernel(const PanelFlowArgs g)
 {
   // one LDS arena, carved per phase:
   //   products : As = arena[0 .. 64*OS), Bs = arena[64*OS .. 128*OS)
-  //   chol     : Pb = arena[0 .. 1024), T = arena[1024 .. 1024 + 64*TS)
+  //   chol     : Pc, Wl, Tl = arena[0 .. 512), [512 .. 1024), [1024 .. 1536)   (careful loop: Pb = [0 .. 1024), T = next 64*TS)
   //   solve    : Ls = arena[0 .. 64*LS), Xs = next 16*OS
   __shared__ __attribute__((aligned(16))) double arena[2 * 64 * PF_OS];
   __shared__ __attribute__((aligned(16))) double S[64 * PF_SS];
@@ -226,83 +226,69 @@ __global__ void __launch_bounds__(256) panel_flow_kernel(const PanelFlowArgs g)
     if(lost) giveup = 1;
   }
   if(tr) pf_trace[(b * 64 + c) * 4 + 1] = wall_clock64();
-  // ---- S = A(b,c) - acc -------------------------------------------------------------------------------------------------
+  // ---- C = A(b,c) - acc -------------------------------------------------------------------------------------------------
   __syncthreads();   // the arena is free, giveup is final
   if(giveup) return;
+  if(!diag) {
+    // a block below the diagonal: into LDS, a column per register of a lane = row (the substitution's layout)
 #pragma unroll
-  for(int tn = 0; tn < 2; tn++)
+    for(int tn = 0; tn < 2; tn++)
 #pragma unroll
-    for(int tm = 0; tm < 2; tm++)
+      for(int tm = 0; tm < 2; tm++)
 #pragma unroll
-      for(int r = 0; r < 4; r++) {
-        const int m = wm * 32 + tm * 16 + (lane & 15), n = wn * 32 + tn * 16 + (lane >> 4) + 4 * r;
-        S[n * PF_SS + m] = a0[tm][tn][r] - acc[tm][tn][r];
-      }
-  __syncthreads();
+        for(int r = 0; r < 4; r++) {
+          const int m = wm * 32 + tm * 16 + (lane & 15), n = wn * 32 + tn * 16 + (lane >> 4) + 4 * r;
+          S[n * PF_SS + m] = a0[tm][tn][r] - acc[tm][tn][r];
+        }
+    __syncthreads();
+  }
   if(tr) pf_trace[(b * 64 + c) * 4 + 2] = wall_clock64();
 
   if(diag) {
-    // ---- chol of the ncol x ncol block in S (potf2_blk_kernel of potrf.hip, columns 8 at a time), each group of 8 columns
-    //      normalised, stored and published as soon as it is final -------------------------------------------------------------
-    double* Pb = arena;
-    double* T = arena + 1024;
+    // ---- chol of the ncol x ncol diagonal block, 8 columns at a time (potf2_blk_kernel of potrf.hip); each group is
+    //      normalised, stored and published as soon as it is final.  The block stays in the accumulator layout it was
+    //      computed in (wave (wm, wn) holds the 32 x 32 quadrant): a group's 8 columns go through LDS to every wave, which
+    //      eliminates them redundantly (lane = row), and the rank-8 update of the rest is two MFMA steps per 16 x 16 tile
+    //      (the same flops as the vector units but no broadcast LDS reads, which bound the vector form).  The strict upper
+    //      triangle is never referenced: zero at the start, its tiles are skipped or hold harmless values of dead rows.
+    double* Pc = arena;            // [8][64] the group's columns
+    double* Wl = arena + 512;      // [8][64] - w_j (the multipliers), as the row operand of the update
+    double* Tl = arena + 1024;     // [8][64] p_j (the eliminated columns), as its column operand
     const int rr = lane, gq = wv;
     const int n = ncol;
-    double a[16];          // column 4 q + gq of the block, row rr
+    double4_t cur[2][2];
 #pragma unroll
-    for(int q = 0; q < 16; q++) {
-      const int cc = 4 * q + gq;
-      double v = 0.0;
-      if(rr < n && cc < n) {
-        if(rr >= cc) v = S[cc * PF_SS + rr];
-      } else if(rr == cc) {
-        v = 1.0;
-      }
-      a[q] = v;
-    }
-    // normalise, store and publish this wave's two columns (8 blk + 2 gq, + 1) of a finished group: L(r, j) = w_j(r) sqrt(p_j(j)).
-    // The pivots are in [1e-280, 1e280] here (or exactly 1 in the padding), so the square root needs no rescaling:
-    // rsq + two Newton steps, the two columns' chains interleaved.
-    auto publish = [&](int blk, const double (&p)[8], const double (&w)[8]) {
-      const double pa = (gq == 0) ? p[0] : (gq == 1) ? p[2] : (gq == 2) ? p[4] : p[6];
-      const double pb = (gq == 0) ? p[1] : (gq == 1) ? p[3] : (gq == 2) ? p[5] : p[7];
-      const double wa = (gq == 0) ? w[0] : (gq == 1) ? w[2] : (gq == 2) ? w[4] : w[6];
-      const double wb = (gq == 0) ? w[1] : (gq == 1) ? w[3] : (gq == 2) ? w[5] : w[7];
-      const int ca = 8 * blk + 2 * gq, cb = ca + 1;
-      const double xa = pf_lane(pa, ca), xb = pf_lane(pb, cb);
-      double ya = __builtin_amdgcn_rsq(xa), yb = __builtin_amdgcn_rsq(xb);
-      double ga = xa * ya, gb = xb * yb, ha = 0.5 * ya, hb = 0.5 * yb;
-      double ra = fma(-ha, ga, 0.5), rb = fma(-hb, gb, 0.5);
-      ga = fma(ga, ra, ga);
-      gb = fma(gb, rb, gb);
-      ha = fma(ha, ra, ha);
-      hb = fma(hb, rb, hb);
-      double ea = fma(-ga, ga, xa), eb = fma(-gb, gb, xb);
-      ga = fma(ea, ha, ga);
-      gb = fma(eb, hb, gb);
-      ea = fma(-ga, ga, xa);
-      eb = fma(-gb, gb, xb);
-      const double da = fma(ea, ha, ga), db = fma(eb, hb, gb);
-      const double la = (rr == ca) ? da : ((rr > ca) ? wa * da : 0.0);           // (identity in the padding: p_j(j) = 1 there)
-      const double lb = (rr == cb) ? db : ((rr > cb) ? wb * db : 0.0);
-      if(rr < nr && ca < n && rr >= ca) g.P[r0 + rr + ((int64_t)c * 64 + ca) * g.lda] = la;
-      if(rr < nr && cb < n && rr >= cb) g.P[r0 + rr + ((int64_t)c * 64 + cb) * g.lda] = lb;
-      pf_put(&g.X[r0 + rr + ((int64_t)c * 64 + ca) * g.ldx], la);
-      pf_put(&g.X[r0 + rr + ((int64_t)c * 64 + cb) * g.ldx], lb);
-    };
-    // fast path, everything static: no branch inside a group; a pivot outside [1e-280, 1e280] (or not positive) only
-    // clears `safe`, and the group is then redone by the careful loop below
+    for(int tn = 0; tn < 2; tn++)
+#pragma unroll
+      for(int tm = 0; tm < 2; tm++)
+#pragma unroll
+        for(int r = 0; r < 4; r++) {
+          const int m = wm * 32 + tm * 16 + (lane & 15), nn = wn * 32 + tn * 16 + (lane >> 4) + 4 * r;
+          double v = 0.0;
+          if(m < n && nn < n) {
+            if(m >= nn) v = a0[tm][tn][r] - acc[tm][tn][r];
+          } else if(m == nn) {
+            v = 1.0;            // identity padding of a ragged last block
+          }
+          cur[tm][tn][r] = v;
+        }
     int done = 0;
     bool safe = true;
 #pragma unroll
     for(int blk = 0; blk < 8; blk++) {
       if(safe) {
-        double* Pc = Pb + (blk & 1) * 512;
         const bool fine = (g.trace == 2) && b == 0 && t == 0;
         if(fine) pf_trace[63 * 256 + blk * 8 + 0] = wall_clock64();
         if(fine) pf_trace[63 * 256 + blk * 8 + 5] = clock64();
-        Pc[gq * 64 + rr] = a[2 * blk];
-        Pc[(4 + gq) * 64 + rr] = a[2 * blk + 1];
+        // the group's columns 8 blk .. 8 blk + 7 live in the quadrants wn = blk / 4, tile tn = (blk / 2) & 1, registers
+        // 2 (blk & 1), + 1: column - 8 blk = (lane >> 4) + 4 (r - 2 (blk & 1))
+        if(wn == blk / 4) {
+#pragma unroll
+          for(int tm = 0; tm < 2; tm++)
+#pragma unroll
+            for(int r2 = 0; r2 < 2; r2++)
+              Pc[((lane >> 4) + 4 * r2) * 64 + wm * 32 + tm * 16 + (lane & 15)] = cur[tm][(blk / 2) & 1][2 * (blk & 1) + r2];
+        }
         __syncthreads();
         if(fine) pf_trace[63 * 256 + blk * 8 + 1] = wall_clock64();
         double p[8], w[8];
@@ -324,22 +310,63 @@ __global__ void __launch_bounds__(256) panel_flow_kernel(const PanelFlowArgs g)
         }
         if(fine) pf_trace[63 * 256 + blk * 8 + 2] = wall_clock64();
         if(ok) {
-          publish(blk, p, w);
-          if(fine) pf_trace[63 * 256 + blk * 8 + 3] = wall_clock64();
+          // this wave's two columns of the group, 8 blk + 2 gq and + 1
+          const double pa = (gq == 0) ? p[0] : (gq == 1) ? p[2] : (gq == 2) ? p[4] : p[6];
+          const double pb = (gq == 0) ? p[1] : (gq == 1) ? p[3] : (gq == 2) ? p[5] : p[7];
+          const double wa = (gq == 0) ? w[0] : (gq == 1) ? w[2] : (gq == 2) ? w[4] : w[6];
+          const double wb = (gq == 0) ? w[1] : (gq == 1) ? w[3] : (gq == 2) ? w[5] : w[7];
           if(blk + 1 < 8) {
+            Wl[(2 * gq) * 64 + rr] = -wa;
+            Wl[(2 * gq + 1) * 64 + rr] = -wb;
+            Tl[(2 * gq) * 64 + rr] = pa;
+            Tl[(2 * gq + 1) * 64 + rr] = pb;
+            __syncthreads();
+            // rest(m, n) -= sum_j w_j(m) p_j(n): the tiles that still have a column right of the group and are not strictly
+            // above the diagonal; the matrix cores work through them while the vector units do the publishing below
+            if(wm >= wn) {
 #pragma unroll
-            for(int j = 0; j < 8; j++) T[rr * PF_TS + j] = p[j];
+              for(int tn = 0; tn < 2; tn++) {
+                if(wn * 32 + tn * 16 + 8 > 8 * blk) {
 #pragma unroll
-            for(int q = 2 * blk + 2; q < 16; q++) {
-              const double* tc = &T[(4 * q + gq) * PF_TS];
-              double s0 = a[q], s1 = 0.0;
+                  for(int tm = 0; tm < 2; tm++) {
+                    if(wm > wn || tm >= tn) {
 #pragma unroll
-              for(int j = 0; j < 8; j += 2) {
-                s0 -= w[j] * tc[j];
-                s1 -= w[j + 1] * tc[j + 1];
+                      for(int kk = 0; kk < 2; kk++) {
+                        const double fa = Wl[(kk * 4 + (lane >> 4)) * 64 + wm * 32 + tm * 16 + (lane & 15)];
+                        const double fb = Tl[(kk * 4 + (lane >> 4)) * 64 + wn * 32 + tn * 16 + (lane & 15)];
+                        cur[tm][tn] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb, fa, cur[tm][tn], 0, 0, 0);
+                      }
+                    }
+                  }
+                }
               }
-              a[q] = s0 + s1;
             }
+          }
+          if(fine) pf_trace[63 * 256 + blk * 8 + 3] = wall_clock64();
+          // normalise, store and publish: L(r, j) = w_j(r) sqrt(p_j(j)).  The pivots are in [1e-280, 1e280] here (or exactly 1
+          // in the padding), so the square root needs no rescaling: rsq + two Newton steps, both columns' chains interleaved.
+          {
+            const int ca = 8 * blk + 2 * gq, cb = ca + 1;
+            const double xa = pf_lane(pa, ca), xb = pf_lane(pb, cb);
+            double ya = __builtin_amdgcn_rsq(xa), yb = __builtin_amdgcn_rsq(xb);
+            double ga = xa * ya, gb = xb * yb, ha = 0.5 * ya, hb = 0.5 * yb;
+            double ra = fma(-ha, ga, 0.5), rb = fma(-hb, gb, 0.5);
+            ga = fma(ga, ra, ga);
+            gb = fma(gb, rb, gb);
+            ha = fma(ha, ra, ha);
+            hb = fma(hb, rb, hb);
+            double ea = fma(-ga, ga, xa), eb = fma(-gb, gb, xb);
+            ga = fma(ea, ha, ga);
+            gb = fma(eb, hb, gb);
+            ea = fma(-ga, ga, xa);
+            eb = fma(-gb, gb, xb);
+            const double da = fma(ea, ha, ga), db = fma(eb, hb, gb);
+            const double la = (rr == ca) ? da : ((rr > ca) ? wa * da : 0.0);           // (identity in the padding: p_j(j) = 1 there)
+            const double lb = (rr == cb) ? db : ((rr > cb) ? wb * db : 0.0);
+            pf_put(&g.X[r0 + rr + ((int64_t)c * 64 + ca) * g.ldx], la);                   // (first: the solves below are polling)
+            pf_put(&g.X[r0 + rr + ((int64_t)c * 64 + cb) * g.ldx], lb);
+            if(rr < nr && ca < n && rr >= ca) g.P[r0 + rr + ((int64_t)c * 64 + ca) * g.lda] = la;
+            if(rr < nr && cb < n && rr >= cb) g.P[r0 + rr + ((int64_t)c * 64 + cb) * g.lda] = lb;
           }
           done = blk + 1;
           if(fine) pf_trace[63 * 256 + blk * 8 + 4] = wall_clock64();
@@ -349,22 +376,49 @@ __global__ void __launch_bounds__(256) panel_flow_kernel(const PanelFlowArgs g)
       }
     }
     if(!safe) {
-      // the careful loop (exact division, LAPACK's info on a non-positive pivot), from the first group the fast path refused
-      for(int sh = 0; sh < done; sh++) {
-#pragma unroll
-        for(int q = 0; q < 14; q++) a[q] = a[q + 2];
-      }
+      // the careful loop (exact division, LAPACK's info on a non-positive pivot), from the first group the fast path refused:
+      // the rest of the block goes through LDS into a column per register of a lane = row, column 8 blk + 4 q + gq in a[q]
       __syncthreads();
+#pragma unroll
+      for(int tn = 0; tn < 2; tn++)
+#pragma unroll
+        for(int tm = 0; tm < 2; tm++)
+#pragma unroll
+          for(int r = 0; r < 4; r++) {
+            const int m = wm * 32 + tm * 16 + (lane & 15), nn = wn * 32 + tn * 16 + (lane >> 4) + 4 * r;
+            S[nn * PF_SS + m] = (m >= nn) ? cur[tm][tn][r] : 0.0;
+          }
+      __syncthreads();
+      double* Pb = arena;
+      double* T = arena + 1024;
+      double a[16];
+#pragma unroll
+      for(int q = 0; q < 16; q++) {
+        const int cc = 8 * done + 4 * q + gq;
+        a[q] = (cc < 64) ? S[cc * PF_SS + rr] : 0.0;
+      }
+      auto publish = [&](int blk, const double (&p)[8], const double (&w)[8]) {
+#pragma unroll
+        for(int j = 0; j < 8; j++) {
+          if((j >> 1) == gq) {
+            const int cj = 8 * blk + j;
+            const double d = sqrt(pf_lane(p[j], cj));
+            const double lv = (rr == cj) ? d : ((rr > cj) ? w[j] * d : 0.0);
+            if(rr < nr && cj < n && rr >= cj) g.P[r0 + rr + ((int64_t)c * 64 + cj) * g.lda] = lv;
+            pf_put(&g.X[r0 + rr + ((int64_t)c * 64 + cj) * g.ldx], lv);
+          }
+        }
+      };
       bool failed = false;
 #pragma unroll 1
       for(int blk = done; blk < 8; blk++) {
-        double* Pc = Pb + (blk & 1) * 512;
+        double* Pc2 = Pb + (blk & 1) * 512;
 #pragma unroll
-        for(int i = 0; i < 2; i++) Pc[(4 * i + gq) * 64 + rr] = a[i];
+        for(int i = 0; i < 2; i++) Pc2[(4 * i + gq) * 64 + rr] = a[i];
         __syncthreads();
         double p[8], w[8];
 #pragma unroll
-        for(int j = 0; j < 8; j++) p[j] = Pc[j * 64 + rr];
+        for(int j = 0; j < 8; j++) p[j] = Pc2[j * 64 + rr];
 #pragma unroll
         for(int j = 0; j < 8; j++) {
           const int cj = 8 * blk + j;
@@ -391,10 +445,10 @@ __global__ void __launch_bounds__(256) panel_flow_kernel(const PanelFlowArgs g)
             const int cc = 8 * blk + 4 * q + gq;
             if(cc < 64) {
               const double* tc = &T[cc * PF_TS];
-              double s = a[q];
+              double sacc = a[q];
 #pragma unroll
-              for(int j = 0; j < 8; j++) s -= w[j] * tc[j];
-              a[q] = s;
+              for(int j = 0; j < 8; j++) sacc -= w[j] * tc[j];
+              a[q] = sacc;
             }
           }
 #pragma unroll
@@ -425,20 +479,26 @@ __global__ void __launch_bounds__(256) panel_flow_kernel(const PanelFlowArgs g)
       if(giveup) return;
       if(blk + 1 < 4) have = pf_try<4>(Lx + (int64_t)(o + 16) * g.ldx, g.ldx, lv);          // in flight during this block's work
       if(fine) pf_trace[62 * 256 + blk * 8 + 2] = wall_clock64();
-      // the 16 x 16 triangle, column-oriented: as soon as x_k is final every later x_i takes its share (independent updates)
-#pragma unroll
-      for(int i = 0; i < 16; i++) x[i] = S[(o + i) * PF_SS + lane];
+      // the 16 x 16 triangle, column-oriented: as soon as x_k is final every later x_i takes its share (independent updates).
+      // The reciprocals of the diagonal first, all 16 chains in flight together (L_kk is a square root of a pivot: no
+      // range problem for rcp + two Newton steps).
+      double rd[16];
 #pragma unroll
       for(int k = 0; k < 16; k++) {
-        const double dk = Ls[(o + k) * PF_LS + o + k];                    // in [1e-140, 1e140]: the fast path's pivot range
+        const double dk = Ls[(o + k) * PF_LS + o + k];
         double xx = __builtin_amdgcn_rcp(dk);
         double e = fma(-dk, xx, 1.0);
         xx = fma(xx, e, xx);
         e = fma(-dk, xx, 1.0);
-        xx = fma(xx, e, xx);
-        x[k] *= xx;
+        rd[k] = fma(xx, e, xx);
+      }
 #pragma unroll
-        for(int i = k + 1; i < 16; i++) x[i] -= x[k] * Ls[(o + i) * PF_LS + o + k];
+      for(int i = 0; i < 16; i++) x[i] = S[(o + i) * PF_SS + lane];
+#pragma unroll
+      for(int k = 0; k < 16; k++) {
+        x[k] *= rd[k];
+#pragma unroll
+        for(int i = k + 1; i < 16; i++) x[i] -= x[k] * Ls[(o + i) * PF_LS + o + k];   // (8-byte broadcast reads: 16-byte ones are slower)
       }
       if(fine) pf_trace[62 * 256 + blk * 8 + 3] = wall_clock64();
       // the columns to the right, S(:, o+16:) -= X L(o+16:, o:o+16)', on the matrix cores (the same flops as the vector
@@ -469,8 +529,8 @@ __global__ void __launch_bounds__(256) panel_flow_kernel(const PanelFlowArgs g)
 #pragma unroll
       for(int i = 0; i < 16; i++) {
         if((i >> 2) == wv) {
+          if(wanted) pf_put(&g.X[r0 + lane + ((int64_t)c * 64 + o + i) * g.ldx], x[i]);     // (first: somebody may be polling)
           if(lane < nr) g.P[r0 + lane + ((int64_t)c * 64 + o + i) * g.lda] = x[i];
-          if(wanted) pf_put(&g.X[r0 + lane + ((int64_t)c * 64 + o + i) * g.ldx], x[i]);
         }
       }
       if(fine) pf_trace[62 * 256 + blk * 8 + 5] = wall_clock64();
