@@ -586,7 +586,7 @@ static int64_t panel_flow_maxrows()
   if(maxrows < 0) {
     const char* e = getenv("GPC_PANEL_FLOW");
     const char* m = getenv("GPC_PANEL_FLOW_MAXROWS");
-    maxrows = (e && atoi(e) == 0) ? 0 : (m ? atoll(m) : 16384);
+    maxrows = (e && atoi(e) == 0) ? 0 : (m ? atoll(m) : 24576);
   }
   return maxrows;
 }
