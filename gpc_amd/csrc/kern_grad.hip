@@ -402,6 +402,342 @@ int launch_grad_sym(const KSpecDev& ks, const GradArgs& g, int per, dim3 grid, d
   return launch_grad_sym_nd<NRBF, 2>(ks, g, per, grid, partial, s);
 }
 
+// ---- symmetric fast path for ONE rbfard term (+ white / bias), D <= 32 ------------------------------------------------------
+// CRbfardKern::getGradParams (CKern.cpp:3359-3403) needs, besides the two sums of the rbf kernel, one sum per input
+// dimension:  S_q = sum_{i != j} W(i,j) (x_iq - x_jq)^2,  W = covGrad o k~.  On the symmetric walk above these are
+//     S_q = sum_i x_iq^2 rho_i  +  sum_i Y2(q,i)  -  2 sum_i x_iq Y(q,i),
+//     rho_i = sum_j W(i,j),   Y(q,i) = sum_j W(i,j) x_jq,   Y2(q,i) = sum_j W(i,j) x_jq^2      (j over the walked tiles,
+// W carrying the tile's weight 2 / 1), and Y, Y2 are matrix products whose W operand needs no data movement at all:
+// register r of a 16 x 16 accumulator tile holds W(i = lane & 15, j = 4 r + (lane >> 4)), which IS the MFMA operand
+// layout for a k-step over j = 4 r .. 4 r + 3.  So the weights go from the exp epilogue straight back into
+// v_mfma_f64_16x16x4 against rows of X^T (16 q per operand, loaded from a transposed copy, squares formed in registers);
+// the mirrored contribution is never needed because only the scalars x_q' W x_q are.  The inputs are centred (differences
+// do not change) and scaled by sqrt(s_q) first, so that x.x' from the same MFMA walk gives the ARD distance and the three
+// terms of S_q do not cancel more than the data's spread demands; S_q comes out in scaled coordinates and the host divides
+// by s_q.  Partial sums per workgroup: the NP_MAIN layout (slots 8, 9, 12, 13) followed by 32 S_q.
+constexpr int NP_ARDSYM = NP_MAIN + 32;
+
+__global__ void __launch_bounds__(256) ard_mean_kernel(const double* __restrict__ X, int64_t ldx, int64_t N, double* __restrict__ mean)
+{
+  __shared__ double sh[4];
+  const int64_t q = blockIdx.x;
+  double a = 0.0;
+  for(int64_t i = threadIdx.x; i < N; i += 256) a += X[i + q * ldx];
+  const double tot = block_sum(a, sh);
+  if(threadIdx.x == 0) mean[q] = tot / (double)N;
+}
+
+// Xs = (X - mean) sqrt(s) column-major (ld N), XT the same transposed (row i at XT + i dp, zero-padded to dp), n1 = |xs_i|^2
+__global__ void __launch_bounds__(256) ard_prep_kernel(const KSpecDev ks, const double* __restrict__ X, int64_t ldx, int64_t N, int D,
+                                                       const double* __restrict__ mean, double* __restrict__ Xs,
+                                                       double* __restrict__ XT, int dp, double* __restrict__ n1)
+{
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if(i >= N) return;
+  double acc = 0.0;
+  for(int q = 0; q < dp; q++) {
+    double v = 0.0;
+    if(q < D) {
+      v = (X[i + (int64_t)q * ldx] - mean[q]) * sqrt(ks.ard_scale[0][q]);
+      Xs[i + (int64_t)q * N] = v;
+      acc = fma(v, v, acc);
+    }
+    XT[i * dp + q] = v;
+  }
+  n1[i] = acc;
+}
+
+template <int NK, int ND, int OCC>
+__global__ void __launch_bounds__(256, OCC) kern_grad_ard_sym_kernel(const KSpecDev ks, const GradArgs g, const double* __restrict__ XT,
+                                                                   int jt_per_block, double* __restrict__ partial)
+{
+  constexpr int QX = (NK > 4) ? 2 : 1;          // 16-wide groups of input dimensions
+  constexpr int DP = 16 * QX;
+  __shared__ double Xj[2][GMDC * GSJ];
+  __shared__ double Nj[2][GMJ];
+  __shared__ double Xi[NK > 2 ? GMDC * GSI : 1];
+  __shared__ double sh[4];
+  __shared__ double red[4][32];
+  const int t = threadIdx.x;
+  const int lane = t & 63, w = t >> 6;
+  const int wm = w & 1, wn = w >> 1;
+  const int64_t i0 = (int64_t)blockIdx.x * GMI;
+  double* mypartial = partial + ((int64_t)blockIdx.x * gridDim.y + blockIdx.y) * NP_ARDSYM;
+  int64_t tiles_j = (g.N + GMJ - 1) / GMJ;
+  if(tiles_j > 2 * ((int64_t)blockIdx.x + 1)) tiles_j = 2 * ((int64_t)blockIdx.x + 1);
+  const int64_t jt0 = (int64_t)blockIdx.y * jt_per_block;
+  int64_t jt1 = jt0 + jt_per_block;
+  if(jt1 > tiles_j) jt1 = tiles_j;
+  if(jt0 >= jt1) {
+    if(t < NP_ARDSYM) mypartial[t] = 0.0;
+    return;
+  }
+  const int dc = (int)g.D;   // <= 4 NK
+
+  constexpr bool AF_LDS = (NK > 2);
+  double af[AF_LDS ? 1 : NK][4];
+  if(AF_LDS) {
+#pragma unroll
+    for(int u = 0; u < (GMDC * GMI) / 256; u++) {
+      const int idx = t + 256 * u;
+      const int kr = idx >> 7, row = idx & 127;
+      int64_t gi = i0 + row;
+      if(gi > g.N - 1) gi = g.N - 1;
+      Xi[kr * GSI + row] = (kr < dc) ? g.X[gi + (int64_t)kr * g.ldx] : 0.0;
+    }
+  } else {
+#pragma unroll
+    for(int kk = 0; kk < (AF_LDS ? 1 : NK); kk++)
+#pragma unroll
+      for(int tm = 0; tm < 4; tm++) {
+        int64_t gi = i0 + wm * 64 + tm * 16 + (lane & 15);
+        if(gi > g.N - 1) gi = g.N - 1;
+        int kr = kk * 4 + (lane >> 4);
+        if(kr > dc - 1) kr = dc - 1;
+        af[kk][tm] = (kk * 4 + (lane >> 4) < dc) ? g.X[gi + (int64_t)kr * g.ldx] : 0.0;
+      }
+  }
+  double ni[4];
+  double ai[ND > 0 ? ND : 1][4];
+#pragma unroll
+  for(int tm = 0; tm < 4; tm++) {
+    int64_t gi = i0 + wm * 64 + tm * 16 + (lane & 15);
+    if(gi > g.N - 1) gi = g.N - 1;
+    ni[tm] = g.n1[gi];
+#pragma unroll
+    for(int o = 0; o < ND; o++) ai[o][tm] = g.A[gi + (int64_t)o * g.lda];
+  }
+
+  const int ws = __builtin_amdgcn_readfirstlane(w);
+  double vj[8], vn;
+  auto prefetch = [&](int64_t jt) {
+    int64_t gj = jt * GMJ + lane;
+    if(gj > g.N - 1) gj = g.N - 1;
+#pragma unroll
+    for(int u = 0; u < 8; u++) {
+      const int d = ws + 4 * u;
+      vj[u] = 0.0;
+      if(d < dc) vj[u] = (g.X + (int64_t)d * g.ldx)[gj];
+    }
+    vn = g.n1[gj];
+  };
+  prefetch(jt0);
+
+  double s_d2e = 0.0, s_e = 0.0, s_all = 0.0, s_tr = 0.0;
+  double rho[4] = {0.0, 0.0, 0.0, 0.0};
+  gdouble4 Y1[4][QX];
+  double Bq[QX];             // sum_j kappa_j x_jq^2 for q = (lane & 15) + 16 qx, over this lane's columns j = 4 r + (lane >> 4)
+#pragma unroll
+  for(int qx = 0; qx < QX; qx++) Bq[qx] = 0.0;
+#pragma unroll
+  for(int tm = 0; tm < 4; tm++)
+#pragma unroll
+    for(int qx = 0; qx < QX; qx++) Y1[tm][qx] = (gdouble4){0.0, 0.0, 0.0, 0.0};
+  const double hiw = ks.ard_hiw[0];
+
+  for(int64_t jt = jt0; jt < jt1; jt++) {
+    double* Xjb = Xj[(jt - jt0) & 1];
+    double* Njb = Nj[(jt - jt0) & 1];
+    const int64_t j0 = jt * GMJ;
+#pragma unroll
+    for(int u = 0; u < 8; u++) {
+      const int idx = t + 256 * u;
+      Xjb[(idx >> 6) * GSJ + (idx & 63)] = vj[u];
+    }
+    if(t < GMJ) Njb[t] = vn;
+    __syncthreads();
+    if(jt + 1 < jt1) prefetch(jt + 1);
+
+    const bool full = (i0 + GMI <= g.N) && (j0 + GMJ <= g.N);
+    const bool mirror = (j0 + GMJ <= i0);
+    const double wgt = mirror ? 2.0 : 1.0;
+    double c[2][4][4];
+    auto load_cg = [&](int tn) {
+#pragma unroll
+      for(int r = 0; r < 4; r++) {
+        const int64_t gj = j0 + wn * 32 + tn * 16 + (lane >> 4) + 4 * r;
+        const int64_t gjc = (gj < g.N) ? gj : (g.N - 1);
+        double aj[ND > 0 ? ND : 1];
+#pragma unroll
+        for(int o = 0; o < ND; o++) aj[o] = g.A[gjc + (int64_t)o * g.lda];
+#pragma unroll
+        for(int tm = 0; tm < 4; tm++) {
+          const int64_t gi = i0 + wm * 64 + tm * 16 + (lane & 15);
+          const int64_t gic = (gi < g.N) ? gi : (g.N - 1);
+          double v = g.cg[gic + gjc * g.ldc];
+          if(ND > 0) {
+            double aa = 0.0;
+#pragma unroll
+            for(int o = 0; o < ND; o++) aa = fma(ai[o][tm], aj[o], aa);
+            v = -0.5 * ((double)ND * v - aa);
+          }
+          c[tn][r][tm] = (full || (gi < g.N && gj < g.N)) ? v : 0.0;
+        }
+      }
+    };
+    load_cg(0);
+#pragma unroll
+    for(int tn = 0; tn < 2; tn++) {
+      // rows of X^T for this half's 16 columns: r -> j = 4 r + (lane >> 4), QX groups of 16 dimensions; asked for now, used after
+      // the dot products and the exponentials
+      double xc[4][QX];
+#pragma unroll
+      for(int r = 0; r < 4; r++) {
+        int64_t jj = j0 + wn * 32 + tn * 16 + 4 * r + (lane >> 4);
+        if(jj > g.N - 1) jj = g.N - 1;
+#pragma unroll
+        for(int qx = 0; qx < QX; qx++) xc[r][qx] = XT[jj * DP + qx * 16 + (lane & 15)];
+      }
+      gdouble4 acc[4];
+#pragma unroll
+      for(int a = 0; a < 4; a++) acc[a] = (gdouble4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll(NK > 2 ? 2 : NK)
+      for(int kk = 0; kk < NK; kk++) {
+        const int kr = kk * 4 + (lane >> 4);
+        const double b = Xjb[kr * GSJ + wn * 32 + tn * 16 + (lane & 15)];
+#pragma unroll
+        for(int tm = 0; tm < 4; tm++) {
+          const double a = AF_LDS ? Xi[kr * GSI + wm * 64 + tm * 16 + (lane & 15)] : af[AF_LDS ? 0 : kk][tm];
+          acc[tm] = __builtin_amdgcn_mfma_f64_16x16x4f64(b, a, acc[tm], 0, 0, 0);
+        }
+      }
+      if(tn == 0) load_cg(1);
+      // the weights W = wgt * covGrad * exp(-hiw d2) replace the dot products in acc, register for register
+#pragma unroll
+      for(int r = 0; r < 4; r++) {
+        const int jl = wn * 32 + tn * 16 + (lane >> 4) + 4 * r;
+        const int64_t gj = j0 + jl;
+        const double nj = Njb[jl];
+#pragma unroll
+        for(int th = 0; th < 4; th += 2) {
+#pragma unroll
+          for(int u = 0; u < 2; u++) {
+            const int tm = th + u;
+            const int64_t gi = i0 + wm * 64 + tm * 16 + (lane & 15);
+            const double cw = c[tn][r][tm] * wgt;
+            const bool isdiag = (gi == gj);
+            const double cm = isdiag ? 0.0 : cw;
+            const double d2 = fma(-2.0, acc[tm][r], ni[tm] + nj);
+            s_all += cw;
+            s_tr += isdiag ? cw : 0.0;
+            const double e = cm * exp(-(hiw * d2));
+            s_d2e = fma(d2, e, s_d2e);
+            s_e += e;
+            rho[tm] += e;
+            acc[tm][r] = e;
+          }
+        }
+      }
+      // Y(q, i) += sum_j x_jq W(i, j): k-step r covers j = 4 r .. 4 r + 3 of this half.  The x_jq^2 term needs only the
+      // column sums kappa_j = sum_i W(i, j): a butterfly over the 16 lanes that share j, after which lane (j, q) holds both
+      // kappa_j and x_jq
+#pragma unroll
+      for(int r = 0; r < 4; r++) {
+        double kap = (acc[0][r] + acc[1][r]) + (acc[2][r] + acc[3][r]);
+        kap += __shfl_xor(kap, 1, 64);
+        kap += __shfl_xor(kap, 2, 64);
+        kap += __shfl_xor(kap, 4, 64);
+        kap += __shfl_xor(kap, 8, 64);
+#pragma unroll
+        for(int qx = 0; qx < QX; qx++) {
+          const double x1 = xc[r][qx];
+          Bq[qx] = fma(kap * x1, x1, Bq[qx]);
+#pragma unroll
+          for(int tm = 0; tm < 4; tm++) Y1[tm][qx] = __builtin_amdgcn_mfma_f64_16x16x4f64(x1, acc[tm][r], Y1[tm][qx], 0, 0, 0);
+        }
+      }
+    }
+  }
+
+  // ---- the walk is over: scalars as in kern_grad_sym_kernel, then S_q -----------------------------------------------------
+  double out[NP_MAIN];
+#pragma unroll
+  for(int p = 0; p < NP_MAIN; p++) out[p] = 0.0;
+  out[8] = s_d2e;
+  out[9] = s_e;
+  out[12] = s_all;
+  out[13] = s_tr;
+#pragma unroll
+  for(int p = 0; p < NP_MAIN; p++) {
+    if(p == 8 || p == 9 || p == 12 || p == 13) {
+      const double rsum = block_sum(out[p], sh);
+      if(t == 0) mypartial[p] = rsum;
+    } else if(t == 0) {
+      mypartial[p] = 0.0;
+    }
+  }
+  // rho_i over the four column groups of the wave (lanes with the same lane & 15)
+#pragma unroll
+  for(int tm = 0; tm < 4; tm++) {
+    rho[tm] += __shfl_xor(rho[tm], 16, 64);
+    rho[tm] += __shfl_xor(rho[tm], 32, 64);
+  }
+  // sum_i (rho_i x_iq^2 - 2 x_iq Y(q,i)): this lane's dimensions are q = (lane >> 4) + 4 r + 16 qx, its rows lane & 15 of each of
+  // the wave's four 16-row tiles
+  if(t < 128) red[t >> 5][t & 31] = 0.0;
+  __syncthreads();
+#pragma unroll
+  for(int qx = 0; qx < QX; qx++)
+#pragma unroll
+    for(int r = 0; r < 4; r++) {
+      const int q = (lane >> 4) + 4 * r + 16 * qx;
+      double v = 0.0;
+#pragma unroll
+      for(int tm = 0; tm < 4; tm++) {
+        int64_t gi = i0 + wm * 64 + tm * 16 + (lane & 15);
+        if(gi > g.N - 1) gi = g.N - 1;                              // (rows past the end carry zero weights)
+        const double x = (q < dc) ? g.X[gi + (int64_t)q * g.ldx] : 0.0;
+        v += x * fma(rho[tm], x, -2.0 * Y1[tm][qx][r]);
+      }
+      v += __shfl_xor(v, 1, 64);
+      v += __shfl_xor(v, 2, 64);
+      v += __shfl_xor(v, 4, 64);
+      v += __shfl_xor(v, 8, 64);
+      if((lane & 15) == 0) red[w][q] = v;
+      asm volatile("" ::: "memory");   // one group of loads at a time: hoisted together they would set the kernel's register count
+    }
+  __syncthreads();
+  // ... + sum_j kappa_j x_jq^2: lane (lane >> 4, q = lane & 15) holds its columns' share; the four column groups of the wave are
+  // added in a fixed order by the lane of group 0
+#pragma unroll
+  for(int qx = 0; qx < QX; qx++) {
+    double v = Bq[qx];
+    const double v1 = __shfl(v, (lane & 15) + 16, 64), v2 = __shfl(v, (lane & 15) + 32, 64), v3 = __shfl(v, (lane & 15) + 48, 64);
+    if(lane < 16) red[w][lane + 16 * qx] += (v + v1) + (v2 + v3);
+  }
+  __syncthreads();
+  if(t < 32) mypartial[NP_MAIN + t] = (red[0][t] + red[1][t]) + (red[2][t] + red[3][t]);
+}
+
+template <int ND>
+int launch_grad_ard_sym(const KSpecDev& ks, const GradArgs& g, const double* XT, int per, dim3 grid, double* partial, hipStream_t s)
+{
+  // workgroups per CU the kernel is compiled for: at two per CU (256 registers a wave) every variant spills -- the per-dimension
+  // accumulators alone are 16 or 32 doubles a lane -- which costs more than the lost occupancy from D = 5 up (N = 65 536:
+  // D = 8 8.7 -> 8.5 ms, D = 16 12.4 -> 9.1, D = 32 19.8 -> 12.6), but not at D <= 4 (7.5 ms against 18.2).  GPC_KGRAD_ARD_OCC
+  // = 1 / 2 forces one or the other.
+  static int occ_env = -1;
+  if(occ_env < 0) {
+    const char* e = getenv("GPC_KGRAD_ARD_OCC");
+    occ_env = e ? atoi(e) : 0;
+  }
+  const int occ8 = occ_env ? occ_env : (g.D <= 4 ? 2 : 1);
+#define GPC_ARD_LAUNCH(NKV)                                                                                              \
+  do {                                                                                                                     \
+    if(occ8 == 1)                                                                                                          \
+      hipLaunchKernelGGL((kern_grad_ard_sym_kernel<NKV, ND, 1>), grid, dim3(256), 0, s, ks, g, XT, per, partial);          \
+    else                                                                                                                   \
+      hipLaunchKernelGGL((kern_grad_ard_sym_kernel<NKV, ND, 2>), grid, dim3(256), 0, s, ks, g, XT, per, partial);          \
+  } while(0)
+  if(g.D <= 4) GPC_ARD_LAUNCH(1);
+  else if(g.D <= 8) GPC_ARD_LAUNCH(2);
+  else if(g.D <= 16) GPC_ARD_LAUNCH(4);
+  else GPC_ARD_LAUNCH(8);
+#undef GPC_ARD_LAUNCH
+  GPC_HIP_CHECK(hipGetLastError());
+  return GPC_OK;
+}
+
 // per-dimension ARD sums: S_k = sum_{i != j} cg(i,j) k~(i,j) (x_ik - x_jk)^2 for k in [dim0, dim0 + 32)
 __global__ void __launch_bounds__(256) ard_dim_grad_kernel(const KSpecDev ks, const GradArgs g, int64_t dim0,
                                                            double* __restrict__ partial)
@@ -615,7 +951,54 @@ static int kern_grad_impl(const gpc_kspec* ksp, const double* X, int64_t N, int6
     }
     return GPC_OK;
   }
-  if(nd > 0) return GPC_OK;   // fused request outside the symmetric kernel's domain: nothing launched, *took_fused stays false
+  // one rbfard term (+ white / bias), D <= 32: the symmetric walk with the per-dimension sums as MFMA products
+  static int use_ard_sym = -1;
+  if(use_ard_sym < 0) {
+    const char* e = getenv("GPC_KGRAD_ARD_SYM");
+    use_ard_sym = e ? atoi(e) : 1;
+  }
+  bool scales_ok = ard && ks.n_ard == 1;
+  for(int64_t q = 0; scales_ok && q < D; q++) scales_ok = ks.ard_scale[0][q] > 1e-150;   // (S_q is divided by s_q below)
+  if(use_sym && use_ard_sym && scales_ok && !dot && D >= 1 && D <= GMDC && nd <= 2) {
+    const int dp = (D > 16) ? 32 : 16;
+    const int64_t nrb = sym_nrb, per = sym_per, ny = sym_ny, nwg = sym_nwg;
+    void* wx = nullptr;
+    GPC_CHECK(workspace(WS_XSCALED, sizeof(double) * ((size_t)N * (size_t)(D + dp) + (size_t)nwg * NP_ARDSYM + 64), &wx));
+    double* Xs = static_cast<double*>(wx);
+    double* XT = Xs + (size_t)N * D;
+    double* mean = XT + (size_t)N * dp;
+    double* part2 = mean + 64;
+    hipLaunchKernelGGL(ard_mean_kernel, dim3((unsigned)D), dim3(256), 0, s, X, ldx, N, mean);
+    hipLaunchKernelGGL(ard_prep_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, ks, X, ldx, N, (int)D, mean, Xs, XT, dp,
+                       nrm);
+    GPC_HIP_CHECK(hipGetLastError());
+    GradArgs ga = g;
+    ga.X = Xs;
+    ga.ldx = N;
+    const dim3 grid((unsigned)nrb, (unsigned)ny);
+    if(nd == 0) GPC_CHECK(launch_grad_ard_sym<0>(ks, ga, XT, (int)per, grid, part2, s));
+    else if(nd == 1) GPC_CHECK(launch_grad_ard_sym<1>(ks, ga, XT, (int)per, grid, part2, s));
+    else GPC_CHECK(launch_grad_ard_sym<2>(ks, ga, XT, (int)per, grid, part2, s));
+    double S3[NP_ARDSYM];
+    GPC_CHECK(fetch_partials(part2, nwg, NP_ARDSYM, S3, s));
+    if(took_fused) *took_fused = true;
+    for(int t = 0; t < ksp->n_terms; t++) {
+      double* gt = gout + ksp->offs[t];
+      const double* p = ksp->params + ksp->offs[t];
+      switch(ksp->types[t]) {
+      case GPC_KERN_RBFARD:
+        gt[0] = -0.5 * p[1] * S3[8];
+        gt[1] = S3[13] + S3[9];
+        for(int64_t q = 0; q < D; q++) gt[2 + q] = -0.5 * p[0] * p[1] * (S3[NP_MAIN + q] / ks.ard_scale[0][q]);
+        break;
+      case GPC_KERN_WHITE: gt[0] = S3[13]; break;
+      case GPC_KERN_BIAS: gt[0] = S3[12]; break;
+      default: break;
+      }
+    }
+    return GPC_OK;
+  }
+  if(nd > 0) return GPC_OK;   // fused request outside the symmetric kernels' domain: nothing launched, *took_fused stays false
   if(dot && ard)
     hipLaunchKernelGGL((kern_grad_kernel<true, true>), dim3((unsigned)nblk), dim3(256), 0, s, ks, g, partial);
   else if(dot)

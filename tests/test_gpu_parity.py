@@ -363,8 +363,41 @@ def test_kern_grad_fused_covgrad(api, N, D, d):
     assert np.abs(got - want).max() <= 1e-12 * max(1.0, np.abs(want).max())
     assert np.array_equal(got, api.kern_grad_fused(ks, Xd, Id, Ad))                      # fixed-order reduction
     ard = api.kspec([("rbfard", [1.0, 1.0] + [0.5] * D), ("white", [0.1])])
-    assert api.kern_grad_fused(ard, Xd, Id, Ad) is None                                 # outside the fused pass: refused
+    got = api.kern_grad_fused(ard, Xd, Id, Ad)                                          # one rbfard term: fused as well
+    assert got is not None
+    want = api.kern_grad(ard, Xd, cg)
+    assert np.abs(got - want).max() <= 1e-12 * max(1.0, np.abs(want).max())
+    mixed = api.kspec([("rbfard", [1.0, 1.0] + [0.5] * D), ("lin", [0.2])])
+    assert api.kern_grad_fused(mixed, Xd, Id, Ad) is None                               # outside the fused passes: refused
     assert api.kern_grad_fused(ks, Xd, Id, api.from_host(rng.randn(N, 3))) is None
+
+
+@pytest.mark.parametrize("shift", [0.0, 40.0])
+@pytest.mark.parametrize("N,D", [(1, 1), (63, 3), (129, 4), (300, 5), (517, 8), (640, 9), (700, 16), (333, 17), (900, 32)])
+def test_kern_grad_ard_vs_numpy(api, N, D, shift):
+    """CRbfardKern::getGradParams (CKern.cpp:3359-3403) on the symmetric MFMA walk -- the per-dimension sums as matrix
+    products of the weight tile with rows of X^T -- against the defining double sums; inputs far from the origin too (the
+    kernel centres them: only differences matter)."""
+    rng = np.random.RandomState(7 * N + D)
+    X = rng.randn(N, D) / np.sqrt(D) + shift
+    cg = rng.randn(N, N)
+    cg = cg + cg.T
+    iw, var = 1.3, 0.7
+    scales = rng.uniform(0.1, 1.0, D)
+    terms = [("rbfard", [iw, var] + list(scales)), ("bias", [0.3]), ("white", [0.05])]
+    got = api.kern_grad(api.kspec(terms), api.from_host(X), api.from_host(cg))
+    dq2 = (X[:, None, :] - X[None, :, :]) ** 2
+    d2 = (dq2 * scales).sum(-1)
+    kt = np.exp(-0.5 * iw * d2)
+    off = ~np.eye(N, dtype=bool)
+    w = np.where(off, cg * kt, 0.0)
+    want = [float(-0.5 * var * (w * d2).sum()), float(np.trace(cg) + w.sum())]
+    want += [float(-0.5 * iw * var * (w * dq2[:, :, q]).sum()) for q in range(D)]
+    want += [float(cg.sum()), float(np.trace(cg))]
+    want = np.array(want)
+    assert np.abs(got - want).max() <= 1e-10 * max(1.0, np.abs(want).max()) * max(1.0, N / 10.0)
+    again = api.kern_grad(api.kspec(terms), api.from_host(X), api.from_host(cg))
+    assert np.array_equal(got, again)                                            # fixed-order reduction
 
 
 @pytest.mark.parametrize("name", KERN_FIXTURES)
