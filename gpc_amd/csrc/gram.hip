@@ -558,6 +558,8 @@ __global__ void __launch_bounds__(256, 2) gram_sym_kernel(const KSpecDev ks, con
     if(!SPLIT) products(0, 2);
     const bool full = (i0 + MI <= g.N) && (j0 + MJ <= g.N);
     const bool mirror = (j0 + MJ <= i0);   // strictly left of the diagonal block (workgroup-uniform)
+    const bool rowstore = (g.debug == 16);   // experiment, off: 512-byte runs through the staging patch lose to the direct store
+                                             // (N = 65 536: 7.9 -> 8.5 ms at D = 32, 6.5 -> 7.1 ms at D = 8)
 #pragma unroll
     for(int tn = 0; tn < 2; tn++) {
       if(SPLIT) {
@@ -585,10 +587,25 @@ __global__ void __launch_bounds__(256, 2) gram_sym_kernel(const KSpecDev ks, con
             const int64_t gi = i0 + wm * 64 + tm * 16 + (lane & 15);
             double k = kv[u];
             if(gi == gj) k = fma(ks.lin_var, ni[tm], diag_const);   // diagComputeElement
-            if(full || (gi < g.N && gj < g.N)) g.K[gi + gj * g.ldk] = k;
-            if(mirror) Tw[(tm * 16 + (lane & 15)) * TS + 4 * r + (lane >> 4)] = k;
+            if(!rowstore && (full || (gi < g.N && gj < g.N))) g.K[gi + gj * g.ldk] = k;
+            if(mirror || rowstore) Tw[(tm * 16 + (lane & 15)) * TS + 4 * r + (lane >> 4)] = k;
           }
         }
+      }
+      if(rowstore) {
+        // the direct store as well through the staging patch, read with lanes along i: one column of the patch per
+        // instruction, 512 contiguous bytes (straight from the accumulator layout an instruction writes four 128-byte
+        // pieces of four different columns)
+        __builtin_amdgcn_wave_barrier();
+        const int64_t gi = i0 + wm * 64 + lane;
+        double* Kp = g.K + gi + (j0 + wn * 32 + tn * 16) * g.ldk;
+#pragma unroll 4
+        for(int u = 0; u < 16; u++) {
+          const double k = Tw[lane * TS + u];
+          if(full || (gi < g.N && j0 + wn * 32 + tn * 16 + u < g.N)) *Kp = k;
+          Kp += g.ldk;
+        }
+        if(!mirror) __builtin_amdgcn_wave_barrier();
       }
       if(mirror) {
         // the wave's 64 (i) x 16 (j) patch of this tn, now read with lanes along j: K(j, i), 128-byte runs
