@@ -284,7 +284,12 @@ int gpc_chol_inverse_f64(int64_t N, double* A, int64_t lda, double* invK, int64_
   GPC_CHECK(workspace(WS_INFO, 64, &wi));
   int* d_info = static_cast<int*>(wi);
   GPC_HIP_CHECK(hipMemsetAsync(d_info, 0, sizeof(int), s));
-  if(N > 2048) {
+  static int64_t aug_max = -1;
+  if(aug_max < 0) {
+    const char* e = getenv("GPC_CHOLINV_MAXN");
+    aug_max = e ? atoll(e) : 3072;
+  }
+  if(N > aug_max) {
     // large matrices: the factorisation and dpotri as two calls (an augmented factorisation would triple the flops)
     GPC_CHECK(potrf_lower(N, A, lda, d_info, s));
     GPC_CHECK(read_info(d_info, info, s));

@@ -287,7 +287,7 @@ void CGp::updateK() const
   double jit = 0.0;
   int info = 0;
   bool haveInverse = false;
-  if(needInverse && N <= 2048) {
+  if(needInverse && N <= 3072) {
     // small model, gradient wanted: factor and inverse in ONE chain of launches (the identity rides through the
     // factorisation, gpc_chol_inverse_f64); jitChol's schedule only if that attempt fails
     if(!dInvK) dInvK = devAlloc((size_t)N * N);
