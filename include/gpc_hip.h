@@ -308,8 +308,15 @@ int gpc_profile_read(int kind, int64_t* launches, double* total_ms, double* algo
  * roofline fraction is quoted against next to the datasheet peak.  Also returns the shader cycles per MFMA per SIMD
  * (s_memtime) and the effective shader clock during the probe; either pointer may be NULL. */
 int gpc_probe_mfma_f64(double* tflops, double* cycles_per_mfma_per_simd, double* clock_ghz, void* stream);
+/* The phase stamps of the last dataflow panel factorisation (panel_flow.hip) that ran with env GPC_PANEL_FLOW_TRACE = 1 or 2:
+ * out[(b * 64 + c) * 4 + k], block (b, c) of the panel (b, c < 64), k = start / products done / block ready / end, in ticks of
+ * the 100 MHz constant clock (tools/flow_check.py prints them).  n = number of values wanted (<= 64 * 64 * 4). */
+int gpc_debug_panel_flow_trace(long long* out, int64_t n);
 
 /* ---- tuning knobs (also read from env GPC_NB / GPC_JB on first use) ---------------------------------------------- */
+/* Outer panel width of gpc_potrf_f64.  Unset (and no GPC_NB), the width follows the remaining columns: 1024, 2048 once <= 8192
+ * columns are left, and the last <= 4096 columns as one dataflow launch (panel_flow.hip; env GPC_PANEL_FLOW=0 switches that
+ * kernel off, GPC_PANEL_FLOW_MAXROWS sets the tallest panel it takes, default 24576). */
 int gpc_set_potrf_blocking(int64_t nb_outer, int64_t jb_inner);
 /* Look-ahead of depth 1 in gpc_potrf_f64 (panel k+1 on a second, high-priority HIP stream while the trailing update
  * of panel k runs); on by default, env GPC_LOOKAHEAD=0 or this call turn it off. */
