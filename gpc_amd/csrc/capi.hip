@@ -334,7 +334,10 @@ int gpc_chol_inverse_f64(int64_t N, double* A, int64_t lda, double* invK, int64_
   // L back into A.  (The whole block: W's upper triangle still holds the values it was given, i.e. A's own.)
   GPC_HIP_CHECK(hipMemcpy2DAsync(A, sizeof(double) * (size_t)lda, W, sizeof(double) * (size_t)ld2, sizeof(double) * (size_t)N,
                                  (size_t)N, hipMemcpyDeviceToDevice, s));
-  GPC_CHECK(gemm(false, true, N, N, Np, 1.0, W + Np, ld2, W + Np, ld2, 0.0, invK, ldi, 1, s));
+  {
+    KStartScope ks;   // L^-T is upper triangular: a tile's product starts at its own first row (as in potri_full)
+    GPC_CHECK(gemm(false, true, N, N, Np, 1.0, W + Np, ld2, W + Np, ld2, 0.0, invK, ldi, 1, s));
+  }
   return symmetrize(true, N, invK, ldi, s);
 }
 
