@@ -149,27 +149,34 @@ __global__ void __launch_bounds__(256) panel_flow_kernel(const PanelFlowArgs g)
     double* Bs = arena + 64 * PF_OS;
     const double* pa = g.X + r0 + lane + (int64_t)wv * g.ldx;                 // row `lane` of row block b, column wv + 4 i
     const double* pb = g.X + (int64_t)c * 64 + lane + (int64_t)wv * g.ldx;    // ... of row block c
-    double va[16], vb[16];
+    // Full chunks t = 0 .. c-2, their operands requested TWO chunks ahead (one set of registers being staged and multiplied,
+    // two in flight): a device-scope atomic load takes 2-3 us to come back, a 64-deep product 1.7 us, and one workgroup has
+    // the CU to itself, so the second outstanding chunk is what keeps the matrix cores busy.  A request is one round of
+    // loads; whoever finds a sentinel among them when the values are needed polls (pf_fetch).
+    double va[3][16], vb[3][16];
+    bool have[3] = {false, false, false};
     bool lost = false;
-    auto fetch = [&](int tt) {
-      if(!pf_fetch<16>(g, pa + (int64_t)tt * 64 * g.ldx, 4 * g.ldx, va)) lost = true;
-      if(diag) {
-#pragma unroll
-        for(int i = 0; i < 16; i++) vb[i] = va[i];
-      } else if(!pf_fetch<16>(g, pb + (int64_t)tt * 64 * g.ldx, 4 * g.ldx, vb)) {
-        lost = true;
+    auto request = [&](int slot, int tt) {
+      bool ok = pf_try<16>(pa + (int64_t)tt * 64 * g.ldx, 4 * g.ldx, va[slot]);
+      if(!diag) ok = pf_try<16>(pb + (int64_t)tt * 64 * g.ldx, 4 * g.ldx, vb[slot]) && ok;
+      have[slot] = ok;
+    };
+    auto complete = [&](int slot, int tt) {
+      if(!have[slot]) {
+        if(!pf_fetch<16>(g, pa + (int64_t)tt * 64 * g.ldx, 4 * g.ldx, va[slot])) lost = true;
+        if(!diag && !pf_fetch<16>(g, pb + (int64_t)tt * 64 * g.ldx, 4 * g.ldx, vb[slot])) lost = true;
       }
     };
-    if(c > 1) fetch(0);
-    for(int tt = 0; tt + 1 < c; tt++) {
+    auto multiply = [&](int slot) {
       __syncthreads();                                                   // the previous chunk's fragment reads are done
 #pragma unroll
       for(int i = 0; i < 16; i++) {
-        As[(wv + 4 * i) * PF_OS + lane] = va[i];
-        Bs[(wv + 4 * i) * PF_OS + lane] = vb[i];
+        As[(wv + 4 * i) * PF_OS + lane] = va[slot][i];
+        Bs[(wv + 4 * i) * PF_OS + lane] = diag ? va[slot][i] : vb[slot][i];
       }
       __syncthreads();
-      if(tt + 2 < c) fetch(tt + 1);
+    };
+    auto products = [&]() {
 #pragma unroll
       for(int kk = 0; kk < 16; kk++) {
         double a[2], bb[2];
@@ -183,6 +190,22 @@ __global__ void __launch_bounds__(256) panel_flow_kernel(const PanelFlowArgs g)
         for(int tn = 0; tn < 2; tn++)
 #pragma unroll
           for(int tm = 0; tm < 2; tm++) acc[tm][tn] = __builtin_amdgcn_mfma_f64_16x16x4f64(bb[tn], a[tm], acc[tm][tn], 0, 0, 0);
+      }
+    };
+    const int nfull = c - 1;
+    if(nfull > 0) request(0, 0);
+    if(nfull > 1) request(1, 1);
+    // the slots rotate 0, 1, 2; unrolled by three so that every register index is static
+    for(int t0 = 0; t0 < nfull; t0 += 3) {
+#pragma unroll
+      for(int u = 0; u < 3; u++) {
+        const int tt = t0 + u;
+        if(tt < nfull) {
+          complete(u, tt);
+          multiply(u);
+          if(tt + 2 < nfull) request((u + 2) % 3, tt + 2);
+          products();
+        }
       }
     }
     // the last pair of blocks, (b, c-1) and (c, c-1), is the one still being solved when this block sits on the critical
