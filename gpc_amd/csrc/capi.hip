@@ -287,7 +287,7 @@ int gpc_chol_inverse_f64(int64_t N, double* A, int64_t lda, double* invK, int64_
   static int64_t aug_max = -1;
   if(aug_max < 0) {
     const char* e = getenv("GPC_CHOLINV_MAXN");
-    aug_max = e ? atoll(e) : 3072;
+    aug_max = e ? atoll(e) : 6144;
   }
   if(N > aug_max) {
     // large matrices: the factorisation and dpotri as two calls (an augmented factorisation would triple the flops)
@@ -323,7 +323,7 @@ int gpc_chol_inverse_f64(int64_t N, double* A, int64_t lda, double* invK, int64_
     GPC_CHECK(set_identity(Np - N, Np - N, W + N + (size_t)N * ld2, ld2, s));
   }
   GPC_CHECK(set_identity(N, N, W + Np, ld2, s));
-  GPC_CHECK(potrf_lower_tall(rows, Np, W, ld2, d_info, s));
+  GPC_CHECK(potrf_lower_tall(rows, Np, W, ld2, d_info, s, true));
   GPC_CHECK(read_info(d_info, info, s));
   if(*info != 0) return GPC_OK;
   if(logdet) {

@@ -31,6 +31,7 @@ struct PanelFlowArgs {
   int64_t lda, M;
   int nbk, ncb;       // columns, column blocks of 64 (the last one may be narrower)
   int nrb;            // row blocks of 64
+  int zb0, zshift;    // rows from block zb0 on hold an identity whose row block i is zero left of column block i - zshift (zb0 < 0: none)
   int64_t col0;       // global index of the panel's first column (for info)
   int* info;          // LAPACK info word (device)
   int* ctl;           // [0] ticket counter, [1] abort flag (1 = pivot failure, 2 = time-out)
@@ -122,6 +123,11 @@ __global__ void __launch_bounds__(256) panel_flow_kernel(const PanelFlowArgs g)
   const int nr = (int)((g.M - r0 < 64) ? (g.M - r0) : 64);        // real rows
   const int ncol = (c == g.ncb - 1) ? (g.nbk - 64 * c) : 64;      // real columns
   const bool diag = (b == c);
+  // rows of an identity riding below the matrix (chol_inverse's [K; I]): block (b, c) left of the identity's own diagonal is
+  // zero and stays zero -- nothing to compute, nothing to publish, and nobody asks for it (products of such a row start at
+  // its first non-zero column block)
+  const int tstart = (g.zb0 >= 0 && b >= g.zb0 && b - g.zb0 - g.zshift > 0) ? (b - g.zb0 - g.zshift) : 0;
+  if(c < tstart) return;
   const bool tr = g.trace && b < 64 && t == 0;
   if(tr) pf_trace[(b * 64 + c) * 4 + 0] = wall_clock64();
 
@@ -144,7 +150,7 @@ __global__ void __launch_bounds__(256) panel_flow_kernel(const PanelFlowArgs g)
   for(int i = 0; i < 2; i++)
 #pragma unroll
     for(int j = 0; j < 2; j++) acc[i][j] = (double4_t){0.0, 0.0, 0.0, 0.0};
-  if(c > 0) {
+  if(c > tstart) {
     double* As = arena;
     double* Bs = arena + 64 * PF_OS;
     const double* pa = g.X + r0 + lane + (int64_t)wv * g.ldx;                 // row `lane` of row block b, column wv + 4 i
@@ -192,18 +198,18 @@ __global__ void __launch_bounds__(256) panel_flow_kernel(const PanelFlowArgs g)
           for(int tm = 0; tm < 2; tm++) acc[tm][tn] = __builtin_amdgcn_mfma_f64_16x16x4f64(bb[tn], a[tm], acc[tm][tn], 0, 0, 0);
       }
     };
-    const int nfull = c - 1;
-    if(nfull > 0) request(0, 0);
-    if(nfull > 1) request(1, 1);
+    const int nfull = c - 1 - tstart;                     // chunks t = tstart .. c-2
+    if(nfull > 0) request(0, tstart);
+    if(nfull > 1) request(1, tstart + 1);
     // the slots rotate 0, 1, 2; unrolled by three so that every register index is static
     for(int t0 = 0; t0 < nfull; t0 += 3) {
 #pragma unroll
       for(int u = 0; u < 3; u++) {
         const int tt = t0 + u;
         if(tt < nfull) {
-          complete(u, tt);
+          complete(u, tstart + tt);
           multiply(u);
-          if(tt + 2 < nfull) request((u + 2) % 3, tt + 2);
+          if(tt + 2 < nfull) request((u + 2) % 3, tstart + tt + 2);
           products();
         }
       }
@@ -566,8 +572,11 @@ __global__ void __launch_bounds__(256) panel_flow_kernel(const PanelFlowArgs g)
 }  // namespace
 
 // Factor the nbk-column panel whose diagonal block starts at P (M rows, M >= nbk): one launch.  Returns GPC_EUNSUPPORTED
-// when the shape is outside what the kernel takes (the caller then runs the launch chain).
-int panel_flow(int64_t M, int64_t nbk, double* P, int64_t lda, int* d_info, int64_t col0, hipStream_t s)
+// when the shape is outside what the kernel takes (the caller then runs the launch chain).  zero_row0 >= 0: the rows from
+// zero_row0 on (a multiple of 64, relative to the panel) are an identity block whose 64-row block i is still zero left of
+// column block i - zero_shift of this panel; those blocks are skipped.
+int panel_flow(int64_t M, int64_t nbk, double* P, int64_t lda, int* d_info, int64_t col0, hipStream_t s, int64_t zero_row0,
+               int64_t zero_shift)
 {
   if(M < nbk || nbk <= 0 || nbk > 4096) return GPC_EUNSUPPORTED;
   const int64_t nrb = (M + 63) / 64;
@@ -588,6 +597,8 @@ int panel_flow(int64_t M, int64_t nbk, double* P, int64_t lda, int* d_info, int6
   g.nbk = (int)nbk;
   g.ncb = ncb;
   g.nrb = (int)nrb;
+  g.zb0 = (zero_row0 >= 0 && zero_row0 % 64 == 0) ? (int)(zero_row0 / 64) : -1;
+  g.zshift = (int)zero_shift;
   g.col0 = col0;
   g.info = d_info;
   g.ctl = ctl;

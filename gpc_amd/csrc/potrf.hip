@@ -597,11 +597,12 @@ static int64_t panel_flow_maxrows()
 // the whole remaining panel after every 64 columns this moves 1.75x fewer bytes of the panel through HBM (the
 // 64-deep updates are memory-bound) in half as many GEMM launches: 1.51 -> 1.29 ms for a 65 536 x 512 panel.
 constexpr int64_t SLAB = 128;
-int factor_panel(int64_t N, double* A, int64_t lda, int64_t k0, int64_t nbk, int* d_info, hipStream_t s, int64_t col0 = 0)
+int factor_panel(int64_t N, double* A, int64_t lda, int64_t k0, int64_t nbk, int* d_info, hipStream_t s, int64_t col0 = 0,
+                 int64_t zrow = -1)
 {
   // short panels: the whole panel as one dataflow launch (panel_flow.hip) instead of five launches per 128 columns
   if(N - k0 <= panel_flow_maxrows()) {
-    const int rc = panel_flow(N - k0, nbk, A + k0 + k0 * lda, lda, d_info, col0 + k0, s);
+    const int rc = panel_flow(N - k0, nbk, A + k0 + k0 * lda, lda, d_info, col0 + k0, s, zrow >= 0 ? zrow - k0 : -1, k0 / 64);
     if(rc != GPC_EUNSUPPORTED) return rc;
   }
   const int64_t kend = k0 + nbk;
@@ -779,15 +780,20 @@ int potrf_lower(int64_t N, double* A, int64_t lda, int* d_info, hipStream_t s, i
 // Right-looking Cholesky of the leading Ncols x Ncols block of a TALL array (Nrows >= Ncols rows): the rows below the
 // square take every panel solve and trailing update along, so an identity stored there comes out as L^-T (chol_inverse in
 // capi.hip).  Same panel chain, no look-ahead (small matrices only); the updates are lower trapezoids.
-int potrf_lower_tall(int64_t Nrows, int64_t Ncols, double* A, int64_t lda, int* d_info, hipStream_t s)
+int potrf_lower_tall(int64_t Nrows, int64_t Ncols, double* A, int64_t lda, int* d_info, hipStream_t s, bool identity_below)
 {
+  // identity_below: rows Ncols .. Nrows-1 hold an identity in their leading columns.  Row Ncols + i is zero left of column i
+  // until that column is factored, so a panel that ends at column kend only has to carry the identity rows i < kend along
+  // (the others are zero in its columns and stay untouched); inside the dataflow kernel the zero blocks are skipped too.
+  const int64_t nid = Nrows - Ncols;
   int64_t nbk = 0;
   for(int64_t k0 = 0; k0 < Ncols; k0 += nbk) {
     const int64_t NB = panel_width(Ncols - k0);
     nbk = (Ncols - k0 < NB) ? (Ncols - k0) : NB;
     const int64_t kend = k0 + nbk;
-    GPC_CHECK(factor_panel(Nrows, A, lda, k0, nbk, d_info, s, 0));
-    const int64_t mc = Ncols - kend, mr = Nrows - kend;
+    const int64_t rows = identity_below ? (Ncols + (nid < kend ? nid : kend)) : Nrows;
+    GPC_CHECK(factor_panel(rows, A, lda, k0, nbk, d_info, s, 0, (identity_below && Ncols % 64 == 0) ? Ncols : -1));
+    const int64_t mc = Ncols - kend, mr = rows - kend;
     if(mc > 0) {
       const double* L21 = A + kend + k0 * lda;
       TrailingScope role;

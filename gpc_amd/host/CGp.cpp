@@ -287,9 +287,9 @@ void CGp::updateK() const
   double jit = 0.0;
   int info = 0;
   bool haveInverse = false;
-  if(needInverse && N <= 3072) {
-    // small model, gradient wanted: factor and inverse in ONE chain of launches (the identity rides through the
-    // factorisation, gpc_chol_inverse_f64); jitChol's schedule only if that attempt fails
+  if(needInverse && N <= 8192) {
+    // small model, gradient wanted: factor + log-det + inverse in ONE call (gpc_chol_inverse_f64: up to N = 6144 the identity
+    // rides through the factorisation, beyond that it is dpotrf + dpotri); jitChol's schedule only if that attempt fails
     if(!dInvK) dInvK = devAlloc((size_t)N * N);
     gpcCheck(gpc_gram_sym_f64(&ks, dX, N, D, N, dL, N, 0));
     gpcCheck(gpc_chol_inverse_f64(N, dL, N, dInvK, N, &logDetK, &info, 0));
