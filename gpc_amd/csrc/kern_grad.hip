@@ -551,7 +551,8 @@ __global__ void __launch_bounds__(256, OCC) kern_grad_ard_sym_kernel(const KSpec
     const bool full = (i0 + GMI <= g.N) && (j0 + GMJ <= g.N);
     const bool mirror = (j0 + GMJ <= i0);
     const double wgt = mirror ? 2.0 : 1.0;
-    double c[2][4][4];
+    constexpr bool LEAN = (OCC == 2);   // two workgroups per CU: no covGrad held for the next half (the other workgroup's waves cover the latency)
+    double c[LEAN ? 1 : 2][4][4];
     auto load_cg = [&](int tn) {
 #pragma unroll
       for(int r = 0; r < 4; r++) {
@@ -571,13 +572,14 @@ __global__ void __launch_bounds__(256, OCC) kern_grad_ard_sym_kernel(const KSpec
             for(int o = 0; o < ND; o++) aa = fma(ai[o][tm], aj[o], aa);
             v = -0.5 * ((double)ND * v - aa);
           }
-          c[tn][r][tm] = (full || (gi < g.N && gj < g.N)) ? v : 0.0;
+          c[LEAN ? 0 : tn][r][tm] = (full || (gi < g.N && gj < g.N)) ? v : 0.0;
         }
       }
     };
-    load_cg(0);
+    if(!LEAN) load_cg(0);
 #pragma unroll
     for(int tn = 0; tn < 2; tn++) {
+      if(LEAN) load_cg(tn);
       // rows of X^T for this half's 16 columns: r -> j = 4 r + (lane >> 4), QX groups of 16 dimensions; asked for now, used after
       // the dot products and the exponentials
       double xc[4][QX];
@@ -601,7 +603,7 @@ __global__ void __launch_bounds__(256, OCC) kern_grad_ard_sym_kernel(const KSpec
           acc[tm] = __builtin_amdgcn_mfma_f64_16x16x4f64(b, a, acc[tm], 0, 0, 0);
         }
       }
-      if(tn == 0) load_cg(1);
+      if(!LEAN && tn == 0) load_cg(1);
       // the weights W = wgt * covGrad * exp(-hiw d2) replace the dot products in acc, register for register
 #pragma unroll
       for(int r = 0; r < 4; r++) {
@@ -614,7 +616,7 @@ __global__ void __launch_bounds__(256, OCC) kern_grad_ard_sym_kernel(const KSpec
           for(int u = 0; u < 2; u++) {
             const int tm = th + u;
             const int64_t gi = i0 + wm * 64 + tm * 16 + (lane & 15);
-            const double cw = c[tn][r][tm] * wgt;
+            const double cw = c[LEAN ? 0 : tn][r][tm] * wgt;
             const bool isdiag = (gi == gj);
             const double cm = isdiag ? 0.0 : cw;
             const double d2 = fma(-2.0, acc[tm][r], ni[tm] + nj);
@@ -712,16 +714,17 @@ __global__ void __launch_bounds__(256, OCC) kern_grad_ard_sym_kernel(const KSpec
 template <int ND>
 int launch_grad_ard_sym(const KSpecDev& ks, const GradArgs& g, const double* XT, int per, dim3 grid, double* partial, hipStream_t s)
 {
-  // workgroups per CU the kernel is compiled for: at two per CU (256 registers a wave) every variant spills -- the per-dimension
-  // accumulators alone are 16 or 32 doubles a lane -- which costs more than the lost occupancy from D = 5 up (N = 65 536:
-  // D = 8 8.7 -> 8.5 ms, D = 16 12.4 -> 9.1, D = 32 19.8 -> 12.6), but not at D <= 4 (7.5 ms against 18.2).  GPC_KGRAD_ARD_OCC
-  // = 1 / 2 forces one or the other.
+  // workgroups per CU the kernel is compiled for.  At two per CU (256 registers a wave) the variant keeps no covGrad values for
+  // the next half in registers (the other workgroup's waves cover that latency) and still spills a little; that wins up to
+  // D = 8 (N = 65 536: D = 4 6.3 ms, D = 8 6.9 ms = 2.5 TB/s of the 4 N^2 bytes, against 18.2 / 8.4 ms at one per CU) and loses
+  // beyond, where the per-dimension accumulators and the LDS-resident row operand push the spills past 150 registers
+  // (D = 16: 12.0 ms against 9.1, D = 32: 19.8 against 12.6).  GPC_KGRAD_ARD_OCC = 1 / 2 forces one or the other.
   static int occ_env = -1;
   if(occ_env < 0) {
     const char* e = getenv("GPC_KGRAD_ARD_OCC");
     occ_env = e ? atoi(e) : 0;
   }
-  const int occ8 = occ_env ? occ_env : (g.D <= 4 ? 2 : 1);
+  const int occ8 = occ_env ? occ_env : (g.D <= 8 ? 2 : 1);
 #define GPC_ARD_LAUNCH(NKV)                                                                                              \
   do {                                                                                                                     \
     if(occ8 == 1)                                                                                                          \
