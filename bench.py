@@ -439,8 +439,14 @@ def main():
             t_potri, _ = timed(lambda: api.potri(inv, "L"))                # CMatrix::pdinv for the gradient
             phases.update({"potri_ms": t_potri, "potri_tflops_at_2N3_over_3": 2.0 * N ** 3 / 3.0 / (t_potri * 1e-3) * 1e-12})
             # CKern::getGradParams over a symmetric N x N covGrad (the inverse stands in for it: same bytes, same work)
+            api.kern_grad(ks, Xd, inv)                                     # (first call allocates its partial-sum workspace)
             t_kg, _ = timed(lambda: api.kern_grad(ks, Xd, inv))
             phases.update({"kern_grad_ms": t_kg, "kern_grad_GBs_of_4N2_bytes": 4.0 * N * N / (t_kg * 1e-3) * 1e-9})
+            # the same pass for an rbfard kernel of the same input dimension (CRbfardKern::getGradParams: D more sums)
+            ks_ard = api.kspec([("rbfard", [2.0 / D, 1.0] + [0.5] * D), ("white", [0.1])])
+            api.kern_grad(ks_ard, Xd, inv)
+            t_ka, _ = timed(lambda: api.kern_grad(ks_ard, Xd, inv))
+            phases.update({"kern_grad_rbfard_ms": t_ka, "kern_grad_rbfard_GBs_of_4N2_bytes": 4.0 * N * N / (t_ka * 1e-3) * 1e-9})
             del inv
         except (RuntimeError, api._lib.GpcError) as e:                      # not enough HBM for the two extra N x N buffers
             phases["potri_ms"] = None

@@ -316,7 +316,7 @@ __global__ void __launch_bounds__(256, 2) kern_grad_sym_kernel(const KSpecDev ks
 #pragma unroll
       for(int a = 0; a < 4; a++) acc[a] = (gdouble4){0.0, 0.0, 0.0, 0.0};
 #pragma unroll(NK > 2 ? 2 : NK)
-      for(int kk = 0; kk < NK; kk++) {
+      for(int kk = 0; kk < NK; kk++) {   // (fully unrolled, NK = 4 needs no scratch but runs slower: 6.4 -> 8.6 ms at N = 65 536)
         const int kr = kk * 4 + (lane >> 4);
         const double b = Xjb[kr * GSJ + wn * 32 + tn * 16 + (lane & 15)];
 #pragma unroll
@@ -593,8 +593,8 @@ __global__ void __launch_bounds__(256, OCC) kern_grad_ard_sym_kernel(const KSpec
       gdouble4 acc[4];
 #pragma unroll
       for(int a = 0; a < 4; a++) acc[a] = (gdouble4){0.0, 0.0, 0.0, 0.0};
-#pragma unroll(NK > 2 ? 2 : NK)
-      for(int kk = 0; kk < NK; kk++) {
+#pragma unroll
+      for(int kk = 0; kk < NK; kk++) {   // (fully unrolled: as a loop of two-step bodies it costs 100 more registers)
         const int kr = kk * 4 + (lane >> 4);
         const double b = Xjb[kr * GSJ + wn * 32 + tn * 16 + (lane & 15)];
 #pragma unroll
@@ -716,15 +716,15 @@ int launch_grad_ard_sym(const KSpecDev& ks, const GradArgs& g, const double* XT,
 {
   // workgroups per CU the kernel is compiled for.  At two per CU (256 registers a wave) the variant keeps no covGrad values for
   // the next half in registers (the other workgroup's waves cover that latency) and still spills a little; that wins up to
-  // D = 8 (N = 65 536: D = 4 6.3 ms, D = 8 6.9 ms = 2.5 TB/s of the 4 N^2 bytes, against 18.2 / 8.4 ms at one per CU) and loses
-  // beyond, where the per-dimension accumulators and the LDS-resident row operand push the spills past 150 registers
-  // (D = 16: 12.0 ms against 9.1, D = 32: 19.8 against 12.6).  GPC_KGRAD_ARD_OCC = 1 / 2 forces one or the other.
+  // D = 16 (N = 65 536: D = 4 6.3 ms, D = 8 6.9 ms = 2.5 TB/s of the 4 N^2 bytes, D = 16 8.6 ms, against 18.2 / 8.4 / 8.9 ms at
+  // one per CU) and loses at D = 32, where the second group of per-dimension accumulators pushes the spills past 150 registers
+  // (16.9 ms against 11.5).  GPC_KGRAD_ARD_OCC = 1 / 2 forces one or the other.
   static int occ_env = -1;
   if(occ_env < 0) {
     const char* e = getenv("GPC_KGRAD_ARD_OCC");
     occ_env = e ? atoi(e) : 0;
   }
-  const int occ8 = occ_env ? occ_env : (g.D <= 8 ? 2 : 1);
+  const int occ8 = occ_env ? occ_env : (g.D <= 16 ? 2 : 1);
 #define GPC_ARD_LAUNCH(NKV)                                                                                              \
   do {                                                                                                                     \
     if(occ8 == 1)                                                                                                          \
