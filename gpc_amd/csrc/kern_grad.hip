@@ -185,6 +185,12 @@ __global__ void __launch_bounds__(256) kern_grad_kernel(const KSpecDev ks, const
 // HBM-read bound: 4 N^2 bytes.  Partial sums per workgroup in the NP_MAIN layout of kern_grad_kernel, added on the host
 // in a fixed order (deterministic).
 constexpr int GMI = 128, GMJ = 64, GSJ = 80, GMDC = 32, GSI = 144;
+// From this many k-steps (D > 12) the kernel does not request the next half-tile's covGrad values while it works on the current
+// one: holding them costs 32 registers, which at NK >= 4 meant scratch; the CU's other workgroup covers the latency instead
+// (N = 65 536: D = 16 6.4 -> 5.8 ms, D = 32 7.4 -> 6.9 ms; below that the early request still wins by a few per cent).
+#ifndef GPC_KG_LEAN_NK
+#define GPC_KG_LEAN_NK 4
+#endif
 typedef double gdouble4 __attribute__((ext_vector_type(4)));
 
 template <int NRBF, int NK, int ND = 0>
@@ -285,7 +291,8 @@ __global__ void __launch_bounds__(256, 2) kern_grad_sym_kernel(const KSpecDev ks
     const bool full = (i0 + GMI <= g.N) && (j0 + GMJ <= g.N);
     const bool mirror = (j0 + GMJ <= i0);   // strictly left of the diagonal block: every element stands for two
     const double wgt = mirror ? 2.0 : 1.0;
-    double c[2][4][4];
+    constexpr bool LEAN = (NK >= GPC_KG_LEAN_NK);   // no covGrad held for the next half
+    double c[LEAN ? 1 : 2][4][4];
     auto load_cg = [&](int tn) {
 #pragma unroll
       for(int r = 0; r < 4; r++) {
@@ -305,13 +312,14 @@ __global__ void __launch_bounds__(256, 2) kern_grad_sym_kernel(const KSpecDev ks
             for(int o = 0; o < ND; o++) aa = fma(ai[o][tm], aj[o], aa);
             v = -0.5 * ((double)ND * v - aa);
           }
-          c[tn][r][tm] = (full || (gi < g.N && gj < g.N)) ? v : 0.0;
+          c[LEAN ? 0 : tn][r][tm] = (full || (gi < g.N && gj < g.N)) ? v : 0.0;
         }
       }
     };
-    load_cg(0);
+    if(!LEAN) load_cg(0);
 #pragma unroll
     for(int tn = 0; tn < 2; tn++) {
+      if(LEAN) load_cg(tn);
       gdouble4 acc[4];
 #pragma unroll
       for(int a = 0; a < 4; a++) acc[a] = (gdouble4){0.0, 0.0, 0.0, 0.0};
@@ -325,7 +333,7 @@ __global__ void __launch_bounds__(256, 2) kern_grad_sym_kernel(const KSpecDev ks
           acc[tm] = __builtin_amdgcn_mfma_f64_16x16x4f64(b, a, acc[tm], 0, 0, 0);
         }
       }
-      if(tn == 0) load_cg(1);
+      if(!LEAN && tn == 0) load_cg(1);
 #pragma unroll
       for(int r = 0; r < 4; r++) {
         const int jl = wn * 32 + tn * 16 + (lane >> 4) + 4 * r;
@@ -338,7 +346,7 @@ __global__ void __launch_bounds__(256, 2) kern_grad_sym_kernel(const KSpecDev ks
           for(int u = 0; u < 2; u++) {
             const int tm = th + u;
             const int64_t gi = i0 + wm * 64 + tm * 16 + (lane & 15);
-            const double cw = c[tn][r][tm] * wgt;
+            const double cw = c[LEAN ? 0 : tn][r][tm] * wgt;
             const bool isdiag = (gi == gj);            // only inside the diagonal block (wgt = 1)
             const double cm = isdiag ? 0.0 : cw;       // the diagonal takes no part in the rbf sums
             const double dot = acc[tm][r];
