@@ -31,7 +31,7 @@ CGp::CGp(CKern* kernel, CNoise* nois, CMatrix* Xin, int approx, unsigned int act
     : pX(Xin), py(nois->py), pkern(kernel), pnoise(nois), ownsKernNoise(false), fileNumData(0), fileInputDim(0),
       numActive(actSetSize), scale(1, nois->getOutputDim(), 1.0),
       bias(1, nois->getOutputDim(), 0.0), refTransRounding(true), MupToDate(false), KupToDate(false),
-      AlphaUpToDate(false), invKupToDate(false), LcholRounded(false), dX(0), dM(0), dL(0), dInvKm(0), dAlpha(0), dInvK(0),
+      AlphaUpToDate(false), invKupToDate(false), invKmUpToDate(false), LcholRounded(false), dX(0), dM(0), dL(0), dInvKm(0), dAlpha(0), dInvK(0),
       dCovGrad(0), logDetK(0.0), lastJitter(0.0), needInverse(false), approxType(approx), betaVal(1e3),
       inducingFixed(false), dXu(0), dKuu(0), dKuf(0), dInvKuu(0), dA(0), dAinv(0), dLA(0), dE(0), dAlphaU(0), dIKK(0),
       logDetKuu(0.0), logDetA(0.0), sumDiagD(0.0), LArounded(false), dVf(0), dBet(0), sumLogDiagD(0.0), sumLogLm(0.0), sMsM(0.0),
@@ -57,7 +57,7 @@ CGp::CGp(CKern* kernel, CNoise* nois, CMatrix* Xin, int approx, unsigned int act
 CGp::CGp()
     : pX(0), py(0), pkern(0), pnoise(0), ownsKernNoise(true), fileNumData(0), fileInputDim(0), numActive(0), scale(1, 1, 1.0),
       bias(1, 1, 0.0), refTransRounding(true), MupToDate(false), KupToDate(false), AlphaUpToDate(false),
-      invKupToDate(false), LcholRounded(false), dX(0), dM(0), dL(0), dInvKm(0), dAlpha(0), dInvK(0), dCovGrad(0), logDetK(0.0), lastJitter(0.0),
+      invKupToDate(false), invKmUpToDate(false), LcholRounded(false), dX(0), dM(0), dL(0), dInvKm(0), dAlpha(0), dInvK(0), dCovGrad(0), logDetK(0.0), lastJitter(0.0),
       needInverse(false), approxType(FTC), betaVal(1e3), inducingFixed(false), dXu(0), dKuu(0), dKuf(0), dInvKuu(0), dA(0),
       dAinv(0), dLA(0), dE(0), dAlphaU(0), dIKK(0), logDetKuu(0.0), logDetA(0.0), sumDiagD(0.0), LArounded(false), dVf(0), dBet(0), sumLogDiagD(0.0),
       sumLogLm(0.0), sMsM(0.0), gridPr(1), gridPc(1), gridDecided(0), gridNs(-1)
@@ -278,6 +278,10 @@ void CGp::updateK() const
     gpcCheck(gpc_memcpy_d2d(dInvK, dL, sizeof(double) * (size_t)N * N, 0));
     gpcCheck(gpc_potri_f64('L', N, dInvK, N, 0));
     invKupToDate = true;
+    if(!invKmUpToDate) {   // the objective-only evaluation left L^-1 m in dInvKm; the gradient wants K^-1 m (dsymv in the reference, CGp.cpp:928)
+      gpcCheck(gpc_gemm_f64('N', 'N', N, d, N, 1.0, dInvK, N, dM, N, 0.0, dInvKm, N, 0));
+      invKmUpToDate = true;
+    }
     return;
   }
   if(!dL) dL = devAlloc((size_t)N * N);
@@ -301,10 +305,25 @@ void CGp::updateK() const
   if(info != 0) throw ndlexceptions::MatrixNonPosDef();
   if(jit > 1e-2 && getVerbosity() > 2)
     std::cout << "Warning: jitter of " << jit << " added to K in _updateInvK()." << std::endl;
-  // invK * m without forming invK (the reference uses dsymv on the explicit inverse, CGp.cpp:928)
-  gpcCheck(gpc_gp_alpha_f64(N, d, dL, N, dM, N, dInvKm, N, 0));
   quad.assign((size_t)d, 0.0);
-  gpcCheck(gpc_coldot_f64(N, d, dM, N, dInvKm, N, &quad[0], 0));
+  if(haveInverse) {
+    // invK * m on the explicit inverse, as the reference does (dsymv, CGp.cpp:928); a few columns: the row-per-thread product
+    gpcCheck(gpc_gemm_f64('N', 'N', N, d, N, 1.0, dInvK, N, dM, N, 0.0, dInvKm, N, 0));
+    gpcCheck(gpc_coldot_f64(N, d, dM, N, dInvKm, N, &quad[0], 0));
+    invKmUpToDate = true;
+  } else if(!needInverse) {
+    // objective only: m' K^-1 m = |L^-1 m|^2 needs ONE triangular solve, not the two of K^-1 m (which updateAlpha / the
+    // gradient branch above compute when they are asked for)
+    gpcCheck(gpc_memcpy_d2d(dInvKm, dM, sizeof(double) * (size_t)N * d, 0));
+    gpcCheck(gpc_trsm_f64('L', 'L', 'N', 'N', N, d, 1.0, dL, N, dInvKm, N, 0));
+    gpcCheck(gpc_coldot_f64(N, d, dInvKm, N, dInvKm, N, &quad[0], 0));
+    invKmUpToDate = false;
+  } else {
+    // invK * m without forming invK first
+    gpcCheck(gpc_gp_alpha_f64(N, d, dL, N, dM, N, dInvKm, N, 0));
+    gpcCheck(gpc_coldot_f64(N, d, dM, N, dInvKm, N, &quad[0], 0));
+    invKmUpToDate = true;
+  }
   if(haveInverse) {
     invKupToDate = true;
   } else if(needInverse) {
@@ -361,7 +380,7 @@ void CGp::updateAlpha() const
     gpcCheck(gpc_ref_trans_rounding_f64(N, dL, N, 0));
     LcholRounded = true;
   }
-  if(refTransRounding)
+  if(refTransRounding || !invKmUpToDate)
     gpcCheck(gpc_gp_alpha_f64(N, d, dL, N, dM, N, dAlpha, N, 0));   // Alpha.trsm(LcholK ...) twice, CGp.cpp:481-483
   else
     gpcCheck(gpc_memcpy_d2d(dAlpha, dInvKm, sizeof(double) * (size_t)N * d, 0));

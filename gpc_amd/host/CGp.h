@@ -135,6 +135,7 @@ class CGp : public CProbabilisticOptimisable {
   // caches (mutable, as in the reference: the model is not re-entrant)
   mutable CMatrix m;          // host N x d
   mutable bool MupToDate, KupToDate, AlphaUpToDate, invKupToDate;
+  mutable bool invKmUpToDate;   // dInvKm holds K^-1 m of the current K (an objective-only evaluation leaves L^-1 m there instead)
   mutable bool LcholRounded;  // dL carries the reference's fp32 rounding (applied lazily by updateAlpha)
   mutable double* dX;         // device copy of X (N x D)
   mutable double* dM;         // device copy of m
