@@ -158,6 +158,20 @@ def test_potrf_with_pivots_outside_the_fast_reciprocal_range(api, scale):
     assert rel(np.tril(api.to_host(Ad)), L) < 1e-12
 
 
+def test_potrf_random_sizes_repeatable(api):
+    """Random sizes through the dataflow panels: the factor against numpy, and bit for bit the same on a second run (every block
+    adds its products in a fixed order; nothing in the kernel depends on which workgroup ran first)."""
+    rng = np.random.RandomState(20260929)
+    for _ in range(8):
+        N = int(rng.choice([rng.randint(1, 200), rng.randint(200, 1500), rng.randint(1500, 4500)]))
+        K = spd(N, N)
+        A1, A2 = api.from_host(K), api.from_host(K)
+        assert api.potrf(A1, "L") == 0 and api.potrf(A2, "L") == 0
+        L1, L2 = np.tril(api.to_host(A1)), np.tril(api.to_host(A2))
+        assert np.array_equal(L1, L2), N
+        assert rel(L1, np.linalg.cholesky(K)) < 1e-12, N
+
+
 def test_potrf_blocking_invariance(api):
     # different outer panel widths give the same factor up to rounding
     N = 1500
