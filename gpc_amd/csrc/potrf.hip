@@ -811,6 +811,10 @@ extern "C" int gpc_set_potrf_blocking(int64_t nb_outer, int64_t jb_inner)
     gpc::set_error("inner block is fixed at 64 in this build");
     return GPC_EINVAL;
   }
+  if(nb_outer == 0) {
+    gpc::g_nb_outer = -1;   // back to the default: widths by remaining columns (panel_width()), GPC_NB no longer consulted
+    return GPC_OK;
+  }
   if(nb_outer < gpc::JB || nb_outer % gpc::JB != 0) {
     gpc::set_error("outer block must be a positive multiple of 64");
     return GPC_EINVAL;

@@ -317,7 +317,7 @@ int gpc_debug_panel_flow_trace(long long* out, int64_t n);
 /* Outer panel width of gpc_potrf_f64.  Unset (and no GPC_NB), the width follows the remaining columns: 1024, 2048 once <= 8192
  * columns are left, and the last <= 4096 columns as one dataflow launch (panel_flow.hip; env GPC_PANEL_FLOW=0 switches that
  * kernel off, GPC_PANEL_FLOW_MAXROWS sets the tallest panel it takes, default 24576). */
-int gpc_set_potrf_blocking(int64_t nb_outer, int64_t jb_inner);
+int gpc_set_potrf_blocking(int64_t nb_outer, int64_t jb_inner);   /* nb_outer = 0: back to the default policy */
 /* Look-ahead of depth 1 in gpc_potrf_f64 (panel k+1 on a second, high-priority HIP stream while the trailing update
  * of panel k runs); on by default, env GPC_LOOKAHEAD=0 or this call turn it off. */
 int gpc_set_potrf_lookahead(int on);

@@ -182,7 +182,7 @@ def test_potrf_blocking_invariance(api):
         Ad = api.from_host(A)
         assert api.potrf(Ad, "L") == 0
         outs.append(np.tril(api.to_host(Ad)))
-    api.check(api.lib().gpc_set_potrf_blocking(512, 64))
+    api.check(api.lib().gpc_set_potrf_blocking(0, 0))          # the default policy again
     for o in outs[1:]:
         assert rel(o, outs[0]) < 1e-12
 
@@ -705,6 +705,27 @@ def test_chol_inverse(api, N):
         Kbad[30, 30] = -1.0
         _, _, info = api.chol_inverse(api.from_host(Kbad))
         assert info == 31
+
+
+@pytest.mark.parametrize("nb", [64, 512])
+def test_chol_inverse_over_several_panels(api, nb):
+    """The augmented factorisation with narrow outer panels: the identity riding below K is carried only as far as it has
+    become non-zero (between panels) and its zero blocks are skipped inside the dataflow kernel with a column offset."""
+    N = 1500
+    rng = np.random.RandomState(nb)
+    B = rng.randn(N, N // 2)
+    K = B @ B.T / (N // 2) + np.eye(N) * (0.5 + rng.rand(N))
+    api.check(api.lib().gpc_set_potrf_blocking(nb, 64))
+    try:
+        Kd = api.from_host(K)
+        inv, logdet, info = api.chol_inverse(Kd)
+    finally:
+        api.check(api.lib().gpc_set_potrf_blocking(0, 0))          # the default policy again
+    assert info == 0
+    Lref = np.linalg.cholesky(K)
+    assert abs(logdet - 2.0 * np.log(np.diag(Lref)).sum()) <= 1e-10 * abs(logdet)
+    assert np.abs(np.tril(api.to_host(Kd)) - Lref).max() <= 1e-11 * np.abs(Lref).max()
+    assert np.abs(api.to_host(inv) @ K - np.eye(N)).max() < 1e-9
 
 
 @pytest.mark.parametrize("M,n,K", [(256, 1, 300), (1000, 12, 1000), (4096, 16, 777), (300, 3, 5000), (70000, 2, 64)])
