@@ -3,12 +3,15 @@
 // Replaces dpotrf_ as called by CMatrix::potrf / chol / jitChol (CMatrix.cpp:371-403, 767-804; lapack.h:59-65).
 //
 // Structure:
-//   outer panels of NB = 1024 columns (panel_width()).  After panel k is final its trailing update A22 -= L21 * L21' (depth
+//   outer panels of NB = 1024 columns -- 2048 once <= 8192 columns are left, the last <= 4096 as one panel (panel_width()).
+//   A panel of <= 24 576 rows is ONE launch of the dataflow kernel of panel_flow.hip (a workgroup per 64 x 64 block, blocks
+//   published through a polled exchange buffer); taller panels, and everything when GPC_PANEL_FLOW=0, take the launch chain
+//   described below.  After panel k is final its trailing update A22 -= L21 * L21' (depth
 //   NB, the fp64 MFMA tiles of gemm_f64.hip, N^3/3 of the flops) is split in two launches:
 //       U1(k): the NB columns that form panel k+1 (lower trapezoid),   U2(k): everything to the right of them.
 //   LOOK-AHEAD (N >= 28 672): U1/U2 run on the caller's stream, the panels on a second, high-priority stream (per host
 //   thread); panel k+1 starts as soon as U1(k) is done and is factored while U2(k) keeps every CU busy.
-//   Inside a panel, two levels: 128-column slabs of two 64-column steps, per slab
+//   Inside a panel of the launch chain, two levels: 128-column slabs of two 64-column steps, per slab
 //     potf2_blk_kernel          one workgroup, the 64 x 64 diagonal block in registers, columns 8 at a time (the four waves
 //                               exchange their shares through LDS once per 8 columns, every wave then factors the 64 x 8 block
 //                               redundantly with pivots and multipliers travelling through v_readlane);
