@@ -103,7 +103,7 @@ int potrf_panel(int64_t M, int64_t nb, double* A, int64_t lda, int* d_info, int6
 // panel_flow.hip: one panel (diagonal dpotrf + the rows below) as ONE dataflow launch; GPC_EUNSUPPORTED outside its domain
 int panel_flow(int64_t M, int64_t nbk, double* P, int64_t lda, int* d_info, int64_t col0, hipStream_t s, int64_t zero_row0 = -1,
                int64_t zero_shift = 0);
-// ... and what it leaves in the info word when one of its polls was not answered within ~1 s (device shared or pre-empted):
+// ... and what it leaves in the info word when one of its polls was not answered within ~10 s (device shared or pre-empted):
 // not a LAPACK info, the factor is unusable.  Whoever reads the info word back reports an error.
 constexpr int PANEL_FLOW_TIMEOUT = (int)0x80000000;
 int potrf_lower_tall(int64_t Nrows, int64_t Ncols, double* A, int64_t lda, int* d_info, hipStream_t s, bool identity_below = false);

@@ -12,7 +12,7 @@
 // consumers read it with device-scope atomic loads and poll the VALUES until they stop being the sentinel.  No flags and
 // no fences: the XCDs' L2s are not coherent with each other, so an agent-scope release / acquire fence costs an L2
 // write-back / invalidate per use (the first version of this kernel had two per column block and lost to the launch chain).
-// A poll that is not answered after ~1 s, or a non-positive pivot anywhere, raises ctl[1]; everybody then leaves (the host
+// A poll that is not answered after ~10 s, or a non-positive pivot anywhere, raises ctl[1]; everybody then leaves (the host
 // sees LAPACK's info, or an error).  The critical path per 64 columns is chol(c,c) -> [the solve of (c+1,c) runs 16 columns
 // behind it] -> last product chunk of (c+1,c+1) -> chol(c+1,c+1).
 #include "gpc_common.hpp"
@@ -70,7 +70,7 @@ __device__ __forceinline__ bool pf_try(const double* p, int64_t step, double (&v
 template <int NV>
 __device__ __forceinline__ bool pf_fetch(const PanelFlowArgs& g, const double* p, int64_t step, double (&v)[NV])
 {
-  for(int it = 0; it < (1 << 20); it++) {
+  for(int it = 0; it < (1 << 23); it++) {
     if(pf_try<NV>(p, step, v)) return true;
     if((it & 63) == 63 && __hip_atomic_load(&g.ctl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return false;
     __builtin_amdgcn_s_sleep(1);

@@ -368,7 +368,7 @@ __global__ void __launch_bounds__(256) trsv_step_t_kernel(const double* __restri
 // a producer publishes with device-scope atomic stores -- one memory round trip per dependency instead of two.
 // Block ids come from a ticket counter, so a workgroup only ever waits for workgroups that are already running:
 // deadlock-free whatever the dispatch order and however few of them are resident.  A poll that is not answered after
-// ~2^20 tries poisons the solution with NaN (and sets ctl[1]) instead of hanging the device.
+// ~2^23 tries (~10 s) poisons the solution with NaN (and sets ctl[1]) instead of hanging the device.
 // Per 64-step launch sequence this replaces: N / 64 dependent launches of 11.5 us (forward) / 17 us (backward).
 constexpr unsigned long long FLOW_SENT = 0xFFF8C0DEFACE0001ull;
 constexpr int FLOW_MAXRHS = 4;
@@ -383,10 +383,10 @@ __global__ void __launch_bounds__(256) flow_init_kernel(unsigned long long* __re
 __device__ __forceinline__ double flow_poll(const double* p, int* ctl, int* sticky)
 {
   const unsigned long long* q = reinterpret_cast<const unsigned long long*>(p);
-  for(int it = 0; it < (1 << 20); it++) {
+  for(int it = 0; it < (1 << 23); it++) {
     const unsigned long long v = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if(v != FLOW_SENT) return __longlong_as_double((long long)v);
-    // somebody else already gave up: do not wait out another timeout per dependency (bounds a failure to ~1 s in all)
+    // somebody else already gave up: do not wait out another timeout per dependency (bounds a failure to ~10 s in all)
     if((it & 1023) == 1023 && __hip_atomic_load(&ctl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
     __builtin_amdgcn_s_sleep(1);
   }
@@ -605,7 +605,7 @@ static int g_trsv_flow = -1;
 
 }  // namespace
 
-// Has a dataflow solve on this thread's streams given up since the last call (a poll unanswered after ~1 s: the device was
+// Has a dataflow solve on this thread's streams given up since the last call (a poll unanswered after ~10 s: the device was
 // shared or pre-empted)?  Its result is NaN-poisoned; callers that are about to hand a host scalar back report it.
 int take_solve_fault(hipStream_t s, int* fault)
 {
