@@ -63,6 +63,18 @@ struct WsSet {
 static thread_local WsSet g_wsset;
 #define g_ws g_wsset.b
 
+// GPC_POISON_ALLOC=1 (testing aid): every buffer the library allocates starts as all-ones bytes -- NaN as doubles -- so that a
+// kernel reading memory nobody wrote shows up in the results instead of depending on what the allocator happened to return.
+bool poison_allocations()
+{
+  static int on = -1;
+  if(on < 0) {
+    const char* e = getenv("GPC_POISON_ALLOC");
+    on = (e && atoi(e) != 0) ? 1 : 0;
+  }
+  return on != 0;
+}
+
 int workspace(int slot, size_t bytes, void** out)
 {
   if(slot < 0 || slot >= WS_NSLOTS) return GPC_EINVAL;
@@ -86,6 +98,10 @@ int workspace(int slot, size_t bytes, void** out)
     w.bytes = want;
     w.dev = dev;
     if(slot == WS_INFO) GPC_HIP_CHECK(hipMemset(w.p, 0, want));   // holds a sticky flag (gpc_common.hpp)
+    else if(poison_allocations()) {
+      GPC_HIP_CHECK(hipMemset(w.p, 0xFF, want));
+      GPC_HIP_CHECK(hipDeviceSynchronize());   // (the fill must not land after a kernel of a non-blocking stream has written the buffer)
+    }
   }
   *out = w.p;
   return GPC_OK;
@@ -187,6 +203,10 @@ int gpc_malloc(void** dptr, size_t bytes)
     set_error("hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
     (void)hipGetLastError();
     return GPC_ENOMEM;
+  }
+  if(gpc::poison_allocations()) {
+    GPC_HIP_CHECK(hipMemset(*dptr, 0xFF, bytes ? bytes : 8));
+    GPC_HIP_CHECK(hipDeviceSynchronize());
   }
   return GPC_OK;
 }

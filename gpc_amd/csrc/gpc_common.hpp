@@ -52,6 +52,7 @@ enum WorkspaceSlot {
   WS_NSLOTS = 10
 };
 int workspace(int slot, size_t bytes, void** out);
+bool poison_allocations();   // GPC_POISON_ALLOC=1: new buffers start as NaN (testing aid)
 // WS_INFO layout (64 bytes, zeroed when allocated): int[0] = LAPACK info of the running factorisation, int[4] = sticky
 // "a dataflow triangular solve timed out" flag (trsm.hip), read and cleared by take_solve_fault
 constexpr int SOLVE_FAULT_WORD = 4;

@@ -216,6 +216,10 @@ struct HipOps : GridOps {
       (void)hipGetLastError();
       return GPC_ENOMEM;
     }
+    if(poison_allocations()) {
+      HIPOPS_CHECK(hipMemset(*p, 0xFF, bytes ? bytes : 16));
+      HIPOPS_CHECK(hipDeviceSynchronize());
+    }
     return GPC_OK;
   }
   int release(void* p) override

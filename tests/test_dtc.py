@@ -101,6 +101,39 @@ def test_hip_dtc_through_the_cpp_cgp(golden, name, tmp_path):
 
 
 @pytest.mark.gpu
+def test_hip_paths_do_not_read_unwritten_memory(golden, tmp_path):
+    """GPC_POISON_ALLOC=1 makes every buffer the library allocates start as NaN: the FITC evaluation (Gram, cross-Gram, factor,
+    solves, gradient passes) and an exact-GP learn through the C++ host layer still reproduce the reference."""
+    import subprocess
+    g = golden("gp_dtc")
+    name = "fa"
+    X, y, Xu, beta, Xs = problem(g, name)
+    for nm, A in (("X", X), ("y", y), ("Xs", Xs), ("Xu", Xu)):
+        _write_txt(tmp_path / (nm + ".txt"), A)
+    exe = os.path.join(ROOT, "gpc_amd", "host", "gp_hosttest")
+    r = subprocess.run([exe, "dtc", str(tmp_path / "X.txt"), str(tmp_path / "y.txt"), str(tmp_path / "Xs.txt"),
+                        _spec(CASES[name]), str(tmp_path / "Xu.txt"), "%.17g" % beta, "0"] +
+                       ([APPROX[name[0]][1]] if name[0] in APPROX else []),
+                       env=dict(os.environ, GPC_POISON_ALLOC="1"),
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, stdin=subprocess.DEVNULL, timeout=600)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    v = _parse(r.stdout.decode())
+    assert abs(v["ll"][0] - g[name + "_ll"][0, 0]) <= 1e-8 * abs(g[name + "_ll"][0, 0])
+    assert close(v["grads"], g[name + "_grads"], 1e-8)
+    assert close(v["mu"], g[name + "_mu"], 1e-8)
+    gp = os.path.join(ROOT, "gpc_amd", "host", "gp")
+    svml = os.path.join(ROOT, "tests", "golden", "sinc.svml")
+    outs = []
+    for poison in ("0", "1"):
+        model = str(tmp_path / ("m%s.model" % poison))
+        r = subprocess.run([gp, "-s", "1", "learn", "-#", "30", svml, model], env=dict(os.environ, GPC_POISON_ALLOC=poison),
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, stdin=subprocess.DEVNULL, timeout=600)
+        assert r.returncode == 0, r.stderr.decode()[-2000:]
+        outs.append([ln for ln in open(model).read().splitlines() if not ln.startswith("#")])
+    assert outs[0] == outs[1]                      # the same model (the comment header names the output file)
+
+
+@pytest.mark.gpu
 def test_gp_learn_dtc_cli_on_sinc(golden, tmp_path):
     """`gp -s 3 learn -A dtc -a 10`: the seeded Mersenne twister picks the reference's inducing inputs (exactly), 40 SCG
     iterations end near the reference's end state, and the sparse model file is read back by `gp display`."""
