@@ -410,7 +410,6 @@ __global__ void __launch_bounds__(256) trsv_flow_kernel(const double* __restrict
   __shared__ double T2[64 * 65];   // the inverse of the diagonal block on its way to registers; later the backward solve's turning patch
   __shared__ double Dinv[64];
   __shared__ double Y[FLOW_MAXRHS * 64];
-  __shared__ double Xs[2][FLOW_MAXRHS][64];
   __shared__ double Red[3][FLOW_MAXRHS][64];
   __shared__ int tk_s;
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
@@ -484,13 +483,16 @@ __global__ void __launch_bounds__(256) trsv_flow_kernel(const double* __restrict
 #pragma unroll
         for(int u = 0; u < 16; u++) an[u] = Lrow[((j + 1) * 64 + u) * ldl];
       }
-      if(w < d) Xs[j & 1][w][lane] = flow_poll(&Xf[j * 64 + lane + (int64_t)w * M], ctl, sticky);
-      __syncthreads();
+      // every wave polls the 16 values of x_j it multiplies with itself (lane l asks for element 16 w + (l & 15)) and hands
+      // them round with v_readlane: no LDS staging, no barrier in this loop -- the four waves run ahead of each other and
+      // keep more of L in flight
 #pragma unroll
-      for(int u = 0; u < 16; u++)
+      for(int v = 0; v < FLOW_MAXRHS; v++)
+        if(v < d) {
+          const double xv = flow_poll(&Xf[j * 64 + 16 * w + (lane & 15) + (int64_t)v * M], ctl, sticky);
 #pragma unroll
-        for(int v = 0; v < FLOW_MAXRHS; v++)
-          if(v < d) acc[v] += a[u] * Xs[j & 1][v][16 * w + u];
+          for(int u = 0; u < 16; u++) acc[v] += a[u] * readlane_f64(xv, u);
+        }
 #pragma unroll
       for(int u = 0; u < 16; u++) a[u] = an[u];
     }
