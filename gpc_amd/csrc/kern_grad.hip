@@ -873,7 +873,8 @@ extern "C" int gpc_kern_grad_f64(const gpc_kspec* ksp, const double* X, int64_t 
 
 // CGp::updateG without the covGrad matrix (CGp.cpp:666-679 + 1096-1117 in one pass): the kernel reads invK and the
 // N x d matrix A = invK * m and forms covGrad(i,j) = -0.5 (d invK(i,j) - sum_o A(i,o) A(j,o)) in registers.  Taken when the
-// kernel has no rbfard term, D <= 32 and d <= 2; otherwise GPC_EUNSUPPORTED (the caller materialises covGrad as before).
+// kernel is on one of the symmetric MFMA walks (no rbfard term and at most two rbf terms, or exactly one rbfard term with
+// bias / white only), D <= 32 and d <= 2; otherwise GPC_EUNSUPPORTED (the caller materialises covGrad as before).
 extern "C" int gpc_kern_grad_fused_f64(const gpc_kspec* ksp, const double* X, int64_t N, int64_t D, int64_t ldx,
                                        const double* invK, int64_t ldi, const double* A, int64_t lda, int64_t d, double* gout,
                                        void* stream)

@@ -246,8 +246,8 @@ int gpc_kern_grad_f64(const gpc_kspec* ks, const double* X, int64_t N, int64_t D
 
 /* The same sums WITHOUT a covGrad matrix: covGrad(i,j) = -0.5 (d invK(i,j) - sum_o A(i,o) A(j,o)), A = invK * m (N x d) --
  * CGp::updateCovGradient summed over the outputs -- is formed inside the pass from invK and A (CGp.cpp:666-679 and
- * 1096-1117 as one read of half of invK).  Kernels without an rbfard term, D <= 32, d <= 2; otherwise GPC_EUNSUPPORTED
- * and nothing is computed (callers then build covGrad with gpc_covgrad_f64 / gpc_covgrad_multi_f64). */
+ * 1096-1117 as one read of half of invK).  Kernels without an rbfard term (at most two rbf terms) or with exactly one rbfard
+ * term next to bias / white only; D <= 32, d <= 2; otherwise GPC_EUNSUPPORTED and nothing is computed (callers then build covGrad with gpc_covgrad_f64 / gpc_covgrad_multi_f64). */
 int gpc_kern_grad_fused_f64(const gpc_kspec* ks, const double* X, int64_t N, int64_t D, int64_t ldx,
                             const double* invK, int64_t ldi, const double* A, int64_t lda, int64_t d, double* g, void* stream);
 
