@@ -175,6 +175,25 @@ static int runGp(const gpcb_file& in, const char* outPath)
     writeCMatrix(fp, "invK", model.invK);
     writeCMatrix(fp, "covGrad", model.covGrad);
   }
+  // full-size goldens: only the entries at the given (i, j) pairs leave the process (N = 8192: three 512 MB matrices otherwise)
+  const gpcb_array* si = gpcb_find(&in, "sample_i");
+  const gpcb_array* sj = gpcb_find(&in, "sample_j");
+  if(si && sj)
+  {
+    unsigned int ns = (unsigned int)(si->rows * si->cols);
+    CMatrix Ks(1, ns), Ls(1, ns), iKs(1, ns);
+    for(unsigned int s = 0; s < ns; s++)
+    {
+      unsigned int i = (unsigned int)si->data[s], j = (unsigned int)sj->data[s];
+      unsigned int lo_i = i > j ? i : j, lo_j = i > j ? j : i;
+      Ks.setVal(model.K.getVal(i, j), 0, s);
+      Ls.setVal(model.LcholK.getVal(lo_i, lo_j), 0, s);
+      iKs.setVal(model.invK.getVal(i, j), 0, s);
+    }
+    writeCMatrix(fp, "K_samples", Ks);
+    writeCMatrix(fp, "L_samples", Ls);
+    writeCMatrix(fp, "invK_samples", iKs);
+  }
   if(xs)
   {
     toCMatrix(Xstar, xs);

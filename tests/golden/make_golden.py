@@ -60,9 +60,15 @@ def kern_from_ref(outname, terms, seedmat="rbfKernTest"):
          K2=ref["K2"], K4=ref["K4"], k2=ref["k2"], g2=ref["g2"], g4=ref["g4"], source="ref_driver")
 
 
-def gp_fixture(outname, terms, X, y, Xs, scale=None, bias=None, extra=None, dump_samples=True):
+def gp_fixture(outname, terms, X, y, Xs, scale=None, bias=None, extra=None, dump_samples=True, sample_in_driver=False):
     arrays = dict(refrun.kern_arrays(terms))
-    arrays.update({"X": X, "y": y, "Xstar": Xs, "dump_matrices": 1.0 if dump_samples else 0.0})
+    arrays.update({"X": X, "y": y, "Xstar": Xs, "dump_matrices": 1.0 if dump_samples and not sample_in_driver else 0.0})
+    N = X.shape[0]
+    rng = np.random.RandomState(7)
+    ii = rng.randint(0, N, 256)
+    jj = rng.randint(0, N, 256)
+    if sample_in_driver:        # large N: the driver returns the sampled entries, not three N x N matrices
+        arrays.update({"sample_i": ii.astype(np.float64), "sample_j": jj.astype(np.float64)})
     if scale is not None:
         arrays["scale"] = scale
     if bias is not None:
@@ -71,11 +77,10 @@ def gp_fixture(outname, terms, X, y, Xs, scale=None, bias=None, extra=None, dump
     out = dict(types=np.array([t for t, _ in terms]), nat_params=np.array([p for _, ps in terms for p in ps]),
                Xstar=Xs, ll=ref["ll"], logdet=ref["logdet"], grads=ref["grads"], opt_params=ref["opt_params"],
                alpha=ref["alpha"], mu=ref["mu"], var=ref["var"], yPred=ref["yPred"], errBar=ref["errBar"], m=ref["m"])
-    if dump_samples:
-        N = X.shape[0]
-        rng = np.random.RandomState(7)
-        ii = rng.randint(0, N, 256)
-        jj = rng.randint(0, N, 256)
+    if sample_in_driver:
+        out.update(sample_i=ii, sample_j=jj, K_samples=ref["K_samples"].ravel(), L_samples=ref["L_samples"].ravel(),
+                   invK_samples=ref["invK_samples"].ravel())
+    elif dump_samples:
         lo = np.maximum(ii, jj), np.minimum(ii, jj)
         out.update(sample_i=ii, sample_j=jj, K_samples=ref["K"][ii, jj], L_samples=ref["L"][lo[0], lo[1]],
                    invK_samples=ref["invK"][ii, jj])
@@ -138,12 +143,26 @@ def main():
         Xs = synth.make_xstar(64, c["D"], seed=1234)
         g = gp_fixture("", c["kern"], X, y, Xs)
         save("synth_%s_%d" % (cfg, N), N=N, D=c["D"], seed=1234, x_checksum=X.sum(), y_checksum=y.sum(), **g)
+    synth_full_size()
     # rbfard + bias + white (the GP-LVM / `-k rbf -i 1` kernel) on a seeded 512 x 4 problem
     X, y = synth.make_xy(512, 4, seed=77)
     Xs = synth.make_xstar(32, 4, seed=77)
     terms = [("rbfard", [1.2, 0.9, 0.8, 0.3, 0.6, 0.45]), ("bias", [0.1]), ("white", [0.05])]
     g = gp_fixture("", terms, X, y, Xs)
     save("synth_ard_512", N=512, D=4, seed=77, x_checksum=X.sum(), y_checksum=y.sum(), **g)
+
+
+def synth_full_size():
+    """BASELINE config 2 at its real size (N = 8192, D = 8; SURVEY.md section 8d: "oracle runs directly") and N = 4096 with the
+    kernels of configs 2 and 3 -- 4096 is where the factorisation becomes ONE dataflow launch for the whole matrix.  The
+    compiled reference returns ll, log|K|, the gradient, alpha, predictions at 64 points and 256 sampled entries of K,
+    LcholK and invK."""
+    for cfg, N in (("cfg2", 4096), ("cfg3", 4096), ("cfg2", 8192)):
+        c = synth.scaled_config(cfg, N)
+        X, y = synth.make_xy(N, c["D"], seed=1234)
+        Xs = synth.make_xstar(64, c["D"], seed=1234)
+        g = gp_fixture("", c["kern"], X, y, Xs, sample_in_driver=True)
+        save("synth_%s_%d" % (cfg, N), N=N, D=c["D"], seed=1234, x_checksum=X.sum(), y_checksum=y.sum(), **g)
 
 
 def sinc_golden():
@@ -418,6 +437,8 @@ if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "all"
     if what in ("all", "main"):
         main()
+    if what == "fullsize":
+        synth_full_size()
     if what in ("all", "sinc"):
         sinc_golden()
     if what in ("all", "gplvm"):

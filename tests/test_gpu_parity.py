@@ -511,7 +511,11 @@ def test_gp_ftc500_fixture(api, golden, name):
 
 @pytest.mark.parametrize("name,cfg", [("synth_cfg2_256", "cfg2"), ("synth_cfg2_1024", "cfg2"),
                                       ("synth_cfg3_1024", "cfg3"), ("synth_cfg4_1024", "cfg4"),
-                                      ("synth_cfg2_2048", "cfg2")])
+                                      ("synth_cfg2_2048", "cfg2"),
+                                      # N = 4096: the whole factorisation is ONE dataflow launch (panel_width()); cfg 2 at its
+                                      # real size N = 8192: the compiled reference run directly
+                                      ("synth_cfg2_4096", "cfg2"), ("synth_cfg3_4096", "cfg3"),
+                                      ("synth_cfg2_8192", "cfg2")])
 def test_gp_synthetic_goldens(api, golden, name, cfg):
     from gpc_amd import synth
     g = golden(name)
