@@ -124,6 +124,7 @@ GRID_SIGNATURES = {
     "gradient": (c_int, [GP, DP]),
     "sync": (c_int, [GP]),
     "barrier": (c_int, [GP]),
+    "abort": (c_int, [GP]),
     "set_lookahead": (c_int, [GP, c_int]),
     "info": (c_int, [GP, POINTER(c_int64)]),
     "stats": (c_int, [GP, POINTER(c_double), c_int]),

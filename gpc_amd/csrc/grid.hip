@@ -497,6 +497,10 @@ struct RcclApi {
   decltype(&ncclCommDestroy) CommDestroy = nullptr;
   decltype(&ncclBroadcast) Broadcast = nullptr;
   decltype(&ncclAllReduce) AllReduce = nullptr;
+  decltype(&ncclSend) Send = nullptr;
+  decltype(&ncclRecv) Recv = nullptr;
+  decltype(&ncclGroupStart) GroupStart = nullptr;
+  decltype(&ncclGroupEnd) GroupEnd = nullptr;
   decltype(&ncclGetErrorString) GetErrorString = nullptr;
   std::string where;
 };
@@ -526,10 +530,14 @@ RcclApi* rccl_api()
     GPC_RCCL_SYM(CommDestroy);
     GPC_RCCL_SYM(Broadcast);
     GPC_RCCL_SYM(AllReduce);
+    GPC_RCCL_SYM(Send);
+    GPC_RCCL_SYM(Recv);
+    GPC_RCCL_SYM(GroupStart);
+    GPC_RCCL_SYM(GroupEnd);
     GPC_RCCL_SYM(GetErrorString);
 #undef GPC_RCCL_SYM
     if(!api.GetUniqueId || !api.CommInitRank || !api.CommSplit || !api.CommDestroy || !api.Broadcast || !api.AllReduce ||
-       !api.GetErrorString) {
+       !api.Send || !api.Recv || !api.GroupStart || !api.GroupEnd || !api.GetErrorString) {
       dlclose(api.handle);
       api.handle = nullptr;
     }
@@ -553,12 +561,21 @@ struct RcclComm : GridComm {
   double* scratch = nullptr;                           // device words for the host-valued reductions
   hipStream_t main = nullptr;
   static constexpr int SCRATCH = 512;
+  int me[3] = {0, 0, 0};                               // this rank's index inside each axis group
   bool force = false;   // GPC_GRID_FORCE_RCCL=1: issue the collectives even in groups of one (exercises the RCCL calls on one GPU)
+  // How a panel leaves its root.  xGMI is point to point (every pair of the node's GPUs has its own link), so the default is
+  // a fan-out: the root sends to every peer directly inside one group call and the all-gather of the column panel is the
+  // same thing between all pairs -- no ring whose slowest hop every byte crosses.  GPC_GRID_EXCHANGE=collective uses
+  // ncclBroadcast (per root) instead, for A/B runs on hardware.
+  bool fanout = true;
   explicit RcclComm(RcclApi* a) : api(a)
   {
     const char* e = getenv("GPC_GRID_FORCE_RCCL");
     force = e && atoi(e) != 0;
+    e = getenv("GPC_GRID_EXCHANGE");
+    if(e && strcmp(e, "collective") == 0) fanout = false;
   }
+  int group_size(int axis) const override { return size[axis]; }
   int init(int rank, int nranks, int pr, int pc, const void* uid, GridOps* ops)
   {
     ncclUniqueId id;
@@ -572,6 +589,9 @@ struct RcclComm : GridComm {
     if(pr > 1 || force) RCCL_CHECK(api->CommSplit(comm[AX_WORLD], c, r, &comm[AX_COL], nullptr));
     size[AX_ROW] = pc;
     size[AX_COL] = pr;
+    me[AX_ROW] = c;
+    me[AX_COL] = r;
+    me[AX_WORLD] = rank;
     HIPOPS_CHECK(hipMalloc((void**)&scratch, sizeof(double) * SCRATCH));
     return GPC_OK;
   }
@@ -585,7 +605,39 @@ struct RcclComm : GridComm {
   int bcast(void* buf, int64_t count, int root, int axis, GridOps* ops, int st) override
   {
     if((size[axis] == 1 && !force) || count <= 0) return GPC_OK;
-    RCCL_CHECK(api->Broadcast(buf, buf, (size_t)count, ncclDouble, root, comm[axis], (hipStream_t)ops->native_stream(st)));
+    hipStream_t s = (hipStream_t)ops->native_stream(st);
+    if(!fanout || size[axis] <= 2) {
+      RCCL_CHECK(api->Broadcast(buf, buf, (size_t)count, ncclDouble, root, comm[axis], s));
+      return GPC_OK;
+    }
+    RCCL_CHECK(api->GroupStart());
+    if(me[axis] == root) {
+      for(int p = 0; p < size[axis]; p++)
+        if(p != root) RCCL_CHECK(api->Send(buf, (size_t)count, ncclDouble, p, comm[axis], s));
+    } else {
+      RCCL_CHECK(api->Recv(buf, (size_t)count, ncclDouble, root, comm[axis], s));
+    }
+    RCCL_CHECK(api->GroupEnd());
+    return GPC_OK;
+  }
+  int allgatherv(void* buf, const int64_t* start, const int64_t* count, int axis, GridOps* ops, int st) override
+  {
+    const int n = size[axis], i = me[axis];
+    if(n == 1 && !force) return GPC_OK;
+    hipStream_t s = (hipStream_t)ops->native_stream(st);
+    double* b = (double*)buf;
+    if(!fanout || n == 1) {
+      for(int p = 0; p < n; p++)
+        if(count[p] > 0) RCCL_CHECK(api->Broadcast(b + start[p], b + start[p], (size_t)count[p], ncclDouble, p, comm[axis], s));
+      return GPC_OK;
+    }
+    RCCL_CHECK(api->GroupStart());
+    for(int p = 0; p < n; p++) {
+      if(p == i) continue;
+      if(count[i] > 0) RCCL_CHECK(api->Send(b + start[i], (size_t)count[i], ncclDouble, p, comm[axis], s));
+      if(count[p] > 0) RCCL_CHECK(api->Recv(b + start[p], (size_t)count[p], ncclDouble, p, comm[axis], s));
+    }
+    RCCL_CHECK(api->GroupEnd());
     return GPC_OK;
   }
   int allreduce_dev(double* buf, int64_t count, int axis, GridOps* ops, int st) override

@@ -23,6 +23,9 @@ using namespace gpc::grid;
 int grid_fail(gpc_grid* g, int rc)
 {
   if(g && rc != GPC_OK && !g->gp->error().empty()) g->err = g->gp->error();
+  // a device error or an allocation failure on ONE rank: the ranks that wait for it in a host-side rendezvous (thread ranks)
+  // return GPC_EHIP as well instead of waiting for ever.  Argument errors (GPC_EINVAL) hit every rank alike, before any exchange.
+  if(g && (rc == GPC_EHIP || rc == GPC_ENOMEM)) g->gp->comm()->abort_group();
   return rc;
 }
 
@@ -103,7 +106,7 @@ int GRID_API(create_transport)(gpc_grid** out, int rank, int pr, int pc, int64_t
   gpc_grid* g = new(std::nothrow) gpc_grid();
   if(!g) return GPC_ENOMEM;
   g->device = dev;
-  std::unique_ptr<GridComm> comm(new CallbackComm(*t));
+  std::unique_ptr<GridComm> comm(new CallbackComm(*t, pr, pc));
   g->gp.reset(new GridGp(std::move(ops), std::move(comm), pr, pc, rank / pc, rank % pc, nb));
   *out = g;
   return GPC_OK;
@@ -209,6 +212,13 @@ int GRID_API(sync)(gpc_grid* g)
   GRID_CHECK(grid_enter(g->device));
   GRID_CHECK(g->gp->ops()->sync(ST_PANEL));
   return g->gp->ops()->sync(ST_MAIN);
+}
+
+int GRID_API(abort)(gpc_grid* g)
+{
+  if(!g) return GPC_EINVAL;
+  g->gp->comm()->abort_group();
+  return GPC_OK;
 }
 
 int GRID_API(barrier)(gpc_grid* g)

@@ -31,6 +31,7 @@
 #include <string.h>
 #include <vector>
 #include <mutex>
+#include <atomic>
 #include <condition_variable>
 #include <memory>
 #include <string>
@@ -171,10 +172,18 @@ struct GridOps {
 struct GridComm {
   virtual ~GridComm() {}
   virtual int bcast(void* buf, int64_t count, int root, int axis, GridOps* ops, int st) = 0;     // count doubles
+  // In-place all-gather of unequal pieces: member i of the axis group contributes buf[start[i] .. start[i] + count[i])
+  // (doubles, same offsets on every member; pieces may be empty); afterwards every member holds every piece.  One exchange
+  // in which every pair of members talks over its own link, instead of one broadcast per source after the other.
+  virtual int allgatherv(void* buf, const int64_t* start, const int64_t* count, int axis, GridOps* ops, int st) = 0;
   virtual int allreduce_dev(double* buf, int64_t count, int axis, GridOps* ops, int st) = 0;     // sum, in place
   virtual int allreduce_host(double* v, int n, int axis) = 0;                                     // sum
   virtual int allmin_host(int64_t* v) = 0;                                                        // world
   virtual int barrier() = 0;
+  // a rank gives up (device error, out of memory): whoever waits for it in a host-side rendezvous returns GPC_EHIP too
+  // instead of waiting for ever.  Only the in-process board has such waits; RCCL has its own abort.
+  virtual void abort_group() {}
+  virtual int group_size(int axis) const = 0;
 };
 
 // Caller-supplied transport (MPI, gloo, ...): plain C callbacks.  The library synchronises stream `st` before a call, the
@@ -182,11 +191,19 @@ struct GridComm {
 // pointers for the HIP library).
 struct CallbackComm : GridComm {
   gpc_grid_transport t;
-  explicit CallbackComm(const gpc_grid_transport& tt) : t(tt) {}
+  CallbackComm(const gpc_grid_transport& tt, int pr_, int pc_) : t(tt), pr(pr_), pc(pc_) {}
   int bcast(void* buf, int64_t count, int root, int axis, GridOps* ops, int st) override
   {
     GRID_CHECK(ops->sync(st));
     return t.bcast(t.ctx, buf, count, root, axis) == 0 ? GPC_OK : GPC_EHIP;
+  }
+  int allgatherv(void* buf, const int64_t* start, const int64_t* count, int axis, GridOps* ops, int st) override
+  {
+    GRID_CHECK(ops->sync(st));   // the transport knows broadcasts only: one per non-empty piece
+    const int n = group_size(axis);
+    for(int i = 0; i < n; i++)
+      if(count[i] > 0 && t.bcast(t.ctx, (double*)buf + start[i], count[i], i, axis) != 0) return GPC_EHIP;
+    return GPC_OK;
   }
   int allreduce_dev(double* buf, int64_t count, int axis, GridOps* ops, int st) override
   {
@@ -194,6 +211,8 @@ struct CallbackComm : GridComm {
     return t.allreduce_sum(t.ctx, buf, count, axis, 1) == 0 ? GPC_OK : GPC_EHIP;
   }
   int allreduce_host(double* v, int n, int axis) override { return t.allreduce_sum(t.ctx, v, n, axis, 0) == 0 ? GPC_OK : GPC_EHIP; }
+  int pr = 1, pc = 1;
+  int group_size(int axis) const override { return axis == AX_ROW ? pc : (axis == AX_COL ? pr : pr * pc); }
   int allmin_host(int64_t* v) override { return t.allreduce_min_i64(t.ctx, v) == 0 ? GPC_OK : GPC_EHIP; }
   int barrier() override
   {
@@ -205,6 +224,9 @@ struct CallbackComm : GridComm {
 // In-process ranks (one host thread each; single-process multi-GPU, and the way a single GPU runs pr x pc > 1 in the
 // tests): a shared board with a reusable barrier per axis group.  A broadcast is the receivers copying out of the root's
 // buffer on their own streams once the root's event has fired; the root's stream then waits for their copies.
+// Every event is created, recorded and destroyed by the rank that owns it (an event belongs to a device; the roots rotate
+// with k, so a group-wide source event would be recorded from other devices than the one it was created on); the other
+// ranks only make their streams WAIT for it, which HIP allows across devices.
 struct LocalBoard {
   int pr, pc;
   struct Group {
@@ -212,16 +234,15 @@ struct LocalBoard {
     std::condition_variable cv;
     int n = 0, arrived = 0;
     uint64_t gen = 0;
-    const void* src = nullptr;
-    void* src_event = nullptr;
-    std::vector<void*> done_events;
-    std::vector<double> acc;
+    std::vector<const void*> src;        // per member: the buffer it offers in the current exchange
+    std::vector<void*> src_events;       // per member: recorded by that member when its piece is ready
+    std::vector<void*> done_events;      // per member: recorded by that member when it has copied what it needs
     std::vector<std::vector<double>> parts;
     std::vector<int64_t> imin;
   };
   std::vector<std::unique_ptr<Group>> rows, cols;
   Group world;
-  bool failed = false;
+  std::atomic<bool> failed{false};
   LocalBoard(int pr_, int pc_) : pr(pr_), pc(pc_)
   {
     for(int i = 0; i < pr; i++) { rows.emplace_back(new Group()); init(*rows.back(), pc); }
@@ -231,32 +252,72 @@ struct LocalBoard {
   static void init(Group& g, int n)
   {
     g.n = n;
+    g.src.assign(n, nullptr);
+    g.src_events.assign(n, nullptr);
     g.done_events.assign(n, nullptr);
     g.parts.resize(n);
     g.imin.assign(n, 0);
   }
   Group& group(int axis, int r, int c) { return axis == AX_ROW ? *rows[r] : (axis == AX_COL ? *cols[c] : world); }
-  static void sync(Group& g)
+  // rendezvous of the group's members; GPC_EHIP as soon as any rank of the board has given up
+  int sync(Group& g)
   {
     std::unique_lock<std::mutex> lk(g.m);
+    if(failed.load()) return GPC_EHIP;
     const uint64_t my = g.gen;
     if(++g.arrived == g.n) {
       g.arrived = 0;
       g.gen++;
       g.cv.notify_all();
     } else {
-      g.cv.wait(lk, [&] { return g.gen != my; });
+      g.cv.wait(lk, [&] { return g.gen != my || failed.load(); });
+      if(g.gen == my) return GPC_EHIP;
     }
+    return GPC_OK;
+  }
+  void fail()
+  {
+    failed.store(true);
+    auto wake = [](Group& g) {
+      std::lock_guard<std::mutex> lk(g.m);
+      g.cv.notify_all();
+    };
+    for(auto& g : rows) wake(*g);
+    for(auto& g : cols) wake(*g);
+    wake(world);
   }
 };
 
 struct LocalComm : GridComm {
   std::shared_ptr<LocalBoard> board;
   int r, c;
-  std::vector<void*> my_done;   // events this rank records after copying out of a root's buffer, one per axis
-  GridOps* ops0 = nullptr;
-  LocalComm(std::shared_ptr<LocalBoard> b, int r_, int c_) : board(b), r(r_), c(c_) { my_done.assign(3, nullptr); }
+  void* my_src[3] = {nullptr, nullptr, nullptr};    // this rank's "my piece is ready" event, one per axis
+  void* my_done[3] = {nullptr, nullptr, nullptr};   // this rank's "I have copied" event, one per axis
+  GridOps* ops0 = nullptr;                          // the ops the events came from (outlives this object: see GridGp)
+  LocalComm(std::shared_ptr<LocalBoard> b, int r_, int c_) : board(b), r(r_), c(c_) {}
+  ~LocalComm() override
+  {
+    for(int a = 0; a < 3 && ops0; a++) {
+      if(my_src[a]) ops0->event_destroy(my_src[a]);
+      if(my_done[a]) ops0->event_destroy(my_done[a]);
+    }
+  }
   int index(int axis) const { return axis == AX_ROW ? c : (axis == AX_COL ? r : r * board->pc + c); }
+  int group_size(int axis) const override { return axis == AX_ROW ? board->pc : (axis == AX_COL ? board->pr : board->pr * board->pc); }
+  void abort_group() override { board->fail(); }
+  // any failure between two rendezvous would leave the peers waiting: tell them
+  int leave(int rc)
+  {
+    if(rc != GPC_OK) board->fail();
+    return rc;
+  }
+  int my_events(int axis, GridOps* ops)
+  {
+    ops0 = ops;
+    if(!my_src[axis]) my_src[axis] = ops->event_create();
+    if(!my_done[axis]) my_done[axis] = ops->event_create();
+    return my_src[axis] && my_done[axis] ? GPC_OK : GPC_EHIP;
+  }
   int bcast(void* buf, int64_t count, int root, int axis, GridOps* ops, int st) override
   {
     LocalBoard::Group& g = board->group(axis, r, c);
@@ -264,26 +325,54 @@ struct LocalComm : GridComm {
     const int me = index(axis);
     static const bool trace = getenv("GPC_GRID_TRACE") != nullptr;
     if(trace) fprintf(stderr, "[%d,%d] bcast axis %d root %d count %lld st %d\n", r, c, axis, root, (long long)count, st);
-    if(!my_done[axis]) my_done[axis] = ops->event_create();
-    if(me == root) {
-      if(!g.src_event) g.src_event = ops->event_create();
-      GRID_CHECK(ops->record(g.src_event, st));
-      g.src = buf;
+    int rc = my_events(axis, ops);
+    if(rc == GPC_OK && me == root) {
+      rc = ops->record(my_src[axis], st);
+      g.src[me] = buf;
+      g.src_events[me] = my_src[axis];
     }
-    LocalBoard::sync(g);
-    int rc = GPC_OK;
+    if(rc != GPC_OK) return leave(rc);
+    GRID_CHECK(board->sync(g));
     if(me != root) {
-      rc = ops->wait(st, g.src_event);
-      if(rc == GPC_OK) rc = ops->copy(buf, g.src, sizeof(double) * (size_t)count, st);
+      rc = ops->wait(st, g.src_events[root]);
+      if(rc == GPC_OK) rc = ops->copy(buf, g.src[root], sizeof(double) * (size_t)count, st);
       if(rc == GPC_OK) rc = ops->record(my_done[axis], st);
       g.done_events[me] = my_done[axis];
+      if(rc != GPC_OK) return leave(rc);
     }
-    LocalBoard::sync(g);
+    GRID_CHECK(board->sync(g));
     if(me == root)
       for(int i = 0; i < g.n && rc == GPC_OK; i++)
         if(i != root) rc = ops->wait(st, g.done_events[i]);
-    LocalBoard::sync(g);
-    return rc;
+    if(rc != GPC_OK) return leave(rc);
+    return board->sync(g);
+  }
+  int allgatherv(void* buf, const int64_t* start, const int64_t* count, int axis, GridOps* ops, int st) override
+  {
+    LocalBoard::Group& g = board->group(axis, r, c);
+    if(g.n == 1) return GPC_OK;
+    const int me = index(axis);
+    int rc = my_events(axis, ops);
+    if(rc == GPC_OK) rc = ops->record(my_src[axis], st);
+    if(rc != GPC_OK) return leave(rc);
+    g.src[me] = buf;
+    g.src_events[me] = my_src[axis];
+    GRID_CHECK(board->sync(g));
+    for(int i = 0; i < g.n && rc == GPC_OK; i++) {
+      if(i == me || count[i] <= 0) continue;
+      rc = ops->wait(st, g.src_events[i]);
+      if(rc == GPC_OK)
+        rc = ops->copy((double*)buf + start[i], (const double*)g.src[i] + start[i], sizeof(double) * (size_t)count[i], st);
+    }
+    if(rc == GPC_OK) rc = ops->record(my_done[axis], st);
+    g.done_events[me] = my_done[axis];
+    if(rc != GPC_OK) return leave(rc);
+    GRID_CHECK(board->sync(g));
+    // the others read my piece out of my buffer: nothing later on this stream may overwrite it before they are done
+    for(int i = 0; i < g.n && rc == GPC_OK; i++)
+      if(i != me && count[me] > 0) rc = ops->wait(st, g.done_events[i]);
+    if(rc != GPC_OK) return leave(rc);
+    return board->sync(g);
   }
   int allreduce_dev(double* buf, int64_t count, int axis, GridOps* ops, int st) override
   {
@@ -291,14 +380,14 @@ struct LocalComm : GridComm {
     if(g.n == 1) return GPC_OK;
     const int me = index(axis);
     g.parts[me].resize((size_t)count);
-    GRID_CHECK(ops->download(g.parts[me].data(), buf, sizeof(double) * (size_t)count, st));
-    LocalBoard::sync(g);
+    const int rc = ops->download(g.parts[me].data(), buf, sizeof(double) * (size_t)count, st);
+    if(rc != GPC_OK) return leave(rc);
+    GRID_CHECK(board->sync(g));
     std::vector<double> sum((size_t)count, 0.0);
     for(int i = 0; i < g.n; i++)
       for(int64_t j = 0; j < count; j++) sum[(size_t)j] += g.parts[i][(size_t)j];   // rank order: same bits everywhere
-    LocalBoard::sync(g);
-    GRID_CHECK(ops->upload(buf, sum.data(), sizeof(double) * (size_t)count));
-    return GPC_OK;
+    GRID_CHECK(board->sync(g));
+    return leave(ops->upload(buf, sum.data(), sizeof(double) * (size_t)count));
   }
   int allreduce_host(double* v, int n, int axis) override
   {
@@ -306,36 +395,33 @@ struct LocalComm : GridComm {
     if(g.n == 1) return GPC_OK;
     const int me = index(axis);
     g.parts[me].assign(v, v + n);
-    LocalBoard::sync(g);
+    GRID_CHECK(board->sync(g));
     for(int j = 0; j < n; j++) {
       double s = 0.0;
       for(int i = 0; i < g.n; i++) s += g.parts[i][(size_t)j];
       v[j] = s;
     }
-    LocalBoard::sync(g);
-    return GPC_OK;
+    return board->sync(g);
   }
   int allmin_host(int64_t* v) override
   {
     LocalBoard::Group& g = board->world;
     if(g.n == 1) return GPC_OK;
     g.imin[index(AX_WORLD)] = *v;
-    LocalBoard::sync(g);
+    GRID_CHECK(board->sync(g));
     int64_t m = g.imin[0];
     for(int i = 1; i < g.n; i++) m = g.imin[i] < m ? g.imin[i] : m;
-    LocalBoard::sync(g);
+    GRID_CHECK(board->sync(g));
     *v = m;
     return GPC_OK;
   }
-  int barrier() override
-  {
-    LocalBoard::sync(board->world);
-    return GPC_OK;
-  }
+  int barrier() override { return board->sync(board->world); }
 };
 
 struct SelfComm : GridComm {   // a 1 x 1 grid: nothing to exchange
   int bcast(void*, int64_t, int, int, GridOps*, int) override { return GPC_OK; }
+  int allgatherv(void*, const int64_t*, const int64_t*, int, GridOps*, int) override { return GPC_OK; }
+  int group_size(int) const override { return 1; }
   int allreduce_dev(double*, int64_t, int, GridOps*, int) override { return GPC_OK; }
   int allreduce_host(double*, int, int) override { return GPC_OK; }
   int allmin_host(int64_t*) override { return GPC_OK; }
@@ -866,25 +952,33 @@ class GridGp {
       count_coll(AX_ROW, 8.0 * (double)(ldw * nb_), c_ != kc);
     }
     if(pr_ > 1 && jl0 < L.Lc) {
-      // column panel: tiles L(J,k), J = c + pc*jl > k, grouped by the process row that holds them (J mod pr)
+      // column panel: tiles L(J,k), J = c + pc*jl > k, grouped by the process row that holds them (J mod pr).  Every rank
+      // packs the tiles it holds into its region of V and ONE in-place all-gather over the process column hands every rank
+      // the other regions -- each pair of ranks over its own link -- instead of pr broadcasts one after the other.
       const int64_t g = Layout::gcd(pr_, pc_);
       const int64_t q = pr_ / g;          // consecutive tiles of one source are q local column tiles apart
+      std::vector<int64_t> start((size_t)pr_, 0), count((size_t)pr_, 0);
+      double recv = 0.0;
       for(int s = 0; s < pr_; s++) {
         // first jl >= jl0 with (c + pc*jl) mod pr == s
         int64_t jf = -1;
         for(int64_t jl = jl0; jl < jl0 + q && jl < L.Lc; jl++)
           if((int)((c_ + pc_ * jl) % pr_) == s) { jf = jl; break; }
         if(jf < 0) continue;
-        const int64_t count = (L.Lc - 1 - jf) / q + 1;
-        double* dst = V_[b] + slot_[(size_t)jf] * nb_ * nb_;
+        const int64_t ntile = (L.Lc - 1 - jf) / q + 1;
+        start[(size_t)s] = slot_[(size_t)jf] * nb_ * nb_;
+        count[(size_t)s] = ntile * nb_ * nb_;
         if(r_ == s) {
           const int64_t J = c_ + pc_ * jf;
           const int64_t first = J / pr_ - il0;                 // row tile of W that holds L(J,k)
-          GRID_CHECK(ops_->pack_tiles(dst, W, ldw, first, pc_ / g, count, nb_, st));
+          GRID_CHECK(ops_->pack_tiles(V_[b] + start[(size_t)s], W, ldw, first, pc_ / g, ntile, nb_, st));
+        } else {
+          recv += 8.0 * (double)count[(size_t)s];
         }
-        GRID_CHECK(comm_->bcast(dst, count * nb_ * nb_, s, AX_COL, ops_.get(), st));
-        count_coll(AX_COL, 8.0 * (double)(count * nb_ * nb_), r_ != s);
       }
+      GRID_CHECK(comm_->allgatherv(V_[b], start.data(), count.data(), AX_COL, ops_.get(), st));
+      stats_.collectives++;
+      stats_.bytes_recv[AX_COL] += recv;
     }
     if(st != ST_MAIN) GRID_CHECK(ops_->record(ev_panel_[b], st));
     return GPC_OK;

@@ -144,6 +144,11 @@ class Grid(object):
     def barrier(self):
         self.b.check(self.b.barrier(self.h), self.h)
 
+    def abort(self):
+        """this rank gives up: the thread ranks waiting for it return an error instead of hanging (not collective)"""
+        if self.h:
+            self.b.abort(self.h)
+
     def loglik(self):
         ll = c_double(0.0)
         self.b.check(self.b.loglik(self.h, byref(ll)), self.h)
@@ -236,11 +241,8 @@ def run_local(grids, fn):
             out[i] = fn(grids[i], i)
         except BaseException as e:   # noqa: B902 -- re-raised below
             err[i] = e
-            # the other ranks are now waiting for this one inside a collective: say why before they are left hanging
-            import sys
-            import traceback
-            sys.stderr.write("gpc_amd.grid: rank %d failed: %r\n" % (i, e))
-            traceback.print_exc()
+            # the other ranks may be waiting for this one inside a collective: release them (they fail with GPC_EHIP)
+            grids[i].abort()
 
     if len(grids) == 1:
         work(0)
@@ -250,9 +252,11 @@ def run_local(grids, fn):
             t.start()
         for t in ts:
             t.join()
-    for e in err:
-        if e is not None:
-            raise e
+    # the first failure that is not just "another rank gave up" is the one worth reporting
+    errs = [e for e in err if e is not None]
+    if errs:
+        own = [e for e in errs if not (isinstance(e, GpcError) and e.rc == _lib.GPC_EHIP)]
+        raise (own or errs)[0]
     return out
 
 

@@ -206,6 +206,11 @@ int gpc_grid_posterior(gpc_grid* g, double* mu_host, int64_t ldmu, double* var_h
 int gpc_grid_gradient(gpc_grid* g, double* g_host);
 int gpc_grid_sync(gpc_grid* g);
 int gpc_grid_barrier(gpc_grid* g);
+/* Not collective.  This rank gives up (its thread hit an error outside the library): the other ranks of a
+ * gpc_grid_create_local grid that wait for it inside a collective entry point return GPC_EHIP instead of waiting for ever;
+ * the grid is unusable afterwards (destroy it).  The library calls this itself when an entry point fails with GPC_EHIP /
+ * GPC_ENOMEM on one rank.  No effect on RCCL / transport grids (their own time-outs apply). */
+int gpc_grid_abort(gpc_grid* g);
 int gpc_grid_set_lookahead(gpc_grid* g, int on);
 /* out[12] = N, nb, T (tiles per side), pr, pc, r, c, local rows, local columns, extra rows, local tile rows, columns */
 int gpc_grid_info(gpc_grid* g, int64_t* out);

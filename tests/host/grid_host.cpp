@@ -7,6 +7,7 @@
 #include <string.h>
 #include <math.h>
 #include <vector>
+#include <atomic>
 #include "../../gpc_amd/csrc/grid_sched.hpp"
 extern "C" {
 #include "../../oracle/gpc_oracle.h"
@@ -17,7 +18,17 @@ using namespace gpc::grid;
 
 static_assert(sizeof(orc_kspec) == sizeof(gpc_kspec), "kspec layouts must agree");
 
+// failure injection (tests): the n-th pack_tiles / copy2d call from now on, on whichever rank issues it, fails like a device error
+static std::atomic<long> g_fail_countdown(-1);
+
 struct HostOps : GridOps {
+  static bool injected()
+  {
+    long v = g_fail_countdown.load();
+    while(v > 0)
+      if(g_fail_countdown.compare_exchange_weak(v, v - 1)) return v == 1;
+    return false;
+  }
   int alloc(void** p, size_t bytes) override
   {
     *p = nullptr;
@@ -142,6 +153,7 @@ struct HostOps : GridOps {
   }
   int copy2d(double* dst, int64_t ldd, const double* src, int64_t lds, int64_t m, int64_t n, int) override
   {
+    if(injected()) return GPC_EHIP;
     for(int64_t j = 0; j < n; j++) memcpy(dst + j * ldd, src + j * lds, sizeof(double) * (size_t)m);
     return GPC_OK;
   }
@@ -285,6 +297,8 @@ int grid_unique_id(void*) { return GPC_EUNSUPPORTED; }   // RCCL lives in libgpc
 int grid_make_collective_comm(std::unique_ptr<GridComm>&, int, int, int, int, const void*, GridOps*) { return GPC_EUNSUPPORTED; }
 
 }  // namespace
+
+extern "C" void gridtest_inject_failure(long nth_copy) { g_fail_countdown.store(nth_copy); }
 
 #define GRID_API(name) gridtest_##name
 #include "../../gpc_amd/csrc/grid_capi_impl.hpp"

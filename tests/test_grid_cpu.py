@@ -254,6 +254,47 @@ def _free_port():
     return p
 
 
+@pytest.mark.timeout(120)
+@pytest.mark.parametrize("pr,pc,nth", [(2, 2, 3), (2, 4, 11), (4, 2, 1)])
+def test_a_failing_rank_releases_the_others(hb, pr, pc, nth):
+    """One rank's device call fails in the middle of a factorisation: the thread ranks that wait for it in the board's
+    rendezvous return GPC_EHIP too (they used to wait for ever), and a Python exception on one rank does the same."""
+    from gpc_amd._lib import GpcError
+    X, Y, _ = gc.make_problem(600, 3, 1, 0, 3)
+    grids = grid.create_local(pr, pc, 128, binding=hb)
+
+    def work(g, rank):
+        g.set_problem(gc.TERMS, X, Y, None)
+        g.barrier()
+        if rank == 0:
+            hb.cdll.gridtest_inject_failure(nth)
+        g.barrier()
+        return g.update_k()
+
+    try:
+        with pytest.raises(GpcError):
+            grid.run_local(grids, work)
+    finally:
+        hb.cdll.gridtest_inject_failure(-1)
+        for g in grids:
+            g.destroy()
+
+    grids = grid.create_local(pr, pc, 128, binding=hb)
+
+    def work2(g, rank):
+        g.set_problem(gc.TERMS, X, Y, None)
+        if rank == pr * pc - 1:
+            raise ValueError("this rank's own code failed")
+        return g.update_k()
+
+    try:
+        with pytest.raises(ValueError):
+            grid.run_local(grids, work2)
+    finally:
+        for g in grids:
+            g.destroy()
+
+
 @pytest.mark.parametrize("pr,pc", [(1, 2), (2, 1), (2, 2)])
 def test_one_process_per_rank_over_gloo(pr, pc, tmp_path):
     """world_size 2 / 4 over gloo: the grid's exchange goes through gpc_grid_create_transport callbacks that call
