@@ -65,6 +65,8 @@ struct GemmArgs {
                          //   column panel is kept tile by tile in the order it arrives from the process column
   int64_t stair_nb;
   int64_t st_I0, st_pr, st_J0, st_pc, st_jl0;
+  int64_t st_il0;        // reflected rounds (Stair2D::refl_r >= 0): see stair_row()
+  int st_refl_r;
   const int64_t* voff;
   // tri == 5: compact enumeration of the super-tiles that hold at least one valid tile.  Super-column sj holds the
   // super-rows st_first[sj] .. super_m-1; st_cum[sj] = how many such super-tiles lie in columns < sj.  (Launching the
@@ -78,6 +80,14 @@ struct GemmArgs {
 // One operand stage = 128 (row index r) x 16 (k) doubles = 4 double2 per thread.
 // KC=false: element (r,k) at P[r + k*ld]; thread owns rows 2*lane, 2*lane+1 and k = wave + 4*i.
 // KC=true : element (r,k) at P[k + r*ld]; thread owns k = 2*(t&7), +1 and rows (t>>3) + 32*i.
+// global tile row of nb-row-tile t of a 2-D staircase's C (GemmArgs::tri == 5)
+__host__ __device__ __forceinline__ int64_t stair_row(const GemmArgs& g, int64_t t)
+{
+  if(g.st_refl_r < 0) return g.st_I0 + t * g.st_pr;
+  const int64_t il = g.st_il0 + t;
+  return g.st_pr * il + ((il & 1) ? g.st_pr - 1 - g.st_refl_r : g.st_refl_r);
+}
+
 template <bool KC, bool VEC>
 __device__ __forceinline__ void load_stage(const double* __restrict__ P, int64_t ld, int64_t r0, int64_t rmax,
                                            int64_t k0, int64_t kmax, bool full, double2_t (&reg)[4])
@@ -358,7 +368,7 @@ __global__ void __launch_bounds__(128 * NWN, NWN) gemm_nt_fast_kernel(const Gemm
   bool diag5 = false;
   if(g.tri == 5) {
     const int64_t rt = m0 / g.stair_nb, ct = n0 / g.stair_nb;
-    const int64_t I = g.st_I0 + rt * g.st_pr, J = g.st_J0 + ct * g.st_pc;
+    const int64_t I = stair_row(g, rt), J = g.st_J0 + ct * g.st_pc;
     if(I < J) return;
     roff = (int)(m0 - rt * g.stair_nb);
     coff = (int)(n0 - ct * g.stair_nb);
@@ -582,7 +592,8 @@ static int gemm_ex(bool transa, bool transb, int64_t M, int64_t N, int64_t K, do
   g.super_n = (g.tiles_n + SUPER - 1) / SUPER;
   g.tri = tri;
   g.stair_nb = 0;
-  g.st_I0 = g.st_pr = g.st_J0 = g.st_pc = g.st_jl0 = 0;
+  g.st_I0 = g.st_pr = g.st_J0 = g.st_pc = g.st_jl0 = g.st_il0 = 0;
+  g.st_refl_r = -1;
   g.voff = nullptr;
   if(tri == 5) {
     g.stair_nb = st2->nb;
@@ -591,6 +602,8 @@ static int gemm_ex(bool transa, bool transb, int64_t M, int64_t N, int64_t K, do
     g.st_J0 = st2->J0;
     g.st_pc = st2->pc;
     g.st_jl0 = st2->jl0;
+    g.st_il0 = st2->il0;
+    g.st_refl_r = st2->refl_r;
     g.voff = st2->voff;
   }
   {
@@ -620,8 +633,13 @@ static int gemm_ex(bool transa, bool transb, int64_t M, int64_t N, int64_t K, do
       const int64_t ct = tj / R;
       const int64_t J = g.st_J0 + ct * g.st_pc;
       int64_t rt = J > g.st_I0 ? (J - g.st_I0 + g.st_pr - 1) / g.st_pr : 0;   // first nb-tile row with I >= J
+      if(g.st_refl_r >= 0) {                              // reflected rounds: tile row I lives in round I / pr
+        rt = J / g.st_pr > g.st_il0 ? J / g.st_pr - g.st_il0 : 0;
+        const int64_t rows = (M + g.stair_nb - 1) / g.stair_nb;
+        while(rt < rows && stair_row(g, rt) < J) rt++;
+      }
       int64_t f = rt * R;
-      if(g.st_I0 + rt * g.st_pr == J) f += tj % R;        // inside the diagonal nb-tile: 128-tiles on or below its diagonal
+      if(stair_row(g, rt) == J) f += tj % R;              // inside the diagonal nb-tile: 128-tiles on or below its diagonal
       int64_t sf = f / SUPER;
       if(sf > g.super_m) sf = g.super_m;
       g.st_first[sj] = (uint16_t)sf;

@@ -70,6 +70,8 @@ struct Stair2D {
   int64_t I0, pr;        // global tile row of C's first nb-row-tile, and the stride between consecutive local tile rows
   int64_t J0, pc;        // same for columns
   int64_t jl0;           // absolute local column-tile index of C's first column tile (index into voff)
+  int64_t il0 = 0;       // reflected rounds (grid_sched.hpp Layout::refl; refl_r >= 0): local row tile t of C is global tile
+  int refl_r = -1;       // row pr (il0 + t) + (il0 + t odd ? pr-1 - refl_r : refl_r) instead of I0 + t pr
   const int64_t* voff;   // DEVICE table: offset (in doubles, from Vbase) of the B operand of every local column tile
 };
 int gemm_stair2d(int64_t M, int64_t N, int64_t K, double alpha, const double* W, int64_t ldw, const double* Vbase,

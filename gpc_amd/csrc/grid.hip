@@ -59,11 +59,14 @@ __global__ void __launch_bounds__(256) zero_rows_kernel(double* __restrict__ A, 
 }
 
 // one workgroup per local tile row: the nb entries of the GLOBAL diagonal it holds (if any)
+// global tile row of local tile row il on process row r (Layout::grow_s; refl: the rounds alternate direction)
+__device__ __forceinline__ int64_t tile_row(int64_t il, int r, int pr, int refl) { return (int64_t)pr * il + ((refl && (il & 1)) ? pr - 1 - r : r); }
+
 __global__ void __launch_bounds__(256) set_diag_kernel(double* __restrict__ A, int64_t lld, int64_t nb, int r, int pr, int c,
-                                                       int pc, int64_t T, int64_t N, const double* __restrict__ dg)
+                                                       int pc, int64_t T, int64_t N, const double* __restrict__ dg, int refl)
 {
   const int64_t il = blockIdx.x;
-  const int64_t I = r + (int64_t)pr * il;
+  const int64_t I = tile_row(il, r, pr, refl);
   if(I >= T || (I - c) % pc != 0 || I < c) return;
   const int64_t jl = (I - c) / pc;
   for(int64_t i = threadIdx.x; i < nb; i += 256) {
@@ -106,11 +109,11 @@ __device__ __forceinline__ double block_sum(double v, double* sh)
 }
 
 __global__ void __launch_bounds__(256) diag_logsum_kernel(const double* __restrict__ A, int64_t lld, int64_t nb, int r, int pr,
-                                                          int c, int pc, int64_t T, double* __restrict__ partial)
+                                                          int c, int pc, int64_t T, double* __restrict__ partial, int refl)
 {
   __shared__ double sh[4];
   const int64_t il = blockIdx.x;
-  const int64_t I = r + (int64_t)pr * il;
+  const int64_t I = tile_row(il, r, pr, refl);
   double v = 0.0;
   if(I < T && I >= c && (I - c) % pc == 0) {
     const int64_t jl = (I - c) / pc;
@@ -313,7 +316,7 @@ struct HipOps : GridOps {
   {
     const int64_t pad0 = L.N - (L.T - 1) * L.nb;   // rows of the last tile that are real
     if(pad0 < L.nb) {
-      if((int)((L.T - 1) % L.pr) == L.r && L.nloc > 0) {
+      if(L.owner_row(L.T - 1) == L.r && L.nloc > 0) {
         const int64_t il = (L.T - 1) / L.pr;
         hipLaunchKernelGGL(zero_rows_kernel, dim3((unsigned)(L.nloc < 1024 ? L.nloc : 1024)), dim3(256), 0, st[s], A, L.lld,
                            il * L.nb + pad0, L.nb - pad0, L.nloc);
@@ -325,7 +328,7 @@ struct HipOps : GridOps {
     }
     if(L.Lr > 0 && L.Lc > 0)
       hipLaunchKernelGGL(set_diag_kernel, dim3((unsigned)L.Lr), dim3(256), 0, st[s], A, L.lld, L.nb, L.r, L.pr, L.c, L.pc, L.T,
-                         L.N, dg);
+                         L.N, dg, L.refl ? 1 : 0);
     HIPOPS_CHECK(hipGetLastError());
     return GPC_OK;
   }
@@ -378,6 +381,8 @@ struct HipOps : GridOps {
     sd.pc = u.pc;
     sd.jl0 = u.jl0;
     sd.voff = u.voff_dev;
+    sd.il0 = u.il_begin;
+    sd.refl_r = u.refl_r;
     TrailingScope role;
     static int p1 = -1;
     if(p1 < 0) { const char* e = getenv("GPC_GRID_P1_TRI"); p1 = e ? atoi(e) : 0; }
@@ -396,7 +401,7 @@ struct HipOps : GridOps {
     double* part = nullptr;
     GPC_CHECK(scratch(sizeof(double) * (size_t)L.Lr, &part));
     hipLaunchKernelGGL(diag_logsum_kernel, dim3((unsigned)L.Lr), dim3(256), 0, st[s], A, L.lld, L.nb, L.r, L.pr, L.c, L.pc, L.T,
-                       part);
+                       part, L.refl ? 1 : 0);
     HIPOPS_CHECK(hipGetLastError());
     std::vector<double> h((size_t)L.Lr);
     GPC_CHECK(download(h.data(), part, sizeof(double) * h.size(), s));
@@ -802,15 +807,16 @@ extern "C" int gpc_bench_update(int mode, int64_t m, int64_t nb, int pr, int pc,
   HIPOPS_CHECK(hipEventCreate(&e0));
   HIPOPS_CHECK(hipEventCreate(&e1));
   gpc::Stair2D sd;
-  sd.nb = nb; sd.I0 = r; sd.pr = pr; sd.J0 = c; sd.pc = pc; sd.jl0 = 0; sd.voff = voff;
+  sd.nb = nb; sd.I0 = L.grow(0); sd.pr = pr; sd.J0 = c; sd.pc = pc; sd.jl0 = 0; sd.voff = voff;
+  sd.il0 = 0; sd.refl_r = L.refl ? r : -1;
   double fl = 0.0;
   for(int64_t jl = 0; jl < L.Lc; jl++) {
     const int64_t J = c + (int64_t)pc * jl;
-    const int64_t ilf = gpc::grid::Layout::first_after(J - 1, r, pr);
+    const int64_t ilf = L.first_after_row(J - 1, r);
     const double rows = (double)(L.mloc - ilf * nb);
     if(rows <= 0) continue;
     fl += rows * (double)nb;
-    if(ilf < L.Lr && r + pr * ilf == J) fl -= 0.5 * (double)nb * (double)(nb - 1);
+    if(ilf < L.Lr && L.grow(ilf) == J) fl -= 0.5 * (double)nb * (double)(nb - 1);
   }
   fl *= 2.0 * (double)nb;
   if(mode == 1) fl = (double)m * (double)(m + 1) * (double)nb;
@@ -838,6 +844,7 @@ extern "C" int gpc_bench_update(int mode, int64_t m, int64_t nb, int pr, int pc,
     } else if(mode == 7) {
       gpc::Stair2D s7;
       s7.nb = nb; s7.I0 = 1; s7.pr = 1; s7.J0 = 1; s7.pc = 1; s7.jl0 = 1; s7.voff = voff6;
+      s7.il0 = 0; s7.refl_r = -1;
       const double* P = A6 + nb;   // rows below tile 0; V base = P - 1 * nb so that voff[J] = J * nb
       rc = gpc::gemm_stair2d(m + 16, m, nb, -1.0, P, lld6, P - nb, lld6, A6 + nb + nb * lld6, lld6, s7, nullptr);
     } else
@@ -854,5 +861,43 @@ extern "C" int gpc_bench_update(int mode, int64_t m, int64_t nb, int pr, int pc,
   if(A6) (void)hipFree(A6);
   if(voff6) (void)hipFree(voff6);
   (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  return rc;
+}
+
+// Measurement aid (tools/grid_costs.py; not part of the declared C-ABI): average time of factoring one tall panel
+// (M x nb: the diagonal tile and the rows below it in one call, as a grid rank does it) on an SPD-like array.
+extern "C" int gpc_bench_panel(int64_t M, int64_t nb, int reps, double* ms)
+{
+  GPC_CHECK(gpc::ensure_device());
+  if(M < nb || nb <= 0 || nb % 64 != 0) return GPC_EINVAL;
+  double *A = nullptr, *A0 = nullptr;
+  int* info = nullptr;
+  HIPOPS_CHECK(hipMalloc((void**)&A, sizeof(double) * (size_t)(M * nb)));
+  HIPOPS_CHECK(hipMalloc((void**)&A0, sizeof(double) * (size_t)(M * nb)));
+  HIPOPS_CHECK(hipMalloc((void**)&info, 64));
+  HIPOPS_CHECK(hipMemset(info, 0, 64));
+  hipLaunchKernelGGL(bench_fill_kernel, dim3(2048), dim3(256), 0, nullptr, A0, M * nb, 1e-2);
+  hipLaunchKernelGGL(set_identity_diag_kernel, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, nullptr, A0, M, nb);   // diagonal 1: positive definite
+  hipEvent_t e0, e1;
+  HIPOPS_CHECK(hipEventCreate(&e0));
+  HIPOPS_CHECK(hipEventCreate(&e1));
+  float total = 0.f, copy = 0.f;
+  int rc = GPC_OK;
+  for(int pass = 0; pass < 2; pass++) {            // pass 0 times the restoring copy alone, pass 1 copy + factorisation
+    for(int it = 0; it < reps + 1 && rc == GPC_OK; it++) {
+      if(it == 1) HIPOPS_CHECK(hipEventRecord(e0, nullptr));
+      HIPOPS_CHECK(hipMemcpyAsync(A, A0, sizeof(double) * (size_t)(M * nb), hipMemcpyDeviceToDevice, nullptr));
+      if(pass == 1) rc = gpc::potrf_panel(M, nb, A, M, info, 0, nullptr);
+    }
+    HIPOPS_CHECK(hipEventRecord(e1, nullptr));
+    HIPOPS_CHECK(hipEventSynchronize(e1));
+    HIPOPS_CHECK(hipEventElapsedTime(pass == 0 ? &copy : &total, e0, e1));
+  }
+  int h = 0;
+  HIPOPS_CHECK(hipMemcpy(&h, info, sizeof(int), hipMemcpyDeviceToHost));
+  *ms = (double)(total - copy) / reps;
+  (void)hipFree(A); (void)hipFree(A0); (void)hipFree(info);
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  if(rc == GPC_OK && h != 0) { gpc::set_error("gpc_bench_panel: info = %d", h); return GPC_EHIP; }
   return rc;
 }

@@ -228,13 +228,13 @@ int GRID_API(barrier)(gpc_grid* g)
   return g->gp->comm()->barrier();
 }
 
-// out[0..11] = N, nb, T, pr, pc, r, c, mloc, nloc, extra rows, local tile rows, local tile columns
+// out[0..12] = N, nb, T, pr, pc, r, c, mloc, nloc, extra rows, local tile rows, local tile columns, rounds reflected (0 / 1)
 int GRID_API(info)(gpc_grid* g, int64_t* out)
 {
   if(!g || !out) return GPC_EINVAL;
   const Layout& L = g->gp->layout();
-  const int64_t v[12] = {L.N, L.nb, L.T, L.pr, L.pc, L.r, L.c, L.mloc, L.nloc, L.E, L.Lr, L.Lc};
-  for(int i = 0; i < 12; i++) out[i] = v[i];
+  const int64_t v[13] = {L.N, L.nb, L.T, L.pr, L.pc, L.r, L.c, L.mloc, L.nloc, L.E, L.Lr, L.Lc, L.refl ? 1 : 0};
+  for(int i = 0; i < 13; i++) out[i] = v[i];
   return GPC_OK;
 }
 

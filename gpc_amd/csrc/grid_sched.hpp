@@ -61,15 +61,48 @@ struct Layout {
   bool has_extra = false;       // this rank's process row carries the extra rows (tile row T)
   int64_t mloc = 0, nloc = 0, lld = 0;
 
-  void init(int64_t N_, int64_t nb_, int pr_, int pc_, int r_, int c_, int64_t E_)
+  // Row ownership.  Plain cyclic (tile row I on process row I mod pr) gives the last process row the lowest tile row of
+  // every round of pr -- the longest one: on a pr x 1 grid with T / pr = 8 rounds its trailing updates are 37 % more work
+  // than process row 0's (replay of the scheduler's trace, tools/grid_model.py), and the slowest rank sets the time.  With
+  // one process column the rounds therefore alternate direction (0 .. pr-1, pr-1 .. 0, ...): tile row I of round g = I / pr
+  // sits on process row I mod pr in even rounds and pr-1 - I mod pr in odd ones, still as local tile row g.  Columns stay
+  // plain cyclic (with pc > 1 the column exchange relies on the period of J mod pr).
+  bool refl = false;
+  static bool reflect_default()
+  {
+    const char* e = getenv("GPC_GRID_REFLECT");
+    return !e || atoi(e) != 0;
+  }
+  int64_t grow_s(int s, int64_t il) const { return (int64_t)pr * il + ((refl && (il & 1)) ? pr - 1 - s : s); }
+  int64_t grow(int64_t il) const { return grow_s(r, il); }                       // global tile row of local tile row il
+  int owner_row(int64_t I) const
+  {
+    const int p = (int)(I % pr);
+    return (refl && ((I / pr) & 1)) ? pr - 1 - p : p;
+  }
+  int64_t rows_of(int s) const                                                    // local tile rows of process row s (I < T)
+  {
+    const int64_t full = T / pr;
+    const int p = (refl && (full & 1)) ? pr - 1 - s : s;
+    return full + (p < (int)(T % pr) ? 1 : 0);
+  }
+  int64_t first_after_row(int64_t k, int s) const                                  // first local tile row of s with I > k
+  {
+    if(k < 0) return 0;
+    const int64_t g = k / pr;
+    return grow_s(s, g) > k ? g : g + 1;
+  }
+
+  void init(int64_t N_, int64_t nb_, int pr_, int pc_, int r_, int c_, int64_t E_, int reflect = -1)
   {
     N = N_; nb = nb_; pr = pr_; pc = pc_; r = r_; c = c_; E = E_;
+    refl = pc == 1 && pr > 1 && (reflect < 0 ? reflect_default() : reflect != 0);
     T = (N + nb - 1) / nb;
     Np = T * nb;
     E2 = (E + 15) & ~(int64_t)15;
-    Lr = ntiles(T, r, pr);
+    Lr = rows_of(r);
     Lc = ntiles(T, c, pc);
-    has_extra = E > 0 && (int)(T % pr) == r;
+    has_extra = E > 0 && owner_row(T) == r;
     mloc = Lr * nb + (has_extra ? E2 : 0);
     nloc = Lc * nb;
     lld = mloc > 2 ? mloc : 2;
@@ -77,9 +110,9 @@ struct Layout {
   static int64_t ntiles(int64_t T, int first, int stride) { return first >= T ? 0 : (T - first + stride - 1) / stride; }
   // first local tile index whose global index exceeds k (first = r or c, stride = pr or pc)
   static int64_t first_after(int64_t k, int first, int stride) { return k < first ? 0 : (k - first) / stride + 1; }
-  int64_t il0(int64_t k) const { return first_after(k, r, pr); }
+  int64_t il0(int64_t k) const { return first_after_row(k, r); }
   int64_t jl0(int64_t k) const { return first_after(k, c, pc); }
-  int extra_row() const { return (int)(T % pr); }
+  int extra_row() const { return owner_row(T); }
   int rank() const { return r * pc + c; }
   static int64_t gcd(int64_t a, int64_t b) { while(b) { int64_t t = a % b; a = b; b = t; } return a; }
 };
@@ -94,6 +127,14 @@ struct UpdateArgs {
   const int64_t* voff_host;     // the same table on the host (for implementations that run there)
   double* C; int64_t ldc;
   int64_t nb, I0, J0, jl0; int pr, pc;
+  int64_t il_begin = 0; int refl_r = -1;   // reflected rounds (Layout::refl): local tile row t of C is global tile row
+                                           // pr (il_begin + t) + (odd round ? pr-1 - refl_r : refl_r); -1: I0 + t pr
+  int64_t grow(int64_t t) const
+  {
+    if(refl_r < 0) return I0 + t * pr;
+    const int64_t il = il_begin + t;
+    return (int64_t)pr * il + ((il & 1) ? pr - 1 - refl_r : refl_r);
+  }
 };
 
 struct GridOps {
@@ -443,6 +484,7 @@ class GridGp {
   GridGp(std::unique_ptr<GridOps> ops, std::unique_ptr<GridComm> comm, int pr, int pc, int r, int c, int64_t nb)
       : ops_(std::move(ops)), comm_(std::move(comm)), pr_(pr), pc_(pc), r_(r), c_(c), nb_(nb)
   {
+    if(const char* e = getenv("GPC_GRID_FUSED_ROWS")) fused_rows = atoll(e);
   }
   ~GridGp() { free_all(); }
 
@@ -456,6 +498,12 @@ class GridGp {
   double jitter() const { return jitter_; }
   const double* local_block() const { return A_; }
   int lookahead = 1;   // 0: everything on one stream, no overlap (debugging / A-B measurements)
+  // A panel whose tallest per-rank share (diagonal tile + rows below it) has at most this many rows is factored by every
+  // rank of the owning process column in ONE call on [tile; its rows] -- the UNFACTORED tile travels down the column and
+  // each rank factors it again beside its own rows (0.28 ms of redundant work) -- instead of tile factorisation, broadcast
+  // of the factor, and a separate triangular solve: measured on one MI355X at nb = 1024, 8192 rows: 0.50 ms against
+  // 0.32 + 0.59; 16 384 rows: 0.85 against 0.32 + 0.78; from 32 768 rows the separate solve wins (2.3 against 1.6 ms).
+  int64_t fused_rows = 20480;   // GPC_GRID_FUSED_ROWS; 0 = never
 
   // Problem definition: X (N x D), Y (N x d, may be null), Xstar (Ns x D, may be null) are HOST arrays, column-major,
   // identical on every rank.  (Re)allocates the local block when the shape changes.
@@ -478,7 +526,12 @@ class GridGp {
     GRID_CHECK(upload_matrix(X_, X, N, D, ldx));
     if(d > 0) GRID_CHECK(upload_matrix(Y_, Y, N, d, ldy));
     if(Ns > 0) GRID_CHECK(upload_matrix(Xs_, Xs, Ns, D, ldxs));
-    GRID_CHECK(ops_->gather_rows(X_, N, D, N, r_, pr_, L_.Lr, nb_, Xr_, imax(L_.Lr * nb_, 1), ST_MAIN));
+    if(!L_.refl) {
+      GRID_CHECK(ops_->gather_rows(X_, N, D, N, r_, pr_, L_.Lr, nb_, Xr_, imax(L_.Lr * nb_, 1), ST_MAIN));
+    } else {
+      for(int64_t il = 0; il < L_.Lr; il++)   // reflected rounds: no single stride
+        GRID_CHECK(ops_->gather_rows(X_, N, D, N, L_.grow(il), 1, 1, nb_, Xr_ + il * nb_, imax(L_.Lr * nb_, 1), ST_MAIN));
+    }
     GRID_CHECK(ops_->gather_rows(X_, N, D, N, c_, pc_, L_.Lc, nb_, Xc_, imax(L_.Lc * nb_, 1), ST_MAIN));
     factored_ = alpha_valid_ = false;
     return GPC_OK;
@@ -564,7 +617,11 @@ class GridGp {
       int64_t jfirst = jl0;
       if(k + 1 < L.T) {
         const bool next_col = (int)((k + 1) % pc_) == c_;
-        const bool next_diag = next_col && pr_ > 1 && (int)((k + 1) % pr_) == r_;   // this rank factors diagonal tile k+1
+        // this rank factors diagonal tile k+1 -- and its tile leaves early only if that buys something: with a fused panel
+        // step the factorisation waits for the whole tile column anyway, so the early tile only lets the broadcast start
+        // under the rest of U1; when all of U1 is one round of workgroups (<= 512 tiles of 128 x 128) it costs a launch more
+        const bool u1_small = panel_fused(k + 1) && (M / 128) * (nb_ / 128) <= 512;
+        const bool next_diag = next_col && pr_ > 1 && L.owner_row(k + 1) == r_ && !u1_small;
         bool have_u1a = false;
         if(next_col && M > 0 && jl0 < L.Lc) {
           // U1: the tiles of panel k+1 first, so that its factorisation overlaps the rest of this update -- and of those
@@ -647,7 +704,7 @@ class GridGp {
     GRID_CHECK(ops_->zero(alr_, sizeof(double) * (size_t)(imax(L.Lr, 1) * nb_ * d_), ST_MAIN));
     const int64_t ldr = imax(L.Lr, 1) * nb_;
     for(int64_t k = L.T - 1; k >= 0; k--) {
-      const int kr = (int)(k % pr_), kc = (int)(k % pc_);
+      const int kr = L.owner_row(k), kc = (int)(k % pc_);
       if(c_ == kc) {
         const int64_t jl = k / pc_, il0 = L.il0(k);
         const int64_t Mb = (L.Lr - il0) * nb_;   // matrix rows below tile k on this rank
@@ -734,15 +791,18 @@ class GridGp {
     for(int64_t J = 0; J < L.T && rc == GPC_OK; J++) {
       const int jc = (int)(J % pc_);
       for(int s = 0; s < pr_ && rc == GPC_OK; s++) {
-        const int64_t ilf = Layout::first_after(J - 1, s, pr_);          // first local tile row of process row s with I >= J
-        const int64_t cnt = Layout::ntiles(L.T, s, pr_) - ilf;
+        const int64_t ilf = L.first_after_row(J - 1, s);                 // first local tile row of process row s with I >= J
+        const int64_t cnt = L.rows_of(s) - ilf;
         if(cnt <= 0) continue;
         if(r_ == s && c_ == jc)
           rc = ops_->copy2d(strip, cnt * nb_, A_ + ilf * nb_ + (J / pc_) * nb_ * L.lld, L.lld, cnt * nb_, nb_, ST_MAIN);
         if(rc == GPC_OK) rc = comm_->bcast(strip, cnt * nb_ * nb_, s * pc_ + jc, AX_WORLD, ops_.get(), ST_MAIN);
         count_coll(AX_WORLD, 8.0 * (double)(cnt * nb_ * nb_), !(r_ == s && c_ == jc));
-        if(rc == GPC_OK)
+        if(rc == GPC_OK && !L.refl)
           rc = ops_->scatter_row_tiles(Lf + J * nb_ * L.Np, L.Np, s + pr_ * ilf, pr_, strip, cnt * nb_, cnt, nb_, nb_, ST_MAIN);
+        for(int64_t t = 0; L.refl && t < cnt && rc == GPC_OK; t++)
+          rc = ops_->scatter_row_tiles(Lf + J * nb_ * L.Np, L.Np, L.grow_s(s, ilf + t), 1, strip + t * nb_, cnt * nb_, 1, nb_, nb_,
+                                       ST_MAIN);
       }
     }
     // 2. my tile columns of K^-1 and their share of the gradient.  G of them are solved for at once (the triangular solves are
@@ -786,7 +846,7 @@ class GridGp {
   {
     const Layout& L = L_;
     const bool extra = (I == L.T);
-    const bool mine = (extra ? L.has_extra : (int)(I % pr_) == r_) && (int)(J % pc_) == c_ && J < L.T && I <= L.T;
+    const bool mine = (extra ? L.has_extra : L.owner_row(I) == r_) && (int)(J % pc_) == c_ && J < L.T && I <= L.T;
     if(owned) *owned = mine ? 1 : 0;
     if(!mine) return GPC_OK;
     const int64_t il = extra ? L.Lr : I / pr_, jl = J / pc_;
@@ -847,6 +907,10 @@ class GridGp {
       ev_panel_[b] = ops_->event_create();
       ev_free_[b] = ops_->event_create();
     }
+    if(pr_ > 1 && fused_rows > 0) {   // staging of [tile; rows] on the ranks that do not own the diagonal tile
+      const int64_t rows = fused_rows < nb_ + L.mloc ? fused_rows : nb_ + L.mloc;
+      GRID_CHECK(A(St_, rows * nb_));
+    }
     ev_ready_ = ops_->event_create();
     ev_u1_ = ops_->event_create();
     ev_u1a_ = ops_->event_create();
@@ -857,12 +921,12 @@ class GridGp {
     region_start_.assign((size_t)pr_ + 1, 0);
     if(pr_ > 1) {
       std::vector<int64_t> cnt((size_t)pr_, 0);
-      for(int64_t jl = 0; jl < L.Lc; jl++) cnt[(size_t)((c_ + pc_ * jl) % pr_)]++;
+      for(int64_t jl = 0; jl < L.Lc; jl++) cnt[(size_t)L.owner_row(c_ + pc_ * jl)]++;
       for(int s = 0; s < pr_; s++) region_start_[(size_t)s + 1] = region_start_[(size_t)s] + cnt[(size_t)s];
       std::vector<int64_t> seen((size_t)pr_, 0);
       slot_.assign((size_t)imax(L.Lc, 1), 0);
       for(int64_t jl = 0; jl < L.Lc; jl++) {
-        const int s = (int)((c_ + pc_ * jl) % pr_);
+        const int s = L.owner_row(c_ + pc_ * jl);
         slot_[(size_t)jl] = region_start_[(size_t)s] + seen[(size_t)s]++;
         voff_host_[(size_t)jl] = slot_[(size_t)jl] * nb_ * nb_;
       }
@@ -878,7 +942,7 @@ class GridGp {
   {
     if(!ops_) return;
     double** ps[] = {&A_, &X_, &Xr_, &Xc_, &dg_, &Y_, &al_, &alr_, &t_, &Xs_, &W_[0], &W_[1], &V_[0], &V_[1], &Dg_[0], &Dg_[1],
-                     &Lf_, &strip_, &Zg_};
+                     &Lf_, &strip_, &Zg_, &St_};
     for(double** p : ps)
       if(*p) {
         ops_->release(*p);
@@ -911,6 +975,19 @@ class GridGp {
     }
   }
 
+  // tallest share of panel k over the ranks of its process column (tile included); the same number on every rank
+  int64_t panel_rows_max(int64_t k) const
+  {
+    const Layout& L = L_;
+    int64_t most = 0;
+    for(int s = 0; s < pr_; s++) {
+      const int64_t rows = L.rows_of(s) - L.first_after_row(k, s);
+      most = rows > most ? rows : most;
+    }
+    return nb_ + most * nb_ + (L.E > 0 ? L.E2 : 0);
+  }
+  bool panel_fused(int64_t k) const { return pr_ > 1 && fused_rows > 0 && panel_rows_max(k) <= fused_rows; }
+
   // steps (1)-(4) of panel k on stream st; leaves W / V of parity k&1 complete and records ev_panel_[k&1].
   // before_potrf / before_solve: events of the update stream after which the diagonal tile / the whole tile column k carry
   // the previous panel's update (null: same stream, nothing to wait for)
@@ -918,7 +995,7 @@ class GridGp {
   {
     const Layout& L = L_;
     const int b = (int)(k & 1);
-    const int kr = (int)(k % pr_), kc = (int)(k % pc_);
+    const int kr = L.owner_row(k), kc = (int)(k % pc_);
     const int64_t il0 = L.il0(k), jl0 = L.jl0(k);
     const int64_t M = L.mloc - il0 * nb_;          // rows below tile k on this rank (extra rows included)
     const double* W = nullptr;
@@ -931,6 +1008,26 @@ class GridGp {
         // the whole panel is local: diagonal block + the rows below it in one chain (dpotrf + dtrsm)
         if(before_solve) GRID_CHECK(ops_->wait(st, before_solve));
         GRID_CHECK(ops_->potrf_panel(L.mloc - k * nb_, nb_, col + k * nb_, L.lld, k * nb_, info_dev_, st));
+      } else if(panel_fused(k)) {
+        // the updated, still unfactored tile goes down the column; every rank factors [tile; its rows] in one call
+        if(r_ == kr) {
+          const int64_t il = k / pr_;
+          if(before_potrf) GRID_CHECK(ops_->wait(st, before_potrf));
+          GRID_CHECK(ops_->copy2d(Dg_[b], nb_, col + il * nb_, L.lld, nb_, nb_, st));
+        }
+        GRID_CHECK(comm_->bcast(Dg_[b], nb_ * nb_, kr, AX_COL, ops_.get(), st));
+        count_coll(AX_COL, 8.0 * (double)(nb_ * nb_), r_ != kr);
+        if(before_solve) GRID_CHECK(ops_->wait(st, before_solve));
+        if(r_ == kr) {
+          const int64_t il = k / pr_;      // the tile and this rank's rows below it are neighbours in the local block
+          GRID_CHECK(ops_->potrf_panel(nb_ + M, nb_, col + il * nb_, L.lld, k * nb_, info_dev_, st));
+        } else if(M > 0) {
+          const int64_t lds = nb_ + M;
+          GRID_CHECK(ops_->copy2d(St_, lds, Dg_[b], nb_, nb_, nb_, st));
+          GRID_CHECK(ops_->copy2d(St_ + nb_, lds, col + il0 * nb_, L.lld, M, nb_, st));
+          GRID_CHECK(ops_->potrf_panel(lds, nb_, St_, lds, k * nb_, info_dev_, st));
+          GRID_CHECK(ops_->copy2d(col + il0 * nb_, L.lld, St_ + nb_, lds, M, nb_, st));
+        }
       } else {
         if(r_ == kr) {
           const int64_t il = k / pr_;
@@ -956,22 +1053,23 @@ class GridGp {
       // packs the tiles it holds into its region of V and ONE in-place all-gather over the process column hands every rank
       // the other regions -- each pair of ranks over its own link -- instead of pr broadcasts one after the other.
       const int64_t g = Layout::gcd(pr_, pc_);
-      const int64_t q = pr_ / g;          // consecutive tiles of one source are q local column tiles apart
-      std::vector<int64_t> start((size_t)pr_, 0), count((size_t)pr_, 0);
+      std::vector<int64_t> start((size_t)pr_, 0), count((size_t)pr_, 0), jfirst((size_t)pr_, -1);
       double recv = 0.0;
+      for(int64_t jl = jl0; jl < L.Lc; jl++) {          // the slots of one source are consecutive, in the order of jl
+        const int s = L.owner_row(c_ + pc_ * jl);
+        if(jfirst[(size_t)s] < 0) {
+          jfirst[(size_t)s] = jl;
+          start[(size_t)s] = slot_[(size_t)jl] * nb_ * nb_;
+        }
+        count[(size_t)s] += nb_ * nb_;
+      }
       for(int s = 0; s < pr_; s++) {
-        // first jl >= jl0 with (c + pc*jl) mod pr == s
-        int64_t jf = -1;
-        for(int64_t jl = jl0; jl < jl0 + q && jl < L.Lc; jl++)
-          if((int)((c_ + pc_ * jl) % pr_) == s) { jf = jl; break; }
-        if(jf < 0) continue;
-        const int64_t ntile = (L.Lc - 1 - jf) / q + 1;
-        start[(size_t)s] = slot_[(size_t)jf] * nb_ * nb_;
-        count[(size_t)s] = ntile * nb_ * nb_;
+        if(count[(size_t)s] == 0) continue;
         if(r_ == s) {
-          const int64_t J = c_ + pc_ * jf;
-          const int64_t first = J / pr_ - il0;                 // row tile of W that holds L(J,k)
-          GRID_CHECK(ops_->pack_tiles(V_[b] + start[(size_t)s], W, ldw, first, pc_ / g, ntile, nb_, st));
+          // my tiles sit pc / gcd row tiles apart in the row panel (one apart when the rounds are reflected: pc = 1)
+          const int64_t J = c_ + pc_ * jfirst[(size_t)s];
+          GRID_CHECK(ops_->pack_tiles(V_[b] + start[(size_t)s], W, ldw, J / pr_ - il0, pc_ / g, count[(size_t)s] / (nb_ * nb_), nb_,
+                                      st));
         } else {
           recv += 8.0 * (double)count[(size_t)s];
         }
@@ -1009,7 +1107,9 @@ class GridGp {
     u.C = A_ + il_begin * nb_ + jl_first * nb_ * L.lld;
     u.ldc = L.lld;
     u.nb = nb_;
-    u.I0 = r_ + pr_ * il_begin;
+    u.I0 = L.grow(il_begin);
+    u.il_begin = il_begin;
+    u.refl_r = L.refl ? r_ : -1;
     u.J0 = c_ + pc_ * jl_first;
     u.jl0 = jl_first;
     u.pr = pr_;
@@ -1018,8 +1118,8 @@ class GridGp {
     double entries = 0.0;
     for(int64_t jl = jl_first; jl < jl_first + ncolt; jl++) {
       const int64_t J = c_ + pc_ * jl;
-      int64_t ilf = Layout::first_after(J - 1, r_, pr_);   // first local row tile with I >= J
-      const bool diag_in_range = ilf >= il_begin && ilf < L.Lr && r_ + pr_ * ilf == J && (il_end < 0 || ilf < il_end);
+      int64_t ilf = L.first_after_row(J - 1, r_);          // first local row tile with I >= J
+      const bool diag_in_range = ilf >= il_begin && ilf < L.Lr && L.grow(ilf) == J && (il_end < 0 || ilf < il_end);
       if(ilf < il_begin) ilf = il_begin;
       double rows = (double)((il_end < 0 ? L.mloc : il_end * nb_) - ilf * nb_);
       if(rows <= 0) continue;
@@ -1055,6 +1155,7 @@ class GridGp {
   double *A_ = nullptr, *X_ = nullptr, *Xr_ = nullptr, *Xc_ = nullptr, *dg_ = nullptr, *Y_ = nullptr, *al_ = nullptr,
          *alr_ = nullptr, *t_ = nullptr, *Xs_ = nullptr;
   double *W_[2] = {nullptr, nullptr}, *V_[2] = {nullptr, nullptr}, *Dg_[2] = {nullptr, nullptr};
+  double* St_ = nullptr;                                      // [tile; rows] of a fused panel step (see fused_rows)
   double *Lf_ = nullptr, *strip_ = nullptr, *Zg_ = nullptr;   // gradient(): replicated factor, one strip in flight, the solves' block
   int* info_dev_ = nullptr;
   int64_t* voff_dev_ = nullptr;

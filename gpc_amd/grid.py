@@ -64,6 +64,13 @@ def default_shape(nranks):
     return pr, nranks // pr
 
 
+def owner_row(I, pr, refl):
+    """process row of tile row I (Layout::owner_row in csrc/grid_sched.hpp): plain cyclic, or -- on a pr x 1 grid -- rounds of
+    pr tile rows that alternate direction"""
+    p = I % pr
+    return pr - 1 - p if (refl and (I // pr) & 1) else p
+
+
 def _kspec(terms_or_ks):
     if isinstance(terms_or_ks, KSpec):
         return terms_or_ks
@@ -93,9 +100,9 @@ class Grid(object):
             self.h = None
 
     def info(self):
-        out = (c_int64 * 12)()
+        out = (c_int64 * 16)()
         self.b.check(self.b.info(self.h, out), self.h)
-        keys = ["N", "nb", "T", "pr", "pc", "r", "c", "mloc", "nloc", "E", "Lr", "Lc"]
+        keys = ["N", "nb", "T", "pr", "pc", "r", "c", "mloc", "nloc", "E", "Lr", "Lc", "refl"]
         return dict(zip(keys, [int(v) for v in out]))
 
     def stats(self, reset=False):
@@ -189,8 +196,8 @@ class Grid(object):
         inf = self.info()
         T, pr, pc, r, c = inf["T"], inf["pr"], inf["pc"], inf["r"], inf["c"]
         out = {}
-        rows = list(range(r, T, pr))
-        if extras and inf["E"] > 0 and T % pr == r:
+        rows = [I for I in range(T) if owner_row(I, pr, inf["refl"]) == r]
+        if extras and inf["E"] > 0 and owner_row(T, pr, inf["refl"]) == r:
             rows.append(T)
         for I in rows:
             for J in range(c, T, pc):

@@ -212,7 +212,9 @@ int gpc_grid_barrier(gpc_grid* g);
  * GPC_ENOMEM on one rank.  No effect on RCCL / transport grids (their own time-outs apply). */
 int gpc_grid_abort(gpc_grid* g);
 int gpc_grid_set_lookahead(gpc_grid* g, int on);
-/* out[12] = N, nb, T (tiles per side), pr, pc, r, c, local rows, local columns, extra rows, local tile rows, columns */
+/* out[13] = N, nb, T (tiles per side), pr, pc, r, c, local rows, local columns, extra rows, local tile rows, columns,
+ * rows reflected (1 on a pr x 1 grid: the rounds of pr tile rows alternate direction, tile row I lives on process row
+ * I mod pr in even rounds I / pr and on pr-1 - I mod pr in odd ones; 0: plain cyclic) */
 int gpc_grid_info(gpc_grid* g, int64_t* out);
 /* out[8] = bytes received along the process row / column / world, collectives entered, algorithmic flops of this rank's
  * trailing updates, their launches, their algorithmic HBM bytes, 0 -- since the last reset */

@@ -118,13 +118,16 @@ def rel(a, b):
 def recv_bytes_model(N, nb, pr, pc, r, c, E2_rows_on=None):
     """Bytes rank (r, c) receives over one factorisation (matrix rows only), by the counting the scheduler does:
     diagonal tiles down the column, row panels along the row, column-panel tiles inside the column."""
+    from gpc_amd.grid import owner_row
     T = (N + nb - 1) // nb
+    refl = 1 if (pc == 1 and pr > 1 and os.environ.get("GPC_GRID_REFLECT", "1") != "0") else 0
+    mine = [I for I in range(T) if owner_row(I, pr, refl) == r]
     row = col = 0.0
     for k in range(T):
-        kr, kc = k % pr, k % pc
-        il0 = 0 if k < r else (k - r) // pr + 1
+        kr, kc = owner_row(k, pr, refl), k % pc
+        il0 = len([I for I in mine if I <= k])
         jl0 = 0 if k < c else (k - c) // pc + 1
-        Lr = 0 if r >= T else (T - r + pr - 1) // pr
+        Lr = len(mine)
         Lc = 0 if c >= T else (T - c + pc - 1) // pc
         M = (Lr - il0) * nb + (E2_rows_on or 0)
         if pr > 1 and c == kc and r != kr:
@@ -133,6 +136,6 @@ def recv_bytes_model(N, nb, pr, pc, r, c, E2_rows_on=None):
             row += 8.0 * max(M, 2) * nb
         if pr > 1:
             for jl in range(jl0, Lc):
-                if (c + pc * jl) % pr != r:
+                if owner_row(c + pc * jl, pr, refl) != r:
                     col += 8.0 * nb * nb
     return row, col

@@ -117,7 +117,7 @@ struct HostOps : GridOps {
           for(int64_t i = 0; i < L.mloc; i++) col[i] = 0.0;
         for(int64_t il = 0; il < L.Lr; il++)
           for(int64_t i = 0; i < L.nb; i++) {
-            const int64_t gi = (L.r + L.pr * il) * L.nb + i;
+            const int64_t gi = L.grow(il) * L.nb + i;
             if(gi == gj) col[il * L.nb + i] = gi < L.N ? dg[gi] : 1.0;
             else if(gi >= L.N) col[il * L.nb + i] = 0.0;
           }
@@ -173,7 +173,7 @@ struct HostOps : GridOps {
       const double* vrow = u.Vbase + u.voff_host[u.jl0 + ct] + cn;   // V(J)(cn, :) with stride ldv
       for(int64_t m = 0; m < u.M; m++) {
         const int64_t rt = m / nb, rm = m - rt * nb;
-        const int64_t I = u.I0 + rt * u.pr;
+        const int64_t I = u.grow(rt);
         if(I < J || (I == J && rm < cn)) continue;
         double s = 0.0;
         for(int64_t k = 0; k < u.K; k++) s += u.W[m + k * u.ldw] * vrow[k * u.ldv];
@@ -186,7 +186,7 @@ struct HostOps : GridOps {
   {
     double s = 0.0;
     for(int64_t il = 0; il < L.Lr; il++) {
-      const int64_t I = L.r + L.pr * il;
+      const int64_t I = L.grow(il);
       if(I < L.c || (I - L.c) % L.pc != 0) continue;
       const int64_t jl = (I - L.c) / L.pc;
       for(int64_t i = 0; i < L.nb; i++) s += log(A[il * L.nb + i + (jl * L.nb + i) * L.lld]);

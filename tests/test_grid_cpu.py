@@ -67,7 +67,8 @@ def _check(res, exp, N, nb, Xs):
         assert np.array_equal(r["alpha"], res[0]["alpha"])
 
 
-@pytest.mark.parametrize("pr,pc", [(1, 1), (1, 2), (2, 1), (2, 2), (2, 4), (4, 2), (1, 4), (3, 2), (2, 3), (1, 8)])
+@pytest.mark.parametrize("pr,pc", [(1, 1), (1, 2), (2, 1), (2, 2), (2, 4), (4, 2), (1, 4), (3, 2), (2, 3), (1, 8), (4, 1), (8, 1),
+                                   (3, 1)])
 def test_grid_shapes_against_numpy(hb, pr, pc):
     N, D, d, Ns, nb = 700, 3, 2, 5, 128        # T = 6 tiles, ragged last tile (60 real rows), odd extra-row count
     X, Y, Xs = gc.make_problem(N, D, d, Ns, 7)
@@ -83,7 +84,7 @@ def test_ragged_sizes_on_2x2(hb, N):
     _check(_solve_local(hb, 2, 2, 128, gc.TERMS, X, Y, Xs), exp, N, 128, Xs)
 
 
-@pytest.mark.parametrize("pr,pc", [(1, 1), (1, 2), (2, 2), (2, 4), (3, 2)])
+@pytest.mark.parametrize("pr,pc", [(1, 1), (1, 2), (2, 2), (2, 4), (3, 2), (4, 1), (8, 1)])
 def test_gradient_against_numpy(hb, pr, pc):
     """CGp::updateG on the grid (replicated factor, every rank its own tile columns of K^-1, one all-reduce) against the
     defining sums: rbf + lin + bias + white, ragged last tile, two outputs."""
@@ -106,6 +107,56 @@ def test_gradient_against_numpy(hb, pr, pc):
     for got, _ in res:
         assert gc.rel(got, want) < 1e-8
         assert np.array_equal(got, res[0][0])
+
+
+@pytest.mark.parametrize("pr,N,nb", [(4, 1500, 128), (8, 1000, 128), (8, 2100, 128), (3, 900, 256), (2, 700, 128), (8, 2048, 128),
+                                      (4, 1024, 128)])
+def test_reflected_rounds_on_one_process_column(hb, pr, N, nb, monkeypatch):
+    """pr x 1 grids alternate the direction of their rounds of pr tile rows (Layout::refl: the trailing updates of the
+    process rows balance).  Ragged sizes with a partial last round, extra rows (targets and test inputs) on whichever
+    process row owns tile row T; the same problem with plain cyclic rows (GPC_GRID_REFLECT=0) must give the same factor --
+    to rounding, the tiles' sums are formed in the same order either way -- and both must agree with numpy."""
+    X, Y, Xs = gc.make_problem(N, 3, 2, 7, 31)
+    exp = gc.expected(gc.TERMS, X, Y, Xs)
+    res = _solve_local(hb, pr, 1, nb, gc.TERMS, X, Y, Xs)
+    assert all(r["inf"]["refl"] == 1 for r in res)
+    _check(res, exp, N, nb, Xs)
+    # the rows are where Layout says: round g of process row r holds tile row pr g + (r or pr-1-r)
+    for r, out in enumerate(res):
+        rows = sorted(set(I for (I, J) in out["tiles"]))
+        assert rows == [I for I in range(out["inf"]["T"]) if grid.owner_row(I, pr, 1) == r]
+    # the work is balanced: no process row holds more than one tile row above the average number of lower tiles
+    T = res[0]["inf"]["T"]
+    tiles = [len(out["tiles"]) for out in res]
+    if T % (2 * pr) == 0:          # whole pairs of rounds: every process row holds exactly the same number of lower tiles
+        assert max(tiles) == min(tiles)
+    monkeypatch.setenv("GPC_GRID_REFLECT", "0")
+    plain = _solve_local(hb, pr, 1, nb, gc.TERMS, X, Y, Xs)
+    assert all(r["inf"]["refl"] == 0 for r in plain)
+    _check(plain, exp, N, nb, Xs)
+    assert abs(plain[0]["logdet"] - res[0]["logdet"]) <= 1e-14 * abs(res[0]["logdet"])   # (the ranks' partial sums differ)
+    La = grid.assemble_factor([r["tiles"] for r in res], N, nb)
+    Lb = grid.assemble_factor([r["tiles"] for r in plain], N, nb)
+    assert np.array_equal(La, Lb)
+
+
+def test_fused_and_separate_panel_steps_agree(hb, monkeypatch):
+    """GPC_GRID_FUSED_ROWS: every rank of the owning process column factors [tile; its rows] in one call (the unfactored
+    tile travels) or the owner factors the tile, sends the factor and the others solve.  Same arithmetic on the host
+    stand-in, so the same bits; both switch-over points inside one factorisation are crossed (limit = 3 tiles)."""
+    N, nb = 1300, 128
+    X, Y, Xs = gc.make_problem(N, 3, 1, 4, 5)
+    exp = gc.expected(gc.TERMS, X, Y, Xs)
+    out = {}
+    for limit in ("0", "384", "1000000"):
+        monkeypatch.setenv("GPC_GRID_FUSED_ROWS", limit)
+        for shape in ((2, 2), (4, 1)):
+            res = _solve_local(hb, shape[0], shape[1], nb, gc.TERMS, X, Y, Xs)
+            _check(res, exp, N, nb, Xs)
+            out[(limit, shape)] = grid.assemble_factor([r["tiles"] for r in res], N, nb)
+    for shape in ((2, 2), (4, 1)):
+        assert np.array_equal(out[("0", shape)], out[("384", shape)])
+        assert np.array_equal(out[("0", shape)], out[("1000000", shape)])
 
 
 def test_new_kernel_parameters_invalidate_everything(hb):

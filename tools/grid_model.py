@@ -1,0 +1,481 @@
+#!/usr/bin/env python
+"""Predicted multi-GPU scaling of the 2-D block-cyclic factorisation, from the scheduler's own trace.
+
+The box this repository is developed on has ONE GPU; the 8-GPU runs are the driver's.  This tool says what to expect
+from them and which grid shape / exchange to pick, without a hand-written formula:
+
+  1. tools/grid_model/libgridtrace.so runs the REAL scheduler (gpc_amd/csrc/grid_sched.hpp -- the code libgpc_hip.so runs)
+     for every rank of a pr x pc grid over a recording GridOps / GridComm: every kernel, copy, event record / wait and
+     exchange, in host issue order, with its stream and size;
+  2. this file replays those traces as a discrete-event simulation: two in-order streams per GPU with HIP event
+     semantics, kernels at the times MEASURED on one MI355X (tools/grid_costs.py -> profiles/r03_grid_costs.json: the
+     staircase update by size, the panel solve, the tile factorisation, copies), exchanges matched across ranks and
+     priced as latency + bytes / link bandwidth (parameters: xGMI is point to point, one link per pair of GPUs), panel-
+     stream kernels taking their share of the chip away from the trailing update that runs beside them.
+
+usage: python tools/grid_model.py [--costs profiles/r03_grid_costs.json] [--link-gbs 50,100] [--workload cfg3,cfg4]
+                                  [--shapes 1x1,1x2,2x1,2x2,4x1,2x4,4x2,8x1] [--nb 1024] [--json out.json]
+tests/test_grid_model.py pins the trace to gpc_grid_stats and the P = 1 replay to the measured single-GPU grid run.
+"""
+import argparse
+import bisect
+import collections
+import ctypes
+import heapq
+import json
+import math
+import os
+import subprocess
+import sys
+import tempfile
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+TRACE_LIB = os.path.join(HERE, "grid_model", "libgridtrace.so")
+
+WORKLOADS = {"cfg2": (8192, 8), "cfg3": (65536, 32), "cfg4": (131072, 16)}
+
+
+# ---- 1. the scheduler's trace ---------------------------------------------------------------------------------------------
+def trace_lib():
+    if not os.path.exists(TRACE_LIB) or os.path.getmtime(TRACE_LIB) < os.path.getmtime(
+            os.path.join(ROOT, "gpc_amd", "csrc", "grid_sched.hpp")):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(HERE, "grid_model")])
+    lib = ctypes.CDLL(TRACE_LIB)
+    lib.gridtrace_run.restype = ctypes.c_int
+    lib.gridtrace_run.argtypes = [ctypes.c_int, ctypes.c_int] + [ctypes.c_long] * 5 + [ctypes.c_int, ctypes.c_int, ctypes.c_char_p,
+                                                                                      ctypes.POINTER(ctypes.c_double)]
+    return lib
+
+
+def trace(pr, pc, nb, N, D, d=0, Ns=0, lookahead=1, what=1):
+    """-> (ops_by_rank, stats_by_rank): the ops of one step (after the problem set-up), per rank in host issue order"""
+    lib = trace_lib()
+    stats = (ctypes.c_double * (8 * pr * pc))()
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, "trace.jsonl")
+        rc = lib.gridtrace_run(pr, pc, nb, N, D, d, Ns, lookahead, what, path.encode(), stats)
+        if rc != 0:
+            raise RuntimeError("gridtrace_run failed: %d" % rc)
+        ops = [[] for _ in range(pr * pc)]
+        started = [False] * (pr * pc)
+        for line in open(path):
+            o = json.loads(line)
+            if o["op"] == "begin":
+                started[o["rank"]] = True
+            elif started[o["rank"]]:
+                ops[o["rank"]].append(o)
+    keys = ["bytes_row", "bytes_col", "bytes_world", "collectives", "update_flops", "update_launches", "update_bytes"]
+    st = [dict(zip(keys, stats[8 * r:8 * r + 7])) for r in range(pr * pc)]
+    return ops, st
+
+
+# ---- 2. measured kernel times ---------------------------------------------------------------------------------------------------
+class Costs(object):
+    """Interpolates the single-GPU measurements of tools/grid_costs.py."""
+
+    def __init__(self, path):
+        self.raw = json.load(open(path))
+        self.upd = {}
+        for nb in sorted(set(u["nb"] for u in self.raw["update"])):
+            pts = sorted((u["flops"], u["ms"]) for u in self.raw["update"] if u["nb"] == nb)
+            # several shapes share (nearly) the same flop count: keep the slower one per bucket (the model should not flatter)
+            xs, ys = [], []
+            for fl, ms in pts:
+                if xs and fl < xs[-1] * 1.02:
+                    ys[-1] = max(ys[-1], ms)
+                else:
+                    xs.append(fl)
+                    ys.append(ms)
+            for i in range(1, len(ys)):          # time never falls as the work grows
+                ys[i] = max(ys[i], ys[i - 1])
+            self.upd[nb] = (xs, ys)
+        self.trsm = {}
+        for nb in sorted(set(t["nb"] for t in self.raw["trsm_rlt"])):
+            pts = sorted((t["rows"], t["ms"]) for t in self.raw["trsm_rlt"] if t["nb"] == nb)
+            self.trsm[nb] = ([p[0] for p in pts], [p[1] for p in pts])
+        self.potrf = {p["nb"]: p["ms"] for p in self.raw["potrf_tile"]}
+        self.panel = {}
+        for nb in sorted(set(t["nb"] for t in self.raw.get("potrf_panel", []))):
+            pts = sorted((t["rows"], t["ms"]) for t in self.raw["potrf_panel"] if t["nb"] == nb)
+            self.panel[nb] = ([p[0] for p in pts], [p[1] for p in pts])
+        pts = sorted((c["bytes"], c["ms"]) for c in self.raw["copy"])
+        self.cp = ([p[0] for p in pts], [p[1] for p in pts])
+        g = self.raw["gram_cross"]
+        self.gram_gbs = min(8.0 * x["rows"] * x["cols"] / x["ms"] * 1e-6 for x in g)
+        self.launch = self.raw.get("small_launch_ms", 0.006)
+        self.host_issue = self.raw.get("host_issue_ms", 0.004)
+
+    @staticmethod
+    def _interp(xs, ys, x, loglog=True):
+        if x <= xs[0]:
+            return ys[0] * (max(x, 1e-30) / xs[0]) if not loglog else ys[0]     # below the table: the smallest launch's time
+        if x >= xs[-1]:
+            return ys[-1] * x / xs[-1]                                          # above: proportional
+        i = bisect.bisect_right(xs, x)
+        x0, x1, y0, y1 = xs[i - 1], xs[i], ys[i - 1], ys[i]
+        if loglog:
+            t = (math.log(x) - math.log(x0)) / (math.log(x1) - math.log(x0))
+            return math.exp(math.log(y0) + t * (math.log(y1) - math.log(y0)))
+        return y0 + (y1 - y0) * (x - x0) / (x1 - x0)
+
+    def _nb(self, table, nb):
+        return nb if nb in table else min(table, key=lambda k: abs(k - nb))
+
+    def update_ms(self, nb, flops):
+        k = self._nb(self.upd, nb)
+        xs, ys = self.upd[k]
+        return self._interp(xs, ys, flops * (k / float(nb)) if k != nb else flops)
+
+    def trsm_ms(self, nb, rows):
+        xs, ys = self.trsm[self._nb(self.trsm, nb)]
+        return self._interp(xs, ys, rows)
+
+    def potrf_ms(self, nb):
+        k = self._nb(self.potrf, nb)
+        return self.potrf[k] * (nb / float(k)) ** 2
+
+    def panel_ms(self, nb, rows):
+        if not self.panel:
+            return self.potrf_ms(nb) + (self.trsm_ms(nb, rows - nb) if rows > nb else 0.0)
+        xs, ys = self.panel[self._nb(self.panel, nb)]
+        return self._interp(xs, ys, rows)
+
+    def copy_ms(self, nbytes):
+        return max(self.launch, self._interp(self.cp[0], self.cp[1], nbytes))
+
+    def gram_ms(self, rows, cols):
+        return self.launch + 8.0 * rows * cols / (self.gram_gbs * 1e6)
+
+
+# ---- 3. the replay ----------------------------------------------------------------------------------------------------------
+class Params(object):
+    def __init__(self, link_gbs=50.0, alpha_us=25.0, exchange="fanout", preempt_us=50.0, rccl_chip_share=0.06,
+                 host_sync_us=15.0):
+        self.link_gbs = link_gbs          # one direction of one xGMI link, as RCCL delivers it
+        self.alpha_us = alpha_us          # start-up of one exchange (launch of the RCCL kernel + the handshake)
+        self.exchange = exchange          # "fanout": direct send / recv between every pair; "ring": ring broadcast per root
+        self.preempt_us = preempt_us      # a panel-stream kernel beside a running update waits for workgroups to retire
+        self.rccl_chip_share = rccl_chip_share
+        self.host_sync_us = host_sync_us
+
+
+# share of the chip a panel-stream kernel takes from the trailing update that runs beside it
+CHIP_SHARE = {"trsm_rlt": 1.0, "potrf_tile": 0.5, "potrf_panel": 1.0, "copy": 0.3, "zero": 0.3, "gram": 1.0, "small": 0.05,
+              "gemm": 0.5, "trsm_l": 0.5, "kern_grad": 1.0, "update": 1.0}
+
+
+def op_ms(o, costs, nb):
+    k = o["op"]
+    if k == "update":
+        return costs.update_ms(o["k"], o["flops"])
+    if k == "trsm_rlt":
+        return costs.trsm_ms(o["n"], o["rows"])
+    if k == "potrf_tile":
+        return costs.potrf_ms(o["n"])
+    if k == "potrf_panel":
+        return costs.panel_ms(o["n"], o["rows"])
+    if k in ("copy", "zero"):
+        return costs.copy_ms(o["bytes"]) * (0.5 if k == "zero" else 1.0)
+    if k == "gram":
+        return costs.gram_ms(o["rows"], o["cols"])
+    if k == "small":
+        return costs.launch + o.get("bytes", 0) / 2.0e9
+    if k == "gemm":
+        return costs.launch + o["flops"] / 30e9          # small products of the back substitution
+    if k == "trsm_l":
+        return costs.launch * (o["n"] / 64.0)
+    if k == "kern_grad":
+        return costs.launch + 4.0 * o["rows"] * o["cols"] / 2.0e9
+    return 0.0
+
+
+COLLECTIVES = ("bcast", "allgatherv", "allreduce", "allreduce_host")
+HOST_BLOCKING = ("download", "sync", "allreduce_host")
+
+
+def simulate(ops, costs, par, nb):
+    """-> dict(ms=makespan, per_rank=[...]).  ops: per rank, host issue order."""
+    P = len(ops)
+    NS = 2
+    # stream queues and, for every wait, the record it refers to (the last record of that event issued before it)
+    queue = [[[] for _ in range(NS)] for _ in range(P)]
+    for r in range(P):
+        last_rec = {}
+        for i, o in enumerate(ops[r]):
+            o["_i"] = i
+            if o["st"] < 0:
+                continue
+            if o["op"] == "record":
+                last_rec[o["ev"]] = i
+            elif o["op"] == "wait":
+                o["_rec"] = last_rec.get(o["ev"])
+            queue[r][o["st"]].append(i)
+    head = [[0] * NS for _ in range(P)]
+    busy = [[None] * NS for _ in range(P)]            # op index running on the stream
+    done_t = [dict() for _ in range(P)]               # op index -> completion time
+    issued = [0] * P                                  # ops issued by the host so far
+    host_block = [None] * P                           # op index the host waits for
+    now = [0.0]
+    heap = []
+    seq = [0]
+    # main-stream compute under contention: remaining work (ms at full chip), rate, last update
+    mainop = [None] * P                               # dict(i, rem, rate, t, ver)
+    prio_share = [0.0] * P
+    arrivals = collections.defaultdict(dict)          # collective key -> member -> (rank, st, i, t)
+    stats = {"main_busy": [0.0] * P, "coll_ms": [0.0] * P, "coll_wait_ms": [0.0] * P}
+
+    def push(t, kind, *payload):
+        seq[0] += 1
+        heapq.heappush(heap, (t, seq[0], kind, payload))
+
+    def rate_of(r):
+        return max(0.03, 1.0 - prio_share[r])
+
+    def retime_main(r):
+        m = mainop[r]
+        if m is None:
+            return
+        t = now[0]
+        m["rem"] -= (t - m["t"]) * m["rate"]
+        m["t"] = t
+        m["rate"] = rate_of(r)
+        m["ver"] += 1
+        push(t + max(m["rem"], 0.0) / m["rate"], "main_done", r, m["i"], m["ver"])
+
+    def finish(r, st, i):
+        done_t[r][i] = now[0]
+        ops[r][i]["_t1"] = now[0]
+        busy[r][st] = None
+        head[r][st] += 1
+        if host_block[r] == i:
+            host_block[r] = None
+            push(now[0] + par.host_sync_us * 1e-3, "issue", r)
+
+    def group_members(o):
+        return len(o["pieces"]) if o["op"] == "allgatherv" else o["_n"]
+
+    def try_collective(key):
+        arr = arrivals[key]
+        any_op = ops[next(iter(arr.values()))[0]][next(iter(arr.values()))[2]]
+        n = any_op["_n"]
+        kind = any_op["op"]
+        a_ms = par.alpha_us * 1e-3
+        bw = par.link_gbs * 1e6       # bytes per ms
+
+        def sched(member, t_fin):
+            r, st, i, t_arr = arr[member]
+            if "_sched" in ops[r][i]:
+                return
+            ops[r][i]["_sched"] = True
+            stats["coll_ms"][r] += t_fin - t_arr
+            push(t_fin, "coll_done", r, st, i)
+
+        if kind == "bcast" and par.exchange == "fanout":
+            root = any_op["root"]
+            if root not in arr:
+                return
+            t_root = arr[root][3]
+            nbytes = any_op["bytes"]
+            for m in list(arr):
+                if m != root:
+                    sched(m, max(t_root, arr[m][3]) + a_ms + nbytes / bw)
+            if len(arr) == n:
+                sched(root, max(v[3] for v in arr.values()) + a_ms + nbytes / bw)
+            return
+        if kind == "allgatherv" and par.exchange == "fanout":
+            pieces = any_op["pieces"]
+            for m in list(arr):
+                partners = [q for q in range(n) if q != m and (pieces[q] > 0 or pieces[m] > 0)]
+                if all(q in arr for q in partners):
+                    t_fin = arr[m][3] + (a_ms if partners else 0.0)
+                    for q in partners:
+                        t_fin = max(t_fin, max(arr[m][3], arr[q][3]) + a_ms + max(pieces[q], pieces[m]) / bw)
+                    sched(m, t_fin)
+            return
+        if len(arr) < n:
+            return
+        t0 = max(v[3] for v in arr.values())
+        if kind == "bcast":                      # ring: every byte crosses n - 1 links one after the other, pipelined
+            t_fin = t0 + a_ms * (n - 1) + any_op["bytes"] / bw
+        elif kind == "allgatherv":               # one ring broadcast per non-empty piece, one after the other
+            t_fin = t0 + sum(a_ms * (n - 1) + p / bw for p in any_op["pieces"] if p > 0)
+        else:                                    # small all-reduces
+            t_fin = t0 + 2 * a_ms + any_op.get("bytes", 8) / bw
+        for m in arr:
+            sched(m, t_fin)
+
+    def startable(r, st):
+        q = queue[r][st]
+        if busy[r][st] is not None or head[r][st] >= len(q):
+            return None
+        i = q[head[r][st]]
+        return i if i < issued[r] else None
+
+    def try_start(r, st):
+        progressed = False
+        while True:
+            i = startable(r, st)
+            if i is None:
+                return progressed
+            o = ops[r][i]
+            k = o["op"]
+            if k == "record":
+                finish(r, st, i)
+                progressed = True
+                continue
+            if k == "wait":
+                rec = o.get("_rec")
+                if rec is None or rec in done_t[r]:
+                    finish(r, st, i)
+                    progressed = True
+                    continue
+                return progressed
+            if k in ("download", "sync"):
+                finish(r, st, i)          # everything before it on the stream is done: the host may go on
+                progressed = True
+                continue
+            busy[r][st] = i
+            progressed = True
+            o["_t0"] = now[0]
+            if k in COLLECTIVES:
+                key = (k, o["axis"], o["group"], o["seq"])
+                arrivals[key][o["me"]] = (r, st, i, now[0])
+                prio_share[r] += par.rccl_chip_share
+                retime_main(r)
+                try_collective(key)
+                return progressed
+            ms = op_ms(o, costs, nb)
+            if st == 0 and k in ("update", "gram"):
+                mainop[r] = {"i": i, "rem": ms, "rate": rate_of(r), "t": now[0], "ver": 0}
+                push(now[0] + ms / mainop[r]["rate"], "main_done", r, i, 0)
+            else:
+                share = CHIP_SHARE.get(k, 0.2) if st != 0 else 0.0
+                delay = par.preempt_us * 1e-3 if (st != 0 and mainop[r] is not None and share >= 0.3) else 0.0
+                o["_share"] = share
+                prio_share[r] += share
+                retime_main(r)
+                push(now[0] + delay + ms, "op_done", r, st, i)
+            return progressed
+
+    for r in range(P):
+        gs = {}
+        for o in ops[r]:
+            if o["op"] in COLLECTIVES:
+                o["_n"] = len(o["pieces"]) if o["op"] == "allgatherv" else None
+        push(0.0, "issue", r)
+    # group sizes for bcast / allreduce: count the distinct members that ever appear under the key's (axis, group)
+    members = collections.defaultdict(set)
+    for r in range(P):
+        for o in ops[r]:
+            if o["op"] in COLLECTIVES:
+                members[(o["axis"], o["group"])].add(o["me"])
+    for r in range(P):
+        for o in ops[r]:
+            if o["op"] in COLLECTIVES and o["_n"] is None:
+                o["_n"] = len(members[(o["axis"], o["group"])])
+
+    while heap:
+        t, _, kind, pl = heapq.heappop(heap)
+        now[0] = t
+        if kind == "issue":
+            r = pl[0]
+            if host_block[r] is not None or issued[r] >= len(ops[r]):
+                continue
+            o = ops[r][issued[r]]
+            issued[r] += 1
+            if o["st"] >= 0 and o["op"] in HOST_BLOCKING:
+                host_block[r] = o["_i"]
+            else:
+                push(t + costs.host_issue, "issue", r)
+        elif kind == "main_done":
+            r, i, ver = pl
+            m = mainop[r]
+            if m is None or m["i"] != i or m["ver"] != ver:
+                continue
+            stats["main_busy"][r] += 0.0
+            mainop[r] = None
+            finish(r, 0, i)
+        elif kind == "op_done":
+            r, st, i = pl
+            prio_share[r] -= ops[r][i].get("_share", 0.0)
+            retime_main(r)
+            finish(r, st, i)
+        elif kind == "coll_done":
+            r, st, i = pl
+            prio_share[r] -= par.rccl_chip_share
+            retime_main(r)
+            finish(r, st, i)
+        again = True
+        while again:
+            again = False
+            for r in range(P):
+                for st in range(NS):
+                    if try_start(r, st):
+                        again = True
+    left = [(r, st, queue[r][st][head[r][st]]) for r in range(P) for st in range(NS) if head[r][st] < len(queue[r][st])]
+    if left:
+        r, st, i = left[0]
+        raise RuntimeError("replay stalled: rank %d stream %d at op %r (%d streams unfinished)" % (r, st, ops[r][i], len(left)))
+    end = [max(done_t[r].values()) if done_t[r] else 0.0 for r in range(P)]
+    upd = [sum(op_ms(o, costs, nb) for o in ops[r] if o["op"] == "update") for r in range(P)]
+    # where the time of each stream went: kernels / exchanges by kind (an exchange counts from the moment this rank entered it)
+    where = []
+    for r in range(P):
+        w = collections.defaultdict(float)
+        for o in ops[r]:
+            if "_t0" in o and "_t1" in o:
+                w["%d:%s" % (o["st"], o["op"])] += o["_t1"] - o["_t0"]
+        where.append(dict(w))
+    return {"ms": max(end), "per_rank_end_ms": end, "update_ms": upd, "exchange_ms": stats["coll_ms"], "where": where}
+
+
+def predict(costs, workload, pr, pc, nb, par, lookahead=1):
+    N, D = WORKLOADS[workload] if isinstance(workload, str) else workload
+    ops, st = trace(pr, pc, nb, N, D, lookahead=lookahead)
+    out = simulate(ops, costs, par, nb)
+    out["stats"] = st
+    out["N"], out["D"], out["pr"], out["pc"], out["nb"] = N, D, pr, pc, nb
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--costs", default=os.path.join(ROOT, "profiles", "r03_grid_costs.json"))
+    ap.add_argument("--link-gbs", default="50,100")
+    ap.add_argument("--alpha-us", type=float, default=25.0)
+    ap.add_argument("--workload", default="cfg3,cfg4")
+    ap.add_argument("--shapes", default="1x1,1x2,2x1,2x2,4x1,1x4,2x4,4x2,8x1,1x8")
+    ap.add_argument("--nb", default="1024")
+    ap.add_argument("--exchange", default="fanout,ring")
+    ap.add_argument("--json", default=None)
+    a = ap.parse_args()
+    costs = Costs(a.costs)
+    rows = []
+    for wl in a.workload.split(","):
+        N, D = WORKLOADS[wl]
+        base = {}
+        for nb in [int(x) for x in a.nb.split(",")]:
+            one = predict(costs, wl, 1, 1, nb, Params())
+            base[nb] = one["ms"]
+            print("%s N=%d nb=%d: 1x1 through the grid path: %.1f ms (%.1f TFLOP/s)" % (wl, N, nb, one["ms"], N ** 3 / 3.0 / one["ms"] * 1e-9))
+            for ex in a.exchange.split(","):
+                for bw in [float(x) for x in a.link_gbs.split(",")]:
+                    for shape in a.shapes.split(","):
+                        pr, pc = [int(x) for x in shape.split("x")]
+                        if pr * pc == 1:
+                            continue
+                        par = Params(link_gbs=bw, alpha_us=a.alpha_us, exchange=ex)
+                        o = predict(costs, wl, pr, pc, nb, par)
+                        row = {"workload": wl, "N": N, "nb": nb, "shape": shape, "ranks": pr * pc, "exchange": ex, "link_gbs": bw,
+                               "ms": o["ms"], "speedup_vs_1x1": base[nb] / o["ms"], "max_update_ms": max(o["update_ms"]),
+                               "max_exchange_ms": max(o["exchange_ms"])}
+                        rows.append(row)
+                        print("  %-4s %-7s %5.0f GB/s  %-4s %9.1f ms  x%.2f   (updates %.1f ms, in exchanges %.1f ms)" % (
+                            wl, ex, bw, shape, o["ms"], row["speedup_vs_1x1"], row["max_update_ms"], row["max_exchange_ms"]), flush=True)
+    if a.json:
+        json.dump(rows, open(a.json, "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()
