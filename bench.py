@@ -321,24 +321,23 @@ def main():
     if gridded:
         from gpc_amd import grid
         shape = os.environ.get("GPC_GRID", "")
-        pr, pc = (int(v) for v in shape.lower().split("x")) if shape else grid.default_shape(world)
-        if pr * pc != world:
-            sys.exit("bench.py: GPC_GRID=%s does not have %d ranks" % (shape, world))
         nb = int(os.environ.get("GPC_GRID_NB", "1024" if N >= 49152 else "512"))
-        if rehearsal and world > 1:
-            g = grid.create_transport(rank, pr, pc, nb, grid.torch_transport(rank, pr, pc))
-        else:
+
+        def make_grid(pr, pc):
+            if rehearsal and world > 1:
+                return grid.create_transport(rank, pr, pc, nb, grid.torch_transport(rank, pr, pc))
             uid = [grid.unique_id() if (rank == 0 and world > 1) else None]
             if world > 1:
                 dist.broadcast_object_list(uid, src=0)
-            g = grid.create(rank, world, pr, pc, nb, uid[0])
-        if world > 1 and os.environ.get("GPC_BENCH_SELFCHECK", "1") == "1":
+            return grid.create(rank, world, pr, pc, nb, uid[0])
+
+        def selfcheck(gr, pr, pc):
             # untimed: the grid must reproduce the single-GPU log-determinant of a small problem on every rank
             Xc, _ = synth.make_xy(8192, D, seed=99)
             _, ref_ld, _, info0 = api.gp_update_k(api.kspec(cfg["kern"]), api.from_host(Xc))
             torch.cuda.synchronize()
-            g.set_problem(cfg["kern"], Xc, None, None)
-            ld, _, info1 = g.update_k()
+            gr.set_problem(cfg["kern"], Xc, None, None)
+            ld, _, info1 = gr.update_k()
             ok = info0 == 0 and info1 == 0 and abs(ld - ref_ld) <= 1e-8 * abs(ref_ld)
             flag = torch.tensor([1.0 if ok else 0.0], dtype=torch.float64)
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
@@ -347,6 +346,49 @@ def main():
                                  % (rank, ld, info1, ref_ld, info0))
                 fail("the %d x %d grid does not reproduce the single-GPU factorisation of the N = 8192 check problem"
                      % (pr, pc), dist_selfcheck_failed=True)
+
+        if shape:
+            candidates = [tuple(int(v) for v in shape.lower().split("x"))]
+        else:
+            candidates = [grid.default_shape(world)]
+            # untimed calibration (GPC_BENCH_CALIBRATE=0 skips it): the model behind default_shape() was fed one GPU's kernel
+            # times and an ASSUMED link bandwidth; on the node itself the two candidate layouts are simply tried on a
+            # quarter-size problem and the faster one runs the timed steps.  Both are reported.
+            if world >= 4 and os.environ.get("GPC_BENCH_CALIBRATE", "1") == "1" and grid.square_shape(world) != candidates[0]:
+                candidates.append(grid.square_shape(world))
+        for pr, pc in candidates:
+            if pr * pc != world:
+                sys.exit("bench.py: a %d x %d grid does not have %d ranks" % (pr, pc, world))
+        calibration = []
+        best = None
+        for pr, pc in candidates:
+            gr = make_grid(pr, pc)
+            if world > 1 and os.environ.get("GPC_BENCH_SELFCHECK", "1") == "1":
+                selfcheck(gr, pr, pc)
+            t_cal = None
+            if len(candidates) > 1:
+                ncal = int(os.environ.get("GPC_BENCH_CALIBRATE_N", str(max(4096, N // 2))))
+                Xc, _ = synth.make_xy(ncal, D, seed=7)
+                gr.set_problem(cfg["kern"], Xc, None, None)
+                ts = []
+                for it in range(3):
+                    gr.sync()
+                    dist.barrier()
+                    t0 = time.perf_counter()
+                    gr.update_k()
+                    gr.sync()
+                    tt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+                    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                    ts.append(float(tt.item()))
+                t_cal = min(ts[1:])
+                calibration.append({"grid": "%dx%d" % (pr, pc), "N": ncal, "ms": t_cal * 1e3})
+            if best is None or (t_cal is not None and t_cal < best[0]):
+                if best is not None:
+                    best[1].destroy()
+                best = (t_cal, gr, pr, pc)
+            else:
+                gr.destroy()
+        _, g, pr, pc = best
         g.set_problem(cfg["kern"], X, None, None)
         g.stats(reset=True)
 
@@ -505,7 +547,10 @@ def main():
             out["grid"] = {"rank0_bytes_received_per_step": {"along_row": gstats["bytes_row"] / args.steps,
                                                              "along_column": gstats["bytes_col"] / args.steps},
                            "rank0_collectives_per_step": gstats["collectives"] / args.steps,
-                           "rank0_update_tflops": achieved}
+                           "rank0_update_tflops": achieved, "shape": "%dx%d" % (pr, pc), "tile": nb,
+                           "rows_reflected": bool(g.info().get("refl", 0)),
+                           "exchange": os.environ.get("GPC_GRID_EXCHANGE", "fanout"),
+                           "calibration": calibration or None}
         if phases is not None:
             phases["gram_ms"] = gram_ms / max(1, gram_n)
             phases["potrf_logdet_ms"] = dt / args.steps * 1e3 - phases["gram_ms"]

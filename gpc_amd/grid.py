@@ -56,8 +56,17 @@ def product_binding():
 
 
 def default_shape(nranks):
-    """pr x pc for a node's GPU count (1x1, 1x2, 2x2, 2x4); pr <= pc keeps the row panels --
-    the larger of the two exchanged pieces -- spread over more senders."""
+    """pr x pc for a node's GPU count: tall, nranks x 1.  The GPUs of a node are connected pair by pair (xGMI, one link per
+    pair), so what an exchange costs is set by the busiest LINK.  With one process column every panel exchange is an
+    all-gather in which each rank sends its 1/P of the panel to the P-1 others over P-1 different links; a wide grid has the
+    pr ranks of the owning process column feed everybody else (cfg 3 on 8 GPUs, replay of the scheduler's trace at
+    50 GB/s per link, tools/grid_model.py: 8x1 235 ms, 4x2 288 ms, 2x4 389 ms).  The rounds of tile rows alternate direction
+    on such a grid, which balances the ranks' trailing updates (csrc/grid_sched.hpp, Layout::refl)."""
+    return nranks, 1
+
+
+def square_shape(nranks):
+    """the most nearly square pr x pc with pr <= pc (1x2, 2x2, 2x4): the alternative bench.py's calibration times"""
     pr = 1
     while (pr * 2) * (pr * 2) <= nranks and nranks % (pr * 2) == 0:
         pr *= 2

@@ -35,7 +35,7 @@ CGp::CGp(CKern* kernel, CNoise* nois, CMatrix* Xin, int approx, unsigned int act
       dCovGrad(0), logDetK(0.0), lastJitter(0.0), needInverse(false), approxType(approx), betaVal(1e3),
       inducingFixed(false), dXu(0), dKuu(0), dKuf(0), dInvKuu(0), dA(0), dAinv(0), dLA(0), dE(0), dAlphaU(0), dIKK(0),
       logDetKuu(0.0), logDetA(0.0), sumDiagD(0.0), LArounded(false), dVf(0), dBet(0), sumLogDiagD(0.0), sumLogLm(0.0), sMsM(0.0),
-      gridPr(1), gridPc(1), gridDecided(0), gridNs(-1)
+      gridPr(1), gridPc(1), gridDecided(0), gridNs(-1), gridProblemStale(true)
 {
   if(Xin->getRows() != nois->getNumData())
     throw ndlexceptions::MatrixError("CGp: X and the targets disagree on the number of data");   // CGp.cpp:60
@@ -60,7 +60,7 @@ CGp::CGp()
       invKupToDate(false), invKmUpToDate(false), LcholRounded(false), dX(0), dM(0), dL(0), dInvKm(0), dAlpha(0), dInvK(0), dCovGrad(0), logDetK(0.0), lastJitter(0.0),
       needInverse(false), approxType(FTC), betaVal(1e3), inducingFixed(false), dXu(0), dKuu(0), dKuf(0), dInvKuu(0), dA(0),
       dAinv(0), dLA(0), dE(0), dAlphaU(0), dIKK(0), logDetKuu(0.0), logDetA(0.0), sumDiagD(0.0), LArounded(false), dVf(0), dBet(0), sumLogDiagD(0.0),
-      sumLogLm(0.0), sMsM(0.0), gridPr(1), gridPc(1), gridDecided(0), gridNs(-1)
+      sumLogLm(0.0), sMsM(0.0), gridPr(1), gridPc(1), gridDecided(0), gridNs(-1), gridProblemStale(true)
 {
   const char* e = std::getenv("GPC_EXACT_TRANS");
   if(e && e[0] == '1') refTransRounding = false;
@@ -84,7 +84,11 @@ void CGp::setData(CMatrix* Xin, CMatrix* yin)
   devFree(dIKK);
   devFree(dVf);
   MupToDate = KupToDate = AlphaUpToDate = invKupToDate = false;
+  // another N may need another decision (one GPU or the grid) and another tile size
+  gridRelease();
+  gridDecided = 0;
   gridNs = -1;
+  gridProblemStale = true;
 }
 CGp::~CGp()
 {
@@ -124,6 +128,7 @@ void CGp::updateM() const
   if(!dM) dM = devAlloc((size_t)N * d);
   gpcCheck(gpc_memcpy_h2d(dM, m.getVals(), sizeof(double) * (size_t)N * d, 0));
   MupToDate = true;
+  gridProblemStale = true;   // the ranks of a grid hold the old targets
   KupToDate = false;   // quad / invKm depend on m
   AlphaUpToDate = false;
 }
@@ -172,10 +177,18 @@ bool CGp::useGrid() const
     if(gpc_device_info(0, 0, 0, &hbm, 0) != GPC_OK || ndev < 2) return false;
     const double need = 8.0 * (double)getNumData() * (double)getNumData();
     if(need <= 0.85 * (double)hbm) return false;
-    pr = 1;
-    pc = 2;
-    if(ndev >= 4) pr = 2;
-    if(ndev >= 8) pc = 4;
+    // tall grids (P x 1): the GPUs of a node are connected pair by pair (xGMI), and with one process column every panel
+    // exchange is an all-gather in which each of the P ranks sends its 1/P of the panel over P-1 different links, where a
+    // wide grid has the few ranks of the owning process column feed everybody else (replay of the
+    // scheduler's trace, cfg 3 on 8 GPUs at 50 GB/s per link: 8x1 235 ms, 4x2 288 ms, 2x4 389 ms)
+    pr = ndev >= 8 ? 8 : (ndev >= 4 ? 4 : 2);
+    pc = 1;
+    if(getVerbosity() > 0) {
+      const double replica = 8.0 * (double)getNumData() * (double)getNumData() + need / (double)(pr * pc);
+      if(replica > 0.9 * (double)hbm)
+        std::cout << "CGp: K does not fit one GPU: likelihood and predictions run on the grid; the gradient would need the "
+                     "whole factor beside each rank's block (" << replica * 1e-9 << " GB) and will report GPC_ENOMEM." << std::endl;
+    }
   }
   const char* same = std::getenv("GPC_GRID_DEVICES");   // "same": every rank on the current device (tests on a 1-GPU box)
   const bool one_device = same && std::string(same) == "same";
@@ -211,7 +224,9 @@ void CGp::gridUpdateK(const CMatrix* Xstar) const
   const int64_t Ns = Xstar ? (int64_t)Xstar->getRows() : 0;
   gpc_kspec ks;
   pkern->toKspec(ks);
-  const bool fresh = gridNs != (long)Ns || Ns > 0;     // new data / new test inputs: restage; else only the kernel changed
+  // new data, new targets (setScale / setBias / setData went through updateM) or new test inputs: restage; else only the
+  // kernel changed
+  const bool fresh = gridNs != (long)Ns || Ns > 0 || gridProblemStale;
   std::vector<double> ld(grids.size(), 0.0), jit(grids.size(), 0.0);
   std::vector<int> info(grids.size(), 0);
   quad.assign((size_t)d, 0.0);
@@ -248,6 +263,7 @@ void CGp::gridUpdateK(const CMatrix* Xstar) const
     return rc;
   });
   gridNs = (long)Ns;
+  gridProblemStale = false;
   logDetK = ld[0];
   lastJitter = jit[0];
   if(info[0] != 0) throw ndlexceptions::MatrixNonPosDef();

@@ -158,6 +158,7 @@ class CGp : public CProbabilisticOptimisable {
   mutable std::vector<gpc_grid*> grids;
   mutable int gridPr, gridPc, gridDecided;
   mutable long gridNs;                   // test inputs carried by the grid's current problem (-1: no problem set)
+  mutable bool gridProblemStale;         // the data or the targets changed since the ranks were given the problem
   mutable std::vector<double> gridAlpha, gridMu, gridVar;
 };
 

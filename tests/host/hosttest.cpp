@@ -221,6 +221,16 @@ static int testGpGrid(int argc, char** argv)
   CMatrix g(1, model.getOptNumParams());
   std::printf("ll_with_grad %.17g\n", model.logLikelihoodGradient(g));
   printMat("grads", g);
+  {   // new targets (setBias -> updateM) must reach the ranks of a grid: only the kernel travels between evaluations otherwise
+    CMatrix bias2(1, y.getCols(), 0.0);
+    for(unsigned int j = 0; j < y.getCols(); j++) bias2.setVal(bias.getVal(j) + 0.25, j);
+    model.setBias(bias2);
+    model.updateM();
+    std::printf("ll_new_bias %.17g\n", model.logLikelihood());
+    model.setBias(bias);
+    model.updateM();
+    std::printf("ll_old_bias_again %.17g\n", model.logLikelihood());
+  }
   if(argc > 6) {   // a few SCG iterations on the grid: `gp learn` beyond one GPU
     model.setVerbosity(0);
     model.optimise((unsigned int)std::atoi(argv[6]));

@@ -62,7 +62,7 @@ def _check(res, exp, N, nb, Xs, tol=TOL):
         assert np.array_equal(r["alpha"], res[0]["alpha"])
 
 
-@pytest.mark.parametrize("pr,pc", [(1, 1), (1, 2), (2, 1), (2, 2), (2, 4), (4, 2), (1, 8), (3, 2)])
+@pytest.mark.parametrize("pr,pc", [(1, 1), (1, 2), (2, 1), (2, 2), (2, 4), (4, 2), (1, 8), (3, 2), (4, 1), (8, 1), (3, 1)])
 def test_grid_shapes_against_numpy(pr, pc):
     N, D, d, Ns, nb = 1500, 3, 2, 5, 128     # T = 12 tiles, ragged last tile, odd extra-row count
     X, Y, Xs = gc.make_problem(N, D, d, Ns, 7)
@@ -100,6 +100,25 @@ def test_factor_without_right_hand_sides(pr, pc, N, nb):
     assert all(r[1] == 0 for r in res)
     assert abs(res[0][0] - 2.0 * np.log(np.diag(L)).sum()) < 1e-9 * abs(res[0][0])
     assert gc.rel(grid.assemble_factor([r[2] for r in res], N, nb), L) < TOL
+
+
+@pytest.mark.parametrize("pr,pc,N,nb,limit", [(8, 1, 4096, 256, None), (8, 1, 4100, 256, "0"), (4, 1, 3000, 128, "768"),
+                                              (2, 4, 4096, 256, "100000"), (2, 4, 4096, 256, "0"), (4, 2, 5000, 512, None),
+                                              (8, 1, 8192, 512, None)])
+def test_reflected_rounds_and_fused_panel_steps(pr, pc, N, nb, limit, monkeypatch):
+    """The tall grids the model prefers (pr x 1: reflected rounds of tile rows) and the two forms of a panel step --
+    [tile; rows] factored in one call by every rank of the owning column (the unfactored tile travels), or tile
+    factorisation + broadcast + triangular solve (GPC_GRID_FUSED_ROWS = 0, or panels taller than the limit) -- on the HIP
+    kernels under thread ranks, several steps deep so that a missing stream dependency would show."""
+    if limit is not None:
+        monkeypatch.setenv("GPC_GRID_FUSED_ROWS", limit)
+    X, Y, Xs = gc.make_problem(N, 4, 1, 3, N + pr)
+    exp = gc.expected(gc.TERMS, X, Y, Xs)
+    res = _solve(pr, pc, nb, gc.TERMS, X, Y, Xs)
+    _check(res, exp, N, nb, Xs)
+    again = _solve(pr, pc, nb, gc.TERMS, X, Y, Xs)
+    for ra, rb in zip(res, again):       # and the same bits when repeated
+        assert ra["logdet"] == rb["logdet"] and np.array_equal(ra["alpha"], rb["alpha"])
 
 
 def test_lookahead_off_gives_the_same_bits():
@@ -175,7 +194,9 @@ def test_cfg4_kernel_against_the_reference_golden(golden, pr, pc, nb):
     (2, 2, 3, [("rbf", [1.3, 0.9]), ("lin", [0.15]), ("bias", [0.2]), ("white", [0.05])]),
     (2, 4, 16, [("rbf", [0.3, 0.9]), ("white", [0.05])]),
     (2, 2, 32, [("rbf", [0.1, 1.1]), ("white", [0.1])]),                      # the D > 16 instance of the cross pass
-    (1, 2, 4, [("rbfard", [1.1, 0.8, 0.7, 0.4, 0.55, 0.3]), ("white", [0.05])])])
+    (1, 2, 4, [("rbfard", [1.1, 0.8, 0.7, 0.4, 0.55, 0.3]), ("white", [0.05])]),
+    (8, 1, 3, [("rbf", [1.3, 0.9]), ("bias", [0.2]), ("white", [0.05])]),      # reflected rounds
+    (4, 1, 8, [("rbf", [0.6, 0.9]), ("white", [0.05])])])
 def test_gradient_against_numpy_and_the_single_gpu_model(pr, pc, D, terms):
     from gpc_amd import grid
     from gpc_amd.gp import CGp
@@ -271,11 +292,49 @@ def test_bench_multi_rank_control_flow_rehearsal():
     assert r.returncode == 0, r.stderr.decode()[-2000:]
     line = json.loads(r.stdout.decode().strip().splitlines()[-1])
     assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["value"] > 0
-    assert "REHEARSAL" in line["config"]["parallelism"] and "1 x 2" in line["config"]["parallelism"]
+    assert "REHEARSAL" in line["config"]["parallelism"] and "2 x 1" in line["config"]["parallelism"]
     assert line["roofline"]["achieved"] > 0 and line["grid"]["rank0_collectives_per_step"] > 0
+    assert line["grid"]["shape"] == "2x1" and line["grid"]["rows_reflected"] is True
+    # four ranks: the two candidate layouts (4 x 1 and 2 x 2) are both checked and timed before the timed steps
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--workload", "cfg2", "--steps", "1",
+                        "--warmup", "1", "--no-cpu-baseline"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    line = json.loads(r.stdout.decode().strip().splitlines()[-1])
+    cal = line["grid"]["calibration"]
+    assert [c["grid"] for c in cal] == ["4x1", "2x2"] and all(c["ms"] > 0 for c in cal)
+    assert line["grid"]["shape"] == min(cal, key=lambda c: c["ms"])["grid"]
     # without the rehearsal switch the second rank has no GPU of its own: the run must refuse, not degrade
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "cfg2", "--steps", "1",
                         "--warmup", "0", "--no-cpu-baseline"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
     import torch
     if torch.cuda.device_count() < 2:
         assert r.returncode != 0 and b"refusing to share devices" in r.stderr
+
+
+def test_bench_two_ranks_over_real_rccl():
+    """`bench.py --gpus 2 --workload cfg2` with one process per GPU over RCCL (xGMI): the first multi-GPU box that runs this
+    suite executes RcclComm with more than one rank -- communicator split, the grouped send / recv exchanges, the start-up
+    self-check against the single-GPU log|K|.  Needs two GPUs; the authoring box has one."""
+    import json
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs >= 2 GPUs: RCCL refuses two ranks on one device (box has %d)" % torch.cuda.device_count())
+    for exchange in ("fanout", "collective"):
+        env = dict(os.environ, GPC_GRID_EXCHANGE=exchange)
+        env.pop("GPC_BENCH_TRANSPORT", None)
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "cfg2", "--steps", "3",
+                            "--warmup", "1", "--no-cpu-baseline"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                           timeout=900)
+        assert r.returncode == 0, r.stderr.decode()[-3000:]
+        line = json.loads(r.stdout.decode().strip().splitlines()[-1])
+        assert line["n_gpus"] == 2 and line["value"] > 0 and "REHEARSAL" not in line["config"]["parallelism"]
+        assert line["grid"]["shape"] == "2x1" and line["grid"]["exchange"] == exchange
+        assert line["grid"]["rank0_bytes_received_per_step"]["along_column"] > 0
+    n = torch.cuda.device_count()
+    if n >= 4:      # and the widest power of two the box has, with both layouts calibrated
+        w = 8 if n >= 8 else 4
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(w), "--workload", "cfg2", "--steps", "3",
+                            "--warmup", "1", "--no-cpu-baseline"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1200)
+        assert r.returncode == 0, r.stderr.decode()[-3000:]
+        line = json.loads(r.stdout.decode().strip().splitlines()[-1])
+        assert line["n_gpus"] == w and line["value"] > 0 and len(line["grid"]["calibration"]) == 2

@@ -75,7 +75,7 @@ def _write_txt(path, A):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("shape", ["1x2", "2x2", "2x4"])
+@pytest.mark.parametrize("shape", ["1x2", "2x2", "2x4", "4x1", "8x1"])
 def test_cgp_on_a_multi_gpu_grid(tmp_path, shape):
     """The C++ CGp with GPC_GRID=PRxPC: the model factors on the 2-D block-cyclic grid (one host thread per rank; here all
     ranks on the box's one GPU) and must give the numbers the single-GPU model gives (plain fp64 on both sides), and the
@@ -96,6 +96,10 @@ def test_cgp_on_a_multi_gpu_grid(tmp_path, shape):
     assert rel(v["ll_after_predict"], one["ll"]) < 1e-10 and rel(v["ll_roundtrip"], one["ll"]) < 1e-10
     assert rel(v["ll_with_grad"], one["ll"]) < 1e-10
     assert rel(v["grads"], one["grads"]) < 1e-8 and rel(v["grads"], g["grads"]) < 1e-8
+    # new targets reach the ranks (setBias + updateM between evaluations): against the same calls on one GPU
+    ref = _parse(_run([os.path.join(HOST, "gp_hosttest"), "gpgrid"] + args, env=dict(os.environ, GPC_GRID="1x1")))
+    assert rel(v["ll_new_bias"], ref["ll_new_bias"]) < 1e-10 and abs(ref["ll_new_bias"][0] - ref["ll"][0]) > 1.0
+    assert rel(v["ll_old_bias_again"], one["ll"]) < 1e-10
 
 
 @pytest.mark.gpu
