@@ -14,7 +14,7 @@ GPC_EINVAL, GPC_ENODEV, GPC_EHIP, GPC_ENOMEM, GPC_EUNSUPPORTED = -1, -2, -3, -4,
 _ERRNAMES = {-1: "GPC_EINVAL", -2: "GPC_ENODEV", -3: "GPC_EHIP", -4: "GPC_ENOMEM", -5: "GPC_EUNSUPPORTED"}
 
 GPC_KERN_RBF, GPC_KERN_RBFARD, GPC_KERN_WHITE, GPC_KERN_BIAS, GPC_KERN_LIN = 1, 2, 3, 4, 5
-GPC_MAX_TERMS, GPC_MAX_PARAMS, GPC_MAX_ARD_DIM = 8, 160, 64
+GPC_MAX_TERMS, GPC_MAX_PARAMS, GPC_MAX_ARD_DIM = 16, 160, 64
 
 
 class GpcError(RuntimeError):
@@ -36,6 +36,7 @@ I64, DP, VP = c_int64, c_void_p, c_void_p   # device pointers travel as void*
 SIGNATURES = {
     "gpc_version": (c_int, []),
     "gpc_last_error": (c_char_p, []),
+    "gpc_shutdown": (c_int, []),
     "gpc_device_count": (c_int, [POINTER(c_int)]),
     "gpc_set_device": (c_int, [c_int]),
     "gpc_device_info": (c_int, [c_char_p, c_size_t, POINTER(c_int), POINTER(c_size_t), POINTER(c_int)]),

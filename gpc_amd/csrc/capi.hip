@@ -8,6 +8,8 @@
 #include <ctype.h>
 #include <math.h>
 #include <thread>
+#include <mutex>
+#include <stdlib.h>
 
 namespace gpc {
 
@@ -36,6 +38,13 @@ int ensure_device()
     return GPC_ENODEV;
   }
   g_dev_state = 1;
+  // leave in a defined order: the calling thread's streams / events / scratch go before the HIP runtime's own exit-time
+  // teardown (handlers run in reverse order of registration, and the runtime was initialised by the call above)
+  static std::once_flag once;
+  std::call_once(once, [] {
+    const char* e = getenv("GPC_ATEXIT_SHUTDOWN");     // 0: leave the exit path as the HIP runtime finds it (tools/exit_crash_loop.sh's control)
+    if(!e || atoi(e) != 0) atexit([] { (void)gpc_shutdown(); });
+  });
   return GPC_OK;
 }
 
@@ -108,6 +117,19 @@ int workspace(int slot, size_t bytes, void** out)
 }
 
 int potri_full(bool lower, int64_t N, double* A, int64_t lda, hipStream_t s);
+void release_lookahead();     // potrf.hip
+void release_profile();       // profile.hip
+
+// the calling thread's scratch slots
+static void release_workspace()
+{
+  for(int i = 0; i < WS_NSLOTS; i++)
+    if(g_ws[i].p) {
+      (void)hipFree(g_ws[i].p);
+      g_ws[i].p = nullptr;
+      g_ws[i].bytes = 0;
+    }
+}
 
 static int read_info(int* d_info, int* info, hipStream_t s)
 {
@@ -547,3 +569,27 @@ int gpc_gp_posterior_f64(const gpc_kspec* ks, const double* X, int64_t N, int64_
 
 }  // extern "C"
 
+
+
+// Releases what the library holds on behalf of the CALLING thread -- its look-ahead stream and events, the profiling events,
+// its scratch buffers -- after synchronising every device, so that nothing of the library's is alive when the HIP runtime
+// tears itself down.  Registered with atexit at the first successful device call; callable any time (the next call
+// re-creates what it needs).  Other host threads give their scratch back when they end; grids are the caller's to destroy.
+// librccl stays mapped: closing a library that owns threads and communicators at exit is how exit-time crashes are made.
+extern "C" int gpc_shutdown(void)
+{
+  if(g_dev_state != 1) return GPC_OK;
+  int n = 0, cur = 0;
+  if(hipGetDeviceCount(&n) != hipSuccess || hipGetDevice(&cur) != hipSuccess) {
+    (void)hipGetLastError();
+    return GPC_OK;   // the runtime is already gone: nothing can be released any more, and nothing needs to be
+  }
+  for(int d = 0; d < n; d++)
+    if(hipSetDevice(d) == hipSuccess) (void)hipDeviceSynchronize();
+  (void)hipSetDevice(cur);
+  gpc::release_lookahead();
+  gpc::release_profile();
+  gpc::release_workspace();
+  (void)hipGetLastError();
+  return GPC_OK;
+}

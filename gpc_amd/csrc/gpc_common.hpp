@@ -1,5 +1,6 @@
 // gpc_common.hpp -- shared declarations of libgpc_hip.so (gfx950 only; no portability layer on purpose).
 #pragma once
+#include <vector>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stddef.h>
@@ -64,6 +65,7 @@ int ensure_device();
 // 3 = only i>=j for a tall C (M >= N) whose (0,0) sits on the diagonal.
 int gemm(bool transa, bool transb, int64_t M, int64_t N, int64_t K, double alpha, const double* A, int64_t lda,
          const double* B, int64_t ldb, double beta, double* C, int64_t ldc, int tri, hipStream_t s);
+int trsm_right_lt_identity(int64_t M, int64_t n, const double* L, int64_t ldl, double* B, int64_t ldb, hipStream_t s);   // trsm.hip
 // 2-D block-cyclic staircase update (grid.hip); see GemmArgs::tri == 5 in gemm_f64.hip
 struct Stair2D {
   int64_t nb;            // tile size (multiple of 128)
@@ -139,6 +141,8 @@ struct KSpecDev {
   int need_dot;              // rbf or lin present
 };
 int collapse_kspec(const gpc_kspec* ks, int64_t D, KSpecDev* out);
+// a compound with more terms than one pass holds, cut into specs of at most max_rbf rbf / max_ard rbfard terms (gram.hip)
+int split_kspec(const gpc_kspec* ks, int max_rbf, int max_ard, std::vector<gpc_kspec>* chunks, std::vector<std::vector<int>>* where);
 
 // Optional HIP-event instrumentation of the dominant launches (bench.py's roofline leg; off by default).
 enum ProfKind { PROF_SYRK = 0, PROF_GRAM = 1, PROF_NKINDS = 2 };

@@ -217,9 +217,33 @@ extern "C" int gpc_covgrad_multi_f64(int64_t N, int64_t d, const double* invK, i
   return GPC_OK;
 }
 
+static int launch_gradx_pass(const gpc_kspec* ksp, const double* X, int64_t N, int64_t ldx, const double* X2, int64_t N2,
+                             int64_t ldx2, int64_t D, const double* covGrad, int64_t ldc, double* gX, int64_t ldg,
+                             double pair_factor, hipStream_t s);
+
+// dL/dX is a sum over the compound's terms (CCmpndKern::getGradX, CKern.cpp:184-193): a compound with more rbf / rbfard terms
+// than one pass holds is taken in several, the later ones added to the first one's result
 static int launch_gradx(const gpc_kspec* ksp, const double* X, int64_t N, int64_t ldx, const double* X2, int64_t N2,
                         int64_t ldx2, int64_t D, const double* covGrad, int64_t ldc, double* gX, int64_t ldg,
                         double pair_factor, hipStream_t s)
+{
+  std::vector<gpc_kspec> chunks;
+  GPC_CHECK(split_kspec(ksp, 4, 1, &chunks, nullptr));
+  GPC_CHECK(launch_gradx_pass(&chunks[0], X, N, ldx, X2, N2, ldx2, D, covGrad, ldc, gX, ldg, pair_factor, s));
+  if(chunks.size() == 1 || N == 0 || D == 0) return GPC_OK;
+  void* wt = nullptr;
+  GPC_CHECK(workspace(WS_TRSM_TMP, sizeof(double) * (size_t)N * (size_t)D, &wt));
+  double* tmp = static_cast<double*>(wt);
+  for(size_t c = 1; c < chunks.size(); c++) {
+    GPC_CHECK(launch_gradx_pass(&chunks[c], X, N, ldx, X2, N2, ldx2, D, covGrad, ldc, tmp, N, pair_factor, s));
+    GPC_CHECK(gpc_axpby_f64(N, D, 1.0, tmp, N, 1.0, gX, ldg, s));
+  }
+  return GPC_OK;
+}
+
+static int launch_gradx_pass(const gpc_kspec* ksp, const double* X, int64_t N, int64_t ldx, const double* X2, int64_t N2,
+                             int64_t ldx2, int64_t D, const double* covGrad, int64_t ldc, double* gX, int64_t ldg,
+                             double pair_factor, hipStream_t s)
 {
   if(D > 16) {
     set_error("kern_gradx: input dimension %lld > 16 is outside the accelerated set", (long long)D);
@@ -293,6 +317,9 @@ extern "C" int gpc_kern_gradx_cross_f64(const gpc_kspec* ksp, const double* X, i
   return launch_gradx(ksp, X, N, ldx, X2, N2, ldx2, D, covGrad, ldc, gX, ldg, 1.0, as_stream(stream));
 }
 
+static int kern_grad_cross_pass(const gpc_kspec* ksp, const double* X, int64_t N, int64_t ldx, const double* X2, int64_t N2,
+                                int64_t ldx2, int64_t D, const double* covGrad, int64_t ldc, double* gout, hipStream_t s);
+
 extern "C" int gpc_kern_grad_cross_f64(const gpc_kspec* ksp, const double* X, int64_t N, int64_t ldx, const double* X2,
                                        int64_t N2, int64_t ldx2, int64_t D, const double* covGrad, int64_t ldc,
                                        double* gout, void* stream)
@@ -302,6 +329,25 @@ extern "C" int gpc_kern_grad_cross_f64(const gpc_kspec* ksp, const double* X, in
                   ldc >= (N > 1 ? N : 1),
               "kern_grad_cross args");
   hipStream_t s = as_stream(stream);
+  // a term's parameter sums involve that term alone: compounds beyond one pass (4 rbf, 1 rbfard) go chunk by chunk
+  std::vector<gpc_kspec> chunks;
+  std::vector<std::vector<int>> where;
+  GPC_CHECK(split_kspec(ksp, 4, 1, &chunks, &where));
+  if(chunks.size() == 1) return kern_grad_cross_pass(ksp, X, N, ldx, X2, N2, ldx2, D, covGrad, ldc, gout, s);
+  for(size_t c = 0; c < chunks.size(); c++) {
+    double gsub[GPC_MAX_PARAMS];
+    GPC_CHECK(kern_grad_cross_pass(&chunks[c], X, N, ldx, X2, N2, ldx2, D, covGrad, ldc, gsub, s));
+    for(int i = 0; i < chunks[c].n_terms; i++) {
+      const int t = where[c][(size_t)i];
+      for(int q = 0; q < chunks[c].offs[i + 1] - chunks[c].offs[i]; q++) gout[ksp->offs[t] + q] = gsub[chunks[c].offs[i] + q];
+    }
+  }
+  return GPC_OK;
+}
+
+static int kern_grad_cross_pass(const gpc_kspec* ksp, const double* X, int64_t N, int64_t ldx, const double* X2, int64_t N2,
+                                int64_t ldx2, int64_t D, const double* covGrad, int64_t ldc, double* gout, hipStream_t s)
+{
   KSpecDev ks;
   GPC_CHECK(collapse_kspec(ksp, D, &ks));
   if(D > 32 || (D > 16 && ks.n_ard > 0)) {

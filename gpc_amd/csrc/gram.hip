@@ -12,6 +12,7 @@
 // come from a pre-pass, and the cross term is an FMA dot product per pair.  The diagonal of the symmetric Gram uses
 // the reference's diagComputeElement values exactly (variance sums), not exp(-0).
 #include "gpc_common.hpp"
+#include <vector>
 #include <string.h>
 #include <stdlib.h>
 
@@ -36,6 +37,7 @@ struct GramArgs {
   int mirror;            // 1: the whole symmetric Gram of one X is being built: tiles left of the diagonal block are
                          //    computed once and stored twice (K(i,j) and K(j,i)); tiles right of it are skipped
   int debug;             // ablation knob (env GPC_GRAM_DEBUG): 2 no MFMA loop, 3 no stores; 0 in production
+  int accum;             // 1: K += the terms of this spec (a further pass of a compound with more terms than one pass holds)
 };
 
 __global__ void __launch_bounds__(256) row_norms_kernel(const double* __restrict__ X, int64_t ldx, int64_t N,
@@ -159,6 +161,10 @@ __global__ void __launch_bounds__(256) gram_kernel(const KSpecDev ks, const Gram
       out[a] = k;
     }
     double* p = g.K + gi + gj * g.ldk;
+    if(g.accum) {
+      if(gi < g.N) out[0] += p[0];
+      if(gi + 1 < g.N) out[1] += p[1];
+    }
     if(gi + 1 < g.N) {
       if(vec_ok)
         *reinterpret_cast<double2_t*>(p) = (double2_t){out[0], out[1]};
@@ -635,7 +641,7 @@ int launch_gram(const KSpecDev& ks, const GramArgs& g, hipStream_t s)
     const char* e = getenv("GPC_GRAM_MFMA");
     use_mfma = e ? (atoi(e) != 0) : 1;
   }
-  if(use_mfma && ks.need_dot && ks.n_ard == 0 && (g.N2 + MJ - 1) / MJ <= 65535) {
+  if(use_mfma && !g.accum && ks.need_dot && ks.n_ard == 0 && (g.N2 + MJ - 1) / MJ <= 65535) {
     const int64_t tiles_i = (g.N + MI - 1) / MI, tiles_j = (g.N2 + MJ - 1) / MJ;
     prof_begin(PROF_GRAM, 8.0 * ((double)g.N * (double)g.N2 + (double)(g.N + g.N2) * (double)g.D), s);
     if(g.D <= MDC && use_mfma != 2) {
@@ -745,6 +751,53 @@ __global__ void __launch_bounds__(256) ard_scale_kernel(const double* __restrict
 
 }  // namespace
 
+// Cuts a compound into specs of at most max_rbf rbf and max_ard rbfard terms each.  White / bias / lin terms (plain sums in
+// every kernel here) all go into the first chunk.  (*where)[c][t] = index in the full spec of term t of chunk c.
+int split_kspec(const gpc_kspec* ks, int max_rbf, int max_ard, std::vector<gpc_kspec>* chunks, std::vector<std::vector<int>>* where)
+{
+  if(!ks || ks->n_terms < 0 || ks->n_terms > GPC_MAX_TERMS) {
+    set_error("kernel spec: bad term count");
+    return GPC_EINVAL;
+  }
+  chunks->clear();
+  if(where) where->clear();
+  std::vector<int> n_rbf, n_ard;
+  auto add_chunk = [&] {
+    gpc_kspec e;
+    memset(&e, 0, sizeof(e));
+    chunks->push_back(e);
+    if(where) where->push_back(std::vector<int>());
+    n_rbf.push_back(0);
+    n_ard.push_back(0);
+  };
+  add_chunk();
+  for(int t = 0; t < ks->n_terms; t++) {
+    const int type = ks->types[t];
+    const int off = ks->offs[t], np = ks->offs[t + 1] - ks->offs[t];
+    if(off < 0 || np < 0 || off + np > GPC_MAX_PARAMS) {
+      set_error("kernel spec: bad parameter offsets");
+      return GPC_EINVAL;
+    }
+    size_t c = 0;
+    if(type == GPC_KERN_RBF) {
+      while(c < chunks->size() && n_rbf[c] >= max_rbf) c++;
+    } else if(type == GPC_KERN_RBFARD) {
+      while(c < chunks->size() && n_ard[c] >= max_ard) c++;
+    }
+    if(c == chunks->size()) add_chunk();
+    gpc_kspec& e = (*chunks)[c];
+    const int o = e.offs[e.n_terms];
+    e.types[e.n_terms] = type;
+    for(int q = 0; q < np; q++) e.params[o + q] = ks->params[off + q];
+    e.offs[e.n_terms + 1] = o + np;
+    e.n_terms++;
+    if(type == GPC_KERN_RBF) n_rbf[c]++;
+    if(type == GPC_KERN_RBFARD) n_ard[c]++;
+    if(where) (*where)[c].push_back(t);
+  }
+  return GPC_OK;
+}
+
 int collapse_kspec(const gpc_kspec* ks, int64_t D, KSpecDev* o)
 {
   if(!ks || ks->n_terms < 0 || ks->n_terms > GPC_MAX_TERMS) {
@@ -802,9 +855,27 @@ int collapse_kspec(const gpc_kspec* ks, int64_t D, KSpecDev* o)
 
 using namespace gpc;
 
+static int gram_pass(const gpc_kspec* ksp, const double* X, int64_t N, int64_t ldx, const double* X2, int64_t N2,
+                     int64_t ldx2, int64_t D, double* K, int64_t ldk, int64_t i_off, int64_t j_off, int sym_diag,
+                     bool same_x, int accum, hipStream_t s);
+
+// CCmpndKern has no limit on its components (CKern.h:382-433); one pass of the kernels here holds four rbf terms and one
+// rbfard term.  A longer compound is built in several passes: the first one writes K with the terms it can hold (and all
+// white / bias / lin terms, which are plain sums), every further pass adds its terms to K in place.
 static int gram_common(const gpc_kspec* ksp, const double* X, int64_t N, int64_t ldx, const double* X2, int64_t N2,
                        int64_t ldx2, int64_t D, double* K, int64_t ldk, int64_t i_off, int64_t j_off, int sym_diag,
                        bool same_x, hipStream_t s)
+{
+  std::vector<gpc_kspec> chunks;
+  GPC_CHECK(split_kspec(ksp, 4, 1, &chunks, nullptr));
+  for(size_t c = 0; c < chunks.size(); c++)
+    GPC_CHECK(gram_pass(&chunks[c], X, N, ldx, X2, N2, ldx2, D, K, ldk, i_off, j_off, sym_diag, same_x, c > 0 ? 1 : 0, s));
+  return GPC_OK;
+}
+
+static int gram_pass(const gpc_kspec* ksp, const double* X, int64_t N, int64_t ldx, const double* X2, int64_t N2,
+                     int64_t ldx2, int64_t D, double* K, int64_t ldk, int64_t i_off, int64_t j_off, int sym_diag,
+                     bool same_x, int accum, hipStream_t s)
 {
   KSpecDev ks;
   GPC_CHECK(collapse_kspec(ksp, D, &ks));
@@ -826,8 +897,9 @@ static int gram_common(const gpc_kspec* ksp, const double* X, int64_t N, int64_t
     static int sym = -1;
     if(sym < 0) { const char* e = getenv("GPC_GRAM_SYM"); sym = e ? (atoi(e) != 0) : 1; }
     // "mirror" request; honoured by the persistent MFMA kernel only (launch_gram clears it on the other paths)
-    g.mirror = (sym && same_x && sym_diag && X == X2 && N == N2 && i_off == 0 && j_off == 0) ? 1 : 0;
+    g.mirror = (sym && !accum && same_x && sym_diag && X == X2 && N == N2 && i_off == 0 && j_off == 0) ? 1 : 0;
   }
+  g.accum = accum;
   {
     static int dbg = -1;
     if(dbg < 0) { const char* e = getenv("GPC_GRAM_DEBUG"); dbg = e ? atoi(e) : 0; }
@@ -840,7 +912,7 @@ static int gram_common(const gpc_kspec* ksp, const double* X, int64_t N, int64_t
   // 1e-10 the Gram entries are held to.
   static int ard_fast = -1;
   if(ard_fast < 0) { const char* e = getenv("GPC_GRAM_ARD_SCALED"); ard_fast = e ? (atoi(e) != 0) : 1; }
-  if(ard_fast && ks.n_ard == 1 && ks.n_rbf == 0 && ks.lin_var == 0.0 && D >= 1 && D <= 32 && N > 0 && N2 > 0) {
+  if(ard_fast && !accum && ks.n_ard == 1 && ks.n_rbf == 0 && ks.lin_var == 0.0 && D >= 1 && D <= 32 && N > 0 && N2 > 0) {
     void* wx = nullptr;
     GPC_CHECK(workspace(WS_XSCALED, sizeof(double) * (size_t)((N + (same_x ? 0 : N2)) * D), &wx));
     double* Xs = static_cast<double*>(wx);
@@ -918,8 +990,16 @@ extern "C" int gpc_gram_diag_f64(const gpc_kspec* ksp, const double* X, int64_t 
   GPC_CHECK(ensure_device());
   GPC_REQUIRE(N >= 0 && D >= 0 && ldx >= N, "gram_diag dims");
   if(N == 0) return GPC_OK;
+  std::vector<gpc_kspec> chunks;
+  GPC_CHECK(split_kspec(ksp, 4, 1, &chunks, nullptr));
   KSpecDev ks;
-  GPC_CHECK(collapse_kspec(ksp, D, &ks));
+  GPC_CHECK(collapse_kspec(&chunks[0], D, &ks));
+  for(size_t c = 1; c < chunks.size(); c++) {      // the terms beyond one pass are rbf / rbfard: their diagonal is their variance
+    KSpecDev more;
+    GPC_CHECK(collapse_kspec(&chunks[c], D, &more));
+    for(int r = 0; r < more.n_rbf; r++) ks.bias_var += more.rbf_var[r];
+    for(int r = 0; r < more.n_ard; r++) ks.bias_var += more.ard_var[r];
+  }
   hipLaunchKernelGGL(gram_diag_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, as_stream(stream), ks, X,
                      ldx, N, D, d);
   GPC_HIP_CHECK(hipGetLastError());

@@ -165,15 +165,38 @@ __global__ void __launch_bounds__(256) set_identity_diag_kernel(double* A, int64
 
 // see GridOps::covgrad_block
 __global__ void __launch_bounds__(256) covgrad_block_kernel(double* __restrict__ S, int64_t lds, int64_t M, const double* __restrict__ Al,
-                                                            int64_t lda, int nd, int64_t g0)
+                                                            int64_t lda, int nd, int64_t g0, int upper, int64_t j0)
 {
-  const int64_t j = blockIdx.y;
+  const int64_t j = j0 + blockIdx.y;
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if(i >= M) return;
   double aa = 0.0;
   for(int o = 0; o < nd; o++) aa = fma(Al[g0 + i + (int64_t)o * lda], Al[g0 + j + (int64_t)o * lda], aa);
   const double c = -0.5 * ((double)nd * S[i + j * lds] - aa);
-  S[i + j * lds] = i > j ? 2.0 * c : (i == j ? c : 0.0);
+  const bool twice = upper ? j > i : i > j;
+  S[i + j * lds] = twice ? 2.0 * c : (i == j ? c : 0.0);
+}
+
+// out(j, e) = alpha sum_i A(i, j) v(i, e) (+ beta out): the tall-and-skinny transposed product of the back substitution
+// (nb columns of up to N / pr rows against d <= 4 vectors).  One workgroup per column, rows in coalesced strides, a fixed-order
+// block reduction: memory-bound (the generic GEMM kernel took 2.6 ms for 268 MB here).
+__global__ void __launch_bounds__(256) gemv_t_kernel(const double* __restrict__ A, int64_t lda, int64_t M, const double* __restrict__ v,
+                                                     int64_t ldv, int d, double alpha, double beta, double* __restrict__ out, int64_t ldo)
+{
+  __shared__ double sh[4];
+  const int64_t j = blockIdx.x;
+  const double* col = A + j * lda;
+  double acc[4] = {0.0, 0.0, 0.0, 0.0};
+  for(int64_t i = threadIdx.x; i < M; i += 256) {
+    const double a = col[i];
+#pragma unroll
+    for(int e = 0; e < 4; e++)
+      if(e < d) acc[e] = fma(a, v[i + (int64_t)e * ldv], acc[e]);
+  }
+  for(int e = 0; e < d; e++) {
+    const double t = block_sum(acc[e], sh);
+    if(threadIdx.x == 0) out[j + (int64_t)e * ldo] = alpha * t + (beta == 0.0 ? 0.0 : beta * out[j + (int64_t)e * ldo]);
+  }
 }
 
 // ---- GridOps on HIP ------------------------------------------------------------------------------------------------------
@@ -430,6 +453,11 @@ struct HipOps : GridOps {
   int gemm(char ta, char tb, int64_t M, int64_t N, int64_t K, double alpha, const double* A, int64_t lda, const double* B,
            int64_t ldb, double beta, double* C, int64_t ldc, int s) override
   {
+    if(ta == 'T' && tb == 'N' && N >= 1 && N <= 4 && M > 0 && K > 0) {
+      hipLaunchKernelGGL(gemv_t_kernel, dim3((unsigned)M), dim3(256), 0, st[s], A, lda, K, B, ldb, (int)N, alpha, beta, C, ldc);
+      HIPOPS_CHECK(hipGetLastError());
+      return GPC_OK;
+    }
     return gpc::gemm(ta == 'T', tb == 'T', M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, 0, st[s]);
   }
   int trsm_llt(const double* Lkk, int64_t ldl, int64_t n, double* B, int64_t ldb, int64_t nrhs, int s) override
@@ -464,13 +492,22 @@ struct HipOps : GridOps {
     return gpc::diag_reduce(0, n, A, lda, out, st[s]);
   }
   int covgrad_block(double* S, int64_t lds, int64_t M, int64_t nbc, const double* Al, int64_t lda, int64_t nd, int64_t g0,
-                    int s) override
+                    int upper, int s) override
   {
     if(M <= 0 || nbc <= 0) return GPC_OK;
-    hipLaunchKernelGGL(covgrad_block_kernel, dim3((unsigned)((M + 255) / 256), (unsigned)nbc), dim3(256), 0, st[s], S, lds, M, Al,
-                       lda, (int)nd, g0);
+    for(int64_t j0 = 0; j0 < nbc; j0 += 32768) {
+      const int64_t nc = nbc - j0 < 32768 ? nbc - j0 : 32768;
+      hipLaunchKernelGGL(covgrad_block_kernel, dim3((unsigned)((M + 255) / 256), (unsigned)nc), dim3(256), 0, st[s], S, lds, M, Al,
+                         lda, (int)nd, g0, upper, j0);
+    }
     HIPOPS_CHECK(hipGetLastError());
     return GPC_OK;
+  }
+  int trsm_right(const double* L, int64_t ldl, int64_t n, bool trans, bool identity_rows, double* B, int64_t ldb, int64_t M,
+                 int s) override
+  {
+    if(trans && identity_rows && M <= n) return gpc::trsm_right_lt_identity(M, n, L, ldl, B, ldb, st[s]);
+    return gpc::trsm('R', 'L', trans ? 'T' : 'N', 'N', M, n, 1.0, L, ldl, B, ldb, st[s]);
   }
   int kern_grad_block(const gpc_kspec* ks, const double* Xa, int64_t Na, int64_t lda, const double* Xb, int64_t Nb, int64_t ldb,
                       int64_t D, const double* C, int64_t ldc, double* g, int s) override

@@ -239,7 +239,8 @@ int GRID_API(info)(gpc_grid* g, int64_t* out)
 }
 
 // out[0..7] = bytes received along process rows / columns / world, collectives entered, algorithmic flops of this
-// rank's trailing updates, their launches, 0, 0 -- since the last reset
+// rank's trailing updates, their launches, their algorithmic HBM bytes -- since the last reset -- and the device bytes this
+// rank's problem holds right now (local block, panel buffers, the gradient's replicated factor once it has been called)
 int GRID_API(stats)(gpc_grid* g, double* out, int reset)
 {
   if(!g || !out) return GPC_EINVAL;
@@ -251,7 +252,7 @@ int GRID_API(stats)(gpc_grid* g, double* out, int reset)
   out[4] = s.update_flops;
   out[5] = (double)s.update_launches;
   out[6] = s.update_bytes;
-  out[7] = 0.0;
+  out[7] = s.bytes_held;
   if(reset) g->gp->reset_stats();
   return GPC_OK;
 }

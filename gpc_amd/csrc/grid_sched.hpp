@@ -28,6 +28,7 @@
 #include <stddef.h>
 #include <stdio.h>
 #include <math.h>
+#include <time.h>
 #include <string.h>
 #include <vector>
 #include <mutex>
@@ -185,16 +186,21 @@ struct GridOps {
   virtual int trsm_llt(const double* Lkk, int64_t ldl, int64_t n, double* B, int64_t ldb, int64_t nrhs, int st) = 0;
   // ---- gradient (see GridGp::gradient)
   virtual int trsm_lln(const double* L, int64_t ldl, int64_t n, double* B, int64_t ldb, int64_t nrhs, int st) = 0;   // B := L^-1 B
+  // B (M x n) := B L^-T (trans) or B L^-1 (!trans) for the lower-triangular n x n L: the rows of B are independent
+  // identity_rows: B holds the first M rows of the identity (an implementation may skip the rows that are still zero)
+  virtual int trsm_right(const double* L, int64_t ldl, int64_t n, bool trans, bool identity_rows, double* B, int64_t ldb, int64_t M,
+                         int st) = 0;
   // dst row tile (first + t*step), all ncols columns := src row tile t (src is count*nb x ncols, leading dimension lds)
   virtual int scatter_row_tiles(double* dst, int64_t ldd, int64_t first, int64_t step, const double* src, int64_t lds,
                                 int64_t count, int64_t nb, int64_t ncols, int st) = 0;
   virtual int set_identity(double* A, int64_t lda, int64_t n, int st) = 0;      // the n x n block at A := I
   virtual int sum_diag(const double* A, int64_t lda, int64_t n, double* out_host, int st) = 0;
-  // In place on the M x nb block S = K^-1(g0 + i, g0 + j):  C(i,j) = w * -0.5 (nd S(i,j) - sum_o Al(g0+i,o) Al(g0+j,o)) with
-  // w = 2 below the block's diagonal, 1 on it, 0 above it (CGp::updateCovGradient, CGp.cpp:666-679, summed over outputs; the
-  // weight 2 stands for the mirrored element the lower-triangular sweep never forms)
+  // In place on the M x nbc block S = K^-1(g0 + i, g0 + j):  C(i,j) = w * -0.5 (nd S(i,j) - sum_o Al(g0+i,o) Al(g0+j,o)) with
+  // w = 2 on one side of the block's diagonal (below it, or above it when `upper`), 1 on it, 0 on the other side
+  // (CGp::updateCovGradient, CGp.cpp:666-679, summed over outputs; the weight 2 stands for the mirrored element the
+  // one-sided sweep never forms)
   virtual int covgrad_block(double* S, int64_t lds, int64_t M, int64_t nbc, const double* Al, int64_t lda, int64_t nd,
-                            int64_t g0, int st) = 0;
+                            int64_t g0, int upper, int st) = 0;
   // g[p] = sum over the block of C(i,n) dk(Xa_i, Xb_n)/dtheta_p, natural parameters in spec order, white = 0
   // (CKern::getGradParams(g, X, X2, covGrad)); g is a host array of ks->offs[n_terms] doubles
   virtual int kern_grad_block(const gpc_kspec* ks, const double* Xa, int64_t Na, int64_t lda, const double* Xb, int64_t Nb,
@@ -477,6 +483,7 @@ struct GridStats {
   double update_flops = 0;            // algorithmic flops of this rank's trailing updates
   double update_bytes = 0;            // ... and their algorithmic HBM bytes: both panels once + read and write of the entries updated
   int64_t update_launches = 0;
+  double bytes_held = 0;              // device memory this rank's problem holds (local block, panels, gradient buffers); not reset
 };
 
 class GridGp {
@@ -492,7 +499,12 @@ class GridGp {
   GridComm* comm() { return comm_.get(); }
   const Layout& layout() const { return L_; }
   const GridStats& stats() const { return stats_; }
-  void reset_stats() { stats_ = GridStats(); }
+  void reset_stats()
+  {
+    const double held = stats_.bytes_held;
+    stats_ = GridStats();
+    stats_.bytes_held = held;
+  }
   const std::string& error() const { return err_; }
   double logdet() const { return logdet_; }
   double jitter() const { return jitter_; }
@@ -765,11 +777,21 @@ class GridGp {
 
   // CGp::updateG (CGp.cpp:1080-1117) for the distributed model: g[p] = sum_ij covGrad(i,j) dK(i,j)/dtheta_p for the natural
   // kernel parameters in spec order (the transform chain rule stays with the caller), identical on every rank.
-  // K^-1 is not formed by a distributed dpotri.  The factor is replicated instead (one broadcast per tile-column strip; it
-  // has to fit beside the local block: 8 N^2 bytes, 137 GB at N = 131 072), and every rank then solves for ITS tile columns
-  // of the lower triangle of K^-1 on its own --  S(J:, J) = L(J:, J:)^-T L(J:, J:)^-1 E_J, two triangular solves on the
-  // trailing block, (2/3) N^3 / P flops per rank like a distributed dpotri, no exchange -- and runs the kernel-gradient
-  // pass over that block column.  One all-reduce of the parameter sums at the end.
+  // K^-1 = V V' with V = L^-T (dpotri's two halves, CMatrix.cpp:414-432), formed by rows:
+  //   1. the factor is replicated (one all-gather per tile column; it has to fit beside the local block: 8 N^2 bytes, 137 GB
+  //      at N = 131 072 -- gpc_grid_stats reports the bytes a rank holds);
+  //   2. every rank solves X L' = E for ITS groups of tile rows of V (E = rows of the identity; rows of a right-sided solve
+  //      are independent, the solve runs on the trailing block L(J:, J:) only, and it is the library's chip-wide
+  //      right-sided chain, the one dpotri uses): N^3 / 3 flops over all ranks;
+  //   3. the groups of V are exchanged (one all-gather per round of groups) into the upper part of the same buffer
+  //      (shifted right by one group height, so that a group's zero entries never land on the factor);
+  //   4. every rank forms its groups of rows of K^-1, K^-1(J, I) = sum_{m >= I} V(J, m) V(I, m)' for I >= J, as NT products
+  //      on the matrix cores that start at column I (the zeros of the triangular operand are skipped): N^3 / 3 flops again;
+  //   5. covGrad = -0.5 (d K^-1 - alpha alpha') on the block (each unordered pair once, weight 2 off the diagonal), the
+  //      cross-block kernel-gradient pass, one all-reduce of the parameter sums.
+  // (2/3) N^3 / P flops per rank like a distributed dpotri; round 2 solved block columns with left-sided solves (22 TFLOP/s
+  // at N = 32 768 on one rank).  A group is a run of consecutive tile rows (<= 4096 rows; rows of one group start at almost the
+  // same column, so little of the trailing block is solved for nothing); groups are dealt to the ranks by cost, largest first.
   int gradient(double* g_host)
   {
     const Layout& L = L_;
@@ -777,60 +799,175 @@ class GridGp {
     if(!alpha_valid_) GRID_CHECK(alpha(nullptr, 0));
     const int np = ks_.offs[ks_.n_terms];
     const int P = pr_ * pc_, me = r_ * pc_ + c_;
-    // the three gradient buffers live as long as the problem does (an optimiser calls this once per iteration; allocating
+    // rows of a group: 8192 on one or two ranks (the solve's products run closer to the kernel's rate the more rows they
+    // have), 4096 beyond (a round of P groups is in flight at once: P W N doubles)
+    const int64_t Gmax = imax(1, (P <= 2 ? 8192 : 4096) / nb_), W = Gmax * nb_, ldf = L.Np;
+    // groups of consecutive tile rows, dealt by cost (a row J costs (T - J)^2: a solve and a product on the trailing block)
+    struct Group { int64_t J0, rows; double cost; int owner, round; };
+    std::vector<Group> groups;
+    int rounds = 0;
+    {
+      double total = 0.0;
+      for(int64_t J = 0; J < L.T; J++) total += (double)(L.T - J) * (double)(L.T - J);
+      const double limit = P > 1 ? total / (3.0 * P) : 1e300;
+      for(int64_t J = 0; J < L.T;) {
+        Group g = {J, 0, 0.0, 0, 0};
+        while(J < L.T && g.rows < Gmax) {
+          const double c = (double)(L.T - J) * (double)(L.T - J);
+          if(g.rows > 0 && g.cost + c > limit) break;
+          g.cost += c;
+          g.rows++;
+          J++;
+        }
+        groups.push_back(g);
+      }
+      std::vector<size_t> order(groups.size());
+      for(size_t i = 0; i < order.size(); i++) order[i] = i;
+      for(size_t i = 1; i < order.size(); i++)       // by cost, largest first; ties keep the row order (insertion sort: stable)
+        for(size_t j = i; j > 0 && groups[order[j]].cost > groups[order[j - 1]].cost; j--) std::swap(order[j], order[j - 1]);
+      std::vector<double> load((size_t)P, 0.0);
+      for(size_t i : order) {
+        int best = 0;
+        for(int m = 1; m < P; m++)
+          if(load[(size_t)m] < load[(size_t)best]) best = m;
+        groups[i].owner = best;
+        load[(size_t)best] += groups[i].cost;
+      }
+      std::vector<int> seen((size_t)P, 0);
+      for(Group& g : groups) {                       // a rank's groups in row order: its r-th one travels in round r
+        g.round = seen[(size_t)g.owner]++;
+        rounds = g.round + 1 > rounds ? g.round + 1 : rounds;
+      }
+    }
+    int mine_n = 0;
+    for(const Group& g : groups) mine_n += g.owner == me;
+    // GPC_GRID_TRACE_GRADIENT=1: the phases' wall-clock times on stderr (each closed by a stream synchronisation: a measuring aid)
+    static const bool phase_trace = getenv("GPC_GRID_TRACE_GRADIENT") != nullptr;
+    struct timespec ts0;
+    clock_gettime(CLOCK_MONOTONIC, &ts0);
+    auto phase = [&](const char* what) {
+      if(!phase_trace) return;
+      (void)ops_->sync(ST_MAIN);
+      struct timespec t1;
+      clock_gettime(CLOCK_MONOTONIC, &t1);
+      fprintf(stderr, "[%d,%d] gradient: %-28s %9.2f ms\n", r_, c_, what, (t1.tv_sec - ts0.tv_sec) * 1e3 + (t1.tv_nsec - ts0.tv_nsec) * 1e-6);
+      ts0 = t1;
+    };
+    // the gradient buffers live as long as the problem does (an optimiser calls this once per iteration; allocating
     // 8 N^2 bytes each time would cost more than the solves)
-    const int64_t G = imax(1, 4096 / nb_);
     int rc = GPC_OK;
-    if(!Lf_) rc = ops_->alloc((void**)&Lf_, sizeof(double) * (size_t)(L.Np * L.Np));
-    if(rc == GPC_OK && !strip_)
-      rc = ops_->alloc((void**)&strip_, sizeof(double) * (size_t)(((L.T + pr_ - 1) / pr_) * nb_ * nb_ + 16));   // any row's strip
-    if(rc == GPC_OK && !Zg_) rc = ops_->alloc((void**)&Zg_, sizeof(double) * (size_t)(L.Np * nb_ * G));
-    GRID_CHECK(rc);
+    if(!Lf_) rc = held_alloc(Lf_, ldf * (L.Np + W));                                  // L below the diagonal, V shifted right by W
+    if(rc == GPC_OK && !strip_) rc = held_alloc(strip_, L.T * nb_ * nb_ + 16);        // one tile column of the factor
+    if(rc == GPC_OK && !Zg_) rc = held_alloc(Zg_, (int64_t)P * W * L.Np);             // a round of groups in flight; later a block of K^-1
+    if(rc == GPC_OK && !Vm_) rc = held_alloc(Vm_, (int64_t)imax(mine_n, 1) * W * L.Np);   // this rank's own groups of V
+    if(rc != GPC_OK)
+      return fail(rc, "grid gradient: the replicated factor (8 N^2 bytes) and the exchange blocks do not fit beside this rank's block");
     double *Lf = Lf_, *strip = strip_, *Z = Zg_;
-    // 1. replicate the lower tiles of the factor
+    // 1. replicate the lower tiles of the factor, one tile column per exchange: process row s of the owning process column
+    // contributes the tiles it holds (I >= J on its rows), everybody receives all of them
+    std::vector<int64_t> start((size_t)P, 0), count((size_t)P, 0);
     for(int64_t J = 0; J < L.T && rc == GPC_OK; J++) {
       const int jc = (int)(J % pc_);
-      for(int s = 0; s < pr_ && rc == GPC_OK; s++) {
+      int64_t off = 0;
+      double recv = 0.0;
+      for(int m = 0; m < P; m++) start[(size_t)m] = count[(size_t)m] = 0;
+      for(int s = 0; s < pr_; s++) {
         const int64_t ilf = L.first_after_row(J - 1, s);                 // first local tile row of process row s with I >= J
         const int64_t cnt = L.rows_of(s) - ilf;
         if(cnt <= 0) continue;
-        if(r_ == s && c_ == jc)
-          rc = ops_->copy2d(strip, cnt * nb_, A_ + ilf * nb_ + (J / pc_) * nb_ * L.lld, L.lld, cnt * nb_, nb_, ST_MAIN);
-        if(rc == GPC_OK) rc = comm_->bcast(strip, cnt * nb_ * nb_, s * pc_ + jc, AX_WORLD, ops_.get(), ST_MAIN);
-        count_coll(AX_WORLD, 8.0 * (double)(cnt * nb_ * nb_), !(r_ == s && c_ == jc));
-        if(rc == GPC_OK && !L.refl)
-          rc = ops_->scatter_row_tiles(Lf + J * nb_ * L.Np, L.Np, s + pr_ * ilf, pr_, strip, cnt * nb_, cnt, nb_, nb_, ST_MAIN);
-        for(int64_t t = 0; L.refl && t < cnt && rc == GPC_OK; t++)
-          rc = ops_->scatter_row_tiles(Lf + J * nb_ * L.Np, L.Np, L.grow_s(s, ilf + t), 1, strip + t * nb_, cnt * nb_, 1, nb_, nb_,
-                                       ST_MAIN);
+        const int m = s * pc_ + jc;
+        start[(size_t)m] = off;
+        count[(size_t)m] = cnt * nb_ * nb_;
+        if(m == me)
+          rc = ops_->copy2d(strip + off, cnt * nb_, A_ + ilf * nb_ + (J / pc_) * nb_ * L.lld, L.lld, cnt * nb_, nb_, ST_MAIN);
+        else
+          recv += 8.0 * (double)(cnt * nb_ * nb_);
+        off += cnt * nb_ * nb_;
+      }
+      if(rc == GPC_OK) rc = comm_->allgatherv(strip, start.data(), count.data(), AX_WORLD, ops_.get(), ST_MAIN);
+      stats_.collectives++;
+      stats_.bytes_recv[AX_WORLD] += recv;
+      for(int s = 0; s < pr_ && rc == GPC_OK; s++) {
+        const int m = s * pc_ + jc;
+        const int64_t cnt = count[(size_t)m] / (nb_ * nb_);
+        if(cnt <= 0) continue;
+        const int64_t ilf = L.first_after_row(J - 1, s);
+        const double* src = strip + start[(size_t)m];
+        if(!L.refl) {
+          rc = ops_->scatter_row_tiles(Lf + J * nb_ * ldf, ldf, s + pr_ * ilf, pr_, src, cnt * nb_, cnt, nb_, nb_, ST_MAIN);
+        } else {
+          for(int64_t t = 0; t < cnt && rc == GPC_OK; t++)   // reflected rounds: no single stride between a rank's tile rows
+            rc = ops_->scatter_row_tiles(Lf + J * nb_ * ldf, ldf, L.grow_s(s, ilf + t), 1, src + t * nb_, cnt * nb_, 1, nb_, nb_,
+                                         ST_MAIN);
+        }
       }
     }
-    // 2. my tile columns of K^-1 and their share of the gradient.  G of them are solved for at once (the triangular solves are
-    // chains of N/64 small dependent kernels whatever the number of right-hand sides: 4096 of them cost what 512 do), on the
-    // trailing block of the first; the columns of the later tiles just start with a few zero rows.
+    GRID_CHECK(rc);
+    phase("alpha + replicated factor");
+    // 2 + 3. my groups of V = L^-T, round by round; every round's groups go to everybody
+    for(int r = 0; r < rounds && rc == GPC_OK; r++) {
+      int64_t off = 0;
+      double recv = 0.0;
+      for(int m = 0; m < P; m++) start[(size_t)m] = count[(size_t)m] = 0;
+      const Group* in_round[4096];
+      for(int m = 0; m < P; m++) in_round[m] = nullptr;
+      for(const Group& g : groups)
+        if(g.round == r) in_round[g.owner] = &g;
+      for(int m = 0; m < P; m++) {
+        if(!in_round[m]) continue;
+        const int64_t M = in_round[m]->rows * nb_, n = L.Np - in_round[m]->J0 * nb_;
+        start[(size_t)m] = off;
+        count[(size_t)m] = M * n;
+        off += M * n;
+        if(m != me) recv += 8.0 * (double)(M * n);
+      }
+      if(in_round[me]) {
+        const int64_t gmin = in_round[me]->J0 * nb_, M = in_round[me]->rows * nb_, n = L.Np - gmin;
+        double* Vb = Vm_ + (int64_t)r * W * L.Np;                               // kept for step 4
+        rc = ops_->zero(Vb, sizeof(double) * (size_t)(M * n), ST_MAIN);
+        if(rc == GPC_OK) rc = ops_->set_identity(Vb, M, M, ST_MAIN);           // row i of the group is row gmin + i of the identity
+        if(rc == GPC_OK) rc = ops_->trsm_right(Lf + gmin + gmin * ldf, ldf, n, true, true, Vb, M, M, ST_MAIN);      // X L' = E
+        if(rc == GPC_OK) rc = ops_->copy(Z + start[(size_t)me], Vb, sizeof(double) * (size_t)(M * n), ST_MAIN);
+        phase("  solve X L' = E (a group)");
+      }
+      if(rc == GPC_OK) rc = comm_->allgatherv(Z, start.data(), count.data(), AX_WORLD, ops_.get(), ST_MAIN);
+      stats_.collectives++;
+      stats_.bytes_recv[AX_WORLD] += recv;
+      for(int m = 0; m < P && rc == GPC_OK; m++) {
+        if(!in_round[m]) continue;
+        const int64_t gmin = in_round[m]->J0 * nb_, M = in_round[m]->rows * nb_, n = L.Np - gmin;
+        // V(gmin + i, gmin + j) -> column gmin + j + W of row gmin + i: right of every entry of L in these rows (M <= W)
+        rc = ops_->copy2d(Lf + gmin + (gmin + W) * ldf, ldf, Z + start[(size_t)m], M, M, n, ST_MAIN);
+      }
+    }
+    GRID_CHECK(rc);
+    phase("exchange of V");
+    // 4 + 5. my groups of rows of K^-1 and their share of the gradient
     std::vector<double> acc((size_t)imax(np, 1), 0.0), part((size_t)imax(np, 1), 0.0);
     double trace = 0.0;
-    for(int64_t J0 = me; J0 < L.T && rc == GPC_OK; J0 += P * G) {
-      int64_t cnt = 0;
-      while(cnt < G && J0 + cnt * P < L.T) cnt++;
-      const int64_t gmin = J0 * nb_, M = L.Np - gmin;
-      rc = ops_->zero(Z, sizeof(double) * (size_t)(M * nb_ * cnt), ST_MAIN);
-      for(int64_t t = 0; t < cnt && rc == GPC_OK; t++)
-        rc = ops_->set_identity(Z + t * P * nb_ + t * nb_ * M, M, nb_, ST_MAIN);      // E of tile column J0 + t P
-      const double* Lt = Lf + gmin + gmin * L.Np;
-      if(rc == GPC_OK) rc = ops_->trsm_lln(Lt, L.Np, M, Z, M, nb_ * cnt, ST_MAIN);
-      if(rc == GPC_OK) rc = ops_->trsm_llt(Lt, L.Np, M, Z, M, nb_ * cnt, ST_MAIN);
-      for(int64_t t = 0; t < cnt && rc == GPC_OK; t++) {
-        const int64_t g0 = (J0 + t * P) * nb_;
-        double* Zt = Z + (g0 - gmin) + t * nb_ * M;                                   // K^-1(g0:, g0:g0+nb)
-        const int64_t Mv = L.N - g0, nv = Mv < nb_ ? Mv : nb_;                        // rows / columns that are data, not padding
-        rc = ops_->covgrad_block(Zt, M, Mv, nv, al_, L.Np, d_, g0, ST_MAIN);
-        double tr = 0.0;
-        if(rc == GPC_OK) rc = ops_->sum_diag(Zt, M, nv, &tr, ST_MAIN);
-        if(rc == GPC_OK) rc = ops_->kern_grad_block(&ks_, X_ + g0, Mv, L.N, X_ + g0, nv, L.N, D_, Zt, M, part.data(), ST_MAIN);
-        trace += tr;
-        for(int p = 0; p < np; p++) acc[(size_t)p] += part[(size_t)p];
+    for(size_t gi = 0; gi < groups.size() && rc == GPC_OK; gi++) {
+      if(groups[gi].owner != me) continue;
+      const int64_t gmin = groups[gi].J0 * nb_, M = groups[gi].rows * nb_;
+      const int64_t Mv = L.N - gmin < M ? L.N - gmin : M, nv = L.N - gmin;        // rows / columns that are data, not padding
+      if(Mv <= 0) continue;
+      const double* Vb = Vm_ + (int64_t)groups[gi].round * W * L.Np;
+      for(int64_t c = groups[gi].J0; c < L.T && rc == GPC_OK; c++) {
+        // tile column c: K^-1(J rows, c) = V(J, m >= c nb) V(c, m >= c nb)' -- the product starts at the column where the
+        // triangular operand does (with whole groups as column blocks the coarse start costs 1.9x the flops on one rank).
+        // One tile column at a time: a wider block may not reach into the next group, whose rows were stored from THEIR
+        // first column on only (measured: two columns at a time are no faster)
+        const int64_t g2 = c * nb_, K = L.Np - g2;
+        rc = ops_->gemm('N', 'T', M, nb_, K, 1.0, Vb + (g2 - gmin) * M, M, Lf + g2 + (g2 + W) * ldf, ldf, 0.0, Z + (g2 - gmin) * M, M,
+                        ST_MAIN);
       }
+      phase("  V V' (a group)");
+      if(rc == GPC_OK) rc = ops_->covgrad_block(Z, M, Mv, nv, al_, L.Np, d_, gmin, 1, ST_MAIN);
+      double tr = 0.0;
+      if(rc == GPC_OK) rc = ops_->sum_diag(Z, M, Mv, &tr, ST_MAIN);
+      if(rc == GPC_OK) rc = ops_->kern_grad_block(&ks_, X_ + gmin, Mv, L.N, X_ + gmin, nv, L.N, D_, Z, M, part.data(), ST_MAIN);
+      trace += tr;
+      for(int p = 0; p < np; p++) acc[(size_t)p] += part[(size_t)p];
+      phase("  covGrad + kernel pass");
     }
     GRID_CHECK(rc);
     // the white terms see only the diagonal of covGrad (CWhiteKern::getGradParams, CKern.cpp:735-739)
@@ -873,6 +1010,14 @@ class GridGp {
     if(receivers_or_flag) stats_.bytes_recv[axis] += bytes;
   }
 
+  int held_alloc(double*& p, int64_t n)
+  {
+    const size_t bytes = sizeof(double) * (size_t)imax(n, 2);
+    const int rc = ops_->alloc((void**)&p, bytes);
+    if(rc == GPC_OK) stats_.bytes_held += (double)bytes;
+    return rc;
+  }
+
   int upload_matrix(double* dst, const double* src, int64_t rows, int64_t cols, int64_t ld)
   {
     if(ld == rows) return ops_->upload(dst, src, sizeof(double) * (size_t)(rows * cols));
@@ -884,7 +1029,7 @@ class GridGp {
   int allocate()
   {
     const Layout& L = L_;
-    auto A = [&](double*& p, int64_t n) { return ops_->alloc((void**)&p, sizeof(double) * (size_t)imax(n, 2)); };
+    auto A = [&](double*& p, int64_t n) { return held_alloc(p, n); };
     GRID_CHECK(A(A_, L.lld * imax(L.nloc, 1)));
     GRID_CHECK(A(X_, L.N * D_));
     GRID_CHECK(A(Xr_, imax(L.Lr, 1) * nb_ * D_));
@@ -942,7 +1087,7 @@ class GridGp {
   {
     if(!ops_) return;
     double** ps[] = {&A_, &X_, &Xr_, &Xc_, &dg_, &Y_, &al_, &alr_, &t_, &Xs_, &W_[0], &W_[1], &V_[0], &V_[1], &Dg_[0], &Dg_[1],
-                     &Lf_, &strip_, &Zg_, &St_};
+                     &Lf_, &strip_, &Zg_, &St_, &Vm_};
     for(double** p : ps)
       if(*p) {
         ops_->release(*p);
@@ -959,6 +1104,7 @@ class GridGp {
         *e = nullptr;
       }
     alpha_valid_ = factored_ = false;
+    stats_.bytes_held = 0;
   }
 
   // The row panel of step k as this rank sees it after panel_phase(k): pointer to the rows below tile k, leading dimension.
@@ -1156,7 +1302,7 @@ class GridGp {
          *alr_ = nullptr, *t_ = nullptr, *Xs_ = nullptr;
   double *W_[2] = {nullptr, nullptr}, *V_[2] = {nullptr, nullptr}, *Dg_[2] = {nullptr, nullptr};
   double* St_ = nullptr;                                      // [tile; rows] of a fused panel step (see fused_rows)
-  double *Lf_ = nullptr, *strip_ = nullptr, *Zg_ = nullptr;   // gradient(): replicated factor, one strip in flight, the solves' block
+  double *Lf_ = nullptr, *strip_ = nullptr, *Zg_ = nullptr, *Vm_ = nullptr;   // gradient(): replicated factor, one strip in flight, the solves' block
   int* info_dev_ = nullptr;
   int64_t* voff_dev_ = nullptr;
   std::vector<int64_t> voff_host_, slot_, region_start_;

@@ -12,6 +12,8 @@
 // 1 KiB runs).  A fixed-size grid strides over the tiles and writes per-workgroup partial sums that the host adds in
 // a fixed order, so the result is deterministic.
 #include "gpc_common.hpp"
+#include <vector>
+#include <string.h>
 #include <string.h>
 #include <stdlib.h>
 
@@ -38,6 +40,19 @@ struct GradArgs {
   int64_t lda;
   int nd;
 };
+
+template <int NW>
+__device__ __forceinline__ double block_sum_n(double v, double* sh)
+{
+  for(int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  __syncthreads();
+  if(lane == 0) sh[w] = v;
+  __syncthreads();
+  double r = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+  if(NW == 8) r += (sh[NW - 4] + sh[NW - 3]) + (sh[NW - 2] + sh[NW - 1]);
+  return r;
+}
 
 __device__ __forceinline__ double block_sum(double v, double* sh)
 {
@@ -455,8 +470,11 @@ __global__ void __launch_bounds__(256) ard_prep_kernel(const KSpecDev ks, const 
   n1[i] = acc;
 }
 
-template <int NK, int ND, int OCC>
-__global__ void __launch_bounds__(256, OCC) kern_grad_ard_sym_kernel(const KSpecDev ks, const GradArgs g, const double* __restrict__ XT,
+// NW waves per workgroup: 4 (each a 64 x 32 patch of the 128 x 64 tile) or 8 (32 x 32 each: half the per-lane state -- the
+// accumulators Y, the covGrad values, the dot products -- so that at D > 16, where the 4-wave form fits one wave per SIMD
+// only, two waves share a SIMD without spilling and cover each other's memory latency).
+template <int NK, int ND, int OCC, int NW = 4>
+__global__ void __launch_bounds__(64 * NW, OCC) kern_grad_ard_sym_kernel(const KSpecDev ks, const GradArgs g, const double* __restrict__ XT,
                                                                    int jt_per_block, double* __restrict__ partial)
 {
   constexpr int QX = (NK > 4) ? 2 : 1;          // 16-wide groups of input dimensions
@@ -464,11 +482,15 @@ __global__ void __launch_bounds__(256, OCC) kern_grad_ard_sym_kernel(const KSpec
   __shared__ double Xj[2][GMDC * GSJ];
   __shared__ double Nj[2][GMJ];
   __shared__ double Xi[NK > 2 ? GMDC * GSI : 1];
-  __shared__ double sh[4];
-  __shared__ double red[4][32];
+  constexpr int NT = 64 * NW;           // threads
+  constexpr int RW = 256 / NW;          // rows of a wave's patch: 64 or 32
+  constexpr int TM = RW / 16;           // its 16-row MFMA tiles: 4 or 2
+  static_assert(NW == 4 || NW == 8, "waves per workgroup");
+  __shared__ double sh[NW];
+  __shared__ double red[NW][32];
   const int t = threadIdx.x;
   const int lane = t & 63, w = t >> 6;
-  const int wm = w & 1, wn = w >> 1;
+  const int wm = w & (NW / 2 - 1), wn = w / (NW / 2);
   const int64_t i0 = (int64_t)blockIdx.x * GMI;
   double* mypartial = partial + ((int64_t)blockIdx.x * gridDim.y + blockIdx.y) * NP_ARDSYM;
   int64_t tiles_j = (g.N + GMJ - 1) / GMJ;
@@ -483,11 +505,11 @@ __global__ void __launch_bounds__(256, OCC) kern_grad_ard_sym_kernel(const KSpec
   const int dc = (int)g.D;   // <= 4 NK
 
   constexpr bool AF_LDS = (NK > 2);
-  double af[AF_LDS ? 1 : NK][4];
+  double af[AF_LDS ? 1 : NK][TM];
   if(AF_LDS) {
 #pragma unroll
-    for(int u = 0; u < (GMDC * GMI) / 256; u++) {
-      const int idx = t + 256 * u;
+    for(int u = 0; u < (GMDC * GMI) / NT; u++) {
+      const int idx = t + NT * u;
       const int kr = idx >> 7, row = idx & 127;
       int64_t gi = i0 + row;
       if(gi > g.N - 1) gi = g.N - 1;
@@ -497,19 +519,19 @@ __global__ void __launch_bounds__(256, OCC) kern_grad_ard_sym_kernel(const KSpec
 #pragma unroll
     for(int kk = 0; kk < (AF_LDS ? 1 : NK); kk++)
 #pragma unroll
-      for(int tm = 0; tm < 4; tm++) {
-        int64_t gi = i0 + wm * 64 + tm * 16 + (lane & 15);
+      for(int tm = 0; tm < TM; tm++) {
+        int64_t gi = i0 + wm * RW + tm * 16 + (lane & 15);
         if(gi > g.N - 1) gi = g.N - 1;
         int kr = kk * 4 + (lane >> 4);
         if(kr > dc - 1) kr = dc - 1;
         af[kk][tm] = (kk * 4 + (lane >> 4) < dc) ? g.X[gi + (int64_t)kr * g.ldx] : 0.0;
       }
   }
-  double ni[4];
-  double ai[ND > 0 ? ND : 1][4];
+  double ni[TM];
+  double ai[ND > 0 ? ND : 1][TM];
 #pragma unroll
-  for(int tm = 0; tm < 4; tm++) {
-    int64_t gi = i0 + wm * 64 + tm * 16 + (lane & 15);
+  for(int tm = 0; tm < TM; tm++) {
+    int64_t gi = i0 + wm * RW + tm * 16 + (lane & 15);
     if(gi > g.N - 1) gi = g.N - 1;
     ni[tm] = g.n1[gi];
 #pragma unroll
@@ -517,13 +539,14 @@ __global__ void __launch_bounds__(256, OCC) kern_grad_ard_sym_kernel(const KSpec
   }
 
   const int ws = __builtin_amdgcn_readfirstlane(w);
-  double vj[8], vn;
+  constexpr int VJ = (GMDC * GMJ) / NT;   // staged values of the column tile per thread: 8 or 4
+  double vj[VJ], vn;
   auto prefetch = [&](int64_t jt) {
     int64_t gj = jt * GMJ + lane;
     if(gj > g.N - 1) gj = g.N - 1;
 #pragma unroll
-    for(int u = 0; u < 8; u++) {
-      const int d = ws + 4 * u;
+    for(int u = 0; u < VJ; u++) {
+      const int d = ws + NW * u;
       vj[u] = 0.0;
       if(d < dc) vj[u] = (g.X + (int64_t)d * g.ldx)[gj];
     }
@@ -532,13 +555,15 @@ __global__ void __launch_bounds__(256, OCC) kern_grad_ard_sym_kernel(const KSpec
   prefetch(jt0);
 
   double s_d2e = 0.0, s_e = 0.0, s_all = 0.0, s_tr = 0.0;
-  double rho[4] = {0.0, 0.0, 0.0, 0.0};
-  gdouble4 Y1[4][QX];
+  double rho[TM];
+#pragma unroll
+  for(int tm = 0; tm < TM; tm++) rho[tm] = 0.0;
+  gdouble4 Y1[TM][QX];
   double Bq[QX];             // sum_j kappa_j x_jq^2 for q = (lane & 15) + 16 qx, over this lane's columns j = 4 r + (lane >> 4)
 #pragma unroll
   for(int qx = 0; qx < QX; qx++) Bq[qx] = 0.0;
 #pragma unroll
-  for(int tm = 0; tm < 4; tm++)
+  for(int tm = 0; tm < TM; tm++)
 #pragma unroll
     for(int qx = 0; qx < QX; qx++) Y1[tm][qx] = (gdouble4){0.0, 0.0, 0.0, 0.0};
   const double hiw = ks.ard_hiw[0];
@@ -548,8 +573,8 @@ __global__ void __launch_bounds__(256, OCC) kern_grad_ard_sym_kernel(const KSpec
     double* Njb = Nj[(jt - jt0) & 1];
     const int64_t j0 = jt * GMJ;
 #pragma unroll
-    for(int u = 0; u < 8; u++) {
-      const int idx = t + 256 * u;
+    for(int u = 0; u < VJ; u++) {
+      const int idx = t + NT * u;
       Xjb[(idx >> 6) * GSJ + (idx & 63)] = vj[u];
     }
     if(t < GMJ) Njb[t] = vn;
@@ -560,7 +585,7 @@ __global__ void __launch_bounds__(256, OCC) kern_grad_ard_sym_kernel(const KSpec
     const bool mirror = (j0 + GMJ <= i0);
     const double wgt = mirror ? 2.0 : 1.0;
     constexpr bool LEAN = (OCC == 2);   // two workgroups per CU: no covGrad held for the next half (the other workgroup's waves cover the latency)
-    double c[LEAN ? 1 : 2][4][4];
+    double c[LEAN ? 1 : 2][4][TM];
     auto load_cg = [&](int tn) {
 #pragma unroll
       for(int r = 0; r < 4; r++) {
@@ -570,8 +595,8 @@ __global__ void __launch_bounds__(256, OCC) kern_grad_ard_sym_kernel(const KSpec
 #pragma unroll
         for(int o = 0; o < ND; o++) aj[o] = g.A[gjc + (int64_t)o * g.lda];
 #pragma unroll
-        for(int tm = 0; tm < 4; tm++) {
-          const int64_t gi = i0 + wm * 64 + tm * 16 + (lane & 15);
+        for(int tm = 0; tm < TM; tm++) {
+          const int64_t gi = i0 + wm * RW + tm * 16 + (lane & 15);
           const int64_t gic = (gi < g.N) ? gi : (g.N - 1);
           double v = g.cg[gic + gjc * g.ldc];
           if(ND > 0) {
@@ -598,16 +623,16 @@ __global__ void __launch_bounds__(256, OCC) kern_grad_ard_sym_kernel(const KSpec
 #pragma unroll
         for(int qx = 0; qx < QX; qx++) xc[r][qx] = XT[jj * DP + qx * 16 + (lane & 15)];
       }
-      gdouble4 acc[4];
+      gdouble4 acc[TM];
 #pragma unroll
-      for(int a = 0; a < 4; a++) acc[a] = (gdouble4){0.0, 0.0, 0.0, 0.0};
+      for(int a = 0; a < TM; a++) acc[a] = (gdouble4){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
       for(int kk = 0; kk < NK; kk++) {   // (fully unrolled: as a loop of two-step bodies it costs 100 more registers)
         const int kr = kk * 4 + (lane >> 4);
         const double b = Xjb[kr * GSJ + wn * 32 + tn * 16 + (lane & 15)];
 #pragma unroll
-        for(int tm = 0; tm < 4; tm++) {
-          const double a = AF_LDS ? Xi[kr * GSI + wm * 64 + tm * 16 + (lane & 15)] : af[AF_LDS ? 0 : kk][tm];
+        for(int tm = 0; tm < TM; tm++) {
+          const double a = AF_LDS ? Xi[kr * GSI + wm * RW + tm * 16 + (lane & 15)] : af[AF_LDS ? 0 : kk][tm];
           acc[tm] = __builtin_amdgcn_mfma_f64_16x16x4f64(b, a, acc[tm], 0, 0, 0);
         }
       }
@@ -619,11 +644,11 @@ __global__ void __launch_bounds__(256, OCC) kern_grad_ard_sym_kernel(const KSpec
         const int64_t gj = j0 + jl;
         const double nj = Njb[jl];
 #pragma unroll
-        for(int th = 0; th < 4; th += 2) {
+        for(int th = 0; th < TM; th += 2) {
 #pragma unroll
           for(int u = 0; u < 2; u++) {
             const int tm = th + u;
-            const int64_t gi = i0 + wm * 64 + tm * 16 + (lane & 15);
+            const int64_t gi = i0 + wm * RW + tm * 16 + (lane & 15);
             const double cw = c[LEAN ? 0 : tn][r][tm] * wgt;
             const bool isdiag = (gi == gj);
             const double cm = isdiag ? 0.0 : cw;
@@ -643,7 +668,8 @@ __global__ void __launch_bounds__(256, OCC) kern_grad_ard_sym_kernel(const KSpec
       // kappa_j and x_jq
 #pragma unroll
       for(int r = 0; r < 4; r++) {
-        double kap = (acc[0][r] + acc[1][r]) + (acc[2][r] + acc[3][r]);
+        double kap = acc[0][r] + acc[1][r];
+        if(TM == 4) kap += acc[TM - 2][r] + acc[TM - 1][r];
         kap += __shfl_xor(kap, 1, 64);
         kap += __shfl_xor(kap, 2, 64);
         kap += __shfl_xor(kap, 4, 64);
@@ -653,7 +679,7 @@ __global__ void __launch_bounds__(256, OCC) kern_grad_ard_sym_kernel(const KSpec
           const double x1 = xc[r][qx];
           Bq[qx] = fma(kap * x1, x1, Bq[qx]);
 #pragma unroll
-          for(int tm = 0; tm < 4; tm++) Y1[tm][qx] = __builtin_amdgcn_mfma_f64_16x16x4f64(x1, acc[tm][r], Y1[tm][qx], 0, 0, 0);
+          for(int tm = 0; tm < TM; tm++) Y1[tm][qx] = __builtin_amdgcn_mfma_f64_16x16x4f64(x1, acc[tm][r], Y1[tm][qx], 0, 0, 0);
         }
       }
     }
@@ -670,7 +696,7 @@ __global__ void __launch_bounds__(256, OCC) kern_grad_ard_sym_kernel(const KSpec
 #pragma unroll
   for(int p = 0; p < NP_MAIN; p++) {
     if(p == 8 || p == 9 || p == 12 || p == 13) {
-      const double rsum = block_sum(out[p], sh);
+      const double rsum = block_sum_n<NW>(out[p], sh);
       if(t == 0) mypartial[p] = rsum;
     } else if(t == 0) {
       mypartial[p] = 0.0;
@@ -678,13 +704,13 @@ __global__ void __launch_bounds__(256, OCC) kern_grad_ard_sym_kernel(const KSpec
   }
   // rho_i over the four column groups of the wave (lanes with the same lane & 15)
 #pragma unroll
-  for(int tm = 0; tm < 4; tm++) {
+  for(int tm = 0; tm < TM; tm++) {
     rho[tm] += __shfl_xor(rho[tm], 16, 64);
     rho[tm] += __shfl_xor(rho[tm], 32, 64);
   }
   // sum_i (rho_i x_iq^2 - 2 x_iq Y(q,i)): this lane's dimensions are q = (lane >> 4) + 4 r + 16 qx, its rows lane & 15 of each of
   // the wave's four 16-row tiles
-  if(t < 128) red[t >> 5][t & 31] = 0.0;
+  if(t < 32 * NW) red[t >> 5][t & 31] = 0.0;
   __syncthreads();
 #pragma unroll
   for(int qx = 0; qx < QX; qx++)
@@ -693,8 +719,8 @@ __global__ void __launch_bounds__(256, OCC) kern_grad_ard_sym_kernel(const KSpec
       const int q = (lane >> 4) + 4 * r + 16 * qx;
       double v = 0.0;
 #pragma unroll
-      for(int tm = 0; tm < 4; tm++) {
-        int64_t gi = i0 + wm * 64 + tm * 16 + (lane & 15);
+      for(int tm = 0; tm < TM; tm++) {
+        int64_t gi = i0 + wm * RW + tm * 16 + (lane & 15);
         if(gi > g.N - 1) gi = g.N - 1;                              // (rows past the end carry zero weights)
         const double x = (q < dc) ? g.X[gi + (int64_t)q * g.ldx] : 0.0;
         v += x * fma(rho[tm], x, -2.0 * Y1[tm][qx][r]);
@@ -716,7 +742,11 @@ __global__ void __launch_bounds__(256, OCC) kern_grad_ard_sym_kernel(const KSpec
     if(lane < 16) red[w][lane + 16 * qx] += (v + v1) + (v2 + v3);
   }
   __syncthreads();
-  if(t < 32) mypartial[NP_MAIN + t] = (red[0][t] + red[1][t]) + (red[2][t] + red[3][t]);
+  if(t < 32) {
+    double v = (red[0][t] + red[1][t]) + (red[2][t] + red[3][t]);
+    if(NW == 8) v += (red[NW - 4][t] + red[NW - 3][t]) + (red[NW - 2][t] + red[NW - 1][t]);
+    mypartial[NP_MAIN + t] = v;
+  }
 }
 
 template <int ND>
@@ -733,6 +763,31 @@ int launch_grad_ard_sym(const KSpecDev& ks, const GradArgs& g, const double* XT,
     occ_env = e ? atoi(e) : 0;
   }
   const int occ8 = occ_env ? occ_env : (g.D <= 16 ? 2 : 1);
+  // D > 8: eight waves of 32 x 32 patches, one workgroup per CU = two waves per SIMD without spills (246 registers; the four-wave
+  // form needs 452 at D = 32, i.e. one wave per SIMD).  N = 65 536: D = 32 11.7 -> 10.2 ms, D = 16 8.7 -> 8.0 ms; at D <= 8 the
+  // four-wave form at two workgroups per CU stays ahead (6.8 against 7.2 ms).  PMC (profiles/r03_pmc_kgrad_ard.txt, D = 32): the
+  // matrix pipe is busy 36 % -> 43 % of the time, 1.9e9 vector instructions beside 5.4e8 MFMA ops: the exponentials and the
+  // weights are as much work as the two products.  GPC_KGRAD_ARD_NW=4 / 8 forces a form.
+  static int nw_env = -1;
+  if(nw_env < 0) {
+    const char* e = getenv("GPC_KGRAD_ARD_NW");
+    nw_env = e ? atoi(e) : 0;
+  }
+  if((g.D > 8 && nw_env != 4) || nw_env == 8 || nw_env == 82) {
+    const int occ = (nw_env == 82) ? 2 : 1;     // (8 / 82: eight waves at every D, one / two workgroups per CU; A/B runs)
+#define GPC_ARD_LAUNCH8(NKV)                                                                                                    \
+  do {                                                                                                                            \
+    if(occ == 1) hipLaunchKernelGGL((kern_grad_ard_sym_kernel<NKV, ND, 1, 8>), grid, dim3(512), 0, s, ks, g, XT, per, partial);   \
+    else hipLaunchKernelGGL((kern_grad_ard_sym_kernel<NKV, ND, 2, 8>), grid, dim3(512), 0, s, ks, g, XT, per, partial);           \
+  } while(0)
+    if(g.D <= 4) GPC_ARD_LAUNCH8(1);
+    else if(g.D <= 8) GPC_ARD_LAUNCH8(2);
+    else if(g.D <= 16) GPC_ARD_LAUNCH8(4);
+    else GPC_ARD_LAUNCH8(8);
+#undef GPC_ARD_LAUNCH8
+    GPC_HIP_CHECK(hipGetLastError());
+    return GPC_OK;
+  }
 #define GPC_ARD_LAUNCH(NKV)                                                                                              \
   do {                                                                                                                     \
     if(occ8 == 1)                                                                                                          \
@@ -860,8 +915,90 @@ int fetch_partials(const double* d_p, int64_t nblk, int np, double* sums, hipStr
 
 using namespace gpc;
 
-static int kern_grad_impl(const gpc_kspec* ksp, const double* X, int64_t N, int64_t D, int64_t ldx, const double* covGrad,
+static int kern_grad_pass(const gpc_kspec* ksp, const double* X, int64_t N, int64_t D, int64_t ldx, const double* covGrad,
                           int64_t ldc, const double* A, int64_t lda, int nd, double* gout, hipStream_t s, bool* took_fused);
+
+// The parameter gradient is a sum over covGrad that separates by term: dK/dtheta of a term's parameter involves that term
+// alone (CCmpndKern::getGradParams, CKern.cpp:284-298, simply concatenates its components' results).  So a compound outside the
+// domain of ONE of the fast symmetric kernels -- an rbfard term beside rbf / lin terms, more than two rbf terms, several
+// rbfard terms -- is evaluated in several passes over (half of) covGrad, each on the fast kernel of its terms, instead of one
+// pass of the scalar kernel over all of it (0.7-1.5 TB/s): the distance terms two rbf at a time together with every lin /
+// bias / white term, each rbfard term alone (the first one takes bias / white along when there is no distance term).
+static int kern_grad_impl(const gpc_kspec* ksp, const double* X, int64_t N, int64_t D, int64_t ldx, const double* covGrad,
+                          int64_t ldc, const double* A, int64_t lda, int nd, double* gout, hipStream_t s, bool* took_fused)
+{
+  if(!ksp || ksp->n_terms < 0 || ksp->n_terms > GPC_MAX_TERMS) {
+    set_error("kernel spec: bad term count");
+    return GPC_EINVAL;
+  }
+  int n_rbf = 0, n_ard = 0, n_lin = 0;
+  for(int t = 0; t < ksp->n_terms; t++) {
+    n_rbf += ksp->types[t] == GPC_KERN_RBF;
+    n_ard += ksp->types[t] == GPC_KERN_RBFARD;
+    n_lin += ksp->types[t] == GPC_KERN_LIN;
+  }
+  const bool has_dot = n_rbf + n_lin > 0;
+  static int split = -1;
+  if(split < 0) {
+    const char* e = getenv("GPC_KGRAD_SPLIT");     // 0: mixed compounds on the one-pass scalar kernel, as before (A/B runs)
+    split = e ? atoi(e) : 1;
+  }
+  const bool one_pass = (n_ard == 0 && n_rbf <= 2) || (n_ard == 1 && !has_dot) || (!split && n_ard <= 1 && n_rbf <= 4);
+  if(one_pass) return kern_grad_pass(ksp, X, N, D, ldx, covGrad, ldc, A, lda, nd, gout, s, took_fused);
+  // chunk 0: all lin / bias / white terms with the first two rbf terms (or, without distance terms, with the first rbfard
+  // term); then two rbf terms per chunk; then one rbfard term per chunk
+  std::vector<std::vector<int>> chunks(1);
+  int rbf_in0 = 0;
+  bool ard_in0 = false;
+  std::vector<int> later_rbf, later_ard;
+  for(int t = 0; t < ksp->n_terms; t++) {
+    const int ty = ksp->types[t];
+    if(ty == GPC_KERN_RBF) {
+      if(rbf_in0 < 2) { chunks[0].push_back(t); rbf_in0++; }
+      else later_rbf.push_back(t);
+    } else if(ty == GPC_KERN_RBFARD) {
+      if(!has_dot && !ard_in0) { chunks[0].push_back(t); ard_in0 = true; }
+      else later_ard.push_back(t);
+    } else {
+      chunks[0].push_back(t);
+    }
+  }
+  for(size_t i = 0; i < later_rbf.size(); i += 2) {
+    chunks.push_back(std::vector<int>(later_rbf.begin() + (long)i, later_rbf.begin() + (long)(i + 2 < later_rbf.size() ? i + 2 : later_rbf.size())));
+  }
+  for(int t : later_ard) chunks.push_back(std::vector<int>(1, t));
+  const int nparams = ksp->offs[ksp->n_terms];
+  for(int p = 0; p < nparams; p++) gout[p] = 0.0;
+  bool all_fused = true;
+  for(const std::vector<int>& ch : chunks) {
+    if(ch.empty()) continue;
+    gpc_kspec sub;
+    memset(&sub, 0, sizeof(sub));
+    for(int t : ch) {
+      const int off = ksp->offs[t], np = ksp->offs[t + 1] - off;
+      if(off < 0 || np < 0 || off + np > GPC_MAX_PARAMS) {
+        set_error("kernel spec: bad parameter offsets");
+        return GPC_EINVAL;
+      }
+      const int o = sub.offs[sub.n_terms];
+      sub.types[sub.n_terms] = ksp->types[t];
+      for(int q = 0; q < np; q++) sub.params[o + q] = ksp->params[off + q];
+      sub.offs[sub.n_terms + 1] = o + np;
+      sub.n_terms++;
+    }
+    double gsub[GPC_MAX_PARAMS];
+    bool took = false;
+    GPC_CHECK(kern_grad_pass(&sub, X, N, D, ldx, covGrad, ldc, A, lda, nd, gsub, s, &took));
+    all_fused = all_fused && took;
+    if(nd > 0 && !took) break;     // a fused request one of the passes cannot take: the caller materialises covGrad
+    for(int i = 0; i < sub.n_terms; i++) {
+      const int t = ch[(size_t)i];
+      for(int q = 0; q < sub.offs[i + 1] - sub.offs[i]; q++) gout[ksp->offs[t] + q] = gsub[sub.offs[i] + q];
+    }
+  }
+  if(took_fused) *took_fused = all_fused;
+  return GPC_OK;
+}
 
 extern "C" int gpc_kern_grad_f64(const gpc_kspec* ksp, const double* X, int64_t N, int64_t D, int64_t ldx,
                                  const double* covGrad, int64_t ldc, double* gout, void* stream)
@@ -889,7 +1026,7 @@ extern "C" int gpc_kern_grad_fused_f64(const gpc_kspec* ksp, const double* X, in
   return took ? GPC_OK : GPC_EUNSUPPORTED;
 }
 
-static int kern_grad_impl(const gpc_kspec* ksp, const double* X, int64_t N, int64_t D, int64_t ldx, const double* covGrad,
+static int kern_grad_pass(const gpc_kspec* ksp, const double* X, int64_t N, int64_t D, int64_t ldx, const double* covGrad,
                           int64_t ldc, const double* A, int64_t lda, int nd, double* gout, hipStream_t s, bool* took_fused)
 {
   KSpecDev ks;

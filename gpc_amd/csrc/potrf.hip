@@ -566,6 +566,15 @@ struct LookAhead {
 };
 thread_local LookAhead g_la;   // per host thread, like the scratch buffers (capi.hip)
 
+void release_lookahead_impl()
+{
+  for(hipEvent_t e : g_la.ev) (void)hipEventDestroy(e);
+  g_la.ev.clear();
+  g_la.next = 0;
+  if(g_la.panel) (void)hipStreamDestroy(g_la.panel);
+  g_la.panel = nullptr;
+}
+
 int ensure_lookahead()
 {
   int dev = 0;
@@ -659,6 +668,8 @@ int factor_panel(int64_t N, double* A, int64_t lda, int64_t k0, int64_t nbk, int
 }
 
 }  // namespace
+
+void release_lookahead() { release_lookahead_impl(); }   // gpc_shutdown (capi.hip)
 
 // Factor one tall panel (M x nb, M >= nb): diagonal blocks + substitution solve + in-panel updates.  Used by the
 // multi-GPU grid when one rank holds the whole panel (grid.hip: a 1 x pc grid).

@@ -72,6 +72,20 @@ void prof_end(int kind, hipStream_t s)
   g_open[kind] = false;
 }
 
+void release_profile()
+{
+  for(int k = 0; k < PROF_NKINDS; k++) {
+    for(Rec& r : g_recs[k]) g_pool.push_back(r);
+    g_recs[k].clear();
+    g_open[k] = false;
+  }
+  for(Rec& r : g_pool) {
+    (void)hipEventDestroy(r.a);
+    (void)hipEventDestroy(r.b);
+  }
+  g_pool.clear();
+}
+
 }  // namespace gpc
 
 using namespace gpc;

@@ -833,6 +833,14 @@ int trsm(char side, char uplo, char trans, char diag, int64_t M, int64_t Nrhs, d
   return trsm_impl(sd == 'L', ul == 'L', tc != 'N', dg == 'U', M, Nrhs, alpha, A, lda, B, ldb, false, s);
 }
 
+// B (M x n, M <= n) holds the first M rows of the identity; B := B L^-T for the lower-triangular n x n L: rows of V = L^-T.
+// Row i is zero left of column i until the sweep gets there, so the rows beyond the current column block are skipped
+// (trsm_impl's tri_rhs: the work is what the rows' own lengths ask for, not M n^2).
+int trsm_right_lt_identity(int64_t M, int64_t n, const double* L, int64_t ldl, double* B, int64_t ldb, hipStream_t s)
+{
+  return trsm_impl(false, true, true, false, M, n, 1.0, L, ldl, B, ldb, true, s);
+}
+
 int set_identity(int64_t M, int64_t N, double* B, int64_t ldb, hipStream_t s)
 {
   for(int64_t j0 = 0; j0 < N; j0 += 32768) {

@@ -118,7 +118,7 @@ class Grid(object):
         out = (c_double * 8)()
         self.b.check(self.b.stats(self.h, out, 1 if reset else 0), self.h)
         return {"bytes_row": out[0], "bytes_col": out[1], "bytes_world": out[2], "collectives": int(out[3]),
-                "update_flops": out[4], "update_launches": int(out[5]), "update_bytes": out[6]}
+                "update_flops": out[4], "update_launches": int(out[5]), "update_bytes": out[6], "bytes_held": out[7]}
 
     def set_lookahead(self, on):
         self.b.check(self.b.set_lookahead(self.h, 1 if on else 0), self.h)

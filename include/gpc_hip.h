@@ -50,7 +50,7 @@ extern "C" {
 #define GPC_KERN_WHITE 3
 #define GPC_KERN_BIAS 4
 #define GPC_KERN_LIN 5
-#define GPC_MAX_TERMS 8
+#define GPC_MAX_TERMS 16
 #define GPC_MAX_PARAMS 160
 #define GPC_MAX_ARD_DIM 64
 
@@ -65,6 +65,11 @@ typedef struct gpc_kspec {
 int gpc_version(void);                           /* 100*major + minor */
 const char* gpc_last_error(void);                /* text of the last GPC_EHIP / GPC_EINVAL on this thread */
 int gpc_device_count(int* count);
+/* Synchronises every device and releases what the library holds for the calling thread (look-ahead stream and events,
+ * profiling events, scratch).  Registered with atexit() at the first device call, so that the library is out of the way
+ * before the HIP runtime's own exit-time teardown; a host that unloads the library earlier (dlclose, a mex file being
+ * cleared) calls it itself.  Safe to call more than once; later calls into the library re-create what they need. */
+int gpc_shutdown(void);
 int gpc_set_device(int device);
 int gpc_device_info(char* name, size_t name_len, int* cu_count, size_t* hbm_bytes, int* clock_khz);
 
@@ -201,8 +206,9 @@ int gpc_grid_alpha(gpc_grid* g, double* alpha_host, int64_t lda);              /
 int gpc_grid_posterior(gpc_grid* g, double* mu_host, int64_t ldmu, double* var_host);   /* before output scale / bias */
 /* CGp::updateG (CGp.cpp:1080-1117): g[p] = sum_ij covGrad(i,j) dK(i,j)/dtheta_p, natural kernel parameters in spec order
  * (offs[n_terms] doubles), covGrad = -0.5 (d K^-1 - Alpha Alpha').  The factor is replicated (it must fit one GPU next to
- * the local block: N <= ~170 000 on 288 GB) and every rank solves for its own tile columns of K^-1: (2/3) N^3 / P flops per
- * rank, no distributed dpotri.  Cross-block kernel pass: D <= 32 without an rbfard term, D <= 16 with one. */
+ * the local block: N <= ~170 000 on 288 GB; gpc_grid_stats out[7] reports what a rank holds) and every rank forms its own
+ * groups of tile rows of K^-1 by two right-sided solves on the trailing block: (2/3) N^3 / P flops per rank, no distributed
+ * dpotri.  Cross-block kernel pass: D <= 32 without an rbfard term, D <= 16 with one. */
 int gpc_grid_gradient(gpc_grid* g, double* g_host);
 int gpc_grid_sync(gpc_grid* g);
 int gpc_grid_barrier(gpc_grid* g);
@@ -217,7 +223,8 @@ int gpc_grid_set_lookahead(gpc_grid* g, int on);
  * I mod pr in even rounds I / pr and on pr-1 - I mod pr in odd ones; 0: plain cyclic) */
 int gpc_grid_info(gpc_grid* g, int64_t* out);
 /* out[8] = bytes received along the process row / column / world, collectives entered, algorithmic flops of this rank's
- * trailing updates, their launches, their algorithmic HBM bytes, 0 -- since the last reset */
+ * trailing updates, their launches, their algorithmic HBM bytes -- since the last reset -- and out[7] = the device bytes this
+ * rank's problem holds (local block, panel buffers, and the gradient's replicated factor once gpc_grid_gradient has run) */
 int gpc_grid_stats(gpc_grid* g, double* out, int reset);
 /* tests: tile (I, J) of the factor to the host (nb x nb, leading dimension nb; I == T addresses the extra rows);
  * *owned = 0 and nothing copied when the tile lives on another rank */

@@ -24,7 +24,7 @@
 #define ORC_KERN_WHITE 3
 #define ORC_KERN_BIAS 4
 #define ORC_KERN_LIN 5
-#define ORC_MAX_TERMS 8
+#define ORC_MAX_TERMS 16
 #define ORC_MAX_PARAMS 160
 
 /* same layout as struct gpc_kspec (include/gpc_hip.h) */

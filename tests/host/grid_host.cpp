@@ -246,15 +246,21 @@ struct HostOps : GridOps {
     *out = s;
     return GPC_OK;
   }
+  int trsm_right(const double* L, int64_t ldl, int64_t n, bool trans, bool, double* B, int64_t ldb, int64_t M, int) override
+  {
+    orc_trsm('R', 'L', trans ? 'T' : 'N', 'N', (long)M, (long)n, 1.0, L, (long)ldl, B, (long)ldb);
+    return GPC_OK;
+  }
   int covgrad_block(double* S, int64_t lds, int64_t M, int64_t nbc, const double* Al, int64_t lda, int64_t nd, int64_t g0,
-                    int) override
+                    int upper, int) override
   {
     for(int64_t j = 0; j < nbc; j++)
       for(int64_t i = 0; i < M; i++) {
         double aa = 0.0;
         for(int64_t o = 0; o < nd; o++) aa += Al[g0 + i + o * lda] * Al[g0 + j + o * lda];
         const double c = -0.5 * ((double)nd * S[i + j * lds] - aa);
-        S[i + j * lds] = i > j ? 2.0 * c : (i == j ? c : 0.0);
+        const bool twice = upper ? j > i : i > j;
+        S[i + j * lds] = twice ? 2.0 * c : (i == j ? c : 0.0);
       }
     return GPC_OK;
   }

@@ -382,7 +382,10 @@ def test_kern_grad_fused_covgrad(api, N, D, d):
     want = api.kern_grad(ard, Xd, cg)
     assert np.abs(got - want).max() <= 1e-12 * max(1.0, np.abs(want).max())
     mixed = api.kspec([("rbfard", [1.0, 1.0] + [0.5] * D), ("lin", [0.2])])
-    assert api.kern_grad_fused(mixed, Xd, Id, Ad) is None                               # outside the fused passes: refused
+    got = api.kern_grad_fused(mixed, Xd, Id, Ad)            # two fused passes: the lin term, then the rbfard term on its own
+    assert got is not None
+    want = api.kern_grad(mixed, Xd, cg)
+    assert np.abs(got - want).max() <= 1e-12 * max(1.0, np.abs(want).max())
     assert api.kern_grad_fused(ks, Xd, Id, api.from_host(rng.randn(N, 3))) is None
 
 
@@ -854,12 +857,141 @@ def test_error_behaviour_of_the_c_abi(api):
     with pytest.raises(_lib.GpcError) as e:
         api.gram_sym(ks, api.from_host(np.zeros((3, 2))))
     assert e.value.rc == _lib.GPC_EUNSUPPORTED
-    ks5 = api.kspec([("rbf", [1.0, 1.0])] * 5)                    # more rbf terms than one pass handles
-    with pytest.raises(_lib.GpcError):
-        api.gram_sym(ks5, api.from_host(np.zeros((3, 2))))
+    ks5 = api.kspec([("rbf", [1.0, 1.0])] * 5)                    # more rbf terms than one pass holds: a second pass, no refusal
+    assert np.array_equal(api.to_host(api.gram_sym(ks5, api.from_host(np.zeros((3, 2))))), np.full((3, 3), 5.0))
     X17 = api.from_host(np.zeros((8, 17)))                        # latent-gradient passes cover D <= 16
     with pytest.raises(_lib.GpcError) as e:
         api.kern_gradx(api.kspec([("rbf", [1.0, 1.0])]), X17, api.from_host(np.zeros((8, 8))))
     assert e.value.rc == _lib.GPC_EUNSUPPORTED
     # a failed call leaves the library usable
     assert api.potrf(api.from_host(np.eye(4) * 4.0), "L") == 0
+
+
+def test_two_host_threads_drive_two_models(api, golden):
+    """The contract of include/gpc_hip.h: scratch, the look-ahead stream and its events, the GEMM role flags and the error text
+    belong to the calling host thread, so two threads may drive two models at once (each on a stream of its own).  Two
+    different problems -- one large enough for look-ahead panels and the dataflow kernels, one with an rbfard term --
+    evaluated concurrently, repeatedly, must give the bits they give when evaluated alone."""
+    import threading
+    import torch
+    from gpc_amd.gp import CGp
+    from gpc_amd import synth
+    Xa, ya = synth.make_xy(3000, 8, 11)
+    Xb, yb = synth.make_xy(1500, 4, 12)
+    ka = [("rbf", [0.5, 1.0]), ("white", [0.05])]
+    kb = [("rbfard", [1.2, 0.9, 0.8, 0.3, 0.6, 0.45]), ("bias", [0.1]), ("white", [0.05])]
+    Xs = synth.make_xstar(16, 8, 3)
+
+    def evaluate(kern, X, y, xs):
+        m = CGp(kern, X, y)
+        g, ll = m.logLikelihoodGradient()
+        mu, var = m.posteriorMeanVar(xs)
+        return ll, np.array(g), np.array(mu), np.array(var)
+
+    alone = [evaluate(ka, Xa, ya, Xs), evaluate(kb, Xb, yb, Xs[:, :4])]
+    out, err = [[], []], []
+
+    def work(i, kern, X, y, xs):
+        try:
+            with torch.cuda.stream(torch.cuda.Stream()):
+                for _ in range(4):
+                    out[i].append(evaluate(kern, X, y, xs))
+                torch.cuda.current_stream().synchronize()
+        except BaseException as e:   # noqa: B902
+            err.append(e)
+
+    ts = [threading.Thread(target=work, args=(0, ka, Xa, ya, Xs)), threading.Thread(target=work, args=(1, kb, Xb, yb, Xs[:, :4]))]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not err, err
+    for i in range(2):
+        assert len(out[i]) == 4
+        for got in out[i]:
+            assert got[0] == alone[i][0]
+            for a, b in zip(got[1:], alone[i][1:]):
+                assert np.array_equal(a, b)
+
+
+def _np_kernel_and_grads(terms, X, cg):
+    """dense numpy K (sym) and the parameter sums sum_ij cg(i,j) dK(i,j)/dtheta for rbf / rbfard / lin / bias / white terms"""
+    N = X.shape[0]
+    G = X @ X.T
+    n = np.diag(G)
+    d2 = np.maximum(n[:, None] + n[None, :] - 2.0 * G, 0.0)
+    np.fill_diagonal(d2, 0.0)
+    K = np.zeros((N, N))
+    g = []
+    for name, p in terms:
+        if name == "rbf":
+            kt = np.exp(-0.5 * p[0] * d2)
+            K += p[1] * kt
+            g += [float((cg * (-0.5 * p[1] * d2 * kt)).sum()), float((cg * kt).sum())]
+        elif name == "rbfard":
+            s = np.asarray(p[2:])
+            dq = (X[:, None, :] - X[None, :, :]) ** 2
+            da = (dq * s).sum(-1)
+            kt = np.exp(-0.5 * p[0] * da)
+            K += p[1] * kt
+            g += [float((cg * (-0.5 * p[1] * da * kt)).sum()), float((cg * kt).sum())]
+            g += [float((cg * (-0.5 * p[0] * p[1] * dq[:, :, q] * kt)).sum()) for q in range(X.shape[1])]
+        elif name == "lin":
+            K += p[0] * G
+            g.append(float((cg * G).sum()))
+        elif name == "bias":
+            K += p[0]
+            g.append(float(cg.sum()))
+        elif name == "white":
+            K += p[0] * np.eye(N)
+            g.append(float(np.trace(cg)))
+    return K, np.array(g)
+
+
+@pytest.mark.parametrize("N,D,terms", [
+    (300, 4, [("rbfard", [1.1, 0.8, 0.7, 0.4, 0.55, 0.3]), ("rbf", [0.6, 0.9]), ("lin", [0.2]), ("bias", [0.1]), ("white", [0.05])]),
+    (517, 8, [("rbf", [1.3, 0.7]), ("rbfard", [0.9, 0.5] + [0.2 + 0.1 * q for q in range(8)]), ("white", [0.05])]),
+    (260, 3, [("rbfard", [1.1, 0.8, 0.7, 0.4, 0.55]), ("rbfard", [0.4, 1.2, 0.3, 0.9, 0.15]), ("bias", [0.1]), ("white", [0.02])]),
+    (333, 5, [("rbf", [0.2 * (i + 1), 0.3 + 0.1 * i]) for i in range(6)] + [("white", [0.05])]),
+    (200, 20, [("rbfard", [0.7, 0.8] + [0.1 + 0.04 * q for q in range(20)]), ("rbf", [0.3, 0.5]), ("white", [0.05])]),
+    (150, 2, [("rbfard", [1.0, 0.5, 0.3, 0.6]), ("rbfard", [2.0, 0.25, 0.9, 0.1]), ("rbfard", [0.5, 0.7, 0.5, 0.5]), ("rbf", [1.0, 0.2]),
+              ("rbf", [3.0, 0.1]), ("rbf", [0.1, 0.4]), ("lin", [0.3]), ("bias", [0.2]), ("white", [0.01])])])
+def test_compounds_beyond_one_pass(api, N, D, terms):
+    """CCmpndKern has no limit on its components (CKern.h:382-433).  Compounds outside what ONE pass of the kernels holds --
+    an rbfard term beside rbf / lin terms, several rbfard terms, more than four rbf terms -- are built / differentiated in
+    several passes (gram.hip: accumulate passes; kern_grad.hip: one pass per group of terms on the fast symmetric kernels)
+    and must agree with the defining sums: symmetric Gram, cross Gram, diagonal, parameter gradient, the fused-covGrad form."""
+    rng = np.random.RandomState(N + D)
+    X = rng.randn(N, D) / np.sqrt(D)
+    cg = rng.randn(N, N)
+    cg = cg + cg.T
+    K, want = _np_kernel_and_grads(terms, X, cg)
+    ks = api.kspec(terms)
+    Xd = api.from_host(X)
+    Kg = api.to_host(api.gram_sym(ks, Xd))
+    assert np.abs(Kg - K).max() < 1e-12 * max(1.0, np.abs(K).max())
+    assert np.abs(api.to_host(api.gram_diag(ks, Xd)).ravel() - np.diag(K)).max() < 1e-13 * np.abs(K).max()
+    X2 = rng.randn(77, D) / np.sqrt(D)
+    Kc = api.to_host(api.gram_cross(ks, Xd, api.from_host(X2)))
+    Kfull, _ = _np_kernel_and_grads([t for t in terms if t[0] != "white"], np.vstack([X, X2]), np.zeros((N + 77, N + 77)))
+    assert np.abs(Kc - Kfull[:N, N:]).max() < 1e-12 * max(1.0, np.abs(K).max())
+    got = api.kern_grad(ks, Xd, api.from_host(cg))
+    assert np.abs(got - want).max() <= 1e-11 * max(1.0, np.abs(want).max()) * max(1.0, N / 10.0)
+    assert np.array_equal(got, api.kern_grad(ks, Xd, api.from_host(cg)))
+    # the model on top: the gradient of the log-likelihood by central differences of the log-likelihood itself
+    from gpc_amd.gp import CGp
+    y = np.sin(X.sum(1, keepdims=True)) + 0.1 * rng.randn(N, 1)
+    m = CGp(terms, X, y, ref_trans_rounding=False)
+    g0, ll0 = m.logLikelihoodGradient()
+    p0 = np.array(m.getOptParams()).ravel()
+    for idx in (0, len(p0) // 2, len(p0) - 1):
+        h = 1e-5
+        lls = []
+        for sgn in (1.0, -1.0):
+            p = p0.copy()
+            p[idx] += sgn * h
+            m.setOptParams(p)
+            lls.append(m.logLikelihood())
+        fd = (lls[0] - lls[1]) / (2 * h)
+        assert abs(fd - g0[idx]) <= 2e-5 * max(1.0, abs(g0[idx])), (idx, fd, g0[idx])
+    m.setOptParams(p0)

@@ -202,7 +202,12 @@ struct TraceOps : GridOps {
     s->op(st, "download", "\"bytes\":8");
     return GPC_OK;
   }
-  int covgrad_block(double*, int64_t, int64_t M, int64_t nbc, const double*, int64_t, int64_t, int64_t, int st) override
+  int trsm_right(const double*, int64_t, int64_t n, bool, bool, double*, int64_t, int64_t M, int st) override
+  {
+    s->op(st, "trsm_right", "\"rows\":%lld,\"n\":%lld", (long long)M, (long long)n);
+    return GPC_OK;
+  }
+  int covgrad_block(double*, int64_t, int64_t M, int64_t nbc, const double*, int64_t, int64_t, int64_t, int, int st) override
   {
     s->op(st, "small", "\"bytes\":%lld", (long long)(16 * M * nbc));
     return GPC_OK;

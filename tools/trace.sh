@@ -3,7 +3,7 @@
 export TMPDIR=/tmp
 L=$1; shift
 rm -rf /tmp/tr_$L; cd /tmp
-rocprofv3 --kernel-trace --stats -d /tmp/tr_$L -o t -- "$@" > /tmp/tr_$L.out 2>&1
+( cd ${GRAFT_REPO_ROOT:-.}; rocprofv3 --kernel-trace --stats -d /tmp/tr_$L -o t -- "$@" ) > /tmp/tr_$L.out 2>&1
 python - /tmp/tr_$L <<'PY'
 import sqlite3, glob, sys
 for f in glob.glob(sys.argv[1] + "/**/*.db", recursive=True):
