@@ -106,7 +106,12 @@ int workspace(int slot, size_t bytes, void** out)
     }
     w.bytes = want;
     w.dev = dev;
-    if(slot == WS_INFO) GPC_HIP_CHECK(hipMemset(w.p, 0, want));   // holds a sticky flag (gpc_common.hpp)
+    if(slot == WS_INFO) {   // holds a sticky flag (gpc_common.hpp)
+      GPC_HIP_CHECK(hipMemset(w.p, 0, want));
+      GPC_HIP_CHECK(hipStreamSynchronize(nullptr));   // hipMemset on device memory returns before it has run, and the library's
+                                                      // non-blocking streams do not wait for the null stream: the first reader
+                                                      // of a fresh word (gpc_grid_*'s fault check on a rank thread) saw garbage
+    }
     else if(poison_allocations()) {
       GPC_HIP_CHECK(hipMemset(w.p, 0xFF, want));
       GPC_HIP_CHECK(hipDeviceSynchronize());   // (the fill must not land after a kernel of a non-blocking stream has written the buffer)
@@ -131,12 +136,15 @@ static void release_workspace()
     }
 }
 
+static thread_local bool g_flow_timed_out = false;   // the last read_info saw the dataflow kernel's time-out marker
+
 static int read_info(int* d_info, int* info, hipStream_t s)
 {
   GPC_HIP_CHECK(hipMemcpyAsync(info, d_info, sizeof(int), hipMemcpyDeviceToHost, s));
   GPC_HIP_CHECK(hipStreamSynchronize(s));
   if(*info == PANEL_FLOW_TIMEOUT) {
     *info = 0;
+    g_flow_timed_out = true;
     set_error("the dataflow panel factorisation timed out (device shared or pre-empted?); the factor is unusable -- repeat the "
               "call, or set GPC_PANEL_FLOW=0 for the launch chain");
     return GPC_EHIP;
@@ -251,8 +259,20 @@ int gpc_memcpy_h2d(void* dst, const void* src, size_t bytes, void* stream)
 int gpc_memcpy_d2h(void* dst, const void* src, size_t bytes, void* stream)
 {
   GPC_CHECK(ensure_device());
+  // the thread's sticky "a dataflow triangular solve gave up" word travels in the same synchronisation: device results
+  // reach a host that uses this library through here, so a solve that timed out (its output is NaN-poisoned) is reported
+  // as GPC_EHIP at the latest when its results are fetched -- also when no host-scalar call (gpc_coldot_f64) follows it
+  int fault = 0;
+  int* sticky = g_ws[WS_INFO].p ? static_cast<int*>(g_ws[WS_INFO].p) + SOLVE_FAULT_WORD : nullptr;
   GPC_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, as_stream(stream)));
+  if(sticky) GPC_HIP_CHECK(hipMemcpyAsync(&fault, sticky, sizeof(int), hipMemcpyDeviceToHost, as_stream(stream)));
   GPC_HIP_CHECK(hipStreamSynchronize(as_stream(stream)));
+  if(fault) {
+    GPC_HIP_CHECK(hipMemsetAsync(sticky, 0, sizeof(int), as_stream(stream)));
+    set_error("a dataflow triangular solve timed out (device shared or pre-empted?); its result is NaN -- repeat the call, or "
+              "set GPC_TRSV_FLOW=0 for the stepped kernels");
+    return GPC_EHIP;
+  }
   return GPC_OK;
 }
 
@@ -482,8 +502,25 @@ int gpc_gp_update_k_f64(const gpc_kspec* ks, const double* X, int64_t N, int64_t
   GPC_CHECK(diag_reduce(0, N, K, ldk, &tr, s));
   double jitter = 1e-6 * tr / (double)(N > 0 ? N : 1);
   double total = 0.0;
+  bool chain_only = false;
   for(int tries = 0;;) {
-    GPC_CHECK(potrf_any('L', N, K, ldk, info, s));
+    g_flow_timed_out = false;
+    int rc;
+    if(chain_only) {
+      FlowOffScope chain;
+      rc = potrf_any('L', N, K, ldk, info, s);
+    } else {
+      rc = potrf_any('L', N, K, ldk, info, s);
+    }
+    if(rc == GPC_EHIP && g_flow_timed_out && !chain_only) {
+      // the dataflow panel kernel gave up waiting (device shared or pre-empted): K is regenerated -- this entry point owns its
+      // input -- and factored once more on the launch chain, which waits for nothing but the stream
+      chain_only = true;
+      GPC_CHECK(gpc_gram_sym_f64(ks, X, N, D, ldx, K, ldk, stream));
+      if(total != 0.0) GPC_CHECK(add_diag(N, K, ldk, total, s));
+      continue;
+    }
+    GPC_CHECK(rc);
     if(*info == 0) break;
     total += jitter;   // A.addDiag(jitter)
     jitter *= 10.0;

@@ -111,6 +111,11 @@ int panel_flow(int64_t M, int64_t nbk, double* P, int64_t lda, int* d_info, int6
 // ... and what it leaves in the info word when one of its polls was not answered within ~10 s (device shared or pre-empted):
 // not a LAPACK info, the factor is unusable.  Whoever reads the info word back reports an error.
 constexpr int PANEL_FLOW_TIMEOUT = (int)0x80000000;
+extern thread_local int g_flow_off;     // potrf.hip: > 0 = this thread's factorisations use the launch chain only
+struct FlowOffScope {
+  FlowOffScope() { g_flow_off++; }
+  ~FlowOffScope() { g_flow_off--; }
+};
 int potrf_lower_tall(int64_t Nrows, int64_t Ncols, double* A, int64_t lda, int* d_info, hipStream_t s, bool identity_below = false);
 // misc.hip: C (M x n, n <= 16) = alpha A (M x K) B (K x n) + beta C -- the skinny products of CGp / CGplvm (invK * m)
 int gemm_skinny(int64_t M, int64_t n, int64_t K, double alpha, const double* A, int64_t lda, const double* B, int64_t ldb,

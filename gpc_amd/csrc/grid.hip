@@ -526,6 +526,17 @@ struct HipOps : GridOps {
     if(rc == GPC_OK && *out == PANEL_FLOW_TIMEOUT) *out = -1;   // "this rank's factor is unusable" (GridGp::factor agrees on it)
     return rc;
   }
+  void dataflow_kernels(bool on) override { gpc::g_flow_off += on ? -1 : 1; }
+  int check_faults(int s) override
+  {
+    int fault = 0;
+    GPC_CHECK(gpc::take_solve_fault(st[s], &fault));
+    if(fault) {
+      gpc::set_error("a dataflow triangular solve timed out on this rank (device shared or pre-empted?); its result is NaN");
+      return GPC_EHIP;
+    }
+    return GPC_OK;
+  }
   void prof_update_begin(double flops, int s) override { gpc::prof_begin(PROF_SYRK, flops, st[s]); }
   void prof_update_end(int s) override { gpc::prof_end(PROF_SYRK, st[s]); }
 };

@@ -208,6 +208,10 @@ struct GridOps {
   // dst(i, e) += src(e, i): the extra rows of a tile, transposed (nb x d)
   virtual int add_transposed(double* dst, int64_t ldd, const double* src, int64_t lds, int64_t n, int64_t d, int st) = 0;
   virtual int read_info(const int* info_dev, int* out_host, int st) = 0;
+  // has a dataflow triangular solve of this thread given up since the last check (its result is NaN-poisoned)?  GPC_EHIP if so
+  virtual int check_faults(int st) { (void)st; return GPC_OK; }
+  // off: this rank's panel factorisations avoid the one-launch dataflow kernels (the retry after one of them timed out)
+  virtual void dataflow_kernels(bool on) { (void)on; }
   // HIP events around the trailing updates (bench.py's roofline leg); the host stand-in ignores them
   virtual void prof_update_begin(double flops, int st) { (void)flops; (void)st; }
   virtual void prof_update_end(int st) { (void)st; }
@@ -583,13 +587,26 @@ class GridGp {
     GRID_CHECK(fill(0.0));
     double jitter = -1.0, total = 0.0;
     int tries = 0, inf = 0;
+    bool chain_only = false;
     for(;;) {
       if(jitter < 0.0) {
         double tr = 0.0;   // trace(K) = sum of the replicated diagonal values: no exchange needed
         GRID_CHECK(ops_->sum_host(dg_, L_.N, &tr, ST_MAIN));
         jitter = 1e-6 * tr / (double)L_.N;
       }
-      GRID_CHECK(factor(&inf));
+      int rc = factor(&inf);
+      if(rc == GPC_EHIP && flow_timed_out_ && !chain_only) {
+        // a rank's dataflow panel kernel gave up waiting (device shared or pre-empted); every rank knows (factor agrees on it):
+        // the matrix is regenerated and factored once more on the launch chain, which waits for nothing but the streams
+        chain_only = true;
+        ops_->dataflow_kernels(false);
+        rc = fill(total);
+        if(rc == GPC_OK) continue;
+      }
+      if(rc != GPC_OK) {
+        if(chain_only) ops_->dataflow_kernels(true);
+        return rc;
+      }
       if(inf == 0) break;
       total += jitter;
       jitter *= 10.0;
@@ -597,6 +614,7 @@ class GridGp {
       if(jitter > 10.0 || tries >= max_tries) break;
       GRID_CHECK(fill(total));
     }
+    if(chain_only) ops_->dataflow_kernels(true);
     jitter_ = total;
     if(info) *info = inf;
     if(jitter_added) *jitter_added = total;
@@ -674,6 +692,7 @@ class GridGp {
     GRID_CHECK(ops_->read_info(info_dev_, &inf, ST_MAIN));
     int64_t v = inf > 0 ? (int64_t)inf : (inf < 0 ? (int64_t)-1 : ((int64_t)1 << 60));
     GRID_CHECK(comm_->allmin_host(&v));
+    flow_timed_out_ = v < 0;
     if(v < 0) {   // some rank's device-side factorisation gave up (a dataflow kernel's poll timed out): every rank reports it
       factored_ = false;
       return fail(GPC_EHIP, "factor: a rank's panel factorisation timed out (device shared or pre-empted?)");
@@ -739,6 +758,7 @@ class GridGp {
       if(r_ == kr) GRID_CHECK(ops_->copy2d(alr_ + (k / pr_) * nb_, ldr, t_, nb_, nb_, d_, ST_MAIN));
     }
     alpha_valid_ = true;
+    GRID_CHECK(ops_->check_faults(ST_MAIN));
     if(alpha_host) {
       std::vector<double> h((size_t)(L.Np * d_));
       GRID_CHECK(ops_->download(h.data(), al_, sizeof(double) * h.size(), ST_MAIN));
@@ -769,6 +789,7 @@ class GridGp {
     ops_->release(kss);
     GRID_CHECK(rc);
     GRID_CHECK(extra_sumsq(d_, d_ + Ns_, q.data()));
+    GRID_CHECK(ops_->check_faults(ST_MAIN));
     for(int64_t j = 0; j < d_; j++)
       for(int64_t i = 0; i < Ns_; i++) mu_host[i + j * ldmu] = hm[(size_t)(i + j * Ns_)];
     for(int64_t i = 0; i < Ns_; i++) var_host[i] = hk[(size_t)i] - q[(size_t)i];
@@ -973,6 +994,7 @@ class GridGp {
     // the white terms see only the diagonal of covGrad (CWhiteKern::getGradParams, CKern.cpp:735-739)
     for(int t = 0; t < ks_.n_terms; t++)
       if(ks_.types[t] == GPC_KERN_WHITE) acc[(size_t)ks_.offs[t]] += trace;
+    GRID_CHECK(ops_->check_faults(ST_MAIN));
     GRID_CHECK(comm_->allreduce_host(acc.data(), np, AX_WORLD));
     for(int p = 0; p < np; p++) g_host[p] = acc[(size_t)p];
     return GPC_OK;
@@ -1308,7 +1330,7 @@ class GridGp {
   std::vector<int64_t> voff_host_, slot_, region_start_;
   void *ev_panel_[2] = {nullptr, nullptr}, *ev_free_[2] = {nullptr, nullptr}, *ev_ready_ = nullptr, *ev_u1_ = nullptr, *ev_u1a_ = nullptr;
   bool free_valid_[2] = {false, false};
-  bool factored_ = false, alpha_valid_ = false;
+  bool factored_ = false, alpha_valid_ = false, flow_timed_out_ = false;
   double logdet_ = 0.0, jitter_ = 0.0;
   GridStats stats_;
   std::string err_;

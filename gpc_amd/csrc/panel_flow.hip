@@ -36,6 +36,7 @@ struct PanelFlowArgs {
   int* info;          // LAPACK info word (device)
   int* ctl;           // [0] ticket counter, [1] abort flag (1 = pivot failure, 2 = time-out)
   int trace;          // measurement aid: stamp pf_trace
+  int max_polls;      // polls before a wait gives up (2^23: ~10 s; GPC_PANEL_FLOW_POLLS shortens it to provoke the time-out path)
   double* X;          // exchange buffer: every finished block, (64 nrb) x (64 ncb), leading dimension ldx
   int64_t ldx;
 };
@@ -70,7 +71,7 @@ __device__ __forceinline__ bool pf_try(const double* p, int64_t step, double (&v
 template <int NV>
 __device__ __forceinline__ bool pf_fetch(const PanelFlowArgs& g, const double* p, int64_t step, double (&v)[NV])
 {
-  for(int it = 0; it < (1 << 23); it++) {
+  for(int it = 0; it < g.max_polls; it++) {
     if(pf_try<NV>(p, step, v)) return true;
     if((it & 63) == 63 && __hip_atomic_load(&g.ctl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return false;
     __builtin_amdgcn_s_sleep(1);
@@ -606,6 +607,8 @@ int panel_flow(int64_t M, int64_t nbk, double* P, int64_t lda, int* d_info, int6
   g.ldx = ldx;
   static const int trace = [] { const char* e = getenv("GPC_PANEL_FLOW_TRACE"); return e ? atoi(e) : 0; }();
   g.trace = trace;
+  static const int polls = [] { const char* e = getenv("GPC_PANEL_FLOW_POLLS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : (1 << 23); }();
+  g.max_polls = polls;
   const int64_t nblocks = (int64_t)ncb * nrb - (int64_t)ncb * (ncb - 1) / 2;
   hipLaunchKernelGGL(panel_flow_kernel, dim3((unsigned)nblocks), dim3(256), 0, s, g);
   GPC_HIP_CHECK(hipGetLastError());

@@ -30,6 +30,11 @@
 
 namespace gpc {
 
+// While > 0 on this thread the dataflow panel kernel is not used: the retry of a factorisation whose dataflow launch timed out
+// (device shared or pre-empted) goes through the launch chain, which waits for nothing but the stream (FlowOffScope).
+thread_local int g_flow_off = 0;
+
+
 namespace {
 
 constexpr int JB = 64;
@@ -594,6 +599,7 @@ int ensure_lookahead()
 // every panel goes through the dataflow kernel).
 static int64_t panel_flow_maxrows()
 {
+  if(g_flow_off > 0) return 0;
   static int64_t maxrows = -1;
   if(maxrows < 0) {
     const char* e = getenv("GPC_PANEL_FLOW");

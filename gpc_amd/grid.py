@@ -272,7 +272,8 @@ def run_local(grids, fn):
     errs = [e for e in err if e is not None]
     if errs:
         own = [e for e in errs if not (isinstance(e, GpcError) and e.rc == _lib.GPC_EHIP)]
-        raise (own or errs)[0]
+        told = [e for e in errs if isinstance(e, GpcError) and not str(e).rstrip().endswith(":")]   # (a released rank has no message)
+        raise (own or told or errs)[0]
     return out
 
 

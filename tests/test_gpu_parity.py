@@ -6,10 +6,13 @@ Tolerances: 1e-10 absolute for Gram entries (the reference's ndlutil::MATCHTOL, 
 fixture (testMatrix.cpp:606-835), 1e-8 RELATIVE for log-likelihood / alpha / predictive mean and variance
 (BASELINE.json north_star).
 """
+import os
+
 import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 MATCHTOL = 1e-10
 REL = 1e-8
@@ -995,3 +998,39 @@ def test_compounds_beyond_one_pass(api, N, D, terms):
         fd = (lls[0] - lls[1]) / (2 * h)
         assert abs(fd - g0[idx]) <= 2e-5 * max(1.0, abs(g0[idx])), (idx, fd, g0[idx])
     m.setOptParams(p0)
+
+
+def test_dataflow_timeout_falls_back_to_the_launch_chain(api):
+    """A dataflow panel launch whose polls run out (device shared or pre-empted; provoked here with GPC_PANEL_FLOW_POLLS=1: a
+    wait gives up after ONE look) used to end gpc_gp_update_k_f64 with GPC_EHIP.  The entry point owns its input, so it now
+    regenerates K and factors it once more on the launch chain; the grid's update_k does the same on every rank."""
+    import subprocess
+    import sys
+    code = r'''
+import numpy as np, sys
+sys.path.insert(0, %r)
+from gpc_amd import api, synth, grid
+X, y = synth.make_xy(2500, 4, 3)
+terms = [("rbf", [0.8, 1.0]), ("white", [0.05])]
+L, ld, jit, info = api.gp_update_k(api.kspec(terms), api.from_host(X))
+msg = api.lib().gpc_last_error()
+grids = grid.create_local(2, 2, 256)
+def work(g, rank):
+    g.set_problem(terms, X, y, None)
+    return g.update_k()
+res = grid.run_local(grids, work)
+print("RESULT", info, repr(ld), int(b"timed out" in msg), res[0][2], repr(res[0][0]))
+''' % ROOT
+    env = dict(os.environ, GPC_PANEL_FLOW_POLLS="1")
+    r = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    f = [ln for ln in r.stdout.decode().splitlines() if ln.startswith("RESULT")][0].split()
+    from gpc_amd import synth
+    X, _ = synth.make_xy(2500, 4, 3)
+    G = X @ X.T
+    n = np.diag(G)
+    K = np.exp(-0.4 * np.maximum(n[:, None] + n[None, :] - 2 * G, 0.0)) + 0.05 * np.eye(2500)
+    want = 2.0 * np.log(np.diag(np.linalg.cholesky(K))).sum()
+    assert int(f[1]) == 0 and int(f[4]) == 0
+    assert int(f[3]) == 1, "the time-out path was not taken: the test does not test what it says"
+    assert abs(float(f[2]) - want) <= 1e-10 * abs(want) and abs(float(f[5]) - want) <= 1e-10 * abs(want)
