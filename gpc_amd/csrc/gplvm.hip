@@ -34,6 +34,31 @@ __global__ void __launch_bounds__(256) covgrad_multi_kernel(const double* __rest
   cg[i + j * ldc] = -0.5 * ((double)d * invK[i + j * ldi] - aa);
 }
 
+// The same for d <= 16 outputs with a row's A(i, :) held in registers across CJ columns (the one-column form above issues 2 d
+// cached loads per element beside its 16 bytes of HBM traffic and is bound by them: 1.5 TB/s at d = 12).
+template <int DM, int CJ>
+__global__ void __launch_bounds__(256) covgrad_multi_regs_kernel(const double* __restrict__ invK, int64_t ldi,
+                                                                 const double* __restrict__ A, int64_t lda, int d,
+                                                                 double* __restrict__ cg, int64_t ldc, int64_t N, int64_t j0)
+{
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t ic = i < N ? i : N - 1;
+  double ai[DM];
+#pragma unroll
+  for(int k = 0; k < DM; k++) ai[k] = k < d ? A[ic + (int64_t)k * lda] : 0.0;
+  const int64_t jb = j0 + (int64_t)blockIdx.y * CJ;
+#pragma unroll
+  for(int c = 0; c < CJ; c++) {
+    const int64_t j = jb + c;
+    if(j >= N) break;
+    double aa = 0.0;
+#pragma unroll
+    for(int k = 0; k < DM; k++)
+      if(k < d) aa += ai[k] * A[j + (int64_t)k * lda];      // wave-uniform address: scalar loads
+    if(i < N) cg[i + j * ldc] = -0.5 * ((double)d * invK[i + j * ldi] - aa);
+  }
+}
+
 struct GradXArgs {
   const double* X;    // rows i (the points the derivative is taken at), N x D
   const double* X2;   // columns n, N2 x D (== X for the symmetric pass)
@@ -113,7 +138,7 @@ __global__ void __launch_bounds__(256) kern_gradx_kernel(const KSpecDev ks, cons
 // approximations for K_uf (CGp.cpp:1153).  Per workgroup NPC partial sums; the host adds them in a fixed order.
 //   [2t], [2t+1]  rbf term t: sum cg k~ d2, sum cg k~      [8], [9] rbfard: the same with the scaled distance
 //   [10] sum cg (bias)   [11] sum cg x_i.x2_n (lin)   [12 + q] rbfard: sum cg k~ (x_iq - x2_nq)^2
-constexpr int NPC = 12 + 16;
+constexpr int NPC = 12 + GPC_MAX_ARD_DIM;
 template <int DMAX, bool ARD = true>
 __global__ void __launch_bounds__(256) kern_grad_cross_kernel(const KSpecDev ks, const GradXArgs g, double* __restrict__ partial)
 {
@@ -179,7 +204,7 @@ __global__ void __launch_bounds__(256) kern_grad_cross_kernel(const KSpecDev ks,
   block_store(sbias, 10);
   block_store(slin, 11);
 #pragma unroll
-  for(int q = 0; q < 16; q++) block_store((ARD && q < DMAX) ? sdim[(ARD && q < DMAX) ? q : 0] : 0.0, 12 + q);
+  for(int q = 0; q < (ARD ? DMAX : 1); q++) block_store(ARD ? sdim[q] : 0.0, 12 + q);
 }
 
 __global__ void __launch_bounds__(256) gradx_reduce_kernel(const double* __restrict__ part, int nsplit, int D, int64_t N,
@@ -208,6 +233,19 @@ extern "C" int gpc_covgrad_multi_f64(int64_t N, int64_t d, const double* invK, i
               "covgrad_multi dims");
   if(N == 0) return GPC_OK;
   hipStream_t s = as_stream(stream);
+  if(d <= 16) {
+    constexpr int CJ = 8;
+    for(int64_t j0 = 0; j0 < N; j0 += 32768 * CJ) {
+      const int64_t nc = (N - j0 < 32768 * CJ) ? (N - j0) : 32768 * CJ;
+      const dim3 grid((unsigned)((N + 255) / 256), (unsigned)((nc + CJ - 1) / CJ));
+      if(d <= 4)
+        hipLaunchKernelGGL((covgrad_multi_regs_kernel<4, CJ>), grid, dim3(256), 0, s, invK, ldi, A, lda, (int)d, covGrad, ldc, N, j0);
+      else
+        hipLaunchKernelGGL((covgrad_multi_regs_kernel<16, CJ>), grid, dim3(256), 0, s, invK, ldi, A, lda, (int)d, covGrad, ldc, N, j0);
+    }
+    GPC_HIP_CHECK(hipGetLastError());
+    return GPC_OK;
+  }
   for(int64_t j0 = 0; j0 < N; j0 += 32768) {
     const int64_t nc = (N - j0 < 32768) ? (N - j0) : 32768;
     hipLaunchKernelGGL(covgrad_multi_kernel, dim3((unsigned)((N + 255) / 256), (unsigned)nc), dim3(256), 0, s, invK, ldi,
@@ -245,8 +283,8 @@ static int launch_gradx_pass(const gpc_kspec* ksp, const double* X, int64_t N, i
                              int64_t ldx2, int64_t D, const double* covGrad, int64_t ldc, double* gX, int64_t ldg,
                              double pair_factor, hipStream_t s)
 {
-  if(D > 16) {
-    set_error("kern_gradx: input dimension %lld > 16 is outside the accelerated set", (long long)D);
+  if(D > GPC_MAX_ARD_DIM) {
+    set_error("kern_gradx: input dimension %lld > %d is outside the accelerated set", (long long)D, GPC_MAX_ARD_DIM);
     return GPC_EUNSUPPORTED;
   }
   KSpecDev ks;
@@ -282,10 +320,17 @@ static int launch_gradx_pass(const gpc_kspec* ksp, const double* X, int64_t N, i
   GPC_CHECK(workspace(WS_KERN, sizeof(double) * (size_t)nsplit * (size_t)D * (size_t)N, &ws));
   g.part = static_cast<double*>(ws);
   const dim3 grid((unsigned)rb, (unsigned)nsplit);
+  // (D > 16: the same kernel with 32 / 64 dimensions per lane -- a row's whole x, x_n, difference and sums live in
+  // registers, so these instances run at one wave per SIMD; latent spaces and inducing inputs of that dimension are rare, what
+  // counts is that the reference's getGradX has no limit, CKern.cpp:1115-1135, 3268-3293)
   if(D <= 4)
     hipLaunchKernelGGL(kern_gradx_kernel<4>, grid, dim3(256), 0, s, ks, g);
-  else
+  else if(D <= 16)
     hipLaunchKernelGGL(kern_gradx_kernel<16>, grid, dim3(256), 0, s, ks, g);
+  else if(D <= 32)
+    hipLaunchKernelGGL(kern_gradx_kernel<32>, grid, dim3(256), 0, s, ks, g);
+  else
+    hipLaunchKernelGGL(kern_gradx_kernel<64>, grid, dim3(256), 0, s, ks, g);
   GPC_HIP_CHECK(hipGetLastError());
   hipLaunchKernelGGL(gradx_reduce_kernel, dim3((unsigned)((N + 255) / 256), (unsigned)D), dim3(256), 0, s, g.part,
                      (int)nsplit, (int)D, N, gX, ldg);
@@ -350,8 +395,8 @@ static int kern_grad_cross_pass(const gpc_kspec* ksp, const double* X, int64_t N
 {
   KSpecDev ks;
   GPC_CHECK(collapse_kspec(ksp, D, &ks));
-  if(D > 32 || (D > 16 && ks.n_ard > 0)) {
-    set_error("kern_grad_cross: input dimension %lld is outside the accelerated set (32; 16 with an rbfard term)", (long long)D);
+  if(D > GPC_MAX_ARD_DIM) {
+    set_error("kern_grad_cross: input dimension %lld is outside the accelerated set (%d)", (long long)D, GPC_MAX_ARD_DIM);
     return GPC_EUNSUPPORTED;
   }
   const int nparams = ksp->offs[ksp->n_terms];
@@ -387,8 +432,14 @@ static int kern_grad_cross_pass(const gpc_kspec* ksp, const double* X, int64_t N
     hipLaunchKernelGGL(kern_grad_cross_kernel<4>, grid, dim3(256), 0, s, ks, g, partial);
   else if(D <= 16)
     hipLaunchKernelGGL(kern_grad_cross_kernel<16>, grid, dim3(256), 0, s, ks, g, partial);
-  else
+  else if(D <= 32 && ks.n_ard == 0)
     hipLaunchKernelGGL((kern_grad_cross_kernel<32, false>), grid, dim3(256), 0, s, ks, g, partial);
+  else if(D <= 32)
+    hipLaunchKernelGGL((kern_grad_cross_kernel<32, true>), grid, dim3(256), 0, s, ks, g, partial);
+  else if(ks.n_ard == 0)
+    hipLaunchKernelGGL((kern_grad_cross_kernel<64, false>), grid, dim3(256), 0, s, ks, g, partial);
+  else
+    hipLaunchKernelGGL((kern_grad_cross_kernel<64, true>), grid, dim3(256), 0, s, ks, g, partial);
   GPC_HIP_CHECK(hipGetLastError());
   std::vector<double> h((size_t)nblk * NPC);
   GPC_HIP_CHECK(hipMemcpyAsync(h.data(), partial, sizeof(double) * h.size(), hipMemcpyDeviceToHost, s));

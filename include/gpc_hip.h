@@ -208,7 +208,7 @@ int gpc_grid_posterior(gpc_grid* g, double* mu_host, int64_t ldmu, double* var_h
  * (offs[n_terms] doubles), covGrad = -0.5 (d K^-1 - Alpha Alpha').  The factor is replicated (it must fit one GPU next to
  * the local block: N <= ~170 000 on 288 GB; gpc_grid_stats out[7] reports what a rank holds) and every rank forms its own
  * groups of tile rows of K^-1 by two right-sided solves on the trailing block: (2/3) N^3 / P flops per rank, no distributed
- * dpotri.  Cross-block kernel pass: D <= 32 without an rbfard term, D <= 16 with one. */
+ * dpotri.  Cross-block kernel pass: D <= 64. */
 int gpc_grid_gradient(gpc_grid* g, double* g_host);
 int gpc_grid_sync(gpc_grid* g);
 int gpc_grid_barrier(gpc_grid* g);
@@ -296,18 +296,18 @@ int gpc_covgrad_multi_f64(int64_t N, int64_t d, const double* invK, int64_t ldi,
                           double* covGrad, int64_t ldc, void* stream);
 /* gX(i,q) = sum_n covGrad(n,i) * d k(x_i,x_n)/d x_iq, counted as CGplvm.cpp:573-604 counts it (factor 2 off the
  * diagonal, CKern::getDiagGradX on it): replaces CCmpndKern::getGradX (CKern.cpp:184-193; rbf 1115-1135, rbfard
- * 3268-3293, lin 2291-2308) and the dotColCol loop.  covGrad symmetric N x N, X and gX N x D (D <= 16). */
+ * 3268-3293, lin 2291-2308) and the dotColCol loop.  covGrad symmetric N x N, X and gX N x D (D <= 64; fastest up to 16). */
 int gpc_kern_gradx_f64(const gpc_kspec* ks, const double* X, int64_t N, int64_t D, int64_t ldx,
                        const double* covGrad, int64_t ldc, double* gX, int64_t ldg, void* stream);
 
 /* ---- cross-Gram gradient passes (sparse approximations; CGp.cpp:1146-1190) ------------ */
 /* g_p = sum_{i,n} covGrad(i,n) dk(x_i, x2_n)/dtheta_p, natural parameters in spec order:
  * CCmpndKern::getGradParams(g, X, X2, covGrad) (rbf CKern.cpp:1175-1202, rbfard 3318-3357, bias 1015-1019, lin 2354-2368;
- * white contributes 0, 730-734).  covGrad is N x N2; g is a host array; D <= 16. */
+ * white contributes 0, 730-734).  covGrad is N x N2; g is a host array; D <= 64. */
 int gpc_kern_grad_cross_f64(const gpc_kspec* ks, const double* X, int64_t N, int64_t ldx, const double* X2, int64_t N2,
                             int64_t ldx2, int64_t D, const double* covGrad, int64_t ldc, double* g, void* stream);
 /* gX(i,q) = sum_n covGrad(i,n) d k(x_i, x2_n)/d x_iq: CKern::getGradX(gKX, X, i, X2) + dotColRow over n
- * (CGp.cpp:1163-1176, the K_uf part of the inducing-input gradient).  gX is N x D (D <= 16). */
+ * (CGp.cpp:1163-1176, the K_uf part of the inducing-input gradient).  gX is N x D (D <= 64). */
 int gpc_kern_gradx_cross_f64(const gpc_kspec* ks, const double* X, int64_t N, int64_t ldx, const double* X2, int64_t N2,
                              int64_t ldx2, int64_t D, const double* covGrad, int64_t ldc, double* gX, int64_t ldg,
                              void* stream);

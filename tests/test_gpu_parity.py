@@ -442,8 +442,8 @@ def test_kern_gradx_cross_vs_numpy(api):
     """gX(i,q) = sum_n covGrad(i,n) dk(x_i, x2_n)/dx_iq for rbf + rbfard + lin (+ bias, white: no contribution),
     ragged sizes, against the formulas of CKern.cpp:1115-1135, 3268-3293, 2291-2308 written out in numpy"""
     rng = np.random.RandomState(4)
-    for N, N2, D in ((37, 501, 3), (130, 64, 1), (64, 1000, 9)):
-        X, X2, G = rng.randn(N, D), rng.randn(N2, D), rng.randn(N, N2)
+    for N, N2, D in ((37, 501, 3), (130, 64, 1), (64, 1000, 9), (70, 300, 20), (65, 200, 40)):   # D > 16: the 32 / 64-wide instances
+        X, X2, G = rng.randn(N, D) / np.sqrt(D), rng.randn(N2, D) / np.sqrt(D), rng.randn(N, N2)
         s = rng.rand(D) * 0.8 + 0.1
         terms = [("rbf", [0.7, 1.3]), ("rbfard", [1.1, 0.6] + list(s)), ("lin", [0.4]), ("bias", [0.2]), ("white", [0.1])]
         diff = X2[None, :, :] - X[:, None, :]                      # x2_n - x_i
@@ -862,9 +862,9 @@ def test_error_behaviour_of_the_c_abi(api):
     assert e.value.rc == _lib.GPC_EUNSUPPORTED
     ks5 = api.kspec([("rbf", [1.0, 1.0])] * 5)                    # more rbf terms than one pass holds: a second pass, no refusal
     assert np.array_equal(api.to_host(api.gram_sym(ks5, api.from_host(np.zeros((3, 2))))), np.full((3, 3), 5.0))
-    X17 = api.from_host(np.zeros((8, 17)))                        # latent-gradient passes cover D <= 16
+    X65 = api.from_host(np.zeros((8, 65)))                        # latent-gradient passes cover D <= 64 (GPC_MAX_ARD_DIM)
     with pytest.raises(_lib.GpcError) as e:
-        api.kern_gradx(api.kspec([("rbf", [1.0, 1.0])]), X17, api.from_host(np.zeros((8, 8))))
+        api.kern_gradx(api.kspec([("rbf", [1.0, 1.0])]), X65, api.from_host(np.zeros((8, 8))))
     assert e.value.rc == _lib.GPC_EUNSUPPORTED
     # a failed call leaves the library usable
     assert api.potrf(api.from_host(np.eye(4) * 4.0), "L") == 0
@@ -1002,7 +1002,8 @@ def test_compounds_beyond_one_pass(api, N, D, terms):
 
 def test_dataflow_timeout_falls_back_to_the_launch_chain(api):
     """A dataflow panel launch whose polls run out (device shared or pre-empted; provoked here with GPC_PANEL_FLOW_POLLS=1: a
-    wait gives up after ONE look) used to end gpc_gp_update_k_f64 with GPC_EHIP.  The entry point owns its input, so it now
+    wait gives up at its first look at the limit, after 64 polls -- the whole N = 4096 matrix is one launch whose later column
+    blocks wait far longer than that) used to end gpc_gp_update_k_f64 with GPC_EHIP.  The entry point owns its input, so it now
     regenerates K and factors it once more on the launch chain; the grid's update_k does the same on every rank."""
     import subprocess
     import sys
@@ -1010,11 +1011,11 @@ def test_dataflow_timeout_falls_back_to_the_launch_chain(api):
 import numpy as np, sys
 sys.path.insert(0, %r)
 from gpc_amd import api, synth, grid
-X, y = synth.make_xy(2500, 4, 3)
+X, y = synth.make_xy(4096, 4, 3)
 terms = [("rbf", [0.8, 1.0]), ("white", [0.05])]
 L, ld, jit, info = api.gp_update_k(api.kspec(terms), api.from_host(X))
 msg = api.lib().gpc_last_error()
-grids = grid.create_local(2, 2, 256)
+grids = grid.create_local(2, 2, 1024)
 def work(g, rank):
     g.set_problem(terms, X, y, None)
     return g.update_k()
@@ -1026,10 +1027,10 @@ print("RESULT", info, repr(ld), int(b"timed out" in msg), res[0][2], repr(res[0]
     assert r.returncode == 0, r.stderr.decode()[-2000:]
     f = [ln for ln in r.stdout.decode().splitlines() if ln.startswith("RESULT")][0].split()
     from gpc_amd import synth
-    X, _ = synth.make_xy(2500, 4, 3)
+    X, _ = synth.make_xy(4096, 4, 3)
     G = X @ X.T
     n = np.diag(G)
-    K = np.exp(-0.4 * np.maximum(n[:, None] + n[None, :] - 2 * G, 0.0)) + 0.05 * np.eye(2500)
+    K = np.exp(-0.4 * np.maximum(n[:, None] + n[None, :] - 2 * G, 0.0)) + 0.05 * np.eye(4096)
     want = 2.0 * np.log(np.diag(np.linalg.cholesky(K))).sum()
     assert int(f[1]) == 0 and int(f[4]) == 0
     assert int(f[3]) == 1, "the time-out path was not taken: the test does not test what it says"

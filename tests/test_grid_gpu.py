@@ -196,6 +196,9 @@ def test_cfg4_kernel_against_the_reference_golden(golden, pr, pc, nb):
     (2, 2, 32, [("rbf", [0.1, 1.1]), ("white", [0.1])]),                      # the D > 16 instance of the cross pass
     (1, 2, 4, [("rbfard", [1.1, 0.8, 0.7, 0.4, 0.55, 0.3]), ("white", [0.05])]),
     (8, 1, 3, [("rbf", [1.3, 0.9]), ("bias", [0.2]), ("white", [0.05])]),      # reflected rounds
+    (2, 2, 20, [("rbfard", [0.3, 0.9] + [0.2 + 0.03 * q for q in range(20)]), ("white", [0.05])]),   # cross pass with D > 16
+    (2, 1, 6, [("rbfard", [0.8, 0.9, 0.7, 0.4, 0.55, 0.3, 0.6, 0.2]), ("rbf", [0.5, 0.4]), ("rbf", [2.0, 0.1]), ("lin", [0.1]),
+               ("white", [0.05])]),
     (4, 1, 8, [("rbf", [0.6, 0.9]), ("white", [0.05])])])
 def test_gradient_against_numpy_and_the_single_gpu_model(pr, pc, D, terms):
     from gpc_amd import grid
