@@ -55,6 +55,10 @@ struct GemmArgs {
   int debug_same_rows;   // ablation knob (env GPC_GEMM_DEBUG_SAMEROWS): never set in production
   int kstart;            // fast NT kernel only: both operands are upper triangular (square product, K == M == N):
                          // a tile's k-loop starts at its first row m0 (everything left of it is zero)
+  int ksplit;            // > 1 (fast NT kernel, SPLITK instance): the k-range of every tile is cut into ksplit pieces, each a
+  double* part;          // workgroup of its own writing alpha * (its partial product) to part + piece * part_stride (M x N,
+  int64_t part_stride;   // leading dimension M); split_combine_kernel adds the pieces in order.  For products with few tiles
+                         // and a long k (the GP-LVM's K^-1 = V V' at N = 1000: 36 tiles, one round of 64 stages each)
   int atomic_c;          // beta == 1: accumulate into C with no-return fp64 atomics instead of load + add + store
   int tri;               // 0 full, 1 lower (i >= j, C square), 2 upper (i <= j, C square),
                          // 3 lower trapezoid (i >= j, M >= N, full enumeration with skipped tiles)
@@ -161,15 +165,13 @@ __device__ __forceinline__ int frag_off(int base, int kk, int lane)
 }
 
 // logical block id -> (tile_i, tile_j); returns false if this slot has no tile
-__device__ __forceinline__ bool map_tile(const GemmArgs& g, int& ti, int& tj)
+__device__ __forceinline__ bool map_tile(const GemmArgs& g, int& ti, int& tj, const unsigned nb, const unsigned b)
 {
-  // XCD-aware deal: hardware block b runs on XCD b % 8; give each XCD a contiguous range of logical ids.
-  const unsigned nb = gridDim.x;  // multiple of 8
-  const unsigned b = blockIdx.x;
+  // XCD-aware deal: hardware block b runs on XCD b % 8; give each XCD a contiguous range of logical ids (nb: multiple of 8).
   unsigned L = (b & 7u) * (nb >> 3) + (b >> 3);
   // k-start products (potri): a tile's cost falls with its row, so contiguous chunks would hand one XCD all the long
   // tiles.  Deal groups of 64 consecutive ids (about one super-tile: the L2 locality survives) round-robin instead.
-  if(g.kstart) L = (((b >> 3) >> 6) * 8u + (b & 7u)) * 64u + ((b >> 3) & 63u);
+  if(g.kstart == 1) L = (((b >> 3) >> 6) * 8u + (b & 7u)) * 64u + ((b >> 3) & 63u);   // (2: k-start without the deal, see split-k)
   int si, sj, di, dj;
   if(g.tri == 5) {
     // 2-D block-cyclic staircase: the super-tiles with at least one valid tile, column by column, dealt round-robin to
@@ -242,7 +244,7 @@ __global__ void __launch_bounds__(256, 2) gemm_f64_kernel(const GemmArgs g)
 {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   int ti, tj;
-  if(!map_tile(g, ti, tj)) return;
+  if(!map_tile(g, ti, tj, gridDim.x, blockIdx.x)) return;
 
   const int t = threadIdx.x;
   const int lane = t & 63;
@@ -340,7 +342,7 @@ __global__ void __launch_bounds__(256, 2) gemm_f64_kernel(const GemmArgs g)
 //   * ROLE changes nothing but the kernel's NAME: 1 = a trailing update of the Cholesky (the launches bench.py's roofline
 //     times with HIP events), 0 = everything else (in-panel updates, trsm/potri products, plain gpc_gemm_f64 calls), so
 //     that rocprofv3's per-kernel statistics separate the two populations.
-template <int NWN, int ROLE>
+template <int NWN, int ROLE, bool SPLITK = false>
 __global__ void __launch_bounds__(128 * NWN, NWN) gemm_nt_fast_kernel(const GemmArgs g)
 {
   constexpr int NT = 256 / (64 * NWN) * 2;  // n-subtiles per wave: NWN=2 -> 4, NWN=4 -> 2
@@ -348,7 +350,14 @@ __global__ void __launch_bounds__(128 * NWN, NWN) gemm_nt_fast_kernel(const Gemm
   static_assert(NWN == 2 || NWN == 4, "wave grid");
   extern __shared__ __attribute__((aligned(16))) double lds[];
   int ti, tj;
-  if(!map_tile(g, ti, tj)) return;
+  unsigned nbv = gridDim.x, bv = blockIdx.x;
+  int split = 0;
+  if(SPLITK) {   // piece `split` of every tile's k-range; the pieces of a tile keep the tile's XCD (nbv is a multiple of 8)
+    nbv = gridDim.x / (unsigned)g.ksplit;
+    split = (int)(blockIdx.x / nbv);
+    bv = blockIdx.x - (unsigned)split * nbv;
+  }
+  if(!map_tile(g, ti, tj, nbv, bv)) return;
   constexpr int NTHREADS = 128 * NWN;
   constexpr int KROWS = NTHREADS / 64;      // k rows covered per pass: 4 or 8
   constexpr int PASSES = BK / KROWS;        // 4 or 2
@@ -387,7 +396,14 @@ __global__ void __launch_bounds__(128 * NWN, NWN) gemm_nt_fast_kernel(const Gemm
   if(rb > rbmax) rb = rbmax;
   if(rb < 0) rb = 0;
   // upper-triangular operands (potri's V V'): rows >= m0 of A are zero left of column m0, so the product starts there
-  const int64_t kfirst = g.kstart ? (m0 / BK) * BK : 0;
+  int64_t kfirst = g.kstart ? (m0 / BK) * BK : 0;
+  int64_t KT = (g.K - kfirst) / BK;
+  if(SPLITK) {
+    const int64_t per = (KT + g.ksplit - 1) / g.ksplit, kt0 = (int64_t)split * per;
+    kfirst += kt0 * BK;
+    KT = KT - kt0 < per ? KT - kt0 : per;
+    if(KT < 0) KT = 0;
+  }
   const double* pa = g.A + ra + ((int64_t)(t >> 6) + kfirst) * g.lda;
   const double* pb = Bop + rb + ((int64_t)(t >> 6) + kfirst) * g.ldb;
   const int64_t stepa = (int64_t)KROWS * g.lda, stepb = (int64_t)KROWS * g.ldb;
@@ -400,7 +416,6 @@ __global__ void __launch_bounds__(128 * NWN, NWN) gemm_nt_fast_kernel(const Gemm
 #pragma unroll
     for(int j = 0; j < NT; j++) acc[i][j] = (double4_t){0.0, 0.0, 0.0, 0.0};
 
-  const int64_t KT = (g.K - kfirst) / BK;
   double2_t ra_[PASSES], rb_[PASSES];
   if(KT > 0) {
 #pragma unroll
@@ -471,7 +486,9 @@ __global__ void __launch_bounds__(128 * NWN, NWN) gemm_nt_fast_kernel(const Gemm
         bool ok = full_mn || (m < g.M && n < g.N);
         if(g.tri == 5) ok = ok && (!diag5 || roff + (int)(m - m0) >= coff + (int)(n - n0));
         else if(diag_tile) ok = ok && (g.tri == 2 ? (m <= n) : (m >= n));
-        if(ok) {
+        if(SPLITK) {
+          if(ok) g.part[(int64_t)split * g.part_stride + m + n * g.M] = alpha * acc[tm][tn][r];
+        } else if(ok) {
           double* p = g.C + m + n * g.ldc;
           double v = alpha * acc[tm][tn][r];
           if(g.atomic_c) {
@@ -489,6 +506,39 @@ __global__ void __launch_bounds__(128 * NWN, NWN) gemm_nt_fast_kernel(const Gemm
   }
 }
 
+
+// C(m, n) = beta C(m, n) + sum over the pieces, in piece order (deterministic), on the part of C the product writes
+__global__ void __launch_bounds__(256) split_combine_kernel(const GemmArgs g)
+{
+  const int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t n = blockIdx.y;
+  if(m >= g.M) return;
+  if(g.tri == 1 && m < n) {
+    // the kernel writes whole 128 x 128 tiles off the diagonal and the lower part of the diagonal ones: (m, n) above the
+    // diagonal is written only inside an off-diagonal tile, which a lower product never visits
+    return;
+  }
+  double v = 0.0;
+  for(int p = 0; p < g.ksplit; p++) v += g.part[(int64_t)p * g.part_stride + m + n * g.M];
+  double* c = g.C + m + n * g.ldc;
+  *c = g.beta != 0.0 ? v + g.beta * (*c) : v;
+}
+
+int launch_fast_splitk(const GemmArgs& g, unsigned slots, hipStream_t s)
+{
+  static std::atomic<uint64_t> attr_set{0};
+  auto kern = gemm_nt_fast_kernel<4, 0, true>;
+  int dev = 0;
+  GPC_HIP_CHECK(hipGetDevice(&dev));
+  if(!(attr_set.load() >> (dev & 63) & 1)) {
+    GPC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES));
+    attr_set.fetch_or(1ull << (dev & 63));
+  }
+  hipLaunchKernelGGL(kern, dim3(slots * (unsigned)g.ksplit), dim3(512), GEMM_LDS_BYTES, s, g);
+  hipLaunchKernelGGL(split_combine_kernel, dim3((unsigned)((g.M + 255) / 256), (unsigned)g.N), dim3(256), 0, s, g);
+  GPC_HIP_CHECK(hipGetLastError());
+  return GPC_OK;
+}
 
 template <int NWN, int ROLE>
 int launch_fast_role(const GemmArgs& g, unsigned grid, hipStream_t s)
@@ -585,6 +635,9 @@ static int gemm_ex(bool transa, bool transb, int64_t M, int64_t N, int64_t K, do
     use_atomic = e ? (atoi(e) != 0) : 1;
   }
   g.atomic_c = (beta == 1.0 && use_atomic) ? 1 : 0;
+  g.ksplit = 1;
+  g.part = nullptr;
+  g.part_stride = 0;
   g.kstart = (g_gemm_kstart && !transa && transb && M == N && K >= M && tri == 1) ? 1 : 0;
   g.tiles_m = (int)((M + BM - 1) / BM);
   g.tiles_n = (int)((N + BN - 1) / BN);
@@ -672,6 +725,34 @@ static int gemm_ex(bool transa, bool transb, int64_t M, int64_t N, int64_t K, do
   }
   if(tri == 5) return g_gemm_variant == 1 ? launch_fast<2>(g, grid, s) : launch_fast<4>(g, grid, s);
   if(g_gemm_variant > 0 && !a_kc && !b_kc && vec && g.K > 0 && (g.K % BK) == 0 && (M % 2) == 0 && (N % 2) == 0) {
+    // few tiles and a long k: one round of workgroups would each walk the whole k-range while most of the chip idles
+    // (N = 1000, K = 1024: 36 tiles, 161 us).  Cut every tile's k-range into pieces with a workgroup each; the pieces are
+    // added in a fixed order by a second small kernel, so the result does not depend on who finished first.
+    static int splitk = -1;
+    if(splitk < 0) { const char* e = getenv("GPC_GEMM_SPLITK"); splitk = e ? atoi(e) : 1; }
+    const int64_t ntiles = (tri == 1) ? (int64_t)g.tiles_m * (g.tiles_m + 1) / 2 : (int64_t)g.tiles_m * g.tiles_n;
+    if(splitk && g_gemm_variant == 2 && (tri == 0 || tri == 1) && ntiles <= 96 && g.K >= 512 && g_gemm_trailing == 0 &&
+       M <= 0x7fffffff && N <= 65535) {
+      int S = (int)(384 / ntiles);
+      const int64_t stages = g.K / BK;
+      if(S > stages / 8) S = (int)(stages / 8);      // at least 8 stages (128 columns of k) per piece
+      if(S > 16) S = 16;
+      if(S >= 2) {
+        void* wp = nullptr;
+        GPC_CHECK(workspace(WS_SPLITK, sizeof(double) * (size_t)S * (size_t)M * (size_t)N, &wp));
+        g.ksplit = S;
+        g.part = static_cast<double*>(wp);
+        g.part_stride = M * N;
+        unsigned nslots = grid;
+        if(g.kstart) {
+          // the k-start deal pads the grid to whole groups of 512 ids; a workgroup that exits at once still waits for its 73 KB
+          // of LDS, so with a few dozen tiles the plain enumeration (and the tiles' own k-starts) is the better launch
+          g.kstart = 2;
+          nslots = (unsigned)((32ull * g.super_m * g.super_m + 4ull * g.super_m + 7) & ~7ull);
+        }
+        return launch_fast_splitk(g, nslots, s);
+      }
+    }
     return g_gemm_variant == 2 ? launch_fast<4>(g, grid, s) : launch_fast<2>(g, grid, s);
   }
 #define GPC_GEMM_CASE(AK, BK_)                                         \

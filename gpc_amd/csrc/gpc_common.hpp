@@ -50,7 +50,8 @@ enum WorkspaceSlot {
   WS_PANEL_REF = 7,   // potrf panel chain: copy of the 64 rows under the diagonal block (panel_step_kernel)
   WS_AUG = 8,         // chol_inverse: the 2N x N array [K; I] -> [L; L^-T]
   WS_FLOW = 9,        // panel_flow: exchange buffer + control words
-  WS_NSLOTS = 10
+  WS_SPLITK = 10,     // gemm: the pieces of a split-k product
+  WS_NSLOTS = 11
 };
 int workspace(int slot, size_t bytes, void** out);
 bool poison_allocations();   // GPC_POISON_ALLOC=1: new buffers start as NaN (testing aid)

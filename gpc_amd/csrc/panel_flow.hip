@@ -92,6 +92,14 @@ __device__ __forceinline__ void pf_put(double* p, double x)
                      __HIP_MEMORY_SCOPE_AGENT);
 }
 
+__global__ void panel_flow_giveup_kernel(int* ctl, int* info)
+{
+  if(threadIdx.x == 0) {
+    ctl[1] = 2;
+    *info = PANEL_FLOW_TIMEOUT;
+  }
+}
+
 __global__ void __launch_bounds__(256) panel_flow_init_kernel(int* ctl, unsigned long long* X, int64_t n)
 {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -614,6 +622,10 @@ int panel_flow(int64_t M, int64_t nbk, double* P, int64_t lda, int* d_info, int6
   g.trace = trace;
   static const int polls = [] { const char* e = getenv("GPC_PANEL_FLOW_POLLS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : (1 << 23); }();
   g.max_polls = polls;
+  // GPC_PANEL_FLOW_POLLS < 64 (tests): the give-up state is raised before the launch, so that the host's handling of a time-out
+  // (read_info -> the launch-chain retry of gpc_gp_update_k_f64 / the grid) is exercised every time, not when a wait happens
+  // to outlast the limit
+  if(polls < 64) hipLaunchKernelGGL(panel_flow_giveup_kernel, dim3(1), dim3(64), 0, s, ctl, d_info);
   const int64_t nblocks = (int64_t)ncb * nrb - (int64_t)ncb * (ncb - 1) / 2;
   hipLaunchKernelGGL(panel_flow_kernel, dim3((unsigned)nblocks), dim3(256), 0, s, g);
   GPC_HIP_CHECK(hipGetLastError());
