@@ -386,13 +386,13 @@ int gpc_chol_inverse_f64(int64_t N, double* A, int64_t lda, double* invK, int64_
   }
   GPC_CHECK(set_identity(N, N, W + Np, ld2, s));
   GPC_CHECK(potrf_lower_tall(rows, Np, W, ld2, d_info, s, true));
-  GPC_CHECK(read_info(d_info, info, s));
-  if(*info != 0) return GPC_OK;
-  if(logdet) {
-    double sl = 0.0;
-    GPC_CHECK(diag_reduce(1, N, W, ld2, &sl, s));
-    *logdet = 2.0 * sl;
-  }
+  // This path is latency-bound (GP-LVM: 0.7 ms per evaluation, of which the host's waits for scalars are a good part), so the
+  // host does not wait for LAPACK's info before it issues the rest: the log-determinant's partial sums, the copy of L, the
+  // product and the mirror all go onto the stream, and ONE synchronisation at the end brings info and the partial sums
+  // back.  After a failed pivot the later kernels worked on a partial factor; their output is discarded with *info != 0.
+  double* ld_part = nullptr;
+  int64_t ld_n = 0;
+  if(logdet) GPC_CHECK(diag_reduce_launch(1, N, W, ld2, &ld_part, &ld_n, s));
   // L back into A.  (The whole block: W's upper triangle still holds the values it was given, i.e. A's own.)
   GPC_HIP_CHECK(hipMemcpy2DAsync(A, sizeof(double) * (size_t)lda, W, sizeof(double) * (size_t)ld2, sizeof(double) * (size_t)N,
                                  (size_t)N, hipMemcpyDeviceToDevice, s));
@@ -400,7 +400,16 @@ int gpc_chol_inverse_f64(int64_t N, double* A, int64_t lda, double* invK, int64_
     KStartScope ks;   // L^-T is upper triangular: a tile's product starts at its own first row (as in potri_full)
     GPC_CHECK(gemm(false, true, N, N, Np, 1.0, W + Np, ld2, W + Np, ld2, 0.0, invK, ldi, 1, s));
   }
-  return symmetrize(true, N, invK, ldi, s);
+  GPC_CHECK(symmetrize(true, N, invK, ldi, s));
+  if(logdet) {
+    double sl = 0.0;
+    GPC_HIP_CHECK(hipMemcpyAsync(info, d_info, sizeof(int), hipMemcpyDeviceToHost, s));
+    GPC_CHECK(diag_reduce_fetch(ld_part, ld_n, &sl, s));     // (synchronises the stream: info has arrived too)
+    if(*info == PANEL_FLOW_TIMEOUT) return read_info(d_info, info, s);   // reports the time-out as before
+    *logdet = *info == 0 ? 2.0 * sl : 0.0;
+    return GPC_OK;
+  }
+  return read_info(d_info, info, s);
 }
 
 int gpc_trsm_f64(char side, char uplo, char trans, char diag, int64_t M, int64_t Nrhs, double alpha,

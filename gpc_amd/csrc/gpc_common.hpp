@@ -131,6 +131,8 @@ int zero_triangle(bool zero_lower, int64_t N, double* A, int64_t lda, hipStream_
 int add_diag(int64_t N, double* A, int64_t lda, double c, hipStream_t s);
 // sum over the diagonal of f(A(i,i)): what = 0 trace, 1 sum of log.  Result to a host double (synchronises).
 int diag_reduce(int what, int64_t N, const double* A, int64_t lda, double* out_host, hipStream_t s);
+int diag_reduce_launch(int what, int64_t N, const double* A, int64_t lda, double** partial, int64_t* nparts, hipStream_t s);
+int diag_reduce_fetch(const double* partial, int64_t nparts, double* out_host, hipStream_t s);
 
 // device-side kernel spec: terms collapsed into what a Gram element needs
 struct KSpecDev {

@@ -399,6 +399,31 @@ int gemm_skinny(int64_t M, int64_t n, int64_t K, double alpha, const double* A, 
   return GPC_OK;
 }
 
+// The two halves of diag_reduce for callers that want to put more work on the stream before they wait for the scalar:
+// diag_reduce_launch leaves the partial sums in the WS_REDUCE slot, diag_reduce_fetch brings them back (synchronises).
+int diag_reduce_launch(int what, int64_t N, const double* A, int64_t lda, double** partial, int64_t* nparts, hipStream_t s)
+{
+  *partial = nullptr;
+  *nparts = 0;
+  if(N <= 0) return GPC_OK;
+  int64_t nb = (N + 255) / 256;
+  if(nb > 1024) nb = 1024;
+  void* ws = nullptr;
+  GPC_CHECK(workspace(WS_REDUCE, sizeof(double) * (size_t)nb, &ws));
+  hipLaunchKernelGGL(diag_reduce_kernel, dim3((unsigned)nb), dim3(256), 0, s, A, lda, N, what, static_cast<double*>(ws));
+  GPC_HIP_CHECK(hipGetLastError());
+  *partial = static_cast<double*>(ws);
+  *nparts = nb;
+  return GPC_OK;
+}
+
+int diag_reduce_fetch(const double* partial, int64_t nparts, double* out_host, hipStream_t s)
+{
+  *out_host = 0.0;
+  if(nparts <= 0) return GPC_OK;
+  return reduce_partials_to_host(partial, 1, nparts, out_host, s);
+}
+
 int diag_reduce(int what, int64_t N, const double* A, int64_t lda, double* out_host, hipStream_t s)
 {
   *out_host = 0.0;
