@@ -515,7 +515,7 @@ def main():
         traffic, traffic_src = pmc_traffic(args.workload if not args.n else "custom", g is None)
         jobs = world if replicas else 1
         roof = {"bound": "mfma",
-                "kernel": "gemm_nt_fast_kernel<4, 1> (trailing updates U1+U2 of %s)"
+                "kernel": "gemm_nt_fast_kernel<4, 1, false, true> (trailing updates U1+U2 of %s)"
                           % ("the grid's rank 0, 2-D staircase" if g is not None else "gpc_potrf_f64"),
                 "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": traffic,

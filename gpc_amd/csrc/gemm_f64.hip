@@ -342,7 +342,7 @@ __global__ void __launch_bounds__(256, 2) gemm_f64_kernel(const GemmArgs g)
 //   * ROLE changes nothing but the kernel's NAME: 1 = a trailing update of the Cholesky (the launches bench.py's roofline
 //     times with HIP events), 0 = everything else (in-panel updates, trsm/potri products, plain gpc_gemm_f64 calls), so
 //     that rocprofv3's per-kernel statistics separate the two populations.
-template <int NWN, int ROLE, bool SPLITK = false>
+template <int NWN, int ROLE, bool SPLITK = false, bool PF2 = false>
 __global__ void __launch_bounds__(128 * NWN, NWN) gemm_nt_fast_kernel(const GemmArgs g)
 {
   constexpr int NT = 256 / (64 * NWN) * 2;  // n-subtiles per wave: NWN=2 -> 4, NWN=4 -> 2
@@ -417,6 +417,11 @@ __global__ void __launch_bounds__(128 * NWN, NWN) gemm_nt_fast_kernel(const Gemm
     for(int j = 0; j < NT; j++) acc[i][j] = (double4_t){0.0, 0.0, 0.0, 0.0};
 
   double2_t ra_[PASSES], rb_[PASSES];
+  // operands requested TWO stages ahead (PF2): stage kt + 2 is loaded into registers behind the first MFMA group of stage kt and
+  // goes to LDS at the end of stage kt + 1, so a load has 1.75 stages (~6 us) to land instead of 0.75; two register sets
+  // alternate (the loop runs in pairs of stages so that each set is named statically)
+  double2_t ra2_[PASSES], rb2_[PASSES];
+  constexpr bool kPF2 = PF2;
   if(KT > 0) {
 #pragma unroll
     for(int i = 0; i < PASSES; i++) {
@@ -428,17 +433,30 @@ __global__ void __launch_bounds__(128 * NWN, NWN) gemm_nt_fast_kernel(const Gemm
       *reinterpret_cast<double2_t*>(lds + lds_w + i * KROWS * STRIDE_MC) = ra_[i];
       *reinterpret_cast<double2_t*>(lds + OP_ELEMS + lds_w + i * KROWS * STRIDE_MC) = rb_[i];
     }
+    if(PF2 && KT > 1) {   // stage 1 into the first set
+      pa += stagea;
+      pb += stageb;
+#pragma unroll
+      for(int i = 0; i < PASSES; i++) {
+        ra_[i] = *reinterpret_cast<const double2_t*>(pa + i * stepa);
+        rb_[i] = *reinterpret_cast<const double2_t*>(pb + i * stepb);
+      }
+    }
   }
   __syncthreads();
 
   const int fa = wm * 64 + (lane & 15) + (lane >> 4) * STRIDE_MC;               // + s*16 + kk*4*STRIDE_MC
   const int fb = wn * (16 * NT) + (lane & 15) + (lane >> 4) * STRIDE_MC;
 
-  for(int64_t kt = 0; kt < KT; kt++) {
+  // one stage: its 4 k-steps of MFMAs; behind the first of them the loads of stage `kt + ahead` into (la, lb); at its end the
+  // registers (sa, sb) -- stage kt + 1 -- go to the other LDS buffer
+  auto stage = [&](const int64_t kt, double2_t (&la)[PASSES], double2_t (&lb)[PASSES], double2_t (&sa)[PASSES],
+                   double2_t (&sb)[PASSES], const int ahead) {
     const double* As = lds + (kt & 1) * STAGE_ELEMS;
     const double* Bs = As + OP_ELEMS;
     double* nxt = lds + ((kt + 1) & 1) * STAGE_ELEMS;
     const bool more = (kt + 1 < KT);
+    const bool load = (kt + ahead < KT);
 #pragma unroll
     for(int kk = 0; kk < 4; kk++) {
       double a[4], b[NT];
@@ -451,25 +469,36 @@ __global__ void __launch_bounds__(128 * NWN, NWN) gemm_nt_fast_kernel(const Gemm
 #pragma unroll
         for(int tm = 0; tm < 4; tm++)
           acc[tm][tn] = __builtin_amdgcn_mfma_f64_16x16x4f64(b[tn], a[tm], acc[tm][tn], 0, 0, 0);
-      if(kk == 0 && more) {
-        // issue the next stage's loads behind the first MFMA group
+      if(kk == 0 && load) {
+        // issue the loads behind the first MFMA group
         pa += stagea;
         pb += stageb;
 #pragma unroll
         for(int i = 0; i < PASSES; i++) {
-          ra_[i] = *reinterpret_cast<const double2_t*>(pa + i * stepa);
-          rb_[i] = *reinterpret_cast<const double2_t*>(pb + i * stepb);
+          la[i] = *reinterpret_cast<const double2_t*>(pa + i * stepa);
+          lb[i] = *reinterpret_cast<const double2_t*>(pb + i * stepb);
         }
       }
     }
     if(more) {
 #pragma unroll
       for(int i = 0; i < PASSES; i++) {
-        *reinterpret_cast<double2_t*>(nxt + lds_w + i * KROWS * STRIDE_MC) = ra_[i];
-        *reinterpret_cast<double2_t*>(nxt + OP_ELEMS + lds_w + i * KROWS * STRIDE_MC) = rb_[i];
+        *reinterpret_cast<double2_t*>(nxt + lds_w + i * KROWS * STRIDE_MC) = sa[i];
+        *reinterpret_cast<double2_t*>(nxt + OP_ELEMS + lds_w + i * KROWS * STRIDE_MC) = sb[i];
       }
     }
     __syncthreads();
+  };
+  if(!kPF2) {
+    for(int64_t kt = 0; kt < KT; kt++) stage(kt, ra_, rb_, ra_, rb_, 1);
+  } else {
+    // even stages: set 1 (ra_) holds stage kt + 1, stage kt + 2 is loaded into set 2; odd stages the other way round
+    int64_t kt = 0;
+    for(; kt + 1 < KT; kt += 2) {
+      stage(kt, ra2_, rb2_, ra_, rb_, 2);
+      stage(kt + 1, ra_, rb_, ra2_, rb2_, 2);
+    }
+    if(kt < KT) stage(kt, ra2_, rb2_, ra_, rb_, 2);
   }
 
   const double alpha = g.alpha, beta = g.beta;
@@ -540,11 +569,11 @@ int launch_fast_splitk(const GemmArgs& g, unsigned slots, hipStream_t s)
   return GPC_OK;
 }
 
-template <int NWN, int ROLE>
+template <int NWN, int ROLE, bool PF2 = false>
 int launch_fast_role(const GemmArgs& g, unsigned grid, hipStream_t s)
 {
   static std::atomic<uint64_t> attr_set{0};   // one bit per device: the attribute is per device and per function
-  auto kern = gemm_nt_fast_kernel<NWN, ROLE>;
+  auto kern = gemm_nt_fast_kernel<NWN, ROLE, false, PF2>;
   int dev = 0;
   GPC_HIP_CHECK(hipGetDevice(&dev));
   if(!(attr_set.load() >> (dev & 63) & 1)) {
@@ -557,10 +586,31 @@ int launch_fast_role(const GemmArgs& g, unsigned grid, hipStream_t s)
   return GPC_OK;
 }
 
+}  // namespace
+
+// Trailing updates load their operands TWO stages ahead (PF2 instance of the fast kernel: 124 VGPRs, still four waves per
+// SIMD): 64.2 -> 69.3 TFLOP/s at N = 65 536.  The kernel then leaves no room for a panel kernel beside it, so potrf.hip
+// drops its look-ahead and sends every panel through the dataflow kernel when this is on.  GPC_GEMM_PF2=0 restores the
+// one-stage-ahead kernel (and with it the look-ahead and the 24 576-row dataflow limit).  Every other large product takes the
+// same instance (potri 58.3 -> 59.1 TFLOP/s at N = 32 768, a lone 32 768 x 512 syrk 63.0 -> 64.7, the grid gradient 528 ->
+// 510 ms); GPC_GEMM_PF2=1 keeps it to the trailing updates.
+bool gemm_two_ahead()
+{
+  static int pf2 = -1;
+  if(pf2 < 0) { const char* e = getenv("GPC_GEMM_PF2"); pf2 = e ? (atoi(e) != 0) : 1; }
+  return pf2 != 0;
+}
+
+namespace {
+
 template <int NWN>
 int launch_fast(const GemmArgs& g, unsigned grid, hipStream_t s)
 {
   if(g_gemm_trailing == 2) return launch_fast_role<NWN, 2>(g, grid, s);   // slab update inside a Cholesky panel
+  if(NWN == 4 && g_gemm_trailing && gemm_two_ahead()) return launch_fast_role<4, 1, true>(g, grid, s);
+  static int pf2_all = -1;
+  if(pf2_all < 0) { const char* e = getenv("GPC_GEMM_PF2"); pf2_all = (!e || atoi(e) >= 2) ? 1 : 0; }   // 1 = trailing updates only
+  if(NWN == 4 && pf2_all) return launch_fast_role<4, 0, true>(g, grid, s);
   return g_gemm_trailing ? launch_fast_role<NWN, 1>(g, grid, s) : launch_fast_role<NWN, 0>(g, grid, s);
 }
 

@@ -81,6 +81,7 @@ int gemm_stair2d(int64_t M, int64_t N, int64_t K, double alpha, const double* W,
                  int64_t ldv, double* C, int64_t ldc, const Stair2D& st, hipStream_t s);
 // While one of these is alive the fast GEMM launches under its "trailing update" kernel name (see gemm_f64.hip, ROLE).
 extern thread_local int g_gemm_trailing;
+bool gemm_two_ahead();   // gemm_f64.hip: trailing updates use the two-stage-ahead kernel (GPC_GEMM_PF2, default on)
 // potrf.hip: the panel chain's substitution step, shared with trsm.hip (see its definition)
 int panel_solve_rt(const double* Lbb, int64_t lda, int nb, double* B, int64_t ldb, int64_t M, double* C, int64_t ldc, int nc,
                    const double* Lnext, hipStream_t s);

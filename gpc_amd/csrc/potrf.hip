@@ -604,7 +604,7 @@ static int64_t panel_flow_maxrows()
   if(maxrows < 0) {
     const char* e = getenv("GPC_PANEL_FLOW");
     const char* m = getenv("GPC_PANEL_FLOW_MAXROWS");
-    maxrows = (e && atoi(e) == 0) ? 0 : (m ? atoll(m) : 24576);
+    maxrows = (e && atoi(e) == 0) ? 0 : (m ? atoll(m) : (gemm_two_ahead() ? (int64_t(1) << 40) : 24576));
   }
   return maxrows;
 }
@@ -715,12 +715,14 @@ int potrf_lower(int64_t N, double* A, int64_t lda, int* d_info, hipStream_t s, i
   // Look-ahead pays only on large matrices: the panel kernels of a tall panel fill the chip themselves, so running them
   // beside U2 mostly moves time around (N = 65 536: 1.497 -> 1.477 s), and below N ~ 32 768 the contention for CU
   // slots (a panel workgroup has to wait for trailing-update workgroups to retire) costs more than the overlap wins
-  // (N = 8192: 10.65 ms without, 11.06 ms with).  GPC_LOOKAHEAD = 0 / 1 forces it off / on, unset = by size.
+  // (N = 8192: 10.65 ms without, 11.06 ms with).  GPC_LOOKAHEAD = 0 / 1 forces it off / on, unset = by size -- and off at
+  // every size with the two-stage-ahead trailing update (gemm_two_ahead()): that kernel's 124 VGPRs x 4 waves leave a panel
+  // kernel no SIMD to sit on, so the overlap is gone and only the contention remains (N = 65 536: 1450 ms with, 1435 without).
   if(g_lookahead < 0) {
     const char* e = getenv("GPC_LOOKAHEAD");
     g_lookahead = e ? (atoi(e) != 0 ? 1 : 0) : 2;
   }
-  const bool la = (g_lookahead == 1 || (g_lookahead == 2 && N >= 28672)) && N > 2 * panel_width(N);
+  const bool la = (g_lookahead == 1 || (g_lookahead == 2 && N >= 28672 && !gemm_two_ahead())) && N > 2 * panel_width(N);
 
   if(!la) {
     int64_t nbk = 0;

@@ -16,7 +16,7 @@ done
 python - $OUT/pmc_bench_traffic.json <<'PY'
 import sqlite3, glob, json, sys, collections
 res = {"command": "rocprofv3 --pmc <C> -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline  (C = FETCH_SIZE, WRITE_SIZE; separate passes)",
-       "kernel": "gemm_nt_fast_kernel<4, 1> (the trailing-update launches only)", "units": "counter values are KB summed over the 8 XCDs per dispatch"}
+       "kernel": "gemm_nt_fast_kernel<4, 1, false, true> (the trailing-update launches only: the two-stage-ahead instance)", "units": "counter values are KB summed over the 8 XCDs per dispatch"}
 def collect(pattern):
     out = {}
     for c in ("FETCH_SIZE", "WRITE_SIZE"):
@@ -31,7 +31,7 @@ def collect(pattern):
                 tot += v; n += 1; dur += d
         out[c] = {"dispatches": n, "sum_kb": tot, "avg_kb_per_dispatch": tot / max(n, 1), "sum_duration_ms_under_pmc": dur / 1e6}
     return out
-res.update(collect("gemm_nt_fast_kernel<4, 1>"))
+res.update(collect("gemm_nt_fast_kernel<4, 1,"))
 f, w = res["FETCH_SIZE"], res["WRITE_SIZE"]
 # MI355X_MICROARCH.md "HBM": on gfx950 FETCH_SIZE reports half the bytes of wide coalesced reads -> double it; WRITE_SIZE taken as is
 res["hbm_bytes_per_launch"] = (2.0 * f["avg_kb_per_dispatch"] + w["avg_kb_per_dispatch"]) * 1024.0
