@@ -121,6 +121,67 @@ int workspace(int slot, size_t bytes, void** out)
   return GPC_OK;
 }
 
+// the thread's pinned staging buffer for small device -> host transfers (HostFetch, gpc_common.hpp)
+constexpr size_t HOST_STAGE_BYTES = 256 * 1024;
+struct HostStage {
+  char* p = nullptr;
+  ~HostStage()
+  {
+    if(p && std::this_thread::get_id() != g_loader_thread) (void)hipHostFree(p);   // (as WsSet: not after the runtime is gone)
+  }
+};
+static thread_local HostStage g_stage;
+int host_stage(size_t* capacity, char** base)
+{
+  if(!g_stage.p) {
+    void* h = nullptr;
+    if(hipHostMalloc(&h, HOST_STAGE_BYTES, hipHostMallocDefault) != hipSuccess) {
+      (void)hipGetLastError();
+      *capacity = 0;
+      *base = nullptr;
+      return GPC_OK;   // no pinned memory: HostFetch copies into the caller's memory directly
+    }
+    g_stage.p = static_cast<char*>(h);
+  }
+  *capacity = HOST_STAGE_BYTES;
+  *base = g_stage.p;
+  return GPC_OK;
+}
+
+int HostFetch::add(void* dst, const void* src, size_t bytes, hipStream_t s)
+{
+  if(bytes == 0) return GPC_OK;
+  size_t cap = 0;
+  char* base = nullptr;
+  GPC_CHECK(host_stage(&cap, &base));
+  const size_t off = (used + 15) & ~(size_t)15;
+  if(n >= 8 || off + bytes > cap) {
+    GPC_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, s));
+    return GPC_OK;
+  }
+  GPC_HIP_CHECK(hipMemcpyAsync(base + off, src, bytes, hipMemcpyDeviceToHost, s));
+  pieces[n].dst = dst;
+  pieces[n].off = off;
+  pieces[n].bytes = bytes;
+  n++;
+  used = off + bytes;
+  return GPC_OK;
+}
+
+int HostFetch::finish(hipStream_t s)
+{
+  GPC_HIP_CHECK(hipStreamSynchronize(s));
+  if(n > 0) {
+    size_t cap = 0;
+    char* base = nullptr;
+    GPC_CHECK(host_stage(&cap, &base));
+    for(int i = 0; i < n; i++) memcpy(pieces[i].dst, base + pieces[i].off, pieces[i].bytes);
+  }
+  n = 0;
+  used = 0;
+  return GPC_OK;
+}
+
 int potri_full(bool lower, int64_t N, double* A, int64_t lda, hipStream_t s);
 void release_lookahead();     // potrf.hip
 void release_profile();       // profile.hip
@@ -134,14 +195,19 @@ static void release_workspace()
       g_ws[i].p = nullptr;
       g_ws[i].bytes = 0;
     }
+  if(g_stage.p) {
+    (void)hipHostFree(g_stage.p);
+    g_stage.p = nullptr;
+  }
 }
 
 static thread_local bool g_flow_timed_out = false;   // the last read_info saw the dataflow kernel's time-out marker
 
 static int read_info(int* d_info, int* info, hipStream_t s)
 {
-  GPC_HIP_CHECK(hipMemcpyAsync(info, d_info, sizeof(int), hipMemcpyDeviceToHost, s));
-  GPC_HIP_CHECK(hipStreamSynchronize(s));
+  HostFetch f;
+  GPC_CHECK(f.add(info, d_info, sizeof(int), s));
+  GPC_CHECK(f.finish(s));
   if(*info == PANEL_FLOW_TIMEOUT) {
     *info = 0;
     g_flow_timed_out = true;
@@ -264,9 +330,10 @@ int gpc_memcpy_d2h(void* dst, const void* src, size_t bytes, void* stream)
   // as GPC_EHIP at the latest when its results are fetched -- also when no host-scalar call (gpc_coldot_f64) follows it
   int fault = 0;
   int* sticky = g_ws[WS_INFO].p ? static_cast<int*>(g_ws[WS_INFO].p) + SOLVE_FAULT_WORD : nullptr;
-  GPC_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, as_stream(stream)));
-  if(sticky) GPC_HIP_CHECK(hipMemcpyAsync(&fault, sticky, sizeof(int), hipMemcpyDeviceToHost, as_stream(stream)));
-  GPC_HIP_CHECK(hipStreamSynchronize(as_stream(stream)));
+  HostFetch f;
+  GPC_CHECK(f.add(dst, src, bytes, as_stream(stream)));
+  if(sticky) GPC_CHECK(f.add(&fault, sticky, sizeof(int), as_stream(stream)));
+  GPC_CHECK(f.finish(as_stream(stream)));
   if(fault) {
     GPC_HIP_CHECK(hipMemsetAsync(sticky, 0, sizeof(int), as_stream(stream)));
     set_error("a dataflow triangular solve timed out (device shared or pre-empted?); its result is NaN -- repeat the call, or "
@@ -377,14 +444,7 @@ int gpc_chol_inverse_f64(int64_t N, double* A, int64_t lda, double* invK, int64_
   void* wa = nullptr;
   GPC_CHECK(workspace(WS_AUG, sizeof(double) * (size_t)ld2 * (size_t)Np, &wa));
   double* W = static_cast<double*>(wa);
-  GPC_HIP_CHECK(hipMemcpy2DAsync(W, sizeof(double) * (size_t)ld2, A, sizeof(double) * (size_t)lda, sizeof(double) * (size_t)N,
-                                 (size_t)N, hipMemcpyDeviceToDevice, s));
-  if(Np > N) {
-    GPC_HIP_CHECK(hipMemset2DAsync(W + N, sizeof(double) * (size_t)ld2, 0, sizeof(double) * (size_t)(Np - N), (size_t)N, s));
-    GPC_HIP_CHECK(hipMemsetAsync(W + (size_t)N * ld2, 0, sizeof(double) * (size_t)ld2 * (size_t)(Np - N), s));
-    GPC_CHECK(set_identity(Np - N, Np - N, W + N + (size_t)N * ld2, ld2, s));
-  }
-  GPC_CHECK(set_identity(N, N, W + Np, ld2, s));
+  GPC_CHECK(build_augmented(N, Np, A, lda, W, ld2, s));   // [K 0; 0 I; I 0] in one launch (it was five: latency-bound here)
   GPC_CHECK(potrf_lower_tall(rows, Np, W, ld2, d_info, s, true));
   // This path is latency-bound (GP-LVM: 0.7 ms per evaluation, of which the host's waits for scalars are a good part), so the
   // host does not wait for LAPACK's info before it issues the rest: the log-determinant's partial sums, the copy of L, the
@@ -403,8 +463,7 @@ int gpc_chol_inverse_f64(int64_t N, double* A, int64_t lda, double* invK, int64_
   GPC_CHECK(symmetrize(true, N, invK, ldi, s));
   if(logdet) {
     double sl = 0.0;
-    GPC_HIP_CHECK(hipMemcpyAsync(info, d_info, sizeof(int), hipMemcpyDeviceToHost, s));
-    GPC_CHECK(diag_reduce_fetch(ld_part, ld_n, &sl, s));     // (synchronises the stream: info has arrived too)
+    GPC_CHECK(diag_reduce_fetch(ld_part, ld_n, &sl, s, info, d_info));     // (one synchronisation: info arrives with the sums)
     if(*info == PANEL_FLOW_TIMEOUT) return read_info(d_info, info, s);   // reports the time-out as before
     *logdet = *info == 0 ? 2.0 * sl : 0.0;
     return GPC_OK;

@@ -54,6 +54,19 @@ enum WorkspaceSlot {
   WS_NSLOTS = 11
 };
 int workspace(int slot, size_t bytes, void** out);
+// Small device -> host transfers (info words, partial sums, a gradient) go through a pinned buffer owned by the calling
+// thread: a copy into PAGEABLE memory makes the runtime drain the stream, stage the bytes and wait again -- two round trips of
+// 20-30 us each, which is what a GP-LVM evaluation at N = 1000 mostly consisted of.  add() queues a copy (falls back to a
+// direct pageable copy when the piece does not fit), finish() synchronises the stream ONCE and hands the pieces out.
+struct HostFetch {
+  struct Piece { void* dst; size_t off, bytes; };
+  Piece pieces[8];
+  int n = 0;
+  size_t used = 0;
+  int add(void* dst, const void* src, size_t bytes, hipStream_t s);
+  int finish(hipStream_t s);
+};
+int host_stage(size_t* capacity, char** base);   // capi.hip: the thread's pinned staging buffer
 bool poison_allocations();   // GPC_POISON_ALLOC=1: new buffers start as NaN (testing aid)
 // WS_INFO layout (64 bytes, zeroed when allocated): int[0] = LAPACK info of the running factorisation, int[4] = sticky
 // "a dataflow triangular solve timed out" flag (trsm.hip), read and cleared by take_solve_fault
@@ -133,7 +146,9 @@ int add_diag(int64_t N, double* A, int64_t lda, double c, hipStream_t s);
 // sum over the diagonal of f(A(i,i)): what = 0 trace, 1 sum of log.  Result to a host double (synchronises).
 int diag_reduce(int what, int64_t N, const double* A, int64_t lda, double* out_host, hipStream_t s);
 int diag_reduce_launch(int what, int64_t N, const double* A, int64_t lda, double** partial, int64_t* nparts, hipStream_t s);
-int diag_reduce_fetch(const double* partial, int64_t nparts, double* out_host, hipStream_t s);
+int build_augmented(int64_t N, int64_t Np, const double* K, int64_t ldk, double* W, int64_t ldw, hipStream_t s);   // misc.hip
+int diag_reduce_fetch(const double* partial, int64_t nparts, double* out_host, hipStream_t s, int* extra_dst = nullptr,
+                      const int* extra_src = nullptr);   // extra_src: one device int fetched in the same synchronisation
 
 // device-side kernel spec: terms collapsed into what a Gram element needs
 struct KSpecDev {

@@ -442,8 +442,9 @@ static int kern_grad_cross_pass(const gpc_kspec* ksp, const double* X, int64_t N
     hipLaunchKernelGGL((kern_grad_cross_kernel<64, true>), grid, dim3(256), 0, s, ks, g, partial);
   GPC_HIP_CHECK(hipGetLastError());
   std::vector<double> h((size_t)nblk * NPC);
-  GPC_HIP_CHECK(hipMemcpyAsync(h.data(), partial, sizeof(double) * h.size(), hipMemcpyDeviceToHost, s));
-  GPC_HIP_CHECK(hipStreamSynchronize(s));
+  HostFetch f;
+  GPC_CHECK(f.add(h.data(), partial, sizeof(double) * h.size(), s));
+  GPC_CHECK(f.finish(s));
   double S[NPC];
   for(int q = 0; q < NPC; q++) {
     double acc = 0.0;

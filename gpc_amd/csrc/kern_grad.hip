@@ -894,12 +894,12 @@ int fetch_partials(const double* d_p, int64_t nblk, int np, double* sums, hipStr
   const size_t n = (size_t)nblk * np;
   double* h = (double*)malloc(sizeof(double) * n);
   if(!h) return GPC_ENOMEM;
-  hipError_t e = hipMemcpyAsync(h, d_p, sizeof(double) * n, hipMemcpyDeviceToHost, s);
-  if(e == hipSuccess) e = hipStreamSynchronize(s);
-  if(e != hipSuccess) {
+  HostFetch f;
+  int rc = f.add(h, d_p, sizeof(double) * n, s);
+  if(rc == GPC_OK) rc = f.finish(s);
+  if(rc != GPC_OK) {
     free(h);
-    set_error("kern_grad copy-back failed: %s", hipGetErrorString(e));
-    return GPC_EHIP;
+    return rc;
   }
   for(int p = 0; p < np; p++) {
     double a = 0.0;

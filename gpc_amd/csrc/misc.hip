@@ -280,18 +280,21 @@ __global__ void __launch_bounds__(256) scale_vec_kernel(int64_t M, double* __res
   if(i < M) A[i + j * lda] *= by_rows ? v[i] : v[j];
 }
 
-int reduce_partials_to_host(const double* d_partial, int64_t ncols, int64_t nb, double* out_host, hipStream_t s)
+int reduce_partials_to_host(const double* d_partial, int64_t ncols, int64_t nb, double* out_host, hipStream_t s,
+                            int* extra_dst = nullptr, const int* extra_src = nullptr)
 {
-  // small: copy partials back and finish on the host in a fixed order (deterministic)
+  // small: copy partials back and finish on the host in a fixed order (deterministic).  extra_src: one device int that
+  // travels in the same synchronisation (LAPACK's info, the solve-fault word)
   const size_t n = (size_t)(ncols * nb);
-  double* h = (double*)malloc(sizeof(double) * n);
+  double* h = (double*)malloc(sizeof(double) * (n ? n : 1));
   if(!h) return GPC_ENOMEM;
-  hipError_t e = hipMemcpyAsync(h, d_partial, sizeof(double) * n, hipMemcpyDeviceToHost, s);
-  if(e == hipSuccess) e = hipStreamSynchronize(s);
-  if(e != hipSuccess) {
+  HostFetch f;
+  int rc = f.add(h, d_partial, sizeof(double) * n, s);
+  if(rc == GPC_OK && extra_src) rc = f.add(extra_dst, extra_src, sizeof(int), s);
+  if(rc == GPC_OK) rc = f.finish(s);
+  if(rc != GPC_OK) {
     free(h);
-    set_error("reduction copy-back failed: %s", hipGetErrorString(e));
-    return GPC_EHIP;
+    return rc;
   }
   for(int64_t j = 0; j < ncols; j++) {
     double acc = 0.0;
@@ -399,6 +402,18 @@ int gemm_skinny(int64_t M, int64_t n, int64_t K, double alpha, const double* A, 
   return GPC_OK;
 }
 
+__global__ void __launch_bounds__(256) build_augmented_kernel(int64_t N, int64_t Np, const double* __restrict__ K, int64_t ldk,
+                                                              double* __restrict__ W, int64_t ldw)
+{
+  const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x, c = blockIdx.y;
+  if(r >= Np + N) return;
+  double v;
+  if(r < N && c < N) v = K[r + c * ldk];
+  else if(r < Np) v = (r == c) ? 1.0 : 0.0;
+  else v = (r - Np == c) ? 1.0 : 0.0;
+  W[r + c * ldw] = v;
+}
+
 // The two halves of diag_reduce for callers that want to put more work on the stream before they wait for the scalar:
 // diag_reduce_launch leaves the partial sums in the WS_REDUCE slot, diag_reduce_fetch brings them back (synchronises).
 int diag_reduce_launch(int what, int64_t N, const double* A, int64_t lda, double** partial, int64_t* nparts, hipStream_t s)
@@ -417,11 +432,27 @@ int diag_reduce_launch(int what, int64_t N, const double* A, int64_t lda, double
   return GPC_OK;
 }
 
-int diag_reduce_fetch(const double* partial, int64_t nparts, double* out_host, hipStream_t s)
+int diag_reduce_fetch(const double* partial, int64_t nparts, double* out_host, hipStream_t s, int* extra_dst, const int* extra_src)
 {
   *out_host = 0.0;
-  if(nparts <= 0) return GPC_OK;
-  return reduce_partials_to_host(partial, 1, nparts, out_host, s);
+  if(nparts <= 0) {
+    if(extra_src) {
+      HostFetch f;
+      GPC_CHECK(f.add(extra_dst, extra_src, sizeof(int), s));
+      return f.finish(s);
+    }
+    return GPC_OK;
+  }
+  return reduce_partials_to_host(partial, 1, nparts, out_host, s, extra_dst, extra_src);
+}
+
+// W = [K 0; 0 I; I 0] for gpc_chol_inverse_f64 (capi.hip): K is N x N, W is (Np + N) x Np
+int build_augmented(int64_t N, int64_t Np, const double* K, int64_t ldk, double* W, int64_t ldw, hipStream_t s)
+{
+  const int64_t rows = Np + N;
+  hipLaunchKernelGGL(build_augmented_kernel, dim3((unsigned)((rows + 255) / 256), (unsigned)Np), dim3(256), 0, s, N, Np, K, ldk, W, ldw);
+  GPC_HIP_CHECK(hipGetLastError());
+  return GPC_OK;
 }
 
 int diag_reduce(int what, int64_t N, const double* A, int64_t lda, double* out_host, hipStream_t s)
@@ -488,12 +519,15 @@ extern "C" int gpc_coldot_f64(int64_t M, int64_t ncols, const double* A, int64_t
   hipLaunchKernelGGL(coldot_kernel, dim3((unsigned)ncols, (unsigned)nb), dim3(256), 0, s, A, lda, B, ldb, M,
                      static_cast<double*>(ws));
   GPC_HIP_CHECK(hipGetLastError());
-  GPC_CHECK(reduce_partials_to_host(static_cast<double*>(ws), ncols, nb, out, s));
   // the column dots of CGp (m' K^-1 m, CGp.cpp:928-930) follow the dataflow solves: this is where a solve that gave up
-  // (poisoned with NaN) is reported instead of being handed back as GPC_OK
+  // (poisoned with NaN) is reported instead of being handed back as GPC_OK; the sticky word travels with the partial sums
   int fault = 0;
-  GPC_CHECK(take_solve_fault(s, &fault));
+  void* wi = nullptr;
+  GPC_CHECK(workspace(WS_INFO, 64, &wi));
+  int* sticky = static_cast<int*>(wi) + SOLVE_FAULT_WORD;
+  GPC_CHECK(reduce_partials_to_host(static_cast<double*>(ws), ncols, nb, out, s, &fault, sticky));
   if(fault) {
+    GPC_HIP_CHECK(hipMemsetAsync(sticky, 0, sizeof(int), s));
     set_error("a dataflow triangular solve timed out (device shared or pre-empted?); its result is NaN -- repeat the call, or "
               "set GPC_TRSV_FLOW=0 for the stepped kernels");
     return GPC_EHIP;

@@ -27,6 +27,7 @@
 #include "gpc_common.hpp"
 #include <stdlib.h>
 #include <vector>
+#include <utility>
 
 namespace gpc {
 
@@ -702,6 +703,27 @@ static int64_t panel_width(int64_t rem)
     g_nb_outer = (v >= JB) ? (v / JB) * JB : -1;   // -1 = default
   }
   if(g_nb_outer > 0) return g_nb_outer;
+  // GPC_NB_TABLE="rem=width,rem=width,...": the first entry whose rem is >= the columns left decides (measurement aid)
+  static std::vector<std::pair<int64_t, int64_t>> table;
+  static int table_read = 0;
+  if(!table_read) {
+    table_read = 1;
+    if(const char* e = getenv("GPC_NB_TABLE")) {
+      const char* p = e;
+      while(*p) {
+        char* q = nullptr;
+        const int64_t r = strtoll(p, &q, 10);
+        if(q == p || *q != '=') break;
+        p = q + 1;
+        const int64_t w = strtoll(p, &q, 10);
+        if(q == p) break;
+        if(w >= JB) table.emplace_back(r, (w / JB) * JB);
+        p = (*q == ',') ? q + 1 : q;
+      }
+    }
+  }
+  for(const auto& rw : table)
+    if(rem <= rw.first) return rw.second;
   if(panel_flow_maxrows() >= 8192) {
     if(rem <= 4096) return 4096;
     if(rem <= 8192) return 2048;

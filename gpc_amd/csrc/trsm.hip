@@ -615,8 +615,9 @@ int take_solve_fault(hipStream_t s, int* fault)
   GPC_CHECK(workspace(WS_INFO, 64, &wi));
   int* sticky = static_cast<int*>(wi) + SOLVE_FAULT_WORD;
   *fault = 0;
-  GPC_HIP_CHECK(hipMemcpyAsync(fault, sticky, sizeof(int), hipMemcpyDeviceToHost, s));
-  GPC_HIP_CHECK(hipStreamSynchronize(s));
+  HostFetch f;
+  GPC_CHECK(f.add(fault, sticky, sizeof(int), s));
+  GPC_CHECK(f.finish(s));
   if(*fault) GPC_HIP_CHECK(hipMemsetAsync(sticky, 0, sizeof(int), s));
   return GPC_OK;
 }

@@ -9,9 +9,55 @@
 #include <cstdlib>
 #include <fstream>
 #include <iomanip>
+#include <iostream>
+#include <algorithm>
+#include <vector>
+#include <time.h>
 #include "gpc_hip.h"
 
 namespace {
+// GPC_GPLVM_TIMING=1: host wall time per library call of an evaluation, printed when the process ends (measurement aid)
+struct CallClock {
+  enum { NSLOT = 12 };
+  std::vector<double> samples[NSLOT];
+  const char* name[NSLOT];
+  bool on;
+  CallClock() : on(false)
+  {
+    for(int i = 0; i < NSLOT; i++) name[i] = 0;
+    const char* e = getenv("GPC_GPLVM_TIMING");
+    on = e && atoi(e) != 0;
+  }
+  ~CallClock()
+  {
+    if(!on) return;
+    for(int i = 0; i < NSLOT; i++)
+      if(name[i] && !samples[i].empty()) {
+        std::vector<double>& v = samples[i];
+        const double first = v[0];
+        std::sort(v.begin(), v.end());
+        std::cerr << "  [gplvm timing] " << name[i] << ": " << v.size() << " calls, median " << 1e6 * v[v.size() / 2] << " us, min "
+                  << 1e6 * v[0] << ", max " << 1e6 * v.back() << ", first " << 1e6 * first << std::endl;
+      }
+  }
+};
+CallClock g_clock;
+struct Timed {
+  int slot;
+  struct timespec t0;
+  Timed(int s, const char* n) : slot(s)
+  {
+    if(g_clock.on) { g_clock.name[s] = n; clock_gettime(CLOCK_MONOTONIC, &t0); }
+  }
+  ~Timed()
+  {
+    if(!g_clock.on) return;
+    struct timespec t1;
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    g_clock.samples[slot].push_back((t1.tv_sec - t0.tv_sec) + 1e-9 * (t1.tv_nsec - t0.tv_nsec));
+  }
+};
+
 void devFree(double*& p)
 {
   if(p) (void)gpc_free(p);
@@ -188,18 +234,18 @@ void CGplvm::updateK() const
   }
   if(!dK) dK = devAlloc((size_t)N * N);
   if(!dA) dA = devAlloc((size_t)N * d);
-  gpcCheck(gpc_memcpy_h2d(dX, pX->getVals(), sizeof(double) * (size_t)N * q, 0));
+  { Timed t(0, "h2d X"); gpcCheck(gpc_memcpy_h2d(dX, pX->getVals(), sizeof(double) * (size_t)N * q, 0)); }
   gpc_kspec ks;
   pkern->toKspec(ks);
   if(!dL) dL = devAlloc((size_t)N * N);
-  gpcCheck(gpc_gram_sym_f64(&ks, dX, N, q, N, dL, N, 0));                 // _updateK, CGplvm.cpp:418-432
+  { Timed t(1, "gram"); gpcCheck(gpc_gram_sym_f64(&ks, dX, N, q, N, dL, N, 0)); }                // _updateK, CGplvm.cpp:418-432
   int info = 0;
   // LcholK.chol(), logDet(LcholK), invK.pdinv(LcholK) (CGplvm.cpp:441-444) in one pass: dL <- L, dK <- invK
-  gpcCheck(gpc_chol_inverse_f64(N, dL, N, dK, N, &logDetK, &info, 0));
+  { Timed t(2, "chol_inverse"); gpcCheck(gpc_chol_inverse_f64(N, dL, N, dK, N, &logDetK, &info, 0)); }
   if(info != 0) throw ndlexceptions::MatrixNonPosDef();
-  gpcCheck(gpc_gemm_f64('N', 'N', N, d, N, 1.0, dK, N, dM, N, 0.0, dA, N, 0));   // invK * m, column by column in 503 / 374
+  { Timed t(3, "gemm invK m"); gpcCheck(gpc_gemm_f64('N', 'N', N, d, N, 1.0, dK, N, dM, N, 0.0, dA, N, 0)); }  // invK * m, column by column in 503 / 374
   quad.assign((size_t)d, 0.0);
-  gpcCheck(gpc_coldot_f64(N, d, dA, N, dM, N, &quad[0], 0));
+  { Timed t(4, "coldot"); gpcCheck(gpc_coldot_f64(N, d, dA, N, dM, N, &quad[0], 0)); }
   KupToDate = true;
 }
 
@@ -230,16 +276,16 @@ double CGplvm::logLikelihoodGradient(CMatrix& g) const
   gpc_kspec ks;
   pkern->toKspec(ks);
   // sum over the outputs of updateCovGradient (CGplvm.cpp:365-378); both passes below are linear in covGrad
-  gpcCheck(gpc_covgrad_multi_f64(N, d, dK, N, dA, N, dG, N, 0));
+  { Timed t(5, "covgrad_multi"); gpcCheck(gpc_covgrad_multi_f64(N, d, dK, N, dA, N, dG, N, 0)); }
   std::vector<double> gk(nk > 0 ? nk : 1, 0.0);
-  gpcCheck(gpc_kern_grad_f64(&ks, dX, N, q, N, dG, N, &gk[0], 0));        // getGradTransParams, CGplvm.cpp:589-596
+  { Timed t(6, "kern_grad"); gpcCheck(gpc_kern_grad_f64(&ks, dX, N, q, N, dG, N, &gk[0], 0)); }      // getGradTransParams, CGplvm.cpp:589-596
   for(unsigned int t = 0; t < pkern->getNumTransforms(); t++) {
     const unsigned int idx = pkern->getTransformIndex(t);
     gk[idx] *= pkern->getTransformGradFact(pkern->getParam(idx), t);
   }
-  gpcCheck(gpc_kern_gradx_f64(&ks, dX, N, q, N, dG, N, dGX, N, 0));       // getGradX + dotColCol loop, 573-604
+  { Timed t(7, "kern_gradx"); gpcCheck(gpc_kern_gradx_f64(&ks, dX, N, q, N, dG, N, dGX, N, 0)); }      // getGradX + dotColCol loop, 573-604
   std::vector<double> gx((size_t)N * q);
-  gpcCheck(gpc_memcpy_d2h(&gx[0], dGX, sizeof(double) * gx.size(), 0));
+  { Timed t(8, "d2h gx"); gpcCheck(gpc_memcpy_d2h(&gx[0], dGX, sizeof(double) * gx.size(), 0)); }
   for(unsigned int i = 0; i < nk; i++) g.setVal(gk[i], 0, i);
   for(int64_t k = 0; k < q; k++)
     for(int64_t i = 0; i < N; i++) {
