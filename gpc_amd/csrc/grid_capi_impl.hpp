@@ -140,6 +140,8 @@ int GRID_API(set_lookahead)(gpc_grid* g, int on)
 {
   if(!g) return GPC_EINVAL;
   g->gp->lookahead = on ? 1 : 0;
+  if(on == 2) g->gp->panel_first = false;   // 2: the free-running order of rounds 2 / 3a (A/B measurements)
+  if(on == 3) g->gp->panel_first = true;
   return GPC_OK;
 }
 

@@ -496,6 +496,7 @@ class GridGp {
       : ops_(std::move(ops)), comm_(std::move(comm)), pr_(pr), pc_(pc), r_(r), c_(c), nb_(nb)
   {
     if(const char* e = getenv("GPC_GRID_FUSED_ROWS")) fused_rows = atoll(e);
+    if(const char* e = getenv("GPC_GRID_PANEL_FIRST")) panel_first = atoi(e) != 0;
   }
   ~GridGp() { free_all(); }
 
@@ -514,6 +515,15 @@ class GridGp {
   double jitter() const { return jitter_; }
   const double* local_block() const { return A_; }
   int lookahead = 1;   // 0: everything on one stream, no overlap (debugging / A-B measurements)
+  // With look-ahead, U2(k) is held back until the FACTORISATION kernels of panel k+1 have run; only the panel's exchanges
+  // (and the small packing kernels between them) overlap the update.  Measured on MI355X (tools/overlap_probe.py): a
+  // workgroup of the panel kernels (416 registers, 80 KB of LDS) cannot be placed beside one of the update's, so a panel
+  // kernel launched while an update is running starts when the update's LAST workgroups have gone (a 0.32 ms tile
+  // factorisation took 8.1 ms beside a 9.2 ms update) -- the "overlap" of the free-running order was the panel chain AND
+  // its exchanges queueing up behind U2 (1 x 1 grid, N = 65 536: 1528 ms with that look-ahead, 1495 without).  In this
+  // order the chain runs on an idle chip right after U1 and the big exchange (the all-gather of the column panel) has the
+  // whole of U2 to hide behind.  GPC_GRID_PANEL_FIRST=0 / set_lookahead(2): the free-running order.
+  bool panel_first = true;
   // A panel whose tallest per-rank share (diagonal tile + rows below it) has at most this many rows is factored by every
   // rank of the owning process column in ONE call on [tile; its rows] -- the UNFACTORED tile travels down the column and
   // each rank factors it again beside its own rows (0.28 ms of redundant work) -- instead of tile factorisation, broadcast
@@ -676,6 +686,10 @@ class GridGp {
         GRID_CHECK(panel_phase(k + 1, SP, have_u1a ? ev_u1a_ : (SP != ST_MAIN ? ev_u1_ : nullptr), SP != ST_MAIN ? ev_u1_ : nullptr));
       }
       GRID_TRACE("U2");
+      if(pcomp_valid_[b ^ 1]) {      // panel k+1's kernels first (see panel_first)
+        GRID_CHECK(ops_->wait(ST_MAIN, ev_pcomp_[b ^ 1]));
+        pcomp_valid_[b ^ 1] = false;
+      }
       if(M > 0 && jfirst < L.Lc) GRID_CHECK(update(k, il0, jfirst, L.Lc - jfirst, ST_MAIN));
       GRID_TRACE("U2 done");
       if(SP != ST_MAIN) {
@@ -688,6 +702,7 @@ class GridGp {
       GRID_CHECK(ops_->wait(ST_MAIN, ev_u1_));
     }
     free_valid_[0] = free_valid_[1] = false;
+    pcomp_valid_[0] = pcomp_valid_[1] = false;
     int inf = 0;
     GRID_CHECK(ops_->read_info(info_dev_, &inf, ST_MAIN));
     int64_t v = inf > 0 ? (int64_t)inf : (inf < 0 ? (int64_t)-1 : ((int64_t)1 << 60));
@@ -1073,6 +1088,7 @@ class GridGp {
       }
       ev_panel_[b] = ops_->event_create();
       ev_free_[b] = ops_->event_create();
+      ev_pcomp_[b] = ops_->event_create();
     }
     if(pr_ > 1 && fused_rows > 0) {   // staging of [tile; rows] on the ranks that do not own the diagonal tile
       const int64_t rows = fused_rows < nb_ + L.mloc ? fused_rows : nb_ + L.mloc;
@@ -1119,7 +1135,7 @@ class GridGp {
     if(voff_dev_) ops_->release(voff_dev_);
     info_dev_ = nullptr;
     voff_dev_ = nullptr;
-    void** evs[] = {&ev_panel_[0], &ev_panel_[1], &ev_free_[0], &ev_free_[1], &ev_ready_, &ev_u1_, &ev_u1a_};
+    void** evs[] = {&ev_panel_[0], &ev_panel_[1], &ev_free_[0], &ev_free_[1], &ev_ready_, &ev_u1_, &ev_u1a_, &ev_pcomp_[0], &ev_pcomp_[1]};
     for(void** e : evs)
       if(*e) {
         ops_->event_destroy(*e);
@@ -1176,6 +1192,7 @@ class GridGp {
         // the whole panel is local: diagonal block + the rows below it in one chain (dpotrf + dtrsm)
         if(before_solve) GRID_CHECK(ops_->wait(st, before_solve));
         GRID_CHECK(ops_->potrf_panel(L.mloc - k * nb_, nb_, col + k * nb_, L.lld, k * nb_, info_dev_, st));
+        GRID_CHECK(panel_compute_done(b, st));
       } else if(panel_fused(k)) {
         // the updated, still unfactored tile goes down the column; every rank factors [tile; its rows] in one call
         if(r_ == kr) {
@@ -1196,6 +1213,7 @@ class GridGp {
           GRID_CHECK(ops_->potrf_panel(lds, nb_, St_, lds, k * nb_, info_dev_, st));
           GRID_CHECK(ops_->copy2d(col + il0 * nb_, L.lld, St_ + nb_, lds, M, nb_, st));
         }
+        GRID_CHECK(panel_compute_done(b, st));
       } else {
         if(r_ == kr) {
           const int64_t il = k / pr_;
@@ -1209,6 +1227,7 @@ class GridGp {
           if(before_solve) GRID_CHECK(ops_->wait(st, before_solve));
           GRID_CHECK(ops_->trsm_rlt(Dg_[b], nb_, nb_, col + il0 * nb_, L.lld, M, st));
         }
+        GRID_CHECK(panel_compute_done(b, st));
       }
       if(pc_ > 1 && M > 0) GRID_CHECK(ops_->copy2d(W_[b], ldw, col + il0 * nb_, L.lld, M, nb_, st));
     }
@@ -1247,6 +1266,15 @@ class GridGp {
       stats_.bytes_recv[AX_COL] += recv;
     }
     if(st != ST_MAIN) GRID_CHECK(ops_->record(ev_panel_[b], st));
+    return GPC_OK;
+  }
+
+  // the factorisation / solve kernels of the panel of parity b are on stream st: U2 of the step before may go (panel_first)
+  int panel_compute_done(int b, int st)
+  {
+    if(st == ST_MAIN || !panel_first || lookahead != 1) return GPC_OK;
+    GRID_CHECK(ops_->record(ev_pcomp_[b], st));
+    pcomp_valid_[b] = true;
     return GPC_OK;
   }
 
@@ -1330,6 +1358,8 @@ class GridGp {
   std::vector<int64_t> voff_host_, slot_, region_start_;
   void *ev_panel_[2] = {nullptr, nullptr}, *ev_free_[2] = {nullptr, nullptr}, *ev_ready_ = nullptr, *ev_u1_ = nullptr, *ev_u1a_ = nullptr;
   bool free_valid_[2] = {false, false};
+  void* ev_pcomp_[2] = {nullptr, nullptr};      // the factorisation kernels of the panel of that parity are done (panel_first)
+  bool pcomp_valid_[2] = {false, false};
   bool factored_ = false, alpha_valid_ = false, flow_timed_out_ = false;
   double logdet_ = 0.0, jitter_ = 0.0;
   GridStats stats_;

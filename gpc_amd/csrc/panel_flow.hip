@@ -24,7 +24,10 @@ namespace {
 constexpr int PF_OS = 80;   // LDS stride of an operand stage [k][row] in doubles (= 16 mod 32: conflict-free fragment reads)
 constexpr int PF_SS = 65;   // LDS column stride of the working block S[c * PF_SS + r]
 constexpr int PF_LS = 66;   // row stride of the L image for the solve
-constexpr int PF_TS = 18;   // row stride of potf2's multiplier table
+constexpr int PF_TS = 18;
+#ifndef PF_LEAN_NS
+#define PF_LEAN_NS 1
+#endif   // row stride of potf2's multiplier table
 
 struct PanelFlowArgs {
   double* P;          // the panel: M rows x nbk columns, leading dimension lda
@@ -109,15 +112,29 @@ __global__ void __launch_bounds__(256) panel_flow_init_kernel(int* ctl, unsigned
 
 __device__ long long pf_trace[64 * 64 * 4];   // measurement aid (GPC_PANEL_FLOW_TRACE): per block (b < 64, c < 64) four stamps
 
-__global__ void __launch_bounds__(256) panel_flow_kernel(const PanelFlowArgs g)
+// NS: operand sets of the products in registers (NS - 1 requests in flight).  3 is the fast form (416 registers: a SIMD to
+// itself); 2 fits in 256 registers, i.e. BESIDE one workgroup of the trailing-update GEMM on the same CU, which is what a
+// look-ahead panel needs in order to start before the update has drained (see S below for the LDS side of the same story).
+template <int NS>
+__global__ void __launch_bounds__(256, (NS < 3 ? 2 : 1)) panel_flow_kernel(const PanelFlowArgs g)
 {
   // one LDS arena, carved per phase:
   //   products : As = arena[0 .. 64*OS), Bs = arena[64*OS .. 128*OS)
   //   chol     : Pc, Wl, Tl = arena[0 .. 512), [512 .. 1024), [1024 .. 1536)   (careful loop: Pb = [0 .. 1024), T = next 64*TS)
   //   solve    : Ls = arena[0 .. 64*LS), Xs = next 16*OS
+  //   S (the working block of the chol / solve phases) lives BEHIND the solve's carve-up, inside the part only the products
+  //   use: the products are over before S is first written.  That keeps the workgroup at 82 KB of LDS instead of 115 --
+  //   and 86 KB is what one retiring workgroup of the trailing-update GEMM leaves free on a CU (2 x 73.5 of 160 KB): at
+  //   115 KB a panel launched beside a running update could not start before the update's LAST workgroups had gone
+  //   (tools/overlap_probe.py: a 0.32 ms tile factorisation took 8.3 ms beside a 9.3 ms product)
   __shared__ __attribute__((aligned(16))) double arena[2 * 64 * PF_OS];
-  __shared__ __attribute__((aligned(16))) double S[64 * PF_SS];
-  __shared__ int tk_s, giveup;
+  constexpr int S_OFF = 64 * PF_LS + 16 * PF_OS;
+  static_assert(S_OFF + 64 * PF_SS <= 2 * 64 * PF_OS && S_OFF >= 1024 + 64 * PF_TS, "S must fit behind the solve's / careful loop's carve-up");
+  double* const S = arena + S_OFF;
+  // two words in the padding of the arena's last operand row (columns 64 .. 79 of a stage row are never written or read by
+  // the products, and no other phase reaches this far): the workgroup stays at exactly 80 KB, two to a CU
+  int& tk_s = reinterpret_cast<int*>(arena + 2 * 64 * PF_OS - 2)[0];
+  int& giveup = reinterpret_cast<int*>(arena + 2 * 64 * PF_OS - 2)[1];
   const int t = threadIdx.x, lane = t & 63;
   const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
   const int wm = wv & 1, wn = wv >> 1;
@@ -173,8 +190,10 @@ __global__ void __launch_bounds__(256) panel_flow_kernel(const PanelFlowArgs g)
     // two in flight): a device-scope atomic load takes 2-3 us to come back, a 64-deep product 1.7 us, and one workgroup has
     // the CU to itself, so the second outstanding chunk is what keeps the matrix cores busy.  A request is one round of
     // loads; whoever finds a sentinel among them when the values are needed polls (pf_fetch).
-    double va[3][16], vb[3][16];
-    bool have[3] = {false, false, false};
+    double va[NS][16], vb[NS][16];
+    bool have[NS];
+#pragma unroll
+    for(int i = 0; i < NS; i++) have[i] = false;
     bool lost = false;
     auto request = [&](int slot, int tt) {
       bool ok = pf_try<16>(pa + (int64_t)tt * 64 * g.ldx, 4 * g.ldx, va[slot]);
@@ -213,17 +232,19 @@ __global__ void __launch_bounds__(256) panel_flow_kernel(const PanelFlowArgs g)
       }
     };
     const int nfull = c - 1 - tstart;                     // chunks t = tstart .. c-2
-    if(nfull > 0) request(0, tstart);
-    if(nfull > 1) request(1, tstart + 1);
-    // the slots rotate 0, 1, 2; unrolled by three so that every register index is static
-    for(int t0 = 0; t0 < nfull; t0 += 3) {
+    constexpr int AHEAD = (NS == 1) ? 1 : NS - 1;         // chunks requested ahead of the one being multiplied
 #pragma unroll
-      for(int u = 0; u < 3; u++) {
+    for(int i = 0; i < AHEAD; i++)
+      if(i < nfull) request(i % NS, tstart + i);
+    // the slots rotate 0 .. NS-1; unrolled by NS so that every register index is static
+    for(int t0 = 0; t0 < nfull; t0 += NS) {
+#pragma unroll
+      for(int u = 0; u < NS; u++) {
         const int tt = t0 + u;
         if(tt < nfull) {
           complete(u, tstart + tt);
           multiply(u);
-          if(tt + 2 < nfull) request((u + 2) % 3, tstart + tt + 2);
+          if(tt + AHEAD < nfull) request((u + AHEAD) % NS, tstart + tt + AHEAD);
           products();
         }
       }
@@ -585,6 +606,8 @@ __global__ void __launch_bounds__(256) panel_flow_kernel(const PanelFlowArgs g)
 
 }  // namespace
 
+thread_local int g_panel_flow_lean = 0;   // > 0: this thread's panels are launched beside a running trailing update (LeanPanelScope)
+
 // Factor the nbk-column panel whose diagonal block starts at P (M rows, M >= nbk): one launch.  Returns GPC_EUNSUPPORTED
 // when the shape is outside what the kernel takes (the caller then runs the launch chain).  zero_row0 >= 0: the rows from
 // zero_row0 on (a multiple of 64, relative to the panel) are an identity block whose 64-row block i is still zero left of
@@ -627,7 +650,11 @@ int panel_flow(int64_t M, int64_t nbk, double* P, int64_t lda, int* d_info, int6
   // to outlast the limit
   if(polls < 64) hipLaunchKernelGGL(panel_flow_giveup_kernel, dim3(1), dim3(64), 0, s, ctl, d_info);
   const int64_t nblocks = (int64_t)ncb * nrb - (int64_t)ncb * (ncb - 1) / 2;
-  hipLaunchKernelGGL(panel_flow_kernel, dim3((unsigned)nblocks), dim3(256), 0, s, g);
+  static const int lean_env = [] { const char* e = getenv("GPC_PANEL_FLOW_LEAN"); return e ? atoi(e) : -1; }();   // 0 / 1 forces the form
+  if(lean_env >= 0 ? lean_env > 0 : g_panel_flow_lean > 0)
+    hipLaunchKernelGGL(panel_flow_kernel<PF_LEAN_NS>, dim3((unsigned)nblocks), dim3(256), 0, s, g);
+  else
+    hipLaunchKernelGGL(panel_flow_kernel<3>, dim3((unsigned)nblocks), dim3(256), 0, s, g);
   GPC_HIP_CHECK(hipGetLastError());
   return GPC_OK;
 }

@@ -121,7 +121,7 @@ class Grid(object):
                 "update_flops": out[4], "update_launches": int(out[5]), "update_bytes": out[6], "bytes_held": out[7]}
 
     def set_lookahead(self, on):
-        self.b.check(self.b.set_lookahead(self.h, 1 if on else 0), self.h)
+        self.b.check(self.b.set_lookahead(self.h, int(on)), self.h)   # 0 off, 1 on, 2 on with the free-running order
 
     def set_problem(self, terms, X, Y=None, Xstar=None):
         ks = _kspec(terms)

@@ -217,6 +217,10 @@ int gpc_grid_barrier(gpc_grid* g);
  * the grid is unusable afterwards (destroy it).  The library calls this itself when an entry point fails with GPC_EHIP /
  * GPC_ENOMEM on one rank.  No effect on RCCL / transport grids (their own time-outs apply). */
 int gpc_grid_abort(gpc_grid* g);
+/* on = 0: every kernel and exchange of the factorisation on one stream.  1 (default): panel k+1 on a second stream -- its
+ * factorisation kernels run right after U1(k) and BEFORE U2(k) (they cannot share a CU with the update's workgroups, so
+ * launched beside a running U2 they would wait for its end), its exchanges overlap U2(k).  2: the free-running order
+ * (U2(k) and the whole panel chain issued side by side; measurement aid). */
 int gpc_grid_set_lookahead(gpc_grid* g, int on);
 /* out[13] = N, nb, T (tiles per side), pr, pc, r, c, local rows, local columns, extra rows, local tile rows, columns,
  * rows reflected (1 on a pr x 1 grid: the rounds of pr tile rows alternate direction, tile row I lives on process row

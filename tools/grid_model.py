@@ -151,13 +151,18 @@ class Costs(object):
 # ---- 3. the replay ----------------------------------------------------------------------------------------------------------
 class Params(object):
     def __init__(self, link_gbs=50.0, alpha_us=25.0, exchange="fanout", preempt_us=50.0, rccl_chip_share=0.06,
-                 host_sync_us=15.0):
+                 host_sync_us=15.0, coresident=False):
         self.link_gbs = link_gbs          # one direction of one xGMI link, as RCCL delivers it
         self.alpha_us = alpha_us          # start-up of one exchange (launch of the RCCL kernel + the handshake)
         self.exchange = exchange          # "fanout": direct send / recv between every pair; "ring": ring broadcast per root
         self.preempt_us = preempt_us      # a panel-stream kernel beside a running update waits for workgroups to retire
         self.rccl_chip_share = rccl_chip_share
         self.host_sync_us = host_sync_us
+        # Can a factorisation / solve kernel of the panel stream START while a trailing update is running?  Measured on MI355X
+        # (tools/overlap_probe.py): no -- its workgroups (416 registers, 80 KB LDS) do not fit beside the update's, so it
+        # starts when the update has drained (a 0.32 ms tile factorisation launched 1 ms into a 9.2 ms update ended with it).
+        # True replays the assumption of the first round-3 table (start after preempt_us, then share the chip).
+        self.coresident = coresident
 
 
 # share of the chip a panel-stream kernel takes from the trailing update that runs beside it
@@ -335,6 +340,9 @@ def simulate(ops, costs, par, nb):
                 finish(r, st, i)          # everything before it on the stream is done: the host may go on
                 progressed = True
                 continue
+            if (not par.coresident and st != 0 and k not in COLLECTIVES and mainop[r] is not None
+                    and CHIP_SHARE.get(k, 0.2) >= 0.5):
+                return progressed          # waits for the running update to drain (retried after every event)
             busy[r][st] = i
             progressed = True
             o["_t0"] = now[0]
@@ -449,6 +457,8 @@ def main():
     ap.add_argument("--nb", default="1024")
     ap.add_argument("--exchange", default="fanout,ring")
     ap.add_argument("--json", default=None)
+    ap.add_argument("--order", default="1", help="look-ahead order(s): 1 = panel kernels before U2 (default build), 2 = free-running")
+    ap.add_argument("--coresident", action="store_true", help="panel kernels may start beside a running update (not what MI355X does)")
     a = ap.parse_args()
     costs = Costs(a.costs)
     rows = []
@@ -456,23 +466,25 @@ def main():
         N, D = WORKLOADS[wl]
         base = {}
         for nb in [int(x) for x in a.nb.split(",")]:
-            one = predict(costs, wl, 1, 1, nb, Params())
+            one = predict(costs, wl, 1, 1, nb, Params(coresident=a.coresident), lookahead=int(a.order.split(",")[0]))
             base[nb] = one["ms"]
             print("%s N=%d nb=%d: 1x1 through the grid path: %.1f ms (%.1f TFLOP/s)" % (wl, N, nb, one["ms"], N ** 3 / 3.0 / one["ms"] * 1e-9))
-            for ex in a.exchange.split(","):
+            for order in [int(x) for x in a.order.split(",")]:
+              for ex in a.exchange.split(","):
                 for bw in [float(x) for x in a.link_gbs.split(",")]:
                     for shape in a.shapes.split(","):
                         pr, pc = [int(x) for x in shape.split("x")]
                         if pr * pc == 1:
                             continue
-                        par = Params(link_gbs=bw, alpha_us=a.alpha_us, exchange=ex)
-                        o = predict(costs, wl, pr, pc, nb, par)
+                        par = Params(link_gbs=bw, alpha_us=a.alpha_us, exchange=ex, coresident=a.coresident)
+                        o = predict(costs, wl, pr, pc, nb, par, lookahead=order)
                         row = {"workload": wl, "N": N, "nb": nb, "shape": shape, "ranks": pr * pc, "exchange": ex, "link_gbs": bw,
+                               "order": order, "coresident": bool(a.coresident),
                                "ms": o["ms"], "speedup_vs_1x1": base[nb] / o["ms"], "max_update_ms": max(o["update_ms"]),
                                "max_exchange_ms": max(o["exchange_ms"])}
                         rows.append(row)
-                        print("  %-4s %-7s %5.0f GB/s  %-4s %9.1f ms  x%.2f   (updates %.1f ms, in exchanges %.1f ms)" % (
-                            wl, ex, bw, shape, o["ms"], row["speedup_vs_1x1"], row["max_update_ms"], row["max_exchange_ms"]), flush=True)
+                        print("  %-4s order %d %-7s %5.0f GB/s  %-4s %9.1f ms  x%.2f   (updates %.1f ms, in exchanges %.1f ms)" % (
+                            wl, order, ex, bw, shape, o["ms"], row["speedup_vs_1x1"], row["max_update_ms"], row["max_exchange_ms"]), flush=True)
     if a.json:
         json.dump(rows, open(a.json, "w"), indent=1)
 

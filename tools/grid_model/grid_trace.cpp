@@ -303,7 +303,9 @@ extern "C" int gridtrace_run(int pr, int pc, long nb, long N, long D, long d, lo
     const int r = rank / pc, c = rank % pc;
     GridGp gp(std::unique_ptr<GridOps>(new TraceOps(&sink)), std::unique_ptr<GridComm>(new TraceComm(&sink, pr, pc, r, c)), pr, pc,
               r, c, nb);
-    gp.lookahead = lookahead;
+    gp.lookahead = lookahead ? 1 : 0;
+    if(lookahead == 2) gp.panel_first = false;   // the free-running order (as gpc_grid_set_lookahead(g, 2))
+    if(lookahead == 3) gp.panel_first = true;
     rc = gp.set_problem(&ks, dummy, N, D, N, d > 0 ? dummy : nullptr, d, N, Ns > 0 ? dummy : nullptr, Ns, Ns > 0 ? Ns : 1);
     sink.op(-1, "begin");     // everything before this line is problem set-up, not part of a step
     gp.reset_stats();

@@ -30,7 +30,7 @@ n1, ms1, fl1 = api.profile_read(0, reset=True)
 del K
 torch.cuda.empty_cache()
 g = grid.create_local(1, 1, nb)[0]
-g.set_lookahead(os.environ.get("GRID_LA", "1") != "0")
+g.set_lookahead(int(os.environ.get("GRID_LA", "1")))
 g.set_problem(terms, X, y if os.environ.get("GRID_Y", "0") == "1" else None, None)
 g.update_k()
 t0 = time.time()
