@@ -606,8 +606,6 @@ __global__ void __launch_bounds__(256, (NS < 3 ? 2 : 1)) panel_flow_kernel(const
 
 }  // namespace
 
-thread_local int g_panel_flow_lean = 0;   // > 0: this thread's panels are launched beside a running trailing update (LeanPanelScope)
-
 // Factor the nbk-column panel whose diagonal block starts at P (M rows, M >= nbk): one launch.  Returns GPC_EUNSUPPORTED
 // when the shape is outside what the kernel takes (the caller then runs the launch chain).  zero_row0 >= 0: the rows from
 // zero_row0 on (a multiple of 64, relative to the panel) are an identity block whose 64-row block i is still zero left of
@@ -650,8 +648,11 @@ int panel_flow(int64_t M, int64_t nbk, double* P, int64_t lda, int* d_info, int6
   // to outlast the limit
   if(polls < 64) hipLaunchKernelGGL(panel_flow_giveup_kernel, dim3(1), dim3(64), 0, s, ctl, d_info);
   const int64_t nblocks = (int64_t)ncb * nrb - (int64_t)ncb * (ncb - 1) / 2;
-  static const int lean_env = [] { const char* e = getenv("GPC_PANEL_FLOW_LEAN"); return e ? atoi(e) : -1; }();   // 0 / 1 forces the form
-  if(lean_env >= 0 ? lean_env > 0 : g_panel_flow_lean > 0)
+  // GPC_PANEL_FLOW_LEAN=1 (measurement aid): the two-per-CU form.  It does start beside a running trailing update (a tile
+  // factorisation launched 1 ms into a 9.2 ms update: done after 2.0 ms instead of 8.1), but capped at 256 registers the
+  // solve's 120 preloaded entries of L spill and the kernel is 2.5x slower on its own (0.79 against 0.32 ms for a 1024 tile)
+  static const int lean_env = [] { const char* e = getenv("GPC_PANEL_FLOW_LEAN"); return e ? atoi(e) : 0; }();
+  if(lean_env > 0)
     hipLaunchKernelGGL(panel_flow_kernel<PF_LEAN_NS>, dim3((unsigned)nblocks), dim3(256), 0, s, g);
   else
     hipLaunchKernelGGL(panel_flow_kernel<3>, dim3((unsigned)nblocks), dim3(256), 0, s, g);

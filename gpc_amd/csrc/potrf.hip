@@ -726,7 +726,8 @@ static int64_t panel_width(int64_t rem)
     if(rem <= rw.first) return rw.second;
   if(panel_flow_maxrows() >= 8192) {
     if(rem <= 4096) return 4096;
-    if(rem <= 8192) return 2048;
+    // (round 2 had a 2048-wide tier for 4096 < rem <= 8192; with the faster trailing update 1024 wins there too:
+    //  N = 8192 5.63 -> 5.46 ms, 12 288 14.29 -> 14.11, 16 384 29.60 -> 29.48; tools/nb_table_sweep.sh)
   }
   return 1024;
 }
