@@ -28,6 +28,7 @@ namespace gpc {
 
 thread_local int g_gemm_trailing = 0;  // TrailingScope (gpc_common.hpp); per host thread
 thread_local int g_gemm_kstart = 0;    // KStartScope (gpc_common.hpp)
+thread_local int g_gemm_kend = 0;      // KEndScope
 int g_gemm_variant = -1;  // -1: read GPC_GEMM_VARIANT on first use; 0 generic only; 1 fast 4-wave; 2 fast 8-wave
 
 namespace {
@@ -55,6 +56,8 @@ struct GemmArgs {
   int debug_same_rows;   // ablation knob (env GPC_GEMM_DEBUG_SAMEROWS): never set in production
   int kstart;            // fast NT kernel only: both operands are upper triangular (square product, K == M == N):
                          // a tile's k-loop starts at its first row m0 (everything left of it is zero)
+  int kend;              // fast NT kernel only: B (N x K, N == K) is lower triangular, so the k-loop of tile column n0 stops at
+                         // n0 + 128 (the rows of a tall panel times the inverse of its diagonal tile, potrf.hip)
   int ksplit;            // > 1 (fast NT kernel, SPLITK instance): the k-range of every tile is cut into ksplit pieces, each a
   double* part;          // workgroup of its own writing alpha * (its partial product) to part + piece * part_stride (M x N,
   int64_t part_stride;   // leading dimension M); split_combine_kernel adds the pieces in order.  For products with few tiles
@@ -397,7 +400,7 @@ __global__ void __launch_bounds__(128 * NWN, NWN) gemm_nt_fast_kernel(const Gemm
   if(rb < 0) rb = 0;
   // upper-triangular operands (potri's V V'): rows >= m0 of A are zero left of column m0, so the product starts there
   int64_t kfirst = g.kstart ? (m0 / BK) * BK : 0;
-  int64_t KT = (g.K - kfirst) / BK;
+  int64_t KT = ((g.kend && n0 + BN < g.K ? n0 + BN : g.K) - kfirst) / BK;
   if(SPLITK) {
     const int64_t per = (KT + g.ksplit - 1) / g.ksplit, kt0 = (int64_t)split * per;
     kfirst += kt0 * BK;
@@ -689,6 +692,7 @@ static int gemm_ex(bool transa, bool transb, int64_t M, int64_t N, int64_t K, do
   g.part = nullptr;
   g.part_stride = 0;
   g.kstart = (g_gemm_kstart && !transa && transb && M == N && K >= M && tri == 1) ? 1 : 0;
+  g.kend = (g_gemm_kend && !transa && transb && N == K && tri == 0) ? 1 : 0;
   g.tiles_m = (int)((M + BM - 1) / BM);
   g.tiles_n = (int)((N + BN - 1) / BN);
   g.super_m = (g.tiles_m + SUPER - 1) / SUPER;

@@ -51,7 +51,8 @@ enum WorkspaceSlot {
   WS_AUG = 8,         // chol_inverse: the 2N x N array [K; I] -> [L; L^-T]
   WS_FLOW = 9,        // panel_flow: exchange buffer + control words
   WS_SPLITK = 10,     // gemm: the pieces of a split-k product
-  WS_NSLOTS = 11
+  WS_PANEL_TMP = 11,  // potrf: copy of a tall panel's rows below the tile (panel_by_inverse)
+  WS_NSLOTS = 12
 };
 int workspace(int slot, size_t bytes, void** out);
 // Small device -> host transfers (info words, partial sums, a gradient) go through a pinned buffer owned by the calling
@@ -112,6 +113,11 @@ struct TrailingScope {
   ~TrailingScope() { g_gemm_trailing = 0; }
 };
 // While alive: A * B' products whose operands are UPPER triangular start each tile's k-loop at the tile's first row.
+extern thread_local int g_gemm_kend;   // KEndScope: the B operand of an NT product is lower triangular (N == K): tile column n0 stops at k = n0 + 128
+struct KEndScope {
+  KEndScope() { g_gemm_kend = 1; }
+  ~KEndScope() { g_gemm_kend = 0; }
+};
 extern thread_local int g_gemm_kstart;
 struct KStartScope {
   KStartScope() { g_gemm_kstart = 1; }

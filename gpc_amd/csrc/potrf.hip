@@ -616,9 +616,50 @@ static int64_t panel_flow_maxrows()
 // the whole remaining panel after every 64 columns this moves 1.75x fewer bytes of the panel through HBM (the
 // 64-deep updates are memory-bound) in half as many GEMM launches: 1.51 -> 1.29 ms for a 65 536 x 512 panel.
 constexpr int64_t SLAB = 128;
+
+// A TALL panel (M rows, nbk columns) by way of the inverse of its diagonal tile.  The dataflow kernel takes the rows below the
+// tile through 64 x 64 blocks on one CU each (19.5 TFLOP/s on a 32 768-row panel: 1.76 ms); here the tile is factored together
+// with an identity below it -- [A11; I] -> [L11; L11^-T], one dataflow launch of 2 nbk rows, what gpc_chol_inverse_f64 does for
+// a whole matrix -- and the rows below become ONE chip-wide product, L21 = A21 L11^-T, whose k-loop stops at the diagonal of
+// the triangular operand (KEndScope).  A21 is copied aside first: the product cannot run in place (tile column j reads the
+// columns k <= j of its row block that another workgroup overwrites).  Rounding: L21 carries the error of an explicit inverse
+// of L11, cond(L11) eps instead of eps -- L11 is a Cholesky factor of a 1024 x 1024 diagonal block, whose condition is the
+// square root of the block's; the full-size parity tests (K K^-1 e_j, L L' e_j at N = 65 536) hold at the same tolerances.
+int panel_by_inverse(int64_t M, int64_t nbk, double* P, int64_t lda, int* d_info, int64_t col0, hipStream_t s)
+{
+  const int64_t below = M - nbk, ld2 = 2 * nbk;
+  void* wa = nullptr;
+  GPC_CHECK(workspace(WS_AUG, sizeof(double) * (size_t)ld2 * (size_t)nbk, &wa));
+  double* W = static_cast<double*>(wa);
+  void* wt = nullptr;
+  GPC_CHECK(workspace(WS_PANEL_TMP, sizeof(double) * (size_t)below * (size_t)nbk, &wt));
+  double* T = static_cast<double*>(wt);
+  GPC_CHECK(build_augmented(nbk, nbk, P, lda, W, ld2, s));
+  const int rc = panel_flow(ld2, nbk, W, ld2, d_info, col0, s, nbk, 0);
+  if(rc != GPC_OK) return rc;
+  GPC_HIP_CHECK(hipMemcpy2DAsync(T, sizeof(double) * (size_t)below, P + nbk, sizeof(double) * (size_t)lda, sizeof(double) * (size_t)below,
+                                 (size_t)nbk, hipMemcpyDeviceToDevice, s));
+  // L11 back (the whole block: W's upper triangle still holds what it was given)
+  GPC_HIP_CHECK(hipMemcpy2DAsync(P, sizeof(double) * (size_t)lda, W, sizeof(double) * (size_t)ld2, sizeof(double) * (size_t)nbk,
+                                 (size_t)nbk, hipMemcpyDeviceToDevice, s));
+  GPC_CHECK(transpose_inplace(nbk, W + nbk, ld2, s));   // L11^-T (upper) -> L11^-1 (lower): the [n][k] operand of an NT product
+  {
+    KEndScope ke;
+    GPC_CHECK(gemm(false, true, below, nbk, nbk, 1.0, T, below, W + nbk, ld2, 0.0, P + nbk, lda, 0, s));
+  }
+  return GPC_OK;
+}
+
 int factor_panel(int64_t N, double* A, int64_t lda, int64_t k0, int64_t nbk, int* d_info, hipStream_t s, int64_t col0 = 0,
                  int64_t zrow = -1)
 {
+  // tall panels: diagonal tile + its inverse in one dataflow launch, the rows below as one product (GPC_PANEL_INV_MINROWS = 0: off)
+  static const int64_t inv_minrows = [] { const char* e = getenv("GPC_PANEL_INV_MINROWS"); return e ? atoll(e) : (int64_t)12288; }();
+  if(inv_minrows > 0 && zrow < 0 && N - k0 - nbk >= inv_minrows && nbk >= 512 && nbk <= 2048 && nbk % 128 == 0 && (N - k0) % 2 == 0 &&
+     panel_flow_maxrows() >= 2 * nbk) {
+    const int rc = panel_by_inverse(N - k0, nbk, A + k0 + k0 * lda, lda, d_info, col0 + k0, s);
+    if(rc != GPC_EUNSUPPORTED) return rc;
+  }
   // short panels: the whole panel as one dataflow launch (panel_flow.hip) instead of five launches per 128 columns
   if(N - k0 <= panel_flow_maxrows()) {
     const int rc = panel_flow(N - k0, nbk, A + k0 + k0 * lda, lda, d_info, col0 + k0, s, zrow >= 0 ? zrow - k0 : -1, k0 / 64);

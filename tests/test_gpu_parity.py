@@ -1035,3 +1035,44 @@ print("RESULT", info, repr(ld), int(b"timed out" in msg), res[0][2], repr(res[0]
     assert int(f[1]) == 0 and int(f[4]) == 0
     assert int(f[3]) == 1, "the time-out path was not taken: the test does not test what it says"
     assert abs(float(f[2]) - want) <= 1e-10 * abs(want) and abs(float(f[5]) - want) <= 1e-10 * abs(want)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("env", [{"GPC_GEMM_PF2": "0"}, {"GPC_GEMM_PF2": "1", "GPC_LOOKAHEAD": "1"}, {"GPC_PANEL_FLOW_LEAN": "1"},
+                                 {"GPC_NB_TABLE": "2048=2048,8192=512", "GPC_PANEL_FLOW_MAXROWS": "3000"}])
+def test_alternative_kernel_configurations_factor_the_same_matrix(env):
+    """The A/B switches of DESIGN's appendix select other DEVICE code paths (the one-stage-ahead GEMM with look-ahead, the
+    two-per-CU dataflow panel kernel, other panel widths with the launch chain for tall panels); each must still be a correct
+    Cholesky: log|K| of an N = 5000 Gram matrix against numpy (1e-10) and the factor's LL' = K on sampled entries."""
+    import subprocess
+    import sys
+    code = r'''
+import numpy as np, sys
+sys.path.insert(0, %r)
+from gpc_amd import api, synth
+X, y = synth.make_xy(5000, 4, 7)
+terms = [("rbf", [0.8, 1.0]), ("white", [0.05])]
+L, ld, jit, info = api.gp_update_k(api.kspec(terms), api.from_host(X))
+Lh = np.tril(api.to_host(L))
+rows = np.array([0, 1, 63, 64, 1023, 1024, 2047, 4095, 4096, 4999])
+print("RESULT", info, repr(ld), repr(float(np.abs((Lh[rows] @ Lh.T)).max())))
+np.save(sys.argv[1], Lh[rows] @ Lh.T)
+''' % ROOT
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        out = os.path.join(td, "llt.npy")
+        r = subprocess.run([sys.executable, "-c", code, out], env=dict(os.environ, **env), stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                           timeout=600)
+        assert r.returncode == 0, r.stderr.decode()[-2000:]
+        f = [ln for ln in r.stdout.decode().splitlines() if ln.startswith("RESULT")][0].split()
+        got = np.load(out)
+    from gpc_amd import synth
+    X, _ = synth.make_xy(5000, 4, 7)
+    G = X @ X.T
+    n = np.diag(G)
+    K = np.exp(-0.4 * np.maximum(n[:, None] + n[None, :] - 2 * G, 0.0)) + 0.05 * np.eye(5000)
+    want = 2.0 * np.log(np.diag(np.linalg.cholesky(K))).sum()
+    rows = np.array([0, 1, 63, 64, 1023, 1024, 2047, 4095, 4096, 4999])
+    assert int(f[1]) == 0
+    assert abs(float(f[2]) - want) <= 1e-10 * abs(want)
+    assert np.abs(got - K[rows]).max() <= 1e-11

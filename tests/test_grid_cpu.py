@@ -220,6 +220,20 @@ def test_lookahead_off_gives_the_same_bits(hb):
             assert np.array_equal(ra["tiles"][key], rb["tiles"][key])
 
 
+def test_the_two_lookahead_orders_give_the_same_bits(hb):
+    """Look-ahead 1 holds U2(k) back until panel k+1's factorisation kernels are on the stream (grid_sched.hpp: panel_first),
+    look-ahead 2 is the free-running order of rounds 2 / 3a: the same arithmetic in a different order of issue -- on tall,
+    wide and square grids, fused and separate panel steps."""
+    X, Y, Xs = gc.make_problem(900, 3, 1, 4, 12)
+    for pr, pc in ((4, 1), (2, 2), (1, 3)):
+        a = _solve_local(hb, pr, pc, 128, gc.TERMS, X, Y, Xs, lookahead=1)
+        b = _solve_local(hb, pr, pc, 128, gc.TERMS, X, Y, Xs, lookahead=2)
+        for ra, rb in zip(a, b):
+            assert ra["logdet"] == rb["logdet"] and np.array_equal(ra["alpha"], rb["alpha"])
+            for key in ra["tiles"]:
+                assert np.array_equal(ra["tiles"][key], rb["tiles"][key])
+
+
 def test_jitter_schedule_on_a_singular_gram(hb):
     """CMatrix::jitChol (CMatrix.cpp:767-804) on the distributed matrix: duplicated inputs, no white term."""
     X, Y, _ = gc.make_problem(300, 2, 1, 0, 5)

@@ -131,6 +131,18 @@ def test_lookahead_off_gives_the_same_bits():
             assert np.array_equal(ra["tiles"][key], rb["tiles"][key])
 
 
+def test_the_two_lookahead_orders_give_the_same_bits():
+    """panel_first (default) against the free-running order, with the real kernels on two streams per rank."""
+    X, Y, Xs = gc.make_problem(2300, 3, 1, 4, 13)
+    for pr, pc in ((4, 1), (2, 2)):
+        a = _solve(pr, pc, 128, gc.TERMS, X, Y, Xs, lookahead=1)
+        b = _solve(pr, pc, 128, gc.TERMS, X, Y, Xs, lookahead=2)
+        for ra, rb in zip(a, b):
+            assert ra["logdet"] == rb["logdet"] and np.array_equal(ra["alpha"], rb["alpha"])
+            for key in ra["tiles"]:
+                assert np.array_equal(ra["tiles"][key], rb["tiles"][key])
+
+
 def test_gram_tiles_match_the_single_gpu_gram_bit_for_bit():
     """Every rank generates its own tiles; they must be the entries gpc_gram_sym_f64 produces on one GPU."""
     from gpc_amd import api, grid
