@@ -529,7 +529,10 @@ class GridGp {
   // each rank factors it again beside its own rows (0.28 ms of redundant work) -- instead of tile factorisation, broadcast
   // of the factor, and a separate triangular solve: measured on one MI355X at nb = 1024, 8192 rows: 0.50 ms against
   // 0.32 + 0.59; 16 384 rows: 0.85 against 0.32 + 0.78; from 32 768 rows the separate solve wins (2.3 against 1.6 ms).
-  int64_t fused_rows = 20480;   // GPC_GRID_FUSED_ROWS; 0 = never
+  // Since tall panels go through the tile's inverse (potrf.hip: panel_by_inverse, [tile; I] in one dataflow launch + one
+  // chip-wide product for the rows below) the one-call form wins at every height (32 768 rows: 1.05 ms), so the default is
+  // "always"; the three-step form remains for A/B runs (GPC_GRID_FUSED_ROWS=20480 is the round-3a configuration).
+  int64_t fused_rows = (int64_t)1 << 40;   // GPC_GRID_FUSED_ROWS; 0 = never
 
   // Problem definition: X (N x D), Y (N x d, may be null), Xstar (Ns x D, may be null) are HOST arrays, column-major,
   // identical on every rank.  (Re)allocates the local block when the shape changes.
