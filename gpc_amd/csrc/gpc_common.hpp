@@ -126,6 +126,7 @@ struct KStartScope {
 // col0: global index of A's first column, added to the `info` a failing pivot reports
 int potrf_lower(int64_t N, double* A, int64_t lda, int* d_info, hipStream_t s, int64_t col0 = 0);
 int potrf_panel(int64_t M, int64_t nb, double* A, int64_t lda, int* d_info, int64_t col0, hipStream_t s);
+int potrf_panel_rows(int64_t M, int64_t nb, double* tile, int64_t ldt, double* rows, int64_t ldr, int* d_info, int64_t col0, hipStream_t s);
 // panel_flow.hip: one panel (diagonal dpotrf + the rows below) as ONE dataflow launch; GPC_EUNSUPPORTED outside its domain
 int panel_flow(int64_t M, int64_t nbk, double* P, int64_t lda, int* d_info, int64_t col0, hipStream_t s, int64_t zero_row0 = -1,
                int64_t zero_shift = 0);

@@ -371,6 +371,10 @@ struct HipOps : GridOps {
   {
     return gpc::potrf_panel(M, nb, A, lda, info, col0, st[s]);
   }
+  int potrf_panel_rows(int64_t M, int64_t nb, double* tile, int64_t ldt, double* rows, int64_t ldr, int64_t col0, int* info, int s) override
+  {
+    return gpc::potrf_panel_rows(M, nb, tile, ldt, rows, ldr, info, col0, st[s]);
+  }
   int trsm_rlt(const double* Lkk, int64_t ldl, int64_t n, double* B, int64_t ldb, int64_t M, int s) override
   {
     return gpc::trsm('R', 'L', 'T', 'N', M, n, 1.0, Lkk, ldl, B, ldb, st[s]);

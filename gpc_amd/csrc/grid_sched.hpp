@@ -171,6 +171,9 @@ struct GridOps {
   // ---- factorisation
   virtual int potrf_tile(double* A, int64_t lda, int64_t n, int64_t col0, int* info_dev, int st) = 0;
   virtual int potrf_panel(int64_t M, int64_t nb, double* A, int64_t lda, int64_t col0, int* info_dev, int st) = 0;
+  // the M rows below a diagonal tile of which this rank holds an unfactored COPY (tile, ldt): rows := rows L11^-T without
+  // staging [tile; rows] in one array.  GPC_EUNSUPPORTED when the implementation has no such form for this shape.
+  virtual int potrf_panel_rows(int64_t, int64_t, double*, int64_t, double*, int64_t, int64_t, int*, int) { return GPC_EUNSUPPORTED; }
   virtual int trsm_rlt(const double* Lkk, int64_t ldl, int64_t n, double* B, int64_t ldb, int64_t M, int st) = 0;
   virtual int copy2d(double* dst, int64_t ldd, const double* src, int64_t lds, int64_t m, int64_t n, int st) = 0;
   // dst tile t (nb x nb, contiguous) = src rows (first + t*step)*nb .. +nb, all nb columns
@@ -1211,10 +1214,16 @@ class GridGp {
           GRID_CHECK(ops_->potrf_panel(nb_ + M, nb_, col + il * nb_, L.lld, k * nb_, info_dev_, st));
         } else if(M > 0) {
           const int64_t lds = nb_ + M;
-          GRID_CHECK(ops_->copy2d(St_, lds, Dg_[b], nb_, nb_, nb_, st));
-          GRID_CHECK(ops_->copy2d(St_ + nb_, lds, col + il0 * nb_, L.lld, M, nb_, st));
-          GRID_CHECK(ops_->potrf_panel(lds, nb_, St_, lds, k * nb_, info_dev_, st));
-          GRID_CHECK(ops_->copy2d(col + il0 * nb_, L.lld, St_ + nb_, lds, M, nb_, st));
+          // a tall share goes through the inverse of the tile and needs no staging (potrf.hip: potrf_panel_rows)
+          const int direct = ops_->potrf_panel_rows(M, nb_, Dg_[b], nb_, col + il0 * nb_, L.lld, k * nb_, info_dev_, st);
+          if(direct == GPC_EUNSUPPORTED) {
+            GRID_CHECK(ops_->copy2d(St_, lds, Dg_[b], nb_, nb_, nb_, st));
+            GRID_CHECK(ops_->copy2d(St_ + nb_, lds, col + il0 * nb_, L.lld, M, nb_, st));
+            GRID_CHECK(ops_->potrf_panel(lds, nb_, St_, lds, k * nb_, info_dev_, st));
+            GRID_CHECK(ops_->copy2d(col + il0 * nb_, L.lld, St_ + nb_, lds, M, nb_, st));
+          } else {
+            GRID_CHECK(direct);
+          }
         }
         GRID_CHECK(panel_compute_done(b, st));
       } else {

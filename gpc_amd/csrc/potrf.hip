@@ -625,39 +625,54 @@ constexpr int64_t SLAB = 128;
 // columns k <= j of its row block that another workgroup overwrites).  Rounding: L21 carries the error of an explicit inverse
 // of L11, cond(L11) eps instead of eps -- L11 is a Cholesky factor of a 1024 x 1024 diagonal block, whose condition is the
 // square root of the block's; the full-size parity tests (K K^-1 e_j, L L' e_j at N = 65 536) hold at the same tolerances.
-int panel_by_inverse(int64_t M, int64_t nbk, double* P, int64_t lda, int* d_info, int64_t col0, hipStream_t s)
+// tile: the nbk x nbk diagonal block (leading dimension ldt), rows: the `below` rows under it (leading dimension ldr) -- two
+// pointers because a grid rank that does not own the tile holds a received copy of it elsewhere (potrf_panel_rows);
+// store_tile: write L11 back over the tile.
+int panel_by_inverse(int64_t below, int64_t nbk, double* tile, int64_t ldt, double* rows, int64_t ldr, int* d_info, int64_t col0,
+                     hipStream_t s, bool store_tile)
 {
-  const int64_t below = M - nbk, ld2 = 2 * nbk;
+  const int64_t ld2 = 2 * nbk;
   void* wa = nullptr;
   GPC_CHECK(workspace(WS_AUG, sizeof(double) * (size_t)ld2 * (size_t)nbk, &wa));
   double* W = static_cast<double*>(wa);
   void* wt = nullptr;
   GPC_CHECK(workspace(WS_PANEL_TMP, sizeof(double) * (size_t)below * (size_t)nbk, &wt));
   double* T = static_cast<double*>(wt);
-  GPC_CHECK(build_augmented(nbk, nbk, P, lda, W, ld2, s));
+  GPC_CHECK(build_augmented(nbk, nbk, tile, ldt, W, ld2, s));
   const int rc = panel_flow(ld2, nbk, W, ld2, d_info, col0, s, nbk, 0);
   if(rc != GPC_OK) return rc;
-  GPC_HIP_CHECK(hipMemcpy2DAsync(T, sizeof(double) * (size_t)below, P + nbk, sizeof(double) * (size_t)lda, sizeof(double) * (size_t)below,
+  GPC_HIP_CHECK(hipMemcpy2DAsync(T, sizeof(double) * (size_t)below, rows, sizeof(double) * (size_t)ldr, sizeof(double) * (size_t)below,
                                  (size_t)nbk, hipMemcpyDeviceToDevice, s));
   // L11 back (the whole block: W's upper triangle still holds what it was given)
-  GPC_HIP_CHECK(hipMemcpy2DAsync(P, sizeof(double) * (size_t)lda, W, sizeof(double) * (size_t)ld2, sizeof(double) * (size_t)nbk,
-                                 (size_t)nbk, hipMemcpyDeviceToDevice, s));
+  if(store_tile)
+    GPC_HIP_CHECK(hipMemcpy2DAsync(tile, sizeof(double) * (size_t)ldt, W, sizeof(double) * (size_t)ld2, sizeof(double) * (size_t)nbk,
+                                   (size_t)nbk, hipMemcpyDeviceToDevice, s));
   GPC_CHECK(transpose_inplace(nbk, W + nbk, ld2, s));   // L11^-T (upper) -> L11^-1 (lower): the [n][k] operand of an NT product
   {
     KEndScope ke;
-    GPC_CHECK(gemm(false, true, below, nbk, nbk, 1.0, T, below, W + nbk, ld2, 0.0, P + nbk, lda, 0, s));
+    GPC_CHECK(gemm(false, true, below, nbk, nbk, 1.0, T, below, W + nbk, ld2, 0.0, rows, ldr, 0, s));
   }
   return GPC_OK;
+}
+
+static int64_t panel_inv_minrows()
+{
+  static const int64_t v = [] { const char* e = getenv("GPC_PANEL_INV_MINROWS"); return e ? atoll(e) : (int64_t)12288; }();
+  return v;
+}
+static bool panel_inverse_applies(int64_t below, int64_t nbk)
+{
+  return panel_inv_minrows() > 0 && below >= panel_inv_minrows() && nbk >= 512 && nbk <= 2048 && nbk % 128 == 0 && below % 2 == 0 &&
+         panel_flow_maxrows() >= 2 * nbk;
 }
 
 int factor_panel(int64_t N, double* A, int64_t lda, int64_t k0, int64_t nbk, int* d_info, hipStream_t s, int64_t col0 = 0,
                  int64_t zrow = -1)
 {
   // tall panels: diagonal tile + its inverse in one dataflow launch, the rows below as one product (GPC_PANEL_INV_MINROWS = 0: off)
-  static const int64_t inv_minrows = [] { const char* e = getenv("GPC_PANEL_INV_MINROWS"); return e ? atoll(e) : (int64_t)12288; }();
-  if(inv_minrows > 0 && zrow < 0 && N - k0 - nbk >= inv_minrows && nbk >= 512 && nbk <= 2048 && nbk % 128 == 0 && (N - k0) % 2 == 0 &&
-     panel_flow_maxrows() >= 2 * nbk) {
-    const int rc = panel_by_inverse(N - k0, nbk, A + k0 + k0 * lda, lda, d_info, col0 + k0, s);
+  if(zrow < 0 && panel_inverse_applies(N - k0 - nbk, nbk)) {
+    double* P = A + k0 + k0 * lda;
+    const int rc = panel_by_inverse(N - k0 - nbk, nbk, P, lda, P + nbk, lda, d_info, col0 + k0, s, true);
     if(rc != GPC_EUNSUPPORTED) return rc;
   }
   // short panels: the whole panel as one dataflow launch (panel_flow.hip) instead of five launches per 128 columns
@@ -726,6 +741,16 @@ int potrf_panel(int64_t M, int64_t nb, double* A, int64_t lda, int* d_info, int6
   if(M <= 0 || nb <= 0) return GPC_OK;
   // the same two-level chain as the panels of potrf_lower; `info` is reported relative to the caller's column col0
   return factor_panel(M, A, lda, 0, nb, d_info, s, col0);
+}
+
+// The rows of a panel on a grid rank that does NOT own the diagonal tile: `tile` is a copy of the still unfactored tile, `rows`
+// the rank's M rows below it, wherever they are.  Only the tile-inverse form (tall shares); GPC_EUNSUPPORTED otherwise -- the
+// caller then stages [tile; rows] in one array for potrf_panel.  The tile copy is left as it was.
+int potrf_panel_rows(int64_t M, int64_t nb, double* tile, int64_t ldt, double* rows, int64_t ldr, int* d_info, int64_t col0, hipStream_t s)
+{
+  if(M <= 0 || nb <= 0) return GPC_OK;
+  if(!panel_inverse_applies(M, nb)) return GPC_EUNSUPPORTED;
+  return panel_by_inverse(M, nb, tile, ldt, rows, ldr, d_info, col0, s, false);
 }
 
 // Width of the panel that starts with `rem` columns still to factor.  Fixed when GPC_NB / gpc_set_potrf_blocking says

@@ -353,3 +353,60 @@ def test_bench_two_ranks_over_real_rccl():
         assert r.returncode == 0, r.stderr.decode()[-3000:]
         line = json.loads(r.stdout.decode().strip().splitlines()[-1])
         assert line["n_gpus"] == w and line["value"] > 0 and len(line["grid"]["calibration"]) == 2
+
+
+def test_tall_shares_take_the_tile_inverse_form_without_staging():
+    """A rank that does not own the diagonal tile and holds a tall share of the panel computes rows L11^-T through the
+    inverse of its copy of the tile (gpc::potrf_panel_rows) instead of staging [tile; rows]; the owner takes the same form
+    inside potrf_panel.  The default threshold is 12 288 rows; lowered here so that a small problem crosses it (own process:
+    the threshold is read once).  log|K| and alpha against numpy, and the same bits as with the form switched off."""
+    import subprocess
+    import sys
+    code = r'''
+import numpy as np, sys
+sys.path.insert(0, %r)
+from gpc_amd import grid, synth
+N = 7168
+X, y = synth.make_xy(N, 5, 21)
+terms = [("rbf", [0.7, 1.3]), ("white", [0.05])]
+out = []
+for pr in (2, 3):
+    grids = grid.create_local(pr, 1, 512)
+    def work(g, rank):
+        g.set_problem(terms, X, y, None)
+        ld, jit, info = g.update_k()
+        return ld, info, g.alpha()
+    res = grid.run_local(grids, work)
+    out.append((res[0][0], res[0][1], res[0][2]))
+    for g in grids:
+        g.destroy()
+np.save(sys.argv[1], np.concatenate([o[2].ravel() for o in out]))
+print("RESULT", out[0][1], out[1][1], repr(out[0][0]), repr(out[1][0]))
+''' % ROOT
+    import tempfile
+    got = {}
+    for minrows in ("1024", "0"):
+        with tempfile.TemporaryDirectory() as td:
+            f = os.path.join(td, "alpha.npy")
+            r = subprocess.run([sys.executable, "-c", code, f], env=dict(os.environ, GPC_PANEL_INV_MINROWS=minrows), stdout=subprocess.PIPE,
+                               stderr=subprocess.PIPE, timeout=900)
+            assert r.returncode == 0, r.stderr.decode()[-2000:]
+            w = [ln for ln in r.stdout.decode().splitlines() if ln.startswith("RESULT")][0].split()
+            got[minrows] = (int(w[1]), int(w[2]), float(w[3]), float(w[4]), np.load(f))
+    from gpc_amd import synth
+    N = 7168
+    X, y = synth.make_xy(N, 5, 21)
+    G = X @ X.T
+    n = np.diag(G)
+    K = 1.3 * np.exp(-0.35 * np.maximum(n[:, None] + n[None, :] - 2 * G, 0.0)) + 0.05 * np.eye(N)
+    Lc = np.linalg.cholesky(K)
+    want_ld = 2.0 * np.log(np.diag(Lc)).sum()
+    want_alpha = np.linalg.solve(K, y).ravel()
+    for key in ("1024", "0"):
+        i2, i3, ld2, ld3, al = got[key]
+        assert i2 == 0 and i3 == 0
+        assert abs(ld2 - want_ld) <= 1e-10 * abs(want_ld) and abs(ld3 - want_ld) <= 1e-10 * abs(want_ld)
+        assert np.abs(al[:N] - want_alpha).max() <= 1e-8 * np.abs(want_alpha).max()
+        assert np.abs(al[N:] - want_alpha).max() <= 1e-8 * np.abs(want_alpha).max()
+    # two different roundings of the same factor: close, not identical
+    assert np.abs(got["1024"][4] - got["0"][4]).max() <= 1e-9 * np.abs(want_alpha).max()

@@ -134,6 +134,14 @@ struct TraceOps : GridOps {
     s->op(st, "potrf_panel", "\"rows\":%lld,\"n\":%lld", (long long)M, (long long)nb);
     return GPC_OK;
   }
+  // (a tall share: tile-inverse form without staging; priced as the one-call panel of nb + M rows, the recorded cost of which
+  //  was measured on exactly that path)
+  int potrf_panel_rows(int64_t M, int64_t nb, double*, int64_t, double*, int64_t, int64_t, int*, int st) override
+  {
+    if(M < 12288 || nb < 512 || nb > 2048 || M % 2) return GPC_EUNSUPPORTED;
+    s->op(st, "potrf_panel", "\"rows\":%lld,\"n\":%lld", (long long)(M + nb), (long long)nb);
+    return GPC_OK;
+  }
   int trsm_rlt(const double*, int64_t, int64_t n, double*, int64_t, int64_t M, int st) override
   {
     s->op(st, "trsm_rlt", "\"rows\":%lld,\"n\":%lld", (long long)M, (long long)n);
