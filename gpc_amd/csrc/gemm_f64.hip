@@ -53,6 +53,8 @@ struct GemmArgs {
   double alpha, beta;
   int tiles_m, tiles_n;
   int super_m, super_n;  // super-tile counts
+  int tri_h;             // tri 1 / 2: tile rows in the LAST super-tile row (1 .. 8; 8 when tiles_m is a multiple of 8)
+  unsigned tri_total;    // tri 1 / 2: valid tiles = slots of the enumeration (tri_count())
   int debug_same_rows;   // ablation knob (env GPC_GEMM_DEBUG_SAMEROWS): never set in production
   int kstart;            // fast NT kernel only: both operands are upper triangular (square product, K == M == N):
                          // a tile's k-loop starts at its first row m0 (everything left of it is zero)
@@ -204,26 +206,50 @@ __device__ __forceinline__ bool map_tile(const GemmArgs& g, int& ti, int& tj, co
   } else {
     // Compact enumeration of the VALID lower tiles so that every XCD chunk holds the same number of real tiles:
     // super-tile row r holds r full super-tiles (64 tiles each) and one diagonal super-tile (36 lower tiles);
-    // tiles before row r: cum(r) = 32 r^2 + 4 r.
+    // tiles before row r: cum(r) = 32 r^2 + 4 r.  The LAST super-tile row has only h = tiles_m - 8 (S - 1) tile rows: its
+    // super-tiles hold 8 h tiles (column-major, h rows a column) and its diagonal one h (h + 1) / 2.  (Until round 3 the
+    // last row was enumerated in full and its missing tiles returned at once -- but they all sat in the LAST XCDs' chunks, so
+    // the other XCDs carried a full share: a launch cost what the next multiple of 1024 rows costs, m = 4224: 0.50 ms against
+    // 0.39 at 4096; tools/syrk_small_m.py.)
     const unsigned S = (unsigned)g.super_m;
-    if(L >= 32u * S * S + 4u * S) return false;
-    int r = (int)((sqrt(16.0 + 128.0 * (double)L) - 4.0) * (1.0 / 64.0));
-    while(32u * (unsigned)(r + 1) * (unsigned)(r + 1) + 4u * (unsigned)(r + 1) <= L) r++;
-    while(32u * (unsigned)r * (unsigned)r + 4u * (unsigned)r > L) r--;
-    const unsigned rem = L - (32u * (unsigned)r * (unsigned)r + 4u * (unsigned)r);
-    si = r;
-    if(rem < 64u * (unsigned)r) {
-      sj = (int)(rem >> 6);
-      di = (int)(rem & 7u);
-      dj = (int)((rem >> 3) & 7u);
+    if(L >= g.tri_total) return false;
+    const unsigned cum_last = 32u * (S - 1u) * (S - 1u) + 4u * (S - 1u);
+    if(L >= cum_last) {
+      const unsigned h = (unsigned)g.tri_h, rem = L - cum_last;
+      si = (int)S - 1;
+      if(rem < 8u * h * (S - 1u)) {
+        sj = (int)(rem / (8u * h));
+        const unsigned w = rem % (8u * h);
+        di = (int)(w % h);
+        dj = (int)(w / h);
+      } else {
+        const unsigned q = rem - 8u * h * (S - 1u);
+        sj = (int)S - 1;
+        int a = (int)((sqrt(8.0 * (double)q + 1.0) - 1.0) * 0.5);
+        while((unsigned)(a + 1) * (unsigned)(a + 2) / 2 <= q) a++;
+        while((unsigned)a * (unsigned)(a + 1) / 2 > q) a--;
+        di = a;
+        dj = (int)(q - (unsigned)a * (unsigned)(a + 1) / 2);
+      }
     } else {
-      const unsigned q = rem - 64u * (unsigned)r;  // 0..35: triangular inside the diagonal super-tile
-      sj = r;
-      int a = (int)((sqrt(8.0 * (double)q + 1.0) - 1.0) * 0.5);
-      while((unsigned)(a + 1) * (unsigned)(a + 2) / 2 <= q) a++;
-      while((unsigned)a * (unsigned)(a + 1) / 2 > q) a--;
-      di = a;
-      dj = (int)(q - (unsigned)a * (unsigned)(a + 1) / 2);
+      int r = (int)((sqrt(16.0 + 128.0 * (double)L) - 4.0) * (1.0 / 64.0));
+      while(32u * (unsigned)(r + 1) * (unsigned)(r + 1) + 4u * (unsigned)(r + 1) <= L) r++;
+      while(32u * (unsigned)r * (unsigned)r + 4u * (unsigned)r > L) r--;
+      const unsigned rem = L - (32u * (unsigned)r * (unsigned)r + 4u * (unsigned)r);
+      si = r;
+      if(rem < 64u * (unsigned)r) {
+        sj = (int)(rem >> 6);
+        di = (int)(rem & 7u);
+        dj = (int)((rem >> 3) & 7u);
+      } else {
+        const unsigned q = rem - 64u * (unsigned)r;  // 0..35: triangular inside the diagonal super-tile
+        sj = r;
+        int a = (int)((sqrt(8.0 * (double)q + 1.0) - 1.0) * 0.5);
+        while((unsigned)(a + 1) * (unsigned)(a + 2) / 2 <= q) a++;
+        while((unsigned)a * (unsigned)(a + 1) / 2 > q) a--;
+        di = a;
+        dj = (int)(q - (unsigned)a * (unsigned)(a + 1) / 2);
+      }
     }
     if(g.tri == 2) {  // upper: swap roles
       int tmp = si;
@@ -697,6 +723,11 @@ static int gemm_ex(bool transa, bool transb, int64_t M, int64_t N, int64_t K, do
   g.tiles_n = (int)((N + BN - 1) / BN);
   g.super_m = (g.tiles_m + SUPER - 1) / SUPER;
   g.super_n = (g.tiles_n + SUPER - 1) / SUPER;
+  g.tri_h = g.tiles_m - SUPER * (g.super_m - 1);
+  {
+    const uint64_t sm1 = (uint64_t)(g.super_m > 0 ? g.super_m - 1 : 0), h = (uint64_t)(g.tri_h > 0 ? g.tri_h : 0);
+    g.tri_total = (unsigned)(32ull * sm1 * sm1 + 4ull * sm1 + 8ull * h * sm1 + h * (h + 1) / 2);   // = tiles_m (tiles_m + 1) / 2
+  }
   g.tri = tri;
   g.stair_nb = 0;
   g.st_I0 = g.st_pr = g.st_J0 = g.st_pc = g.st_jl0 = g.st_il0 = 0;
@@ -759,7 +790,7 @@ static int gemm_ex(bool transa, bool transb, int64_t M, int64_t N, int64_t K, do
   } else if(tri == 0 || tri == 3)
     slots = (uint64_t)g.super_m * g.super_n * SUPER * SUPER;
   else
-    slots = 32ull * g.super_m * g.super_m + 4ull * g.super_m;  // valid lower tiles of full 8 x 8 super-tiles
+    slots = g.tri_total;  // the valid lower tiles, 8 x 8 super-tile by super-tile
   slots = (slots + 7) & ~7ull;
   if(g_gemm_kstart) slots = (slots + 511) & ~511ull;   // whole groups of 64 ids per XCD (map_tile's k-start deal)
   if(slots > 0x7fffffffull) {
@@ -802,7 +833,7 @@ static int gemm_ex(bool transa, bool transb, int64_t M, int64_t N, int64_t K, do
           // the k-start deal pads the grid to whole groups of 512 ids; a workgroup that exits at once still waits for its 73 KB
           // of LDS, so with a few dozen tiles the plain enumeration (and the tiles' own k-starts) is the better launch
           g.kstart = 2;
-          nslots = (unsigned)((32ull * g.super_m * g.super_m + 4ull * g.super_m + 7) & ~7ull);
+          nslots = (unsigned)(((uint64_t)g.tri_total + 7) & ~7ull);
         }
         return launch_fast_splitk(g, nslots, s);
       }

@@ -794,6 +794,22 @@ static int64_t panel_width(int64_t rem)
     if(rem <= 4096) return 4096;
     // (round 2 had a 2048-wide tier for 4096 < rem <= 8192; with the faster trailing update 1024 wins there too:
     //  N = 8192 5.63 -> 5.46 ms, 12 288 14.29 -> 14.11, 16 384 29.60 -> 29.48; tools/nb_table_sweep.sh)
+    // With few tiles left the trailing update's time moves in steps of 256 tiles (one workgroup per CU; a second one per CU
+    // halves the speed of both: tools/syrk_small_m.py -- 0.128 ms per 256 tiles at K = 1024), so the width is chosen to leave
+    // a tile count just below such a step: N = 8192 as 1280, 1280, 1664, 3968 instead of 4 x 1024 + 4096: 5.36 -> 5.11 ms.
+    if(rem <= 8192) {
+      int64_t best_w = 1024;
+      double best_eff = 0.0;
+      for(int64_t w = 1024; w <= 1664 && w < rem; w += 128) {
+        const int64_t m = (rem - w + 127) / 128, tiles = m * (m + 1) / 2;
+        const double eff = (double)tiles / (256.0 * (double)((tiles + 255) / 256));
+        if(eff > best_eff + (w == 1024 ? 0.0 : 0.04)) {   // wider than 1024 only for a real gain (the panel itself gets dearer)
+          best_eff = eff;
+          best_w = w;
+        }
+      }
+      return best_w;
+    }
   }
   return 1024;
 }
