@@ -353,10 +353,10 @@ def main():
             flag = torch.tensor([1.0 if ok else 0.0], dtype=torch.float64)
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
             if float(flag.item()) != 1.0:
-                sys.stderr.write("rank %d: grid self-check: log|K| %.17g (info %d) vs single GPU %.17g (info %d)\n"
-                                 % (rank, ld, info1, ref_ld, info0))
-                fail("the %d x %d grid does not reproduce the single-GPU factorisation of the N = 8192 check problem"
-                     % (pr, pc), dist_selfcheck_failed=True)
+                sys.stderr.write("rank %d: grid self-check (%s exchange): log|K| %.17g (info %d) vs single GPU %.17g (info %d)\n"
+                                 % (rank, os.environ.get("GPC_GRID_EXCHANGE", "fanout"), ld, info1, ref_ld, info0))
+                return False
+            return True
 
         if shape:
             candidates = [tuple(int(v) for v in shape.lower().split("x"))]
@@ -372,10 +372,26 @@ def main():
                 sys.exit("bench.py: a %d x %d grid does not have %d ranks" % (pr, pc, world))
         calibration = []
         best = None
+        exchange_fallback = None
         for pr, pc in candidates:
             gr = make_grid(pr, pc)
-            if world > 1 and os.environ.get("GPC_BENCH_SELFCHECK", "1") == "1":
-                selfcheck(gr, pr, pc)
+            if world > 1 and os.environ.get("GPC_BENCH_SELFCHECK", "1") == "1" and not selfcheck(gr, pr, pc):
+                # The pairwise send / recv exchange is the default and the faster form on point-to-point links, but it is also
+                # the younger code path; a wrong result there is no reason to report nothing: the same grid is tried once more
+                # on ncclBroadcast per root (GPC_GRID_EXCHANGE=collective), and the line says so (grid.exchange).  Every rank
+                # takes the same decision: the verdict was all-reduced.
+                gr.destroy()
+                gr = None
+                if not rehearsal and os.environ.get("GPC_GRID_EXCHANGE", "fanout") != "collective":
+                    os.environ["GPC_GRID_EXCHANGE"] = "collective"
+                    exchange_fallback = "fanout failed the start-up self-check"
+                    gr = make_grid(pr, pc)
+                    if not selfcheck(gr, pr, pc):
+                        gr.destroy()
+                        gr = None
+                if gr is None:
+                    fail("the %d x %d grid does not reproduce the single-GPU factorisation of the N = 8192 check problem"
+                         % (pr, pc), dist_selfcheck_failed=True)
             t_cal = None
             if len(candidates) > 1:
                 ncal = int(os.environ.get("GPC_BENCH_CALIBRATE_N", str(max(4096, N // 2))))
@@ -561,6 +577,7 @@ def main():
                            "rank0_update_tflops": achieved, "shape": "%dx%d" % (pr, pc), "tile": nb,
                            "rows_reflected": bool(g.info().get("refl", 0)),
                            "exchange": os.environ.get("GPC_GRID_EXCHANGE", "fanout"),
+                           "exchange_fallback": exchange_fallback,
                            "calibration": calibration or None}
         if phases is not None:
             phases["gram_ms"] = gram_ms / max(1, gram_n)
