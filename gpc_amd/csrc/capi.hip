@@ -416,7 +416,7 @@ int gpc_chol_inverse_f64(int64_t N, double* A, int64_t lda, double* invK, int64_
   static int64_t aug_max = -1;
   if(aug_max < 0) {
     const char* e = getenv("GPC_CHOLINV_MAXN");
-    aug_max = e ? atoll(e) : 6144;
+    aug_max = e ? atoll(e) : 7680;   // (round 3: 7168 12.1-12.6 ms against 13.1 for dpotrf + dpotri, tie at 8192: 17.0 / 17.1)
   }
   if(N > aug_max) {
     // large matrices: the factorisation and dpotri as two calls (an augmented factorisation would triple the flops)

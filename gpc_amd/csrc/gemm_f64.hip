@@ -58,6 +58,7 @@ struct GemmArgs {
   int debug_same_rows;   // ablation knob (env GPC_GEMM_DEBUG_SAMEROWS): never set in production
   int kstart;            // fast NT kernel only: both operands are upper triangular (square product, K == M == N):
                          // a tile's k-loop starts at its first row m0 (everything left of it is zero)
+  int trap_deal;         // tri 3: super-tiles dealt round-robin to the XCDs (GPC_GEMM_TRAP_DEAL=0: contiguous chunks, as before)
   int kend;              // fast NT kernel only: B (N x K, N == K) is lower triangular, so the k-loop of tile column n0 stops at
                          // n0 + 128 (the rows of a tall panel times the inverse of its diagonal tile, potrf.hip)
   int ksplit;            // > 1 (fast NT kernel, SPLITK instance): the k-range of every tile is cut into ksplit pieces, each a
@@ -176,7 +177,10 @@ __device__ __forceinline__ bool map_tile(const GemmArgs& g, int& ti, int& tj, co
   unsigned L = (b & 7u) * (nb >> 3) + (b >> 3);
   // k-start products (potri): a tile's cost falls with its row, so contiguous chunks would hand one XCD all the long
   // tiles.  Deal groups of 64 consecutive ids (about one super-tile: the L2 locality survives) round-robin instead.
-  if(g.kstart == 1) L = (((b >> 3) >> 6) * 8u + (b & 7u)) * 64u + ((b >> 3) & 63u);   // (2: k-start without the deal, see split-k)
+  // The lower trapezoid (tri 3) walks ALL super-tiles column by column and skips the tiles above the diagonal; those sit at
+  // the top of every super-tile column, more of them in the later columns, so contiguous chunks leave the XCDs with unequal
+  // numbers of real tiles: the same round-robin deal of whole super-tiles.
+  if(g.kstart == 1 || g.trap_deal) L = (((b >> 3) >> 6) * 8u + (b & 7u)) * 64u + ((b >> 3) & 63u);   // (2: k-start without the deal, see split-k)
   int si, sj, di, dj;
   if(g.tri == 5) {
     // 2-D block-cyclic staircase: the super-tiles with at least one valid tile, column by column, dealt round-robin to
@@ -719,6 +723,11 @@ static int gemm_ex(bool transa, bool transb, int64_t M, int64_t N, int64_t K, do
   g.part_stride = 0;
   g.kstart = (g_gemm_kstart && !transa && transb && M == N && K >= M && tri == 1) ? 1 : 0;
   g.kend = (g_gemm_kend && !transa && transb && N == K && tri == 0) ? 1 : 0;
+  {
+    static int deal = -1;
+    if(deal < 0) { const char* e = getenv("GPC_GEMM_TRAP_DEAL"); deal = e ? atoi(e) : 1; }
+    g.trap_deal = (tri == 3 && deal) ? 1 : 0;
+  }
   g.tiles_m = (int)((M + BM - 1) / BM);
   g.tiles_n = (int)((N + BN - 1) / BN);
   g.super_m = (g.tiles_m + SUPER - 1) / SUPER;
@@ -792,7 +801,7 @@ static int gemm_ex(bool transa, bool transb, int64_t M, int64_t N, int64_t K, do
   else
     slots = g.tri_total;  // the valid lower tiles, 8 x 8 super-tile by super-tile
   slots = (slots + 7) & ~7ull;
-  if(g_gemm_kstart) slots = (slots + 511) & ~511ull;   // whole groups of 64 ids per XCD (map_tile's k-start deal)
+  if(g_gemm_kstart || g.trap_deal) slots = (slots + 511) & ~511ull;   // whole groups of 64 ids per XCD (map_tile's round-robin deal)
   if(slots > 0x7fffffffull) {
     set_error("gemm grid too large");
     return GPC_EINVAL;
