@@ -126,10 +126,14 @@ struct KStartScope {
 // col0: global index of A's first column, added to the `info` a failing pivot reports
 int potrf_lower(int64_t N, double* A, int64_t lda, int* d_info, hipStream_t s, int64_t col0 = 0);
 int potrf_panel(int64_t M, int64_t nb, double* A, int64_t lda, int* d_info, int64_t col0, hipStream_t s);
+int trsm_rlt_flow(int64_t M, int64_t n, const double* L, int64_t lda, double* B, int64_t ldb, bool identity_rows, int* d_info,
+                  hipStream_t s);   // potrf.hip: X L' = B by dataflow launches
 int potrf_panel_rows(int64_t M, int64_t nb, double* tile, int64_t ldt, double* rows, int64_t ldr, int* d_info, int64_t col0, hipStream_t s);
 // panel_flow.hip: one panel (diagonal dpotrf + the rows below) as ONE dataflow launch; GPC_EUNSUPPORTED outside its domain
 int panel_flow(int64_t M, int64_t nbk, double* P, int64_t lda, int* d_info, int64_t col0, hipStream_t s, int64_t zero_row0 = -1,
                int64_t zero_shift = 0);
+int panel_flow_given(int64_t id_rows, int64_t nbk, double* E, int64_t lde, const double* G, int64_t ldg, int64_t g_rows, int64_t g_cols,
+                     int64_t zero_shift, int64_t store_cols, int* d_info, hipStream_t s);   // panel_flow.hip
 // ... and what it leaves in the info word when one of its polls was not answered within ~10 s (device shared or pre-empted):
 // not a LAPACK info, the factor is unusable.  Whoever reads the info word back reports an error.
 constexpr int PANEL_FLOW_TIMEOUT = (int)0x80000000;

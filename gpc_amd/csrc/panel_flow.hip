@@ -42,6 +42,13 @@ struct PanelFlowArgs {
   int max_polls;      // polls before a wait gives up (2^23: ~10 s; GPC_PANEL_FLOW_POLLS shortens it to provoke the time-out path)
   double* X;          // exchange buffer: every finished block, (64 nrb) x (64 ncb), leading dimension ldx
   int64_t ldx;
+  // "given" mode (panel_flow_given: the triangular inversion of dpotri): the row blocks b < zb0 are NOT computed -- they are
+  // the blocks of a finished factor G (leading dimension ldg, g_rows x g_cols real entries, continued as an identity beyond
+  // them) and are only published; P holds the rows from block zb0 on (the identity that turns into L^-T), row 0 of P = row
+  // 64 zb0 of the panel.
+  const double* G;
+  int64_t ldg, g_rows, g_cols;
+  int store_cols;     // columns of P that exist (given mode: P need not have whole 64-column blocks)
 };
 
 constexpr unsigned long long PF_SENT = 0xFFF8C0DEFACE0002ull;
@@ -159,6 +166,20 @@ __global__ void __launch_bounds__(256, (NS < 3 ? 2 : 1)) panel_flow_kernel(const
   // its first non-zero column block)
   const int tstart = (g.zb0 >= 0 && b >= g.zb0 && b - g.zb0 - g.zshift > 0) ? (b - g.zb0 - g.zshift) : 0;
   if(c < tstart) return;
+  if(g.G != nullptr && b < g.zb0) {
+    // a block of the given factor: nothing to compute, its consumers (the products and solves of the rows below) find it in
+    // the exchange buffer like a block that was just factored
+#pragma unroll
+    for(int i = 0; i < 16; i++) {
+      const int m = lane, n = wv + 4 * i;
+      const int64_t gm = r0 + m, gn = (int64_t)c * 64 + n;
+      double v = (gm == gn) ? 1.0 : 0.0;
+      if(gm < g.g_rows && gn < g.g_cols) v = (gm >= gn) ? g.G[gm + gn * g.ldg] : 0.0;
+      pf_put(&g.X[r0 + m + gn * g.ldx], v);
+    }
+    return;
+  }
+  const int64_t rp = (g.G != nullptr) ? r0 - (int64_t)g.zb0 * 64 : r0;   // row of this block in P
   const bool tr = g.trace && b < 64 && t == 0;
   if(tr) pf_trace[(b * 64 + c) * 4 + 0] = wall_clock64();
 
@@ -172,7 +193,7 @@ __global__ void __launch_bounds__(256, (NS < 3 ? 2 : 1)) panel_flow_kernel(const
 #pragma unroll
       for(int r = 0; r < 4; r++) {
         const int m = wm * 32 + tm * 16 + (lane & 15), n = wn * 32 + tn * 16 + (lane >> 4) + 4 * r;
-        a0[tm][tn][r] = (m < nr && n < ncol) ? g.P[r0 + m + ((int64_t)c * 64 + n) * g.lda] : 0.0;
+        a0[tm][tn][r] = (m < nr && n < ncol && c * 64 + n < g.store_cols) ? g.P[rp + m + ((int64_t)c * 64 + n) * g.lda] : 0.0;
       }
 
   // ---- acc = sum_{t<c} L(b,t) L(c,t)' ------------------------------------------------------------------------------------------
@@ -594,7 +615,7 @@ __global__ void __launch_bounds__(256, (NS < 3 ? 2 : 1)) panel_flow_kernel(const
       for(int i = 0; i < 16; i++) {
         if((i >> 2) == wv) {
           if(wanted) pf_put(&g.X[r0 + lane + ((int64_t)c * 64 + o + i) * g.ldx], x[i]);     // (first: somebody may be polling)
-          if(lane < nr) g.P[r0 + lane + ((int64_t)c * 64 + o + i) * g.lda] = x[i];
+          if(lane < nr && c * 64 + o + i < g.store_cols) g.P[rp + lane + ((int64_t)c * 64 + o + i) * g.lda] = x[i];
         }
       }
       if(fine) pf_trace[62 * 256 + blk * 8 + 5] = wall_clock64();
@@ -639,6 +660,9 @@ int panel_flow(int64_t M, int64_t nbk, double* P, int64_t lda, int* d_info, int6
   g.ctl = ctl;
   g.X = X;
   g.ldx = ldx;
+  g.G = nullptr;
+  g.ldg = g.g_rows = g.g_cols = 0;
+  g.store_cols = ncb * 64;
   static const int trace = [] { const char* e = getenv("GPC_PANEL_FLOW_TRACE"); return e ? atoi(e) : 0; }();
   g.trace = trace;
   static const int polls = [] { const char* e = getenv("GPC_PANEL_FLOW_POLLS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : (1 << 23); }();
@@ -656,6 +680,54 @@ int panel_flow(int64_t M, int64_t nbk, double* P, int64_t lda, int* d_info, int6
     hipLaunchKernelGGL(panel_flow_kernel<PF_LEAN_NS>, dim3((unsigned)nblocks), dim3(256), 0, s, g);
   else
     hipLaunchKernelGGL(panel_flow_kernel<3>, dim3((unsigned)nblocks), dim3(256), 0, s, g);
+  GPC_HIP_CHECK(hipGetLastError());
+  return GPC_OK;
+}
+
+// The columns [0, nbk) of X L'^T = E for the rows of E that are not zero there, as ONE dataflow launch: G is the finished
+// factor's block that starts at the panel's diagonal (g_rows x g_cols real entries, leading dimension ldg; continued as an
+// identity, so ragged sizes need no padded copy), E (id_rows x 64 ncb, leading dimension lde) holds the rows -- a right-hand
+// side whose 64-row block i is zero left of column block i - zero_shift of this panel (an identity further along its own
+// diagonal) -- and is overwritten by the solution.  The same blocks, products and substitution as the factorisation's
+// launch; the factor's blocks are published instead of computed (dpotri's V = L^-T: potrf.hip, trtri_flow).
+int panel_flow_given(int64_t id_rows, int64_t nbk, double* E, int64_t lde, const double* G, int64_t ldg, int64_t g_rows, int64_t g_cols,
+                     int64_t zero_shift, int64_t store_cols, int* d_info, hipStream_t s)
+{
+  if(id_rows <= 0 || nbk <= 0 || nbk > 4096) return GPC_EUNSUPPORTED;
+  const int ncb = (int)((nbk + 63) / 64);
+  const int64_t M = (int64_t)ncb * 64 + id_rows, nrb = (M + 63) / 64;
+  const int64_t ldx = 64 * nrb, nx = ldx * 64 * ncb;
+  void* ws = nullptr;
+  GPC_CHECK(workspace(WS_FLOW, sizeof(double) * (size_t)nx + 64, &ws));
+  double* X = static_cast<double*>(ws);
+  int* ctl = reinterpret_cast<int*>(X + nx);
+  hipLaunchKernelGGL(panel_flow_init_kernel, dim3((unsigned)((nx + 255) / 256)), dim3(256), 0, s, ctl,
+                     reinterpret_cast<unsigned long long*>(X), nx);
+  PanelFlowArgs g;
+  g.P = E;
+  g.lda = lde;
+  g.M = M;
+  g.nbk = ncb * 64;      // whole column blocks (G continues as an identity; E's missing columns read as zero and are not stored)
+  g.ncb = ncb;
+  g.nrb = (int)nrb;
+  g.zb0 = ncb;
+  g.zshift = (int)zero_shift;
+  g.col0 = 0;
+  g.info = d_info;
+  g.ctl = ctl;
+  g.X = X;
+  g.ldx = ldx;
+  g.G = G;
+  g.ldg = ldg;
+  g.g_rows = g_rows;
+  g.g_cols = g_cols;
+  g.store_cols = (int)store_cols;
+  g.trace = 0;
+  static const int polls = [] { const char* e = getenv("GPC_PANEL_FLOW_POLLS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : (1 << 23); }();
+  g.max_polls = polls;
+  if(polls < 64) hipLaunchKernelGGL(panel_flow_giveup_kernel, dim3(1), dim3(64), 0, s, ctl, d_info);
+  const int64_t nblocks = (int64_t)ncb * nrb - (int64_t)ncb * (ncb - 1) / 2;
+  hipLaunchKernelGGL(panel_flow_kernel<3>, dim3((unsigned)nblocks), dim3(256), 0, s, g);
   GPC_HIP_CHECK(hipGetLastError());
   return GPC_OK;
 }

@@ -753,6 +753,71 @@ int potrf_panel_rows(int64_t M, int64_t nb, double* tile, int64_t ldt, double* r
   return panel_by_inverse(M, nb, tile, ldt, rows, ldr, d_info, col0, s, false);
 }
 
+// X L' = B for a lower-triangular n x n L (side R, lower, transposed: dpotri's V = L^-T from B = I, the predictive variance's
+// k(X*, X) L^-T, the grid gradient's block rows), the dataflow way.  B (M x n, leading dimension ldb) is overwritten by X.
+// identity_rows: B holds the first M rows of the identity, so row i is zero left of column i and only the rows i < kend take
+// part in a panel (the work is N^3 / 3 for M = n, not M n^2).  Column panel by column panel: ONE launch solves the panel's
+// columns for the rows that are not zero there (panel_flow_given: the factor's blocks are published, the rows of B take the
+// same products and 64-column substitutions as the rows below a diagonal tile in the factorisation), then one product takes
+// the panel out of the columns to its right, B(rows, kend:) -= X L(kend:, panel)'.  With many rows (>= GPC_PANEL_INV_MINROWS)
+// the launch only inverts the tile -- an identity's rows, B's own for identity_rows, a scratch tile otherwise -- and the rows
+// take ONE k-limited product with L_bb^-T, as the tall panels of the factorisation do (panel_by_inverse).  This replaces, per
+// 512 columns, eight launches of the substitution chain and four small products (dpotri at N = 8192: 11.6 -> 9.2 ms, 4096:
+// 3.5 -> 2.4, 65 536: 3.00 -> 2.84 s).  GPC_EUNSUPPORTED outside its domain (the caller keeps the chain).
+int trsm_rlt_flow(int64_t M, int64_t n, const double* L, int64_t lda, double* B, int64_t ldb, bool identity_rows, int* d_info, hipStream_t s)
+{
+  if(n < 128 || M < 1 || panel_flow_maxrows() < 8192) return GPC_EUNSUPPORTED;
+  if(identity_rows && M > n) return GPC_EUNSUPPORTED;
+  // (the products want even sizes and 16-byte aligned operands: B's rows, the columns right of a panel)
+  if(M % 2 != 0 || n % 2 != 0 || ldb % 2 != 0 || lda % 2 != 0) return GPC_EUNSUPPORTED;
+  static const int64_t nb_env = [] { const char* e = getenv("GPC_TRTRI_NB"); return e ? atoll(e) : (int64_t)0; }();   // measurement aid
+  int64_t nbk = 0;
+  for(int64_t k0 = 0; k0 < n; k0 += nbk) {
+    // (width: the launch's work is rows x nbk^2 at the dataflow blocks' rate, the product's 2 rows (n - kend) nbk at the chip's;
+    //  one launch for everything only while the whole problem is small)
+    const int64_t rem = n - k0, NB = nb_env >= 64 ? (nb_env / 64) * 64 : ((n <= 4096 && M <= 4096) ? 4096 : 1024);
+    nbk = rem < NB ? rem : NB;
+    const int64_t kend = k0 + nbk, cols_pad = ((nbk + 63) / 64) * 64;
+    // rows that take part in this panel, and those of them that lie above the identity's own diagonal tile
+    const int64_t rows = identity_rows ? ((k0 + cols_pad < M) ? k0 + cols_pad : M) : M;
+    const int64_t dense = identity_rows ? ((k0 < M) ? k0 : M) : M;
+    if(rows <= 0) break;      // (identity rows: nothing of B reaches these columns)
+    double* Bp = B + k0 * ldb;
+    if(panel_inverse_applies(dense, nbk) && nbk % 64 == 0) {
+      void* wa = nullptr;
+      GPC_CHECK(workspace(WS_AUG, sizeof(double) * (size_t)nbk * (size_t)nbk, &wa));
+      double* Li = static_cast<double*>(wa);
+      void* wt = nullptr;
+      GPC_CHECK(workspace(WS_PANEL_TMP, sizeof(double) * (size_t)dense * (size_t)nbk, &wt));
+      double* T = static_cast<double*>(wt);
+      if(identity_rows && kend <= M) {
+        // the identity's own rows k0 .. kend-1 become L_bb^-T where they are; a copy of it serves the rows above
+        double* Ebb = Bp + k0;
+        GPC_CHECK(panel_flow_given(nbk, nbk, Ebb, ldb, L + k0 + k0 * lda, lda, n - k0, nbk, 0, nbk, d_info, s));
+        GPC_HIP_CHECK(hipMemcpy2DAsync(Li, sizeof(double) * (size_t)nbk, Ebb, sizeof(double) * (size_t)ldb, sizeof(double) * (size_t)nbk,
+                                       (size_t)nbk, hipMemcpyDeviceToDevice, s));
+      } else {
+        if(identity_rows && rows > dense) return GPC_EUNSUPPORTED;   // (a partial identity tile above many dense rows: not worth a case)
+        GPC_CHECK(set_identity(nbk, nbk, Li, nbk, s));
+        GPC_CHECK(panel_flow_given(nbk, nbk, Li, nbk, L + k0 + k0 * lda, lda, n - k0, nbk, 0, nbk, d_info, s));
+      }
+      GPC_CHECK(transpose_inplace(nbk, Li, nbk, s));     // L_bb^-T (upper) -> L_bb^-1 (lower): the [n][k] operand
+      GPC_HIP_CHECK(hipMemcpy2DAsync(T, sizeof(double) * (size_t)dense, Bp, sizeof(double) * (size_t)ldb, sizeof(double) * (size_t)dense,
+                                     (size_t)nbk, hipMemcpyDeviceToDevice, s));
+      KEndScope ke;
+      GPC_CHECK(gemm(false, true, dense, nbk, nbk, 1.0, T, dense, Li, nbk, 0.0, Bp, ldb, 0, s));
+    } else {
+      GPC_CHECK(panel_flow_given(rows, nbk, Bp, ldb, L + k0 + k0 * lda, lda, n - k0, nbk, identity_rows ? k0 / 64 : ((int64_t)1 << 24), nbk,
+                                 d_info, s));
+    }
+    if(kend < n) {
+      TrailingScope role;
+      GPC_CHECK(gemm(false, true, rows, n - kend, nbk, -1.0, Bp, ldb, L + kend + k0 * lda, lda, 1.0, B + kend * ldb, ldb, 0, s));
+    }
+  }
+  return GPC_OK;
+}
+
 // Width of the panel that starts with `rem` columns still to factor.  Fixed when GPC_NB / gpc_set_potrf_blocking says
 // so; otherwise 1024: the update kernel's per-tile start-up and C read-modify-write are amortised over a K twice as
 // deep as with 512 (58.4 -> 61.1 TF at N = 65 536), and since the panel chain became short (blocked potf2, fused step)

@@ -12,6 +12,7 @@
 #include "gpc_common.hpp"
 #include <stdlib.h>
 #include <ctype.h>
+#include <string.h>
 
 namespace gpc {
 
@@ -780,6 +781,31 @@ int trsm_impl(bool left, bool lower, bool tr, bool unit, int64_t M, int64_t Nrhs
   const int64_t nt = left ? M : Nrhs;          // order of the triangular matrix
   const int64_t nvec_all = left ? Nrhs : M;    // number of vectors being solved for
   GPC_CHECK(scale_matrix(M, Nrhs, alpha, B, ldb, s));
+  // side R, lower, transposed (dpotri's V = L^-T, the predictive variance, the grid gradient's block rows): dataflow launches
+  // + products (potrf.hip: trsm_rlt_flow; GPC_TRSM_FLOW=0: the chain below).  A launch that gives up (device shared or
+  // pre-empted) leaves B partly overwritten: reported as an error, the caller's input is gone.
+  static const int use_flow = [] { const char* e = getenv("GPC_TRSM_FLOW"); return e ? atoi(e) : 1; }();
+  if(use_flow && !left && lower && tr && !unit) {
+    void* wi = nullptr;
+    GPC_CHECK(workspace(WS_INFO, 64, &wi));
+    int* d_info = static_cast<int*>(wi);
+    GPC_HIP_CHECK(hipMemsetAsync(d_info, 0, sizeof(int), s));
+    const int rc = trsm_rlt_flow(M, Nrhs, A, lda, B, ldb, tri_rhs, d_info, s);
+    if(rc == GPC_OK) {
+      int mark = 0;
+      HostFetch f;
+      GPC_CHECK(f.add(&mark, d_info, sizeof(int), s));
+      GPC_CHECK(f.finish(s));
+      if(mark == PANEL_FLOW_TIMEOUT) {
+        GPC_HIP_CHECK(hipMemsetAsync(d_info, 0, sizeof(int), s));
+        set_error("a dataflow launch of a triangular solve timed out (device shared or pre-empted?); the right-hand side is partly "
+                  "overwritten -- repeat the call on fresh input, or set GPC_TRSM_FLOW=0 for the launch chain");
+        return GPC_EHIP;
+      }
+      return GPC_OK;
+    }
+    if(rc != GPC_EUNSUPPORTED) return rc;
+  }
   const bool eff_lower = (lower != tr);  // is op(A) lower triangular?
   // left : op(A) X = B.  eff_lower -> forward over row blocks, else backward.
   // right: X op(A) = B.  eff_lower -> backward over column blocks, else forward.
@@ -863,21 +889,35 @@ int potri_full(bool lower, int64_t N, double* A, int64_t lda, hipStream_t s)
 {
   if(N <= 0) return GPC_OK;
   if(!lower) GPC_CHECK(transpose_inplace(N, A, lda, s));
-  // W is N x Np, Np = N rounded up to the GEMM kernel's k-step: the extra columns stay zero, so the product over Np
-  // columns is the product over N and sizes that are not multiples of 16 still take the fast kernel
-  const int64_t Np = (N + 15) & ~(int64_t)15;
+  // W is N x Np, Np = N rounded up to whole 64-column blocks (a multiple of the GEMM kernel's k-step, and what the dataflow
+  // launches of trtri_flow write): the extra columns stay zero, so the product over Np columns is the product over N
+  const int64_t Np = (N + 63) & ~(int64_t)63;
   void* ws = nullptr;
   GPC_CHECK(workspace(WS_POTRI, sizeof(double) * (size_t)N * (size_t)Np, &ws));
   double* W = static_cast<double*>(ws);
-  for(int64_t j0 = 0; j0 < N; j0 += 32768) {
-    const int64_t nc = (N - j0 < 32768) ? (N - j0) : 32768;
-    hipLaunchKernelGGL(set_identity_kernel, dim3((unsigned)((N + 255) / 256), (unsigned)nc), dim3(256), 0, s, W, N,
-                       N, j0);
+  auto identity = [&]() -> int {
+    for(int64_t j0 = 0; j0 < N; j0 += 32768) {
+      const int64_t nc = (N - j0 < 32768) ? (N - j0) : 32768;
+      hipLaunchKernelGGL(set_identity_kernel, dim3((unsigned)((N + 255) / 256), (unsigned)nc), dim3(256), 0, s, W, N,
+                         N, j0);
+    }
+    GPC_HIP_CHECK(hipGetLastError());
+    if(Np > N) GPC_HIP_CHECK(hipMemsetAsync(W + (size_t)N * N, 0, sizeof(double) * (size_t)N * (size_t)(Np - N), s));
+    return GPC_OK;
+  };
+  GPC_CHECK(identity());
+  // V := L^-T (upper triangular; the strictly lower part of W stays exactly zero): the right-side solve of the identity --
+  // dataflow launches + products (trsm_rlt_flow), or the two-level chain (GPC_TRSM_FLOW=0, odd sizes).  A dataflow time-out
+  // leaves L untouched (only W was written): the identity is set up again and the chain takes over.
+  {
+    int rc = trsm_impl(false, true, true, false, N, N, 1.0, A, lda, W, N, true, s);
+    if(rc == GPC_EHIP && strstr(gpc_last_error(), "timed out") != nullptr) {
+      GPC_CHECK(identity());
+      FlowOffScope off;
+      rc = trsm_impl(false, true, true, false, N, N, 1.0, A, lda, W, N, true, s);
+    }
+    GPC_CHECK(rc);
   }
-  GPC_HIP_CHECK(hipGetLastError());
-  if(Np > N) GPC_HIP_CHECK(hipMemsetAsync(W + (size_t)N * N, 0, sizeof(double) * (size_t)N * (size_t)(Np - N), s));
-  // V := L^-T (upper triangular; the strictly lower part of W stays exactly zero)
-  GPC_CHECK(trsm_impl(false, true, true, false, N, N, 1.0, A, lda, W, N, true, s));
   {
     KStartScope ks;   // tiles skip the k < first-row part of the product (zeros of the upper-triangular operand)
     GPC_CHECK(gemm(false, true, N, N, Np, 1.0, W, N, W, N, 0.0, A, lda, 1, s));
