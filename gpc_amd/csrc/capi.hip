@@ -416,7 +416,8 @@ int gpc_chol_inverse_f64(int64_t N, double* A, int64_t lda, double* invK, int64_
   static int64_t aug_max = -1;
   if(aug_max < 0) {
     const char* e = getenv("GPC_CHOLINV_MAXN");
-    aug_max = e ? atoll(e) : 7680;   // (round 3: 7168 12.1-12.6 ms against 13.1 for dpotrf + dpotri, tie at 8192: 17.0 / 17.1)
+    aug_max = e ? atoll(e) : 5120;   // (since dpotri's triangular inversion runs on dataflow launches the two-call route wins
+                                     //  earlier: 5120 5.39 / 5.39 ms, 6144 8.24 / 7.93, 8192 17.0 / 14.6; 4096 3.40 / 3.71)
   }
   if(N > aug_max) {
     // large matrices: the factorisation and dpotri as two calls (an augmented factorisation would triple the flops)

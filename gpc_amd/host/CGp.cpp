@@ -308,7 +308,7 @@ void CGp::updateK() const
   int info = 0;
   bool haveInverse = false;
   if(needInverse && N <= 8192) {
-    // small model, gradient wanted: factor + log-det + inverse in ONE call (gpc_chol_inverse_f64: up to N = 7680 the identity
+    // small model, gradient wanted: factor + log-det + inverse in ONE call (gpc_chol_inverse_f64: up to N = 5120 the identity
     // rides through the factorisation, beyond that it is dpotrf + dpotri); jitChol's schedule only if that attempt fails
     if(!dInvK) dInvK = devAlloc((size_t)N * N);
     gpcCheck(gpc_gram_sym_f64(&ks, dX, N, D, N, dL, N, 0));

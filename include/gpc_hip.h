@@ -116,7 +116,7 @@ int gpc_potri_f64(char uplo, int64_t N, double* A, int64_t lda, void* stream);
 /* jitChol's chol() + logDet + pdinv of CGp::_updateInvK / CGplvm::updateK in ONE pass (CGp.cpp:881-889, CGplvm.cpp:441-444;
  * dpotrf_ + dpotri_, lapack.h:59-73): on entry A holds K (lower triangle read); on exit A's lower triangle holds L, invK
  * the full symmetric inverse, *logdet = log|K| (may be NULL), *info as gpc_potrf_f64 (invK untouched when info != 0).
- * Up to N = 7680 the identity rides through the factorisation of [K; I] and the inverse is one product, which halves the
+ * Up to N = 5120 the identity rides through the factorisation of [K; I] and the inverse is one product, which halves the
  * chain of dependent launches that bounds small matrices; beyond that it is gpc_potrf_f64 + gpc_potri_f64. */
 int gpc_chol_inverse_f64(int64_t N, double* A, int64_t lda, double* invK, int64_t ldi, double* logdet, int* info, void* stream);
 /* dtrsm (lapack.h:208-218; CMatrix::trsm CMatrix.cpp:272-295): B := alpha * op(A)^-1 B (side 'L') or
