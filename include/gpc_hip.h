@@ -120,7 +120,9 @@ int gpc_potri_f64(char uplo, int64_t N, double* A, int64_t lda, void* stream);
  * chain of dependent launches that bounds small matrices; beyond that it is gpc_potrf_f64 + gpc_potri_f64. */
 int gpc_chol_inverse_f64(int64_t N, double* A, int64_t lda, double* invK, int64_t ldi, double* logdet, int* info, void* stream);
 /* dtrsm (lapack.h:208-218; CMatrix::trsm CMatrix.cpp:272-295): B := alpha * op(A)^-1 B (side 'L') or
- * alpha * B op(A)^-1 (side 'R'); B is M x Nrhs; A triangular of order M (L) or Nrhs (R). */
+ * alpha * B op(A)^-1 (side 'R'); B is M x Nrhs; A triangular of order M (L) or Nrhs (R).  The side 'R', lower, transposed,
+ * non-unit case (X L' = B: dpotri's V, the predictive variance) runs on dataflow launches and synchronises the stream before
+ * it returns -- a launch that gave up (device shared or pre-empted) is reported as GPC_EHIP, B is then partly overwritten. */
 int gpc_trsm_f64(char side, char uplo, char trans, char diag, int64_t M, int64_t Nrhs, double alpha,
                  const double* A, int64_t lda, double* B, int64_t ldb, void* stream);
 /* logDet of a Cholesky factor: 2*sum(log(diag)) (CMatrix.cpp:404-412).  *out is a host double. */
