@@ -755,8 +755,8 @@ def test_skinny_products(api, M, n, K):
 def test_cfg4_full_size_properties(api):
     """BASELINE config 4 at its full size on ONE GPU (N = 131 072, D = 16, rbf, gamma = 1; K is 137 GB, so there is room
     for one N x N matrix only): sampled columns of L L' against the Gram columns saved before the factorisation,
-    log|K| against the factor's diagonal, K alpha = m with K regenerated in row blocks, and the tiles a 2 x 4 grid would
-    hold (gpc_gram_block_f64) against the single matrix."""
+    log|K| against the factor's diagonal, K alpha = m with K regenerated in row blocks, the tiles a 2 x 4 grid would
+    hold (gpc_gram_block_f64) against the single matrix, and the explicit inverse (in place on the factor) against K."""
     import torch
     from gpc_amd import synth
     if torch.cuda.get_device_properties(0).total_memory < 200e9:
@@ -791,6 +791,25 @@ def test_cfg4_full_size_properties(api):
         worst = max(worst, float((rows @ alpha - m[i0:i0 + step]).abs().max()))
         del rows
     assert worst < 1e-9 * max(1.0, float(alpha.abs().max()))
+    # CMatrix::pdinv (dpotri, CMatrix.cpp:414-432) at this size: in place on the factor -- there is room for the factor and
+    # dpotri's one N x N workspace (2 x 128 GiB), not for a copy beside them -- then K (K^-1 e_j) = e_j with K one row block at a time
+    del Kcols, col, alpha
+    torch.cuda.empty_cache()
+    api.potri(L, "L")
+    inv = L
+    assert torch.equal(inv[tidx, :], inv[:, tidx].t())
+    cols = [0, 777, 100000, N - 1]
+    V = inv[:, torch.tensor(cols, device="cuda")].clone()
+    worst = 0.0
+    for i0 in range(0, N, step):
+        rows = api.gram_block(ks, Xd, i0, step, 0, N)
+        Z = rows @ V
+        for q, j in enumerate(cols):
+            if i0 <= j < i0 + step:
+                Z[j - i0, q] -= 1.0
+        worst = max(worst, float(Z.abs().max()))
+        del rows, Z
+    assert worst < 1e-9
 
 
 @pytest.mark.parametrize("N", [24000, 24700, 28700, 33000])
