@@ -825,9 +825,12 @@ static int gemm_ex(bool transa, bool transb, int64_t M, int64_t N, int64_t K, do
     static int splitk = -1;
     if(splitk < 0) { const char* e = getenv("GPC_GEMM_SPLITK"); splitk = e ? atoi(e) : 1; }
     const int64_t ntiles = (tri == 1) ? (int64_t)g.tiles_m * (g.tiles_m + 1) / 2 : (int64_t)g.tiles_m * g.tiles_n;
-    if(splitk && g_gemm_variant == 2 && (tri == 0 || tri == 1) && ntiles <= 96 && g.K >= 512 && g_gemm_trailing == 0 &&
+    // (up to 256 tiles: one workgroup per CU runs at full speed, so pieces pay as long as tiles x pieces stays within 512)
+    static int splitk_max = -1;
+    if(splitk_max < 0) { const char* e = getenv("GPC_GEMM_SPLITK_MAXTILES"); splitk_max = e ? atoi(e) : 256; }
+    if(splitk && g_gemm_variant == 2 && (tri == 0 || tri == 1) && ntiles <= splitk_max && g.K >= 512 && g_gemm_trailing == 0 &&
        M <= 0x7fffffff && N <= 65535) {
-      int S = (int)(384 / ntiles);
+      int S = (int)((ntiles <= 96 ? 384 : 512) / ntiles);
       const int64_t stages = g.K / BK;
       if(S > stages / 8) S = (int)(stages / 8);      // at least 8 stages (128 columns of k) per piece
       if(S > 16) S = 16;
