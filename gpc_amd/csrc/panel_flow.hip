@@ -49,6 +49,8 @@ struct PanelFlowArgs {
   const double* G;
   int64_t ldg, g_rows, g_cols;
   int store_cols;     // columns of P that exist (given mode: P need not have whole 64-column blocks)
+  double* Xinv;       // given mode: the INVERSES of the factor's diagonal blocks, transposed ([c][k][n] = Linv_cc(n, k)), published
+                      // by the diagonal blocks' workgroups next to the blocks themselves (nullptr: the rows substitute instead)
 };
 
 constexpr unsigned long long PF_SENT = 0xFFF8C0DEFACE0002ull;
@@ -176,6 +178,38 @@ __global__ void __launch_bounds__(256, (NS < 3 ? 2 : 1)) panel_flow_kernel(const
       double v = (gm == gn) ? 1.0 : 0.0;
       if(gm < g.g_rows && gn < g.g_cols) v = (gm >= gn) ? g.G[gm + gn * g.ldg] : 0.0;
       pf_put(&g.X[r0 + m + gn * g.ldx], v);
+    }
+    if(diag && g.Xinv != nullptr) {
+      // ... and the inverse of a diagonal block: nobody has to wait for it (the factor is given, this workgroup has nothing
+      // else to do), and with it the step every row block walks through per column block -- from its last product to its own
+      // solution -- is one 64-deep MFMA product instead of four dependent 16-column substitutions (13 -> 2 us; trsv_flow_kernel
+      // of trsm.hip does the same for vectors).  Wave 0, lane = column j of L^-1: x_i = (delta_ij - sum_{k<i} L(i,k) x_k) / L(i,i),
+      // the x_k in registers, L(i,k) a wave-uniform LDS operand.
+      double* Lb = arena;                 // Lb[k * 65 + i] = L(i, k)
+      double* Dv = arena + 64 * 65;       // 1 / L(i, i)
+#pragma unroll
+      for(int i = 0; i < 16; i++) {
+        const int m = lane, n = wv + 4 * i;
+        const int64_t gm = r0 + m, gn = (int64_t)c * 64 + n;
+        double v = (gm == gn) ? 1.0 : 0.0;
+        if(gm < g.g_rows && gn < g.g_cols) v = (gm >= gn) ? g.G[gm + gn * g.ldg] : 0.0;
+        Lb[n * 65 + m] = v;
+        if(m == n) Dv[m] = 1.0 / v;
+      }
+      __syncthreads();
+      if(wv == 0) {
+        double xi[64];
+#pragma unroll
+        for(int i = 0; i < 64; i++) {
+          double sacc = (i == lane) ? 1.0 : 0.0;
+#pragma unroll
+          for(int k = 0; k < i; k++) sacc -= Lb[k * 65 + i] * xi[k];
+          xi[i] = sacc * Dv[i];
+        }
+        double* out = g.Xinv + (int64_t)c * 4096 + lane * 64;     // [k = lane][n = i] = Linv(i, lane)
+#pragma unroll
+        for(int i = 0; i < 64; i++) pf_put(out + i, xi[i]);
+      }
     }
     return;
   }
@@ -326,6 +360,49 @@ __global__ void __launch_bounds__(256, (NS < 3 ? 2 : 1)) panel_flow_kernel(const
           S[n * PF_SS + m] = a0[tm][tn][r] - acc[tm][tn][r];
         }
     __syncthreads();
+    if(g.G != nullptr && g.Xinv != nullptr) {
+      // X = C L(c,c)^-T as ONE product with the published inverse: X(m, n) = sum_k C(m, k) Linv(n, k).  C is in S ([k][m], row
+      // stride PF_SS), the inverse goes into the first operand stage ([k][n]); the result comes out in the accumulator layout.
+      double* Bi = arena;
+      double li[16];
+      if(!pf_fetch<16>(g, g.Xinv + (int64_t)c * 4096 + lane + wv * 64, 4 * 64, li)) giveup = 1;
+#pragma unroll
+      for(int i = 0; i < 16; i++) Bi[(wv + 4 * i) * PF_OS + lane] = li[i];
+      __syncthreads();
+      if(giveup) return;
+      double4_t xacc[2][2];
+#pragma unroll
+      for(int i = 0; i < 2; i++)
+#pragma unroll
+        for(int j = 0; j < 2; j++) xacc[i][j] = (double4_t){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for(int kk = 0; kk < 16; kk++) {
+        double a[2], bb[2];
+        const int kr = kk * 4 + (lane >> 4);
+#pragma unroll
+        for(int q = 0; q < 2; q++) {
+          a[q] = S[kr * PF_SS + wm * 32 + q * 16 + (lane & 15)];
+          bb[q] = Bi[kr * PF_OS + wn * 32 + q * 16 + (lane & 15)];
+        }
+#pragma unroll
+        for(int tn = 0; tn < 2; tn++)
+#pragma unroll
+          for(int tm = 0; tm < 2; tm++) xacc[tm][tn] = __builtin_amdgcn_mfma_f64_16x16x4f64(bb[tn], a[tm], xacc[tm][tn], 0, 0, 0);
+      }
+      const bool wanted = (c + 1 < g.ncb);
+#pragma unroll
+      for(int tn = 0; tn < 2; tn++)
+#pragma unroll
+        for(int tm = 0; tm < 2; tm++)
+#pragma unroll
+          for(int r = 0; r < 4; r++) {
+            const int m = wm * 32 + tm * 16 + (lane & 15), n = wn * 32 + tn * 16 + (lane >> 4) + 4 * r;
+            const double v = xacc[tm][tn][r];
+            if(wanted) pf_put(&g.X[r0 + m + ((int64_t)c * 64 + n) * g.ldx], v);
+            if(m < nr && c * 64 + n < g.store_cols) g.P[rp + m + ((int64_t)c * 64 + n) * g.lda] = v;
+          }
+      return;
+    }
   }
   if(tr) pf_trace[(b * 64 + c) * 4 + 2] = wall_clock64();
 
@@ -663,6 +740,7 @@ int panel_flow(int64_t M, int64_t nbk, double* P, int64_t lda, int* d_info, int6
   g.G = nullptr;
   g.ldg = g.g_rows = g.g_cols = 0;
   g.store_cols = ncb * 64;
+  g.Xinv = nullptr;
   static const int trace = [] { const char* e = getenv("GPC_PANEL_FLOW_TRACE"); return e ? atoi(e) : 0; }();
   g.trace = trace;
   static const int polls = [] { const char* e = getenv("GPC_PANEL_FLOW_POLLS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : (1 << 23); }();
@@ -696,14 +774,21 @@ int panel_flow_given(int64_t id_rows, int64_t nbk, double* E, int64_t lde, const
   if(id_rows <= 0 || nbk <= 0 || nbk > 4096) return GPC_EUNSUPPORTED;
   const int ncb = (int)((nbk + 63) / 64);
   const int64_t M = (int64_t)ncb * 64 + id_rows, nrb = (M + 63) / 64;
-  const int64_t ldx = 64 * nrb, nx = ldx * 64 * ncb;
+  // The rows multiply with the published inverse of L(c,c) instead of substituting through it where the launch is bound by its
+  // chain of column blocks -- everything in one launch, i.e. more than 1024 columns (dpotri at N = 2048 0.64 -> 0.57 ms, 4096
+  // 2.56 -> 2.43); the 1024-column panels of larger problems are bound by their products and lose 2-3 % to the extra LDS
+  // round trip (8192: 9.24 -> 9.54 ms).  GPC_FLOW_GIVEN_INV=0 / 1 forces it off / on.
+  static const int inv_env = [] { const char* e = getenv("GPC_FLOW_GIVEN_INV"); return e ? atoi(e) : -1; }();
+  const int use_inv = inv_env >= 0 ? inv_env : (nbk > 1024 ? 1 : 0);
+  const int64_t ldx = 64 * nrb, nx = ldx * 64 * ncb, ninv = use_inv ? (int64_t)ncb * 4096 : 0;
   void* ws = nullptr;
-  GPC_CHECK(workspace(WS_FLOW, sizeof(double) * (size_t)nx + 64, &ws));
+  GPC_CHECK(workspace(WS_FLOW, sizeof(double) * (size_t)(nx + ninv) + 64, &ws));
   double* X = static_cast<double*>(ws);
-  int* ctl = reinterpret_cast<int*>(X + nx);
-  hipLaunchKernelGGL(panel_flow_init_kernel, dim3((unsigned)((nx + 255) / 256)), dim3(256), 0, s, ctl,
-                     reinterpret_cast<unsigned long long*>(X), nx);
+  int* ctl = reinterpret_cast<int*>(X + nx + ninv);
+  hipLaunchKernelGGL(panel_flow_init_kernel, dim3((unsigned)((nx + ninv + 255) / 256)), dim3(256), 0, s, ctl,
+                     reinterpret_cast<unsigned long long*>(X), nx + ninv);
   PanelFlowArgs g;
+  g.Xinv = use_inv ? X + nx : nullptr;
   g.P = E;
   g.lda = lde;
   g.M = M;
