@@ -7,9 +7,12 @@ kernel from X resident in HBM, blocked Cholesky in place, log-determinant.  Defa
 `--workload cfg2` = N = 8 192, D = 8; `--workload cfg4` = N = 131 072, D = 16 (137 GB: still one GPU).
 
 `--gpus N`, N > 1: ONE factorisation of the same workload spread over N ranks, one process per GPU, by the C++ grid
-driver below the C-ABI (gpc_grid_*: 2-D block-cyclic pr x pc tiles, RCCL broadcasts of the diagonal tile / row panel /
+driver below the C-ABI (gpc_grid_*: 2-D block-cyclic pr x pc tiles, RCCL exchanges of the diagonal tile / row panel /
 column panel over xGMI sub-communicators, look-ahead 1), so the total work is fixed ("scaling": "strong") and `value` is
-whole-job factors/s.  Started without a launcher (WORLD_SIZE unset) the script re-executes itself under
+whole-job factors/s.  Which pr x pc and which exchange form (pairwise send / recv or one broadcast per root) is measured on
+the node before the timed steps: every factorisation of N x both forms, self-checked, timed on a half-size problem, all
+reported in `grid.calibration`; `grid.rccl_nranks` is ncclCommCount of the world communicator and `grid.link_probe` the
+measured rate of one panel-sized exchange.  `--gpus 1` is the direct single-GPU path (gpc_gp_update_k_f64), not a 1 x 1 grid.  Started without a launcher (WORLD_SIZE unset) the script re-executes itself under
 torch.distributed.run with N ranks; started by one, it checks that the launcher's world size is the N it was asked for.
 torch.distributed (gloo, CPU) only carries the RCCL unique id, the barriers and the max-over-ranks of the timing.
 Before the timed region every rank factors a small problem both ways (grid and single GPU) and compares log-determinants:
@@ -359,64 +362,100 @@ def main():
                 return False
             return True
 
+        # Which layout and which exchange: decided ON THE NODE, before the timed steps, never from the model alone.  Every
+        # factorisation pr x pc of the world size (8: 8x1, 4x2, 2x4, 1x8) is created once; on it both forms of the panel
+        # exchange -- grouped pairwise ncclSend / ncclRecv ("fanout") and one ncclBroadcast per root ("collective"),
+        # switched on the live grid with gpc_grid_set_exchange -- must first reproduce the single-GPU log|K| of the N = 8192
+        # check problem (a form that does not is reported and skipped, never run) and are then timed on a half-size problem.
+        # The fastest pair runs the timed steps; all pairs are in the line (grid.calibration).  GPC_GRID=PRxPC and / or
+        # GPC_GRID_EXCHANGE=fanout|collective restrict the candidates; GPC_BENCH_CALIBRATE=0 takes the default shape
+        # (grid.default_shape) with the pairwise exchange, falling back to the collective form if the self-check fails.
+        calibrate = os.environ.get("GPC_BENCH_CALIBRATE", "1") == "1" and world > 1
         if shape:
             candidates = [tuple(int(v) for v in shape.lower().split("x"))]
+        elif calibrate:
+            candidates = [(p, world // p) for p in range(world, 0, -1) if world % p == 0]
         else:
             candidates = [grid.default_shape(world)]
-            # untimed calibration (GPC_BENCH_CALIBRATE=0 skips it): the model behind default_shape() was fed one GPU's kernel
-            # times and an ASSUMED link bandwidth; on the node itself the two candidate layouts are simply tried on a
-            # quarter-size problem and the faster one runs the timed steps.  Both are reported.
-            if world >= 4 and os.environ.get("GPC_BENCH_CALIBRATE", "1") == "1" and grid.square_shape(world) != candidates[0]:
-                candidates.append(grid.square_shape(world))
+        ex_env = os.environ.get("GPC_GRID_EXCHANGE", "")
+        if ex_env:
+            exchanges = [ex_env]
+        elif calibrate:
+            exchanges = ["fanout", "collective"]
+        else:
+            exchanges = ["fanout"]
         for pr, pc in candidates:
             if pr * pc != world:
                 sys.exit("bench.py: a %d x %d grid does not have %d ranks" % (pr, pc, world))
+        timed_cal = len(candidates) * len(exchanges) > 1
         calibration = []
-        best = None
+        best = None            # (time, grid, pr, pc, exchange)
         exchange_fallback = None
+        ncal = int(os.environ.get("GPC_BENCH_CALIBRATE_N", str(max(4096, N // 2))))
+        Xcal = synth.make_xy(ncal, D, seed=7)[0] if timed_cal else None
         for pr, pc in candidates:
             gr = make_grid(pr, pc)
-            if world > 1 and os.environ.get("GPC_BENCH_SELFCHECK", "1") == "1" and not selfcheck(gr, pr, pc):
-                # The pairwise send / recv exchange is the default and the faster form on point-to-point links, but it is also
-                # the younger code path; a wrong result there is no reason to report nothing: the same grid is tried once more
-                # on ncclBroadcast per root (GPC_GRID_EXCHANGE=collective), and the line says so (grid.exchange).  Every rank
-                # takes the same decision: the verdict was all-reduced.
+            kept = False
+            tries = list(exchanges)
+            if not calibrate and not ex_env and not rehearsal:
+                tries = ["fanout", "collective"]          # the second only if the first fails its self-check
+            for ex in tries:
+                gr.set_exchange(ex)
+                os.environ["GPC_GRID_EXCHANGE"] = ex       # (what a grid created later -- none is -- would start with)
+                if world > 1 and os.environ.get("GPC_BENCH_SELFCHECK", "1") == "1" and not selfcheck(gr, pr, pc):
+                    calibration.append({"grid": "%dx%d" % (pr, pc), "exchange": ex, "selfcheck": False, "ms": None})
+                    if not calibrate and not ex_env:
+                        exchange_fallback = "fanout failed the start-up self-check"
+                    continue
+                t_cal = None
+                if timed_cal:
+                    gr.set_problem(cfg["kern"], Xcal, None, None)
+                    ts = []
+                    for it in range(3):
+                        gr.sync()
+                        dist.barrier()
+                        t0 = time.perf_counter()
+                        gr.update_k()
+                        gr.sync()
+                        tt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+                        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                        ts.append(float(tt.item()))
+                    t_cal = min(ts[1:])
+                    calibration.append({"grid": "%dx%d" % (pr, pc), "exchange": ex, "selfcheck": True, "N": ncal, "ms": t_cal * 1e3})
+                if best is None or (t_cal is not None and best[0] is not None and t_cal < best[0]):
+                    if best is not None and best[1] is not gr:
+                        best[1].destroy()
+                    best = (t_cal, gr, pr, pc, ex)
+                    kept = True
+                if not timed_cal:
+                    break                                  # first form that passes
+            if not kept:
                 gr.destroy()
-                gr = None
-                if not rehearsal and os.environ.get("GPC_GRID_EXCHANGE", "fanout") != "collective":
-                    os.environ["GPC_GRID_EXCHANGE"] = "collective"
-                    exchange_fallback = "fanout failed the start-up self-check"
-                    gr = make_grid(pr, pc)
-                    if not selfcheck(gr, pr, pc):
-                        gr.destroy()
-                        gr = None
-                if gr is None:
-                    fail("the %d x %d grid does not reproduce the single-GPU factorisation of the N = 8192 check problem"
-                         % (pr, pc), dist_selfcheck_failed=True)
-            t_cal = None
-            if len(candidates) > 1:
-                ncal = int(os.environ.get("GPC_BENCH_CALIBRATE_N", str(max(4096, N // 2))))
-                Xc, _ = synth.make_xy(ncal, D, seed=7)
-                gr.set_problem(cfg["kern"], Xc, None, None)
-                ts = []
-                for it in range(3):
-                    gr.sync()
-                    dist.barrier()
-                    t0 = time.perf_counter()
-                    gr.update_k()
-                    gr.sync()
-                    tt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
-                    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-                    ts.append(float(tt.item()))
-                t_cal = min(ts[1:])
-                calibration.append({"grid": "%dx%d" % (pr, pc), "N": ncal, "ms": t_cal * 1e3})
-            if best is None or (t_cal is not None and t_cal < best[0]):
-                if best is not None:
-                    best[1].destroy()
-                best = (t_cal, gr, pr, pc)
-            else:
-                gr.destroy()
-        _, g, pr, pc = best
+        if best is None:
+            fail("no layout / exchange of the %d-rank grid reproduces the single-GPU factorisation of the N = 8192 check problem"
+                 % world, dist_selfcheck_failed=True, calibration=calibration)
+        _, g, pr, pc, exchange = best
+        g.set_exchange(exchange)
+        os.environ["GPC_GRID_EXCHANGE"] = exchange
+        # the link rate the replay (tools/grid_model.py) had to assume, measured: one panel-sized all-gather along the longer
+        # axis of the chosen grid, in both exchange forms
+        link_probe = None
+        if world > 1:
+            axis = grid.AXIS_COL if pr > 1 else grid.AXIS_ROW
+            members = pr if pr > 1 else pc
+            count = min(max(N // members, nb), 8192) * nb
+            link_probe = {"axis": "column" if pr > 1 else "row", "members": members, "bytes_per_member": 8 * count, "forms": {}}
+            for ex in (["fanout", "collective"] if not ex_env else [ex_env]):
+                g.set_exchange(ex)
+                ms = g.exchange_probe(axis, count, 5)
+                tt = torch.tensor([ms], dtype=torch.float64)
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                ms = float(tt.item())
+                link_probe["forms"][ex] = {"ms": ms, "GBs_per_link_per_direction": 8e-6 * count / ms,
+                                           "GBs_received_per_rank": 8e-6 * count * (members - 1) / ms}
+            g.set_exchange(exchange)
+            link_probe["note"] = ("pairwise: each of the members-1 links of a rank carries bytes_per_member in each direction at "
+                                  "once; the replay behind grid.default_shape assumed 25-100 GB/s per link")
         g.set_problem(cfg["kern"], X, None, None)
         g.stats(reset=True)
 
@@ -466,22 +505,29 @@ def main():
         dt = float(tt.item())
 
     syrk_n, syrk_ms, syrk_flops = api.profile_read(0, reset=True)
+    # (the default configuration: one trailing update per panel; look-ahead / GPC_GEMM_PF2=0 split it in U1 + U2)
+    gemm_default = os.environ.get("GPC_GEMM_PF2", "2") != "0" and os.environ.get("GPC_PANEL_FLOW", "1") != "0"
     gram_n, gram_ms, gram_bytes = api.profile_read(1, reset=True)
     gstats = g.stats() if g is not None else None
     if g is not None:
         syrk_bytes = gstats["update_bytes"]
     else:
-        # algorithmic HBM bytes of the trailing updates of one factor: each reads its panel rows once (8*m*NB) and reads +
-        # writes the lower triangle it updates (2 * 8 * m(m+1)/2); summed over the panels
-        syrk_bytes, k0 = 0.0, 0
-        fixed_nb = int(os.environ.get("GPC_NB", "0"))
-        while k0 < N:
-            rem = N - k0
-            nbp = min(fixed_nb if fixed_nb >= 64 else 1024, rem)   # potrf.hip panel_width()
-            m = rem - nbp
+        # algorithmic HBM bytes of the trailing updates of one factor: each reads its panel rows once (8*m*nb) and reads +
+        # writes the lower triangle it updates (2 * 8 * m(m+1)/2); summed over the panels of the schedule gpc_potrf_f64
+        # actually walks (gpc_potrf_panel_schedule = potrf.hip panel_width(): 1024 ... 1664 ... one launch for the last 4096)
+        cnt = ctypes.c_int64(0)
+        widths = (ctypes.c_int64 * 4096)()
+        api.check(api.lib().gpc_potrf_panel_schedule(N, widths, 4096, ctypes.byref(cnt)))
+        syrk_bytes, k0, launches_expected = 0.0, 0, 0
+        for i in range(min(int(cnt.value), 4096)):
+            nbp = int(widths[i])
+            m = N - k0 - nbp
             if m > 0:
                 syrk_bytes += 8.0 * m * nbp + 8.0 * m * (m + 1)
+                launches_expected += 1
             k0 += nbp
+        assert launches_expected * args.steps == syrk_n or os.environ.get("GPC_LOOKAHEAD") == "1" or not gemm_default, \
+            "the profiled trailing updates (%d) are not the schedule's (%d per step)" % (syrk_n, launches_expected)
         syrk_bytes *= args.steps
 
     phases = None
@@ -580,7 +626,7 @@ def main():
             par = "%d x %d block-cyclic grid (nb=%d) over %d GPU%s, C++ driver below the C-ABI, %s, look-ahead 1" % (
                 inf["pr"], inf["pc"], inf["nb"], world, "" if world == 1 else "s",
                 ("REHEARSAL: exchange through torch.distributed/gloo, ranks may share a GPU -- not a measurement of the metric"
-                 if rehearsal else "RCCL broadcasts of diagonal tile / row panel / column panel") if world > 1 else "no exchange")
+                 if rehearsal else "RCCL exchanges of diagonal tile / row panel / column panel (%s)" % exchange) if world > 1 else "no exchange")
         else:
             par = "1 GPU" if world == 1 else "%d independent replicas (GPC_BENCH_REPLICAS=1)" % world
         out = {"metric": "N x N RBF Gram build + Cholesky factors/sec", "value": jobs * args.steps / dt,
@@ -598,9 +644,15 @@ def main():
                            "rank0_collectives_per_step": gstats["collectives"] / args.steps,
                            "rank0_update_tflops": achieved, "shape": "%dx%d" % (pr, pc), "tile": nb,
                            "rows_reflected": bool(g.info().get("refl", 0)),
-                           "exchange": os.environ.get("GPC_GRID_EXCHANGE", "fanout"),
+                           "exchange": exchange,
                            "exchange_fallback": exchange_fallback,
                            "calibration": calibration or None}
+            ci = g.comm_info()
+            # members of the world communicator as the TRANSPORT counts them (RCCL: ncclCommCount); null in a rehearsal
+            out["grid"]["transport"] = ci["kind"]
+            out["grid"]["rccl_nranks"] = ci["world"] if ci["kind"] == "rccl" else None
+            out["grid"]["comm_members_by_axis"] = {"row": ci["row"], "column": ci["col"], "world": ci["world"]}
+            out["grid"]["link_probe"] = link_probe
         if phases is not None:
             phases["gram_ms"] = gram_ms / max(1, gram_n)
             phases["potrf_logdet_ms"] = dt / args.steps * 1e3 - phases["gram_ms"]

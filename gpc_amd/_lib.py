@@ -85,6 +85,7 @@ SIGNATURES = {
     "gpc_axpby_f64": (c_int, [I64, I64, c_double, DP, I64, c_double, DP, I64, VP]),
     "gpc_scale_vec_f64": (c_int, [I64, I64, DP, I64, DP, c_int, VP]),
     "gpc_set_potrf_blocking": (c_int, [I64, I64]),
+    "gpc_potrf_panel_schedule": (c_int, [I64, POINTER(c_int64), I64, POINTER(c_int64)]),
     "gpc_set_gemm_variant": (c_int, [c_int]),
     "gpc_set_potrf_lookahead": (c_int, [c_int]),
     "gpc_profile_enable": (c_int, [c_int]),
@@ -130,6 +131,9 @@ GRID_SIGNATURES = {
     "info": (c_int, [GP, POINTER(c_int64)]),
     "stats": (c_int, [GP, POINTER(c_double), c_int]),
     "copy_tile": (c_int, [GP, I64, I64, DP, POINTER(c_int)]),
+    "comm_info": (c_int, [GP, POINTER(c_int64)]),
+    "set_exchange": (c_int, [GP, c_int]),
+    "exchange_probe": (c_int, [GP, c_int, I64, c_int, POINTER(c_double)]),
 }
 for _n, _sig in GRID_SIGNATURES.items():
     SIGNATURES["gpc_grid_" + _n] = _sig

@@ -56,8 +56,8 @@ struct GemmArgs {
   int tri_h;             // tri 1 / 2: tile rows in the LAST super-tile row (1 .. 8; 8 when tiles_m is a multiple of 8)
   unsigned tri_total;    // tri 1 / 2: valid tiles = slots of the enumeration (tri_count())
   int debug_same_rows;   // ablation knob (env GPC_GEMM_DEBUG_SAMEROWS): never set in production
-  int kstart;            // fast NT kernel only: both operands are upper triangular (square product, K == M == N):
-                         // a tile's k-loop starts at its first row m0 (everything left of it is zero)
+  int kstart;            // fast NT kernel only: the A operand is upper triangular / trapezoidal (A(m, k) = 0 for k < m; in the
+                         // square products V V' so is B): a tile's k-loop starts at its first row m0 (everything left of it is zero)
   int trap_deal;         // tri 3: super-tiles dealt round-robin to the XCDs (GPC_GEMM_TRAP_DEAL=0: contiguous chunks, as before)
   int kend;              // fast NT kernel only: B (N x K, N == K) is lower triangular, so the k-loop of tile column n0 stops at
                          // n0 + 128 (the rows of a tall panel times the inverse of its diagonal tile, potrf.hip)
@@ -373,11 +373,18 @@ __global__ void __launch_bounds__(256, 2) gemm_f64_kernel(const GemmArgs g)
 //   * NWN = 2: 4 waves, 64 x 64 per wave (2 waves/SIMD with two workgroups per CU);
 //     NWN = 4: 8 waves, 64 x 32 per wave (<= 128 VGPRs -> 4 waves/SIMD).
 //   * ROLE changes nothing but the kernel's NAME: 1 = a trailing update of the Cholesky (the launches bench.py's roofline
-//     times with HIP events), 0 = everything else (in-panel updates, trsm/potri products, plain gpc_gemm_f64 calls), so
-//     that rocprofv3's per-kernel statistics separate the two populations.
-template <int NWN, int ROLE, bool SPLITK = false, bool PF2 = false>
+//     times with HIP events), 2 = slab updates inside a panel of the launch chain, 3 = the rank-nb updates of the
+//     right-sided triangular solves / dpotri (SolveScope), 0 = everything else (plain gpc_gemm_f64 calls, V V'), so that
+//     rocprofv3's per-kernel statistics separate the populations.
+//   * A_KC / B_KC (round 4): the operand is contiguous along k in memory (op(A) = A': stored K x M; op(B)' = B: stored K x N), i.e.
+//     the NN / TN / TT forms of dgemm_ (lapack.h:165-181) on the same pipeline.  Such an operand is staged by rows -- a thread
+//     loads two consecutive k of two adjacent rows (8 threads = one 128-byte run of a row) -- into the [m][k] image
+//     (row stride 18 doubles, conflict-free for the fragment reads like the [k][m] one); everything else is the NT kernel.
+//     k-start / k-end / staircase / split-k stay NT-only.
+template <int NWN, int ROLE, bool SPLITK = false, bool PF2 = false, bool A_KC = false, bool B_KC = false>
 __global__ void __launch_bounds__(128 * NWN, NWN) gemm_nt_fast_kernel(const GemmArgs g)
 {
+  static_assert(!(A_KC || B_KC) || (NWN == 4 && !SPLITK), "k-contiguous operands: eight-wave, unsplit instances only");
   constexpr int NT = 256 / (64 * NWN) * 2;  // n-subtiles per wave: NWN=2 -> 4, NWN=4 -> 2
   constexpr int NL = 8 / (2 * NWN);         // double2 loads per operand per thread per stage: 2 or 1... see below
   static_assert(NWN == 2 || NWN == 4, "wave grid");
@@ -418,7 +425,7 @@ __global__ void __launch_bounds__(128 * NWN, NWN) gemm_nt_fast_kernel(const Gemm
     if(diag5 && roff + BM - 1 < coff) return;
     Bop = g.B + g.voff[g.st_jl0 + ct] + coff;
   }
-  // staging pointers (rows clamped into the matrix; M, N are even and >= 2 on this path)
+  // staging pointers (rows clamped into the matrix; for an m-contiguous operand M resp. N is even and >= 2 on this path)
   int64_t ra = m0 + 2 * lane, rb = (g.tri == 5 ? 0 : n0) + 2 * lane;
   const int64_t rbmax = (g.tri == 5 ? BN : g.N) - 2;
   if(g.debug_same_rows) {  // ablation: every tile reads operand rows 0..127 (all L2 hits); results are wrong
@@ -439,9 +446,32 @@ __global__ void __launch_bounds__(128 * NWN, NWN) gemm_nt_fast_kernel(const Gemm
   }
   const double* pa = g.A + ra + ((int64_t)(t >> 6) + kfirst) * g.lda;
   const double* pb = Bop + rb + ((int64_t)(t >> 6) + kfirst) * g.ldb;
-  const int64_t stepa = (int64_t)KROWS * g.lda, stepb = (int64_t)KROWS * g.ldb;
-  const int64_t stagea = (int64_t)BK * g.lda, stageb = (int64_t)BK * g.ldb;
+  int64_t stepa = (int64_t)KROWS * g.lda, stepb = (int64_t)KROWS * g.ldb;
+  int64_t stagea = (int64_t)BK * g.lda, stageb = (int64_t)BK * g.ldb;
   const int lds_w = (t >> 6) * STRIDE_MC + 2 * lane;  // [k][m] image, k = (t>>6) + KROWS*i
+  // k-contiguous operand: thread = (rows 2 (t >> 3), +1; k = 2 (t & 7), +1): the two passes are ADJACENT rows, so their distance
+  // is the leading dimension (uniform, like the m-contiguous form's) and one clamp -- the row pair into the matrix -- serves
+  // both; rows past the edge hold some valid row's values and are masked at the store
+  const int lds_wk = 2 * (t >> 3) * STRIDE_KC + 2 * (t & 7);   // [m][k] image
+  if(A_KC) {
+    int64_t r0 = m0 + 2 * (t >> 3);
+    if(r0 > g.M - 2) r0 = g.M - 2;
+    if(r0 < 0) r0 = 0;
+    pa = g.A + 2 * (t & 7) + r0 * g.lda;
+    stepa = g.M > 1 ? g.lda : 0;
+    stagea = BK;
+  }
+  if(B_KC) {
+    int64_t r0 = n0 + 2 * (t >> 3);
+    if(r0 > g.N - 2) r0 = g.N - 2;
+    if(r0 < 0) r0 = 0;
+    pb = g.B + 2 * (t & 7) + r0 * g.ldb;
+    stepb = g.N > 1 ? g.ldb : 0;
+    stageb = BK;
+  }
+  const int lwa = A_KC ? lds_wk : lds_w, lwb = B_KC ? lds_wk : lds_w;
+  constexpr int LPA = A_KC ? STRIDE_KC : KROWS * STRIDE_MC;   // LDS distance between the passes of one operand
+  constexpr int LPB = B_KC ? STRIDE_KC : KROWS * STRIDE_MC;
 
   double4_t acc[4][NT];
 #pragma unroll
@@ -463,8 +493,8 @@ __global__ void __launch_bounds__(128 * NWN, NWN) gemm_nt_fast_kernel(const Gemm
     }
 #pragma unroll
     for(int i = 0; i < PASSES; i++) {
-      *reinterpret_cast<double2_t*>(lds + lds_w + i * KROWS * STRIDE_MC) = ra_[i];
-      *reinterpret_cast<double2_t*>(lds + OP_ELEMS + lds_w + i * KROWS * STRIDE_MC) = rb_[i];
+      *reinterpret_cast<double2_t*>(lds + lwa + i * LPA) = ra_[i];
+      *reinterpret_cast<double2_t*>(lds + OP_ELEMS + lwb + i * LPB) = rb_[i];
     }
     if(PF2 && KT > 1) {   // stage 1 into the first set
       pa += stagea;
@@ -478,8 +508,11 @@ __global__ void __launch_bounds__(128 * NWN, NWN) gemm_nt_fast_kernel(const Gemm
   }
   __syncthreads();
 
-  const int fa = wm * 64 + (lane & 15) + (lane >> 4) * STRIDE_MC;               // + s*16 + kk*4*STRIDE_MC
-  const int fb = wn * (16 * NT) + (lane & 15) + (lane >> 4) * STRIDE_MC;
+  // fragment (row = base + s*16 + (lane & 15), k = kk*4 + (lane >> 4)): [k][m] image: + s*16 + kk*4*STRIDE_MC; [m][k]: + s*16*STRIDE_KC + kk*4
+  const int fa = A_KC ? (wm * 64 + (lane & 15)) * STRIDE_KC + (lane >> 4) : wm * 64 + (lane & 15) + (lane >> 4) * STRIDE_MC;
+  const int fb = B_KC ? (wn * (16 * NT) + (lane & 15)) * STRIDE_KC + (lane >> 4) : wn * (16 * NT) + (lane & 15) + (lane >> 4) * STRIDE_MC;
+  constexpr int FSA = A_KC ? 16 * STRIDE_KC : 16, FKA = A_KC ? 4 : 4 * STRIDE_MC;
+  constexpr int FSB = B_KC ? 16 * STRIDE_KC : 16, FKB = B_KC ? 4 : 4 * STRIDE_MC;
 
   // one stage: its 4 k-steps of MFMAs; behind the first of them the loads of stage `kt + ahead` into (la, lb); at its end the
   // registers (sa, sb) -- stage kt + 1 -- go to the other LDS buffer
@@ -494,9 +527,9 @@ __global__ void __launch_bounds__(128 * NWN, NWN) gemm_nt_fast_kernel(const Gemm
     for(int kk = 0; kk < 4; kk++) {
       double a[4], b[NT];
 #pragma unroll
-      for(int s = 0; s < 4; s++) a[s] = As[fa + s * 16 + kk * 4 * STRIDE_MC];
+      for(int s = 0; s < 4; s++) a[s] = As[fa + s * FSA + kk * FKA];
 #pragma unroll
-      for(int s = 0; s < NT; s++) b[s] = Bs[fb + s * 16 + kk * 4 * STRIDE_MC];
+      for(int s = 0; s < NT; s++) b[s] = Bs[fb + s * FSB + kk * FKB];
 #pragma unroll
       for(int tn = 0; tn < NT; tn++)
 #pragma unroll
@@ -516,8 +549,8 @@ __global__ void __launch_bounds__(128 * NWN, NWN) gemm_nt_fast_kernel(const Gemm
     if(more) {
 #pragma unroll
       for(int i = 0; i < PASSES; i++) {
-        *reinterpret_cast<double2_t*>(nxt + lds_w + i * KROWS * STRIDE_MC) = sa[i];
-        *reinterpret_cast<double2_t*>(nxt + OP_ELEMS + lds_w + i * KROWS * STRIDE_MC) = sb[i];
+        *reinterpret_cast<double2_t*>(nxt + lwa + i * LPA) = sa[i];
+        *reinterpret_cast<double2_t*>(nxt + OP_ELEMS + lwb + i * LPB) = sb[i];
       }
     }
     __syncthreads();
@@ -619,6 +652,23 @@ int launch_fast_role(const GemmArgs& g, unsigned grid, hipStream_t s)
   return GPC_OK;
 }
 
+// the NN / TN / TT forms on the fast pipeline (eight waves, operands two stages ahead)
+template <bool A_KC, bool B_KC, bool PF2>
+int launch_fast_kc(const GemmArgs& g, unsigned grid, hipStream_t s)
+{
+  static std::atomic<uint64_t> attr_set{0};
+  auto kern = gemm_nt_fast_kernel<4, 0, false, PF2, A_KC, B_KC>;
+  int dev = 0;
+  GPC_HIP_CHECK(hipGetDevice(&dev));
+  if(!(attr_set.load() >> (dev & 63) & 1)) {
+    GPC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES));
+    attr_set.fetch_or(1ull << (dev & 63));
+  }
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), GEMM_LDS_BYTES, s, g);
+  GPC_HIP_CHECK(hipGetLastError());
+  return GPC_OK;
+}
+
 }  // namespace
 
 // Trailing updates load their operands TWO stages ahead (PF2 instance of the fast kernel: 124 VGPRs, still four waves per
@@ -640,6 +690,7 @@ template <int NWN>
 int launch_fast(const GemmArgs& g, unsigned grid, hipStream_t s)
 {
   if(g_gemm_trailing == 2) return launch_fast_role<NWN, 2>(g, grid, s);   // slab update inside a Cholesky panel
+  if(NWN == 4 && g_gemm_trailing == 3 && gemm_two_ahead()) return launch_fast_role<4, 3, true>(g, grid, s);   // SolveScope
   if(NWN == 4 && g_gemm_trailing && gemm_two_ahead()) return launch_fast_role<4, 1, true>(g, grid, s);
   static int pf2_all = -1;
   if(pf2_all < 0) { const char* e = getenv("GPC_GEMM_PF2"); pf2_all = (!e || atoi(e) >= 2) ? 1 : 0; }   // 1 = trailing updates only
@@ -721,7 +772,9 @@ static int gemm_ex(bool transa, bool transb, int64_t M, int64_t N, int64_t K, do
   g.ksplit = 1;
   g.part = nullptr;
   g.part_stride = 0;
-  g.kstart = (g_gemm_kstart && !transa && transb && M == N && K >= M && tri == 1) ? 1 : 0;
+  // KStartScope: A(m, k) = 0 for k < m (an upper-triangular / upper-trapezoidal left operand).  Square lower products (V V')
+  // and plain ones whose C is full (dpotri in place: R(blk, 0:k0) = Vd P')
+  g.kstart = (g_gemm_kstart && !transa && transb && K >= M && ((tri == 1 && M == N) || tri == 0)) ? 1 : 0;
   g.kend = (g_gemm_kend && !transa && transb && N == K && tri == 0) ? 1 : 0;
   {
     static int deal = -1;
@@ -801,7 +854,8 @@ static int gemm_ex(bool transa, bool transb, int64_t M, int64_t N, int64_t K, do
   else
     slots = g.tri_total;  // the valid lower tiles, 8 x 8 super-tile by super-tile
   slots = (slots + 7) & ~7ull;
-  if(g_gemm_kstart || g.trap_deal) slots = (slots + 511) & ~511ull;   // whole groups of 64 ids per XCD (map_tile's round-robin deal)
+  const uint64_t slots_plain = slots;   // the enumeration without the round-robin deal's padding
+  if(g.kstart || g.trap_deal) slots = (slots + 511) & ~511ull;   // whole groups of 64 ids per XCD (map_tile's round-robin deal)
   if(slots > 0x7fffffffull) {
     set_error("gemm grid too large");
     return GPC_EINVAL;
@@ -818,6 +872,19 @@ static int gemm_ex(bool transa, bool transb, int64_t M, int64_t N, int64_t K, do
     if(g_gemm_variant < 0 || g_gemm_variant > 2) g_gemm_variant = 2;
   }
   if(tri == 5) return g_gemm_variant == 1 ? launch_fast<2>(g, grid, s) : launch_fast<4>(g, grid, s);
+  // NN / TN / TT (round 4): the fast kernel with the k-contiguous operand(s) staged by rows.  An m-contiguous operand still
+  // wants an even row count (its threads load row pairs); a k-contiguous one has no such need.
+  static const int fast_kc = [] { const char* e = getenv("GPC_GEMM_FAST_KC"); return e ? atoi(e) : 1; }();
+  if(fast_kc && g_gemm_variant == 2 && (a_kc || b_kc) && vec && g.K > 0 && (g.K % BK) == 0 && (a_kc || (M % 2) == 0) &&
+     (b_kc || (N % 2) == 0) && (tri == 0 || tri == 1 || tri == 2 || tri == 3)) {
+    g.kstart = g.kend = 0;
+    // operands two stages ahead (GPC_GEMM_KC_PF2, default by form): the row-staged instances sit at the 128-register limit of
+    // four waves per SIMD, the TN one over it (24 spilled registers)
+    static const int kc_pf2 = [] { const char* e = getenv("GPC_GEMM_KC_PF2"); return e ? atoi(e) : -1; }();
+    if(a_kc && b_kc) return (kc_pf2 > 0) ? launch_fast_kc<true, true, true>(g, grid, s) : launch_fast_kc<true, true, false>(g, grid, s);
+    if(a_kc) return (kc_pf2 != 0) ? launch_fast_kc<true, false, true>(g, grid, s) : launch_fast_kc<true, false, false>(g, grid, s);
+    return (kc_pf2 != 0) ? launch_fast_kc<false, true, true>(g, grid, s) : launch_fast_kc<false, true, false>(g, grid, s);
+  }
   if(g_gemm_variant > 0 && !a_kc && !b_kc && vec && g.K > 0 && (g.K % BK) == 0 && (M % 2) == 0 && (N % 2) == 0) {
     // few tiles and a long k: one round of workgroups would each walk the whole k-range while most of the chip idles
     // (N = 1000, K = 1024: 36 tiles, 161 us).  Cut every tile's k-range into pieces with a workgroup each; the pieces are
@@ -845,7 +912,7 @@ static int gemm_ex(bool transa, bool transb, int64_t M, int64_t N, int64_t K, do
           // the k-start deal pads the grid to whole groups of 512 ids; a workgroup that exits at once still waits for its 73 KB
           // of LDS, so with a few dozen tiles the plain enumeration (and the tiles' own k-starts) is the better launch
           g.kstart = 2;
-          nslots = (unsigned)(((uint64_t)g.tri_total + 7) & ~7ull);
+          nslots = (unsigned)slots_plain;
         }
         return launch_fast_splitk(g, nslots, s);
       }

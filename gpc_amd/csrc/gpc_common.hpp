@@ -112,6 +112,10 @@ struct TrailingScope {
   TrailingScope() { g_gemm_trailing = 1; }
   ~TrailingScope() { g_gemm_trailing = 0; }
 };
+struct SolveScope {   // the large beta = 1 products of the triangular solves / dpotri: the trailing update's code path (no
+  SolveScope() { g_gemm_trailing = 3; }     // split-k, two stages ahead) under a kernel name of their own (ROLE 3), so that
+  ~SolveScope() { g_gemm_trailing = 0; }    // rocprofv3's statistics of ROLE 1 hold the factorisation's updates only
+};
 // While alive: A * B' products whose operands are UPPER triangular start each tile's k-loop at the tile's first row.
 extern thread_local int g_gemm_kend;   // KEndScope: the B operand of an NT product is lower triangular (N == K): tile column n0 stops at k = n0 + 128
 struct KEndScope {
@@ -127,7 +131,7 @@ struct KStartScope {
 int potrf_lower(int64_t N, double* A, int64_t lda, int* d_info, hipStream_t s, int64_t col0 = 0);
 int potrf_panel(int64_t M, int64_t nb, double* A, int64_t lda, int* d_info, int64_t col0, hipStream_t s);
 int trsm_rlt_flow(int64_t M, int64_t n, const double* L, int64_t lda, double* B, int64_t ldb, bool identity_rows, int* d_info,
-                  hipStream_t s);   // potrf.hip: X L' = B by dataflow launches
+                  hipStream_t s, double* inplace_tile = nullptr);   // potrf.hip: X L' = B by dataflow launches (B == L: in place)
 int potrf_panel_rows(int64_t M, int64_t nb, double* tile, int64_t ldt, double* rows, int64_t ldr, int* d_info, int64_t col0, hipStream_t s);
 // panel_flow.hip: one panel (diagonal dpotrf + the rows below) as ONE dataflow launch; GPC_EUNSUPPORTED outside its domain
 int panel_flow(int64_t M, int64_t nbk, double* P, int64_t lda, int* d_info, int64_t col0, hipStream_t s, int64_t zero_row0 = -1,

@@ -558,6 +558,7 @@ struct RcclApi {
   decltype(&ncclRecv) Recv = nullptr;
   decltype(&ncclGroupStart) GroupStart = nullptr;
   decltype(&ncclGroupEnd) GroupEnd = nullptr;
+  decltype(&ncclCommCount) CommCount = nullptr;
   decltype(&ncclGetErrorString) GetErrorString = nullptr;
   std::string where;
 };
@@ -591,6 +592,7 @@ RcclApi* rccl_api()
     GPC_RCCL_SYM(Recv);
     GPC_RCCL_SYM(GroupStart);
     GPC_RCCL_SYM(GroupEnd);
+    GPC_RCCL_SYM(CommCount);
     GPC_RCCL_SYM(GetErrorString);
 #undef GPC_RCCL_SYM
     if(!api.GetUniqueId || !api.CommInitRank || !api.CommSplit || !api.CommDestroy || !api.Broadcast || !api.AllReduce ||
@@ -633,6 +635,23 @@ struct RcclComm : GridComm {
     if(e && strcmp(e, "collective") == 0) fanout = false;
   }
   int group_size(int axis) const override { return size[axis]; }
+  void describe(int64_t* out) const override
+  {
+    // the member counts RCCL itself reports for the communicators the exchanges run on (0: no communicator for that axis --
+    // a group of one); -1 when this librccl has no ncclCommCount
+    for(int a = 0; a < 3; a++) {
+      int n = 0;
+      if(comm[a] && (!api->CommCount || api->CommCount(comm[a], &n) != ncclSuccess)) n = -1;
+      out[a] = n;
+    }
+    out[3] = 1;
+    out[4] = fanout ? 0 : 1;
+  }
+  int set_exchange(int mode) override
+  {
+    fanout = (mode == 0);
+    return GPC_OK;
+  }
   int init(int rank, int nranks, int pr, int pc, const void* uid, GridOps* ops)
   {
     ncclUniqueId id;

@@ -10,6 +10,7 @@
 //   grid_make_collective_comm(...)         the RCCL communicator (or GPC_EUNSUPPORTED)
 //   grid_unique_id(void* uid)              fill GPC_GRID_UID_BYTES
 #include <new>
+#include <chrono>
 
 struct gpc_grid {
   std::unique_ptr<gpc::grid::GridGp> gp;
@@ -238,6 +239,57 @@ int GRID_API(info)(gpc_grid* g, int64_t* out)
   const int64_t v[13] = {L.N, L.nb, L.T, L.pr, L.pc, L.r, L.c, L.mloc, L.nloc, L.E, L.Lr, L.Lc, L.refl ? 1 : 0};
   for(int i = 0; i < 13; i++) out[i] = v[i];
   return GPC_OK;
+}
+
+// out[0..4]: what the transport reports about itself (GridComm::describe): members of the row / column / world communicator as
+// the transport counts them, its kind (0 single rank, 1 RCCL, 2 in-process board, 3 callbacks), the exchange form (0 pairwise, 1
+// one broadcast per root); out[5] = this rank's index in the world
+int GRID_API(comm_info)(gpc_grid* g, int64_t* out)
+{
+  if(!g || !out) return GPC_EINVAL;
+  g->gp->comm()->describe(out);
+  out[5] = g->gp->rank();
+  return GPC_OK;
+}
+
+int GRID_API(set_exchange)(gpc_grid* g, int mode)
+{
+  if(!g || (mode != 0 && mode != 1)) return GPC_EINVAL;
+  return g->gp->comm()->set_exchange(mode);
+}
+
+// One panel-sized exchange, timed: every member of the axis group contributes `count` doubles to an in-place all-gather
+// (the exchange of the column panel, GridComm::allgatherv -- pairwise send / recv or one broadcast per root, whichever form
+// the grid is set to), `reps` times after one untimed round; *ms = host wall time per exchange between two stream
+// synchronisations.  Collective over the axis group.  With n members every rank receives (n - 1) count doubles per exchange,
+// over n - 1 links when the exchange is pairwise: bench.py turns this into GB/s per link and prints it beside the replay's
+// assumption (tools/grid_model.py).
+int GRID_API(exchange_probe)(gpc_grid* g, int axis, int64_t count, int reps, double* ms)
+{
+  if(!g || !ms || axis < 0 || axis > 2 || count <= 0 || reps <= 0) return GPC_EINVAL;
+  GRID_CHECK(grid_enter(g->device));
+  GridOps* ops = g->gp->ops();
+  GridComm* comm = g->gp->comm();
+  const int n = comm->group_size(axis);
+  void* buf = nullptr;
+  int rc = ops->alloc(&buf, sizeof(double) * (size_t)count * (size_t)n);
+  if(rc != GPC_OK) return grid_fail(g, rc);
+  std::vector<int64_t> start((size_t)n), cnt((size_t)n);
+  for(int i = 0; i < n; i++) {
+    start[(size_t)i] = (int64_t)i * count;
+    cnt[(size_t)i] = count;
+  }
+  rc = ops->zero(buf, sizeof(double) * (size_t)count * (size_t)n, ST_MAIN);
+  if(rc == GPC_OK) rc = comm->allgatherv(buf, start.data(), cnt.data(), axis, ops, ST_MAIN);   // untimed: connections, buffers
+  if(rc == GPC_OK) rc = ops->sync(ST_MAIN);
+  if(rc == GPC_OK) rc = comm->barrier();
+  const std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+  for(int it = 0; it < reps && rc == GPC_OK; it++) rc = comm->allgatherv(buf, start.data(), cnt.data(), axis, ops, ST_MAIN);
+  if(rc == GPC_OK) rc = ops->sync(ST_MAIN);
+  const double dt = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  (void)ops->release(buf);
+  *ms = dt / (double)reps;
+  return grid_fail(g, rc);
 }
 
 // out[0..7] = bytes received along process rows / columns / world, collectives entered, algorithmic flops of this

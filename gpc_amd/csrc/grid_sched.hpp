@@ -238,6 +238,17 @@ struct GridComm {
   // instead of waiting for ever.  Only the in-process board has such waits; RCCL has its own abort.
   virtual void abort_group() {}
   virtual int group_size(int axis) const = 0;
+  // What the transport itself reports (gpc_grid_comm_info): out[0..2] = members of the row / column / world communicator as the
+  // TRANSPORT counts them (RCCL: ncclCommCount; 0 = no communicator for that axis), out[3] = kind (0 single rank, 1 RCCL, 2
+  // in-process board, 3 caller's callbacks), out[4] = exchange form (0 pairwise send / recv, 1 one broadcast per root)
+  virtual void describe(int64_t* out) const
+  {
+    for(int a = 0; a < 3; a++) out[a] = group_size(a);
+    out[3] = 0;
+    out[4] = 0;
+  }
+  // 0: panels leave their root as grouped pairwise sends (default), 1: as ncclBroadcast per root.  Transports with one form ignore it.
+  virtual int set_exchange(int mode) { (void)mode; return GPC_OK; }
 };
 
 // Caller-supplied transport (MPI, gloo, ...): plain C callbacks.  The library synchronises stream `st` before a call, the
@@ -272,6 +283,12 @@ struct CallbackComm : GridComm {
   {
     double z = 0.0;
     return allreduce_host(&z, 1, AX_WORLD);
+  }
+  void describe(int64_t* out) const override
+  {
+    GridComm::describe(out);
+    out[3] = 3;
+    out[4] = 1;
   }
 };
 
@@ -349,6 +366,11 @@ struct LocalComm : GridComm {
   void* my_done[3] = {nullptr, nullptr, nullptr};   // this rank's "I have copied" event, one per axis
   GridOps* ops0 = nullptr;                          // the ops the events came from (outlives this object: see GridGp)
   LocalComm(std::shared_ptr<LocalBoard> b, int r_, int c_) : board(b), r(r_), c(c_) {}
+  void describe(int64_t* out) const override
+  {
+    GridComm::describe(out);
+    out[3] = 2;
+  }
   ~LocalComm() override
   {
     for(int a = 0; a < 3 && ops0; a++) {
@@ -505,6 +527,7 @@ class GridGp {
 
   GridOps* ops() { return ops_.get(); }
   GridComm* comm() { return comm_.get(); }
+  int rank() const { return r_ * pc_ + c_; }
   const Layout& layout() const { return L_; }
   const GridStats& stats() const { return stats_; }
   void reset_stats()

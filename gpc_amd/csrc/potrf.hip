@@ -3,14 +3,18 @@
 // Replaces dpotrf_ as called by CMatrix::potrf / chol / jitChol (CMatrix.cpp:371-403, 767-804; lapack.h:59-65).
 //
 // Structure:
-//   outer panels of NB = 1024 columns -- 2048 once <= 8192 columns are left, the last <= 4096 as one panel (panel_width()).
-//   A panel of <= 24 576 rows is ONE launch of the dataflow kernel of panel_flow.hip (a workgroup per 64 x 64 block, blocks
-//   published through a polled exchange buffer); taller panels, and everything when GPC_PANEL_FLOW=0, take the launch chain
-//   described below.  After panel k is final its trailing update A22 -= L21 * L21' (depth
-//   NB, the fp64 MFMA tiles of gemm_f64.hip, N^3/3 of the flops) is split in two launches:
-//       U1(k): the NB columns that form panel k+1 (lower trapezoid),   U2(k): everything to the right of them.
-//   LOOK-AHEAD (N >= 28 672): U1/U2 run on the caller's stream, the panels on a second, high-priority stream (per host
-//   thread); panel k+1 starts as soon as U1(k) is done and is factored while U2(k) keeps every CU busy.
+//   outer panels of 1024 columns while more than 8192 columns are left, 1024-1664 down to 4096 (whatever leaves the trailing
+//   update a full last round of 256 tiles), the last <= 4096 columns as one panel (panel_width()).
+//   By default EVERY panel is one launch of the dataflow kernel of panel_flow.hip (a workgroup per 64 x 64 block, blocks
+//   published through a polled exchange buffer); a panel with >= 12 288 rows below its diagonal tile factors [tile; I] in that
+//   launch and takes the rows below as ONE k-limited product with the tile's inverse (panel_by_inverse).  The launch chain
+//   described below factors everything when GPC_PANEL_FLOW=0, after a dataflow time-out, and the panels taller than
+//   GPC_PANEL_FLOW_MAXROWS.  After panel k is final its trailing update A22 -= L21 * L21' (depth NB, the fp64 MFMA tiles of
+//   gemm_f64.hip, N^3/3 of the flops) is ONE launch.
+//   LOOK-AHEAD is OFF by default: the trailing-update kernel (operands two stages ahead) fills every CU's registers and LDS,
+//   so a panel kernel launched beside it does not start before it drains.  With GPC_GEMM_PF2=0 (one stage ahead) the
+//   round-2 form returns: look-ahead from N >= 28 672 -- the update split in U1(k) (the columns of panel k+1) and U2(k) (the
+//   rest), panels on a second, high-priority stream (per host thread) -- and dataflow panels up to 24 576 rows.
 //   Inside a panel of the launch chain, two levels: 128-column slabs of two 64-column steps, per slab
 //     potf2_blk_kernel          one workgroup, the 64 x 64 diagonal block in registers, columns 8 at a time (the four waves
 //                               exchange their shares through LDS once per 8 columns, every wave then factors the 64 x 8 block
@@ -28,6 +32,7 @@
 #include <stdlib.h>
 #include <vector>
 #include <utility>
+#include <type_traits>
 
 namespace gpc {
 
@@ -554,29 +559,40 @@ int panel_solve_rt(const double* Lbb, int64_t lda, int nb, double* B, int64_t ld
 
 namespace {
 
-// second stream + event pool for the look-ahead (created once per process and device)
+// second stream + event pool for the look-ahead (created once per host thread and device).  Trivially destructible on
+// purpose: gpc_shutdown runs from atexit, i.e. AFTER the exiting thread's thread_local destructors -- a std::vector here
+// would already be destroyed when release_lookahead_impl() walks it.  The pool is a raw array freed only there.
 struct LookAhead {
-  hipStream_t panel = nullptr;
-  int dev = -1;
-  std::vector<hipEvent_t> ev;
-  size_t next = 0;
+  hipStream_t panel;
+  int dev;
+  hipEvent_t* ev;
+  size_t count, cap, next;
   hipEvent_t get()
   {
-    if(next == ev.size()) {
+    if(next == count) {
+      if(count == cap) {
+        const size_t ncap = cap ? 2 * cap : 256;
+        hipEvent_t* ne = static_cast<hipEvent_t*>(realloc(ev, ncap * sizeof(hipEvent_t)));
+        if(!ne) return nullptr;
+        ev = ne;
+        cap = ncap;
+      }
       hipEvent_t e;
       if(hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
-      ev.push_back(e);
+      ev[count++] = e;
     }
     return ev[next++];
   }
 };
-thread_local LookAhead g_la;   // per host thread, like the scratch buffers (capi.hip)
+static_assert(std::is_trivially_destructible<LookAhead>::value, "must survive thread_local destruction (atexit order)");
+thread_local LookAhead g_la = {nullptr, -1, nullptr, 0, 0, 0};   // per host thread, like the scratch buffers (capi.hip)
 
 void release_lookahead_impl()
 {
-  for(hipEvent_t e : g_la.ev) (void)hipEventDestroy(e);
-  g_la.ev.clear();
-  g_la.next = 0;
+  for(size_t i = 0; i < g_la.count; i++) (void)hipEventDestroy(g_la.ev[i]);
+  free(g_la.ev);
+  g_la.ev = nullptr;
+  g_la.count = g_la.cap = g_la.next = 0;
   if(g_la.panel) (void)hipStreamDestroy(g_la.panel);
   g_la.panel = nullptr;
 }
@@ -590,7 +606,7 @@ int ensure_lookahead()
   GPC_HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));
   GPC_HIP_CHECK(hipStreamCreateWithPriority(&g_la.panel, hipStreamNonBlocking, hi));
   g_la.dev = dev;
-  g_la.ev.clear();
+  g_la.count = g_la.next = 0;   // (events of another device's pool are abandoned, not reused across devices)
   return GPC_OK;
 }
 
@@ -764,18 +780,43 @@ int potrf_panel_rows(int64_t M, int64_t nb, double* tile, int64_t ldt, double* r
 // take ONE k-limited product with L_bb^-T, as the tall panels of the factorisation do (panel_by_inverse).  This replaces, per
 // 512 columns, eight launches of the substitution chain and four small products (dpotri at N = 8192: 11.6 -> 9.2 ms, 4096:
 // 3.5 -> 2.4, 65 536: 3.00 -> 2.84 s).  GPC_EUNSUPPORTED outside its domain (the caller keeps the chain).
-int trsm_rlt_flow(int64_t M, int64_t n, const double* L, int64_t lda, double* B, int64_t ldb, bool identity_rows, int* d_info, hipStream_t s)
+// IN PLACE (dpotri without an N x N workspace; potri_full in trsm.hip): B is L's own array -- the factor in the lower triangle,
+// the right-hand side (an identity) in the strictly upper one, which the caller has zeroed.  Only the diagonal nbk x nbk tile
+// is claimed by both: per panel it is copied aside (`inplace_tile`, nbk x nbk doubles: the copy is the "given" factor block of
+// the launch; the rows below it, the operand of the trailing product, stay where they are) and replaced by an identity tile,
+// which the panel's solve turns into L_bb^-T.  Nothing reads a block of B left of its diagonal tile (the identity's zero
+// blocks are skipped), so L's rows below survive until their own panel, and after the last panel the upper triangle
+// including the diagonal tiles holds V = L^-T (the lower parts of the diagonal tiles are zero, L's strictly-lower tiles are
+// still L's).
+int trsm_rlt_flow(int64_t M, int64_t n, const double* L, int64_t lda, double* B, int64_t ldb, bool identity_rows, int* d_info, hipStream_t s,
+                  double* inplace_tile)
 {
   if(n < 128 || M < 1 || panel_flow_maxrows() < 8192) return GPC_EUNSUPPORTED;
   if(identity_rows && M > n) return GPC_EUNSUPPORTED;
   // (the products want even sizes and 16-byte aligned operands: B's rows, the columns right of a panel)
   if(M % 2 != 0 || n % 2 != 0 || ldb % 2 != 0 || lda % 2 != 0) return GPC_EUNSUPPORTED;
+  const bool inplace = inplace_tile != nullptr;
+  if(inplace && (!identity_rows || M != n || B != L || ldb != lda)) return GPC_EINVAL;
   static const int64_t nb_env = [] { const char* e = getenv("GPC_TRTRI_NB"); return e ? atoll(e) : (int64_t)0; }();   // measurement aid
+  // (width: the launch's work is rows x nbk^2 at the dataflow blocks' rate, the product's 2 rows (n - kend) nbk at the chip's;
+  //  one launch for everything only while the whole problem is small)
+  const int64_t NB = nb_env >= 64 ? (nb_env / 64) * 64 : ((n <= 4096 && M <= 4096) ? 4096 : 1024);
+  // What a panel does is decided from sizes alone, so that nothing below can find itself outside the kernels' domain AFTER
+  // earlier panels have overwritten B (round 3 returned GPC_EUNSUPPORTED from inside the loop for an identity tile that
+  // straddles M above >= GPC_PANEL_INV_MINROWS dense rows; such a panel now takes the one-launch form):
+  //   0 = one launch over all participating rows;  1 = tile inverse, the identity's own tile in place;  2 = tile inverse from a scratch identity
+  auto plan = [&](int64_t k0, int64_t nbk) -> int {
+    const int64_t kend = k0 + nbk, cols_pad = ((nbk + 63) / 64) * 64;
+    const int64_t rows = identity_rows ? ((k0 + cols_pad < M) ? k0 + cols_pad : M) : M;
+    const int64_t dense = identity_rows ? ((k0 < M) ? k0 : M) : M;
+    if(!(panel_inverse_applies(dense, nbk) && nbk % 64 == 0)) return 0;
+    if(identity_rows && kend <= M) return 1;
+    if(identity_rows && rows > dense) return 0;
+    return 2;
+  };
   int64_t nbk = 0;
   for(int64_t k0 = 0; k0 < n; k0 += nbk) {
-    // (width: the launch's work is rows x nbk^2 at the dataflow blocks' rate, the product's 2 rows (n - kend) nbk at the chip's;
-    //  one launch for everything only while the whole problem is small)
-    const int64_t rem = n - k0, NB = nb_env >= 64 ? (nb_env / 64) * 64 : ((n <= 4096 && M <= 4096) ? 4096 : 1024);
+    const int64_t rem = n - k0;
     nbk = rem < NB ? rem : NB;
     const int64_t kend = k0 + nbk, cols_pad = ((nbk + 63) / 64) * 64;
     // rows that take part in this panel, and those of them that lie above the identity's own diagonal tile
@@ -783,23 +824,33 @@ int trsm_rlt_flow(int64_t M, int64_t n, const double* L, int64_t lda, double* B,
     const int64_t dense = identity_rows ? ((k0 < M) ? k0 : M) : M;
     if(rows <= 0) break;      // (identity rows: nothing of B reaches these columns)
     double* Bp = B + k0 * ldb;
-    if(panel_inverse_applies(dense, nbk) && nbk % 64 == 0) {
+    const double* G = L + k0 + k0 * lda;   // the factor's block at the panel's diagonal
+    int64_t ldg = lda, g_rows = n - k0;
+    if(inplace) {
+      GPC_HIP_CHECK(hipMemcpy2DAsync(inplace_tile, sizeof(double) * (size_t)nbk, G, sizeof(double) * (size_t)lda, sizeof(double) * (size_t)nbk,
+                                     (size_t)nbk, hipMemcpyDeviceToDevice, s));
+      GPC_CHECK(set_identity(nbk, nbk, Bp + k0, ldb, s));
+      G = inplace_tile;
+      ldg = nbk;
+      g_rows = nbk;
+    }
+    const int mode = plan(k0, nbk);
+    if(mode != 0) {
       void* wa = nullptr;
       GPC_CHECK(workspace(WS_AUG, sizeof(double) * (size_t)nbk * (size_t)nbk, &wa));
       double* Li = static_cast<double*>(wa);
       void* wt = nullptr;
       GPC_CHECK(workspace(WS_PANEL_TMP, sizeof(double) * (size_t)dense * (size_t)nbk, &wt));
       double* T = static_cast<double*>(wt);
-      if(identity_rows && kend <= M) {
+      if(mode == 1) {
         // the identity's own rows k0 .. kend-1 become L_bb^-T where they are; a copy of it serves the rows above
         double* Ebb = Bp + k0;
-        GPC_CHECK(panel_flow_given(nbk, nbk, Ebb, ldb, L + k0 + k0 * lda, lda, n - k0, nbk, 0, nbk, d_info, s));
+        GPC_CHECK(panel_flow_given(nbk, nbk, Ebb, ldb, G, ldg, g_rows, nbk, 0, nbk, d_info, s));
         GPC_HIP_CHECK(hipMemcpy2DAsync(Li, sizeof(double) * (size_t)nbk, Ebb, sizeof(double) * (size_t)ldb, sizeof(double) * (size_t)nbk,
                                        (size_t)nbk, hipMemcpyDeviceToDevice, s));
       } else {
-        if(identity_rows && rows > dense) return GPC_EUNSUPPORTED;   // (a partial identity tile above many dense rows: not worth a case)
         GPC_CHECK(set_identity(nbk, nbk, Li, nbk, s));
-        GPC_CHECK(panel_flow_given(nbk, nbk, Li, nbk, L + k0 + k0 * lda, lda, n - k0, nbk, 0, nbk, d_info, s));
+        GPC_CHECK(panel_flow_given(nbk, nbk, Li, nbk, G, ldg, g_rows, nbk, 0, nbk, d_info, s));
       }
       GPC_CHECK(transpose_inplace(nbk, Li, nbk, s));     // L_bb^-T (upper) -> L_bb^-1 (lower): the [n][k] operand
       GPC_HIP_CHECK(hipMemcpy2DAsync(T, sizeof(double) * (size_t)dense, Bp, sizeof(double) * (size_t)ldb, sizeof(double) * (size_t)dense,
@@ -807,11 +858,10 @@ int trsm_rlt_flow(int64_t M, int64_t n, const double* L, int64_t lda, double* B,
       KEndScope ke;
       GPC_CHECK(gemm(false, true, dense, nbk, nbk, 1.0, T, dense, Li, nbk, 0.0, Bp, ldb, 0, s));
     } else {
-      GPC_CHECK(panel_flow_given(rows, nbk, Bp, ldb, L + k0 + k0 * lda, lda, n - k0, nbk, identity_rows ? k0 / 64 : ((int64_t)1 << 24), nbk,
-                                 d_info, s));
+      GPC_CHECK(panel_flow_given(rows, nbk, Bp, ldb, G, ldg, g_rows, nbk, identity_rows ? k0 / 64 : ((int64_t)1 << 24), nbk, d_info, s));
     }
     if(kend < n) {
-      TrailingScope role;
+      SolveScope role;
       GPC_CHECK(gemm(false, true, rows, n - kend, nbk, -1.0, Bp, ldb, L + kend + k0 * lda, lda, 1.0, B + kend * ldb, ldb, 0, s));
     }
   }
@@ -1012,6 +1062,25 @@ extern "C" int gpc_set_potrf_blocking(int64_t nb_outer, int64_t jb_inner)
     return GPC_EINVAL;
   }
   gpc::g_nb_outer = nb_outer;   // fixed from now on (adaptive widths only when never set and GPC_NB is absent)
+  return GPC_OK;
+}
+
+// The panel schedule gpc_potrf_f64 walks for an N x N matrix (panel_width() by remaining columns): widths[i] = columns of
+// panel i, *count = number of panels (also when cap is too small: the caller can size its array from a first call).
+extern "C" int gpc_potrf_panel_schedule(int64_t N, int64_t* widths, int64_t cap, int64_t* count)
+{
+  if(N < 0 || !count || (cap > 0 && !widths)) {
+    gpc::set_error("gpc_potrf_panel_schedule: bad arguments");
+    return GPC_EINVAL;
+  }
+  int64_t n = 0, nbk = 0;
+  for(int64_t k0 = 0; k0 < N; k0 += nbk) {
+    const int64_t NB = gpc::panel_width(N - k0);
+    nbk = (N - k0 < NB) ? (N - k0) : NB;
+    if(n < cap) widths[n] = nbk;
+    n++;
+  }
+  *count = n;
   return GPC_OK;
 }
 

@@ -878,8 +878,99 @@ int set_identity(int64_t M, int64_t N, double* B, int64_t ldb, hipStream_t s)
   return GPC_OK;
 }
 
+// Vc (w rows, leading dimension ldv, wp >= w columns) := the upper triangle (with diagonal) of the w x w tile at T, zero elsewhere
+__global__ void __launch_bounds__(256) copy_upper_tile_kernel(const double* __restrict__ T, int64_t ldt, int64_t w, double* __restrict__ Vc,
+                                                              int64_t ldv)
+{
+  const int64_t j = blockIdx.y;            // 0 .. wp-1
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if(i < w) Vc[i + j * ldv] = (j < w && i <= j) ? T[i + j * ldt] : 0.0;
+}
+
+// dpotri IN PLACE (lapack.h:67-73, CMatrix.cpp:414-432: dtrtri + dlauum on the factor's own array) for the lower case, large N.
+// Scratch: three tiles of at most w x w (w <= 2048) plus what the panels' tile-inverse form copies aside (rows x 1024) -- O(N nb),
+// no N x N array.  Two phases, both made of the factorisation's own kernels:
+//   A. V = L^-T into the UPPER triangle (trsm_rlt_flow in place: the strictly upper part starts as zero = the identity's, a
+//      panel's diagonal tile is copied aside and becomes L_bb^-T; rank-1024 updates of the columns to the right).  N^3/3.
+//   B. lower(A) = V V' right-looking over column blocks of V (the transposed dlauum): with P = V(0:k0, blk), Vd = V(blk, blk)
+//      (upper triangular, copied aside because R(blk, blk) lands on the same tile),
+//          R(0:k0, 0:k0) += P P'     the Cholesky's trailing-update shape (same kernel instance, ROLE 3)
+//          R(blk, 0:k0)   = Vd P'    first (and only) touch of that row block: beta = 0 over L's dead entries; k >= row only
+//          R(blk, blk)    = Vd Vd'   lower part
+//      R's strictly lower tiles overwrite L (dead after phase A), its diagonal tiles' lower parts the zeros under V's
+//      diagonal tiles; the strictly upper tiles of V are only read.  N^3/3.
+//   C. mirror.
+// The first block of phase B takes the ragged width (N mod w), so that every product with a k-range inside the matrix has
+// K = w, a multiple of the kernel's stage depth.
+static int64_t potri_inplace_min()
+{
+  const char* e = getenv("GPC_POTRI_INPLACE_MINN");   // read per call (tests switch it): a getenv beside an O(N^3) call
+  return e ? atoll(e) : (int64_t)8193;
+}
+
+static int potri_inplace_lower(int64_t N, double* A, int64_t lda, hipStream_t s)
+{
+  if(N % 2 != 0 || lda % 2 != 0 || N < 2048) return GPC_EUNSUPPORTED;
+  static const int use_flow = [] { const char* e = getenv("GPC_TRSM_FLOW"); return e ? atoi(e) : 1; }();
+  if(!use_flow) return GPC_EUNSUPPORTED;   // (the launch chain's form of the solve is not in place)
+  const int64_t wenv = [] { const char* e = getenv("GPC_POTRI_LAUUM_NB"); return e ? atoll(e) : (int64_t)0; }();
+  const int64_t w = (wenv >= 128 && wenv <= 4096) ? (wenv / 128) * 128 : 1024;
+  const int64_t tmax = w > 1024 ? w : 1024;
+  void* ws = nullptr;
+  GPC_CHECK(workspace(WS_POTRI, sizeof(double) * (size_t)tmax * (size_t)tmax * 2, &ws));
+  double* tileA = static_cast<double*>(ws);                  // phase A: the panel's copy of L_bb (1024 x 1024)
+  double* Vc = tileA + (size_t)tmax * (size_t)tmax;          // phase B: copy of V's diagonal block (w x w)
+  void* wi = nullptr;
+  GPC_CHECK(workspace(WS_INFO, 64, &wi));
+  int* d_info = static_cast<int*>(wi);
+  GPC_HIP_CHECK(hipMemsetAsync(d_info, 0, sizeof(int), s));
+  // applicability is decided before anything is written (trsm_rlt_flow returns GPC_EUNSUPPORTED up front or not at all), but the
+  // zeroing has to come first: do the same checks here
+  GPC_CHECK(zero_triangle(false, N, A, lda, s));     // the identity's strictly upper part (the old upper triangle is dead: dpotri + mirror)
+  {
+    const int rc = trsm_rlt_flow(N, N, A, lda, A, lda, true, d_info, s, tileA);
+    if(rc != GPC_OK) return rc;   // GPC_EUNSUPPORTED: nothing but the (dead) upper triangle was touched
+    int mark = 0;
+    HostFetch f;
+    GPC_CHECK(f.add(&mark, d_info, sizeof(int), s));
+    GPC_CHECK(f.finish(s));
+    if(mark == PANEL_FLOW_TIMEOUT) {
+      GPC_HIP_CHECK(hipMemsetAsync(d_info, 0, sizeof(int), s));
+      set_error("a dataflow launch of the in-place dpotri timed out (device shared or pre-empted?); the factor is partly overwritten -- "
+                "repeat the call on a fresh factor");
+      return GPC_EHIP;
+    }
+  }
+  const int64_t w0 = N - ((N - 1) / w) * w;   // first block: 1 .. w columns, the others w
+  for(int64_t k0 = 0; k0 < N;) {
+    const int64_t wk = (k0 == 0) ? w0 : w, kend = k0 + wk;
+    const int64_t wp = (wk + 15) & ~(int64_t)15;
+    double* Akk = A + k0 + k0 * lda;
+    hipLaunchKernelGGL(copy_upper_tile_kernel, dim3((unsigned)((wk + 255) / 256), (unsigned)wp), dim3(256), 0, s, Akk, lda, wk, Vc, wk);
+    GPC_HIP_CHECK(hipGetLastError());
+    if(k0 > 0) {
+      const double* P = A + k0 * lda;     // V(0:k0, blk)
+      {
+        SolveScope role;
+        GPC_CHECK(gemm(false, true, k0, k0, wk, 1.0, P, lda, P, lda, 1.0, A, lda, 1, s));
+      }
+      KStartScope ks;   // Vd(m, k) = 0 for k < m
+      GPC_CHECK(gemm(false, true, wk, k0, wp, 1.0, Vc, wk, P, lda, 0.0, A + k0, lda, 0, s));
+    }
+    {
+      KStartScope ks;
+      GPC_CHECK(gemm(false, true, wk, wk, wp, 1.0, Vc, wk, Vc, wk, 0.0, Akk, lda, 1, s));
+    }
+    k0 = kend;
+  }
+  GPC_CHECK(symmetrize(true, N, A, lda, s));
+  return GPC_OK;
+}
+
 // A (factor in triangle uplo) -> full symmetric inverse of the factored matrix, in place (dpotri + mirror).
 //   lower: K^-1 = L^-T L^-1 = V V' with V = L^-T (upper triangular).
+// From N = GPC_POTRI_INPLACE_MINN (default 8193) on, even N: in place, O(N nb) scratch (potri_inplace_lower above).  Smaller
+// problems -- launch-bound, one or a few dataflow launches -- keep the form with V in a scratch array of N x N <= 512 MB:
 //   1. V := I * L^-T by the right-side solve (side R, lower, transposed): its rank-512 updates X_b * L(rest, b)' are in
 //      the NT form of the fast GEMM kernel, and the identity right-hand side keeps the work at N^3/3 (tri_rhs);
 //   2. lower(A) := V V' with the same kernel, every tile starting its k-loop at its own first row (V(i,k) = 0 for
@@ -889,6 +980,10 @@ int potri_full(bool lower, int64_t N, double* A, int64_t lda, hipStream_t s)
 {
   if(N <= 0) return GPC_OK;
   if(!lower) GPC_CHECK(transpose_inplace(N, A, lda, s));
+  if(N >= potri_inplace_min()) {
+    const int rc = potri_inplace_lower(N, A, lda, s);
+    if(rc != GPC_EUNSUPPORTED) return rc;
+  }
   // W is N x Np, Np = N rounded up to whole 64-column blocks (a multiple of the GEMM kernel's k-step, and what the dataflow
   // launches of trtri_flow write): the extra columns stay zero, so the product over Np columns is the product over N
   const int64_t Np = (N + 63) & ~(int64_t)63;

@@ -120,6 +120,24 @@ class Grid(object):
         return {"bytes_row": out[0], "bytes_col": out[1], "bytes_world": out[2], "collectives": int(out[3]),
                 "update_flops": out[4], "update_launches": int(out[5]), "update_bytes": out[6], "bytes_held": out[7]}
 
+    def comm_info(self):
+        """what the transport reports about itself: communicator sizes by axis, kind, exchange form, this rank"""
+        out = (c_int64 * 8)()
+        self.b.check(self.b.comm_info(self.h, out), self.h)
+        kinds = {0: "single", 1: "rccl", 2: "local-board", 3: "callbacks"}
+        return {"row": int(out[0]), "col": int(out[1]), "world": int(out[2]), "kind": kinds.get(int(out[3]), "?"),
+                "exchange": "collective" if int(out[4]) else "fanout", "rank": int(out[5])}
+
+    def set_exchange(self, mode):
+        """'fanout' (grouped pairwise send / recv) or 'collective' (one broadcast per root); every rank the same"""
+        self.b.check(self.b.set_exchange(self.h, {"fanout": 0, "collective": 1}[mode]), self.h)
+
+    def exchange_probe(self, axis, count, reps=5):
+        """ms per in-place all-gather of `count` doubles per member along `axis` (collective over that group)"""
+        ms = c_double(0.0)
+        self.b.check(self.b.exchange_probe(self.h, int(axis), int(count), int(reps), byref(ms)), self.h)
+        return ms.value
+
     def set_lookahead(self, on):
         self.b.check(self.b.set_lookahead(self.h, int(on)), self.h)   # 0 off, 1 on, 2 on with the free-running order
 

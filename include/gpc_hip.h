@@ -232,6 +232,19 @@ int gpc_grid_info(gpc_grid* g, int64_t* out);
  * trailing updates, their launches, their algorithmic HBM bytes -- since the last reset -- and out[7] = the device bytes this
  * rank's problem holds (local block, panel buffers, and the gradient's replicated factor once gpc_grid_gradient has run) */
 int gpc_grid_stats(gpc_grid* g, double* out, int reset);
+/* What the transport reports about itself: out[0..2] = members of the process-row / process-column / world communicator as the
+ * TRANSPORT counts them (RCCL: ncclCommCount of the communicators the exchanges run on; 0 = a group of one has none),
+ * out[3] = kind (0 single rank, 1 RCCL, 2 in-process board, 3 caller's callbacks), out[4] = exchange form (0 pairwise
+ * ncclSend / ncclRecv, 1 one ncclBroadcast per root), out[5] = this rank.  bench.py prints out[2] as grid.rccl_nranks. */
+int gpc_grid_comm_info(gpc_grid* g, int64_t* out);
+/* The form in which panels leave their root on an RCCL grid: 0 = grouped pairwise sends (default; every pair of GPUs has its
+ * own xGMI link), 1 = ncclBroadcast per root.  Same effect as env GPC_GRID_EXCHANGE=fanout / collective at creation, but
+ * switchable on a live grid (bench.py times both before the timed steps).  Collective in effect: every rank must set the same. */
+int gpc_grid_set_exchange(gpc_grid* g, int mode);
+/* One panel-sized exchange, timed on the node itself: every member of the axis group (0 row, 1 column, 2 world) contributes
+ * `count` doubles to the in-place all-gather the factorisation uses for its column panel; *ms = wall time per exchange
+ * (average of `reps` after one untimed round).  Collective over the axis group. */
+int gpc_grid_exchange_probe(gpc_grid* g, int axis, int64_t count, int reps, double* ms);
 /* tests: tile (I, J) of the factor to the host (nb x nb, leading dimension nb; I == T addresses the extra rows);
  * *owned = 0 and nothing copied when the tile lives on another rank */
 int gpc_grid_copy_tile(gpc_grid* g, int64_t I, int64_t J, double* host, int* owned);
@@ -334,12 +347,19 @@ int gpc_probe_mfma_f64(double* tflops, double* cycles_per_mfma_per_simd, double*
 int gpc_debug_panel_flow_trace(long long* out, int64_t n);
 
 /* ---- tuning knobs (also read from env GPC_NB / GPC_JB on first use) ---------------------------------------------- */
-/* Outer panel width of gpc_potrf_f64.  Unset (and no GPC_NB), the width follows the remaining columns: 1024, 2048 once <= 8192
- * columns are left, and the last <= 4096 columns as one dataflow launch (panel_flow.hip; env GPC_PANEL_FLOW=0 switches that
- * kernel off, GPC_PANEL_FLOW_MAXROWS sets the tallest panel it takes, default 24576). */
+/* Outer panel width of gpc_potrf_f64.  Unset (and no GPC_NB), the width follows the remaining columns (potrf.hip
+ * panel_width()): 1024 while more than 8192 columns are left, 1024-1664 down to 4096 (whatever leaves the trailing update a
+ * full last round of tiles) and the last <= 4096 columns as one dataflow launch.  Every panel is one launch of the dataflow
+ * kernel (panel_flow.hip; panels with >= 12 288 rows below the tile factor [tile; I] and take the rows as one product);
+ * env GPC_PANEL_FLOW=0 switches to the launch chain, GPC_PANEL_FLOW_MAXROWS bounds the panel height the kernel takes. */
 int gpc_set_potrf_blocking(int64_t nb_outer, int64_t jb_inner);   /* nb_outer = 0: back to the default policy */
+/* The schedule that policy produces for an N x N matrix: widths[i] = columns of panel i (at most cap of them are written),
+ * *count = number of panels.  bench.py prices the trailing updates' algorithmic bytes from it. */
+int gpc_potrf_panel_schedule(int64_t N, int64_t* widths, int64_t cap, int64_t* count);
 /* Look-ahead of depth 1 in gpc_potrf_f64 (panel k+1 on a second, high-priority HIP stream while the trailing update
- * of panel k runs); on by default, env GPC_LOOKAHEAD=0 or this call turn it off. */
+ * of panel k runs).  OFF by default since the trailing update loads its operands two stages ahead (it fills every CU's
+ * register file, so a panel kernel beside it cannot start: DESIGN.md 3.2); env GPC_LOOKAHEAD=1 or this call turn it on,
+ * GPC_GEMM_PF2=0 restores the by-size rule (on from N = 28 672) together with the one-stage-ahead update. */
 int gpc_set_potrf_lookahead(int on);
 /* GEMM kernel variant for the A*B^T shapes: 0 generic, 1 fast 4-wave, 2 fast 8-wave (default; env GPC_GEMM_VARIANT). */
 int gpc_set_gemm_variant(int variant);

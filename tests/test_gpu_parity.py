@@ -42,7 +42,10 @@ def spd(n, seed, cond_shift=1.0):
 
 @pytest.mark.parametrize("ta,tb", [("N", "N"), ("N", "T"), ("T", "N"), ("T", "T")])
 @pytest.mark.parametrize("M,N,K", [(128, 128, 16), (256, 384, 64), (37, 53, 29), (300, 1, 64), (129, 130, 131),
-                                   (1, 1, 1), (64, 200, 0)])
+                                   (1, 1, 1), (64, 200, 0),
+                                   # K % 16 == 0: the fast kernel in all four forms (round 4), ragged tile edges, single rows / columns
+                                   (300, 202, 48), (129, 131, 32), (1000, 66, 1024), (130, 2, 16), (2, 130, 16), (1, 5, 16), (5, 1, 160),
+                                   (770, 515, 272)])
 def test_gemm_vs_numpy(api, ta, tb, M, N, K):
     rng = np.random.RandomState(M * 7 + N * 3 + K)
     A = rng.randn(*((M, K) if ta == "N" else (K, M)))
@@ -210,6 +213,42 @@ def test_potri_vs_numpy(api, N, uplo):
     out = api.to_host(Ad)
     assert rel(out, np.linalg.inv(A)) < 1e-10
     assert np.array_equal(out, out.T)
+
+
+@pytest.mark.parametrize("N,uplo,w", [(2048, "L", 0), (2050, "L", 0), (3000, "U", 0), (4098, "L", 512), (5000, "L", 2048), (9216, "L", 0),
+                                      (12544, "U", 0), (13000, "L", 2048), (16390, "L", 0)])
+def test_potri_in_place(api, monkeypatch, N, uplo, w):
+    """dpotri in place on the factor (lapack.h:67-73, CMatrix.cpp:414-432): V = L^-T into the upper triangle, lower(V V') over L,
+    scratch O(N nb).  Forced on from N = 2048 (default: from 8193), ragged sizes, both triangles, three block widths of the
+    second phase; the result against numpy's inverse and against the N x N-scratch form of the same library, and the device
+    memory the call takes."""
+    import torch
+    rng = np.random.RandomState(N)
+    B = rng.randn(N, N // 2)
+    K = B @ B.T / (N // 2) + np.diag(0.5 + rng.rand(N))
+    Kd = api.from_host(K)
+    assert api.potrf(Kd, uplo) == 0
+    F = Kd.clone()
+    api.lib().gpc_workspace_release()
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info()
+    monkeypatch.setenv("GPC_POTRI_INPLACE_MINN", "2048")
+    if w:
+        monkeypatch.setenv("GPC_POTRI_LAUUM_NB", str(w))
+    api.potri(Kd, uplo)
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info()
+    out = api.to_host(Kd)
+    assert np.array_equal(out, out.T)
+    assert np.abs(out @ K - np.eye(N)).max() < 1e-9
+    # scratch: two tiles of max(w, 1024)^2, the exchange buffer of a 1024-column dataflow launch and the rows x 1024 copy of the
+    # tile-inverse panels -- far below one N x N array from N = 9216 on
+    if N >= 9216:
+        assert free0 - free1 < 0.5 * 8 * N * N, "in-place dpotri took %.0f MB of scratch" % ((free0 - free1) / 2.0 ** 20)
+    monkeypatch.setenv("GPC_POTRI_INPLACE_MINN", str(1 << 40))
+    api.potri(F, uplo)
+    ref = api.to_host(F)
+    assert np.abs(out - ref).max() <= 1e-11 * np.abs(ref).max()
 
 
 # ---- TRSM ------------------------------------------------------------------------------------------------------------------
@@ -791,12 +830,16 @@ def test_cfg4_full_size_properties(api):
         worst = max(worst, float((rows @ alpha - m[i0:i0 + step]).abs().max()))
         del rows
     assert worst < 1e-9 * max(1.0, float(alpha.abs().max()))
-    # CMatrix::pdinv (dpotri, CMatrix.cpp:414-432) at this size: in place on the factor -- there is room for the factor and
-    # dpotri's one N x N workspace (2 x 128 GiB), not for a copy beside them -- then K (K^-1 e_j) = e_j with K one row block at a time
+    # CMatrix::pdinv (dpotri, CMatrix.cpp:414-432) at this size: in place on the factor, O(N nb) scratch (round 4; until then one
+    # N x N workspace beside it) -- then K (K^-1 e_j) = e_j with K one row block at a time
     del Kcols, col, alpha
     torch.cuda.empty_cache()
+    api.lib().gpc_workspace_release()
     api.potri(L, "L")
     inv = L
+    free_b, total_b = torch.cuda.mem_get_info()
+    assert total_b - free_b <= 2 * 8 * N * N, "dpotri at cfg 4 holds %.1f GiB (two N x N arrays are %.1f)" % (
+        (total_b - free_b) / 2.0 ** 30, 2 * 8 * N * N / 2.0 ** 30)
     assert torch.equal(inv[tidx, :], inv[:, tidx].t())
     cols = [0, 777, 100000, N - 1]
     V = inv[:, torch.tensor(cols, device="cuda")].clone()

@@ -210,6 +210,36 @@ def test_more_ranks_than_tiles(hb):
     _check(_solve_local(hb, 2, 4, 128, gc.TERMS, X, Y, None), exp, 200, 128, None)
 
 
+@pytest.mark.parametrize("pr,pc", [(1, 1), (2, 1), (2, 2), (4, 2)])
+def test_comm_info_exchange_switch_and_link_probe(hb, pr, pc):
+    """gpc_grid_comm_info / set_exchange / exchange_probe (what bench.py's N > 1 line reports as grid.transport, rccl_nranks and
+    link_probe) on thread ranks: the board reports its group sizes, the exchange form can be switched on a live grid without
+    changing a bit of the factor, and the probe's all-gather completes on every axis."""
+    X, Y, _ = gc.make_problem(520, 3, 1, 0, 5)
+    grids = grid.create_local(pr, pc, 128, binding=hb)
+
+    def work(g, rank):
+        ci = g.comm_info()
+        g.set_problem(gc.TERMS, X, Y, None)
+        a = g.update_k()
+        g.set_exchange("collective")
+        b = g.update_k()
+        g.set_exchange("fanout")
+        ms = [g.exchange_probe(ax, 1000, 2) for ax in (grid.AXIS_ROW, grid.AXIS_COL, grid.AXIS_WORLD)]
+        return ci, a, b, ms
+
+    try:
+        res = grid.run_local(grids, work)
+    finally:
+        for g in grids:
+            g.destroy()
+    for rank, (ci, a, b, ms) in enumerate(res):
+        assert ci["rank"] == rank and ci["kind"] == ("single" if pr * pc == 1 else "local-board")
+        assert (ci["row"], ci["col"], ci["world"]) == (pc, pr, pr * pc)
+        assert a == b and a[2] == 0
+        assert all(m >= 0.0 for m in ms)
+
+
 def test_lookahead_off_gives_the_same_bits(hb):
     X, Y, Xs = gc.make_problem(640, 3, 1, 4, 11)
     a = _solve_local(hb, 2, 2, 128, gc.TERMS, X, Y, Xs, lookahead=True)

@@ -309,15 +309,24 @@ def test_bench_multi_rank_control_flow_rehearsal():
     assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["value"] > 0
     assert "REHEARSAL" in line["config"]["parallelism"] and "2 x 1" in line["config"]["parallelism"]
     assert line["roofline"]["achieved"] > 0 and line["grid"]["rank0_collectives_per_step"] > 0
-    assert line["grid"]["shape"] == "2x1" and line["grid"]["rows_reflected"] is True
-    # four ranks: the two candidate layouts (4 x 1 and 2 x 2) are both checked and timed before the timed steps
+    cal = line["grid"]["calibration"]
+    assert sorted((c["grid"], c["exchange"]) for c in cal) == sorted((g, e) for g in ("2x1", "1x2") for e in ("fanout", "collective"))
+    assert line["grid"]["shape"] == min(cal, key=lambda c: c["ms"])["grid"]
+    assert line["grid"]["rows_reflected"] is (line["grid"]["shape"] == "2x1")
+    assert line["grid"]["transport"] == "callbacks" and line["grid"]["rccl_nranks"] is None     # a rehearsal is not RCCL, and says so
+    lp = line["grid"]["link_probe"]
+    assert lp["members"] == 2 and all(f["ms"] > 0 and f["GBs_per_link_per_direction"] > 0 for f in lp["forms"].values())
+    # four ranks: every factorisation of the world size (4 x 1, 2 x 2, 1 x 4) x both exchange forms is self-checked and timed
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--workload", "cfg2", "--steps", "1",
                         "--warmup", "1", "--no-cpu-baseline"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
     assert r.returncode == 0, r.stderr.decode()[-2000:]
     line = json.loads(r.stdout.decode().strip().splitlines()[-1])
     cal = line["grid"]["calibration"]
-    assert [c["grid"] for c in cal] == ["4x1", "2x2"] and all(c["ms"] > 0 for c in cal)
-    assert line["grid"]["shape"] == min(cal, key=lambda c: c["ms"])["grid"]
+    assert sorted((c["grid"], c["exchange"]) for c in cal) == sorted((g, e) for g in ("4x1", "2x2", "1x4")
+                                                                     for e in ("fanout", "collective"))
+    assert all(c["selfcheck"] and c["ms"] > 0 for c in cal)
+    fastest = min(cal, key=lambda c: c["ms"])
+    assert line["grid"]["shape"] == fastest["grid"] and line["grid"]["exchange"] == fastest["exchange"]
     # without the rehearsal switch the second rank has no GPU of its own: the run must refuse, not degrade
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "cfg2", "--steps", "1",
                         "--warmup", "0", "--no-cpu-baseline"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
@@ -343,8 +352,12 @@ def test_bench_two_ranks_over_real_rccl():
         assert r.returncode == 0, r.stderr.decode()[-3000:]
         line = json.loads(r.stdout.decode().strip().splitlines()[-1])
         assert line["n_gpus"] == 2 and line["value"] > 0 and "REHEARSAL" not in line["config"]["parallelism"]
-        assert line["grid"]["shape"] == "2x1" and line["grid"]["exchange"] == exchange
-        assert line["grid"]["rank0_bytes_received_per_step"]["along_column"] > 0
+        assert line["grid"]["shape"] in ("2x1", "1x2") and line["grid"]["exchange"] == exchange
+        assert {c["grid"] for c in line["grid"]["calibration"]} == {"2x1", "1x2"}
+        recv = line["grid"]["rank0_bytes_received_per_step"]
+        assert recv["along_column"] + recv["along_row"] > 0
+        assert line["grid"]["transport"] == "rccl" and line["grid"]["rccl_nranks"] == 2      # ncclCommCount of the world communicator
+        assert line["grid"]["link_probe"]["forms"][exchange]["GBs_per_link_per_direction"] > 1.0
     n = torch.cuda.device_count()
     if n >= 4:      # and the widest power of two the box has, with both layouts calibrated
         w = 8 if n >= 8 else 4
@@ -352,7 +365,10 @@ def test_bench_two_ranks_over_real_rccl():
                             "--warmup", "1", "--no-cpu-baseline"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1200)
         assert r.returncode == 0, r.stderr.decode()[-3000:]
         line = json.loads(r.stdout.decode().strip().splitlines()[-1])
-        assert line["n_gpus"] == w and line["value"] > 0 and len(line["grid"]["calibration"]) == 2
+        assert line["n_gpus"] == w and line["value"] > 0 and line["grid"]["rccl_nranks"] == w
+        shapes = {"%dx%d" % (p, w // p) for p in range(1, w + 1) if w % p == 0}
+        assert {(c["grid"], c["exchange"]) for c in line["grid"]["calibration"]} == {(g, e) for g in shapes for e in ("fanout", "collective")}
+        assert set(line["grid"]["link_probe"]["forms"]) == {"fanout", "collective"}
 
 
 def test_tall_shares_take_the_tile_inverse_form_without_staging():

@@ -103,6 +103,36 @@ def test_cgp_on_a_multi_gpu_grid(tmp_path, shape):
 
 
 @pytest.mark.gpu
+def test_cgp_grid_on_distinct_devices(tmp_path):
+    """The path `gp learn` takes to several GPUs: the C++ CGp's in-process grid (gpc_grid_create_local: one host thread per
+    rank, LocalComm peer-to-peer copies, cross-device event waits) with every rank on a device OF ITS OWN -- no
+    GPC_GRID_DEVICES=same.  2 x 1 and 1 x 2 on two GPUs; 2 x 2 and 4 x 1 from four; 8 x 1, 4 x 2 and 2 x 4 on eight.  Against the
+    single-GPU model and the compiled reference's golden of cfg 4's kernel.  Needs >= 2 GPUs; skips (with the reason) otherwise."""
+    import torch
+    n = torch.cuda.device_count()
+    if n < 2:
+        pytest.skip("needs >= 2 GPUs: the in-process grid's peer copies between distinct devices (box has %d)" % n)
+    from gpc_amd import synth
+    g = dict(np.load(os.path.join(GOLDEN, "synth_cfg4_1024.npz")))
+    X, y = synth.make_xy(1024, 16, 1234)
+    _write_txt(tmp_path / "X.txt", X)
+    _write_txt(tmp_path / "y.txt", y)
+    _write_txt(tmp_path / "Xs.txt", g["Xstar"])
+    args = [str(tmp_path / "X.txt"), str(tmp_path / "y.txt"), str(tmp_path / "Xs.txt"), "rbf:1,1"]
+    one = _parse(_run([os.path.join(HOST, "gp_hosttest"), "gp"] + args + ["exact"]))
+    shapes = ["2x1", "1x2"] + (["2x2", "4x1"] if n >= 4 else []) + (["8x1", "4x2", "2x4"] if n >= 8 else [])
+    for shape in shapes:
+        env = dict(os.environ, GPC_GRID=shape, GPC_GRID_NB="128")
+        env.pop("GPC_GRID_DEVICES", None)
+        v = _parse(_run([os.path.join(HOST, "gp_hosttest"), "gpgrid"] + args, env=env))
+        assert rel(v["ll"], g["ll"]) < 1e-8 and rel(v["logdet"], g["logdet"]) < 1e-8, shape
+        assert rel(v["ll"], one["ll"]) < 1e-10 and rel(v["logdet"], one["logdet"]) < 1e-10, shape
+        assert rel(v["mu"], one["mu"]) < 1e-8 and rel(v["var"], one["var"]) < 1e-8, shape
+        assert rel(v["grads"], one["grads"]) < 1e-8 and rel(v["grads"], g["grads"]) < 1e-8, shape
+        assert rel(v["ll_after_predict"], one["ll"]) < 1e-10 and rel(v["ll_roundtrip"], one["ll"]) < 1e-10, shape
+
+
+@pytest.mark.gpu
 def test_gp_learn_on_a_grid_follows_the_single_gpu_run(tmp_path):
     """15 SCG iterations with every likelihood / gradient evaluation on a 2 x 2 grid end where the single-GPU model ends."""
     from gpc_amd import synth

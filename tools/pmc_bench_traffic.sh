@@ -7,6 +7,9 @@ export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/profiles_$TAG
 mkdir -p $OUT; cd /tmp
+# GPC_BENCH_PHASES=0: nothing but the timed steps runs, so the dispatches named gemm_nt_fast_kernel<4, 1, ...> are exactly the
+# trailing updates of ONE factor (the phases' dpotri uses the same instance under role 0 since round 4, but keep them out anyway)
+export GPC_BENCH_PHASES=0
 CMD="python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline"
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmcb_$c
@@ -15,7 +18,7 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 python - $OUT/pmc_bench_traffic.json <<'PY'
 import sqlite3, glob, json, sys, collections
-res = {"command": "rocprofv3 --pmc <C> -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline  (C = FETCH_SIZE, WRITE_SIZE; separate passes)",
+res = {"command": "GPC_BENCH_PHASES=0 rocprofv3 --pmc <C> -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline  (C = FETCH_SIZE, WRITE_SIZE; separate passes)",
        "kernel": "gemm_nt_fast_kernel<4, 1, false, true> (the trailing-update launches only: the two-stage-ahead instance)", "units": "counter values are KB summed over the 8 XCDs per dispatch"}
 def collect(pattern):
     out = {}
