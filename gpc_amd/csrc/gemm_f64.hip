@@ -28,6 +28,7 @@ namespace gpc {
 
 thread_local int g_gemm_trailing = 0;  // TrailingScope (gpc_common.hpp); per host thread
 thread_local int g_gemm_kstart = 0;    // KStartScope (gpc_common.hpp)
+thread_local int64_t g_gemm_kstart_off = 0;
 thread_local int g_gemm_kend = 0;      // KEndScope
 int g_gemm_variant = -1;  // -1: read GPC_GEMM_VARIANT on first use; 0 generic only; 1 fast 4-wave; 2 fast 8-wave
 
@@ -58,6 +59,7 @@ struct GemmArgs {
   int debug_same_rows;   // ablation knob (env GPC_GEMM_DEBUG_SAMEROWS): never set in production
   int kstart;            // fast NT kernel only: the A operand is upper triangular / trapezoidal (A(m, k) = 0 for k < m; in the
                          // square products V V' so is B): a tile's k-loop starts at its first row m0 (everything left of it is zero)
+  int64_t kstart_off;    // ... A(m, k) = 0 for k < m - kstart_off (the operand's triangle starts kstart_off rows down)
   int trap_deal;         // tri 3: super-tiles dealt round-robin to the XCDs (GPC_GEMM_TRAP_DEAL=0: contiguous chunks, as before)
   int kend;              // fast NT kernel only: B (N x K, N == K) is lower triangular, so the k-loop of tile column n0 stops at
                          // n0 + 128 (the rows of a tall panel times the inverse of its diagonal tile, potrf.hip)
@@ -436,7 +438,7 @@ __global__ void __launch_bounds__(128 * NWN, NWN) gemm_nt_fast_kernel(const Gemm
   if(rb > rbmax) rb = rbmax;
   if(rb < 0) rb = 0;
   // upper-triangular operands (potri's V V'): rows >= m0 of A are zero left of column m0, so the product starts there
-  int64_t kfirst = g.kstart ? (m0 / BK) * BK : 0;
+  int64_t kfirst = (g.kstart && m0 > g.kstart_off) ? ((m0 - g.kstart_off) / BK) * BK : 0;
   int64_t KT = ((g.kend && n0 + BN < g.K ? n0 + BN : g.K) - kfirst) / BK;
   if(SPLITK) {
     const int64_t per = (KT + g.ksplit - 1) / g.ksplit, kt0 = (int64_t)split * per;
@@ -458,7 +460,7 @@ __global__ void __launch_bounds__(128 * NWN, NWN) gemm_nt_fast_kernel(const Gemm
     if(r0 > g.M - 2) r0 = g.M - 2;
     if(r0 < 0) r0 = 0;
     pa = g.A + 2 * (t & 7) + r0 * g.lda;
-    stepa = g.M > 1 ? g.lda : 0;
+    stepa = g.lda;
     stagea = BK;
   }
   if(B_KC) {
@@ -466,7 +468,7 @@ __global__ void __launch_bounds__(128 * NWN, NWN) gemm_nt_fast_kernel(const Gemm
     if(r0 > g.N - 2) r0 = g.N - 2;
     if(r0 < 0) r0 = 0;
     pb = g.B + 2 * (t & 7) + r0 * g.ldb;
-    stepb = g.N > 1 ? g.ldb : 0;
+    stepb = g.ldb;
     stageb = BK;
   }
   const int lwa = A_KC ? lds_wk : lds_w, lwb = B_KC ? lds_wk : lds_w;
@@ -774,7 +776,9 @@ static int gemm_ex(bool transa, bool transb, int64_t M, int64_t N, int64_t K, do
   g.part_stride = 0;
   // KStartScope: A(m, k) = 0 for k < m (an upper-triangular / upper-trapezoidal left operand).  Square lower products (V V')
   // and plain ones whose C is full (dpotri in place: R(blk, 0:k0) = Vd P')
-  g.kstart = (g_gemm_kstart && !transa && transb && K >= M && ((tri == 1 && M == N) || tri == 0)) ? 1 : 0;
+  // or a lower trapezoid whose operand rows from `off` on form the triangle (dpotri in place: [P; Vd] [P; Vd]')
+  g.kstart_off = g_gemm_kstart_off;
+  g.kstart = (g_gemm_kstart && !transa && transb && K + g.kstart_off >= M && ((tri == 1 && M == N) || tri == 0 || tri == 3)) ? 1 : 0;
   g.kend = (g_gemm_kend && !transa && transb && N == K && tri == 0) ? 1 : 0;
   {
     static int deal = -1;
@@ -872,14 +876,16 @@ static int gemm_ex(bool transa, bool transb, int64_t M, int64_t N, int64_t K, do
     if(g_gemm_variant < 0 || g_gemm_variant > 2) g_gemm_variant = 2;
   }
   if(tri == 5) return g_gemm_variant == 1 ? launch_fast<2>(g, grid, s) : launch_fast<4>(g, grid, s);
-  // NN / TN / TT (round 4): the fast kernel with the k-contiguous operand(s) staged by rows.  An m-contiguous operand still
-  // wants an even row count (its threads load row pairs); a k-contiguous one has no such need.
+  // NN / TN / TT (round 4): the fast kernel with the k-contiguous operand(s) staged by rows.  Even M and N as for NT: a thread
+  // stages a PAIR of operand rows either way (one clamp per pair keeps the distance between its two loads uniform); odd sizes
+  // and k-ranges that are not whole stages stay on the generic kernel below.
   static const int fast_kc = [] { const char* e = getenv("GPC_GEMM_FAST_KC"); return e ? atoi(e) : 1; }();
-  if(fast_kc && g_gemm_variant == 2 && (a_kc || b_kc) && vec && g.K > 0 && (g.K % BK) == 0 && (a_kc || (M % 2) == 0) &&
-     (b_kc || (N % 2) == 0) && (tri == 0 || tri == 1 || tri == 2 || tri == 3)) {
+  if(fast_kc && g_gemm_variant == 2 && (a_kc || b_kc) && vec && g.K > 0 && (g.K % BK) == 0 && (M % 2) == 0 && (N % 2) == 0 &&
+     (tri == 0 || tri == 1 || tri == 2 || tri == 3)) {
     g.kstart = g.kend = 0;
     // operands two stages ahead (GPC_GEMM_KC_PF2, default by form): the row-staged instances sit at the 128-register limit of
-    // four waves per SIMD, the TN one over it (24 spilled registers)
+    // four waves per SIMD, the TN one over it (24 spilled registers: 65.5 TFLOP/s at M = N = K = 8192 against 68.7 one stage
+    // ahead; NN 71.6 / 69.9, TT 70.9 / 70.6 two / one stage ahead -- the generic kernel they replace: 64)
     static const int kc_pf2 = [] { const char* e = getenv("GPC_GEMM_KC_PF2"); return e ? atoi(e) : -1; }();
     if(a_kc && b_kc) return (kc_pf2 > 0) ? launch_fast_kc<true, true, true>(g, grid, s) : launch_fast_kc<true, true, false>(g, grid, s);
     if(a_kc) return (kc_pf2 != 0) ? launch_fast_kc<true, false, true>(g, grid, s) : launch_fast_kc<true, false, false>(g, grid, s);

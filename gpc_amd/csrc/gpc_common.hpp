@@ -123,9 +123,10 @@ struct KEndScope {
   ~KEndScope() { g_gemm_kend = 0; }
 };
 extern thread_local int g_gemm_kstart;
+extern thread_local int64_t g_gemm_kstart_off;   // ... A(m, k) = 0 for k < m - off: the triangle starts `off` rows down (a trapezoid)
 struct KStartScope {
-  KStartScope() { g_gemm_kstart = 1; }
-  ~KStartScope() { g_gemm_kstart = 0; }
+  explicit KStartScope(int64_t off = 0) { g_gemm_kstart = 1; g_gemm_kstart_off = off; }
+  ~KStartScope() { g_gemm_kstart = 0; g_gemm_kstart_off = 0; }
 };
 // col0: global index of A's first column, added to the `info` a failing pivot reports
 int potrf_lower(int64_t N, double* A, int64_t lda, int* d_info, hipStream_t s, int64_t col0 = 0);
@@ -182,6 +183,12 @@ struct KSpecDev {
 int collapse_kspec(const gpc_kspec* ks, int64_t D, KSpecDev* out);
 // a compound with more terms than one pass holds, cut into specs of at most max_rbf rbf / max_ard rbfard terms (gram.hip)
 int split_kspec(const gpc_kspec* ks, int max_rbf, int max_ard, std::vector<gpc_kspec>* chunks, std::vector<std::vector<int>>* where);
+
+// pair_walk.hip: the full-matrix passes (dL/dX, cross-Gram parameter sums) on an MFMA walk; GPC_EUNSUPPORTED outside their domain
+int pair_walk_gradx(const gpc_kspec* ksp, const double* X, int64_t N, int64_t ldx, const double* X2, int64_t N2, int64_t ldx2,
+                    int64_t D, const double* G, int64_t ldg, double* gX, int64_t ldgx, double pair_factor, hipStream_t s);
+int pair_walk_grad_cross(const KSpecDev& ks, const double* X, int64_t N, int64_t ldx, const double* X2, int64_t N2, int64_t ldx2,
+                         int64_t D, const double* G, int64_t ldg, double* S, hipStream_t s);
 
 // Optional HIP-event instrumentation of the dominant launches (bench.py's roofline leg; off by default).
 enum ProfKind { PROF_SYRK = 0, PROF_GRAM = 1, PROF_NKINDS = 2 };

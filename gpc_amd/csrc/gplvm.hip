@@ -294,6 +294,11 @@ static int launch_gradx_pass(const gpc_kspec* ksp, const double* X, int64_t N, i
     return GPC_EUNSUPPORTED;
   }
   if(N == 0 || D == 0) return GPC_OK;
+  // large enough, D <= 32: the MFMA walk of pair_walk.hip (round 4; 0.65-0.86 -> TB/s figures in DESIGN.md section 3)
+  {
+    const int rc = pair_walk_gradx(ksp, X, N, ldx, X2, N2, ldx2, D, covGrad, ldc, gX, ldg, pair_factor, s);
+    if(rc != GPC_EUNSUPPORTED) return rc;
+  }
   const int64_t rb = (N + 63) / 64;
   int64_t nsplit = (1024 + rb - 1) / rb;               // >= ~1024 workgroups when the sizes allow it
   const int64_t maxsplit = (N2 + 15) / 16;             // at least 16 columns (4 per wave) per slice
@@ -402,6 +407,14 @@ static int kern_grad_cross_pass(const gpc_kspec* ksp, const double* X, int64_t N
   const int nparams = ksp->offs[ksp->n_terms];
   for(int p = 0; p < nparams; p++) gout[p] = 0.0;
   if(N == 0 || N2 == 0) return GPC_OK;
+  double S[NPC];
+  bool have_sums = false;
+  {
+    const int rc = pair_walk_grad_cross(ks, X, N, ldx, X2, N2, ldx2, D, covGrad, ldc, S, s);   // large enough, D <= 32: the MFMA walk
+    if(rc == GPC_OK) have_sums = true;
+    else if(rc != GPC_EUNSUPPORTED) return rc;
+  }
+  if(!have_sums) {
   const int64_t rb = (N + 63) / 64;
   int64_t nsplit = (512 + rb - 1) / rb;
   const int64_t maxsplit = (N2 + 15) / 16;
@@ -445,11 +458,11 @@ static int kern_grad_cross_pass(const gpc_kspec* ksp, const double* X, int64_t N
   HostFetch f;
   GPC_CHECK(f.add(h.data(), partial, sizeof(double) * h.size(), s));
   GPC_CHECK(f.finish(s));
-  double S[NPC];
   for(int q = 0; q < NPC; q++) {
     double acc = 0.0;
     for(int64_t b = 0; b < nblk; b++) acc += h[(size_t)b * NPC + q];
     S[q] = acc;
+  }
   }
   int irbf = 0;
   for(int t = 0; t < ksp->n_terms; t++) {

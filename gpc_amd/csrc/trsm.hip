@@ -897,6 +897,8 @@ __global__ void __launch_bounds__(256) copy_upper_tile_kernel(const double* __re
 //          R(0:k0, 0:k0) += P P'     the Cholesky's trailing-update shape (same kernel instance, ROLE 3)
 //          R(blk, 0:k0)   = Vd P'    first (and only) touch of that row block: beta = 0 over L's dead entries; k >= row only
 //          R(blk, blk)    = Vd Vd'   lower part
+//      (Tried: the first two as ONE lower-trapezoid launch over [P; Vd] with the row block's k-loops starting at their diagonal --
+//      slower, 2870 against 2770 ms at N = 65 536: a trapezoid launch enumerates the empty super-tiles above the diagonal too.)
 //      R's strictly lower tiles overwrite L (dead after phase A), its diagonal tiles' lower parts the zeros under V's
 //      diagonal tiles; the strictly upper tiles of V are only read.  N^3/3.
 //   C. mirror.
@@ -905,7 +907,7 @@ __global__ void __launch_bounds__(256) copy_upper_tile_kernel(const double* __re
 static int64_t potri_inplace_min()
 {
   const char* e = getenv("GPC_POTRI_INPLACE_MINN");   // read per call (tests switch it): a getenv beside an O(N^3) call
-  return e ? atoll(e) : (int64_t)8193;
+  return e ? atoll(e) : (int64_t)24576;
 }
 
 static int potri_inplace_lower(int64_t N, double* A, int64_t lda, hipStream_t s)
@@ -915,7 +917,8 @@ static int potri_inplace_lower(int64_t N, double* A, int64_t lda, hipStream_t s)
   if(!use_flow) return GPC_EUNSUPPORTED;   // (the launch chain's form of the solve is not in place)
   const int64_t wenv = [] { const char* e = getenv("GPC_POTRI_LAUUM_NB"); return e ? atoll(e) : (int64_t)0; }();
   const int64_t w = (wenv >= 128 && wenv <= 4096) ? (wenv / 128) * 128 : 1024;
-  const int64_t tmax = w > 1024 ? w : 1024;
+  // (a problem of <= 4096 columns is ONE dataflow launch, whose "tile" is the whole factor: in place only in name there)
+  const int64_t tmax = N <= 4096 ? N : (w > 1024 ? w : 1024);
   void* ws = nullptr;
   GPC_CHECK(workspace(WS_POTRI, sizeof(double) * (size_t)tmax * (size_t)tmax * 2, &ws));
   double* tileA = static_cast<double*>(ws);                  // phase A: the panel's copy of L_bb (1024 x 1024)
@@ -969,8 +972,10 @@ static int potri_inplace_lower(int64_t N, double* A, int64_t lda, hipStream_t s)
 
 // A (factor in triangle uplo) -> full symmetric inverse of the factored matrix, in place (dpotri + mirror).
 //   lower: K^-1 = L^-T L^-1 = V V' with V = L^-T (upper triangular).
-// From N = GPC_POTRI_INPLACE_MINN (default 8193) on, even N: in place, O(N nb) scratch (potri_inplace_lower above).  Smaller
-// problems -- launch-bound, one or a few dataflow launches -- keep the form with V in a scratch array of N x N <= 512 MB:
+// From N = GPC_POTRI_INPLACE_MINN (default 24 576) on, even N: in place, O(N nb) scratch (potri_inplace_lower above): 2.77 s
+// against 2.86 at N = 65 536, equal at 32 768, 2.5 % slower at 24 576.  Smaller problems keep the form with V in a scratch array
+// of N x N (< 4.9 GB), whose second phase is ONE launch with every tile's whole k-range in registers -- 5 % faster at
+// N = 16 384, 7 % at 8192 than the in-place form's rank-1024 updates (tools/potri_inplace_ab.py):
 //   1. V := I * L^-T by the right-side solve (side R, lower, transposed): its rank-512 updates X_b * L(rest, b)' are in
 //      the NT form of the fast GEMM kernel, and the identity right-hand side keeps the work at N^3/3 (tri_rhs);
 //   2. lower(A) := V V' with the same kernel, every tile starting its k-loop at its own first row (V(i,k) = 0 for

@@ -219,7 +219,7 @@ def test_potri_vs_numpy(api, N, uplo):
                                       (12544, "U", 0), (13000, "L", 2048), (16390, "L", 0)])
 def test_potri_in_place(api, monkeypatch, N, uplo, w):
     """dpotri in place on the factor (lapack.h:67-73, CMatrix.cpp:414-432): V = L^-T into the upper triangle, lower(V V') over L,
-    scratch O(N nb).  Forced on from N = 2048 (default: from 8193), ragged sizes, both triangles, three block widths of the
+    scratch O(N nb).  Forced on from N = 2048 (default: from 24 576), ragged sizes, both triangles, three block widths of the
     second phase; the result against numpy's inverse and against the N x N-scratch form of the same library, and the device
     memory the call takes."""
     import torch
@@ -493,6 +493,46 @@ def test_kern_gradx_cross_vs_numpy(api):
         want += 0.4 * G @ X2
         got = api.to_host(api.kern_gradx_cross(api.kspec(terms), api.from_host(X), api.from_host(X2), api.from_host(G)))
         assert np.abs(got - want).max() < 1e-11 * max(1.0, np.abs(want).max())
+
+
+PAIR_WALK_TERMS = {
+    "rbf": lambda D, s: [("rbf", [0.7, 1.3])],
+    "rbf2_lin_bias_white": lambda D, s: [("rbf", [0.7, 1.3]), ("rbf", [0.2, 0.5]), ("lin", [0.4]), ("bias", [0.2]), ("white", [0.1])],
+    "rbfard_bias": lambda D, s: [("rbfard", [1.1, 0.6] + list(s)), ("bias", [0.3])],
+    "rbf3_rbfard_lin": lambda D, s: [("rbf", [0.7, 1.3]), ("rbfard", [1.1, 0.6] + list(s)), ("rbf", [0.3, 0.2]), ("lin", [0.4]), ("rbf", [1.5, 0.1])],
+    "lin_only": lambda D, s: [("lin", [0.4]), ("white", [0.1])],
+}
+
+
+@pytest.mark.parametrize("kname", sorted(PAIR_WALK_TERMS))
+@pytest.mark.parametrize("N,N2,D,shift", [(1500, 1700, 3, 0.0), (130, 20000, 8, 0.0), (5000, 513, 1, 0.0), (2048, 2048, 13, 40.0), (1100, 2300, 16, 0.0),
+                                          (1300, 1900, 20, -7.0), (1024, 2100, 32, 0.0)])
+def test_pair_walk_against_the_scalar_kernels(api, monkeypatch, kname, N, N2, D, shift):
+    """The MFMA walk of pair_walk.hip (dL/dX of a cross and of a symmetric weight matrix, the cross-Gram parameter sums; round 4)
+    against gplvm.hip's scalar kernels on the same inputs -- themselves held to the defining sums and the reference's fixtures by
+    the tests above -- over ragged sizes, every instance of the kernel (D = 1 ... 32), compounds that take several sub-passes,
+    and inputs far from the origin (the passes that difference large sums run on centred coordinates)."""
+    rng = np.random.RandomState(N + 7 * N2 + D)
+    X, X2 = rng.randn(N, D) / np.sqrt(D) + shift, rng.randn(N2, D) / np.sqrt(D) + shift
+    G = rng.randn(N, N2)
+    s = rng.rand(D) * 0.8 + 0.1
+    ks = api.kspec(PAIR_WALK_TERMS[kname](D, s))
+    Xd, X2d, Gd = api.from_host(X), api.from_host(X2), api.from_host(G)
+    Gs = rng.randn(N, N)
+    Gs = api.from_host(Gs + Gs.T)
+
+    def run():
+        return (api.to_host(api.kern_gradx_cross(ks, Xd, X2d, Gd)), api.kern_grad_cross(ks, Xd, X2d, Gd), api.to_host(api.kern_gradx(ks, Xd, Gs)))
+
+    monkeypatch.setenv("GPC_PAIR_WALK", "1")
+    monkeypatch.setenv("GPC_PAIR_WALK_MINPAIRS", "1")
+    got = run()
+    again = run()
+    monkeypatch.setenv("GPC_PAIR_WALK", "0")
+    want = run()
+    for a, b, c in zip(got, want, again):
+        assert np.abs(a - b).max() <= 1e-9 * max(1.0, np.abs(b).max()), kname
+        assert np.array_equal(a, c)            # slices and workgroups are added in a fixed order
 
 
 # ---- CGp (FTC) ---------------------------------------------------------------------------------------------------------------
