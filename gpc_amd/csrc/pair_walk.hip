@@ -455,10 +455,16 @@ __global__ void __launch_bounds__(256) pw_rows_reduce_kernel(const double* __res
 template <int NEXP, bool ROWS, bool SQ>
 int launch_walk(const WalkArgs& g, dim3 grid, hipStream_t s)
 {
-  // waves / occupancy by input dimension, as the rbfard parameter kernel settled them (kern_grad.hip launch_grad_ard_sym):
-  // four 64 x 32 patches at two workgroups per CU up to D = 8, eight 32 x 32 patches at one per CU beyond
+  // waves / occupancy by input dimension: four 64 x 32 patches at two workgroups per CU up to D = 16, eight 32 x 32 patches at one
+  // per CU beyond (where the four-wave form's per-lane state no longer fits 256 registers)
+  // D = 9 .. 16: four waves at two workgroups per CU (N = 32 768, D = 16: 3.0 ms = 2.9 TB/s against 4.0 ms with eight waves at
+  // one per CU -- the other way round from the rbfard parameter kernel, whose per-dimension sums cost it more registers);
+  // GPC_PAIR_WALK_FORM=0 keeps the eight-wave form there (A/B)
+  const char* e = getenv("GPC_PAIR_WALK_FORM");
+  const int form = e ? atoi(e) : 1;
   if(g.D <= 4) hipLaunchKernelGGL((pair_walk_kernel<1, 4, 2, NEXP, ROWS, SQ>), grid, dim3(256), 0, s, g);
   else if(g.D <= 8) hipLaunchKernelGGL((pair_walk_kernel<2, 4, 2, NEXP, ROWS, SQ>), grid, dim3(256), 0, s, g);
+  else if(g.D <= 16 && form == 1) hipLaunchKernelGGL((pair_walk_kernel<4, 4, 2, NEXP, ROWS, SQ>), grid, dim3(256), 0, s, g);
   else if(g.D <= 16) hipLaunchKernelGGL((pair_walk_kernel<4, 8, 1, NEXP, ROWS, SQ>), grid, dim3(512), 0, s, g);
   else hipLaunchKernelGGL((pair_walk_kernel<8, 8, 1, NEXP, ROWS, SQ>), grid, dim3(512), 0, s, g);
   GPC_HIP_CHECK(hipGetLastError());

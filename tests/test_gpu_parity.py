@@ -895,6 +895,38 @@ def test_cfg4_full_size_properties(api):
     assert worst < 1e-9
 
 
+def test_cfg4_gradient_through_cgp_on_one_gpu(api):
+    """CGp::logLikelihoodGradient at BASELINE config 4's full size on ONE GPU: the model keeps LcholK and invK (2 x 128 GiB of
+    the 288) and nothing else of size N x N -- dpotri works in place on its copy of the factor (round 4; until then its N x N
+    workspace made this a grid-only evaluation) and covGrad is formed inside the gradient pass.  Checked through identities that
+    hold at any size:  sum_ij covGrad_ij K_ij = -0.5 (N - m' K^-1 m)  -- the gradient with respect to log(variance) of a lone
+    rbf term --, K^-1 symmetric, (K^-1 m) from the inverse against (K^-1 m) from the two triangular solves."""
+    import torch
+    from gpc_amd import synth
+    from gpc_amd.gp import CGp
+    if torch.cuda.get_device_properties(0).total_memory < 290e9:
+        pytest.skip("needs 2 x 128 GiB of HBM")
+    torch.cuda.empty_cache()
+    api.lib().gpc_workspace_release()
+    c = synth.CONFIGS["cfg4"]
+    N, D = c["N"], c["D"]
+    X, y = synth.make_xy(N, D, 1234)
+    model = CGp(c["kern"], X, y)
+    g, ll = model.logLikelihoodGradient()
+    assert np.isfinite(ll) and np.all(np.isfinite(g))
+    free_b, total_b = torch.cuda.mem_get_info()
+    assert total_b - free_b <= 2 * 8 * N * N + (8 << 30), "the model holds %.1f GiB" % ((total_b - free_b) / 2.0 ** 30)
+    quad = float(model.quad[0])
+    want = -0.5 * (N - quad)                        # d ll / d log(variance): exp transform, gradfact = variance
+    assert abs(g[1] - want) <= 1e-8 * abs(want), (g, want)
+    idx = torch.tensor([0, 1, 4095, 65536, 100000, N - 1], device="cuda")
+    assert torch.equal(model.invK[idx, :], model.invK[:, idx].t())
+    am = model.invK[idx, :] @ model.m
+    assert float((am - model.invKm[idx, :]).abs().max()) <= 1e-8 * float(model.invKm.abs().max())
+    del model
+    torch.cuda.empty_cache()
+
+
 @pytest.mark.parametrize("N", [24000, 24700, 28700, 33000])
 def test_potrf_across_the_panel_chain_switches(api, N):
     """Sizes either side of the points where the factorisation changes kernels (fused four-wave panel steps up to
