@@ -12,7 +12,9 @@
 // come from a pre-pass, and the cross term is an FMA dot product per pair.  The diagonal of the symmetric Gram uses
 // the reference's diagComputeElement values exactly (variance sums), not exp(-0).
 #include "gpc_common.hpp"
+#include "gpc_exp.hpp"
 #include <vector>
+#include <type_traits>
 #include <string.h>
 #include <stdlib.h>
 
@@ -38,6 +40,8 @@ struct GramArgs {
                          //    computed once and stored twice (K(i,j) and K(j,i)); tiles right of it are skipped
   int debug;             // ablation knob (env GPC_GRAM_DEBUG): 2 no MFMA loop, 3 no stores; 0 in production
   int accum;             // 1: K += the terms of this spec (a further pass of a compound with more terms than one pass holds)
+  int pair_chunks;       // gram_sym_kernel: > 0 = row blocks are walked in PAIRS (I, nrb-1-I), whose joint walk -- the same length
+                         // for every pair -- is cut into this many equal chunks, one workgroup each (see the kernel)
 };
 
 __global__ void __launch_bounds__(256) row_norms_kernel(const double* __restrict__ X, int64_t ldx, int64_t N,
@@ -189,15 +193,17 @@ __global__ void __launch_bounds__(256) gram_kernel(const KSpecDev ks, const Gram
 // MFMA-path kernel (per-tile, persistent, symmetric) rounds identically: the block build used by the multi-GPU path
 // and the mirrored single-GPU build give the same bits.
 template <int NRBF>
-__device__ __forceinline__ double gram_value(const KSpecDev& ks, double ni, double nj, double dot, int n_rbf_rt)
+__device__ __forceinline__ double gram_value(const KSpecDev& ks, double ni, double nj, double dot, int n_rbf_rt, const double* etab)
 {
+  // etab: the workgroup's LDS copy of gpc_exp.hpp's table (round 4: the table-driven exponential, 16 vector instructions
+  // instead of ocml's ~40 -- the exponentials were 1.7 ms of the 8.0 ms N = 65 536 build)
   const double d2 = fma(-2.0, dot, ni + nj);
   double k = fma(ks.lin_var, dot, ks.bias_var);
   if(NRBF >= 0) {
 #pragma unroll
-    for(int q = 0; q < (NRBF >= 0 ? NRBF : 0); q++) k = fma(ks.rbf_var[q], exp(-(ks.rbf_hiw[q] * d2)), k);
+    for(int q = 0; q < (NRBF >= 0 ? NRBF : 0); q++) k = fma(ks.rbf_var[q], gpc_exp_tab(-(ks.rbf_hiw[q] * d2), etab), k);
   } else {
-    for(int q = 0; q < n_rbf_rt; q++) k = fma(ks.rbf_var[q], exp(-(ks.rbf_hiw[q] * d2)), k);
+    for(int q = 0; q < n_rbf_rt; q++) k = fma(ks.rbf_var[q], gpc_exp_tab(-(ks.rbf_hiw[q] * d2), etab), k);
   }
   return k;
 }
@@ -209,6 +215,8 @@ __global__ void __launch_bounds__(256, 2) gram_mfma_kernel(const KSpecDev ks, co
 {
   __shared__ double Xi[MDC * SI];
   __shared__ double Xj[MDC * SJ];
+  __shared__ double Etab[64];
+  gpc_exp_tab_fill(Etab);      // published by the staging barriers below (D >= 1: at least one round)
   const int t = threadIdx.x;
   const int lane = t & 63, w = t >> 6;
   const int wm = w & 1, wn = w >> 1;
@@ -297,7 +305,7 @@ __global__ void __launch_bounds__(256, 2) gram_mfma_kernel(const KSpecDev ks, co
         const int64_t gi = i0 + wm * 64 + tm * 16 + (lane & 15);
         if(gi >= g.N) continue;
         const double dot = acc[tm][tn][r];
-        double k = gram_value<-1>(ks, ni[tm], nj, dot, ks.n_rbf);
+        double k = gram_value<-1>(ks, ni[tm], nj, dot, ks.n_rbf, Etab);
         if(g.sym_diag && (g.i_off + gi == g.j_off + gj)) k = fma(ks.lin_var, ni[tm], diag_const);
         if(g.debug != 3 || k == 123.456) g.K[gi + gj * g.ldk] = k;
       }
@@ -317,6 +325,8 @@ __global__ void __launch_bounds__(256, 2) gram_mfma_persist_kernel(const KSpecDe
 {
   __shared__ double Xi[MDC * SI];
   __shared__ double Xj[2][MDC * SJ];
+  __shared__ double Etab[64];
+  gpc_exp_tab_fill(Etab);      // published by the first tile's barrier
   const int t = threadIdx.x;
   const int lane = t & 63, w = t >> 6;
   const int wm = w & 1, wn = w >> 1;
@@ -419,7 +429,7 @@ __global__ void __launch_bounds__(256, 2) gram_mfma_persist_kernel(const KSpecDe
         double kv[4];
 #pragma unroll
         for(int tm = 0; tm < 4; tm++) {
-          kv[tm] = gram_value<NRBF>(ks, ni[tm], nj, acc[tm][tn][r], 0);
+          kv[tm] = gram_value<NRBF>(ks, ni[tm], nj, acc[tm][tn][r], 0, Etab);
         }
 #pragma unroll
         for(int tm = 0; tm < 4; tm++) {
@@ -470,17 +480,53 @@ __global__ void __launch_bounds__(256, 2) gram_sym_kernel(const KSpecDev ks, con
   __shared__ double Xj[2][MDC * SJ];
   __shared__ double Nj[2][MJ];
   __shared__ double Tm[4][64 * TS];
+  __shared__ double Etab[64];
+  gpc_exp_tab_fill(Etab);      // published by the first tile's barrier
   const int t = threadIdx.x;
   const int lane = t & 63, w = t >> 6;
   const int wm = w & 1, wn = w >> 1;
-  const int64_t i0 = (int64_t)blockIdx.x * MI;
-  int64_t tiles_j = (g.N + MJ - 1) / MJ;
-  if(tiles_j > 2 * ((int64_t)blockIdx.x + 1)) tiles_j = 2 * ((int64_t)blockIdx.x + 1);
-  const int64_t jt0 = (int64_t)blockIdx.y * jt_per_block;
-  int64_t jt1 = jt0 + jt_per_block;
-  if(jt1 > tiles_j) jt1 = tiles_j;
-  if(jt0 >= jt1) return;
   const int dc = (int)g.D;          // <= 4 NK on this path
+  // What this workgroup walks: up to two segments (row block, range of column tiles).
+  //   pair_chunks == 0 (GPC_GRAM_PAIRS=0): row block blockIdx.x, tiles [y per, (y + 1) per) of its 2 I + 2 -- short chunks keep
+  //     the triangular work balanced, but a chunk is only `per` tiles long and the last ones start late.
+  //   pair_chunks  > 0: row blocks I and nrb - 1 - I together walk 2 nrb + 2 tiles whatever I is; that joint walk is cut into
+  //     pair_chunks equal pieces.  Every workgroup then has the same work (the launch ends everywhere at once) in long
+  //     contiguous walks -- which is also what the stores like: a store-only replica of this kernel writes 6.2 TB/s with one
+  //     long walk per row block against 5.5 with 48-tile chunks (tools/probes/symstore_probe.hip).
+  const int64_t tj_all = (g.N + MJ - 1) / MJ, nrb = (g.N + MI - 1) / MI;
+  int64_t segI[2] = {0, 0}, segA[2] = {0, 0}, segB[2] = {0, 0};
+  if(g.pair_chunks > 0) {
+    const int64_t I1 = blockIdx.x, I2 = nrb - 1 - (int64_t)blockIdx.x;
+    int64_t L1 = 2 * (I1 + 1), L2 = (I2 > I1) ? 2 * (I2 + 1) : 0;
+    if(L1 > tj_all) L1 = tj_all;
+    if(L2 > tj_all) L2 = tj_all;
+    const int64_t L = L1 + L2, a = L * (int64_t)blockIdx.y / g.pair_chunks, b = L * ((int64_t)blockIdx.y + 1) / g.pair_chunks;
+    segI[0] = I1;
+    segA[0] = a < L1 ? a : L1;
+    segB[0] = b < L1 ? b : L1;
+    segI[1] = I2;
+    segA[1] = (a > L1 ? a : L1) - L1;
+    segB[1] = (b > L1 ? b : L1) - L1;
+  } else {
+    int64_t tiles_j = tj_all;
+    if(tiles_j > 2 * ((int64_t)blockIdx.x + 1)) tiles_j = 2 * ((int64_t)blockIdx.x + 1);
+    segI[0] = blockIdx.x;
+    segA[0] = (int64_t)blockIdx.y * jt_per_block;
+    segB[0] = segA[0] + jt_per_block;
+    if(segB[0] > tiles_j) segB[0] = tiles_j;
+  }
+  double diag_const = ks.bias_var + ks.white_var;
+  for(int r = 0; r < ks.n_rbf; r++) diag_const += ks.rbf_var[r];
+  const int ws = __builtin_amdgcn_readfirstlane(w);
+  double* Tw = Tm[w];
+  bool walked = false;
+#pragma unroll 1
+  for(int sg = 0; sg < 2; sg++) {
+  const int64_t jt0 = segA[sg], jt1 = segB[sg];
+  if(jt0 >= jt1) continue;
+  if(walked) __syncthreads();       // the other waves may still be reading the previous segment's last column tile
+  walked = true;
+  const int64_t i0 = segI[sg] * MI;
 
   // this wave's 64 rows as MFMA fragments: a[kk][tm] = X(i0 + wm*64 + tm*16 + (lane & 15), 4 kk + (lane >> 4)).
   // Loads are unconditional with clamped indices (no branches): rows past N are never stored, and feature slots past
@@ -503,10 +549,6 @@ __global__ void __launch_bounds__(256, 2) gram_sym_kernel(const KSpecDev ks, con
     if(gi > g.N - 1) gi = g.N - 1;
     ni[tm] = g.n1[gi];
   }
-  double diag_const = ks.bias_var + ks.white_var;
-  for(int r = 0; r < ks.n_rbf; r++) diag_const += ks.rbf_var[r];
-
-  const int ws = __builtin_amdgcn_readfirstlane(w);
   double vj[8], vn;   // next tile's rows (and, in the first 64 threads, their norms), in flight during this tile
   auto prefetch = [&](int64_t jt) {
     const int64_t j0 = jt * MJ;
@@ -523,7 +565,6 @@ __global__ void __launch_bounds__(256, 2) gram_sym_kernel(const KSpecDev ks, con
     vn = g.n1[gj];
   };
   prefetch(jt0);
-  double* Tw = Tm[w];
 
   for(int64_t jt = jt0; jt < jt1; jt++) {
     double* Xjb = Xj[(jt - jt0) & 1];
@@ -566,71 +607,88 @@ __global__ void __launch_bounds__(256, 2) gram_sym_kernel(const KSpecDev ks, con
     const bool mirror = (j0 + MJ <= i0);   // strictly left of the diagonal block (workgroup-uniform)
     const bool rowstore = (g.debug == 16);   // experiment, off: 512-byte runs through the staging patch lose to the direct store
                                              // (N = 65 536: 7.9 -> 8.5 ms at D = 32, 6.5 -> 7.1 ms at D = 8)
+    // Two forms of the epilogue.  FAST -- a full tile strictly left of the diagonal block, i.e. all but two tiles of a row
+    // block's walk -- has no edge predicates and no diagonal elements, so its stores need no exec-mask juggling (the general
+    // form spends 18 scalar instructions per element on it) and its addresses are one 64-bit add per (tn, r) instead of one
+    // per store.
+    auto epilogue = [&](auto fast_tag) {
+      constexpr bool FAST = decltype(fast_tag)::value;
+      double* const Kd = g.K + (i0 + wm * 64 + (lane & 15)) + (j0 + wn * 32 + (lane >> 4)) * g.ldk;   // element (tm = 0, tn = 0, r = 0)
 #pragma unroll
-    for(int tn = 0; tn < 2; tn++) {
-      if(SPLIT) {
-        __builtin_amdgcn_sched_barrier(0);
-        products(tn, tn + 1);
-      }
+      for(int tn = 0; tn < 2; tn++) {
+        if(SPLIT) {
+          __builtin_amdgcn_sched_barrier(0);
+          products(tn, tn + 1);
+        }
 #pragma unroll
-      for(int r = 0; r < 4; r++) {
-        __builtin_amdgcn_sched_barrier(0);   // keep the unrolled (tn, r) bodies apart: interleaved they spill
-        const int jl = wn * 32 + tn * 16 + (lane >> 4) + 4 * r;
-        const int64_t gj = j0 + jl;
-        const double nj = Njb[jl];
-        // two rows at a time: enough independent exp chains to overlap, few enough to stay in registers
+        for(int r = 0; r < 4; r++) {
+          __builtin_amdgcn_sched_barrier(0);   // keep the unrolled (tn, r) bodies apart: interleaved they spill
+          const int jl = wn * 32 + tn * 16 + (lane >> 4) + 4 * r;
+          const int64_t gj = j0 + jl;
+          const double nj = Njb[jl];
+          double* const Kc = Kd + (tn * 16 + 4 * r) * g.ldk;
+          // two rows at a time: enough independent exp chains to overlap, few enough to stay in registers
 #pragma unroll
-        for(int th = 0; th < 4; th += 2) {
-          double kv[2];
+          for(int th = 0; th < 4; th += 2) {
+            double kv[2];
 #pragma unroll
-          for(int u = 0; u < 2; u++) {
-            const int tm = th + u;
-            kv[u] = gram_value<NRBF>(ks, ni[tm], nj, acc[tm][tn][r], 0);
+            for(int u = 0; u < 2; u++) {
+              const int tm = th + u;
+              kv[u] = gram_value<NRBF>(ks, ni[tm], nj, acc[tm][tn][r], 0, Etab);
+            }
+#pragma unroll
+            for(int u = 0; u < 2; u++) {
+              const int tm = th + u;
+              double k = kv[u];
+              if(FAST) {
+                Kc[tm * 16] = k;
+                Tw[(tm * 16 + (lane & 15)) * TS + 4 * r + (lane >> 4)] = k;
+              } else {
+                const int64_t gi = i0 + wm * 64 + tm * 16 + (lane & 15);
+                if(gi == gj) k = fma(ks.lin_var, ni[tm], diag_const);   // diagComputeElement
+                if(!rowstore && (full || (gi < g.N && gj < g.N))) g.K[gi + gj * g.ldk] = k;
+                if(mirror || rowstore) Tw[(tm * 16 + (lane & 15)) * TS + 4 * r + (lane >> 4)] = k;
+              }
+            }
           }
-#pragma unroll
-          for(int u = 0; u < 2; u++) {
-            const int tm = th + u;
-            const int64_t gi = i0 + wm * 64 + tm * 16 + (lane & 15);
-            double k = kv[u];
-            if(gi == gj) k = fma(ks.lin_var, ni[tm], diag_const);   // diagComputeElement
-            if(!rowstore && (full || (gi < g.N && gj < g.N))) g.K[gi + gj * g.ldk] = k;
-            if(mirror || rowstore) Tw[(tm * 16 + (lane & 15)) * TS + 4 * r + (lane >> 4)] = k;
+        }
+        if(!FAST && rowstore) {
+          // the direct store as well through the staging patch, read with lanes along i: one column of the patch per
+          // instruction, 512 contiguous bytes (straight from the accumulator layout an instruction writes four 128-byte
+          // pieces of four different columns)
+          __builtin_amdgcn_wave_barrier();
+          const int64_t gi = i0 + wm * 64 + lane;
+          double* Kp = g.K + gi + (j0 + wn * 32 + tn * 16) * g.ldk;
+#pragma unroll 4
+          for(int u = 0; u < 16; u++) {
+            const double k = Tw[lane * TS + u];
+            if(full || (gi < g.N && j0 + wn * 32 + tn * 16 + u < g.N)) *Kp = k;
+            Kp += g.ldk;
           }
+          if(!mirror) __builtin_amdgcn_wave_barrier();
         }
-      }
-      if(rowstore) {
-        // the direct store as well through the staging patch, read with lanes along i: one column of the patch per
-        // instruction, 512 contiguous bytes (straight from the accumulator layout an instruction writes four 128-byte
-        // pieces of four different columns)
-        __builtin_amdgcn_wave_barrier();
-        const int64_t gi = i0 + wm * 64 + lane;
-        double* Kp = g.K + gi + (j0 + wn * 32 + tn * 16) * g.ldk;
+        if(FAST || mirror) {
+          // the wave's 64 (i) x 16 (j) patch of this tn, now read with lanes along j: K(j, i), 128-byte runs
+          __builtin_amdgcn_wave_barrier();
+          const int jl = lane & 15;
+          const int64_t gj = j0 + wn * 32 + tn * 16 + jl;
+          double* Kcol = g.K + gj + (i0 + wm * 64 + (lane >> 4)) * g.ldk;
+          const int64_t step4 = 4 * g.ldk;
 #pragma unroll 4
-        for(int u = 0; u < 16; u++) {
-          const double k = Tw[lane * TS + u];
-          if(full || (gi < g.N && j0 + wn * 32 + tn * 16 + u < g.N)) *Kp = k;
-          Kp += g.ldk;
+          for(int u = 0; u < 16; u++) {
+            const int il = 4 * u + (lane >> 4);
+            const double k = Tw[il * TS + jl];
+            if(FAST || full || (i0 + wm * 64 + il < g.N && gj < g.N)) *Kcol = k;
+            Kcol += step4;
+          }
+          __builtin_amdgcn_wave_barrier();
         }
-        if(!mirror) __builtin_amdgcn_wave_barrier();
       }
-      if(mirror) {
-        // the wave's 64 (i) x 16 (j) patch of this tn, now read with lanes along j: K(j, i), 128-byte runs
-        __builtin_amdgcn_wave_barrier();
-        const int jl = lane & 15;
-        const int64_t gj = j0 + wn * 32 + tn * 16 + jl;
-        double* Kcol = g.K + gj + (i0 + wm * 64 + (lane >> 4)) * g.ldk;
-        const int64_t step4 = 4 * g.ldk;
-#pragma unroll 4
-        for(int u = 0; u < 16; u++) {
-          const int il = 4 * u + (lane >> 4);
-          const double k = Tw[il * TS + jl];
-          if(full || (i0 + wm * 64 + il < g.N && gj < g.N)) *Kcol = k;
-          Kcol += step4;
-        }
-        __builtin_amdgcn_wave_barrier();
-      }
-    }
+    };
+    if(full && mirror && !rowstore) epilogue(std::true_type{});
+    else epilogue(std::false_type{});
   }
+  }   // segments
 }
 
 int launch_gram(const KSpecDev& ks, const GramArgs& g, hipStream_t s)
@@ -657,13 +715,30 @@ int launch_gram(const KSpecDev& ks, const GramArgs& g, hipStream_t s)
         if(per > sym_per) per = sym_per;
       }
       nsplit = (tiles_j + per - 1) / per;
-      const dim3 grid((unsigned)tiles_i, (unsigned)nsplit), block(256);
+      dim3 grid((unsigned)tiles_i, (unsigned)nsplit), block(256);
       if(g.mirror && (ks.n_rbf == 1 || ks.n_rbf == 2)) {
         const int nkk = (int)((g.D + 3) / 4);
+        // paired row blocks, equal chunks (gram_sym_kernel): about 1024 workgroups, i.e. two full rounds of the chip's 512
+        // resident ones, each at least 8 tiles long.  GPC_GRAM_PAIRS=0: the per-row-block chunks of GPC_GRAM_PER tiles.
+        static const int pairs_on = [] { const char* e = getenv("GPC_GRAM_PAIRS"); return e ? atoi(e) : 1; }();
+        static const int64_t pair_wgs = [] { const char* e = getenv("GPC_GRAM_PAIR_WGS"); return e ? atoll(e) : (int64_t)1024; }();
+        GramArgs gp = g;
+        gp.pair_chunks = 0;
+        if(pairs_on) {
+          const int64_t npairs = (tiles_i + 1) / 2, L = 2 * tiles_i + 2;
+          int64_t C = (pair_wgs + npairs - 1) / npairs;
+          if(C > L / 8) C = L / 8;
+          if(C < 1) C = 1;
+          gp.pair_chunks = (int)C;
+          grid = dim3((unsigned)npairs, (unsigned)C);
+        }
+        const GramArgs& g = gp;
+        // (experiment: unused dynamic LDS that keeps a CU to ONE workgroup -- fewer concurrent store streams)
+        static const unsigned lds_pad = [] { const char* e = getenv("GPC_GRAM_LDS_PAD"); return e ? (unsigned)atoi(e) : 0u; }();
 #define GPC_SYM_LAUNCH(R, K)                                                                                         \
   do {                                                                                                             \
-    if(K >= 8 && g.debug != 8) hipLaunchKernelGGL((gram_sym_kernel<R, K, true>), grid, block, 0, s, ks, g, (int)per); \
-    else hipLaunchKernelGGL((gram_sym_kernel<R, K, false>), grid, block, 0, s, ks, g, (int)per);                     \
+    if(K >= 8 && g.debug != 8) hipLaunchKernelGGL((gram_sym_kernel<R, K, true>), grid, block, lds_pad, s, ks, g, (int)per); \
+    else hipLaunchKernelGGL((gram_sym_kernel<R, K, false>), grid, block, lds_pad, s, ks, g, (int)per);                     \
   } while(0)
         if(ks.n_rbf == 1) {
           if(nkk <= 1) GPC_SYM_LAUNCH(1, 1);
@@ -900,6 +975,7 @@ static int gram_pass(const gpc_kspec* ksp, const double* X, int64_t N, int64_t l
     g.mirror = (sym && !accum && same_x && sym_diag && X == X2 && N == N2 && i_off == 0 && j_off == 0) ? 1 : 0;
   }
   g.accum = accum;
+  g.pair_chunks = 0;
   {
     static int dbg = -1;
     if(dbg < 0) { const char* e = getenv("GPC_GRAM_DEBUG"); dbg = e ? atoi(e) : 0; }
