@@ -12,7 +12,9 @@
 // 1 KiB runs).  A fixed-size grid strides over the tiles and writes per-workgroup partial sums that the host adds in
 // a fixed order, so the result is deterministic.
 #include "gpc_common.hpp"
+#include "gpc_exp.hpp"
 #include <vector>
+#include <type_traits>
 #include <string.h>
 #include <string.h>
 #include <stdlib.h>
@@ -216,6 +218,8 @@ __global__ void __launch_bounds__(256, 2) kern_grad_sym_kernel(const KSpecDev ks
   __shared__ double Nj[2][GMJ];
   __shared__ double Xi[NK > 2 ? GMDC * GSI : 1];
   __shared__ double sh[4];
+  __shared__ double Etab[64];
+  gpc_exp_tab_fill(Etab);      // the table of gpc_exp.hpp; published by the first tile's barrier
   const int t = threadIdx.x;
   const int lane = t & 63, w = t >> 6;
   const int wm = w & 1, wn = w >> 1;
@@ -305,80 +309,21 @@ __global__ void __launch_bounds__(256, 2) kern_grad_sym_kernel(const KSpecDev ks
     // covGrad values of a half are requested one half ahead: their latency hides behind the other half's work.
     const bool full = (i0 + GMI <= g.N) && (j0 + GMJ <= g.N);
     const bool mirror = (j0 + GMJ <= i0);   // strictly left of the diagonal block: every element stands for two
-    const double wgt = mirror ? 2.0 : 1.0;
-    constexpr bool LEAN = (NK >= GPC_KG_LEAN_NK);   // no covGrad held for the next half
-    double c[LEAN ? 1 : 2][4][4];
-    auto load_cg = [&](int tn) {
-#pragma unroll
-      for(int r = 0; r < 4; r++) {
-        const int64_t gj = j0 + wn * 32 + tn * 16 + (lane >> 4) + 4 * r;
-        const int64_t gjc = (gj < g.N) ? gj : (g.N - 1);
-        double aj[ND > 0 ? ND : 1];
-#pragma unroll
-        for(int o = 0; o < ND; o++) aj[o] = g.A[gjc + (int64_t)o * g.lda];
-#pragma unroll
-        for(int tm = 0; tm < 4; tm++) {
-          const int64_t gi = i0 + wm * 64 + tm * 16 + (lane & 15);
-          const int64_t gic = (gi < g.N) ? gi : (g.N - 1);
-          double v = g.cg[gic + gjc * g.ldc];
-          if(ND > 0) {   // covGrad from invK: same operations as covgrad_kernel / covgrad_multi_kernel, element by element
-            double aa = 0.0;
-#pragma unroll
-            for(int o = 0; o < ND; o++) aa = fma(ai[o][tm], aj[o], aa);
-            v = -0.5 * ((double)ND * v - aa);
-          }
-          c[LEAN ? 0 : tn][r][tm] = (full || (gi < g.N && gj < g.N)) ? v : 0.0;
-        }
-      }
-    };
-    if(!LEAN) load_cg(0);
-#pragma unroll
-    for(int tn = 0; tn < 2; tn++) {
-      if(LEAN) load_cg(tn);
-      gdouble4 acc[4];
-#pragma unroll
-      for(int a = 0; a < 4; a++) acc[a] = (gdouble4){0.0, 0.0, 0.0, 0.0};
-#pragma unroll(NK > 2 ? 2 : NK)
-      for(int kk = 0; kk < NK; kk++) {   // (fully unrolled, NK = 4 needs no scratch but runs slower: 6.4 -> 8.6 ms at N = 65 536)
-        const int kr = kk * 4 + (lane >> 4);
-        const double b = Xjb[kr * GSJ + wn * 32 + tn * 16 + (lane & 15)];
-#pragma unroll
-        for(int tm = 0; tm < 4; tm++) {
-          const double a = AF_LDS ? Xi[kr * GSI + wm * 64 + tm * 16 + (lane & 15)] : af[AF_LDS ? 0 : kk][tm];
-          acc[tm] = __builtin_amdgcn_mfma_f64_16x16x4f64(b, a, acc[tm], 0, 0, 0);
-        }
-      }
-      if(!LEAN && tn == 0) load_cg(1);
-#pragma unroll
-      for(int r = 0; r < 4; r++) {
-        const int jl = wn * 32 + tn * 16 + (lane >> 4) + 4 * r;
-        const int64_t gj = j0 + jl;
-        const double nj = Njb[jl];
-        // two rows at a time: enough independent exp chains to overlap, few enough to stay in registers
-#pragma unroll
-        for(int th = 0; th < 4; th += 2) {
-#pragma unroll
-          for(int u = 0; u < 2; u++) {
-            const int tm = th + u;
-            const int64_t gi = i0 + wm * 64 + tm * 16 + (lane & 15);
-            const double cw = c[LEAN ? 0 : tn][r][tm] * wgt;
-            const bool isdiag = (gi == gj);            // only inside the diagonal block (wgt = 1)
-            const double cm = isdiag ? 0.0 : cw;       // the diagonal takes no part in the rbf sums
-            const double dot = acc[tm][r];
-            const double d2 = fma(-2.0, dot, ni[tm] + nj);
-            s_all += cw;
-            s_tr += isdiag ? cw : 0.0;
-            s_lin = fma(cw, isdiag ? ni[tm] : dot, s_lin);
-#pragma unroll
-            for(int q = 0; q < NRBF; q++) {
-              const double e = cm * exp(-(ks.rbf_hiw[q] * d2));
-              s_d2e[q] = fma(d2, e, s_d2e[q]);
-              s_e[q] += e;
-            }
-          }
-        }
-      }
+    // FAST (round 4): a full tile strictly left of the diagonal block -- all but two tiles of a walk -- has no edge masks and no
+    // diagonal elements: no selects around the loads, no 64-bit compares in the sums, weight 2 folded into the final sums
+    // The fast form and the table-driven exponential (gpc_exp.hpp) for D <= 8 only: from NK = 4 the kernel sits at its 256
+    // registers and either of them spills (D = 16: 5.8 -> 17 ms with both).  D = 8: 5.1 -> 4.2 ms.
+#define KG_EXP(x) (NK <= 2 ? gpc_exp_tab((x), Etab) : exp(x))
+    if(NK <= 2 && full && mirror) {
+#define KG_FAST true
+#include "kern_grad_sym_tile.inc"
+#undef KG_FAST
+    } else {
+#define KG_FAST false
+#include "kern_grad_sym_tile.inc"
+#undef KG_FAST
     }
+#undef KG_EXP
   }
   double out[NP_MAIN];
 #pragma unroll
@@ -488,6 +433,8 @@ __global__ void __launch_bounds__(64 * NW, OCC) kern_grad_ard_sym_kernel(const K
   static_assert(NW == 4 || NW == 8, "waves per workgroup");
   __shared__ double sh[NW];
   __shared__ double red[NW][32];
+  __shared__ double Etab[64];
+  gpc_exp_tab_fill(Etab);      // the table of gpc_exp.hpp; published by the first tile's barrier
   const int t = threadIdx.x;
   const int lane = t & 63, w = t >> 6;
   const int wm = w & (NW / 2 - 1), wn = w / (NW / 2);
@@ -583,105 +530,16 @@ __global__ void __launch_bounds__(64 * NW, OCC) kern_grad_ard_sym_kernel(const K
 
     const bool full = (i0 + GMI <= g.N) && (j0 + GMJ <= g.N);
     const bool mirror = (j0 + GMJ <= i0);
-    const double wgt = mirror ? 2.0 : 1.0;
-    constexpr bool LEAN = (OCC == 2);   // two workgroups per CU: no covGrad held for the next half (the other workgroup's waves cover the latency)
-    double c[LEAN ? 1 : 2][4][TM];
-    auto load_cg = [&](int tn) {
-#pragma unroll
-      for(int r = 0; r < 4; r++) {
-        const int64_t gj = j0 + wn * 32 + tn * 16 + (lane >> 4) + 4 * r;
-        const int64_t gjc = (gj < g.N) ? gj : (g.N - 1);
-        double aj[ND > 0 ? ND : 1];
-#pragma unroll
-        for(int o = 0; o < ND; o++) aj[o] = g.A[gjc + (int64_t)o * g.lda];
-#pragma unroll
-        for(int tm = 0; tm < TM; tm++) {
-          const int64_t gi = i0 + wm * RW + tm * 16 + (lane & 15);
-          const int64_t gic = (gi < g.N) ? gi : (g.N - 1);
-          double v = g.cg[gic + gjc * g.ldc];
-          if(ND > 0) {
-            double aa = 0.0;
-#pragma unroll
-            for(int o = 0; o < ND; o++) aa = fma(ai[o][tm], aj[o], aa);
-            v = -0.5 * ((double)ND * v - aa);
-          }
-          c[LEAN ? 0 : tn][r][tm] = (full || (gi < g.N && gj < g.N)) ? v : 0.0;
-        }
-      }
-    };
-    if(!LEAN) load_cg(0);
-#pragma unroll
-    for(int tn = 0; tn < 2; tn++) {
-      if(LEAN) load_cg(tn);
-      // rows of X^T for this half's 16 columns: r -> j = 4 r + (lane >> 4), QX groups of 16 dimensions; asked for now, used after
-      // the dot products and the exponentials
-      double xc[4][QX];
-#pragma unroll
-      for(int r = 0; r < 4; r++) {
-        int64_t jj = j0 + wn * 32 + tn * 16 + 4 * r + (lane >> 4);
-        if(jj > g.N - 1) jj = g.N - 1;
-#pragma unroll
-        for(int qx = 0; qx < QX; qx++) xc[r][qx] = XT[jj * DP + qx * 16 + (lane & 15)];
-      }
-      gdouble4 acc[TM];
-#pragma unroll
-      for(int a = 0; a < TM; a++) acc[a] = (gdouble4){0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-      for(int kk = 0; kk < NK; kk++) {   // (fully unrolled: as a loop of two-step bodies it costs 100 more registers)
-        const int kr = kk * 4 + (lane >> 4);
-        const double b = Xjb[kr * GSJ + wn * 32 + tn * 16 + (lane & 15)];
-#pragma unroll
-        for(int tm = 0; tm < TM; tm++) {
-          const double a = AF_LDS ? Xi[kr * GSI + wm * RW + tm * 16 + (lane & 15)] : af[AF_LDS ? 0 : kk][tm];
-          acc[tm] = __builtin_amdgcn_mfma_f64_16x16x4f64(b, a, acc[tm], 0, 0, 0);
-        }
-      }
-      if(!LEAN && tn == 0) load_cg(1);
-      // the weights W = wgt * covGrad * exp(-hiw d2) replace the dot products in acc, register for register
-#pragma unroll
-      for(int r = 0; r < 4; r++) {
-        const int jl = wn * 32 + tn * 16 + (lane >> 4) + 4 * r;
-        const int64_t gj = j0 + jl;
-        const double nj = Njb[jl];
-#pragma unroll
-        for(int th = 0; th < TM; th += 2) {
-#pragma unroll
-          for(int u = 0; u < 2; u++) {
-            const int tm = th + u;
-            const int64_t gi = i0 + wm * RW + tm * 16 + (lane & 15);
-            const double cw = c[LEAN ? 0 : tn][r][tm] * wgt;
-            const bool isdiag = (gi == gj);
-            const double cm = isdiag ? 0.0 : cw;
-            const double d2 = fma(-2.0, acc[tm][r], ni[tm] + nj);
-            s_all += cw;
-            s_tr += isdiag ? cw : 0.0;
-            const double e = cm * exp(-(hiw * d2));
-            s_d2e = fma(d2, e, s_d2e);
-            s_e += e;
-            rho[tm] += e;
-            acc[tm][r] = e;
-          }
-        }
-      }
-      // Y(q, i) += sum_j x_jq W(i, j): k-step r covers j = 4 r .. 4 r + 3 of this half.  The x_jq^2 term needs only the
-      // column sums kappa_j = sum_i W(i, j): a butterfly over the 16 lanes that share j, after which lane (j, q) holds both
-      // kappa_j and x_jq
-#pragma unroll
-      for(int r = 0; r < 4; r++) {
-        double kap = acc[0][r] + acc[1][r];
-        if(TM == 4) kap += acc[TM - 2][r] + acc[TM - 1][r];
-        kap += __shfl_xor(kap, 1, 64);
-        kap += __shfl_xor(kap, 2, 64);
-        kap += __shfl_xor(kap, 4, 64);
-        kap += __shfl_xor(kap, 8, 64);
-#pragma unroll
-        for(int qx = 0; qx < QX; qx++) {
-          const double x1 = xc[r][qx];
-          Bq[qx] = fma(kap * x1, x1, Bq[qx]);
-#pragma unroll
-          for(int tm = 0; tm < TM; tm++) Y1[tm][qx] = __builtin_amdgcn_mfma_f64_16x16x4f64(x1, acc[tm][r], Y1[tm][qx], 0, 0, 0);
-        }
-      }
+    // FAST (round 4): full tiles strictly left of the diagonal block -- no edge masks, no diagonal elements, weight 2
+    // (the fast form up to D = 16: beyond, the second copy pushes the eight-wave instance over its 256 registers for no gain)
+    if(NK <= 4 && full && mirror) {
+#define KG_FAST true
+#include "kern_grad_ard_tile.inc"
+#undef KG_FAST
+    } else {
+#define KG_FAST false
+#include "kern_grad_ard_tile.inc"
+#undef KG_FAST
     }
   }
 

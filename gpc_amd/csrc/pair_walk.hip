@@ -236,7 +236,7 @@ __global__ void __launch_bounds__(64 * NW, OCC) pair_walk_kernel(const WalkArgs 
             double wd = 0.0;
 #pragma unroll
             for(int q = 0; q < NEXP; q++) {
-              const double e = cw * exp(-(g.hiw[q] * d2));
+              const double e = cw * exp(-(g.hiw[q] * d2));   // (the table form of gpc_exp.hpp is slower here: D = 8 3.2 -> 4.9 ms; two chains per wave leave its LDS read exposed)
               if(!ROWS) {
                 s_d2e[q] = fma(d2, e, s_d2e[q]);
                 s_e[q] += e;

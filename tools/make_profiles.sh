@@ -43,4 +43,31 @@ for c in FETCH_SIZE WRITE_SIZE; do
   echo "# rocprofv3 --pmc $c -- python tools/gram_bench.py 65536 32   (cfg 3's Gram: gram_sym_kernel; counter values in KB summed over the XCDs)" > $OUT/pmc_gram_$c.txt
   python $R/tools/pmc_query.py /tmp/pmc_g$c gram_sym >> $OUT/pmc_gram_$c.txt 2>&1
 done
+# 4. dpotri alone at cfg 3's size (in place from N = 24 576): kernel trace
+rm -rf /tmp/kt_potri
+timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/kt_potri -o t -- python $R/tools/potri_only.py 65536 > /dev/null 2>&1
+summ /tmp/kt_potri "python tools/potri_only.py 65536   (factor once, then 4 x [copy + gpc_potri_f64 in place])" > $OUT/kernel_trace_potri.txt
+# 5. PMC passes: the dL/dX walk (pair_walk_kernel, N = 32 768, D = 8 and 16), the dataflow panel kernel on a 1024 x 1024 tile
+pmcx() { # file pattern counters -- command...
+  f=$1; pat=$2; set=$3; shift 3
+  rm -rf /tmp/pmcx
+  timeout 300 rocprofv3 --pmc $set -d /tmp/pmcx -o p -- "$@" > /dev/null 2>&1
+  echo "# --pmc $set" >> $f
+  python $R/tools/pmc_query.py /tmp/pmcx "$pat" >> $f 2>&1
+}
+F=$OUT/pmc_gradx.txt
+echo "# rocprofv3 --pmc <counters> -- python tools/grad_bench.py 32768 <D>   (pair_walk_kernel: gpc_kern_gradx_f64; per-dispatch sums over all XCDs; FETCH_SIZE / WRITE_SIZE in KB)" > $F
+for D in 8 16; do
+  echo "# ---- D = $D" >> $F
+  for set in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" \
+             "SQ_INSTS_VALU SQ_INSTS_VMEM SQ_INSTS_LDS SQ_INSTS_SALU SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU_MFMA_MOPS_F64" "FETCH_SIZE" "WRITE_SIZE"; do
+    pmcx $F pair_walk "$set" python $R/tools/grad_bench.py 32768 $D
+  done
+done
+F=$OUT/pmc_panel_flow.txt
+echo "# rocprofv3 --pmc <counters> -- python tools/flow_check.py 1024 child   (panel_flow_kernel on a 1024 x 1024 factorisation: 136 workgroups, 16 dependent steps)" > $F
+for set in "SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY" \
+           "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_INSTS_VALU SQ_INSTS_VMEM"; do
+  pmcx $F panel_flow "$set" python $R/tools/flow_check.py 1024 child
+done
 ls -la $OUT
