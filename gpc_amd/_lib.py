@@ -92,6 +92,7 @@ SIGNATURES = {
     "gpc_profile_read": (c_int, [c_int, POINTER(c_int64), POINTER(c_double), POINTER(c_double), c_int]),
     "gpc_probe_mfma_f64": (c_int, [POINTER(c_double), POINTER(c_double), POINTER(c_double), VP]),
     "gpc_debug_panel_flow_trace": (c_int, [POINTER(ctypes.c_longlong), c_int64]),
+    "gpc_debug_exp_f64": (c_int, [DP, DP, I64, VP]),
 }
 
 

@@ -10,6 +10,7 @@
 //   symv               dsymv_ (lapack.h:130-140)
 //   covgrad            CGp::updateCovGradient (CGp.cpp:666-679)
 #include "gpc_common.hpp"
+#include "gpc_exp.hpp"
 
 namespace gpc {
 
@@ -620,6 +621,28 @@ extern "C" int gpc_scale_vec_f64(int64_t M, int64_t N, double* A, int64_t lda, c
     hipLaunchKernelGGL(scale_vec_kernel, dim3((unsigned)((M + 255) / 256), (unsigned)nc), dim3(256), 0, s, M, A, lda, v_dev,
                        by_rows, j0);
   }
+  GPC_HIP_CHECK(hipGetLastError());
+  return GPC_OK;
+}
+
+namespace gpc {
+namespace {
+__global__ void __launch_bounds__(256) debug_exp_kernel(const double* __restrict__ x, double* __restrict__ y, int64_t n)
+{
+  __shared__ double tab[64];
+  gpc_exp_tab_fill(tab);
+  __syncthreads();
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if(i < n) y[i] = gpc_exp_tab(x[i], tab);
+}
+}  // namespace
+}  // namespace gpc
+
+extern "C" int gpc_debug_exp_f64(const double* x, double* y, int64_t n, void* stream)
+{
+  GPC_CHECK(gpc::ensure_device());
+  if(n <= 0) return GPC_OK;
+  hipLaunchKernelGGL(gpc::debug_exp_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, y, n);
   GPC_HIP_CHECK(hipGetLastError());
   return GPC_OK;
 }

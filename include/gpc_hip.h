@@ -111,11 +111,16 @@ int gpc_potrf_f64(char uplo, int64_t N, double* A, int64_t lda, int* info, void*
 /* CMatrix::chol(): potrf + zero the other triangle (CMatrix.cpp:380-403). */
 int gpc_chol_f64(char uplo, int64_t N, double* A, int64_t lda, int* info, void* stream);
 /* dpotri + mirror (lapack.h:67-73; CMatrix::pdinv(U) CMatrix.cpp:421-432): on entry A holds the factor in triangle
- * `uplo`; on exit A holds the FULL symmetric inverse. */
+ * `uplo`; on exit A holds the FULL symmetric inverse (the other triangle's old content is not preserved).  In place like
+ * dpotri_: from N = 24 576 (even N; env GPC_POTRI_INPLACE_MINN) the scratch is O(N * 1024) doubles -- V = L^-T is formed in
+ * the upper triangle, lower(V V') over the dead factor --; smaller problems use an N x N scratch array (< 4.9 GB), whose
+ * one-launch product is faster there.  A dataflow time-out inside the in-place form returns GPC_EHIP with A partly overwritten. */
 int gpc_potri_f64(char uplo, int64_t N, double* A, int64_t lda, void* stream);
 /* jitChol's chol() + logDet + pdinv of CGp::_updateInvK / CGplvm::updateK in ONE pass (CGp.cpp:881-889, CGplvm.cpp:441-444;
  * dpotrf_ + dpotri_, lapack.h:59-73): on entry A holds K (lower triangle read); on exit A's lower triangle holds L, invK
- * the full symmetric inverse, *logdet = log|K| (may be NULL), *info as gpc_potrf_f64 (invK untouched when info != 0).
+ * the full symmetric inverse, *logdet = log|K| (may be NULL), *info as gpc_potrf_f64.  When *info != 0 the contents of BOTH A
+ * and invK are undefined (the later kernels of the chain are queued before info is read back): a caller that retries with
+ * jitter regenerates K, as jitChol's callers here do.
  * Up to N = 5120 the identity rides through the factorisation of [K; I] and the inverse is one product, which halves the
  * chain of dependent launches that bounds small matrices; beyond that it is gpc_potrf_f64 + gpc_potri_f64. */
 int gpc_chol_inverse_f64(int64_t N, double* A, int64_t lda, double* invK, int64_t ldi, double* logdet, int* info, void* stream);
@@ -127,7 +132,10 @@ int gpc_trsm_f64(char side, char uplo, char trans, char diag, int64_t M, int64_t
                  const double* A, int64_t lda, double* B, int64_t ldb, void* stream);
 /* logDet of a Cholesky factor: 2*sum(log(diag)) (CMatrix.cpp:404-412).  *out is a host double. */
 int gpc_logdet_chol_f64(int64_t N, const double* A, int64_t lda, double* out, void* stream);
-/* dgemm (lapack.h:165-181; CMatrix::gemm): C := alpha*op(A)*op(B) + beta*C, C is M x N, inner dimension K. */
+/* dgemm (lapack.h:165-181; CMatrix::gemm): C := alpha*op(A)*op(B) + beta*C, C is M x N, inner dimension K.  All four operand
+ * forms run on the MFMA pipeline when M, N are even, K % 16 == 0, leading dimensions even and bases 16-byte aligned.  A
+ * product with few tiles and a long K is cut along k into pieces that go through a scratch buffer of the CALLING HOST THREAD:
+ * like every other scratch of this library it assumes that one host thread issues to one stream at a time. */
 int gpc_gemm_f64(char transa, char transb, int64_t M, int64_t N, int64_t K, double alpha,
                  const double* A, int64_t lda, const double* B, int64_t ldb, double beta,
                  double* C, int64_t ldc, void* stream);
@@ -345,6 +353,9 @@ int gpc_probe_mfma_f64(double* tflops, double* cycles_per_mfma_per_simd, double*
  * out[(b * 64 + c) * 4 + k], block (b, c) of the panel (b, c < 64), k = start / products done / block ready / end, in ticks of
  * the 100 MHz constant clock (tools/flow_check.py prints them).  n = number of values wanted (<= 64 * 64 * 4). */
 int gpc_debug_panel_flow_trace(long long* out, int64_t n);
+/* y[i] = the table-driven exponential of the Gram / gradient epilogues (csrc/gpc_exp.hpp) at x[i], device arrays of n doubles:
+ * lets the tests hold that primitive itself to a relative error bound. */
+int gpc_debug_exp_f64(const double* x, double* y, int64_t n, void* stream);
 
 /* ---- tuning knobs (also read from env GPC_NB / GPC_JB on first use) ---------------------------------------------- */
 /* Outer panel width of gpc_potrf_f64.  Unset (and no GPC_NB), the width follows the remaining columns (potrf.hip

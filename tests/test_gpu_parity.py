@@ -38,6 +38,29 @@ def spd(n, seed, cond_shift=1.0):
     return A @ A.T / n + cond_shift * np.eye(n)
 
 
+def test_exp_primitive(api):
+    """The table-driven exponential of the Gram / gradient epilogues (csrc/gpc_exp.hpp: 64-entry table of 2^(j/64), Cody-Waite
+    reduction, degree-5 polynomial) against extended-precision exp over the arguments the kernels produce (-0.5 gamma d^2 <= 0,
+    plus the few ulp above zero that |x|^2 + |x'|^2 - 2 x.x' can give): relative error <= 4e-16."""
+    import torch
+    rng = np.random.RandomState(1)
+    x = np.concatenate([rng.uniform(-1.0, 0.0, 400000), rng.uniform(-30.0, 0.0, 400000), rng.uniform(-700.0, 0.0, 400000),
+                        rng.uniform(-1e-9, 1e-9, 1000), np.array([0.0, -0.0, -1e-300, -708.0, 1.0, 2.5])])
+    xd = api.from_host(x.reshape(-1, 1))
+    yd = api.empty(x.size, 1)
+    api.check(api.lib().gpc_debug_exp_f64(api.ptr(xd), api.ptr(yd), x.size, api.stream()))
+    y = api.to_host(yd).ravel()
+    ref = np.exp(x.astype(np.longdouble))
+    rel = np.abs((y.astype(np.longdouble) - ref) / ref)
+    assert float(rel.max()) <= 4e-16, float(rel.max())
+    assert y[x == 0.0].tolist() == [1.0, 1.0]
+    # far below the smallest normal: flushes towards zero like exp itself, never NaN
+    xt = api.from_host(np.array([-745.0, -800.0, -1e6, -1e300]).reshape(-1, 1))
+    yt = api.empty(4, 1)
+    api.check(api.lib().gpc_debug_exp_f64(api.ptr(xt), api.ptr(yt), 4, api.stream()))
+    assert np.all(api.to_host(yt).ravel() <= 1e-300) and np.all(api.to_host(yt).ravel() >= 0.0)
+
+
 # ---- GEMM / SYRK ------------------------------------------------------------------------------------------------------
 
 @pytest.mark.parametrize("ta,tb", [("N", "N"), ("N", "T"), ("T", "N"), ("T", "T")])
