@@ -8,6 +8,8 @@ from ctypes import (POINTER, Structure, c_char, c_char_p, c_double, c_int, c_int
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "lib", "libgpc_hip.so")
+if os.environ.get("GPC_LIB_VARIANT"):     # A/B measurement aid: another BUILD of the same library (tools only; never a fallback)
+    LIB_PATH = os.path.join(HERE, "lib", "libgpc_hip_%s.so" % os.environ["GPC_LIB_VARIANT"])
 
 GPC_OK = 0
 GPC_EINVAL, GPC_ENODEV, GPC_EHIP, GPC_ENOMEM, GPC_EUNSUPPORTED = -1, -2, -3, -4, -5

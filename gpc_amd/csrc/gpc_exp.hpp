@@ -3,9 +3,9 @@
 //     x = (64 m + j) ln2/64 + f,  |f| <= ln2/128:   exp(x) = 2^m * 2^(j/64) * (1 + f + f^2/2 + ... + f^5/120)
 // 64 correctly rounded values of 2^(j/64) in LDS (one ds_read_b64 per call), a two-constant Cody-Waite reduction, a
 // degree-5 polynomial (the first neglected term is f^6/720 < 3.5e-17), v_ldexp_f64.  Maximum relative error 2.3e-16 over
-// [-700, 0] (tools/exp_accuracy.py; libm: 1.3e-16) at ~16 vector instructions instead of the ~40 of ocml's exp (whose 11 Horner
+// [-700, 0] (tests: test_exp_primitive; libm: 1.3e-16) at ~20 vector instructions instead of the ~40 of ocml's exp (whose 11 Horner
 // steps each compile to a v_mov_b64 of the coefficient + v_fmac_f64): the exponentials were 1.7 of the 8.0 ms of the N = 65 536
-// Gram build and a third of the gradient passes' vector work.  x = -inf gives NaN (no clamp on the path); NaN stays NaN.
+// Gram build and a third of the gradient passes' vector work.  x < -745.2 (and -inf) gives 0; NaN stays NaN.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -50,7 +50,10 @@ __device__ __forceinline__ double gpc_exp_tab(double x, const double* __restrict
   const double u = fma(f, 0x1.999999999999ap-3, 1.0);
   const double w = f2 * 0x1.5555555555555p-5;
   const double pm1 = fma(f2, fma(w, u, a), f);
-  return ldexp(fma(T, pm1, T), ni >> 6);
+  const double r = ldexp(fma(T, pm1, T), ni >> 6);
+  // The reduction is exact only while n * hi is (|x| < ~2800); below the underflow threshold the answer is 0 whatever the
+  // arithmetic above made of it (also for -inf).  A compare + select, so that NaN stays NaN.
+  return (x < -745.2) ? 0.0 : r;
 }
 
 }  // namespace gpc

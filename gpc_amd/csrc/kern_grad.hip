@@ -205,12 +205,19 @@ constexpr int GMI = 128, GMJ = 64, GSJ = 80, GMDC = 32, GSI = 144;
 // From this many k-steps (D > 12) the kernel does not request the next half-tile's covGrad values while it works on the current
 // one: holding them costs 32 registers, which at NK >= 4 meant scratch; the CU's other workgroup covers the latency instead
 // (N = 65 536: D = 16 6.4 -> 5.8 ms, D = 32 7.4 -> 6.9 ms; below that the early request still wins by a few per cent).
+#ifndef GPC_KG_TABLE_EXP
+#define GPC_KG_TABLE_EXP 1
+#endif
 #ifndef GPC_KG_LEAN_NK
 #define GPC_KG_LEAN_NK 4
 #endif
 typedef double gdouble4 __attribute__((ext_vector_type(4)));
 
-template <int NRBF, int NK, int ND = 0>
+// MODE (round 4): the walk is two launches.  MODE 1 takes the full tiles strictly left of a row block's diagonal block -- all but
+// two tiles of its walk --, which need no edge masks, no diagonal test and carry weight 2: ONE predicate-free form of the tile
+// body.  MODE 2 takes the rest (the diagonal block's two tiles; every tile of a ragged last row block) in the general form.  As two
+// copies of the body inside one kernel the D > 8 instances spilled 200+ registers; as two kernels each sits in its own budget.
+template <int NRBF, int NK, int ND = 0, int MODE = 1>
 __global__ void __launch_bounds__(256, 2) kern_grad_sym_kernel(const KSpecDev ks, const GradArgs g, int jt_per_block,
                                                                double* __restrict__ partial)
 {
@@ -227,9 +234,12 @@ __global__ void __launch_bounds__(256, 2) kern_grad_sym_kernel(const KSpecDev ks
   double* mypartial = partial + ((int64_t)blockIdx.x * gridDim.y + blockIdx.y) * NP_MAIN;
   int64_t tiles_j = (g.N + GMJ - 1) / GMJ;
   if(tiles_j > 2 * ((int64_t)blockIdx.x + 1)) tiles_j = 2 * ((int64_t)blockIdx.x + 1);
-  const int64_t jt0 = (int64_t)blockIdx.y * jt_per_block;
+  int64_t split = (i0 + GMI <= g.N) ? 2 * (int64_t)blockIdx.x : 0;   // tiles [0, split): full and strictly left of the diagonal block
+  if(split > tiles_j) split = tiles_j;
+  const int64_t lo = (MODE == 1) ? 0 : split, hi = (MODE == 1) ? split : tiles_j;
+  const int64_t jt0 = lo + (int64_t)blockIdx.y * jt_per_block;
   int64_t jt1 = jt0 + jt_per_block;
-  if(jt1 > tiles_j) jt1 = tiles_j;
+  if(jt1 > hi) jt1 = hi;
   if(jt0 >= jt1) {
     if(t < NP_MAIN) mypartial[t] = 0.0;
     return;
@@ -291,6 +301,41 @@ __global__ void __launch_bounds__(256, 2) kern_grad_sym_kernel(const KSpecDev ks
 #pragma unroll
   for(int q = 0; q < (NRBF > 0 ? NRBF : 1); q++) s_d2e[q] = s_e[q] = 0.0;
 
+  // covGrad values of a half-tile (16 per lane), requested a half ahead.  MODE 1 keeps that distance ACROSS tiles as well -- the
+  // next tile's first half is requested during this tile's second (round 3 asked for it at the top of the tile, i.e. ~0.5 us
+  // before its use: every tile began with an exposed HBM round trip, which is what held these kernels at 1.7-2.5 TB/s)
+  constexpr bool KFAST = (MODE == 1);
+    constexpr bool LEAN = !KFAST && (NK >= GPC_KG_LEAN_NK);   // MODE 2, D > 12: no covGrad held for the next half
+    double c[LEAN ? 1 : 2][4][4];
+    auto load_cg = [&](int tn, const int64_t j0) {
+      const bool full = KFAST || ((i0 + GMI <= g.N) && (j0 + GMJ <= g.N));
+#pragma unroll
+      for(int r = 0; r < 4; r++) {
+        const int64_t gj = j0 + wn * 32 + tn * 16 + (lane >> 4) + 4 * r;
+        const int64_t gjc = (KFAST || gj < g.N) ? gj : (g.N - 1);
+        double aj[ND > 0 ? ND : 1];
+#pragma unroll
+        for(int o = 0; o < ND; o++) aj[o] = g.A[gjc + (int64_t)o * g.lda];
+#pragma unroll
+        for(int tm = 0; tm < 4; tm++) {
+          const int64_t gi = i0 + wm * 64 + tm * 16 + (lane & 15);
+          const int64_t gic = (KFAST || gi < g.N) ? gi : (g.N - 1);
+          double v = g.cg[gic + gjc * g.ldc];
+          if(ND > 0) {   // covGrad from invK: same operations as covgrad_kernel / covgrad_multi_kernel, element by element
+            double aa = 0.0;
+#pragma unroll
+            for(int o = 0; o < ND; o++) aa = fma(ai[o][tm], aj[o], aa);
+            v = -0.5 * ((double)ND * v - aa);
+          }
+          c[LEAN ? 0 : tn][r][tm] = (KFAST || full || (gi < g.N && gj < g.N)) ? v : 0.0;
+        }
+      }
+    };
+  // (D <= 8: with the table exponential the two live halves across the loop edge spill 200 registers -- 4.3 -> 22 ms --, so there
+  //  the first half of a tile is requested at its top as before)
+  constexpr bool XPREF = KFAST && !LEAN && NK > 2;
+  if(XPREF) load_cg(0, jt0 * GMJ);
+
   for(int64_t jt = jt0; jt < jt1; jt++) {
     double* Xjb = Xj[(jt - jt0) & 1];
     double* Njb = Nj[(jt - jt0) & 1];
@@ -311,18 +356,11 @@ __global__ void __launch_bounds__(256, 2) kern_grad_sym_kernel(const KSpecDev ks
     const bool mirror = (j0 + GMJ <= i0);   // strictly left of the diagonal block: every element stands for two
     // FAST (round 4): a full tile strictly left of the diagonal block -- all but two tiles of a walk -- has no edge masks and no
     // diagonal elements: no selects around the loads, no 64-bit compares in the sums, weight 2 folded into the final sums
-    // The fast form and the table-driven exponential (gpc_exp.hpp) for D <= 8 only: from NK = 4 the kernel sits at its 256
-    // registers and either of them spills (D = 16: 5.8 -> 17 ms with both).  D = 8: 5.1 -> 4.2 ms.
-#define KG_EXP(x) (NK <= 2 ? gpc_exp_tab((x), Etab) : exp(x))
-    if(NK <= 2 && full && mirror) {
-#define KG_FAST true
+    // MODE 1 = the fast form (KG_FAST) with the table-driven exponential of gpc_exp.hpp; MODE 2 the general form with ocml's
+#define KG_EXP(x) ((MODE == 1 && NK <= 2 && GPC_KG_TABLE_EXP) ? gpc_exp_tab((x), Etab) : exp(x))
+#define KG_FAST (MODE == 1)
 #include "kern_grad_sym_tile.inc"
 #undef KG_FAST
-    } else {
-#define KG_FAST false
-#include "kern_grad_sym_tile.inc"
-#undef KG_FAST
-    }
 #undef KG_EXP
   }
   double out[NP_MAIN];
@@ -347,17 +385,24 @@ __global__ void __launch_bounds__(256, 2) kern_grad_sym_kernel(const KSpecDev ks
   }
 }
 
+// two launches: the fast tiles on `grid` (partials at partial[0 .. grid.x * grid.y)), the diagonal blocks / ragged row block with one
+// workgroup per row block (partials behind them: grid.x more)
 template <int NRBF, int ND>
 int launch_grad_sym_nd(const KSpecDev& ks, const GradArgs& g, int per, dim3 grid, double* partial, hipStream_t s)
 {
-  if(g.D <= 4)
-    hipLaunchKernelGGL((kern_grad_sym_kernel<NRBF, 1, ND>), grid, dim3(256), 0, s, ks, g, per, partial);
-  else if(g.D <= 8)
-    hipLaunchKernelGGL((kern_grad_sym_kernel<NRBF, 2, ND>), grid, dim3(256), 0, s, ks, g, per, partial);
-  else if(g.D <= 16)
-    hipLaunchKernelGGL((kern_grad_sym_kernel<NRBF, 4, ND>), grid, dim3(256), 0, s, ks, g, per, partial);
-  else
-    hipLaunchKernelGGL((kern_grad_sym_kernel<NRBF, 8, ND>), grid, dim3(256), 0, s, ks, g, per, partial);
+  double* p2 = partial + (size_t)grid.x * grid.y * NP_MAIN;
+  const dim3 grid2(grid.x, 1);
+  const int per2 = 1 << 30;
+#define GPC_SYM_LAUNCH2(NKV)                                                                                                  \
+  do {                                                                                                                        \
+    hipLaunchKernelGGL((kern_grad_sym_kernel<NRBF, NKV, ND, 1>), grid, dim3(256), 0, s, ks, g, per, partial);                 \
+    hipLaunchKernelGGL((kern_grad_sym_kernel<NRBF, NKV, ND, 2>), grid2, dim3(256), 0, s, ks, g, per2, p2);                    \
+  } while(0)
+  if(g.D <= 4) GPC_SYM_LAUNCH2(1);
+  else if(g.D <= 8) GPC_SYM_LAUNCH2(2);
+  else if(g.D <= 16) GPC_SYM_LAUNCH2(4);
+  else GPC_SYM_LAUNCH2(8);
+#undef GPC_SYM_LAUNCH2
   GPC_HIP_CHECK(hipGetLastError());
   return GPC_OK;
 }
@@ -418,7 +463,7 @@ __global__ void __launch_bounds__(256) ard_prep_kernel(const KSpecDev ks, const 
 // NW waves per workgroup: 4 (each a 64 x 32 patch of the 128 x 64 tile) or 8 (32 x 32 each: half the per-lane state -- the
 // accumulators Y, the covGrad values, the dot products -- so that at D > 16, where the 4-wave form fits one wave per SIMD
 // only, two waves share a SIMD without spilling and cover each other's memory latency).
-template <int NK, int ND, int OCC, int NW = 4>
+template <int NK, int ND, int OCC, int NW = 4, int MODE = 1>   // MODE: as kern_grad_sym_kernel
 __global__ void __launch_bounds__(64 * NW, OCC) kern_grad_ard_sym_kernel(const KSpecDev ks, const GradArgs g, const double* __restrict__ XT,
                                                                    int jt_per_block, double* __restrict__ partial)
 {
@@ -442,9 +487,12 @@ __global__ void __launch_bounds__(64 * NW, OCC) kern_grad_ard_sym_kernel(const K
   double* mypartial = partial + ((int64_t)blockIdx.x * gridDim.y + blockIdx.y) * NP_ARDSYM;
   int64_t tiles_j = (g.N + GMJ - 1) / GMJ;
   if(tiles_j > 2 * ((int64_t)blockIdx.x + 1)) tiles_j = 2 * ((int64_t)blockIdx.x + 1);
-  const int64_t jt0 = (int64_t)blockIdx.y * jt_per_block;
+  int64_t split = (i0 + GMI <= g.N) ? 2 * (int64_t)blockIdx.x : 0;   // tiles [0, split): full and strictly left of the diagonal block
+  if(split > tiles_j) split = tiles_j;
+  const int64_t lo = (MODE == 1) ? 0 : split, hi = (MODE == 1) ? split : tiles_j;
+  const int64_t jt0 = lo + (int64_t)blockIdx.y * jt_per_block;
   int64_t jt1 = jt0 + jt_per_block;
-  if(jt1 > tiles_j) jt1 = tiles_j;
+  if(jt1 > hi) jt1 = hi;
   if(jt0 >= jt1) {
     if(t < NP_ARDSYM) mypartial[t] = 0.0;
     return;
@@ -515,6 +563,37 @@ __global__ void __launch_bounds__(64 * NW, OCC) kern_grad_ard_sym_kernel(const K
     for(int qx = 0; qx < QX; qx++) Y1[tm][qx] = (gdouble4){0.0, 0.0, 0.0, 0.0};
   const double hiw = ks.ard_hiw[0];
 
+  // covGrad values of a half-tile, requested a half ahead -- in MODE 1 across tiles as well (see kern_grad_sym_kernel)
+  constexpr bool KFAST = (MODE == 1);
+    constexpr bool LEAN = (OCC == 2);   // two workgroups per CU: no covGrad held for the next half (the other workgroup's waves cover the latency)
+    double c[LEAN ? 1 : 2][4][TM];
+    auto load_cg = [&](int tn, const int64_t j0) {
+      const bool full = KFAST || ((i0 + GMI <= g.N) && (j0 + GMJ <= g.N));
+#pragma unroll
+      for(int r = 0; r < 4; r++) {
+        const int64_t gj = j0 + wn * 32 + tn * 16 + (lane >> 4) + 4 * r;
+        const int64_t gjc = (KFAST || gj < g.N) ? gj : (g.N - 1);
+        double aj[ND > 0 ? ND : 1];
+#pragma unroll
+        for(int o = 0; o < ND; o++) aj[o] = g.A[gjc + (int64_t)o * g.lda];
+#pragma unroll
+        for(int tm = 0; tm < TM; tm++) {
+          const int64_t gi = i0 + wm * RW + tm * 16 + (lane & 15);
+          const int64_t gic = (KFAST || gi < g.N) ? gi : (g.N - 1);
+          double v = g.cg[gic + gjc * g.ldc];
+          if(ND > 0) {
+            double aa = 0.0;
+#pragma unroll
+            for(int o = 0; o < ND; o++) aa = fma(ai[o][tm], aj[o], aa);
+            v = -0.5 * ((double)ND * v - aa);
+          }
+          c[LEAN ? 0 : tn][r][tm] = (KFAST || full || (gi < g.N && gj < g.N)) ? v : 0.0;
+        }
+      }
+    };
+  constexpr bool XPREF = KFAST && !LEAN;
+  if(XPREF) load_cg(0, jt0 * GMJ);
+
   for(int64_t jt = jt0; jt < jt1; jt++) {
     double* Xjb = Xj[(jt - jt0) & 1];
     double* Njb = Nj[(jt - jt0) & 1];
@@ -531,16 +610,11 @@ __global__ void __launch_bounds__(64 * NW, OCC) kern_grad_ard_sym_kernel(const K
     const bool full = (i0 + GMI <= g.N) && (j0 + GMJ <= g.N);
     const bool mirror = (j0 + GMJ <= i0);
     // FAST (round 4): full tiles strictly left of the diagonal block -- no edge masks, no diagonal elements, weight 2
-    // (the fast form up to D = 16: beyond, the second copy pushes the eight-wave instance over its 256 registers for no gain)
-    if(NK <= 4 && full && mirror) {
-#define KG_FAST true
+#define KG_EXP(x) (MODE == 1 ? gpc_exp_tab((x), Etab) : exp(x))
+#define KG_FAST (MODE == 1)
 #include "kern_grad_ard_tile.inc"
 #undef KG_FAST
-    } else {
-#define KG_FAST false
-#include "kern_grad_ard_tile.inc"
-#undef KG_FAST
-    }
+#undef KG_EXP
   }
 
   // ---- the walk is over: scalars as in kern_grad_sym_kernel, then S_q -----------------------------------------------------
@@ -610,6 +684,10 @@ __global__ void __launch_bounds__(64 * NW, OCC) kern_grad_ard_sym_kernel(const K
 template <int ND>
 int launch_grad_ard_sym(const KSpecDev& ks, const GradArgs& g, const double* XT, int per, dim3 grid, double* partial, hipStream_t s)
 {
+  // two launches (MODE 1 / 2, see kern_grad_sym_kernel): the second one's partials follow the first one's
+  double* p2 = partial + (size_t)grid.x * grid.y * NP_ARDSYM;
+  const dim3 grid2(grid.x, 1);
+  const int per2 = 1 << 30;
   // workgroups per CU the kernel is compiled for.  At two per CU (256 registers a wave) the variant keeps no covGrad values for
   // the next half in registers (the other workgroup's waves cover that latency) and still spills a little; that wins up to
   // D = 16 (N = 65 536: D = 4 6.3 ms, D = 8 6.9 ms = 2.5 TB/s of the 4 N^2 bytes, D = 16 8.6 ms, against 18.2 / 8.4 / 8.9 ms at
@@ -635,8 +713,9 @@ int launch_grad_ard_sym(const KSpecDev& ks, const GradArgs& g, const double* XT,
     const int occ = (nw_env == 82) ? 2 : 1;     // (8 / 82: eight waves at every D, one / two workgroups per CU; A/B runs)
 #define GPC_ARD_LAUNCH8(NKV)                                                                                                    \
   do {                                                                                                                            \
-    if(occ == 1) hipLaunchKernelGGL((kern_grad_ard_sym_kernel<NKV, ND, 1, 8>), grid, dim3(512), 0, s, ks, g, XT, per, partial);   \
-    else hipLaunchKernelGGL((kern_grad_ard_sym_kernel<NKV, ND, 2, 8>), grid, dim3(512), 0, s, ks, g, XT, per, partial);           \
+    if(occ == 1) hipLaunchKernelGGL((kern_grad_ard_sym_kernel<NKV, ND, 1, 8, 1>), grid, dim3(512), 0, s, ks, g, XT, per, partial);   \
+    else hipLaunchKernelGGL((kern_grad_ard_sym_kernel<NKV, ND, 2, 8, 1>), grid, dim3(512), 0, s, ks, g, XT, per, partial);           \
+    hipLaunchKernelGGL((kern_grad_ard_sym_kernel<NKV, ND, 1, 8, 2>), grid2, dim3(512), 0, s, ks, g, XT, per2, p2);                    \
   } while(0)
     if(g.D <= 4) GPC_ARD_LAUNCH8(1);
     else if(g.D <= 8) GPC_ARD_LAUNCH8(2);
@@ -649,9 +728,10 @@ int launch_grad_ard_sym(const KSpecDev& ks, const GradArgs& g, const double* XT,
 #define GPC_ARD_LAUNCH(NKV)                                                                                              \
   do {                                                                                                                     \
     if(occ8 == 1)                                                                                                          \
-      hipLaunchKernelGGL((kern_grad_ard_sym_kernel<NKV, ND, 1>), grid, dim3(256), 0, s, ks, g, XT, per, partial);          \
+      hipLaunchKernelGGL((kern_grad_ard_sym_kernel<NKV, ND, 1, 4, 1>), grid, dim3(256), 0, s, ks, g, XT, per, partial);    \
     else                                                                                                                   \
-      hipLaunchKernelGGL((kern_grad_ard_sym_kernel<NKV, ND, 2>), grid, dim3(256), 0, s, ks, g, XT, per, partial);          \
+      hipLaunchKernelGGL((kern_grad_ard_sym_kernel<NKV, ND, 2, 4, 1>), grid, dim3(256), 0, s, ks, g, XT, per, partial);    \
+    hipLaunchKernelGGL((kern_grad_ard_sym_kernel<NKV, ND, 1, 8, 2>), grid2, dim3(512), 0, s, ks, g, XT, per2, p2);          \
   } while(0)
   if(g.D <= 4) GPC_ARD_LAUNCH(1);
   else if(g.D <= 8) GPC_ARD_LAUNCH(2);
@@ -915,7 +995,8 @@ static int kern_grad_pass(const gpc_kspec* ksp, const double* X, int64_t N, int6
   int64_t sym_per = sym_nrb * (sym_nrb + 1) / 768;
   if(sym_per < 4) sym_per = 4;
   if(sym_per > 48) sym_per = 48;
-  const int64_t sym_ny = (2 * sym_nrb + sym_per - 1) / sym_per, sym_nwg = sym_nrb * sym_ny;
+  const int64_t sym_ny = (2 * sym_nrb + sym_per - 1) / sym_per;
+  const int64_t sym_nwg = sym_nrb * sym_ny + sym_nrb;   // the fast tiles' workgroups + one per row block for its diagonal block (two launches)
   size_t pbytes = sizeof(double) * (size_t)nblk * (NP_MAIN > ARD_PASS ? NP_MAIN : ARD_PASS);
   if(pbytes < sizeof(double) * (size_t)sym_nwg * NP_MAIN) pbytes = sizeof(double) * (size_t)sym_nwg * NP_MAIN;
   GPC_CHECK(workspace(WS_KERN, sizeof(double) * (size_t)N + pbytes, &ws));

@@ -55,10 +55,11 @@ def test_exp_primitive(api):
     assert float(rel.max()) <= 4e-16, float(rel.max())
     assert y[x == 0.0].tolist() == [1.0, 1.0]
     # far below the smallest normal: flushes towards zero like exp itself, never NaN
-    xt = api.from_host(np.array([-745.0, -800.0, -1e6, -1e300]).reshape(-1, 1))
-    yt = api.empty(4, 1)
-    api.check(api.lib().gpc_debug_exp_f64(api.ptr(xt), api.ptr(yt), 4, api.stream()))
-    assert np.all(api.to_host(yt).ravel() <= 1e-300) and np.all(api.to_host(yt).ravel() >= 0.0)
+    xt = api.from_host(np.array([-745.0, -800.0, -1e6, -1e300, -np.inf, np.nan]).reshape(-1, 1))
+    yt = api.empty(6, 1)
+    api.check(api.lib().gpc_debug_exp_f64(api.ptr(xt), api.ptr(yt), 6, api.stream()))
+    yh = api.to_host(yt).ravel()
+    assert np.all(yh[:5] <= 1e-300) and np.all(yh[:5] >= 0.0) and np.isnan(yh[5])
 
 
 # ---- GEMM / SYRK ------------------------------------------------------------------------------------------------------
