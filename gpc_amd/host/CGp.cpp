@@ -31,7 +31,7 @@ CGp::CGp(CKern* kernel, CNoise* nois, CMatrix* Xin, int approx, unsigned int act
     : pX(Xin), py(nois->py), pkern(kernel), pnoise(nois), ownsKernNoise(false), fileNumData(0), fileInputDim(0),
       numActive(actSetSize), scale(1, nois->getOutputDim(), 1.0),
       bias(1, nois->getOutputDim(), 0.0), refTransRounding(true), MupToDate(false), KupToDate(false),
-      AlphaUpToDate(false), invKupToDate(false), invKmUpToDate(false), LcholRounded(false), dX(0), dM(0), dL(0), dInvKm(0), dAlpha(0), dInvK(0),
+      AlphaUpToDate(false), invKupToDate(false), invKmUpToDate(false), LcholRounded(false), dGradScr(0), gradScrLen(0), dX(0), dM(0), dL(0), dInvKm(0), dAlpha(0), dInvK(0),
       dCovGrad(0), logDetK(0.0), lastJitter(0.0), needInverse(false), approxType(approx), betaVal(1e3),
       inducingFixed(false), dXu(0), dKuu(0), dKuf(0), dInvKuu(0), dA(0), dAinv(0), dLA(0), dE(0), dAlphaU(0), dIKK(0),
       logDetKuu(0.0), logDetA(0.0), sumDiagD(0.0), LArounded(false), dVf(0), dBet(0), sumLogDiagD(0.0), sumLogLm(0.0), sMsM(0.0),
@@ -57,7 +57,7 @@ CGp::CGp(CKern* kernel, CNoise* nois, CMatrix* Xin, int approx, unsigned int act
 CGp::CGp()
     : pX(0), py(0), pkern(0), pnoise(0), ownsKernNoise(true), fileNumData(0), fileInputDim(0), numActive(0), scale(1, 1, 1.0),
       bias(1, 1, 0.0), refTransRounding(true), MupToDate(false), KupToDate(false), AlphaUpToDate(false),
-      invKupToDate(false), invKmUpToDate(false), LcholRounded(false), dX(0), dM(0), dL(0), dInvKm(0), dAlpha(0), dInvK(0), dCovGrad(0), logDetK(0.0), lastJitter(0.0),
+      invKupToDate(false), invKmUpToDate(false), LcholRounded(false), dGradScr(0), gradScrLen(0), dX(0), dM(0), dL(0), dInvKm(0), dAlpha(0), dInvK(0), dCovGrad(0), logDetK(0.0), lastJitter(0.0),
       needInverse(false), approxType(FTC), betaVal(1e3), inducingFixed(false), dXu(0), dKuu(0), dKuf(0), dInvKuu(0), dA(0),
       dAinv(0), dLA(0), dE(0), dAlphaU(0), dIKK(0), logDetKuu(0.0), logDetA(0.0), sumDiagD(0.0), LArounded(false), dVf(0), dBet(0), sumLogDiagD(0.0),
       sumLogLm(0.0), sMsM(0.0), gridPr(1), gridPc(1), gridDecided(0), gridNs(-1), gridProblemStale(true)
@@ -116,6 +116,17 @@ CGp::~CGp()
   devFree(dIKK);
   devFree(dVf);
   devFree(dBet);
+  devFree(dGradScr);
+}
+
+double* CGp::gradScratch(size_t n) const
+{
+  if(n > gradScrLen) {
+    devFree(dGradScr);
+    dGradScr = devAlloc(n);
+    gradScrLen = n;
+  }
+  return dGradScr;
 }
 
 void CGp::updateM() const
@@ -766,9 +777,12 @@ void CGp::gradientDtc(CMatrix& g) const
   if(g.getRows() != 1 || g.getCols() != getOptNumParams())
     throw ndlexceptions::MatrixError("logLikelihoodGradient: g must be 1 x nParams");
   const double beta = betaVal, dd = (double)d;
-  double *dEET = devAlloc((size_t)M * M), *dAinvEET = devAlloc((size_t)M * M), *dAEA = devAlloc((size_t)M * M),
-         *dGKuu = devAlloc((size_t)M * M), *dAinvKuf = devAlloc((size_t)M * N), *dGKuf = devAlloc((size_t)M * N),
-         *dGXa = devAlloc((size_t)M * D), *dGXb = devAlloc((size_t)M * D);
+  // temporaries: one block kept between evaluations (M x M: EET, AinvEET, AEA, gK_uu, B; M x N: gK_uf;
+  // M x D: the two inducing-input gradients)
+  const size_t mm = (size_t)M * M, mn = (size_t)M * N, md = (size_t)M * D;
+  double* scr = gradScratch(5 * mm + mn + 2 * md + (size_t)M * (d > M ? d : 0));
+  double *dEET = scr, *dAinvEET = dEET + mm, *dAEA = dAinvEET + mm, *dGKuu = dAEA + mm, *dBmat = dGKuu + mm,
+         *dGKuf = dBmat + mm, *dGXa = dGKuf + mn, *dGXb = dGXa + md, *dAinvEbig = dGXb + md;
   gpc_kspec ks;
   pkern->toKspec(ks);
   std::vector<double> t1(nk > 0 ? nk : 1), t2(nk > 0 ? nk : 1), gxa((size_t)M * D), gxb((size_t)M * D), tmp((size_t)(M > d ? M : d));
@@ -784,17 +798,17 @@ void CGp::gradientDtc(CMatrix& g) const
     gpcCheck(gpc_axpby_f64(M, M, -0.5, dAEA, M, 1.0, dGKuu, M, 0));
     if(approxType == DTCVAR)   // gK_uu.syrk(invK_uuK_uf, -beta d, 1.0) before the 0.5 (CGp.cpp:1275-1279)
       gpcCheck(gpc_gemm_f64('N', 'T', M, M, N, -0.5 * beta * dd, dIKK, M, dIKK, M, 1.0, dGKuu, M, 0));
-    // gK_uf = -beta * (AinvEET * AinvK_uf - Ainv * E m') - d * AinvK_uf, with Ainv * (E m') = (Ainv E) m'
-    gpcCheck(gpc_gemm_f64('N', 'N', M, N, M, 1.0, dAinv, M, dKuf, M, 0.0, dAinvKuf, M, 0));
-    double* dAinvE = dEET;   // EET is no longer needed: reuse its storage (M x d <= M x M when d <= M)
-    const bool ownAinvE = d > M;
-    if(ownAinvE) dAinvE = devAlloc((size_t)M * d);
+    // gK_uf = -beta * (AinvEET * Ainv K_uf - Ainv * E m') - d * Ainv K_uf  (CGp.cpp:1281-1291)
+    //       = beta (Ainv E) m'  -  (beta AinvEETAinv + d Ainv) K_uf:
+    // the two M x N x M products of the reference's sequence (Ainv K_uf, then AinvEET times it) are ONE product with the M x M
+    // matrix B = beta AEA + d Ainv, which is already at hand -- 1.4e11 flops less per evaluation at M = 1024, N = 65 536
+    gpcCheck(gpc_axpby_f64(M, M, beta, dAEA, M, 0.0, dBmat, M, 0));
+    gpcCheck(gpc_axpby_f64(M, M, dd, dAinv, M, 1.0, dBmat, M, 0));
+    double* dAinvE = (d > M) ? dAinvEbig : dEET;   // EET is no longer needed: reuse its storage (M x d <= M x M when d <= M)
     gpcCheck(gpc_gemm_f64('N', 'N', M, d, M, 1.0, dAinv, M, dE, M, 0.0, dAinvE, M, 0));
     gpcCheck(gpc_gemm_f64('N', 'T', M, N, d, beta, dAinvE, M, dM, N, 0.0, dGKuf, M, 0));             //  beta * AinvEMT
-    gpcCheck(gpc_gemm_f64('N', 'N', M, N, M, -beta, dAinvEET, M, dAinvKuf, M, 1.0, dGKuf, M, 0));    // -beta * AinvEET AinvK_uf
-    gpcCheck(gpc_axpby_f64(M, N, -dd, dAinvKuf, M, 1.0, dGKuf, M, 0));
+    gpcCheck(gpc_gemm_f64('N', 'N', M, N, M, -1.0, dBmat, M, dKuf, M, 1.0, dGKuf, M, 0));            // -(beta AEA + d Ainv) K_uf
     if(approxType == DTCVAR) gpcCheck(gpc_axpby_f64(M, N, beta * dd, dIKK, M, 1.0, dGKuf, M, 0));   // CGp.cpp:1292-1295
-    if(ownAinvE) devFree(dAinvE);
     // d/d beta
     double trAK = 0.0, trAEAK = 0.0, trAinvEET = 0.0;
     std::vector<double> cd((size_t)M), mm((size_t)d);
@@ -822,10 +836,8 @@ void CGp::gradientDtc(CMatrix& g) const
       gpcCheck(gpc_memcpy_d2h(&gxb[0], dGXb, sizeof(double) * gxb.size(), 0));
     }
   } catch(...) {
-    devFree(dEET); devFree(dAinvEET); devFree(dAEA); devFree(dGKuu); devFree(dAinvKuf); devFree(dGKuf); devFree(dGXa); devFree(dGXb);
     throw;
   }
-  devFree(dEET); devFree(dAinvEET); devFree(dAEA); devFree(dGKuu); devFree(dAinvKuf); devFree(dGKuf); devFree(dGXa); devFree(dGXb);
   // chain rule for the kernel parameters: each pass is transformed on its own in the reference; the sum is the same
   for(unsigned int i = 0; i < nk; i++) t1[i] += t2[i];
   if(approxType == DTCVAR) {
@@ -993,8 +1005,12 @@ void CGp::gradientFitc(CMatrix& g) const
     gpcCheck(gpc_gemm_f64('N', 'T', M, M, N, 0.5 * beta, dIKKDQ, M, dIKKD, M, 1.0, dGKuu, M, 0));
     // gK_uf = (-beta invK_uuK_ufDinvQ - d Ainv K_uf - beta AinvEETAinv K_uf + beta AinvEMT) D^-1
     gpcCheck(gpc_axpby_f64(M, N, -beta, dIKKDQ, M, 0.0, dGKuf, M, 0));
-    gpcCheck(gpc_gemm_f64('N', 'N', M, N, M, -dd, dAinv, M, dKuf, M, 1.0, dGKuf, M, 0));
-    gpcCheck(gpc_gemm_f64('N', 'N', M, N, M, -beta, dAEA, M, dKuf, M, 1.0, dGKuf, M, 0));
+    {   // (d Ainv + beta AEA) K_uf as ONE M x N x M product (as in the DTC branch)
+      double* dB = gradScratch((size_t)M * M);
+      gpcCheck(gpc_axpby_f64(M, M, dd, dAinv, M, 0.0, dB, M, 0));
+      gpcCheck(gpc_axpby_f64(M, M, beta, dAEA, M, 1.0, dB, M, 0));
+      gpcCheck(gpc_gemm_f64('N', 'N', M, N, M, -1.0, dB, M, dKuf, M, 1.0, dGKuf, M, 0));
+    }
     gpcCheck(gpc_axpby_f64(M, N, beta, dAinvEMT, M, 1.0, dGKuf, M, 0));
     gpcCheck(gpc_scale_vec_f64(M, N, dGKuf, M, dVec, 0, 0));
     // kernel parameters and inducing inputs
