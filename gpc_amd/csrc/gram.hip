@@ -724,7 +724,7 @@ int launch_gram(const KSpecDev& ks, const GramArgs& g, hipStream_t s)
         static const int64_t pair_wgs = [] { const char* e = getenv("GPC_GRAM_PAIR_WGS"); return e ? atoll(e) : (int64_t)1024; }();
         GramArgs gp = g;
         gp.pair_chunks = 0;
-        if(pairs_on) {
+        if(pairs_on && tiles_i >= 32) {   // (small matrices: a tile per workgroup fills more of the chip than eight-tile chunks of a few pairs)
           const int64_t npairs = (tiles_i + 1) / 2, L = 2 * tiles_i + 2;
           int64_t C = (pair_wgs + npairs - 1) / npairs;
           if(C > L / 8) C = L / 8;

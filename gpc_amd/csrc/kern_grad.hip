@@ -41,6 +41,8 @@ struct GradArgs {
   const double* A;
   int64_t lda;
   int nd;
+  int all_general;   // symmetric kernels: 1 = ONE launch, every tile in the general form (small N: a second launch costs more than the
+                     // predicate-free form saves); 0 = two launches, MODE 1 + MODE 2
 };
 
 template <int NW>
@@ -234,7 +236,7 @@ __global__ void __launch_bounds__(256, 2) kern_grad_sym_kernel(const KSpecDev ks
   double* mypartial = partial + ((int64_t)blockIdx.x * gridDim.y + blockIdx.y) * NP_MAIN;
   int64_t tiles_j = (g.N + GMJ - 1) / GMJ;
   if(tiles_j > 2 * ((int64_t)blockIdx.x + 1)) tiles_j = 2 * ((int64_t)blockIdx.x + 1);
-  int64_t split = (i0 + GMI <= g.N) ? 2 * (int64_t)blockIdx.x : 0;   // tiles [0, split): full and strictly left of the diagonal block
+  int64_t split = (i0 + GMI <= g.N && !g.all_general) ? 2 * (int64_t)blockIdx.x : 0;   // tiles [0, split): full and strictly left of the diagonal block
   if(split > tiles_j) split = tiles_j;
   const int64_t lo = (MODE == 1) ? 0 : split, hi = (MODE == 1) ? split : tiles_j;
   const int64_t jt0 = lo + (int64_t)blockIdx.y * jt_per_block;
@@ -385,18 +387,32 @@ __global__ void __launch_bounds__(256, 2) kern_grad_sym_kernel(const KSpecDev ks
   }
 }
 
-// two launches: the fast tiles on `grid` (partials at partial[0 .. grid.x * grid.y)), the diagonal blocks / ragged row block with one
-// workgroup per row block (partials behind them: grid.x more)
+// MODE 2's launch: per row block the two tiles of its diagonal block -- and, when N is not a multiple of 128, every tile of the ragged
+// last row block, which therefore gets a workgroup per two tiles (one workgroup walking all of them was 80 us of a 0.1 ms pass at
+// N = 1000).  Returns the slices per row block.
+constexpr int KG_MODE2_PER = 2;
+static inline int64_t kg_mode2_ny(int64_t N)
+{
+  const int64_t tiles_all = (N + GMJ - 1) / GMJ;
+  return (N % GMI != 0) ? (tiles_all + KG_MODE2_PER - 1) / KG_MODE2_PER : 1;
+}
+
+// two launches: the fast tiles on `grid` (partials at partial[0 .. grid.x * grid.y)), the diagonal blocks / ragged row block on
+// grid.x x kg_mode2_ny workgroups (partials behind them)
 template <int NRBF, int ND>
 int launch_grad_sym_nd(const KSpecDev& ks, const GradArgs& g, int per, dim3 grid, double* partial, hipStream_t s)
 {
   double* p2 = partial + (size_t)grid.x * grid.y * NP_MAIN;
-  const dim3 grid2(grid.x, 1);
-  const int per2 = 1 << 30;
+  const dim3 grid2(grid.x, (unsigned)kg_mode2_ny(g.N));
+  const int per2 = KG_MODE2_PER;
 #define GPC_SYM_LAUNCH2(NKV)                                                                                                  \
   do {                                                                                                                        \
-    hipLaunchKernelGGL((kern_grad_sym_kernel<NRBF, NKV, ND, 1>), grid, dim3(256), 0, s, ks, g, per, partial);                 \
-    hipLaunchKernelGGL((kern_grad_sym_kernel<NRBF, NKV, ND, 2>), grid2, dim3(256), 0, s, ks, g, per2, p2);                    \
+    if(g.all_general) {                                                                                                       \
+      hipLaunchKernelGGL((kern_grad_sym_kernel<NRBF, NKV, ND, 2>), grid, dim3(256), 0, s, ks, g, per, partial);               \
+    } else {                                                                                                                  \
+      hipLaunchKernelGGL((kern_grad_sym_kernel<NRBF, NKV, ND, 1>), grid, dim3(256), 0, s, ks, g, per, partial);               \
+      hipLaunchKernelGGL((kern_grad_sym_kernel<NRBF, NKV, ND, 2>), grid2, dim3(256), 0, s, ks, g, per2, p2);                  \
+    }                                                                                                                         \
   } while(0)
   if(g.D <= 4) GPC_SYM_LAUNCH2(1);
   else if(g.D <= 8) GPC_SYM_LAUNCH2(2);
@@ -487,7 +503,7 @@ __global__ void __launch_bounds__(64 * NW, OCC) kern_grad_ard_sym_kernel(const K
   double* mypartial = partial + ((int64_t)blockIdx.x * gridDim.y + blockIdx.y) * NP_ARDSYM;
   int64_t tiles_j = (g.N + GMJ - 1) / GMJ;
   if(tiles_j > 2 * ((int64_t)blockIdx.x + 1)) tiles_j = 2 * ((int64_t)blockIdx.x + 1);
-  int64_t split = (i0 + GMI <= g.N) ? 2 * (int64_t)blockIdx.x : 0;   // tiles [0, split): full and strictly left of the diagonal block
+  int64_t split = (i0 + GMI <= g.N && !g.all_general) ? 2 * (int64_t)blockIdx.x : 0;   // tiles [0, split): full and strictly left of the diagonal block
   if(split > tiles_j) split = tiles_j;
   const int64_t lo = (MODE == 1) ? 0 : split, hi = (MODE == 1) ? split : tiles_j;
   const int64_t jt0 = lo + (int64_t)blockIdx.y * jt_per_block;
@@ -686,8 +702,8 @@ int launch_grad_ard_sym(const KSpecDev& ks, const GradArgs& g, const double* XT,
 {
   // two launches (MODE 1 / 2, see kern_grad_sym_kernel): the second one's partials follow the first one's
   double* p2 = partial + (size_t)grid.x * grid.y * NP_ARDSYM;
-  const dim3 grid2(grid.x, 1);
-  const int per2 = 1 << 30;
+  const dim3 grid2(grid.x, (unsigned)kg_mode2_ny(g.N));
+  const int per2 = KG_MODE2_PER;
   // workgroups per CU the kernel is compiled for.  At two per CU (256 registers a wave) the variant keeps no covGrad values for
   // the next half in registers (the other workgroup's waves cover that latency) and still spills a little; that wins up to
   // D = 16 (N = 65 536: D = 4 6.3 ms, D = 8 6.9 ms = 2.5 TB/s of the 4 N^2 bytes, D = 16 8.6 ms, against 18.2 / 8.4 / 8.9 ms at
@@ -713,9 +729,12 @@ int launch_grad_ard_sym(const KSpecDev& ks, const GradArgs& g, const double* XT,
     const int occ = (nw_env == 82) ? 2 : 1;     // (8 / 82: eight waves at every D, one / two workgroups per CU; A/B runs)
 #define GPC_ARD_LAUNCH8(NKV)                                                                                                    \
   do {                                                                                                                            \
+    if(g.all_general) hipLaunchKernelGGL((kern_grad_ard_sym_kernel<NKV, ND, 1, 8, 2>), grid, dim3(512), 0, s, ks, g, XT, per, partial);  \
+    else {                                                                                                                            \
     if(occ == 1) hipLaunchKernelGGL((kern_grad_ard_sym_kernel<NKV, ND, 1, 8, 1>), grid, dim3(512), 0, s, ks, g, XT, per, partial);   \
     else hipLaunchKernelGGL((kern_grad_ard_sym_kernel<NKV, ND, 2, 8, 1>), grid, dim3(512), 0, s, ks, g, XT, per, partial);           \
     hipLaunchKernelGGL((kern_grad_ard_sym_kernel<NKV, ND, 1, 8, 2>), grid2, dim3(512), 0, s, ks, g, XT, per2, p2);                    \
+    }                                                                                                                                 \
   } while(0)
     if(g.D <= 4) GPC_ARD_LAUNCH8(1);
     else if(g.D <= 8) GPC_ARD_LAUNCH8(2);
@@ -727,11 +746,15 @@ int launch_grad_ard_sym(const KSpecDev& ks, const GradArgs& g, const double* XT,
   }
 #define GPC_ARD_LAUNCH(NKV)                                                                                              \
   do {                                                                                                                     \
+    if(g.all_general) {                                                                                                    \
+      hipLaunchKernelGGL((kern_grad_ard_sym_kernel<NKV, ND, 2, 4, 2>), grid, dim3(256), 0, s, ks, g, XT, per, partial);    \
+    } else {                                                                                                               \
     if(occ8 == 1)                                                                                                          \
       hipLaunchKernelGGL((kern_grad_ard_sym_kernel<NKV, ND, 1, 4, 1>), grid, dim3(256), 0, s, ks, g, XT, per, partial);    \
     else                                                                                                                   \
       hipLaunchKernelGGL((kern_grad_ard_sym_kernel<NKV, ND, 2, 4, 1>), grid, dim3(256), 0, s, ks, g, XT, per, partial);    \
     hipLaunchKernelGGL((kern_grad_ard_sym_kernel<NKV, ND, 1, 8, 2>), grid2, dim3(512), 0, s, ks, g, XT, per2, p2);          \
+    }                                                                                                                      \
   } while(0)
   if(g.D <= 4) GPC_ARD_LAUNCH(1);
   else if(g.D <= 8) GPC_ARD_LAUNCH(2);
@@ -996,7 +1019,8 @@ static int kern_grad_pass(const gpc_kspec* ksp, const double* X, int64_t N, int6
   if(sym_per < 4) sym_per = 4;
   if(sym_per > 48) sym_per = 48;
   const int64_t sym_ny = (2 * sym_nrb + sym_per - 1) / sym_per;
-  const int64_t sym_nwg = sym_nrb * sym_ny + sym_nrb;   // the fast tiles' workgroups + one per row block for its diagonal block (two launches)
+  g.all_general = (N < 4096) ? 1 : 0;
+  const int64_t sym_nwg = g.all_general ? sym_nrb * sym_ny : sym_nrb * sym_ny + sym_nrb * kg_mode2_ny(N);   // the fast tiles' workgroups + the second launch's (diagonal blocks, ragged row block)
   size_t pbytes = sizeof(double) * (size_t)nblk * (NP_MAIN > ARD_PASS ? NP_MAIN : ARD_PASS);
   if(pbytes < sizeof(double) * (size_t)sym_nwg * NP_MAIN) pbytes = sizeof(double) * (size_t)sym_nwg * NP_MAIN;
   GPC_CHECK(workspace(WS_KERN, sizeof(double) * (size_t)N + pbytes, &ws));
