@@ -240,7 +240,7 @@ def test_potri_vs_numpy(api, N, uplo):
 
 
 @pytest.mark.parametrize("N,uplo,w", [(2048, "L", 0), (2050, "L", 0), (3000, "U", 0), (4098, "L", 512), (5000, "L", 2048), (9216, "L", 0),
-                                      (12544, "U", 0), (13000, "L", 2048), (16390, "L", 0)])
+                                      (12544, "U", 0), (13000, "L", 2048), (16390, "L", 0), (9217, "L", 0)])
 def test_potri_in_place(api, monkeypatch, N, uplo, w):
     """dpotri in place on the factor (lapack.h:67-73, CMatrix.cpp:414-432): V = L^-T into the upper triangle, lower(V V') over L,
     scratch O(N nb).  Forced on from N = 2048 (default: from 24 576), ragged sizes, both triangles, three block widths of the
@@ -267,7 +267,7 @@ def test_potri_in_place(api, monkeypatch, N, uplo, w):
     assert np.abs(out @ K - np.eye(N)).max() < 1e-9
     # scratch: two tiles of max(w, 1024)^2, the exchange buffer of a 1024-column dataflow launch and the rows x 1024 copy of the
     # tile-inverse panels -- far below one N x N array from N = 9216 on
-    if N >= 9216:
+    if N >= 9216 and N % 2 == 0:      # (odd N: the products want even sizes, so the N x N-scratch form takes over -- still correct)
         assert free0 - free1 < 0.5 * 8 * N * N, "in-place dpotri took %.0f MB of scratch" % ((free0 - free1) / 2.0 ** 20)
     monkeypatch.setenv("GPC_POTRI_INPLACE_MINN", str(1 << 40))
     api.potri(F, uplo)
