@@ -354,7 +354,6 @@ __global__ void __launch_bounds__(256, 2) kern_grad_sym_kernel(const KSpecDev ks
     // One 16-column half of the wave's patch at a time (products, then sums), so that only 16 accumulators and 16 + 16
     // covGrad values are live: the full 64 x 32 patch at once needs more registers than a wave has at D = 32.  The
     // covGrad values of a half are requested one half ahead: their latency hides behind the other half's work.
-    const bool full = (i0 + GMI <= g.N) && (j0 + GMJ <= g.N);
     const bool mirror = (j0 + GMJ <= i0);   // strictly left of the diagonal block: every element stands for two
     // FAST (round 4): a full tile strictly left of the diagonal block -- all but two tiles of a walk -- has no edge masks and no
     // diagonal elements: no selects around the loads, no 64-bit compares in the sums, weight 2 folded into the final sums
@@ -486,6 +485,12 @@ __global__ void __launch_bounds__(64 * NW, OCC) kern_grad_ard_sym_kernel(const K
   constexpr int QX = (NK > 4) ? 2 : 1;          // 16-wide groups of input dimensions
   constexpr int DP = 16 * QX;
   __shared__ double Xj[2][GMDC * GSJ];
+  // The column tile a second time, transposed ([column][dimension]): the operand of the Y product, x_jq for lane (j, q).  Round 3
+  // fetched it from a row-major copy of X in global memory (eight L2 round trips per half-tile and lane: 1 ms of 9.9 at D = 32);
+  // the values are in this workgroup's LDS anyway.  Row stride 17 / 49 doubles: conflict-free for the staging writes (a lane per
+  // column) and, to one collision per half-wave, for the fragment reads.
+  constexpr int XTS = (DP == 16) ? 17 : 49;
+  __shared__ double XjT[2][GMJ * XTS];
   __shared__ double Nj[2][GMJ];
   __shared__ double Xi[NK > 2 ? GMDC * GSI : 1];
   constexpr int NT = 64 * NW;           // threads
@@ -614,16 +619,17 @@ __global__ void __launch_bounds__(64 * NW, OCC) kern_grad_ard_sym_kernel(const K
     double* Xjb = Xj[(jt - jt0) & 1];
     double* Njb = Nj[(jt - jt0) & 1];
     const int64_t j0 = jt * GMJ;
+    double* XjTb = XjT[(jt - jt0) & 1];
 #pragma unroll
     for(int u = 0; u < VJ; u++) {
       const int idx = t + NT * u;
       Xjb[(idx >> 6) * GSJ + (idx & 63)] = vj[u];
+      if((idx >> 6) < DP) XjTb[(idx & 63) * XTS + (idx >> 6)] = vj[u];
     }
     if(t < GMJ) Njb[t] = vn;
     __syncthreads();
     if(jt + 1 < jt1) prefetch(jt + 1);
 
-    const bool full = (i0 + GMI <= g.N) && (j0 + GMJ <= g.N);
     const bool mirror = (j0 + GMJ <= i0);
     // FAST (round 4): full tiles strictly left of the diagonal block -- no edge masks, no diagonal elements, weight 2
 #define KG_EXP(x) (MODE == 1 ? gpc_exp_tab((x), Etab) : exp(x))
