@@ -6,15 +6,18 @@
 // residency.  Block (b, c):
 //     C = A(b,c) - sum_{t<c} L(b,t) L(c,t)'       MFMA products, one 64-deep chunk per finished block pair, consumed AS THEY
 //                                                 APPEAR (so only the last chunk is ever on the critical path)
-//     b == c :  C = chol(C)                       the 64 x 64 block kernel of potrf.hip, published 8 columns at a time
-//     b >  c :  C = C L(c,c)^-T                   substitution as panel_step_kernel, consuming L(c,c) 16 columns at a time
+//     b == c :  C = chol(C)                       8 columns at a time: one wave eliminates, the other three update (MFMA) and
+//                                                 publish the previous group meanwhile
+//     b >  c :  C = C L(c,c)^-T                   consuming L(c,c) 16 columns at a time, the rows in the MFMA accumulator
+//                                                 layout throughout (lane swaps + MFMA steps, no LDS staging of the solution)
 // Finished blocks are PUBLISHED into an exchange buffer that starts as a sentinel NaN payload arithmetic never produces;
 // consumers read it with device-scope atomic loads and poll the VALUES until they stop being the sentinel.  No flags and
 // no fences: the XCDs' L2s are not coherent with each other, so an agent-scope release / acquire fence costs an L2
 // write-back / invalidate per use (the first version of this kernel had two per column block and lost to the launch chain).
 // A poll that is not answered after ~10 s, or a non-positive pivot anywhere, raises ctl[1]; everybody then leaves (the host
 // sees LAPACK's info, or an error).  The critical path per 64 columns is chol(c,c) -> [the solve of (c+1,c) runs 16 columns
-// behind it] -> last product chunk of (c+1,c+1) -> chol(c+1,c+1).
+// behind it] -> last product chunk of (c+1,c+1) -> chol(c+1,c+1): 15 us (round 3: 18; a hand-over between two workgroups
+// through the exchange buffer is 0.35 - 0.4 us whichever XCDs they run on -- tools/probes/hop_probe.hip).
 #include "gpc_common.hpp"
 
 namespace gpc {
@@ -24,10 +27,10 @@ namespace {
 constexpr int PF_OS = 80;   // LDS stride of an operand stage [k][row] in doubles (= 16 mod 32: conflict-free fragment reads)
 constexpr int PF_SS = 65;   // LDS column stride of the working block S[c * PF_SS + r]
 constexpr int PF_LS = 66;   // row stride of the L image for the solve
-constexpr int PF_TS = 18;
+constexpr int PF_TS = 18;   // row stride of potf2's multiplier table
 #ifndef PF_LEAN_NS
 #define PF_LEAN_NS 1
-#endif   // row stride of potf2's multiplier table
+#endif
 
 struct PanelFlowArgs {
   double* P;          // the panel: M rows x nbk columns, leading dimension lda
@@ -409,13 +412,11 @@ __global__ void __launch_bounds__(256, (NS < 3 ? 2 : 1)) panel_flow_kernel(const
   if(diag) {
     // ---- chol of the ncol x ncol diagonal block, 8 columns at a time (potf2_blk_kernel of potrf.hip); each group is
     //      normalised, stored and published as soon as it is final.  The block stays in the accumulator layout it was
-    //      computed in (wave (wm, wn) holds the 32 x 32 quadrant): a group's 8 columns go through LDS to every wave, which
-    //      eliminates them redundantly (lane = row), and the rank-8 update of the rest is two MFMA steps per 16 x 16 tile
-    //      (the same flops as the vector units but no broadcast LDS reads, which bound the vector form).  The strict upper
-    //      triangle is never referenced: zero at the start, its tiles are skipped or hold harmless values of dead rows.
+    //      computed in (wave (wm, wn) holds the 32 x 32 quadrant): a group's 8 columns go through LDS to the wave that
+    //      eliminates them (lane = row), and the rank-8 update of the rest is two MFMA steps per 16 x 16 tile (the same
+    //      flops as the vector units but no broadcast LDS reads, which bound the vector form).  The strict upper triangle
+    //      is never referenced: zero at the start, its tiles are skipped or hold harmless values of dead rows.
     double* Pc = arena;            // [8][64] the group's columns
-    double* Wl = arena + 512;      // [8][64] - w_j (the multipliers), as the row operand of the update
-    double* Tl = arena + 1024;     // [8][64] p_j (the eliminated columns), as its column operand
     const int rr = lane, gq = wv;
     const int n = ncol;
     double4_t cur[2][2];
@@ -436,107 +437,170 @@ __global__ void __launch_bounds__(256, (NS < 3 ? 2 : 1)) panel_flow_kernel(const
         }
     int done = 0;
     bool safe = true;
+    // (round 4) one wave eliminates, the others update and publish.  The round-3 loop ran every group's elimination in all four
+    // waves (lane = row, redundantly) and then its update and its publishing in all four: 1.3 - 1.5 us per group, all of it
+    // on the critical path.  The quadrant (rows 0..31, columns 32..63) is strictly above the diagonal, so its wave has no
+    // accumulators to update: it is the PIVOT wave.  Per group it reads the staged columns, eliminates them and writes all
+    // eight multiplier / pivot columns to LDS; the other three meanwhile finish the PREVIOUS group (the update of the tiles
+    // the next group does not need, the square roots, the stores, the publishing) on their own SIMDs.  After the barrier
+    // they apply the new group to the one tile column the next group lives in and stage it.  On the critical path per group:
+    // staged columns -> elimination -> barrier -> two MFMA -> stage -> barrier.
+    double* WT = arena + 512;                           // two buffers of [Wl 8 x 64 | Tl 8 x 64]: -w_j (row operand), p_j (column operand)
+    int& okflag = reinterpret_cast<int*>(arena + 2560)[0];
+    const bool pw = (wv == 2);                          // wm = 0, wn = 1
+    const int np = (wv == 3) ? 2 : wv;                  // the other three: publisher 0, 1, 2 takes the group's columns np, np + 3, np + 6
+    if(wn == 0) {
+#pragma unroll
+      for(int tm = 0; tm < 2; tm++)
+#pragma unroll
+        for(int r2 = 0; r2 < 2; r2++) Pc[((lane >> 4) + 4 * r2) * 64 + wm * 32 + tm * 16 + (lane & 15)] = cur[tm][0][r2];
+    }
+    if(t == 0) okflag = 0;
+    __syncthreads();
+    // square roots, stores and publication of group pb's columns np, np + 3, np + 6 from the LDS copies (three chains interleaved)
+    auto publish = [&](int pb) {
+      const double* Wp = WT + (pb & 1) * 1024;
+      const double* Tp = Wp + 512;
+      double wj[3], xd[3];
+#pragma unroll
+      for(int i = 0; i < 3; i++) {
+        const int j = (np + 3 * i < 8) ? np + 3 * i : np;      // (wave-uniform; a third column only for publishers 0 and 1)
+        wj[i] = -Wp[j * 64 + rr];
+        xd[i] = pf_lane(Tp[j * 64 + rr], 8 * pb + j);
+      }
+      double yy[3], gg[3], hh[3], rq[3], eq[3];
+#pragma unroll
+      for(int i = 0; i < 3; i++) yy[i] = __builtin_amdgcn_rsq(xd[i]);
+#pragma unroll
+      for(int i = 0; i < 3; i++) {
+        gg[i] = xd[i] * yy[i];
+        hh[i] = 0.5 * yy[i];
+      }
+#pragma unroll
+      for(int i = 0; i < 3; i++) rq[i] = fma(-hh[i], gg[i], 0.5);
+#pragma unroll
+      for(int i = 0; i < 3; i++) {
+        gg[i] = fma(gg[i], rq[i], gg[i]);
+        hh[i] = fma(hh[i], rq[i], hh[i]);
+      }
+#pragma unroll
+      for(int i = 0; i < 3; i++) eq[i] = fma(-gg[i], gg[i], xd[i]);
+#pragma unroll
+      for(int i = 0; i < 3; i++) gg[i] = fma(eq[i], hh[i], gg[i]);
+#pragma unroll
+      for(int i = 0; i < 3; i++) eq[i] = fma(-gg[i], gg[i], xd[i]);
+#pragma unroll
+      for(int i = 0; i < 3; i++) {
+        if(np + 3 * i < 8) {
+          const int cj = 8 * pb + np + 3 * i;
+          const double d = fma(eq[i], hh[i], gg[i]);
+          const double lv = (rr == cj) ? d : ((rr > cj) ? wj[i] * d : 0.0);      // (identity in the padding: p_j(j) = 1 there)
+          pf_put(&g.X[r0 + rr + ((int64_t)c * 64 + cj) * g.ldx], lv);             // (first: the solves below are polling)
+          if(rr < nr && cj < n && rr >= cj) g.P[r0 + rr + ((int64_t)c * 64 + cj) * g.lda] = lv;
+        }
+      }
+    };
 #pragma unroll
     for(int blk = 0; blk < 8; blk++) {
       if(safe) {
-        const bool fine = (g.trace == 2) && b == 0 && t == 0;
+        double* Wl = WT + (blk & 1) * 1024;
+        double* Tl = Wl + 512;
+        const bool fine = (g.trace == 2) && b == 0 && t == 128;
+        const bool fine0 = (g.trace == 2) && b == 0 && t == 0;
         if(fine) pf_trace[63 * 256 + blk * 8 + 0] = wall_clock64();
-        if(fine) pf_trace[63 * 256 + blk * 8 + 5] = clock64();
-        // the group's columns 8 blk .. 8 blk + 7 live in the quadrants wn = blk / 4, tile tn = (blk / 2) & 1, registers
-        // 2 (blk & 1), + 1: column - 8 blk = (lane >> 4) + 4 (r - 2 (blk & 1))
-        if(wn == blk / 4) {
+        if(fine0) pf_trace[61 * 256 + blk * 8 + 0] = wall_clock64();
+        if(pw) {
+          double p[8], w[8];
 #pragma unroll
-          for(int tm = 0; tm < 2; tm++)
+          for(int j = 0; j < 8; j++) p[j] = Pc[j * 64 + rr];
+          if(fine) pf_trace[63 * 256 + blk * 8 + 1] = wall_clock64();
+          bool ok = true;
 #pragma unroll
-            for(int r2 = 0; r2 < 2; r2++)
-              Pc[((lane >> 4) + 4 * r2) * 64 + wm * 32 + tm * 16 + (lane & 15)] = cur[tm][(blk / 2) & 1][2 * (blk & 1) + r2];
-        }
-        __syncthreads();
-        if(fine) pf_trace[63 * 256 + blk * 8 + 1] = wall_clock64();
-        double p[8], w[8];
+          for(int j = 0; j < 8; j++) {
+            const double pj = pf_lane(p[j], 8 * blk + j);
+            // pj in [2^-930, 2^930) (1.1e-280 .. 9.1e279; zero, negative, Inf and NaN are outside): sign 0 and biased exponent in
+            // [93, 1953), one unsigned compare of the high word -- the pivot is wave-uniform, so this runs on the scalar unit
+            ok = ok && (((unsigned)(__double_as_longlong(pj) >> 32) - (93u << 20)) < ((1953u - 93u) << 20));
+            double xx = __builtin_amdgcn_rcp(pj);
+            double e = fma(-pj, xx, 1.0);
+            xx = fma(xx, e, xx);
+            e = fma(-pj, xx, 1.0);
+            const double rp = fma(xx, e, xx);
+            w[j] = p[j] * rp;
 #pragma unroll
-        for(int j = 0; j < 8; j++) p[j] = Pc[j * 64 + rr];
-        bool ok = true;
+            for(int cc = j + 1; cc < 8; cc++) p[cc] -= w[j] * pf_lane(p[j], 8 * blk + cc);
+          }
+          if(fine) pf_trace[63 * 256 + blk * 8 + 2] = wall_clock64();
 #pragma unroll
-        for(int j = 0; j < 8; j++) {
-          const double pj = pf_lane(p[j], 8 * blk + j);
-          ok = ok && (pj > 1e-280) && (pj < 1e280);
-          double xx = __builtin_amdgcn_rcp(pj);
-          double e = fma(-pj, xx, 1.0);
-          xx = fma(xx, e, xx);
-          e = fma(-pj, xx, 1.0);
-          const double rp = fma(xx, e, xx);
-          w[j] = p[j] * rp;
+          for(int j = 0; j < 8; j++) {
+            Wl[j * 64 + rr] = -w[j];
+            Tl[j * 64 + rr] = p[j];
+          }
+          if(!ok && lane == 0) okflag = 1;
+          if(fine) pf_trace[63 * 256 + blk * 8 + 3] = wall_clock64();
+        } else if(blk > 0) {
+          // the previous group: the tiles its successor did not need, then its publication
+          const int pb = blk - 1;
+          const double* Wp = WT + (pb & 1) * 1024;
+          const double* Tp = Wp + 512;
+          if(wm >= wn) {
 #pragma unroll
-          for(int cc = j + 1; cc < 8; cc++) p[cc] -= w[j] * pf_lane(p[j], 8 * blk + cc);
-        }
-        if(fine) pf_trace[63 * 256 + blk * 8 + 2] = wall_clock64();
-        if(ok) {
-          // this wave's two columns of the group, 8 blk + 2 gq and + 1
-          const double pa = (gq == 0) ? p[0] : (gq == 1) ? p[2] : (gq == 2) ? p[4] : p[6];
-          const double pb = (gq == 0) ? p[1] : (gq == 1) ? p[3] : (gq == 2) ? p[5] : p[7];
-          const double wa = (gq == 0) ? w[0] : (gq == 1) ? w[2] : (gq == 2) ? w[4] : w[6];
-          const double wb = (gq == 0) ? w[1] : (gq == 1) ? w[3] : (gq == 2) ? w[5] : w[7];
-          if(blk + 1 < 8) {
-            Wl[(2 * gq) * 64 + rr] = -wa;
-            Wl[(2 * gq + 1) * 64 + rr] = -wb;
-            Tl[(2 * gq) * 64 + rr] = pa;
-            Tl[(2 * gq + 1) * 64 + rr] = pb;
-            __syncthreads();
-            // rest(m, n) -= sum_j w_j(m) p_j(n): the tiles that still have a column right of the group and are not strictly
-            // above the diagonal; the matrix cores work through them while the vector units do the publishing below
-            if(wm >= wn) {
+            for(int tn = 0; tn < 2; tn++) {
+              if(wn * 32 + tn * 16 + 8 > 8 * pb && wn * 2 + tn != blk / 2) {
 #pragma unroll
-              for(int tn = 0; tn < 2; tn++) {
-                if(wn * 32 + tn * 16 + 8 > 8 * blk) {
+                for(int tm = 0; tm < 2; tm++) {
+                  if(wm > wn || tm >= tn) {
 #pragma unroll
-                  for(int tm = 0; tm < 2; tm++) {
-                    if(wm > wn || tm >= tn) {
-#pragma unroll
-                      for(int kk = 0; kk < 2; kk++) {
-                        const double fa = Wl[(kk * 4 + (lane >> 4)) * 64 + wm * 32 + tm * 16 + (lane & 15)];
-                        const double fb = Tl[(kk * 4 + (lane >> 4)) * 64 + wn * 32 + tn * 16 + (lane & 15)];
-                        cur[tm][tn] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb, fa, cur[tm][tn], 0, 0, 0);
-                      }
+                    for(int kk = 0; kk < 2; kk++) {
+                      const double fa = Wp[(kk * 4 + (lane >> 4)) * 64 + wm * 32 + tm * 16 + (lane & 15)];
+                      const double fb = Tp[(kk * 4 + (lane >> 4)) * 64 + wn * 32 + tn * 16 + (lane & 15)];
+                      cur[tm][tn] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb, fa, cur[tm][tn], 0, 0, 0);
                     }
                   }
                 }
               }
             }
           }
-          if(fine) pf_trace[63 * 256 + blk * 8 + 3] = wall_clock64();
-          // normalise, store and publish: L(r, j) = w_j(r) sqrt(p_j(j)).  The pivots are in [1e-280, 1e280] here (or exactly 1
-          // in the padding), so the square root needs no rescaling: rsq + two Newton steps, both columns' chains interleaved.
-          {
-            const int ca = 8 * blk + 2 * gq, cb = ca + 1;
-            const double xa = pf_lane(pa, ca), xb = pf_lane(pb, cb);
-            double ya = __builtin_amdgcn_rsq(xa), yb = __builtin_amdgcn_rsq(xb);
-            double ga = xa * ya, gb = xb * yb, ha = 0.5 * ya, hb = 0.5 * yb;
-            double ra = fma(-ha, ga, 0.5), rb = fma(-hb, gb, 0.5);
-            ga = fma(ga, ra, ga);
-            gb = fma(gb, rb, gb);
-            ha = fma(ha, ra, ha);
-            hb = fma(hb, rb, hb);
-            double ea = fma(-ga, ga, xa), eb = fma(-gb, gb, xb);
-            ga = fma(ea, ha, ga);
-            gb = fma(eb, hb, gb);
-            ea = fma(-ga, ga, xa);
-            eb = fma(-gb, gb, xb);
-            const double da = fma(ea, ha, ga), db = fma(eb, hb, gb);
-            const double la = (rr == ca) ? da : ((rr > ca) ? wa * da : 0.0);           // (identity in the padding: p_j(j) = 1 there)
-            const double lb = (rr == cb) ? db : ((rr > cb) ? wb * db : 0.0);
-            pf_put(&g.X[r0 + rr + ((int64_t)c * 64 + ca) * g.ldx], la);                   // (first: the solves below are polling)
-            pf_put(&g.X[r0 + rr + ((int64_t)c * 64 + cb) * g.ldx], lb);
-            if(rr < nr && ca < n && rr >= ca) g.P[r0 + rr + ((int64_t)c * 64 + ca) * g.lda] = la;
-            if(rr < nr && cb < n && rr >= cb) g.P[r0 + rr + ((int64_t)c * 64 + cb) * g.lda] = lb;
-          }
-          done = blk + 1;
-          if(fine) pf_trace[63 * 256 + blk * 8 + 4] = wall_clock64();
+          if(fine0) pf_trace[61 * 256 + blk * 8 + 1] = wall_clock64();
+          publish(pb);
+          if(fine0) pf_trace[61 * 256 + blk * 8 + 2] = wall_clock64();
+        }
+        __syncthreads();
+        if(fine) pf_trace[63 * 256 + blk * 8 + 4] = wall_clock64();
+        if(fine0) pf_trace[61 * 256 + blk * 8 + 3] = wall_clock64();
+        if(okflag) {
+          safe = false;      // (the same in every wave: the careful loop takes over from this group)
         } else {
-          safe = false;
+          if(blk + 1 < 8 && wn == (blk + 1) / 4) {
+            // the tile column the next group lives in: this group's update, then its columns to the pivot wave
+            const int tn = ((blk + 1) / 2) & 1;
+            if(wm >= wn) {
+#pragma unroll
+              for(int tm = 0; tm < 2; tm++) {
+                if(wm > wn || tm >= tn) {
+#pragma unroll
+                  for(int kk = 0; kk < 2; kk++) {
+                    const double fa = Wl[(kk * 4 + (lane >> 4)) * 64 + wm * 32 + tm * 16 + (lane & 15)];
+                    const double fb = Tl[(kk * 4 + (lane >> 4)) * 64 + wn * 32 + tn * 16 + (lane & 15)];
+                    cur[tm][tn] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb, fa, cur[tm][tn], 0, 0, 0);
+                  }
+                }
+              }
+            }
+#pragma unroll
+            for(int tm = 0; tm < 2; tm++)
+#pragma unroll
+              for(int r2 = 0; r2 < 2; r2++)
+                Pc[((lane >> 4) + 4 * r2) * 64 + wm * 32 + tm * 16 + (lane & 15)] = cur[tm][tn][2 * ((blk + 1) & 1) + r2];
+          }
+          if(fine0) pf_trace[61 * 256 + blk * 8 + 4] = wall_clock64();
+          done = blk + 1;
+          if(blk + 1 < 8) __syncthreads();
+          if(fine0) pf_trace[61 * 256 + blk * 8 + 5] = wall_clock64();
         }
       }
     }
+    if(safe && !pw) publish(7);
     if(!safe) {
       // the careful loop (exact division, LAPACK's info on a non-positive pivot), from the first group the fast path refused:
       // the rest of the block goes through LDS into a column per register of a lane = row, column 8 blk + 4 q + gq in a[q]
@@ -619,15 +683,25 @@ __global__ void __launch_bounds__(256, (NS < 3 ? 2 : 1)) panel_flow_kernel(const
       }
     }
   } else {
-    // ---- C = C L(c,c)^-T by substitution (panel_step_kernel of potrf.hip: 16-column blocks, four waves), L(c,c) taken from
-    //      the exchange buffer 16 columns at a time, as its workgroup finishes them --------------------------------------------
-    double* Ls = arena;
-    double* Xs = arena + 64 * PF_LS;   // 16 x PF_OS: the group's solution as a product operand
+    // ---- C = C L(c,c)^-T, 16 columns at a time as L(c,c)'s workgroup publishes them (round 4 form).  Wave wv owns the rows
+    //      16 wv .. 16 wv + 15 and keeps them in the MFMA accumulator layout for the whole solve: register r of 16-column tile tn
+    //      at lane l is column 16 tn + 4 r + (l >> 4) of row l & 15.  In that layout register kk of a solved tile IS the row
+    //      operand of the k-step 4 kk .. 4 kk + 3, so the update of the tiles to the right is four MFMA per tile with no staging,
+    //      and the 16 x 16 triangle is a column sweep whose x_k travels across the four 16-lane rows by two lane swaps
+    //      (v_permlane32_swap / v_permlane16_swap) instead of every wave reading every multiplier as an LDS broadcast (the
+    //      round-3 form: the four waves solved all 64 rows redundantly, lane = row, and went through LDS twice per group --
+    //      3.2 us per group, which is why the block under the diagonal finished 4.5 us after it).
+    double* Ls = arena;                // Ls[row * PF_LS + col]: the image of L(c,c)
+    const int q = lane >> 4, lr = lane & 15;
     const double* Lx = g.X + (int64_t)c * 64 + lane + ((int64_t)c * 64 + wv * 4) * g.ldx;   // L(c,c)(lane, 16 blk + 4 wv + u)
     const bool wanted = (c + 1 < g.ncb);                                                     // somebody's product operand
     double lv[4];
     bool have = pf_try<4>(Lx, g.ldx, lv);
-    double x[16];
+    double4_t y[4];
+#pragma unroll
+    for(int tn = 0; tn < 4; tn++)
+#pragma unroll
+      for(int r = 0; r < 4; r++) y[tn][r] = S[(16 * tn + 4 * r + q) * PF_SS + 16 * wv + lr];
 #pragma unroll
     for(int blk = 0; blk < 4; blk++) {
       const int o = blk * 16;
@@ -641,62 +715,76 @@ __global__ void __launch_bounds__(256, (NS < 3 ? 2 : 1)) panel_flow_kernel(const
       if(giveup) return;
       if(blk + 1 < 4) have = pf_try<4>(Lx + (int64_t)(o + 16) * g.ldx, g.ldx, lv);          // in flight during this block's work
       if(fine) pf_trace[62 * 256 + blk * 8 + 2] = wall_clock64();
-      // the 16 x 16 triangle, column-oriented: as soon as x_k is final every later x_i takes its share (independent updates).
-      // The reciprocals of the diagonal first, all 16 chains in flight together (L_kk is a square root of a pivot: no
-      // range problem for rcp + two Newton steps).
-      double rd[16];
-#pragma unroll
-      for(int k = 0; k < 16; k++) {
-        const double dk = Ls[(o + k) * PF_LS + o + k];
+      // reciprocals of the diagonal (square roots of pivots: rcp + two Newton steps): lane's own column lr -- the sweep takes
+      // them from there as wave-uniform values -- and the four columns 4 r + q the lane holds
+      auto recip = [](double dk) {
         double xx = __builtin_amdgcn_rcp(dk);
         double e = fma(-dk, xx, 1.0);
         xx = fma(xx, e, xx);
         e = fma(-dk, xx, 1.0);
-        rd[k] = fma(xx, e, xx);
-      }
+        return fma(xx, e, xx);
+      };
+      const double rdl = recip(Ls[(o + lr) * PF_LS + o + lr]);
+      double nrdv[4];
 #pragma unroll
-      for(int i = 0; i < 16; i++) x[i] = S[(o + i) * PF_SS + lane];
+      for(int r = 0; r < 4; r++) nrdv[r] = -recip(Ls[(o + 4 * r + q) * PF_LS + o + 4 * r + q]);
+      // Four columns at a time (register rk = the columns 4 rk + q of the four 16-lane rows): inside the 4 x 4 diagonal
+      // block x_k goes from row qk to the rows above it by lane swaps (three of them); the rest of the tile then takes the
+      // four columns as ONE MFMA step whose row operand is the register itself (lane row q = k-index q) -- the broadcast
+      // is the matrix core's.  Column operand: L(o + n, o + 4 rk + q), zero for the columns n already solved.
+      double nx[4];
 #pragma unroll
-      for(int k = 0; k < 16; k++) {
-        x[k] *= rd[k];
+      for(int rk = 0; rk < 4; rk++) {
 #pragma unroll
-        for(int i = k + 1; i < 16; i++) x[i] -= x[k] * Ls[(o + i) * PF_LS + o + k];   // (8-byte broadcast reads: 16-byte ones are slower)
+        for(int qk = 0; qk < 3; qk++) {
+          const int k = 4 * rk + qk;
+          union { double d; unsigned u[2]; } vi, vo;
+          vi.d = y[blk][rk];
+#pragma unroll
+          for(int h = 0; h < 2; h++) {
+            if(qk < 2) {
+              const auto p32 = __builtin_amdgcn_permlane32_swap(vi.u[h], vi.u[h], false, false);
+              const unsigned w32 = p32[0];                                      // both halves = rows 0, 1
+              const auto p16 = __builtin_amdgcn_permlane16_swap(w32, w32, false, false);
+              vo.u[h] = (qk & 1) ? p16[1] : p16[0];
+            } else {
+              const auto p16 = __builtin_amdgcn_permlane16_swap(vi.u[h], vi.u[h], false, false);
+              vo.u[h] = p16[0];                                                 // row 3 <- row 2 (the only row that needs it)
+            }
+          }
+          const double xb = vo.d * pf_lane(rdl, k);
+          double m = Ls[(o + 4 * rk + q) * PF_LS + o + k];
+          m = (q > qk) ? m : 0.0;
+          y[blk][rk] = fma(-xb, m, y[blk][rk]);
+        }
+        nx[rk] = y[blk][rk] * nrdv[rk];
+        if(rk < 3) {
+          double lbz = Ls[(o + lr) * PF_LS + o + 4 * rk + q];
+          lbz = (lr >= 4 * (rk + 1)) ? lbz : 0.0;
+          y[blk] = __builtin_amdgcn_mfma_f64_16x16x4f64(lbz, nx[rk], y[blk], 0, 0, 0);
+        }
       }
       if(fine) pf_trace[62 * 256 + blk * 8 + 3] = wall_clock64();
-      // the columns to the right, S(:, o+16:) -= X L(o+16:, o:o+16)', on the matrix cores (the same flops as the vector
-      // units, but no broadcast reads of L: those were LDS-bound): X goes through LDS as the [k][row] operand, wave wv
-      // owns rows 16 wv .. 16 wv + 15 of every 16-column tile
-      if(blk < 3) {
+      double x[4];
 #pragma unroll
-        for(int i = 0; i < 16; i++)
-          if((i >> 2) == wv) Xs[i * PF_OS + lane] = x[i];
-        __syncthreads();
-        double xa[4];
+      for(int r = 0; r < 4; r++) x[r] = -nx[r];
+      // the tiles to the right: y(:, 16 g2 ..) -= X L(16 g2 .., o ..)'
 #pragma unroll
-        for(int kk = 0; kk < 4; kk++) xa[kk] = Xs[(kk * 4 + (lane >> 4)) * PF_OS + wv * 16 + (lane & 15)];
+      for(int g2 = blk + 1; g2 < 4; g2++)
 #pragma unroll
-        for(int n0 = o + 16; n0 < 64; n0 += 16) {
-          double4_t cf = (double4_t){0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-          for(int kk = 0; kk < 4; kk++) {
-            const double lb = Ls[(n0 + (lane & 15)) * PF_LS + o + kk * 4 + (lane >> 4)];
-            cf = __builtin_amdgcn_mfma_f64_16x16x4f64(lb, xa[kk], cf, 0, 0, 0);
-          }
-#pragma unroll
-          for(int r = 0; r < 4; r++) S[(n0 + (lane >> 4) + 4 * r) * PF_SS + wv * 16 + (lane & 15)] -= cf[r];
+        for(int kk = 0; kk < 4; kk++) {
+          const double lb = Ls[(16 * g2 + lr) * PF_LS + o + kk * 4 + q];
+          y[g2] = __builtin_amdgcn_mfma_f64_16x16x4f64(lb, nx[kk], y[g2], 0, 0, 0);
         }
-      }
       if(fine) pf_trace[62 * 256 + blk * 8 + 4] = wall_clock64();
-      // these 16 columns are final: store and publish them (wave wv: columns o + 4 wv + u)
+      // these 16 columns are final: publish and store them
 #pragma unroll
-      for(int i = 0; i < 16; i++) {
-        if((i >> 2) == wv) {
-          if(wanted) pf_put(&g.X[r0 + lane + ((int64_t)c * 64 + o + i) * g.ldx], x[i]);     // (first: somebody may be polling)
-          if(lane < nr && c * 64 + o + i < g.store_cols) g.P[rp + lane + ((int64_t)c * 64 + o + i) * g.lda] = x[i];
-        }
+      for(int r = 0; r < 4; r++) {
+        const int col = o + 4 * r + q, row = 16 * wv + lr;
+        if(wanted) pf_put(&g.X[r0 + row + ((int64_t)c * 64 + col) * g.ldx], x[r]);           // (first: somebody may be polling)
+        if(row < nr && c * 64 + col < g.store_cols) g.P[rp + row + ((int64_t)c * 64 + col) * g.lda] = x[r];
       }
       if(fine) pf_trace[62 * 256 + blk * 8 + 5] = wall_clock64();
-      __syncthreads();
     }
   }
   if(tr) pf_trace[(b * 64 + c) * 4 + 3] = wall_clock64();

@@ -31,11 +31,17 @@ if len(sys.argv) > 2 and sys.argv[2] == "child":
         us = lambda x: (x - t0) / 100.0
         if os.environ.get("GPC_PANEL_FLOW_TRACE") == "2":
             f = tr.reshape(-1)[63 * 256: 63 * 256 + 64].reshape(8, 8)
-            print("chol of block (0,0), per 8-column group (us): stage+sync / pivots / publish / T update")
-            print("   shader clock over blocks 0..7: %.0f MHz" % ((f[7,5]-f[0,5]) / ((f[7,0]-f[0,0]) / 100.)))
+            print("chol of block (0,0), per column group (8 groups of 8 or 4 of 16) (us): stage+sync / pivots / update / publish")
             for k in range(8):
+                if f[k, 0] == 0:
+                    continue
                 print("   blk %d: %.2f %.2f %.2f %.2f" % (k, (f[k,1]-f[k,0])/100., (f[k,2]-f[k,1])/100., (f[k,3]-f[k,2])/100., (f[k,4]-f[k,3])/100.))
         if os.environ.get("GPC_PANEL_FLOW_TRACE") == "2":
+            f = tr.reshape(-1)[61 * 256: 61 * 256 + 64].reshape(8, 8)
+            if f[0, 0] != 0:
+                print("chol of block (0,0), wave 0 (an updating / publishing wave) per group (us): rest update, publish, wait B, tile column + stage, wait A")
+                for k in range(8):
+                    print("   blk %d: %.2f %.2f %.2f %.2f %.2f" % ((k,) + tuple(max(f[k, i + 1] - f[k, i], 0) / 100. for i in range(5))))
             f = tr.reshape(-1)[62 * 256: 62 * 256 + 32].reshape(4, 8)
             print("solve of block (1,0), per 16-column group (us since chol start): start | L there, staged+sync, triangle, trailing, publish")
             for k in range(4):
