@@ -838,9 +838,12 @@ int panel_flow(int64_t M, int64_t nbk, double* P, int64_t lda, int* d_info, int6
   // to outlast the limit
   if(polls < 64) hipLaunchKernelGGL(panel_flow_giveup_kernel, dim3(1), dim3(64), 0, s, ctl, d_info);
   const int64_t nblocks = (int64_t)ncb * nrb - (int64_t)ncb * (ncb - 1) / 2;
-  // GPC_PANEL_FLOW_LEAN=1 (measurement aid): the two-per-CU form.  It does start beside a running trailing update (a tile
-  // factorisation launched 1 ms into a 9.2 ms update: done after 2.0 ms instead of 8.1), but capped at 256 registers the
-  // solve's 120 preloaded entries of L spill and the kernel is 2.5x slower on its own (0.79 against 0.32 ms for a 1024 tile)
+  // GPC_PANEL_FLOW_LEAN=1 (measurement aid): the two-per-CU form (one operand set, 256 registers, 124 bytes of scratch).  It
+  // does start beside a running trailing update (a tile factorisation launched 1 ms into a 9.2 ms update: done after 2.0 ms
+  // instead of 8.1).  Round 4, with the register-resident solve: on its own it is as fast as the default form where the
+  // critical path rules (N = 1000: 0.30 against 0.32 ms), slower where the launch is bound by its products (N = 4096, one
+  // launch: 1.28 against 1.19 ms), 2 % faster on tall panels (N = 16 384: 27.9 against 28.5 ms) -- and look-ahead with it
+  // beside the update still buys nothing at cfg 3 (1393 against 1389 ms: the panels' work is conserved, not hidden).
   static const int lean_env = [] { const char* e = getenv("GPC_PANEL_FLOW_LEAN"); return e ? atoi(e) : 0; }();
   if(lean_env > 0)
     hipLaunchKernelGGL(panel_flow_kernel<PF_LEAN_NS>, dim3((unsigned)nblocks), dim3(256), 0, s, g);
