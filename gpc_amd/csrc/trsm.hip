@@ -403,7 +403,7 @@ __device__ __forceinline__ void flow_publish(double* p, double x)
 }
 
 template <bool FWD>
-__global__ void __launch_bounds__(256) trsv_flow_kernel(const double* __restrict__ L, int64_t ldl, double* __restrict__ B,
+__global__ void __launch_bounds__(256, 2) trsv_flow_kernel(const double* __restrict__ L, int64_t ldl, double* __restrict__ B,
                                                         int64_t ldb, int64_t M, int d, int unit, double* __restrict__ Xf,
                                                         int* __restrict__ ctl, int* __restrict__ sticky)
 {
@@ -464,6 +464,61 @@ __global__ void __launch_bounds__(256) trsv_flow_kernel(const double* __restrict
 #pragma unroll
   for(int u = 0; u < 16; u++) pm[u] = FWD ? T2[(16 * w + u) * 65 + lane] : T2[lane * 65 + 16 * w + u];
 
+  // (round 4) The LAST dependency -- the neighbouring block, whose x arrives last -- is kept out of the loop below: with
+  // Mi = Linv L(i, i-1) (forward; backward Linv' L(i+1, i)') formed now, long before that x can be there, the step on the
+  // critical path is x_i = z - Mi x_last with z = Linv (y - the other dependencies): one wave, 64 multiply-adds with the
+  // x_last elements handed round by v_readlane, no barrier and no LDS between the poll and the publication.  Before, the
+  // last block went through the loop like the others and three barriers + two LDS reductions + the product with Linv
+  // followed it: 3.4 - 3.8 us per block.  Measured (two solves, one right-hand side): N = 8192 0.469 -> 0.429 ms; N = 65 536
+  // unchanged at 7.2 - 7.3 ms = 4.7 TB/s -- there the 512-byte column pieces of the row panels bound it, not this chain;
+  // three right-hand sides at N = 65 536 11.4 -> 9.8 ms (two workgroups per CU for the forward kernel as well: 100 bytes of
+  // scratch in its inverse, which is off the path).
+  const bool has_last = FWD ? (ib > 0) : (ib + 1 < nblk);
+  const int64_t jl = FWD ? ib - 1 : ib + 1;
+  if(has_last) {
+    // P <- the block as the product's column operand, P[k * 65 + n]
+#pragma unroll
+    for(int u = 0; u < 16; u++) {
+      const int c = w + 4 * u;
+      if(FWD) {
+        P[lane * 65 + c] = (lane < nb) ? L[(b0 + lane) + (jl * 64 + c) * ldl] : 0.0;                  // k = my row lane, n = column c of block jl
+      } else {
+        const int64_t rr = jl * 64 + lane;
+        P[c * 65 + lane] = (rr < M && c < nb) ? L[rr + (b0 + c) * ldl] : 0.0;                          // k = my column c, n = row lane of block jl
+      }
+    }
+    __syncthreads();
+    const int wm = w & 1, wn = w >> 1;
+    double4_t macc[2][2];
+#pragma unroll
+    for(int i = 0; i < 2; i++)
+#pragma unroll
+      for(int j = 0; j < 2; j++) macc[i][j] = (double4_t){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for(int kk = 0; kk < 16; kk++) {
+      const int kr = kk * 4 + (lane >> 4);
+      double a[2], bb[2];
+#pragma unroll
+      for(int q = 0; q < 2; q++) {
+        const int m = wm * 32 + q * 16 + (lane & 15);
+        a[q] = FWD ? T2[kr * 65 + m] : T2[m * 65 + kr];                                               // Linv(m, kr) / Linv(kr, m)
+        bb[q] = P[kr * 65 + wn * 32 + q * 16 + (lane & 15)];
+      }
+#pragma unroll
+      for(int tn = 0; tn < 2; tn++)
+#pragma unroll
+        for(int tm = 0; tm < 2; tm++) macc[tm][tn] = __builtin_amdgcn_mfma_f64_16x16x4f64(bb[tn], a[tm], macc[tm][tn], 0, 0, 0);
+    }
+    __syncthreads();
+#pragma unroll
+    for(int tn = 0; tn < 2; tn++)
+#pragma unroll
+      for(int tm = 0; tm < 2; tm++)
+#pragma unroll
+        for(int r = 0; r < 4; r++) P[(wn * 32 + tn * 16 + (lane >> 4) + 4 * r) * 65 + wm * 32 + tm * 16 + (lane & 15)] = macc[tm][tn][r];
+    // (P[j * 65 + m] = Mi(m, j) stays there: wave 0 takes its row at the very end, when the loop's registers are free)
+  }
+
   double tot[FLOW_MAXRHS];   // (wave 0) sum over the dependencies, per right-hand side, for row / column `lane` of my block
 #pragma unroll
   for(int v = 0; v < FLOW_MAXRHS; v++) tot[v] = 0.0;
@@ -475,12 +530,13 @@ __global__ void __launch_bounds__(256) trsv_flow_kernel(const double* __restrict
     double a[16], an[16], acc[FLOW_MAXRHS];
 #pragma unroll
     for(int v = 0; v < FLOW_MAXRHS; v++) acc[v] = 0.0;
-    if(ib > 0) {
+    const int64_t jend = ib - 1;          // (block ib - 1 is the last dependency: see above)
+    if(jend > 0) {
 #pragma unroll
       for(int u = 0; u < 16; u++) a[u] = Lrow[(int64_t)u * ldl];
     }
-    for(int64_t j = 0; j < ib; j++) {
-      if(j + 1 < ib) {
+    for(int64_t j = 0; j < jend; j++) {
+      if(j + 1 < jend) {
 #pragma unroll
         for(int u = 0; u < 16; u++) an[u] = Lrow[((j + 1) * 64 + u) * ldl];
       }
@@ -527,9 +583,10 @@ __global__ void __launch_bounds__(256) trsv_flow_kernel(const double* __restrict
         r[u] = (rr < M) ? x : 0.0;
       }
     };
-    if(ib + 1 < nblk) load_blk(nblk - 1, a);
-    for(int64_t j = nblk - 1; j > ib; j--) {
-      if(j - 1 > ib) load_blk(j - 1, an);
+    const int64_t jend = ib + 1;          // (block ib + 1 is the last dependency: see above)
+    if(jend + 1 < nblk) load_blk(nblk - 1, a);
+    for(int64_t j = nblk - 1; j > jend; j--) {
+      if(j - 1 > jend) load_blk(j - 1, an);
       double xj[FLOW_MAXRHS];
 #pragma unroll
       for(int v = 0; v < FLOW_MAXRHS; v++)
@@ -595,10 +652,27 @@ __global__ void __launch_bounds__(256) trsv_flow_kernel(const double* __restrict
     if(w == 0) {
 #pragma unroll
       for(int v = 0; v < FLOW_MAXRHS; v++)
-        if(v < d && lane < nb) {
-          const double x = ((part[v] + Red[0][v][lane]) + Red[1][v][lane]) + Red[2][v][lane];
-          flow_publish(&Xf[b0 + lane + (int64_t)v * M], x);
-          B[(b0 + lane) + (int64_t)v * ldb] = x;
+        if(v < d) {
+          double x = ((part[v] + Red[0][v][lane]) + Red[1][v][lane]) + Red[2][v][lane];      // z
+          if(has_last) {
+            double Mrow[64];                                                                    // Mi(lane, j)
+#pragma unroll
+            for(int j = 0; j < 64; j++) Mrow[j] = P[j * 65 + lane];
+            const double xl = (jl * 64 + lane < M) ? flow_poll(&Xf[jl * 64 + lane + (int64_t)v * M], ctl, sticky) : 0.0;
+            double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;                                      // (four chains, summed in a fixed order)
+#pragma unroll
+            for(int j = 0; j < 64; j += 4) {
+              s0 = fma(Mrow[j], readlane_f64(xl, j), s0);
+              s1 = fma(Mrow[j + 1], readlane_f64(xl, j + 1), s1);
+              s2 = fma(Mrow[j + 2], readlane_f64(xl, j + 2), s2);
+              s3 = fma(Mrow[j + 3], readlane_f64(xl, j + 3), s3);
+            }
+            x -= (s0 + s1) + (s2 + s3);
+          }
+          if(lane < nb) {
+            flow_publish(&Xf[b0 + lane + (int64_t)v * M], x);
+            B[(b0 + lane) + (int64_t)v * ldb] = x;
+          }
         }
     }
   }
