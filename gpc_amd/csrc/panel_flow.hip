@@ -9,14 +9,14 @@
 //     b == c :  C = chol(C)                       8 columns at a time: one wave eliminates, the other three update (MFMA) and
 //                                                 publish the previous group meanwhile
 //     b >  c :  C = C L(c,c)^-T                   consuming L(c,c) 16 columns at a time, the rows in the MFMA accumulator
-//                                                 layout throughout (lane swaps + MFMA steps, no LDS staging of the solution)
+//                                                 layout throughout (every step an MFMA, no LDS staging of the solution)
 // Finished blocks are PUBLISHED into an exchange buffer that starts as a sentinel NaN payload arithmetic never produces;
 // consumers read it with device-scope atomic loads and poll the VALUES until they stop being the sentinel.  No flags and
 // no fences: the XCDs' L2s are not coherent with each other, so an agent-scope release / acquire fence costs an L2
 // write-back / invalidate per use (the first version of this kernel had two per column block and lost to the launch chain).
 // A poll that is not answered after ~10 s, or a non-positive pivot anywhere, raises ctl[1]; everybody then leaves (the host
 // sees LAPACK's info, or an error).  The critical path per 64 columns is chol(c,c) -> [the solve of (c+1,c) runs 16 columns
-// behind it] -> last product chunk of (c+1,c+1) -> chol(c+1,c+1): 15 us (round 3: 18; a hand-over between two workgroups
+// behind it] -> last product chunk of (c+1,c+1) -> chol(c+1,c+1): 14.4 us (round 3: 18; a hand-over between two workgroups
 // through the exchange buffer is 0.35 - 0.4 us whichever XCDs they run on -- tools/probes/hop_probe.hip).
 #include "gpc_common.hpp"
 
@@ -687,11 +687,11 @@ __global__ void __launch_bounds__(256, (NS < 3 ? 2 : 1)) panel_flow_kernel(const
     //      16 wv .. 16 wv + 15 and keeps them in the MFMA accumulator layout for the whole solve: register r of 16-column tile tn
     //      at lane l is column 16 tn + 4 r + (l >> 4) of row l & 15.  In that layout register kk of a solved tile IS the row
     //      operand of the k-step 4 kk .. 4 kk + 3, so the update of the tiles to the right is four MFMA per tile with no staging,
-    //      and the 16 x 16 triangle is a column sweep whose x_k travels across the four 16-lane rows by two lane swaps
-    //      (v_permlane32_swap / v_permlane16_swap) instead of every wave reading every multiplier as an LDS broadcast (the
-    //      round-3 form: the four waves solved all 64 rows redundantly, lane = row, and went through LDS twice per group --
-    //      3.2 us per group, which is why the block under the diagonal finished 4.5 us after it).
+    //      and the 16 x 16 triangle is four MFMA steps too (below).  The round-3 form solved all 64 rows redundantly in the
+    //      four waves, lane = row, every multiplier an LDS broadcast read, and went through LDS twice per group: 3.2 us per
+    //      group, which is why the block under the diagonal finished 4.5 us after it (now 2.6).
     double* Ls = arena;                // Ls[row * PF_LS + col]: the image of L(c,c)
+    double* Bt = arena + 64 * PF_LS;   // [4][64]: the column operands of a group's four triangle steps
     const int q = lane >> 4, lr = lane & 15;
     const double* Lx = g.X + (int64_t)c * 64 + lane + ((int64_t)c * 64 + wv * 4) * g.ldx;   // L(c,c)(lane, 16 blk + 4 wv + u)
     const bool wanted = (c + 1 < g.ncb);                                                     // somebody's product operand
@@ -715,59 +715,56 @@ __global__ void __launch_bounds__(256, (NS < 3 ? 2 : 1)) panel_flow_kernel(const
       if(giveup) return;
       if(blk + 1 < 4) have = pf_try<4>(Lx + (int64_t)(o + 16) * g.ldx, g.ldx, lv);          // in flight during this block's work
       if(fine) pf_trace[62 * 256 + blk * 8 + 2] = wall_clock64();
-      // reciprocals of the diagonal (square roots of pivots: rcp + two Newton steps): lane's own column lr -- the sweep takes
-      // them from there as wave-uniform values -- and the four columns 4 r + q the lane holds
-      auto recip = [](double dk) {
-        double xx = __builtin_amdgcn_rcp(dk);
-        double e = fma(-dk, xx, 1.0);
-        xx = fma(xx, e, xx);
-        e = fma(-dk, xx, 1.0);
-        return fma(xx, e, xx);
-      };
-      const double rdl = recip(Ls[(o + lr) * PF_LS + o + lr]);
-      double nrdv[4];
+      // The 16 x 16 triangle as FOUR MFMA steps, one per block of four columns K = 4 rk .. 4 rk + 3 (register rk of the tile).
+      // With V = inv(L_KK) the step is  x_K = y_K V',  y_n -= sum_k x_k L(n, k) for the columns n right of K -- both linear
+      // in y_K, so ONE product with the column operand
+      //     B(n, j) = V(n - 4 rk, j)               n in K
+      //             = - sum_k L(n, 4 rk + k) V(k, j)   n right of K          (0 left of K)
+      // whose row operand is the register rk itself and whose accumulator input is the tile with that register cleared.
+      // The operands depend on L(c,c) only, not on the rows: wave rk prepares block rk's (lane (n, j): column j of the 4 x 4
+      // inverse by substitution, then its own entry) and hands it to the others through LDS.  No cross-lane traffic, no
+      // dependent vector chain per column.  (The lane-swap substitution this replaces: 0.9 us per group, issue-bound.)
+      {
+        const int d0 = o + 4 * wv;
+        auto recip = [](double dk) {       // (square roots of pivots: rcp + two Newton steps)
+          double xx = __builtin_amdgcn_rcp(dk);
+          double e = fma(-dk, xx, 1.0);
+          xx = fma(xx, e, xx);
+          e = fma(-dk, xx, 1.0);
+          return fma(xx, e, xx);
+        };
+        const double* Ld = Ls + d0 * PF_LS + d0;          // the 4 x 4 diagonal block (the same for every lane)
+        const double r0i = recip(Ld[0]), r1i = recip(Ld[PF_LS + 1]), r2i = recip(Ld[2 * PF_LS + 2]), r3i = recip(Ld[3 * PF_LS + 3]);
+        const double l10 = Ld[PF_LS], l20 = Ld[2 * PF_LS], l21 = Ld[2 * PF_LS + 1];
+        const double l30 = Ld[3 * PF_LS], l31 = Ld[3 * PF_LS + 1], l32 = Ld[3 * PF_LS + 2];
+        const double v0 = (q == 0) ? r0i : 0.0;
+        const double v1 = (((q == 1) ? 1.0 : 0.0) - l10 * v0) * r1i;
+        const double v2 = ((((q == 2) ? 1.0 : 0.0) - l20 * v0) - l21 * v1) * r2i;
+        const double v3 = (((((q == 3) ? 1.0 : 0.0) - l30 * v0) - l31 * v1) - l32 * v2) * r3i;
+        const int i = lr - 4 * wv;
+        const double* lrow = Ls + (o + lr) * PF_LS + d0;  // L(o + lr, d0 ..): used by the lanes right of the block
+        const double below = -(((lrow[0] * v0 + lrow[1] * v1) + lrow[2] * v2) + lrow[3] * v3);
+        const double inside = (i == 0) ? v0 : (i == 1) ? v1 : (i == 2) ? v2 : v3;
+        Bt[wv * 64 + lane] = (i < 0) ? 0.0 : ((i < 4) ? inside : below);
+      }
+      __syncthreads();
+      double bv[4];
 #pragma unroll
-      for(int r = 0; r < 4; r++) nrdv[r] = -recip(Ls[(o + 4 * r + q) * PF_LS + o + 4 * r + q]);
-      // Four columns at a time (register rk = the columns 4 rk + q of the four 16-lane rows): inside the 4 x 4 diagonal
-      // block x_k goes from row qk to the rows above it by lane swaps (three of them); the rest of the tile then takes the
-      // four columns as ONE MFMA step whose row operand is the register itself (lane row q = k-index q) -- the broadcast
-      // is the matrix core's.  Column operand: L(o + n, o + 4 rk + q), zero for the columns n already solved.
-      double nx[4];
+      for(int rk = 0; rk < 4; rk++) bv[rk] = Bt[rk * 64 + lane];
 #pragma unroll
       for(int rk = 0; rk < 4; rk++) {
-#pragma unroll
-        for(int qk = 0; qk < 3; qk++) {
-          const int k = 4 * rk + qk;
-          union { double d; unsigned u[2]; } vi, vo;
-          vi.d = y[blk][rk];
-#pragma unroll
-          for(int h = 0; h < 2; h++) {
-            if(qk < 2) {
-              const auto p32 = __builtin_amdgcn_permlane32_swap(vi.u[h], vi.u[h], false, false);
-              const unsigned w32 = p32[0];                                      // both halves = rows 0, 1
-              const auto p16 = __builtin_amdgcn_permlane16_swap(w32, w32, false, false);
-              vo.u[h] = (qk & 1) ? p16[1] : p16[0];
-            } else {
-              const auto p16 = __builtin_amdgcn_permlane16_swap(vi.u[h], vi.u[h], false, false);
-              vo.u[h] = p16[0];                                                 // row 3 <- row 2 (the only row that needs it)
-            }
-          }
-          const double xb = vo.d * pf_lane(rdl, k);
-          double m = Ls[(o + 4 * rk + q) * PF_LS + o + k];
-          m = (q > qk) ? m : 0.0;
-          y[blk][rk] = fma(-xb, m, y[blk][rk]);
-        }
-        nx[rk] = y[blk][rk] * nrdv[rk];
-        if(rk < 3) {
-          double lbz = Ls[(o + lr) * PF_LS + o + 4 * rk + q];
-          lbz = (lr >= 4 * (rk + 1)) ? lbz : 0.0;
-          y[blk] = __builtin_amdgcn_mfma_f64_16x16x4f64(lbz, nx[rk], y[blk], 0, 0, 0);
-        }
+        double4_t cin = y[blk];
+        const double yk = cin[rk];
+        cin[rk] = 0.0;
+        y[blk] = __builtin_amdgcn_mfma_f64_16x16x4f64(bv[rk], yk, cin, 0, 0, 0);
       }
       if(fine) pf_trace[62 * 256 + blk * 8 + 3] = wall_clock64();
-      double x[4];
+      double x[4], nx[4];
 #pragma unroll
-      for(int r = 0; r < 4; r++) x[r] = -nx[r];
+      for(int r = 0; r < 4; r++) {
+        x[r] = y[blk][r];
+        nx[r] = -x[r];
+      }
       // the tiles to the right: y(:, 16 g2 ..) -= X L(16 g2 .., o ..)'
 #pragma unroll
       for(int g2 = blk + 1; g2 < 4; g2++)
