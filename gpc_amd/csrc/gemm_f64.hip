@@ -61,6 +61,7 @@ struct GemmArgs {
                          // square products V V' so is B): a tile's k-loop starts at its first row m0 (everything left of it is zero)
   int64_t kstart_off;    // ... A(m, k) = 0 for k < m - kstart_off (the operand's triangle starts kstart_off rows down)
   int trap_deal;         // tri 3: super-tiles dealt round-robin to the XCDs (GPC_GEMM_TRAP_DEAL=0: contiguous chunks, as before)
+  int deal_lg;           // k-start / trapezoid deal: log2 of the ids per dealt group (6: a super-tile's worth; 4 for small launches)
   int kend;              // fast NT kernel only: B (N x K, N == K) is lower triangular, so the k-loop of tile column n0 stops at
                          // n0 + 128 (the rows of a tall panel times the inverse of its diagonal tile, potrf.hip)
   int ksplit;            // > 1 (fast NT kernel, SPLITK instance): the k-range of every tile is cut into ksplit pieces, each a
@@ -182,7 +183,16 @@ __device__ __forceinline__ bool map_tile(const GemmArgs& g, int& ti, int& tj, co
   // The lower trapezoid (tri 3) walks ALL super-tiles column by column and skips the tiles above the diagonal; those sit at
   // the top of every super-tile column, more of them in the later columns, so contiguous chunks leave the XCDs with unequal
   // numbers of real tiles: the same round-robin deal of whole super-tiles.
-  if(g.kstart == 1 || g.trap_deal) L = (((b >> 3) >> 6) * 8u + (b & 7u)) * 64u + ((b >> 3) & 63u);   // (2: k-start without the deal, see split-k)
+  // Within a round of eight groups the cost falls from the first to the last (a k-start product's k-range shrinks with the
+  // row), so a plain round-robin hands XCD 0 the dearest group of EVERY round: N = 8192, V V' of dpotri: XCD 0 gets 1.35x the
+  // mean work and the launch lasts that long (47 TFLOP/s).  The rounds therefore alternate their direction in the pattern
+  // forward, backward, backward, forward (the sums over four rounds of a falling sequence then agree to second order), and
+  // a launch of few groups deals 16 ids at a time instead of 64 (two tile columns of a super-tile: four times the rounds to
+  // even out over; the XCD's 64 resident workgroups then come from four super-tiles).
+  if(g.kstart == 1 || g.trap_deal) {   // (2: k-start without the deal, see split-k)
+    const unsigned lg = (unsigned)g.deal_lg, i = b >> 3, rnd = i >> lg, x = b & 7u, k = rnd & 3u;
+    L = ((rnd * 8u + ((k == 0u || k == 3u) ? x : 7u - x)) << lg) + (i & ((1u << lg) - 1u));
+  }
   int si, sj, di, dj;
   if(g.tri == 5) {
     // 2-D block-cyclic staircase: the super-tiles with at least one valid tile, column by column, dealt round-robin to
@@ -859,7 +869,13 @@ static int gemm_ex(bool transa, bool transb, int64_t M, int64_t N, int64_t K, do
     slots = g.tri_total;  // the valid lower tiles, 8 x 8 super-tile by super-tile
   slots = (slots + 7) & ~7ull;
   const uint64_t slots_plain = slots;   // the enumeration without the round-robin deal's padding
-  if(g.kstart || g.trap_deal) slots = (slots + 511) & ~511ull;   // whole groups of 64 ids per XCD (map_tile's round-robin deal)
+  if(g.kstart || g.trap_deal) slots = (slots + 511) & ~511ull;   // whole rounds of 8 groups of 64 (or 16) ids (map_tile's deal)
+  {
+    // GPC_GEMM_DEAL_GROUP = 64: a super-tile's worth per group, as before.  dpotri with 16 / 64: N = 5120 2.75 / 2.98 ms,
+    // 8192 8.16 / 8.32, 12 288 23.75 / 23.85, 20 480 94.2 / 95.0 (and 8.80 at N = 8192 with 64 dealt plainly round-robin)
+    static const int deal_g = [] { const char* e = getenv("GPC_GEMM_DEAL_GROUP"); return e ? atoi(e) : 16; }();
+    g.deal_lg = (deal_g == 64) ? 6 : 4;
+  }
   if(slots > 0x7fffffffull) {
     set_error("gemm grid too large");
     return GPC_EINVAL;
