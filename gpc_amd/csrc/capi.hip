@@ -135,7 +135,7 @@ int host_stage(size_t* capacity, char** base)
 {
   if(!g_stage.p) {
     void* h = nullptr;
-    if(hipHostMalloc(&h, HOST_STAGE_BYTES, hipHostMallocDefault) != hipSuccess) {
+    if(hipHostMalloc(&h, HOST_STAGE_BYTES, hipHostMallocPortable | hipHostMallocMapped) != hipSuccess) {
       (void)hipGetLastError();
       *capacity = 0;
       *base = nullptr;
@@ -148,38 +148,160 @@ int host_stage(size_t* capacity, char** base)
   return GPC_OK;
 }
 
+// All pieces of one HostFetch travel in ONE small kernel that writes them into the pinned (device-visible) staging buffer,
+// instead of one hipMemcpyAsync each: the runtime turns every such copy into a blit kernel of its own (4-5 us apiece in a
+// trace of the GP-LVM's evaluation, two to three per synchronisation).  GPC_HOST_GATHER=0: the copies, as before.
+struct GatherArgs {
+  const unsigned* src[8];
+  unsigned* dst[8];
+  unsigned words[8];
+  int n;
+};
+__global__ void __launch_bounds__(256) host_gather_kernel(const GatherArgs a)
+{
+  for(int i = 0; i < a.n; i++)
+    for(unsigned w = blockIdx.x * 256 + threadIdx.x; w < a.words[i]; w += gridDim.x * 256) a.dst[i][w] = a.src[i][w];
+}
+static bool host_gather_on()
+{
+  static const int v = [] { const char* e = getenv("GPC_HOST_GATHER"); return e ? atoi(e) : 1; }();
+  return v != 0;
+}
+
+// Postponed fetches of this thread (HostFetch::defer): their pieces sit in [0, g_pending_used) of the staging buffer.  A raw
+// pointer, freed by release_workspace: thread_local objects with destructors do not survive the atexit order (see LookAhead).
+struct PendingFetch {
+  HostFetch::Piece pieces[8];
+  int n;
+  hipStream_t s;
+  std::function<int()> after;
+};
+static thread_local std::vector<PendingFetch>* g_pending = nullptr;
+static thread_local size_t g_pending_used = 0;
+static thread_local int g_defer = 0;
+bool defer_requested() { return g_defer != 0; }
+
 int HostFetch::add(void* dst, const void* src, size_t bytes, hipStream_t s)
 {
   if(bytes == 0) return GPC_OK;
   size_t cap = 0;
   char* base = nullptr;
   GPC_CHECK(host_stage(&cap, &base));
+  if(n == 0 && used == 0) used = g_pending_used;     // behind the postponed pieces
   const size_t off = (used + 15) & ~(size_t)15;
   if(n >= 8 || off + bytes > cap) {
     GPC_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, s));
     return GPC_OK;
   }
-  GPC_HIP_CHECK(hipMemcpyAsync(base + off, src, bytes, hipMemcpyDeviceToHost, s));
+  const bool gather = host_gather_on() && (bytes % 4) == 0 && (reinterpret_cast<uintptr_t>(src) % 4) == 0 && bytes < (size_t(1) << 31);
+  if(!gather) GPC_HIP_CHECK(hipMemcpyAsync(base + off, src, bytes, hipMemcpyDeviceToHost, s));
   pieces[n].dst = dst;
   pieces[n].off = off;
   pieces[n].bytes = bytes;
+  pieces[n].src = gather ? src : nullptr;
   n++;
   used = off + bytes;
   return GPC_OK;
 }
 
-int HostFetch::finish(hipStream_t s)
+int HostFetch::defer(hipStream_t s, std::function<int()> after)
 {
-  GPC_HIP_CHECK(hipStreamSynchronize(s));
-  if(n > 0) {
+  if(!g_pending) g_pending = new std::vector<PendingFetch>();
+  // the pieces are snapshotted into the staging buffer NOW, in stream order: what they point at is typically scratch that the
+  // caller's next launches reuse (the log-determinant's partial sums and the column dots' share a workspace slot)
+  {
     size_t cap = 0;
     char* base = nullptr;
     GPC_CHECK(host_stage(&cap, &base));
-    for(int i = 0; i < n; i++) memcpy(pieces[i].dst, base + pieces[i].off, pieces[i].bytes);
+    GatherArgs ga;
+    ga.n = 0;
+    size_t total = 0;
+    for(int i = 0; i < n; i++)
+      if(pieces[i].src) {
+        ga.src[ga.n] = static_cast<const unsigned*>(pieces[i].src);
+        ga.dst[ga.n] = reinterpret_cast<unsigned*>(base + pieces[i].off);
+        ga.words[ga.n] = (unsigned)(pieces[i].bytes / 4);
+        total += pieces[i].bytes / 4;
+        ga.n++;
+        pieces[i].src = nullptr;
+      }
+    if(ga.n > 0) {
+      unsigned blocks = (unsigned)((total + 2047) / 2048);
+      if(blocks < 1) blocks = 1;
+      if(blocks > 32) blocks = 32;
+      hipLaunchKernelGGL(host_gather_kernel, dim3(blocks), dim3(256), 0, s, ga);
+      GPC_HIP_CHECK(hipGetLastError());
+    }
   }
+  PendingFetch pf;
+  for(int i = 0; i < n; i++) pf.pieces[i] = pieces[i];
+  pf.n = n;
+  pf.s = s;
+  pf.after = std::move(after);
+  g_pending->push_back(std::move(pf));
+  if(used > g_pending_used) g_pending_used = used;
   n = 0;
   used = 0;
   return GPC_OK;
+}
+
+int HostFetch::finish(hipStream_t s)
+{
+  size_t cap = 0;
+  char* base = nullptr;
+  GPC_CHECK(host_stage(&cap, &base));
+  const size_t npend = g_pending ? g_pending->size() : 0;
+  for(size_t k = 0; k < npend; k++)
+    if((*g_pending)[k].s != s) GPC_HIP_CHECK(hipStreamSynchronize((*g_pending)[k].s));   // (its producers ran on another stream)
+  {
+    // one gather kernel per 8 pieces: this fetch's and the postponed ones'
+    GatherArgs ga;
+    ga.n = 0;
+    size_t total = 0;
+    auto flush = [&]() -> int {
+      if(ga.n == 0) return GPC_OK;
+      unsigned blocks = (unsigned)((total + 2047) / 2048);
+      if(blocks < 1) blocks = 1;
+      if(blocks > 32) blocks = 32;
+      hipLaunchKernelGGL(host_gather_kernel, dim3(blocks), dim3(256), 0, s, ga);
+      GPC_HIP_CHECK(hipGetLastError());
+      ga.n = 0;
+      total = 0;
+      return GPC_OK;
+    };
+    auto take = [&](const Piece& pc) -> int {
+      if(!pc.src) return GPC_OK;
+      ga.src[ga.n] = static_cast<const unsigned*>(pc.src);
+      ga.dst[ga.n] = reinterpret_cast<unsigned*>(base + pc.off);
+      ga.words[ga.n] = (unsigned)(pc.bytes / 4);
+      total += pc.bytes / 4;
+      if(++ga.n == 8) return flush();
+      return GPC_OK;
+    };
+    for(size_t k = 0; k < npend; k++)
+      for(int i = 0; i < (*g_pending)[k].n; i++) GPC_CHECK(take((*g_pending)[k].pieces[i]));
+    for(int i = 0; i < n; i++) GPC_CHECK(take(pieces[i]));
+    GPC_CHECK(flush());
+  }
+  GPC_HIP_CHECK(hipStreamSynchronize(s));
+  for(int i = 0; i < n; i++) memcpy(pieces[i].dst, base + pieces[i].off, pieces[i].bytes);
+  n = 0;
+  used = 0;
+  int rc = GPC_OK;
+  if(npend) {
+    // (moved out first: an `after` may itself fetch)
+    std::vector<PendingFetch> todo;
+    todo.swap(*g_pending);
+    g_pending_used = 0;
+    for(auto& pf : todo) {
+      for(int i = 0; i < pf.n; i++) memcpy(pf.pieces[i].dst, base + pf.pieces[i].off, pf.pieces[i].bytes);
+      if(pf.after) {
+        const int r = pf.after();
+        if(rc == GPC_OK) rc = r;
+      }
+    }
+  }
+  return rc;
 }
 
 int potri_full(bool lower, int64_t N, double* A, int64_t lda, hipStream_t s);
@@ -199,6 +321,10 @@ static void release_workspace()
     (void)hipHostFree(g_stage.p);
     g_stage.p = nullptr;
   }
+  delete g_pending;
+  g_pending = nullptr;
+  g_pending_used = 0;
+  g_defer = 0;
 }
 
 static thread_local bool g_flow_timed_out = false;   // the last read_info saw the dataflow kernel's time-out marker
@@ -317,9 +443,42 @@ int gpc_free(void* dptr)
 int gpc_memcpy_h2d(void* dst, const void* src, size_t bytes, void* stream)
 {
   GPC_CHECK(ensure_device());
+  if(defer_requested() && bytes > 0 && bytes <= HOST_STAGE_BYTES / 4) {
+    // gpc_defer(1): the bytes are taken NOW into the thread's pinned staging buffer (the caller may reuse src at once) and go
+    // to the device from there without a wait; that part of the buffer is released by the thread's next synchronising call
+    size_t cap = 0;
+    char* base = nullptr;
+    GPC_CHECK(host_stage(&cap, &base));
+    const size_t off = (g_pending_used + 15) & ~(size_t)15;
+    if(base && off + bytes <= cap) {
+      memcpy(base + off, src, bytes);
+      GPC_HIP_CHECK(hipMemcpyAsync(dst, base + off, bytes, hipMemcpyHostToDevice, as_stream(stream)));
+      if(!g_pending) g_pending = new std::vector<PendingFetch>();
+      PendingFetch pf;
+      pf.n = 0;
+      pf.s = as_stream(stream);
+      g_pending->push_back(std::move(pf));
+      g_pending_used = off + bytes;
+      return GPC_OK;
+    }
+  }
   GPC_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, as_stream(stream)));
   GPC_HIP_CHECK(hipStreamSynchronize(as_stream(stream)));  // pageable host memory: keep the semantics simple
   return GPC_OK;
+}
+
+int gpc_defer(int on)
+{
+  g_defer = on ? 1 : 0;
+  return GPC_OK;
+}
+
+int gpc_sync_pending(void* stream)
+{
+  GPC_CHECK(ensure_device());
+  if(!g_pending || g_pending->empty()) return GPC_OK;
+  HostFetch f;
+  return f.finish(as_stream(stream));
 }
 
 int gpc_memcpy_d2h(void* dst, const void* src, size_t bytes, void* stream)
@@ -330,6 +489,12 @@ int gpc_memcpy_d2h(void* dst, const void* src, size_t bytes, void* stream)
   // as GPC_EHIP at the latest when its results are fetched -- also when no host-scalar call (gpc_coldot_f64) follows it
   int fault = 0;
   int* sticky = g_ws[WS_INFO].p ? static_cast<int*>(g_ws[WS_INFO].p) + SOLVE_FAULT_WORD : nullptr;
+  if(defer_requested() && bytes <= HOST_STAGE_BYTES / 4) {
+    // gpc_defer(1): the copy rides in this thread's next synchronising call (include/gpc_hip.h); dst is valid after that
+    HostFetch f;
+    GPC_CHECK(f.add(dst, src, bytes, as_stream(stream)));
+    return f.defer(as_stream(stream), nullptr);
+  }
   HostFetch f;
   GPC_CHECK(f.add(dst, src, bytes, as_stream(stream)));
   if(sticky) GPC_CHECK(f.add(&fault, sticky, sizeof(int), as_stream(stream)));
@@ -462,6 +627,34 @@ int gpc_chol_inverse_f64(int64_t N, double* A, int64_t lda, double* invK, int64_
     GPC_CHECK(gemm(false, true, N, N, Np, 1.0, W + Np, ld2, W + Np, ld2, 0.0, invK, ldi, 1, s));
   }
   GPC_CHECK(symmetrize(true, N, invK, ldi, s));
+  if(logdet && defer_requested() && ld_n > 0 && ld_n <= 1024) {
+    // gpc_defer(1): no synchronisation here at all -- *info and *logdet are written when this thread's next synchronising
+    // call (the GP-LVM's column dots, two launches further on) brings the partial sums and the info word over
+    double* h = static_cast<double*>(malloc(sizeof(double) * (size_t)ld_n));
+    if(!h) return GPC_ENOMEM;
+    HostFetch f;
+    int rc = f.add(h, ld_part, sizeof(double) * (size_t)ld_n, s);
+    if(rc == GPC_OK) rc = f.add(info, d_info, sizeof(int), s);
+    if(rc != GPC_OK) {
+      free(h);
+      return rc;
+    }
+    const int64_t nparts = ld_n;
+    return f.defer(s, [h, nparts, info, logdet]() -> int {
+      double sl = 0.0;
+      for(int64_t b = 0; b < nparts; b++) sl += h[b];        // (the order of reduce_partials_to_host)
+      free(h);
+      if(*info == PANEL_FLOW_TIMEOUT) {
+        *info = 0;
+        g_flow_timed_out = true;
+        set_error("the dataflow panel factorisation timed out (device shared or pre-empted?); the factor is unusable -- repeat the "
+                  "call, or set GPC_PANEL_FLOW=0 for the launch chain");
+        return GPC_EHIP;
+      }
+      *logdet = *info == 0 ? 2.0 * sl : 0.0;
+      return GPC_OK;
+    });
+  }
   if(logdet) {
     double sl = 0.0;
     GPC_CHECK(diag_reduce_fetch(ld_part, ld_n, &sl, s, info, d_info));     // (one synchronisation: info arrives with the sums)

@@ -2,6 +2,7 @@
 #pragma once
 #include <vector>
 #include <hip/hip_runtime.h>
+#include <functional>
 #include <stdint.h>
 #include <stddef.h>
 #include "gpc_hip.h"
@@ -60,13 +61,18 @@ int workspace(int slot, size_t bytes, void** out);
 // 20-30 us each, which is what a GP-LVM evaluation at N = 1000 mostly consisted of.  add() queues a copy (falls back to a
 // direct pageable copy when the piece does not fit), finish() synchronises the stream ONCE and hands the pieces out.
 struct HostFetch {
-  struct Piece { void* dst; size_t off, bytes; };
+  struct Piece { void* dst; size_t off, bytes; const void* src; };   // src != nullptr: gathered by finish()'s kernel
   Piece pieces[8];
   int n = 0;
   size_t used = 0;
   int add(void* dst, const void* src, size_t bytes, hipStream_t s);
   int finish(hipStream_t s);
+  // Postponed form of finish(): no synchronisation now.  The pieces keep their part of the staging buffer and reach their
+  // destinations -- after which `after` (may be empty) runs -- inside the NEXT finish() of this thread, or in gpc_sync_pending.
+  // For callers that have asked for it (gpc_defer): the outputs of the postponed call are not valid before that.
+  int defer(hipStream_t s, std::function<int()> after);
 };
+bool defer_requested();   // capi.hip: gpc_defer(1) is active on this thread
 int host_stage(size_t* capacity, char** base);   // capi.hip: the thread's pinned staging buffer
 bool poison_allocations();   // GPC_POISON_ALLOC=1: new buffers start as NaN (testing aid)
 // WS_INFO layout (64 bytes, zeroed when allocated): int[0] = LAPACK info of the running factorisation, int[4] = sticky

@@ -214,7 +214,8 @@ __global__ void __launch_bounds__(256) gradx_reduce_kernel(const double* __restr
   const int q = blockIdx.y;
   if(i >= N) return;
   double v = 0.0;
-  for(int s = 0; s < nsplit; s++) v += part[((int64_t)s * D + q) * N + i];
+#pragma unroll 8
+  for(int s = 0; s < nsplit; s++) v += part[((int64_t)s * D + q) * N + i];      // (the loads of eight slices in flight; same order of addition)
   out[i + (int64_t)q * ldo] = v;
 }
 

@@ -1022,7 +1022,10 @@ static int kern_grad_pass(const gpc_kspec* ksp, const double* X, int64_t N, int6
   // the final reductions amortised) on a large one
   const int64_t sym_nrb = (N + GMI - 1) / GMI;
   int64_t sym_per = sym_nrb * (sym_nrb + 1) / 768;
-  if(sym_per < 4) sym_per = 4;
+  // (N = 1000, the GP-LVM's size: 16 row blocks; at four tiles per workgroup 72 workgroups had work and the rbfard pass took
+  //  52 us of a 670 us evaluation; one tile each fills the chip)
+  const int64_t per_min = (N < 2048) ? 1 : 4;
+  if(sym_per < per_min) sym_per = per_min;
   if(sym_per > 48) sym_per = 48;
   const int64_t sym_ny = (2 * sym_nrb + sym_per - 1) / sym_per;
   g.all_general = (N < 4096) ? 1 : 0;

@@ -223,6 +223,14 @@ void CGplvm::setOptParams(const CMatrix& param)
   updateX();
 }
 
+namespace {
+// gpc_defer(1) for the calls inside the scope (include/gpc_hip.h); exception-safe
+struct DeferScope {
+  DeferScope() { (void)gpc_defer(1); }
+  ~DeferScope() { (void)gpc_defer(0); }
+};
+}  // namespace
+
 void CGplvm::updateK() const
 {
   if(KupToDate) return;
@@ -234,18 +242,29 @@ void CGplvm::updateK() const
   }
   if(!dK) dK = devAlloc((size_t)N * N);
   if(!dA) dA = devAlloc((size_t)N * d);
-  { Timed t(0, "h2d X"); gpcCheck(gpc_memcpy_h2d(dX, pX->getVals(), sizeof(double) * (size_t)N * q, 0)); }
+  {
+    Timed t(0, "h2d X");
+    DeferScope defer;     // (no wait of its own: the bytes are staged at once, include/gpc_hip.h)
+    gpcCheck(gpc_memcpy_h2d(dX, pX->getVals(), sizeof(double) * (size_t)N * q, 0));
+  }
   gpc_kspec ks;
   pkern->toKspec(ks);
   if(!dL) dL = devAlloc((size_t)N * N);
   { Timed t(1, "gram"); gpcCheck(gpc_gram_sym_f64(&ks, dX, N, q, N, dL, N, 0)); }                // _updateK, CGplvm.cpp:418-432
   int info = 0;
   // LcholK.chol(), logDet(LcholK), invK.pdinv(LcholK) (CGplvm.cpp:441-444) in one pass: dL <- L, dK <- invK
-  { Timed t(2, "chol_inverse"); gpcCheck(gpc_chol_inverse_f64(N, dL, N, dK, N, &logDetK, &info, 0)); }
-  if(info != 0) throw ndlexceptions::MatrixNonPosDef();
+  // (gpc_defer: the factorisation's info and log-determinant come back in the column dots' synchronisation two launches
+  //  further on instead of one of their own -- the host issues the product and the dots while the device still factors)
+  {
+    Timed t(2, "chol_inverse");
+    DeferScope defer;
+    gpcCheck(gpc_chol_inverse_f64(N, dL, N, dK, N, &logDetK, &info, 0));
+  }
   { Timed t(3, "gemm invK m"); gpcCheck(gpc_gemm_f64('N', 'N', N, d, N, 1.0, dK, N, dM, N, 0.0, dA, N, 0)); }  // invK * m, column by column in 503 / 374
   quad.assign((size_t)d, 0.0);
   { Timed t(4, "coldot"); gpcCheck(gpc_coldot_f64(N, d, dA, N, dM, N, &quad[0], 0)); }
+  gpcCheck(gpc_sync_pending(0));     // (nothing left unless the dots had no rows)
+  if(info != 0) throw ndlexceptions::MatrixNonPosDef();
   KupToDate = true;
 }
 
@@ -278,14 +297,20 @@ double CGplvm::logLikelihoodGradient(CMatrix& g) const
   // sum over the outputs of updateCovGradient (CGplvm.cpp:365-378); both passes below are linear in covGrad
   { Timed t(5, "covgrad_multi"); gpcCheck(gpc_covgrad_multi_f64(N, d, dK, N, dA, N, dG, N, 0)); }
   std::vector<double> gk(nk > 0 ? nk : 1, 0.0);
+  std::vector<double> gx((size_t)N * q);
+  // dL/dX first and its copy to the host postponed (gpc_defer), the parameter sums second: ONE wait for both instead of two
+  { Timed t(7, "kern_gradx"); gpcCheck(gpc_kern_gradx_f64(&ks, dX, N, q, N, dG, N, dGX, N, 0)); }      // getGradX + dotColCol loop, 573-604
+  {
+    Timed t(8, "d2h gx");
+    DeferScope defer;
+    gpcCheck(gpc_memcpy_d2h(&gx[0], dGX, sizeof(double) * gx.size(), 0));
+  }
   { Timed t(6, "kern_grad"); gpcCheck(gpc_kern_grad_f64(&ks, dX, N, q, N, dG, N, &gk[0], 0)); }      // getGradTransParams, CGplvm.cpp:589-596
+  gpcCheck(gpc_sync_pending(0));     // (gx is there: kern_grad's wait brought it; this only covers a pass that did not wait)
   for(unsigned int t = 0; t < pkern->getNumTransforms(); t++) {
     const unsigned int idx = pkern->getTransformIndex(t);
     gk[idx] *= pkern->getTransformGradFact(pkern->getParam(idx), t);
   }
-  { Timed t(7, "kern_gradx"); gpcCheck(gpc_kern_gradx_f64(&ks, dX, N, q, N, dG, N, dGX, N, 0)); }      // getGradX + dotColCol loop, 573-604
-  std::vector<double> gx((size_t)N * q);
-  { Timed t(8, "d2h gx"); gpcCheck(gpc_memcpy_d2h(&gx[0], dGX, sizeof(double) * gx.size(), 0)); }
   for(unsigned int i = 0; i < nk; i++) g.setVal(gk[i], 0, i);
   for(int64_t k = 0; k < q; k++)
     for(int64_t i = 0; i < N; i++) {

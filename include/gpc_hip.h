@@ -82,6 +82,18 @@ int gpc_memcpy_d2h(void* dst_host, const void* src_dev, size_t bytes, void* stre
 int gpc_memcpy_d2d(void* dst_dev, const void* src_dev, size_t bytes, void* stream);
 int gpc_memset(void* dst_dev, int byte, size_t bytes, void* stream);
 int gpc_stream_sync(void* stream);
+
+/* Latency aid for short evaluation loops (the GP-LVM's objective at N = 1000 is four host waits per evaluation, each
+ * ~25 us of idle GPU).  While gpc_defer(1) is set on the calling thread,
+ *   - gpc_chol_inverse_f64 (logdet != NULL, N <= GPC_CHOLINV_MAXN) and
+ *   - gpc_memcpy_d2h (up to 64 KB), and gpc_memcpy_h2d (up to 64 KB: the source is copied at once, the caller may reuse it)
+ * return WITHOUT synchronising: their host outputs (*logdet, *info; the destination buffer) are written later, inside the
+ * next call of this thread that does synchronise with results for the host (gpc_coldot_f64, gpc_kern_grad_f64,
+ * gpc_logdet_chol_f64, ... any call returning host scalars) or inside gpc_sync_pending.  An error detected late (a dataflow
+ * time-out) is returned by that later call.  Everything else behaves as without it.  Replaces nothing in the reference:
+ * it reorders the waits of CGplvm::logLikelihood / logLikelihoodGradient (CGplvm.cpp:480-604). */
+int gpc_defer(int on);
+int gpc_sync_pending(void* stream);
 int gpc_workspace_release(void);                 /* free the library's grow-only scratch buffers */
 
 /* ---- Gram construction ----------------------------------------------------------------------------------------

@@ -1245,3 +1245,44 @@ np.save(sys.argv[1], Lh[rows] @ Lh.T)
     assert int(f[1]) == 0
     assert abs(float(f[2]) - want) <= 1e-10 * abs(want)
     assert np.abs(got - K[rows]).max() <= 1e-11
+
+
+
+def test_defer_postpones_the_wait_not_the_result(api):
+    """gpc_defer (include/gpc_hip.h): chol_inverse and the host copies return without waiting; their outputs arrive with the
+    thread's next waiting call -- the same numbers as without it, also when that call reuses the scratch slot the postponed
+    partial sums sat in (the column dots do: the case that bit during development)."""
+    import ctypes
+    from ctypes import c_double, c_int, byref
+    import torch
+    from gpc_amd import synth
+    from gpc_amd._lib import check
+    lib = api.lib()
+    N, D, d = 700, 3, 5
+    X, _ = synth.make_xy(N, D, 11)
+    M = np.asfortranarray(np.random.default_rng(5).standard_normal((N, d)))
+    ks = api.kspec([("rbf", [1.3, 0.9]), ("white", [0.05])])
+    Xd, Md = api.from_host(X), api.from_host(M)
+    K0 = api.empty(N, N)
+    api.gram_sym(ks, Xd, K0)
+    inv_ref, ld_ref, info_ref = api.chol_inverse(K0.clone())          # the waiting call
+    assert info_ref == 0
+    A2, inv2 = K0.clone(), api.empty(N, N)
+    logdet, info = c_double(123.0), c_int(77)
+    host = np.full(N * d, -1.0)
+    check(lib.gpc_defer(1))
+    check(lib.gpc_chol_inverse_f64(N, api.ptr(A2), api.ld(A2), api.ptr(inv2), api.ld(inv2), byref(logdet), byref(info), api.stream()))
+    check(lib.gpc_memcpy_d2h(host.ctypes.data_as(ctypes.c_void_p), api.ptr(Md), host.nbytes, api.stream()))
+    check(lib.gpc_defer(0))
+    q = api.coldot(Md, Md)            # a waiting call that reuses the reduction scratch
+    assert info.value == 0 and abs(logdet.value - ld_ref) <= 1e-12 * abs(ld_ref)
+    assert np.array_equal(host, M.reshape(-1, order="F"))
+    assert np.allclose(q, (M * M).sum(axis=0), rtol=1e-12)
+    assert torch.equal(inv2, inv_ref)
+    check(lib.gpc_sync_pending(api.stream()))          # nothing pending: a no-op
+    host2 = np.zeros(N * d)
+    check(lib.gpc_defer(1))
+    check(lib.gpc_memcpy_d2h(host2.ctypes.data_as(ctypes.c_void_p), api.ptr(Md), host2.nbytes, api.stream()))
+    check(lib.gpc_defer(0))
+    check(lib.gpc_sync_pending(api.stream()))          # ... and with something pending it delivers
+    assert np.array_equal(host2, host)
