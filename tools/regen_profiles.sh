@@ -1,3 +1,5 @@
+# regenerates the committed rNN profiles on the GPU box: PMC traffic of the bench command first (bench.py replays it), the
+# default and cfg 2 lines, kernel traces and counters (make_profiles.sh, pmc_kgrad.sh), gradient / gemm / DTC / GP-LVM timings
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 bash tools/pmc_bench_traffic.sh r04 > gpurun_out/r47_pmc_bench.log 2>&1

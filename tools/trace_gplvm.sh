@@ -1,3 +1,4 @@
+# kernel + memory-copy trace of the GP-LVM run (config 5): the timeline of one evaluation cycle with its idle gaps (GPU box)
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 cd /tmp
