@@ -31,6 +31,9 @@ constexpr int PF_TS = 18;   // row stride of potf2's multiplier table
 #ifndef PF_LEAN_NS
 #define PF_LEAN_NS 1
 #endif
+#ifndef PF_LEAN_MINROWS
+#define PF_LEAN_MINROWS 5120   // launches of at least this many rows take the two-per-CU form (pf_lean)
+#endif
 
 struct PanelFlowArgs {
   double* P;          // the panel: M rows x nbk columns, leading dimension lda
@@ -789,6 +792,14 @@ __global__ void __launch_bounds__(256, (NS < 3 ? 2 : 1)) panel_flow_kernel(const
 
 }  // namespace
 
+// which form of the kernel a launch of M rows takes (see panel_flow)
+static bool pf_lean(int64_t M)
+{
+  static const int lean_env = [] { const char* e = getenv("GPC_PANEL_FLOW_LEAN"); return e ? atoi(e) : -1; }();
+  static const int64_t minrows = [] { const char* e = getenv("GPC_PANEL_FLOW_LEAN_MINROWS"); return e ? atoll(e) : (int64_t)PF_LEAN_MINROWS; }();
+  return lean_env >= 0 ? (lean_env > 0) : (M >= minrows);
+}
+
 // Factor the nbk-column panel whose diagonal block starts at P (M rows, M >= nbk): one launch.  Returns GPC_EUNSUPPORTED
 // when the shape is outside what the kernel takes (the caller then runs the launch chain).  zero_row0 >= 0: the rows from
 // zero_row0 on (a multiple of 64, relative to the panel) are an identity block whose 64-row block i is still zero left of
@@ -835,14 +846,16 @@ int panel_flow(int64_t M, int64_t nbk, double* P, int64_t lda, int* d_info, int6
   // to outlast the limit
   if(polls < 64) hipLaunchKernelGGL(panel_flow_giveup_kernel, dim3(1), dim3(64), 0, s, ctl, d_info);
   const int64_t nblocks = (int64_t)ncb * nrb - (int64_t)ncb * (ncb - 1) / 2;
-  // GPC_PANEL_FLOW_LEAN=1 (measurement aid): the two-per-CU form (one operand set, 256 registers, 124 bytes of scratch).  It
-  // does start beside a running trailing update (a tile factorisation launched 1 ms into a 9.2 ms update: done after 2.0 ms
-  // instead of 8.1).  Round 4, with the register-resident solve: on its own it is as fast as the default form where the
-  // critical path rules (N = 1000: 0.30 against 0.32 ms), slower where the launch is bound by its products (N = 4096, one
-  // launch: 1.28 against 1.19 ms), 2 % faster on tall panels (N = 16 384: 27.9 against 28.5 ms) -- and look-ahead with it
-  // beside the update still buys nothing at cfg 3 (1393 against 1389 ms: the panels' work is conserved, not hidden).
-  static const int lean_env = [] { const char* e = getenv("GPC_PANEL_FLOW_LEAN"); return e ? atoi(e) : 0; }();
-  if(lean_env > 0)
+  // The two-per-CU form (one operand set, 256 registers, 124 bytes of scratch) against the one-per-CU form (three operand sets,
+  // 416 registers).  Where the critical path rules the two are level or the fat form wins (N = 1000: 0.30 against 0.32 ms, N =
+  // 4096 as one launch: 1.21 against 1.19); a TALL panel is bound by its blocks' products, and two workgroups per CU cover each
+  // other's polls and LDS round trips: N = 7168 3.65 -> 3.47 ms, 8192 4.90 -> 4.71, 10 240 8.45 -> 8.06, 12 288 13.35 -> 12.64, 16 384
+  // 28.3 -> 27.6 (tools/factor_sweep.py under GPC_PANEL_FLOW_LEAN_MINROWS; 5120 ... 6144 rows: level).  So the form is
+  // chosen per launch by the panel's height (pf_lean(); GPC_PANEL_FLOW_LEAN = 0 / 1 forces one form, GPC_PANEL_FLOW_LEAN_MINROWS
+  // moves the height).  The lean form also starts beside a running trailing update (a tile factorisation launched 1 ms into a
+  // 9.2 ms update: done after 2.0 ms instead of 8.1), but look-ahead with it buys nothing on one GPU (cfg 3: 1393 against 1389
+  // ms, N = 8192: 5.28 against 4.72 -- the panels' work is conserved, not hidden).
+  if(pf_lean(M))
     hipLaunchKernelGGL(panel_flow_kernel<PF_LEAN_NS>, dim3((unsigned)nblocks), dim3(256), 0, s, g);
   else
     hipLaunchKernelGGL(panel_flow_kernel<3>, dim3((unsigned)nblocks), dim3(256), 0, s, g);
@@ -900,7 +913,12 @@ int panel_flow_given(int64_t id_rows, int64_t nbk, double* E, int64_t lde, const
   g.max_polls = polls;
   if(polls < 64) hipLaunchKernelGGL(panel_flow_giveup_kernel, dim3(1), dim3(64), 0, s, ctl, d_info);
   const int64_t nblocks = (int64_t)ncb * nrb - (int64_t)ncb * (ncb - 1) / 2;
-  hipLaunchKernelGGL(panel_flow_kernel<3>, dim3((unsigned)nblocks), dim3(256), 0, s, g);
+  // the two-per-CU form from the same height as the factorisation's launches (dpotri at N = 3072 1.20 -> 1.10 ms, 4096 2.07 ->
+  // 1.87, 8192 8.13 -> 7.9, 12 288 23.8 -> 22.8, 16 384 51.6 -> 50.5; N = 2048, a launch of 4096 rows, loses: 0.56 -> 0.61)
+  if(pf_lean(M))
+    hipLaunchKernelGGL(panel_flow_kernel<PF_LEAN_NS>, dim3((unsigned)nblocks), dim3(256), 0, s, g);
+  else
+    hipLaunchKernelGGL(panel_flow_kernel<3>, dim3((unsigned)nblocks), dim3(256), 0, s, g);
   GPC_HIP_CHECK(hipGetLastError());
   return GPC_OK;
 }

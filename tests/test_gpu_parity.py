@@ -1286,3 +1286,66 @@ def test_defer_postpones_the_wait_not_the_result(api):
     check(lib.gpc_defer(0))
     check(lib.gpc_sync_pending(api.stream()))          # ... and with something pending it delivers
     assert np.array_equal(host2, host)
+
+
+_ILLCOND_CODE = r'''
+import sys
+import numpy as np
+sys.path.insert(0, %r)
+import torch
+from gpc_amd import api, synth
+N, D = 14336, 2
+X, y = synth.make_xy(N, D, 99)
+terms = [("rbf", [0.05, 1.0]), ("white", [1e-6])]       # inverse width 0.05 on two inputs: a numerically low-rank Gram + 1e-6 I
+ks = api.kspec(terms)
+Xd = api.from_host(X)
+K = api.gram_sym(ks, Xd)
+idx = [0, 1023, 1024, 2047, 2048, 5000, 13000, N - 1]
+Kcols = K[:, idx].clone()
+tile = K[:1024, :1024].clone()
+ev = torch.linalg.eigvalsh(tile)
+L, ld, jit, info = api.gp_update_k(ks, Xd, K)
+res = 0.0
+for q, j in enumerate(idx):
+    col = L[j:, :j + 1] @ L[j, :j + 1]
+    res = max(res, float((col - Kcols[j:, q]).abs().max()))
+m = api.from_host(y - y.mean())
+alpha = api.gp_alpha(L, m)
+Kf = api.gram_sym(ks, Xd)
+r = float((Kf @ alpha - m).abs().max()) / float(alpha.abs().max())
+print("RESULT", info, repr(jit), repr(ld), repr(res), repr(r), repr(float(ev[-1] / ev[0])))
+np.save(sys.argv[1], api.to_host(L[:, idx]))
+'''
+
+
+def test_tall_panels_by_tile_inverse_on_an_ill_conditioned_gram(api):
+    """Round 3's advisor: from 12 288 rows below a panel's diagonal tile, L21 = A21 inv(L11)' is formed with an EXPLICIT inverse
+    (potrf.hip panel_by_inverse), whose backward error carries cond(L11) where a substitution carries 1.  The benign synthetic
+    configurations do not show the difference; this Gram does (rbf of inverse width 0.05 on two inputs + 1e-6 I: the leading
+    1024 x 1024 tile has a condition number of ~1e9).  The same matrix is factored with the tile-inverse panels (default) and
+    with substitution panels (GPC_PANEL_INV_MINROWS=0, the dataflow solve): both must be backward stable at the level the
+    parity bar needs -- L L' = K on sampled columns, K alpha = m -- and agree with each other in log|K| (1e-8 relative, the
+    north_star tolerance) and in the factor's entries."""
+    import subprocess
+    import sys
+    import tempfile
+    got = {}
+    with tempfile.TemporaryDirectory() as td:
+        for name, env in (("inverse", {}), ("substitution", {"GPC_PANEL_INV_MINROWS": "0"})):
+            out = os.path.join(td, name + ".npy")
+            r = subprocess.run([sys.executable, "-c", _ILLCOND_CODE % ROOT, out], env=dict(os.environ, **env), stdout=subprocess.PIPE,
+                               stderr=subprocess.PIPE, timeout=900)
+            assert r.returncode == 0, r.stderr.decode()[-2000:]
+            f = [ln for ln in r.stdout.decode().splitlines() if ln.startswith("RESULT")][0].split()
+            got[name] = dict(info=int(f[1]), jit=float(f[2]), ld=float(f[3]), res=float(f[4]), solve=float(f[5]), cond=float(f[6]),
+                             cols=np.load(out))
+    a, b = got["inverse"], got["substitution"]
+    print("ill-conditioned Gram: cond(tile) %.2e; L L' - K: inverse %.2e, substitution %.2e; K alpha - m (relative to |alpha|): %.2e, %.2e; "
+          "log|K| %.12e vs %.12e" % (a["cond"], a["res"], b["res"], a["solve"], b["solve"], a["ld"], b["ld"]))
+    assert a["cond"] > 1e8, "the test matrix is not ill-conditioned enough to say anything"
+    assert a["info"] == 0 and b["info"] == 0 and a["jit"] == 0.0 and b["jit"] == 0.0
+    assert b["res"] <= 1e-12 and a["res"] <= 1e-10, (a["res"], b["res"])      # entries of K are <= 1 + 1e-6
+    assert abs(a["ld"] - b["ld"]) <= REL * abs(b["ld"])
+    assert a["solve"] <= 1e-9 and b["solve"] <= 1e-9
+    scale = np.abs(b["cols"]).max()
+    assert np.abs(a["cols"] - b["cols"]).max() <= 1e-7 * scale
