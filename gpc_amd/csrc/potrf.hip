@@ -673,7 +673,7 @@ int panel_by_inverse(int64_t below, int64_t nbk, double* tile, int64_t ldt, doub
 
 static int64_t panel_inv_minrows()
 {
-  static const int64_t v = [] { const char* e = getenv("GPC_PANEL_INV_MINROWS"); return e ? atoll(e) : (int64_t)12288; }();
+  static const int64_t v = [] { const char* e = getenv("GPC_PANEL_INV_MINROWS"); return e ? atoll(e) : (int64_t)28672; }();
   return v;
 }
 static bool panel_inverse_applies(int64_t below, int64_t nbk)

@@ -1319,10 +1319,10 @@ np.save(sys.argv[1], api.to_host(L[:, idx]))
 
 
 def test_tall_panels_by_tile_inverse_on_an_ill_conditioned_gram(api):
-    """Round 3's advisor: from 12 288 rows below a panel's diagonal tile, L21 = A21 inv(L11)' is formed with an EXPLICIT inverse
+    """Round 3's advisor: a tall panel (from 28 672 rows below its diagonal tile; 12 288 until round 4) forms L21 = A21 inv(L11)' with an EXPLICIT inverse
     (potrf.hip panel_by_inverse), whose backward error carries cond(L11) where a substitution carries 1.  The benign synthetic
     configurations do not show the difference; this Gram does (rbf of inverse width 0.05 on two inputs + 1e-6 I: the leading
-    1024 x 1024 tile has a condition number of ~1e9).  The same matrix is factored with the tile-inverse panels (default) and
+    1024 x 1024 tile has a condition number of ~1e9).  The same matrix is factored with the tile-inverse panels (forced at this size) and
     with substitution panels (GPC_PANEL_INV_MINROWS=0, the dataflow solve): both must be backward stable at the level the
     parity bar needs -- L L' = K on sampled columns, K alpha = m -- and agree with each other in log|K| (1e-8 relative, the
     north_star tolerance) and in the factor's entries."""
@@ -1331,7 +1331,7 @@ def test_tall_panels_by_tile_inverse_on_an_ill_conditioned_gram(api):
     import tempfile
     got = {}
     with tempfile.TemporaryDirectory() as td:
-        for name, env in (("inverse", {}), ("substitution", {"GPC_PANEL_INV_MINROWS": "0"})):
+        for name, env in (("inverse", {"GPC_PANEL_INV_MINROWS": "12288"}), ("substitution", {"GPC_PANEL_INV_MINROWS": "0"})):
             out = os.path.join(td, name + ".npy")
             r = subprocess.run([sys.executable, "-c", _ILLCOND_CODE % ROOT, out], env=dict(os.environ, **env), stdout=subprocess.PIPE,
                                stderr=subprocess.PIPE, timeout=900)
