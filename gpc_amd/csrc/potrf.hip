@@ -6,7 +6,7 @@
 //   outer panels of 1024 columns while more than 8192 columns are left, 1024-1664 down to 4096 (whatever leaves the trailing
 //   update a full last round of 256 tiles), the last <= 4096 columns as one panel (panel_width()).
 //   By default EVERY panel is one launch of the dataflow kernel of panel_flow.hip (a workgroup per 64 x 64 block, blocks
-//   published through a polled exchange buffer); a panel with >= 12 288 rows below its diagonal tile factors [tile; I] in that
+//   published through a polled exchange buffer, two workgroups per CU from 5120 rows); a panel with >= 28 672 rows below its diagonal tile factors [tile; I] in that
 //   launch and takes the rows below as ONE k-limited product with the tile's inverse (panel_by_inverse).  The launch chain
 //   described below factors everything when GPC_PANEL_FLOW=0, after a dataflow time-out, and the panels taller than
 //   GPC_PANEL_FLOW_MAXROWS.  After panel k is final its trailing update A22 -= L21 * L21' (depth NB, the fp64 MFMA tiles of
@@ -641,6 +641,9 @@ constexpr int64_t SLAB = 128;
 // columns k <= j of its row block that another workgroup overwrites).  Rounding: L21 carries the error of an explicit inverse
 // of L11, cond(L11) eps instead of eps -- L11 is a Cholesky factor of a 1024 x 1024 diagonal block, whose condition is the
 // square root of the block's; the full-size parity tests (K K^-1 e_j, L L' e_j at N = 65 536) hold at the same tolerances.
+// Round 4: used from 28 672 rows below the tile (12 288 before).  Below that the two-per-CU form of the dataflow launch on the whole
+// panel is faster (N = 16 384 27.4 -> 26.6 ms, 24 576 82.2 -> 80.3, the cfg-3 bench line 1380-1383 -> 1376-1377 ms); above it the two
+// tie at cfg 3 (every panel through the dataflow kernel: 1381-1383 ms) and this form keeps the rows' work on chip-wide products.
 // tile: the nbk x nbk diagonal block (leading dimension ldt), rows: the `below` rows under it (leading dimension ldr) -- two
 // pointers because a grid rank that does not own the tile holds a received copy of it elsewhere (potrf_panel_rows);
 // store_tile: write L11 back over the tile.

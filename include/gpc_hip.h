@@ -373,7 +373,7 @@ int gpc_debug_exp_f64(const double* x, double* y, int64_t n, void* stream);
 /* Outer panel width of gpc_potrf_f64.  Unset (and no GPC_NB), the width follows the remaining columns (potrf.hip
  * panel_width()): 1024 while more than 8192 columns are left, 1024-1664 down to 4096 (whatever leaves the trailing update a
  * full last round of tiles) and the last <= 4096 columns as one dataflow launch.  Every panel is one launch of the dataflow
- * kernel (panel_flow.hip; panels with >= 12 288 rows below the tile factor [tile; I] and take the rows as one product);
+ * kernel (panel_flow.hip; panels with >= 28 672 rows below the tile factor [tile; I] and take the rows as one product);
  * env GPC_PANEL_FLOW=0 switches to the launch chain, GPC_PANEL_FLOW_MAXROWS bounds the panel height the kernel takes. */
 int gpc_set_potrf_blocking(int64_t nb_outer, int64_t jb_inner);   /* nb_outer = 0: back to the default policy */
 /* The schedule that policy produces for an N x N matrix: widths[i] = columns of panel i (at most cap of them are written),
