@@ -514,7 +514,7 @@ def main():
     else:
         # algorithmic HBM bytes of the trailing updates of one factor: each reads its panel rows once (8*m*nb) and reads +
         # writes the lower triangle it updates (2 * 8 * m(m+1)/2); summed over the panels of the schedule gpc_potrf_f64
-        # actually walks (gpc_potrf_panel_schedule = potrf.hip panel_width(): 1024 ... 1664 ... one launch for the last 4096)
+        # actually walks (gpc_potrf_panel_schedule = potrf.hip panel_width(): 1536 ... 1024 ... 1664 ... one launch for the last 4096)
         cnt = ctypes.c_int64(0)
         widths = (ctypes.c_int64 * 4096)()
         api.check(api.lib().gpc_potrf_panel_schedule(N, widths, 4096, ctypes.byref(cnt)))

@@ -3,7 +3,7 @@
 // Replaces dpotrf_ as called by CMatrix::potrf / chol / jitChol (CMatrix.cpp:371-403, 767-804; lapack.h:59-65).
 //
 // Structure:
-//   outer panels of 1024 columns while more than 8192 columns are left, 1024-1664 down to 4096 (whatever leaves the trailing
+//   outer panels of 1536 columns while more than 28 672 columns are left, 1024 down to 8192, 1024-1664 down to 4096 (whatever leaves the trailing
 //   update a full last round of 256 tiles), the last <= 4096 columns as one panel (panel_width()).
 //   By default EVERY panel is one launch of the dataflow kernel of panel_flow.hip (a workgroup per 64 x 64 block, blocks
 //   published through a polled exchange buffer, two workgroups per CU from 5120 rows); a panel with >= 28 672 rows below its diagonal tile factors [tile; I] in that
@@ -929,6 +929,11 @@ static int64_t panel_width(int64_t rem)
       return best_w;
     }
   }
+  // While many columns are left a 1536-wide panel beats 1024: a quarter fewer trailing updates, each with a 1.5x longer k-loop
+  // under the same prologue / epilogue, against panels that cost 1.5x more each (cfg 3 bench line, A/B in one call: 1375.1, 1375.2 ->
+  // 1370.5, 1370.9 ms, the trailing update 0.893 -> 0.898 of peak; N = 49 152 590 -> 588 ms).  1280 / 1408 / 1664 / 1792 gain less or
+  // lose, 2048 loses 20 ms (the [tile; I] launch's chain doubles); from 20 480 or 16 384 columns left instead of 28 672: no further gain.
+  if(rem > 28672) return 1536;
   return 1024;
 }
 

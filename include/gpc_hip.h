@@ -371,7 +371,7 @@ int gpc_debug_exp_f64(const double* x, double* y, int64_t n, void* stream);
 
 /* ---- tuning knobs (also read from env GPC_NB / GPC_JB on first use) ---------------------------------------------- */
 /* Outer panel width of gpc_potrf_f64.  Unset (and no GPC_NB), the width follows the remaining columns (potrf.hip
- * panel_width()): 1024 while more than 8192 columns are left, 1024-1664 down to 4096 (whatever leaves the trailing update a
+ * panel_width()): 1536 while more than 28 672 columns are left, 1024 down to 8192, 1024-1664 down to 4096 (whatever leaves the trailing update a
  * full last round of tiles) and the last <= 4096 columns as one dataflow launch.  Every panel is one launch of the dataflow
  * kernel (panel_flow.hip; panels with >= 28 672 rows below the tile factor [tile; I] and take the rows as one product);
  * env GPC_PANEL_FLOW=0 switches to the launch chain, GPC_PANEL_FLOW_MAXROWS bounds the panel height the kernel takes. */
