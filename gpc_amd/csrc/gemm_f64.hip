@@ -189,8 +189,13 @@ __device__ __forceinline__ bool map_tile(const GemmArgs& g, int& ti, int& tj, co
   // forward, backward, backward, forward (the sums over four rounds of a falling sequence then agree to second order), and
   // a launch of few groups deals 16 ids at a time instead of 64 (two tile columns of a super-tile: four times the rounds to
   // even out over; the XCD's 64 resident workgroups then come from four super-tiles).
-  if(g.kstart == 1 || g.trap_deal) {   // (2: k-start without the deal, see split-k)
-    const unsigned lg = (unsigned)g.deal_lg, i = b >> 3, rnd = i >> lg, x = b & 7u, k = rnd & 3u;
+  // k-end products (a tall panel's rows times the inverse of its tile, KEndScope): a tile's cost RISES with its column, the same
+  // for every row.  Whole super-tiles are dealt round-robin (every XCD then holds the same share of every tile column -- with
+  // contiguous chunks and two super-tile columns, a 1536-wide panel, half the XCDs held the long column: 336 against 288 units),
+  // and the enumeration below runs from the longest tiles to the shortest, so that what is still running when the launch ends are
+  // 8-stage tiles, not 96-stage ones (the launch is only ~10 rounds of workgroups long).
+  if(g.kstart == 1 || g.trap_deal || g.kend == 1) {   // (kstart 2: k-start without the deal, see split-k)
+    const unsigned lg = (g.kend == 1) ? 6u : (unsigned)g.deal_lg, i = b >> 3, rnd = i >> lg, x = b & 7u, k = rnd & 3u;
     L = ((rnd * 8u + ((k == 0u || k == 3u) ? x : 7u - x)) << lg) + (i & ((1u << lg) - 1u));
   }
   int si, sj, di, dj;
@@ -219,6 +224,10 @@ __device__ __forceinline__ bool map_tile(const GemmArgs& g, int& ti, int& tj, co
     sj = s / g.super_m;
     di = (int)(w % SUPER);
     dj = (int)(w / SUPER);
+    if(g.kend == 1) {   // longest k-ranges first: the last super-tile column first, inside a super-tile its last tile column first
+      sj = g.super_n - 1 - sj;
+      dj = SUPER - 1 - dj;
+    }
   } else {
     // Compact enumeration of the VALID lower tiles so that every XCD chunk holds the same number of real tiles:
     // super-tile row r holds r full super-tiles (64 tiles each) and one diagonal super-tile (36 lower tiles);
@@ -791,6 +800,10 @@ static int gemm_ex(bool transa, bool transb, int64_t M, int64_t N, int64_t K, do
   g.kstart = (g_gemm_kstart && !transa && transb && K + g.kstart_off >= M && ((tri == 1 && M == N) || tri == 0 || tri == 3)) ? 1 : 0;
   g.kend = (g_gemm_kend && !transa && transb && N == K && tri == 0) ? 1 : 0;
   {
+    static const int lpt = [] { const char* e = getenv("GPC_GEMM_KEND_LPT"); return e ? atoi(e) : 1; }();
+    if(g.kend && !lpt) g.kend = 2;   // (A/B: the k-limit without the longest-first order and the deal)
+  }
+  {
     static int deal = -1;
     if(deal < 0) { const char* e = getenv("GPC_GEMM_TRAP_DEAL"); deal = e ? atoi(e) : 1; }
     g.trap_deal = (tri == 3 && deal) ? 1 : 0;
@@ -869,7 +882,7 @@ static int gemm_ex(bool transa, bool transb, int64_t M, int64_t N, int64_t K, do
     slots = g.tri_total;  // the valid lower tiles, 8 x 8 super-tile by super-tile
   slots = (slots + 7) & ~7ull;
   const uint64_t slots_plain = slots;   // the enumeration without the round-robin deal's padding
-  if(g.kstart || g.trap_deal) slots = (slots + 511) & ~511ull;   // whole rounds of 8 groups of 64 (or 16) ids (map_tile's deal)
+  if(g.kstart || g.trap_deal || g.kend == 1) slots = (slots + 511) & ~511ull;   // whole rounds of 8 groups of 64 (or 16) ids (map_tile's deal)
   {
     // GPC_GEMM_DEAL_GROUP = 64: a super-tile's worth per group, as before.  dpotri with 16 / 64: N = 5120 2.75 / 2.98 ms,
     // 8192 8.16 / 8.32, 12 288 23.75 / 23.85, 20 480 94.2 / 95.0 (and 8.80 at N = 8192 with 64 dealt plainly round-robin)
@@ -934,6 +947,10 @@ static int gemm_ex(bool transa, bool transb, int64_t M, int64_t N, int64_t K, do
           // the k-start deal pads the grid to whole groups of 512 ids; a workgroup that exits at once still waits for its 73 KB
           // of LDS, so with a few dozen tiles the plain enumeration (and the tiles' own k-starts) is the better launch
           g.kstart = 2;
+          nslots = (unsigned)slots_plain;
+        }
+        if(g.kend == 1) {   // likewise: the k-limit stays, the deal and its padded grid go
+          g.kend = 2;
           nslots = (unsigned)slots_plain;
         }
         return launch_fast_splitk(g, nslots, s);
