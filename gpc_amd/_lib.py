@@ -129,6 +129,8 @@ GRID_SIGNATURES = {
     "alpha": (c_int, [GP, DP, I64]),
     "posterior": (c_int, [GP, DP, I64, DP]),
     "gradient": (c_int, [GP, DP]),
+    "inverse": (c_int, [GP]),
+    "copy_inverse_tile": (c_int, [GP, I64, I64, DP, POINTER(c_int)]),
     "sync": (c_int, [GP]),
     "barrier": (c_int, [GP]),
     "abort": (c_int, [GP]),

@@ -71,7 +71,7 @@ __global__ void __launch_bounds__(256) set_diag_kernel(double* __restrict__ A, i
   const int64_t jl = (I - c) / pc;
   for(int64_t i = threadIdx.x; i < nb; i += 256) {
     const int64_t g = I * nb + i;
-    A[il * nb + i + (jl * nb + i) * lld] = g < N ? dg[g] : 1.0;
+    A[il * nb + i + (jl * nb + i) * lld] = (dg && g < N) ? dg[g] : 1.0;
   }
 }
 
@@ -109,7 +109,8 @@ __device__ __forceinline__ double block_sum(double v, double* sh)
 }
 
 __global__ void __launch_bounds__(256) diag_logsum_kernel(const double* __restrict__ A, int64_t lld, int64_t nb, int r, int pr,
-                                                          int c, int pc, int64_t T, double* __restrict__ partial, int refl)
+                                                          int c, int pc, int64_t T, double* __restrict__ partial, int refl,
+                                                          int plain)
 {
   __shared__ double sh[4];
   const int64_t il = blockIdx.x;
@@ -117,7 +118,10 @@ __global__ void __launch_bounds__(256) diag_logsum_kernel(const double* __restri
   double v = 0.0;
   if(I < T && I >= c && (I - c) % pc == 0) {
     const int64_t jl = (I - c) / pc;
-    for(int64_t i = threadIdx.x; i < nb; i += 256) v += log(A[il * nb + i + (jl * nb + i) * lld]);
+    for(int64_t i = threadIdx.x; i < nb; i += 256) {
+      const double a = A[il * nb + i + (jl * nb + i) * lld];
+      v += plain ? a : log(a);      // plain: the entries themselves (the trace of covGrad; its padding entries are zero)
+    }
   }
   const double s = block_sum(v, sh);
   if(threadIdx.x == 0) partial[il] = s;
@@ -147,34 +151,45 @@ __global__ void __launch_bounds__(256) add_transposed_kernel(double* __restrict_
   for(int64_t e = 0; e < d; e++) dst[i + e * ldd] += src[e + i * lds];
 }
 
-__global__ void __launch_bounds__(256) scatter_row_tiles_kernel(double* __restrict__ dst, int64_t ldd, int64_t first, int64_t step,
-                                                                const double* __restrict__ src, int64_t lds, int64_t nb)
+// see GridOps::copy_tiles: workgroup (column b, tile t)
+__global__ void __launch_bounds__(256) copy_tiles_kernel(double* __restrict__ dst, int64_t dstep, int64_t ldd,
+                                                         const double* __restrict__ src, int64_t sstep, int64_t lds, int64_t nb)
 {
   const int64_t t = blockIdx.y, j = blockIdx.x;
-  const double* s = src + t * nb + j * lds;
-  double* d = dst + (first + t * step) * nb + j * ldd;
+  const double* s = src + t * sstep + j * lds;
+  double* d = dst + t * dstep + j * ldd;
   for(int64_t i = 2 * threadIdx.x; i < nb; i += 512)
     *reinterpret_cast<double2_t*>(d + i) = *reinterpret_cast<const double2_t*>(s + i);
+}
+
+// see GridOps::covgrad_local: one workgroup per 256 rows of one local column; tiles above the global diagonal are skipped
+// (the staircase updates never wrote them: they are still zero)
+__global__ void __launch_bounds__(256) covgrad_local_kernel(double* __restrict__ S, int64_t lld, int64_t nb, int64_t rows, int r, int pr,
+                                                            int c, int pc, int refl, int64_t N, const double* __restrict__ Al,
+                                                            int64_t lda, int nd, int64_t n0)
+{
+  const int64_t n = n0 + blockIdx.y;
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if(i >= rows) return;
+  const int64_t jl = n / nb, il = i / nb;
+  const int64_t gj = (c + (int64_t)pc * jl) * nb + (n - jl * nb);
+  const int64_t gi = tile_row(il, r, pr, refl) * nb + (i - il * nb);
+  if(gi / nb < gj / nb) return;
+  double* p = S + i + n * lld;
+  if(gi < gj || gi >= N || gj >= N) {
+    *p = 0.0;
+    return;
+  }
+  double aa = 0.0;
+  for(int o = 0; o < nd; o++) aa = fma(Al[gi + (int64_t)o * lda], Al[gj + (int64_t)o * lda], aa);
+  const double v = -0.5 * ((double)nd * *p - aa);
+  *p = gi > gj ? 2.0 * v : v;
 }
 
 __global__ void __launch_bounds__(256) set_identity_diag_kernel(double* A, int64_t lda, int64_t n)
 {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if(i < n) A[i + i * lda] = 1.0;
-}
-
-// see GridOps::covgrad_block
-__global__ void __launch_bounds__(256) covgrad_block_kernel(double* __restrict__ S, int64_t lds, int64_t M, const double* __restrict__ Al,
-                                                            int64_t lda, int nd, int64_t g0, int upper, int64_t j0)
-{
-  const int64_t j = j0 + blockIdx.y;
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if(i >= M) return;
-  double aa = 0.0;
-  for(int o = 0; o < nd; o++) aa = fma(Al[g0 + i + (int64_t)o * lda], Al[g0 + j + (int64_t)o * lda], aa);
-  const double c = -0.5 * ((double)nd * S[i + j * lds] - aa);
-  const bool twice = upper ? j > i : i > j;
-  S[i + j * lds] = twice ? 2.0 * c : (i == j ? c : 0.0);
 }
 
 // out(j, e) = alpha sum_i A(i, j) v(i, e) (+ beta out): the tall-and-skinny transposed product of the back substitution
@@ -410,6 +425,10 @@ struct HipOps : GridOps {
     sd.voff = u.voff_dev;
     sd.il0 = u.il_begin;
     sd.refl_r = u.refl_r;
+    if(u.role == 3) {     // the distributed inverse: same launch under the solves' kernel name (the profiles keep ROLE 1 for the factorisation)
+      SolveScope role;
+      return gpc::gemm_stair2d(u.M, u.Ncols, u.K, u.alpha, u.W, u.ldw, u.Vbase, u.ldv, u.C, u.ldc, sd, st[s]);
+    }
     TrailingScope role;
     static int p1 = -1;
     if(p1 < 0) { const char* e = getenv("GPC_GRID_P1_TRI"); p1 = e ? atoi(e) : 0; }
@@ -419,22 +438,48 @@ struct HipOps : GridOps {
       const double* Wd = u.W + skip;
       return gpc::gemm(false, true, u.M - skip, u.Ncols, u.K, -1.0, Wd, u.ldw, Wd, u.ldw, 1.0, u.C + skip, u.ldc, 3, st[s]);
     }
-    return gpc::gemm_stair2d(u.M, u.Ncols, u.K, -1.0, u.W, u.ldw, u.Vbase, u.ldv, u.C, u.ldc, sd, st[s]);
+    return gpc::gemm_stair2d(u.M, u.Ncols, u.K, u.alpha, u.W, u.ldw, u.Vbase, u.ldv, u.C, u.ldc, sd, st[s]);
   }
-  int diag_logsum(const double* A, const Layout& L, double* out, int s) override
+  int diag_sum(const double* A, const Layout& L, bool plain, double* out, int s)
   {
     *out = 0.0;
     if(L.Lr <= 0 || L.Lc <= 0) return GPC_OK;
     double* part = nullptr;
     GPC_CHECK(scratch(sizeof(double) * (size_t)L.Lr, &part));
     hipLaunchKernelGGL(diag_logsum_kernel, dim3((unsigned)L.Lr), dim3(256), 0, st[s], A, L.lld, L.nb, L.r, L.pr, L.c, L.pc, L.T,
-                       part, L.refl ? 1 : 0);
+                       part, L.refl ? 1 : 0, plain ? 1 : 0);
     HIPOPS_CHECK(hipGetLastError());
     std::vector<double> h((size_t)L.Lr);
     GPC_CHECK(download(h.data(), part, sizeof(double) * h.size(), s));
     double t = 0.0;
     for(double v : h) t += v;
-    *out = 2.0 * t;
+    *out = plain ? t : 2.0 * t;
+    return GPC_OK;
+  }
+  int diag_logsum(const double* A, const Layout& L, double* out, int s) override { return diag_sum(A, L, false, out, s); }
+  int covgrad_local(double* S, const Layout& L, const double* Al, int64_t lda, int64_t nd, double* trace, int s) override
+  {
+    *trace = 0.0;
+    const int64_t rows = L.Lr * L.nb;
+    if(rows <= 0 || L.nloc <= 0) return GPC_OK;
+    for(int64_t n0 = 0; n0 < L.nloc; n0 += 32768) {
+      const int64_t nc = L.nloc - n0 < 32768 ? L.nloc - n0 : 32768;
+      hipLaunchKernelGGL(covgrad_local_kernel, dim3((unsigned)((rows + 255) / 256), (unsigned)nc), dim3(256), 0, st[s], S, L.lld, L.nb,
+                         rows, L.r, L.pr, L.c, L.pc, L.refl ? 1 : 0, L.N, Al, lda, (int)nd, n0);
+    }
+    HIPOPS_CHECK(hipGetLastError());
+    return diag_sum(S, L, true, trace, s);
+  }
+  int copy_tiles(double* dst, int64_t dstep, int64_t ldd, const double* src, int64_t sstep, int64_t lds, int64_t count, int64_t nb,
+                 int64_t ncols, int s) override
+  {
+    if(count <= 0 || ncols <= 0) return GPC_OK;
+    for(int64_t t0 = 0; t0 < count; t0 += 65535) {
+      const int64_t nt = count - t0 < 65535 ? count - t0 : 65535;
+      hipLaunchKernelGGL(copy_tiles_kernel, dim3((unsigned)ncols, (unsigned)nt), dim3(256), 0, st[s], dst + t0 * dstep, dstep, ldd,
+                         src + t0 * sstep, sstep, lds, nb);
+    }
+    HIPOPS_CHECK(hipGetLastError());
     return GPC_OK;
   }
   int rows_sumsq(const double* Arow, int64_t lld, int64_t nrows, int64_t ncols, double* out, int s) override
@@ -472,46 +517,12 @@ struct HipOps : GridOps {
   {
     return gpc::trsm('L', 'L', 'N', 'N', n, nrhs, 1.0, L, ldl, B, ldb, st[s]);
   }
-  int scatter_row_tiles(double* dst, int64_t ldd, int64_t first, int64_t step, const double* src, int64_t lds, int64_t count,
-                        int64_t nb, int64_t ncols, int s) override
-  {
-    if(count <= 0 || ncols <= 0) return GPC_OK;
-    for(int64_t t0 = 0; t0 < count; t0 += 65535) {
-      const int64_t nt = count - t0 < 65535 ? count - t0 : 65535;
-      hipLaunchKernelGGL(scatter_row_tiles_kernel, dim3((unsigned)ncols, (unsigned)nt), dim3(256), 0, st[s], dst, ldd,
-                         first + t0 * step, step, src + t0 * nb, lds, nb);
-    }
-    HIPOPS_CHECK(hipGetLastError());
-    return GPC_OK;
-  }
   int set_identity(double* A, int64_t lda, int64_t n, int s) override
   {
     GPC_CHECK(zero2d(A, lda, n, n, s));
     hipLaunchKernelGGL(set_identity_diag_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st[s], A, lda, n);
     HIPOPS_CHECK(hipGetLastError());
     return GPC_OK;
-  }
-  int sum_diag(const double* A, int64_t lda, int64_t n, double* out, int s) override
-  {
-    return gpc::diag_reduce(0, n, A, lda, out, st[s]);
-  }
-  int covgrad_block(double* S, int64_t lds, int64_t M, int64_t nbc, const double* Al, int64_t lda, int64_t nd, int64_t g0,
-                    int upper, int s) override
-  {
-    if(M <= 0 || nbc <= 0) return GPC_OK;
-    for(int64_t j0 = 0; j0 < nbc; j0 += 32768) {
-      const int64_t nc = nbc - j0 < 32768 ? nbc - j0 : 32768;
-      hipLaunchKernelGGL(covgrad_block_kernel, dim3((unsigned)((M + 255) / 256), (unsigned)nc), dim3(256), 0, st[s], S, lds, M, Al,
-                         lda, (int)nd, g0, upper, j0);
-    }
-    HIPOPS_CHECK(hipGetLastError());
-    return GPC_OK;
-  }
-  int trsm_right(const double* L, int64_t ldl, int64_t n, bool trans, bool identity_rows, double* B, int64_t ldb, int64_t M,
-                 int s) override
-  {
-    if(trans && identity_rows && M <= n) return gpc::trsm_right_lt_identity(M, n, L, ldl, B, ldb, st[s]);
-    return gpc::trsm('R', 'L', trans ? 'T' : 'N', 'N', M, n, 1.0, L, ldl, B, ldb, st[s]);
   }
   int kern_grad_block(const gpc_kspec* ks, const double* Xa, int64_t Na, int64_t lda, const double* Xb, int64_t Nb, int64_t ldb,
                       int64_t D, const double* C, int64_t ldc, double* g, int s) override

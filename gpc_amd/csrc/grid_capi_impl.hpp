@@ -195,6 +195,20 @@ int GRID_API(gradient)(gpc_grid* g, double* g_host)
   return grid_fail(g, g->gp->gradient(g_host));
 }
 
+int GRID_API(inverse)(gpc_grid* g)
+{
+  if(!g) return GPC_EINVAL;
+  GRID_CHECK(grid_enter(g->device));
+  return grid_fail(g, g->gp->inverse());
+}
+
+int GRID_API(copy_inverse_tile)(gpc_grid* g, int64_t I, int64_t J, double* host, int* owned)
+{
+  if(!g || !host) return GPC_EINVAL;
+  GRID_CHECK(grid_enter(g->device));
+  return grid_fail(g, g->gp->copy_tile(I, J, host, owned, true));
+}
+
 int GRID_API(posterior)(gpc_grid* g, double* mu_host, int64_t ldmu, double* var_host)
 {
   if(!g || !mu_host || !var_host) return GPC_EINVAL;
@@ -294,7 +308,7 @@ int GRID_API(exchange_probe)(gpc_grid* g, int axis, int64_t count, int reps, dou
 
 // out[0..7] = bytes received along process rows / columns / world, collectives entered, algorithmic flops of this
 // rank's trailing updates, their launches, their algorithmic HBM bytes -- since the last reset -- and the device bytes this
-// rank's problem holds right now (local block, panel buffers, the gradient's replicated factor once it has been called)
+// rank's problem holds right now (local block, panel buffers, the block of K^-1 once the gradient has been called)
 int GRID_API(stats)(gpc_grid* g, double* out, int reset)
 {
   if(!g || !out) return GPC_EINVAL;

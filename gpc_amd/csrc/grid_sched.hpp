@@ -130,6 +130,8 @@ struct UpdateArgs {
   int64_t nb, I0, J0, jl0; int pr, pc;
   int64_t il_begin = 0; int refl_r = -1;   // reflected rounds (Layout::refl): local tile row t of C is global tile row
                                            // pr (il_begin + t) + (odd round ? pr-1 - refl_r : refl_r); -1: I0 + t pr
+  double alpha = -1.0;          // C += alpha W V' (the factorisation's trailing update: -1)
+  int role = 1;                 // 1: a trailing update of the factorisation; 3: an update of the distributed inverse (GridGp::inverse)
   int64_t grow(int64_t t) const
   {
     if(refl_r < 0) return I0 + t * pr;
@@ -164,7 +166,8 @@ struct GridOps {
   virtual int gram_diag(const gpc_kspec* ks, const double* X, int64_t N, int64_t D, int64_t ldx, double shift,
                         double* dg, int st) = 0;
   virtual int sum_host(const double* v, int64_t n, double* out_host, int st) = 0;
-  // entries of the local block on the GLOBAL diagonal := dg[g] (g < N) or 1 (padding); padding rows / columns := 0
+  // entries of the local block on the GLOBAL diagonal := dg[g] (g < N) or 1 (padding; everywhere when dg is null);
+  // padding rows / columns := 0
   virtual int fix_diag_pad(double* A, const Layout& L, const double* dg, int st) = 0;
   // extra rows e = 0..d-1: A(e, n) = Y(gcol(n), e) for gcol < N else 0;  Aex points at the first extra row
   virtual int put_rhs_rows(double* Aex, int64_t lld, const double* Y, int64_t ldy, int64_t d, const Layout& L, int st) = 0;
@@ -180,6 +183,11 @@ struct GridOps {
   virtual int pack_tiles(double* dst, const double* src, int64_t lds, int64_t first, int64_t step, int64_t count,
                          int64_t nb, int st) = 0;
   virtual int update(const UpdateArgs& u, int st) = 0;
+  // for t < count: the nb x ncols block at dst + t*dst_step (leading dimension ldd) := the one at src + t*src_step (lds).
+  // With step = nb^2 and ld = nb on one side that side is a run of contiguous tiles; with step = s*nb and the matrix's
+  // leading dimension it is every s-th row tile of a matrix.
+  virtual int copy_tiles(double* dst, int64_t dst_step, int64_t ldd, const double* src, int64_t src_step, int64_t lds,
+                         int64_t count, int64_t nb, int64_t ncols, int st) = 0;
   // ---- reductions over the local block
   virtual int diag_logsum(const double* A, const Layout& L, double* out_host, int st) = 0;   // sum 2 log A(g,g)
   virtual int rows_sumsq(const double* Arow, int64_t lld, int64_t nrows, int64_t ncols, double* out_host, int st) = 0;
@@ -189,21 +197,13 @@ struct GridOps {
   virtual int trsm_llt(const double* Lkk, int64_t ldl, int64_t n, double* B, int64_t ldb, int64_t nrhs, int st) = 0;
   // ---- gradient (see GridGp::gradient)
   virtual int trsm_lln(const double* L, int64_t ldl, int64_t n, double* B, int64_t ldb, int64_t nrhs, int st) = 0;   // B := L^-1 B
-  // B (M x n) := B L^-T (trans) or B L^-1 (!trans) for the lower-triangular n x n L: the rows of B are independent
-  // identity_rows: B holds the first M rows of the identity (an implementation may skip the rows that are still zero)
-  virtual int trsm_right(const double* L, int64_t ldl, int64_t n, bool trans, bool identity_rows, double* B, int64_t ldb, int64_t M,
-                         int st) = 0;
-  // dst row tile (first + t*step), all ncols columns := src row tile t (src is count*nb x ncols, leading dimension lds)
-  virtual int scatter_row_tiles(double* dst, int64_t ldd, int64_t first, int64_t step, const double* src, int64_t lds,
-                                int64_t count, int64_t nb, int64_t ncols, int st) = 0;
   virtual int set_identity(double* A, int64_t lda, int64_t n, int st) = 0;      // the n x n block at A := I
-  virtual int sum_diag(const double* A, int64_t lda, int64_t n, double* out_host, int st) = 0;
-  // In place on the M x nbc block S = K^-1(g0 + i, g0 + j):  C(i,j) = w * -0.5 (nd S(i,j) - sum_o Al(g0+i,o) Al(g0+j,o)) with
-  // w = 2 on one side of the block's diagonal (below it, or above it when `upper`), 1 on it, 0 on the other side
-  // (CGp::updateCovGradient, CGp.cpp:666-679, summed over outputs; the weight 2 stands for the mirrored element the
-  // one-sided sweep never forms)
-  virtual int covgrad_block(double* S, int64_t lds, int64_t M, int64_t nbc, const double* Al, int64_t lda, int64_t nd,
-                            int64_t g0, int upper, int st) = 0;
+  // CGp::updateCovGradient (CGp.cpp:666-679, summed over the nd outputs) on a rank's whole local block S (lower tiles of
+  // K^-1, block-cyclic as L says; diagonal tiles valid in their lower triangle): element (gi, gj) of the GLOBAL matrix becomes
+  // w * -0.5 (nd S - sum_o Al(gi,o) Al(gj,o)) with w = 2 for gi > gj (the weight stands for the mirrored element the one-sided
+  // sweep never forms), 1 for gi == gj, 0 for gi < gj or an index >= N (padding).  *trace_host = sum of the resulting diagonal
+  // entries this rank holds.
+  virtual int covgrad_local(double* S, const Layout& L, const double* Al, int64_t lda, int64_t nd, double* trace_host, int st) = 0;
   // g[p] = sum over the block of C(i,n) dk(Xa_i, Xb_n)/dtheta_p, natural parameters in spec order, white = 0
   // (CKern::getGradParams(g, X, X2, covGrad)); g is a host array of ks->offs[n_terms] doubles
   virtual int kern_grad_block(const gpc_kspec* ks, const double* Xa, int64_t Na, int64_t lda, const double* Xb, int64_t Nb,
@@ -842,71 +842,18 @@ class GridGp {
 
   // CGp::updateG (CGp.cpp:1080-1117) for the distributed model: g[p] = sum_ij covGrad(i,j) dK(i,j)/dtheta_p for the natural
   // kernel parameters in spec order (the transform chain rule stays with the caller), identical on every rank.
-  // K^-1 = V V' with V = L^-T (dpotri's two halves, CMatrix.cpp:414-432), formed by rows:
-  //   1. the factor is replicated (one all-gather per tile column; it has to fit beside the local block: 8 N^2 bytes, 137 GB
-  //      at N = 131 072 -- gpc_grid_stats reports the bytes a rank holds);
-  //   2. every rank solves X L' = E for ITS groups of tile rows of V (E = rows of the identity; rows of a right-sided solve
-  //      are independent, the solve runs on the trailing block L(J:, J:) only, and it is the library's chip-wide
-  //      right-sided chain, the one dpotri uses): N^3 / 3 flops over all ranks;
-  //   3. the groups of V are exchanged (one all-gather per round of groups) into the upper part of the same buffer
-  //      (shifted right by one group height, so that a group's zero entries never land on the factor);
-  //   4. every rank forms its groups of rows of K^-1, K^-1(J, I) = sum_{m >= I} V(J, m) V(I, m)' for I >= J, as NT products
-  //      on the matrix cores that start at column I (the zeros of the triangular operand are skipped): N^3 / 3 flops again;
-  //   5. covGrad = -0.5 (d K^-1 - alpha alpha') on the block (each unordered pair once, weight 2 off the diagonal), the
-  //      cross-block kernel-gradient pass, one all-reduce of the parameter sums.
-  // (2/3) N^3 / P flops per rank like a distributed dpotri; round 2 solved block columns with left-sided solves (22 TFLOP/s
-  // at N = 32 768 on one rank).  A group is a run of consecutive tile rows (<= 4096 rows; rows of one group start at almost the
-  // same column, so little of the trailing block is solved for nothing); groups are dealt to the ranks by cost, largest first.
+  // covGrad = -0.5 (d K^-1 - alpha alpha') (CGp::updateCovGradient, CGp.cpp:666-679) needs every entry of K^-1
+  // (CMatrix::pdinv -> dpotri_, CMatrix.cpp:414-432, lapack.h:67-73).  K^-1 is formed DISTRIBUTED, block-cyclic like the
+  // factor, by inverse() below; each rank turns its own tiles into covGrad (each unordered pair once, weight 2 off the
+  // diagonal), runs the cross-block kernel-gradient pass on them against the inputs of its tile rows / columns, and one
+  // all-reduce adds the parameter sums.  Nothing of size N x N is replicated: a rank holds its block of the factor, its
+  // block of K^-1 and O(N nb) of panels.
   int gradient(double* g_host)
   {
     const Layout& L = L_;
     if(!factored_ || d_ <= 0) return fail(GPC_EINVAL, "grid gradient: no factor / no targets");
     if(!alpha_valid_) GRID_CHECK(alpha(nullptr, 0));
     const int np = ks_.offs[ks_.n_terms];
-    const int P = pr_ * pc_, me = r_ * pc_ + c_;
-    // rows of a group: 8192 on one or two ranks (the solve's products run closer to the kernel's rate the more rows they
-    // have), 4096 beyond (a round of P groups is in flight at once: P W N doubles)
-    const int64_t Gmax = imax(1, (P <= 2 ? 8192 : 4096) / nb_), W = Gmax * nb_, ldf = L.Np;
-    // groups of consecutive tile rows, dealt by cost (a row J costs (T - J)^2: a solve and a product on the trailing block)
-    struct Group { int64_t J0, rows; double cost; int owner, round; };
-    std::vector<Group> groups;
-    int rounds = 0;
-    {
-      double total = 0.0;
-      for(int64_t J = 0; J < L.T; J++) total += (double)(L.T - J) * (double)(L.T - J);
-      const double limit = P > 1 ? total / (3.0 * P) : 1e300;
-      for(int64_t J = 0; J < L.T;) {
-        Group g = {J, 0, 0.0, 0, 0};
-        while(J < L.T && g.rows < Gmax) {
-          const double c = (double)(L.T - J) * (double)(L.T - J);
-          if(g.rows > 0 && g.cost + c > limit) break;
-          g.cost += c;
-          g.rows++;
-          J++;
-        }
-        groups.push_back(g);
-      }
-      std::vector<size_t> order(groups.size());
-      for(size_t i = 0; i < order.size(); i++) order[i] = i;
-      for(size_t i = 1; i < order.size(); i++)       // by cost, largest first; ties keep the row order (insertion sort: stable)
-        for(size_t j = i; j > 0 && groups[order[j]].cost > groups[order[j - 1]].cost; j--) std::swap(order[j], order[j - 1]);
-      std::vector<double> load((size_t)P, 0.0);
-      for(size_t i : order) {
-        int best = 0;
-        for(int m = 1; m < P; m++)
-          if(load[(size_t)m] < load[(size_t)best]) best = m;
-        groups[i].owner = best;
-        load[(size_t)best] += groups[i].cost;
-      }
-      std::vector<int> seen((size_t)P, 0);
-      for(Group& g : groups) {                       // a rank's groups in row order: its r-th one travels in round r
-        g.round = seen[(size_t)g.owner]++;
-        rounds = g.round + 1 > rounds ? g.round + 1 : rounds;
-      }
-    }
-    int mine_n = 0;
-    for(const Group& g : groups) mine_n += g.owner == me;
-    // GPC_GRID_TRACE_GRADIENT=1: the phases' wall-clock times on stderr (each closed by a stream synchronisation: a measuring aid)
     static const bool phase_trace = getenv("GPC_GRID_TRACE_GRADIENT") != nullptr;
     struct timespec ts0;
     clock_gettime(CLOCK_MONOTONIC, &ts0);
@@ -918,123 +865,17 @@ class GridGp {
       fprintf(stderr, "[%d,%d] gradient: %-28s %9.2f ms\n", r_, c_, what, (t1.tv_sec - ts0.tv_sec) * 1e3 + (t1.tv_nsec - ts0.tv_nsec) * 1e-6);
       ts0 = t1;
     };
-    // the gradient buffers live as long as the problem does (an optimiser calls this once per iteration; allocating
-    // 8 N^2 bytes each time would cost more than the solves)
-    int rc = GPC_OK;
-    if(!Lf_) rc = held_alloc(Lf_, ldf * (L.Np + W));                                  // L below the diagonal, V shifted right by W
-    if(rc == GPC_OK && !strip_) rc = held_alloc(strip_, L.T * nb_ * nb_ + 16);        // one tile column of the factor
-    if(rc == GPC_OK && !Zg_) rc = held_alloc(Zg_, (int64_t)P * W * L.Np);             // a round of groups in flight; later a block of K^-1
-    if(rc == GPC_OK && !Vm_) rc = held_alloc(Vm_, (int64_t)imax(mine_n, 1) * W * L.Np);   // this rank's own groups of V
-    if(rc != GPC_OK)
-      return fail(rc, "grid gradient: the replicated factor (8 N^2 bytes) and the exchange blocks do not fit beside this rank's block");
-    double *Lf = Lf_, *strip = strip_, *Z = Zg_;
-    // 1. replicate the lower tiles of the factor, one tile column per exchange: process row s of the owning process column
-    // contributes the tiles it holds (I >= J on its rows), everybody receives all of them
-    std::vector<int64_t> start((size_t)P, 0), count((size_t)P, 0);
-    for(int64_t J = 0; J < L.T && rc == GPC_OK; J++) {
-      const int jc = (int)(J % pc_);
-      int64_t off = 0;
-      double recv = 0.0;
-      for(int m = 0; m < P; m++) start[(size_t)m] = count[(size_t)m] = 0;
-      for(int s = 0; s < pr_; s++) {
-        const int64_t ilf = L.first_after_row(J - 1, s);                 // first local tile row of process row s with I >= J
-        const int64_t cnt = L.rows_of(s) - ilf;
-        if(cnt <= 0) continue;
-        const int m = s * pc_ + jc;
-        start[(size_t)m] = off;
-        count[(size_t)m] = cnt * nb_ * nb_;
-        if(m == me)
-          rc = ops_->copy2d(strip + off, cnt * nb_, A_ + ilf * nb_ + (J / pc_) * nb_ * L.lld, L.lld, cnt * nb_, nb_, ST_MAIN);
-        else
-          recv += 8.0 * (double)(cnt * nb_ * nb_);
-        off += cnt * nb_ * nb_;
-      }
-      if(rc == GPC_OK) rc = comm_->allgatherv(strip, start.data(), count.data(), AX_WORLD, ops_.get(), ST_MAIN);
-      stats_.collectives++;
-      stats_.bytes_recv[AX_WORLD] += recv;
-      for(int s = 0; s < pr_ && rc == GPC_OK; s++) {
-        const int m = s * pc_ + jc;
-        const int64_t cnt = count[(size_t)m] / (nb_ * nb_);
-        if(cnt <= 0) continue;
-        const int64_t ilf = L.first_after_row(J - 1, s);
-        const double* src = strip + start[(size_t)m];
-        if(!L.refl) {
-          rc = ops_->scatter_row_tiles(Lf + J * nb_ * ldf, ldf, s + pr_ * ilf, pr_, src, cnt * nb_, cnt, nb_, nb_, ST_MAIN);
-        } else {
-          for(int64_t t = 0; t < cnt && rc == GPC_OK; t++)   // reflected rounds: no single stride between a rank's tile rows
-            rc = ops_->scatter_row_tiles(Lf + J * nb_ * ldf, ldf, L.grow_s(s, ilf + t), 1, src + t * nb_, cnt * nb_, 1, nb_, nb_,
-                                         ST_MAIN);
-        }
-      }
-    }
-    GRID_CHECK(rc);
-    phase("alpha + replicated factor");
-    // 2 + 3. my groups of V = L^-T, round by round; every round's groups go to everybody
-    for(int r = 0; r < rounds && rc == GPC_OK; r++) {
-      int64_t off = 0;
-      double recv = 0.0;
-      for(int m = 0; m < P; m++) start[(size_t)m] = count[(size_t)m] = 0;
-      const Group* in_round[4096];
-      for(int m = 0; m < P; m++) in_round[m] = nullptr;
-      for(const Group& g : groups)
-        if(g.round == r) in_round[g.owner] = &g;
-      for(int m = 0; m < P; m++) {
-        if(!in_round[m]) continue;
-        const int64_t M = in_round[m]->rows * nb_, n = L.Np - in_round[m]->J0 * nb_;
-        start[(size_t)m] = off;
-        count[(size_t)m] = M * n;
-        off += M * n;
-        if(m != me) recv += 8.0 * (double)(M * n);
-      }
-      if(in_round[me]) {
-        const int64_t gmin = in_round[me]->J0 * nb_, M = in_round[me]->rows * nb_, n = L.Np - gmin;
-        double* Vb = Vm_ + (int64_t)r * W * L.Np;                               // kept for step 4
-        rc = ops_->zero(Vb, sizeof(double) * (size_t)(M * n), ST_MAIN);
-        if(rc == GPC_OK) rc = ops_->set_identity(Vb, M, M, ST_MAIN);           // row i of the group is row gmin + i of the identity
-        if(rc == GPC_OK) rc = ops_->trsm_right(Lf + gmin + gmin * ldf, ldf, n, true, true, Vb, M, M, ST_MAIN);      // X L' = E
-        if(rc == GPC_OK) rc = ops_->copy(Z + start[(size_t)me], Vb, sizeof(double) * (size_t)(M * n), ST_MAIN);
-        phase("  solve X L' = E (a group)");
-      }
-      if(rc == GPC_OK) rc = comm_->allgatherv(Z, start.data(), count.data(), AX_WORLD, ops_.get(), ST_MAIN);
-      stats_.collectives++;
-      stats_.bytes_recv[AX_WORLD] += recv;
-      for(int m = 0; m < P && rc == GPC_OK; m++) {
-        if(!in_round[m]) continue;
-        const int64_t gmin = in_round[m]->J0 * nb_, M = in_round[m]->rows * nb_, n = L.Np - gmin;
-        // V(gmin + i, gmin + j) -> column gmin + j + W of row gmin + i: right of every entry of L in these rows (M <= W)
-        rc = ops_->copy2d(Lf + gmin + (gmin + W) * ldf, ldf, Z + start[(size_t)m], M, M, n, ST_MAIN);
-      }
-    }
-    GRID_CHECK(rc);
-    phase("exchange of V");
-    // 4 + 5. my groups of rows of K^-1 and their share of the gradient
-    std::vector<double> acc((size_t)imax(np, 1), 0.0), part((size_t)imax(np, 1), 0.0);
+    phase("alpha");
+    GRID_CHECK(inverse());
+    phase("distributed inverse");
+    std::vector<double> acc((size_t)imax(np, 1), 0.0);
     double trace = 0.0;
-    for(size_t gi = 0; gi < groups.size() && rc == GPC_OK; gi++) {
-      if(groups[gi].owner != me) continue;
-      const int64_t gmin = groups[gi].J0 * nb_, M = groups[gi].rows * nb_;
-      const int64_t Mv = L.N - gmin < M ? L.N - gmin : M, nv = L.N - gmin;        // rows / columns that are data, not padding
-      if(Mv <= 0) continue;
-      const double* Vb = Vm_ + (int64_t)groups[gi].round * W * L.Np;
-      for(int64_t c = groups[gi].J0; c < L.T && rc == GPC_OK; c++) {
-        // tile column c: K^-1(J rows, c) = V(J, m >= c nb) V(c, m >= c nb)' -- the product starts at the column where the
-        // triangular operand does (with whole groups as column blocks the coarse start costs 1.9x the flops on one rank).
-        // One tile column at a time: a wider block may not reach into the next group, whose rows were stored from THEIR
-        // first column on only (measured: two columns at a time are no faster)
-        const int64_t g2 = c * nb_, K = L.Np - g2;
-        rc = ops_->gemm('N', 'T', M, nb_, K, 1.0, Vb + (g2 - gmin) * M, M, Lf + g2 + (g2 + W) * ldf, ldf, 0.0, Z + (g2 - gmin) * M, M,
-                        ST_MAIN);
-      }
-      phase("  V V' (a group)");
-      if(rc == GPC_OK) rc = ops_->covgrad_block(Z, M, Mv, nv, al_, L.Np, d_, gmin, 1, ST_MAIN);
-      double tr = 0.0;
-      if(rc == GPC_OK) rc = ops_->sum_diag(Z, M, Mv, &tr, ST_MAIN);
-      if(rc == GPC_OK) rc = ops_->kern_grad_block(&ks_, X_ + gmin, Mv, L.N, X_ + gmin, nv, L.N, D_, Z, M, part.data(), ST_MAIN);
-      trace += tr;
-      for(int p = 0; p < np; p++) acc[(size_t)p] += part[(size_t)p];
-      phase("  covGrad + kernel pass");
+    if(L.Lr > 0 && L.Lc > 0) {
+      GRID_CHECK(ops_->covgrad_local(Bi_, L, al_, L.Np, d_, &trace, ST_MAIN));
+      GRID_CHECK(ops_->kern_grad_block(&ks_, Xr_, L.Lr * nb_, L.Lr * nb_, Xc_, L.Lc * nb_, L.Lc * nb_, D_, Bi_, L.lld, acc.data(),
+                                       ST_MAIN));
     }
-    GRID_CHECK(rc);
+    phase("covGrad + kernel pass");
     // the white terms see only the diagonal of covGrad (CWhiteKern::getGradParams, CKern.cpp:735-739)
     for(int t = 0; t < ks_.n_terms; t++)
       if(ks_.types[t] == GPC_KERN_WHITE) acc[(size_t)ks_.offs[t]] += trace;
@@ -1044,11 +885,79 @@ class GridGp {
     return GPC_OK;
   }
 
+  // K^-1 on the grid: dpotri (lapack.h:67-73; CMatrix::pdinv, CMatrix.cpp:414-432) block-cyclic, in ONE sweep over the tile
+  // rows.  With W = L^-1 (lower triangular) K^-1 = W' W.  The block Bi_ has the layout of the factor's block and starts as the
+  // identity; at step k
+  //   (1) tile row k of Bi_ holds B(k, j) = delta_kj I - sum_{m<k} L(k,m) W(m,j), j <= k: the ranks of process row owner(k) form
+  //       W(k, j) = L(k,k)^-1 B(k, j) through the inverse of the diagonal tile -- transposed, as the rows of an n_k x nb matrix
+  //       WT (tile j of it = W(k,j)') -- and clear the tile row;
+  //   (2) WT goes down every process column (each rank needs the tiles of ITS columns j): the column operand of both updates;
+  //   (3) the tiles W(k,i)' of a rank's ROWS i <= k sit on the ranks of its process row (column i mod pc after (2)): one
+  //       all-gather along the row hands them over -- the mirror image of the factorisation's column-panel exchange;
+  //   (4) dtrtri's share, rows I > k:   B(I, j) -= L(I,k) W(k,j)      (L(I,k): this rank's rows of panel k of the factor,
+  //       along process rows exactly as in the factorisation);
+  //   (5) dlauum's share, rows i <= k:  S(i, j) += W(k,i)' W(k,j), j <= i  -- tile row k itself starts from zero in (1).
+  // (4) touches rows below k only and (5) rows up to k only, so the accumulating inverse S and the not yet solved rows B share
+  // one block, the factor stays intact in A_ (the posterior needs it), and both updates are the factorisation's own MFMA
+  // staircase launch (NT form, tile-addressed column operand).  2 N^3 / (3 P) flops per rank; a rank receives the volume of
+  // two factorisations; memory: the block + O(N nb).  Look-ahead as in factor(): step k+1's (1)-(3) on the panel stream
+  // after the one tile row of (4) it depends on.
+  int inverse()
+  {
+    const Layout& L = L_;
+    if(!factored_) return fail(GPC_EINVAL, "grid inverse: no factor");
+    GRID_CHECK(alloc_inverse());
+    const int64_t lld = L.lld;
+    GRID_CHECK(ops_->zero(Bi_, sizeof(double) * (size_t)(lld * imax(L.nloc, 1)), ST_MAIN));
+    GRID_CHECK(ops_->fix_diag_pad(Bi_, L, nullptr, ST_MAIN));
+    const int SP = lookahead ? ST_PANEL : ST_MAIN;
+    GRID_CHECK(ops_->record(ev_ready_, ST_MAIN));
+    if(SP != ST_MAIN) GRID_CHECK(ops_->wait(SP, ev_ready_));
+    GRID_CHECK(inverse_panel(0, SP, nullptr));
+    for(int64_t k = 0; k < L.T; k++) {
+      const int b = (int)(k & 1);
+      if(SP != ST_MAIN) GRID_CHECK(ops_->wait(ST_MAIN, ev_panel_[b]));
+      const int64_t il0 = L.il0(k);
+      int64_t first = il0;
+      if(k + 1 < L.T) {
+        if(L.owner_row(k + 1) == r_ && il0 < L.Lr) {       // the one tile row the next step starts from
+          GRID_CHECK(inverse_update(k, il0, il0 + 1, -1.0, ST_MAIN));
+          first = il0 + 1;
+        }
+        if(SP != ST_MAIN) {
+          GRID_CHECK(ops_->record(ev_u1_, ST_MAIN));
+          if(free_valid_[b ^ 1]) GRID_CHECK(ops_->wait(SP, ev_free_[b ^ 1]));   // the updates of step k-1 have released the other buffers
+        }
+        GRID_CHECK(inverse_panel(k + 1, SP, SP != ST_MAIN ? ev_u1_ : nullptr));
+      }
+      if(pcomp_valid_[b ^ 1]) {      // the next step's kernels before the bulk of this step's updates (see panel_first)
+        GRID_CHECK(ops_->wait(ST_MAIN, ev_pcomp_[b ^ 1]));
+        pcomp_valid_[b ^ 1] = false;
+      }
+      GRID_CHECK(inverse_update(k, first, L.Lr, -1.0, ST_MAIN));     // (4)
+      GRID_CHECK(inverse_update(k, 0, il0, 1.0, ST_MAIN));           // (5)
+      if(SP != ST_MAIN) {
+        GRID_CHECK(ops_->record(ev_free_[b], ST_MAIN));
+        free_valid_[b] = true;
+      }
+    }
+    if(SP != ST_MAIN) {
+      GRID_CHECK(ops_->record(ev_u1_, SP));
+      GRID_CHECK(ops_->wait(ST_MAIN, ev_u1_));
+    }
+    free_valid_[0] = free_valid_[1] = false;
+    pcomp_valid_[0] = pcomp_valid_[1] = false;
+    return ops_->check_faults(ST_MAIN);
+  }
+  const double* inverse_block() const { return Bi_; }
+
   // tests / debugging: tile (I, J) of the local block to the host (nb x nb, ld nb); *owned = 0 if it lives elsewhere
-  int copy_tile(int64_t I, int64_t J, double* host, int* owned)
+  int copy_tile(int64_t I, int64_t J, double* host, int* owned, bool of_inverse = false)
   {
     const Layout& L = L_;
     const bool extra = (I == L.T);
+    const double* blk = of_inverse ? Bi_ : A_;
+    if(!blk || (of_inverse && extra)) return fail(GPC_EINVAL, "grid copy_tile: no such block");
     const bool mine = (extra ? L.has_extra : L.owner_row(I) == r_) && (int)(J % pc_) == c_ && J < L.T && I <= L.T;
     if(owned) *owned = mine ? 1 : 0;
     if(!mine) return GPC_OK;
@@ -1057,7 +966,7 @@ class GridGp {
     std::vector<double> col((size_t)rows);
     GRID_CHECK(ops_->sync(ST_MAIN));
     for(int64_t j = 0; j < nb_; j++) {
-      GRID_CHECK(ops_->download(col.data(), A_ + il * nb_ + (jl * nb_ + j) * L.lld, sizeof(double) * (size_t)rows, ST_MAIN));
+      GRID_CHECK(ops_->download(col.data(), blk + il * nb_ + (jl * nb_ + j) * L.lld, sizeof(double) * (size_t)rows, ST_MAIN));
       memcpy(host + j * nb_, col.data(), sizeof(double) * (size_t)rows);
     }
     return GPC_OK;
@@ -1154,7 +1063,7 @@ class GridGp {
   {
     if(!ops_) return;
     double** ps[] = {&A_, &X_, &Xr_, &Xc_, &dg_, &Y_, &al_, &alr_, &t_, &Xs_, &W_[0], &W_[1], &V_[0], &V_[1], &Dg_[0], &Dg_[1],
-                     &Lf_, &strip_, &Zg_, &St_, &Vm_};
+                     &St_, &Bi_, &WT_[0], &WT_[1], &Wq_[0], &Wq_[1], &Qt_[0], &Qt_[1], &Dinv_};
     for(double** p : ps)
       if(*p) {
         ops_->release(*p);
@@ -1162,8 +1071,10 @@ class GridGp {
       }
     if(info_dev_) ops_->release(info_dev_);
     if(voff_dev_) ops_->release(voff_dev_);
+    if(vofm_dev_) ops_->release(vofm_dev_);
     info_dev_ = nullptr;
     voff_dev_ = nullptr;
+    vofm_dev_ = nullptr;
     void** evs[] = {&ev_panel_[0], &ev_panel_[1], &ev_free_[0], &ev_free_[1], &ev_ready_, &ev_u1_, &ev_u1a_, &ev_pcomp_[0], &ev_pcomp_[1]};
     for(void** e : evs)
       if(*e) {
@@ -1313,6 +1224,162 @@ class GridGp {
     return GPC_OK;
   }
 
+  // ---- the distributed inverse (see inverse()) ----------------------------------------------------------------------------
+  int alloc_inverse()
+  {
+    const Layout& L = L_;
+    if(Bi_) return GPC_OK;
+    int rc = held_alloc(Bi_, L.lld * imax(L.nloc, 1));
+    const int64_t rows = imax(L.Lr, 1) * nb_, cols = imax(L.nloc, nb_);
+    for(int b = 0; b < 2 && rc == GPC_OK; b++) {
+      rc = held_alloc(WT_[b], cols * nb_);
+      if(rc == GPC_OK && pr_ * pc_ > 1) rc = held_alloc(Wq_[b], rows * nb_);
+      if(rc == GPC_OK && pc_ > 1) rc = held_alloc(Qt_[b], rows * nb_);
+    }
+    if(rc == GPC_OK) rc = held_alloc(Dinv_, nb_ * nb_);
+    if(rc == GPC_OK) {
+      std::vector<int64_t> v((size_t)imax(L.Lc, 1));
+      for(size_t j = 0; j < v.size(); j++) v[j] = (int64_t)j * nb_;     // tile j of WT = its rows j nb ..
+      vofm_host_ = v;
+      rc = ops_->alloc((void**)&vofm_dev_, sizeof(int64_t) * v.size());
+      if(rc == GPC_OK) rc = ops_->upload(vofm_dev_, v.data(), sizeof(int64_t) * v.size());
+    }
+    if(rc != GPC_OK) return fail(rc, "grid gradient: this rank's block of K^-1 (as large as its block of the factor) does not fit");
+    return GPC_OK;
+  }
+
+  // Steps (1)-(3) of inverse() for tile row k on stream st; leaves WT / Wq (and the row panel of the factor) of parity k&1
+  // complete and records ev_panel_[k&1].  before: event of the update stream after which tile row k carries step k-1's update.
+  int inverse_panel(int64_t k, int st, void* before)
+  {
+    const Layout& L = L_;
+    const int b = (int)(k & 1);
+    const int kr = L.owner_row(k), kc = (int)(k % pc_);
+    const int64_t ilk = k / pr_, jlk = k / pc_, il0 = L.il0(k);
+    const int64_t nk = L.jl0(k), ncols = nk * nb_;              // this rank's tile columns j <= k
+    const int64_t nr = il0;                                       // this rank's tile rows i <= k
+    // the rows of panel k of the factor this process row needs: I > k, and the diagonal tile on the row that solves
+    const int64_t ilp = (r_ == kr) ? ilk : il0;
+    const int64_t Mp = (L.Lr - ilp) * nb_;
+    if(pc_ > 1 && Mp > 0) {
+      if(c_ == kc) GRID_CHECK(ops_->copy2d(W_[b], Mp, A_ + ilp * nb_ + jlk * nb_ * L.lld, L.lld, Mp, nb_, st));
+      GRID_CHECK(comm_->bcast(W_[b], Mp * nb_, kc, AX_ROW, ops_.get(), st));
+      count_coll(AX_ROW, 8.0 * (double)(Mp * nb_), c_ != kc);
+    }
+    if(r_ == kr && nk > 0) {
+      const double* Lkk = pc_ > 1 ? W_[b] : A_ + ilk * nb_ + jlk * nb_ * L.lld;
+      const int64_t ldl = pc_ > 1 ? Mp : L.lld;
+      if(before) GRID_CHECK(ops_->wait(st, before));
+      GRID_CHECK(ops_->set_identity(Dinv_, nb_, nb_, st));
+      GRID_CHECK(ops_->trsm_lln(Lkk, ldl, nb_, Dinv_, nb_, nb_, st));
+      double* row = Bi_ + ilk * nb_;
+      // WT(j, a) = sum_b row(b, j) Dinv(a, b) = (L(k,k)^-1 B(k, :))(a, j)
+      GRID_CHECK(ops_->gemm('T', 'T', ncols, nb_, nb_, 1.0, row, L.lld, Dinv_, nb_, 0.0, WT_[b], ncols, st));
+      GRID_CHECK(ops_->zero2d(row, L.lld, nb_, ncols, st));
+      inv_flops_ += 2.0 * (double)ncols * (double)nb_ * (double)nb_;
+    }
+    GRID_CHECK(panel_compute_done(b, st));
+    if(nk > 0 && pr_ > 1) {
+      GRID_CHECK(comm_->bcast(WT_[b], ncols * nb_, kr, AX_COL, ops_.get(), st));
+      count_coll(AX_COL, 8.0 * (double)(ncols * nb_), r_ != kr);
+    }
+    // the row operand of (5): tile il of Wq = W(k, grow(il))', il < nr
+    if(nr > 0 && pr_ * pc_ > 1) {
+      const int64_t ldq = imax(L.Lr, 1) * nb_;
+      if(pc_ == 1) {
+        // every tile is here already (tile I of WT): pick this rank's rows
+        if(!L.refl) {
+          GRID_CHECK(ops_->copy_tiles(Wq_[b], nb_, ldq, WT_[b] + r_ * nb_, pr_ * nb_, ncols, nr, nb_, nb_, st));
+        } else {
+          for(int par = 0; par < 2; par++) {      // reflected rounds: even and odd rounds each have a stride of their own
+            const int64_t cnt = (nr - par + 1) / 2;
+            if(cnt <= 0) continue;
+            GRID_CHECK(ops_->copy_tiles(Wq_[b] + par * nb_, 2 * nb_, ldq, WT_[b] + L.grow(par) * nb_, 2 * pr_ * nb_, ncols, cnt, nb_, nb_, st));
+          }
+        }
+      } else {
+        // member c' of this process row holds the tiles J = c' (mod pc); those of MY rows are J = r (mod pr) as well: every
+        // lcm(pr, pc)-th tile from the first common one on.  Contiguous pieces, one in-place all-gather, unpack by strides.
+        const int64_t g = Layout::gcd(pr_, pc_), lcm = (int64_t)pr_ * pc_ / g;
+        std::vector<int64_t> start((size_t)pc_, 0), count((size_t)pc_, 0), J0((size_t)pc_, -1);
+        int64_t off = 0;
+        double recv = 0.0;
+        for(int cc = 0; cc < pc_; cc++) {
+          for(int64_t J = cc; J < lcm && J <= k; J += pc_)
+            if((int)(J % pr_) == r_) { J0[(size_t)cc] = J; break; }
+          if(J0[(size_t)cc] < 0) continue;
+          const int64_t cnt = (k - J0[(size_t)cc]) / lcm + 1;
+          start[(size_t)cc] = off;
+          count[(size_t)cc] = cnt * nb_ * nb_;
+          off += cnt * nb_ * nb_;
+          if(cc != c_) recv += 8.0 * (double)(cnt * nb_ * nb_);
+        }
+        if(count[(size_t)c_] > 0)
+          GRID_CHECK(ops_->copy_tiles(Qt_[b] + start[(size_t)c_], nb_ * nb_, nb_, WT_[b] + ((J0[(size_t)c_] - c_) / pc_) * nb_,
+                                      (lcm / pc_) * nb_, ncols, count[(size_t)c_] / (nb_ * nb_), nb_, nb_, st));
+        GRID_CHECK(comm_->allgatherv(Qt_[b], start.data(), count.data(), AX_ROW, ops_.get(), st));
+        stats_.collectives++;
+        stats_.bytes_recv[AX_ROW] += recv;
+        for(int cc = 0; cc < pc_; cc++)
+          if(count[(size_t)cc] > 0)
+            GRID_CHECK(ops_->copy_tiles(Wq_[b] + ((J0[(size_t)cc] - r_) / pr_) * nb_, (lcm / pr_) * nb_, ldq, Qt_[b] + start[(size_t)cc],
+                                        nb_ * nb_, nb_, count[(size_t)cc] / (nb_ * nb_), nb_, nb_, st));
+      }
+    }
+    if(st != ST_MAIN) GRID_CHECK(ops_->record(ev_panel_[b], st));
+    return GPC_OK;
+  }
+
+  // (4) / (5) of inverse() on the local tile rows il_begin .. il_end - 1 and the tile columns j <= k: Bi += alpha Wop WT'
+  int inverse_update(int64_t k, int64_t il_begin, int64_t il_end, double alpha, int st)
+  {
+    const Layout& L = L_;
+    const int b = (int)(k & 1);
+    const int64_t nk = L.jl0(k);
+    if(il_end > L.Lr) il_end = L.Lr;
+    if(il_end <= il_begin || nk <= 0) return GPC_OK;
+    UpdateArgs u;
+    u.M = (il_end - il_begin) * nb_;
+    u.Ncols = nk * nb_;
+    u.K = nb_;
+    if(alpha < 0.0) {          // rows below k: the factor's panel
+      const int kr = L.owner_row(k);
+      const int64_t ilp = (r_ == kr) ? k / pr_ : L.il0(k);
+      if(pc_ > 1) {
+        u.W = W_[b] + (il_begin - ilp) * nb_;
+        u.ldw = (L.Lr - ilp) * nb_;
+      } else {
+        u.W = A_ + il_begin * nb_ + (k / pc_) * nb_ * L.lld;
+        u.ldw = L.lld;
+      }
+    } else if(pr_ * pc_ > 1) {
+      u.W = Wq_[b] + il_begin * nb_;
+      u.ldw = imax(L.Lr, 1) * nb_;
+    } else {
+      u.W = WT_[b] + il_begin * nb_;
+      u.ldw = u.Ncols;
+    }
+    u.Vbase = WT_[b];
+    u.ldv = u.Ncols;
+    u.voff_dev = vofm_dev_;
+    u.voff_host = vofm_host_.data();
+    u.C = Bi_ + il_begin * nb_;
+    u.ldc = L.lld;
+    u.nb = nb_;
+    u.I0 = L.grow(il_begin);
+    u.il_begin = il_begin;
+    u.refl_r = L.refl ? r_ : -1;
+    u.J0 = c_;
+    u.jl0 = 0;
+    u.pr = pr_;
+    u.pc = pc_;
+    u.alpha = alpha;
+    u.role = 3;
+    inv_flops_ += 2.0 * (double)nb_ * (double)u.M * (double)u.Ncols;    // (an upper bound for (5): its staircase skips I < J)
+    inv_launches_++;
+    return ops_->update(u, st);
+  }
+
   // A(I,J) -= W(I) V(J)' for local column tiles jl_first .. jl_first + ncolt - 1 and the rows below tile k -- all of them
   // (il_begin = il0(k), il_end < 0) or the local row tiles il_begin .. il_end - 1 only
   int update(int64_t k, int64_t il_begin, int64_t jl_first, int64_t ncolt, int st, int64_t il_end = -1)
@@ -1387,7 +1454,13 @@ class GridGp {
          *alr_ = nullptr, *t_ = nullptr, *Xs_ = nullptr;
   double *W_[2] = {nullptr, nullptr}, *V_[2] = {nullptr, nullptr}, *Dg_[2] = {nullptr, nullptr};
   double* St_ = nullptr;                                      // [tile; rows] of a fused panel step (see fused_rows)
-  double *Lf_ = nullptr, *strip_ = nullptr, *Zg_ = nullptr, *Vm_ = nullptr;   // gradient(): replicated factor, one strip in flight, the solves' block
+  // inverse(): this rank's block of K^-1 (shape of A_), the transposed tile row (column operand), the row operand of the
+  // dlauum share, the tile-major staging of its all-gather, the inverse of a diagonal tile
+  double *Bi_ = nullptr, *WT_[2] = {nullptr, nullptr}, *Wq_[2] = {nullptr, nullptr}, *Qt_[2] = {nullptr, nullptr}, *Dinv_ = nullptr;
+  int64_t* vofm_dev_ = nullptr;
+  std::vector<int64_t> vofm_host_;
+  double inv_flops_ = 0.0;
+  int64_t inv_launches_ = 0;
   int* info_dev_ = nullptr;
   int64_t* voff_dev_ = nullptr;
   std::vector<int64_t> voff_host_, slot_, region_start_;

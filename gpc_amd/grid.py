@@ -210,15 +210,21 @@ class Grid(object):
         self.b.check(self.b.gradient(self.h, g.ctypes.data), self.h)
         return g
 
-    def copy_tile(self, I, J):
-        """tile (I, J) of the local block as an nb x nb array, or None when it lives on another rank"""
+    def inverse(self):
+        """CMatrix::pdinv on the distributed factor: K^-1 block-cyclic, lower tiles, in a block beside the factor's"""
+        self.b.check(self.b.inverse(self.h), self.h)
+
+    def copy_tile(self, I, J, of_inverse=False):
+        """tile (I, J) of the local block (of the factor, or of K^-1 after inverse() / gradient()) as an nb x nb array, or
+        None when it lives on another rank"""
         nb = self.info()["nb"]
         buf = np.zeros((nb, nb), order="F")
         owned = c_int(0)
-        self.b.check(self.b.copy_tile(self.h, I, J, buf.ctypes.data, byref(owned)), self.h)
+        fn = self.b.copy_inverse_tile if of_inverse else self.b.copy_tile
+        self.b.check(fn(self.h, I, J, buf.ctypes.data, byref(owned)), self.h)
         return buf if owned.value else None
 
-    def local_tiles(self, lower_only=True, extras=False):
+    def local_tiles(self, lower_only=True, extras=False, of_inverse=False):
         """{(I, J): tile} for every tile this rank owns (tests)."""
         inf = self.info()
         T, pr, pc, r, c = inf["T"], inf["pr"], inf["pc"], inf["r"], inf["c"]
@@ -230,7 +236,7 @@ class Grid(object):
             for J in range(c, T, pc):
                 if lower_only and J > I:
                     continue
-                out[(I, J)] = self.copy_tile(I, J)
+                out[(I, J)] = self.copy_tile(I, J, of_inverse)
         return out
 
 

@@ -194,12 +194,9 @@ bool CGp::useGrid() const
     // scheduler's trace, cfg 3 on 8 GPUs at 50 GB/s per link: 8x1 235 ms, 4x2 288 ms, 2x4 389 ms)
     pr = ndev >= 8 ? 8 : (ndev >= 4 ? 4 : 2);
     pc = 1;
-    if(getVerbosity() > 0) {
-      const double replica = 8.0 * (double)getNumData() * (double)getNumData() + need / (double)(pr * pc);
-      if(replica > 0.9 * (double)hbm)
-        std::cout << "CGp: K does not fit one GPU: likelihood and predictions run on the grid; the gradient would need the "
-                     "whole factor beside each rank's block (" << replica * 1e-9 << " GB) and will report GPC_ENOMEM." << std::endl;
-    }
+    if(getVerbosity() > 0)   // a rank holds its block of the factor and, for the gradient, its block of K^-1 (gpc_grid_inverse)
+      std::cout << "CGp: K does not fit one GPU: running on a " << pr << " x " << pc << " grid, "
+                << 2.0 * need / (double)(pr * pc) * 1e-9 << " GB per GPU (factor + inverse)." << std::endl;
   }
   const char* same = std::getenv("GPC_GRID_DEVICES");   // "same": every rank on the current device (tests on a 1-GPU box)
   const bool one_device = same && std::string(same) == "same";
@@ -292,7 +289,7 @@ void CGp::updateK() const
     return;
   }
   if(useGrid()) {
-    if(!KupToDate) gridUpdateK(0);   // the grid never forms invK: its gradient solves for block columns of it (gpc_grid_gradient)
+    if(!KupToDate) gridUpdateK(0);   // invK lives block-cyclic on the grid (gpc_grid_inverse inside gpc_grid_gradient), never here
     return;
   }
   if(KupToDate && (invKupToDate || !needInverse)) return;
@@ -443,8 +440,8 @@ double CGp::logLikelihoodGradient(CMatrix& g) const
   const unsigned int np = pkern->getNumParams();
   if(g.getRows() != 1 || g.getCols() != np) throw ndlexceptions::MatrixError("logLikelihoodGradient: g must be 1 x nParams");
   if(useGrid()) {
-    // updateG on the grid: every rank solves for its tile columns of K^-1 from the replicated factor and runs the
-    // kernel-gradient pass over them; the parameter sums come back all-reduced (natural space, spec order)
+    // updateG on the grid: K^-1 is formed block-cyclic beside the factor (gpc_grid_inverse), every rank runs the covGrad +
+    // kernel-gradient pass over its own tiles; the parameter sums come back all-reduced (natural space, spec order)
     updateK();
     std::vector<std::vector<double> > gr(grids.size(), std::vector<double>(np > 0 ? np : 1, 0.0));
     std::vector<gpc_grid*>& gs = grids;

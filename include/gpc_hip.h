@@ -190,7 +190,7 @@ int gpc_trace_f64(int64_t N, const double* A, int64_t lda, double* out, void* st
  *                             devices == NULL puts all ranks on the current device (how one GPU tests a grid);
  *   gpc_grid_create_transport the caller's own transport (MPI, gloo, ...) through plain C callbacks.
  * X, Y, Xstar and all results are HOST arrays (column-major), identical on every rank; every entry point except
- * gpc_grid_info / stats / copy_tile / set_lookahead / destroy is collective. */
+ * gpc_grid_info / stats / copy_tile / copy_inverse_tile / set_lookahead / destroy is collective. */
 typedef struct gpc_grid gpc_grid;
 #define GPC_GRID_UID_BYTES 128
 #define GPC_GRID_AXIS_ROW 0      /* the ranks of my process row    (index in the group = my column c) */
@@ -227,11 +227,18 @@ int gpc_grid_quadform(gpc_grid* g, double* q);                                /*
 int gpc_grid_alpha(gpc_grid* g, double* alpha_host, int64_t lda);              /* CGp::updateAlpha: K^-1 Y, N x d */
 int gpc_grid_posterior(gpc_grid* g, double* mu_host, int64_t ldmu, double* var_host);   /* before output scale / bias */
 /* CGp::updateG (CGp.cpp:1080-1117): g[p] = sum_ij covGrad(i,j) dK(i,j)/dtheta_p, natural kernel parameters in spec order
- * (offs[n_terms] doubles), covGrad = -0.5 (d K^-1 - Alpha Alpha').  The factor is replicated (it must fit one GPU next to
- * the local block: N <= ~170 000 on 288 GB; gpc_grid_stats out[7] reports what a rank holds) and every rank forms its own
- * groups of tile rows of K^-1 by two right-sided solves on the trailing block: (2/3) N^3 / P flops per rank, no distributed
- * dpotri.  Cross-block kernel pass: D <= 64. */
+ * (offs[n_terms] doubles), covGrad = -0.5 (d K^-1 - Alpha Alpha') (CGp.cpp:666-679).  K^-1 is formed block-cyclic by
+ * gpc_grid_inverse; every rank runs the covGrad + kernel-gradient pass over its own tiles; one all-reduce of the parameter
+ * sums.  Nothing of size N x N is replicated: a rank holds its block of the factor, its block of K^-1 and O(N nb) of panel
+ * buffers (gpc_grid_stats out[7]), so the gradient runs wherever the factorisation does.  Cross-block kernel pass: D <= 64. */
 int gpc_grid_gradient(gpc_grid* g, double* g_host);
+/* CMatrix::pdinv (CMatrix.cpp:414-432; dpotri_, lapack.h:67-73) on the distributed factor: K^-1 = L^-T L^-1 block-cyclic in a
+ * block of its own (the factor stays), one right-looking sweep that interleaves dtrtri's and dlauum's updates tile row by
+ * tile row -- 2 N^3 / (3 P) flops per rank on the factorisation's staircase kernel, the exchange volume of two
+ * factorisations.  Leaves the lower tiles (I >= J; diagonal tiles in their lower triangle) of K^-1 where the factor's tiles
+ * are: tile (I, J) on rank (owner_row(I), J mod pc).  gpc_grid_copy_inverse_tile reads one back (tests). */
+int gpc_grid_inverse(gpc_grid* g);
+int gpc_grid_copy_inverse_tile(gpc_grid* g, int64_t I, int64_t J, double* host, int* owned);
 int gpc_grid_sync(gpc_grid* g);
 int gpc_grid_barrier(gpc_grid* g);
 /* Not collective.  This rank gives up (its thread hit an error outside the library): the other ranks of a
@@ -250,7 +257,8 @@ int gpc_grid_set_lookahead(gpc_grid* g, int on);
 int gpc_grid_info(gpc_grid* g, int64_t* out);
 /* out[8] = bytes received along the process row / column / world, collectives entered, algorithmic flops of this rank's
  * trailing updates, their launches, their algorithmic HBM bytes -- since the last reset -- and out[7] = the device bytes this
- * rank's problem holds (local block, panel buffers, and the gradient's replicated factor once gpc_grid_gradient has run) */
+ * rank's problem holds (local block of the factor, panel buffers, and -- once gpc_grid_gradient / gpc_grid_inverse has run --
+ * the equally large block of K^-1 with its O(N nb) panels: about 2 * 8 N^2 / P in all) */
 int gpc_grid_stats(gpc_grid* g, double* out, int reset);
 /* What the transport reports about itself: out[0..2] = members of the process-row / process-column / world communicator as the
  * TRANSPORT counts them (RCCL: ncclCommCount of the communicators the exchanges run on; 0 = a group of one has none),

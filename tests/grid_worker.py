@@ -30,6 +30,8 @@ def run(rank, world, port, pr, pc, nb, N, D, d, Ns, outdir, flavour):
     if Ns:
         out["mu"], out["var"] = g.posterior()
     out["tiles"] = np.array(g.local_tiles(), dtype=object)
+    out["grad"] = g.gradient(len(gc.expected_gradient(gc.TERMS, X[:4], Y[:4])))     # (the sums' count; the values come from all of X)
+    out["held"] = g.stats()["bytes_held"]
     np.savez(os.path.join(outdir, "rank%d.npz" % rank), **out)
     g.destroy()
     dist.barrier()

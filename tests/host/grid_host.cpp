@@ -118,7 +118,7 @@ struct HostOps : GridOps {
         for(int64_t il = 0; il < L.Lr; il++)
           for(int64_t i = 0; i < L.nb; i++) {
             const int64_t gi = L.grow(il) * L.nb + i;
-            if(gi == gj) col[il * L.nb + i] = gi < L.N ? dg[gi] : 1.0;
+            if(gi == gj) col[il * L.nb + i] = (dg && gi < L.N) ? dg[gi] : 1.0;
             else if(gi >= L.N) col[il * L.nb + i] = 0.0;
           }
       }
@@ -177,9 +177,39 @@ struct HostOps : GridOps {
         if(I < J || (I == J && rm < cn)) continue;
         double s = 0.0;
         for(int64_t k = 0; k < u.K; k++) s += u.W[m + k * u.ldw] * vrow[k * u.ldv];
-        u.C[m + n * u.ldc] -= s;
+        u.C[m + n * u.ldc] += u.alpha * s;
       }
     }
+    return GPC_OK;
+  }
+  int copy_tiles(double* dst, int64_t dstep, int64_t ldd, const double* src, int64_t sstep, int64_t lds, int64_t count, int64_t nb,
+                 int64_t ncols, int) override
+  {
+    if(injected()) return GPC_EHIP;
+    for(int64_t t = 0; t < count; t++)
+      for(int64_t j = 0; j < ncols; j++) memcpy(dst + t * dstep + j * ldd, src + t * sstep + j * lds, sizeof(double) * (size_t)nb);
+    return GPC_OK;
+  }
+  int covgrad_local(double* S, const Layout& L, const double* Al, int64_t lda, int64_t nd, double* trace, int) override
+  {
+    double tr = 0.0;
+    for(int64_t n = 0; n < L.nloc; n++) {
+      const int64_t jl = n / L.nb, gj = (L.c + L.pc * jl) * L.nb + (n - jl * L.nb);
+      for(int64_t i = 0; i < L.Lr * L.nb; i++) {
+        const int64_t il = i / L.nb, gi = L.grow(il) * L.nb + (i - il * L.nb);
+        double* p = S + i + n * L.lld;
+        if(gi < gj || gi >= L.N || gj >= L.N) {
+          *p = 0.0;
+          continue;
+        }
+        double aa = 0.0;
+        for(int64_t o = 0; o < nd; o++) aa += Al[gi + o * lda] * Al[gj + o * lda];
+        const double v = -0.5 * ((double)nd * *p - aa);
+        *p = gi > gj ? 2.0 * v : v;
+        if(gi == gj) tr += v;
+      }
+    }
+    *trace = tr;
     return GPC_OK;
   }
   int diag_logsum(const double* A, const Layout& L, double* out, int) override
@@ -225,43 +255,10 @@ struct HostOps : GridOps {
     orc_trsm('L', 'L', 'N', 'N', (long)n, (long)nrhs, 1.0, L, (long)ldl, B, (long)ldb);
     return GPC_OK;
   }
-  int scatter_row_tiles(double* dst, int64_t ldd, int64_t first, int64_t step, const double* src, int64_t lds, int64_t count,
-                        int64_t nb, int64_t ncols, int) override
-  {
-    for(int64_t t = 0; t < count; t++)
-      for(int64_t j = 0; j < ncols; j++)
-        memcpy(dst + (first + t * step) * nb + j * ldd, src + t * nb + j * lds, sizeof(double) * (size_t)nb);
-    return GPC_OK;
-  }
   int set_identity(double* A, int64_t lda, int64_t n, int) override
   {
     for(int64_t j = 0; j < n; j++)
       for(int64_t i = 0; i < n; i++) A[i + j * lda] = i == j ? 1.0 : 0.0;
-    return GPC_OK;
-  }
-  int sum_diag(const double* A, int64_t lda, int64_t n, double* out, int) override
-  {
-    double s = 0.0;
-    for(int64_t i = 0; i < n; i++) s += A[i + i * lda];
-    *out = s;
-    return GPC_OK;
-  }
-  int trsm_right(const double* L, int64_t ldl, int64_t n, bool trans, bool, double* B, int64_t ldb, int64_t M, int) override
-  {
-    orc_trsm('R', 'L', trans ? 'T' : 'N', 'N', (long)M, (long)n, 1.0, L, (long)ldl, B, (long)ldb);
-    return GPC_OK;
-  }
-  int covgrad_block(double* S, int64_t lds, int64_t M, int64_t nbc, const double* Al, int64_t lda, int64_t nd, int64_t g0,
-                    int upper, int) override
-  {
-    for(int64_t j = 0; j < nbc; j++)
-      for(int64_t i = 0; i < M; i++) {
-        double aa = 0.0;
-        for(int64_t o = 0; o < nd; o++) aa += Al[g0 + i + o * lda] * Al[g0 + j + o * lda];
-        const double c = -0.5 * ((double)nd * S[i + j * lds] - aa);
-        const bool twice = upper ? j > i : i > j;
-        S[i + j * lds] = twice ? 2.0 * c : (i == j ? c : 0.0);
-      }
     return GPC_OK;
   }
   int kern_grad_block(const gpc_kspec* ks, const double* Xa, int64_t Na, int64_t lda, const double* Xb, int64_t Nb, int64_t ldb,

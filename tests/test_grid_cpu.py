@@ -84,10 +84,88 @@ def test_ragged_sizes_on_2x2(hb, N):
     _check(_solve_local(hb, 2, 2, 128, gc.TERMS, X, Y, Xs), exp, N, 128, Xs)
 
 
-@pytest.mark.parametrize("pr,pc", [(1, 1), (1, 2), (2, 2), (2, 4), (3, 2), (4, 1), (8, 1)])
+GRADIENT_SHAPES = [(1, 1), (1, 2), (2, 1), (2, 2), (2, 4), (4, 2), (3, 2), (2, 3), (4, 1), (8, 1), (1, 4), (3, 1), (1, 8)]
+
+
+@pytest.mark.parametrize("pr,pc", GRADIENT_SHAPES)
+def test_distributed_inverse_against_numpy(hb, pr, pc):
+    """CMatrix::pdinv on the grid (gpc_grid_inverse: dtrtri's and dlauum's updates interleaved in one block-cyclic sweep, the
+    factor left intact): the lower tiles every rank ends up with are numpy's inverse; the factor's tiles have not changed;
+    a rank holds two blocks and O(N nb) of panels -- no replica of anything N x N."""
+    N, D, nb = 700, 3, 128        # T = 6 tiles, ragged last tile
+    X, Y, _ = gc.make_problem(N, D, 1, 0, 7)
+    K = gc.kern(gc.TERMS, X, X, True)
+    want = np.linalg.inv(K)
+    grids = grid.create_local(pr, pc, nb, binding=hb)
+
+    def work(g, rank):
+        g.set_problem(gc.TERMS, X, Y, None)
+        assert g.update_k()[2] == 0
+        before = g.local_tiles()
+        g.inverse()
+        after = g.local_tiles()
+        assert all(np.array_equal(before[k], after[k]) for k in before)
+        return g.local_tiles(of_inverse=True), g.stats(), g.info()
+
+    try:
+        res = grid.run_local(grids, work)
+    finally:
+        for g in grids:
+            g.destroy()
+    Ki = grid.assemble_factor([r[0] for r in res], N, nb)     # lower triangle of whatever the tiles hold
+    assert gc.rel(Ki, np.tril(want)) < 1e-9
+    T, P = (N + nb - 1) // nb, pr * pc
+    for _, st, inf in res:
+        block = 8.0 * inf["mloc"] * max(inf["nloc"], 1)
+        assert st["bytes_held"] <= 2.0 * block + 8.0 * 16 * nb * (T * nb) + 1e5
+        assert st["bytes_held"] <= 3.0 * 8.0 * (T * nb + nb * max(pr, pc)) ** 2 / P + 8.0 * 16 * nb * (T * nb) + 1e5
+
+
+def test_inverse_lookahead_and_reflection_do_not_change_a_bit(hb, monkeypatch):
+    """The sweep's look-ahead (tile row k+1 solved and exchanged on the panel stream beside step k's updates) only reorders
+    the issue; reflected and plain rounds of a pr x 1 grid sum every tile in the same order."""
+    N, nb = 900, 128
+    X, Y, _ = gc.make_problem(N, 3, 1, 0, 3)
+    out = {}
+    for shape in ((2, 2), (4, 1), (1, 3), (2, 3)):
+        for la in (0, 1, 2):
+            grids = grid.create_local(shape[0], shape[1], nb, binding=hb)
+
+            def work(g, rank):
+                g.set_lookahead(la)
+                g.set_problem(gc.TERMS, X, Y, None)
+                assert g.update_k()[2] == 0
+                g.inverse()
+                return g.local_tiles(of_inverse=True)
+
+            try:
+                res = grid.run_local(grids, work)
+            finally:
+                for g in grids:
+                    g.destroy()
+            out[(shape, la)] = grid.assemble_factor(res, N, nb)
+        assert np.array_equal(out[(shape, 0)], out[(shape, 1)]) and np.array_equal(out[(shape, 0)], out[(shape, 2)])
+    monkeypatch.setenv("GPC_GRID_REFLECT", "0")
+    grids = grid.create_local(4, 1, nb, binding=hb)
+
+    def work2(g, rank):
+        g.set_problem(gc.TERMS, X, Y, None)
+        assert g.update_k()[2] == 0
+        g.inverse()
+        return g.local_tiles(of_inverse=True)
+
+    try:
+        res = grid.run_local(grids, work2)
+    finally:
+        for g in grids:
+            g.destroy()
+    assert np.array_equal(grid.assemble_factor(res, N, nb), out[((4, 1), 1)])
+
+
+@pytest.mark.parametrize("pr,pc", GRADIENT_SHAPES)
 def test_gradient_against_numpy(hb, pr, pc):
-    """CGp::updateG on the grid (replicated factor, every rank its own tile columns of K^-1, one all-reduce) against the
-    defining sums: rbf + lin + bias + white, ragged last tile, two outputs."""
+    """CGp::updateG on the grid (K^-1 block-cyclic by gpc_grid_inverse, every rank the covGrad + kernel pass over its own tiles,
+    one all-reduce) against the defining sums: rbf + lin + bias + white, ragged last tile, two outputs."""
     N, D, d, nb = 600, 3, 2, 128
     terms = [("rbf", [1.3, 0.9]), ("lin", [0.15]), ("bias", [0.2]), ("white", [0.05])]
     X, Y, _ = gc.make_problem(N, D, d, 0, 13)
@@ -107,6 +185,30 @@ def test_gradient_against_numpy(hb, pr, pc):
     for got, _ in res:
         assert gc.rel(got, want) < 1e-8
         assert np.array_equal(got, res[0][0])
+
+
+@pytest.mark.parametrize("N", [128, 129, 255, 384, 1000, 1153])
+def test_gradient_ragged_sizes(hb, N):
+    """ragged N (padding inside the last tile: its identity block must not reach covGrad) on a square, a tall and a wide grid"""
+    terms = [("rbf", [1.3, 0.9]), ("bias", [0.2]), ("white", [0.05])]
+    X, Y, _ = gc.make_problem(N, 2, 1, 0, N)
+    want = gc.expected_gradient(terms, X, Y)
+    for pr, pc in ((2, 2), (4, 1), (2, 4)):
+        grids = grid.create_local(pr, pc, 128, binding=hb)
+
+        def work(g, rank):
+            g.set_problem(terms, X, Y, None)
+            assert g.update_k()[2] == 0
+            first = g.gradient(len(want))
+            return first, g.gradient(len(want)), g.loglik()      # a second call reuses the held blocks
+
+        try:
+            res = grid.run_local(grids, work)
+        finally:
+            for g in grids:
+                g.destroy()
+        for a, b, _ in res:
+            assert gc.rel(a, want) < 1e-8 and np.array_equal(a, b)
 
 
 @pytest.mark.parametrize("pr,N,nb", [(4, 1500, 128), (8, 1000, 128), (8, 2100, 128), (3, 900, 256), (2, 700, 128), (8, 2048, 128),
@@ -411,3 +513,6 @@ def test_one_process_per_rank_over_gloo(pr, pc, tmp_path):
         z["info"] = int(z["info"])
         res.append(z)
     _check(res, exp, N, nb, Xs)
+    want = gc.expected_gradient(gc.TERMS, X, Y)          # the distributed inverse + gradient over the same transport
+    for z in res:
+        assert gc.rel(z["grad"], want) < 1e-8 and np.array_equal(z["grad"], res[0]["grad"])

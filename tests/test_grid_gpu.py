@@ -241,6 +241,49 @@ def test_gradient_against_numpy_and_the_single_gpu_model(pr, pc, D, terms):
     assert gc.rel(res[0] * fac, g1) < 1e-8
 
 
+@pytest.mark.parametrize("pr,pc,N,nb", [(1, 1, 1100, 128), (2, 2, 1100, 128), (4, 1, 1500, 128), (2, 4, 2100, 256), (8, 1, 2304, 128),
+                                       (2, 1, 2050, 512), (1, 2, 1030, 512)])
+def test_distributed_inverse_on_shared_gpu_ranks(pr, pc, N, nb):
+    """CMatrix::pdinv on the grid with the HIP kernels (gpc_grid_inverse): the lower tiles of K^-1 against numpy and against the
+    single-GPU gpc_potri_f64, the factor untouched, a rank's memory = two blocks + O(N nb) -- nothing N x N replicated."""
+    from gpc_amd import api, grid
+    import torch
+    terms = [("rbf", [0.7, 0.9]), ("bias", [0.2]), ("white", [0.05])]
+    X, Y, _ = gc.make_problem(N, 4, 1, 0, 17)
+    K = gc.kern(terms, X, X, True)
+    want = np.linalg.inv(K)
+    grids = grid.create_local(pr, pc, nb)
+
+    def work(g, rank):
+        g.set_problem(terms, X, Y, None)
+        assert g.update_k()[2] == 0
+        before = g.local_tiles()
+        g.inverse()
+        after = g.local_tiles()
+        assert all(np.array_equal(before[k], after[k]) for k in before)
+        return g.local_tiles(of_inverse=True), g.stats(), g.info()
+
+    try:
+        res = grid.run_local(grids, work)
+    finally:
+        for g in grids:
+            g.destroy()
+    Ki = grid.assemble_factor([r[0] for r in res], N, nb)
+    assert gc.rel(Ki, np.tril(want)) < 1e-9
+    # the single-GPU path's dpotri on the same matrix
+    Kd = api.from_host(K)
+    assert api.potrf(Kd, "L") == 0
+    api.potri(Kd, "L")
+    torch.cuda.synchronize()
+    one = np.tril(Kd.cpu().numpy())
+    assert gc.rel(Ki, one) < 1e-9
+    T, P = (N + nb - 1) // nb, pr * pc
+    for _, st, inf in res:
+        block = 8.0 * inf["mloc"] * max(inf["nloc"], 1)
+        assert st["bytes_held"] <= 2.0 * block + 8.0 * 16 * nb * (T * nb) + 1e5
+        assert st["bytes_held"] <= 3.0 * 8.0 * (T * nb + nb * max(pr, pc)) ** 2 / P + 8.0 * 16 * nb * (T * nb) + 1e5
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))

@@ -157,9 +157,26 @@ struct TraceOps : GridOps {
     if(count > 0) s->op(st, "copy", "\"bytes\":%lld", (long long)(8 * count * nb * nb));
     return GPC_OK;
   }
+  int copy_tiles(double*, int64_t, int64_t, const double*, int64_t, int64_t, int64_t count, int64_t nb, int64_t ncols, int st) override
+  {
+    if(count > 0 && ncols > 0) s->op(st, "copy", "\"bytes\":%lld", (long long)(8 * count * nb * ncols));
+    return GPC_OK;
+  }
+  int covgrad_local(double*, const Layout& L, const double*, int64_t, int64_t, double* trace, int st) override
+  {
+    *trace = 0.0;
+    s->op(st, "small", "\"bytes\":%lld", (long long)(16 * L.Lr * L.nb * L.nloc));
+    s->op(st, "download", "\"bytes\":8");
+    return GPC_OK;
+  }
   void prof_update_begin(double flops, int) override { pending_flops = flops; }
   int update(const UpdateArgs& u, int st) override
   {
+    if(u.role == 3) {   // an update of the distributed inverse: priced like a trailing update of the same extent, named apart
+      s->op(st, "inv_update", "\"flops\":%.17g,\"rows\":%lld,\"cols\":%lld,\"k\":%lld", 2.0 * (double)u.M * (double)u.Ncols * (double)u.K,
+            (long long)u.M, (long long)u.Ncols, (long long)u.K);
+      return GPC_OK;
+    }
     s->op(st, "update", "\"flops\":%.17g,\"rows\":%lld,\"cols\":%lld,\"k\":%lld", pending_flops, (long long)u.M,
           (long long)u.Ncols, (long long)u.K);
     return GPC_OK;
@@ -193,31 +210,9 @@ struct TraceOps : GridOps {
     s->op(st, "trsm_l", "\"n\":%lld,\"nrhs\":%lld", (long long)n, (long long)nrhs);
     return GPC_OK;
   }
-  int scatter_row_tiles(double*, int64_t, int64_t, int64_t, const double*, int64_t, int64_t count, int64_t nb, int64_t ncols,
-                        int st) override
-  {
-    s->op(st, "copy", "\"bytes\":%lld", (long long)(8 * count * nb * ncols));
-    return GPC_OK;
-  }
   int set_identity(double*, int64_t, int64_t n, int st) override
   {
     s->op(st, "zero", "\"bytes\":%lld", (long long)(8 * n * n));
-    return GPC_OK;
-  }
-  int sum_diag(const double*, int64_t, int64_t, double* out, int st) override
-  {
-    *out = 0.0;
-    s->op(st, "download", "\"bytes\":8");
-    return GPC_OK;
-  }
-  int trsm_right(const double*, int64_t, int64_t n, bool, bool, double*, int64_t, int64_t M, int st) override
-  {
-    s->op(st, "trsm_right", "\"rows\":%lld,\"n\":%lld", (long long)M, (long long)n);
-    return GPC_OK;
-  }
-  int covgrad_block(double*, int64_t, int64_t M, int64_t nbc, const double*, int64_t, int64_t, int64_t, int, int st) override
-  {
-    s->op(st, "small", "\"bytes\":%lld", (long long)(16 * M * nbc));
     return GPC_OK;
   }
   int kern_grad_block(const gpc_kspec* ks, const double*, int64_t Na, int64_t, const double*, int64_t Nb, int64_t, int64_t,
