@@ -48,6 +48,7 @@ SIGNATURES = {
     "gpc_memcpy_d2h": (c_int, [c_void_p, c_void_p, c_size_t, VP]),
     "gpc_defer": (c_int, [c_int]),
     "gpc_sync_pending": (c_int, [VP]),
+    "gpc_discard_pending": (c_int, []),
     "gpc_memcpy_d2d": (c_int, [c_void_p, c_void_p, c_size_t, VP]),
     "gpc_memset": (c_int, [c_void_p, c_int, c_size_t, VP]),
     "gpc_stream_sync": (c_int, [VP]),

@@ -1,3 +1,4 @@
+#include <memory>
 // capi.hip -- the extern "C" boundary of libgpc_hip.so (include/gpc_hip.h): argument checking, device / workspace
 // management, LAPACK-style wrappers and the fused CGp (FTC) drivers.  No CPU fallback lives here: every entry point
 // needs a HIP device and fails with GPC_ENODEV otherwise.
@@ -481,6 +482,16 @@ int gpc_sync_pending(void* stream)
   return f.finish(as_stream(stream));
 }
 
+// Drops this thread's postponed fetches without delivering them (their destinations may be gone: a caller unwinding between a
+// deferred call and its flush).  Nothing is written, no callback runs; the staging buffer is reusable at once -- a gather kernel
+// still in flight only writes into that buffer, never into a destination.
+int gpc_discard_pending(void)
+{
+  if(g_pending) g_pending->clear();
+  g_pending_used = 0;
+  return GPC_OK;
+}
+
 int gpc_memcpy_d2h(void* dst, const void* src, size_t bytes, void* stream)
 {
   GPC_CHECK(ensure_device());
@@ -491,9 +502,21 @@ int gpc_memcpy_d2h(void* dst, const void* src, size_t bytes, void* stream)
   int* sticky = g_ws[WS_INFO].p ? static_cast<int*>(g_ws[WS_INFO].p) + SOLVE_FAULT_WORD : nullptr;
   if(defer_requested() && bytes <= HOST_STAGE_BYTES / 4) {
     // gpc_defer(1): the copy rides in this thread's next synchronising call (include/gpc_hip.h); dst is valid after that
+    // ... and so does the sticky fault word: the synchronising call that delivers dst reports the fault, as documented
     HostFetch f;
     GPC_CHECK(f.add(dst, src, bytes, as_stream(stream)));
-    return f.defer(as_stream(stream), nullptr);
+    if(!sticky) return f.defer(as_stream(stream), nullptr);
+    std::shared_ptr<int> late(new(std::nothrow) int(0));
+    if(!late) return GPC_ENOMEM;
+    GPC_CHECK(f.add(late.get(), sticky, sizeof(int), as_stream(stream)));
+    hipStream_t s = as_stream(stream);
+    return f.defer(s, [late, sticky, s]() -> int {
+      if(!*late) return GPC_OK;
+      (void)hipMemsetAsync(sticky, 0, sizeof(int), s);
+      set_error("a dataflow triangular solve timed out (device shared or pre-empted?); its result is NaN -- repeat the call, or "
+                "set GPC_TRSV_FLOW=0 for the stepped kernels");
+      return GPC_EHIP;
+    });
   }
   HostFetch f;
   GPC_CHECK(f.add(dst, src, bytes, as_stream(stream)));
@@ -630,20 +653,18 @@ int gpc_chol_inverse_f64(int64_t N, double* A, int64_t lda, double* invK, int64_
   if(logdet && defer_requested() && ld_n > 0 && ld_n <= 1024) {
     // gpc_defer(1): no synchronisation here at all -- *info and *logdet are written when this thread's next synchronising
     // call (the GP-LVM's column dots, two launches further on) brings the partial sums and the info word over
-    double* h = static_cast<double*>(malloc(sizeof(double) * (size_t)ld_n));
-    if(!h) return GPC_ENOMEM;
+    // (the partial sums' landing place is owned by the callback: dropped with it if the pending fetch is discarded)
+    std::shared_ptr<std::vector<double>> hp(new(std::nothrow) std::vector<double>());
+    if(!hp) return GPC_ENOMEM;
+    hp->resize((size_t)ld_n);
     HostFetch f;
-    int rc = f.add(h, ld_part, sizeof(double) * (size_t)ld_n, s);
-    if(rc == GPC_OK) rc = f.add(info, d_info, sizeof(int), s);
-    if(rc != GPC_OK) {
-      free(h);
-      return rc;
-    }
+    GPC_CHECK(f.add(hp->data(), ld_part, sizeof(double) * (size_t)ld_n, s));
+    GPC_CHECK(f.add(info, d_info, sizeof(int), s));
     const int64_t nparts = ld_n;
-    return f.defer(s, [h, nparts, info, logdet]() -> int {
+    return f.defer(s, [hp, nparts, info, logdet]() -> int {
+      const double* h = hp->data();
       double sl = 0.0;
       for(int64_t b = 0; b < nparts; b++) sl += h[b];        // (the order of reduce_partials_to_host)
-      free(h);
       if(*info == PANEL_FLOW_TIMEOUT) {
         *info = 0;
         g_flow_timed_out = true;

@@ -138,7 +138,7 @@ struct KStartScope {
 int potrf_lower(int64_t N, double* A, int64_t lda, int* d_info, hipStream_t s, int64_t col0 = 0);
 int potrf_panel(int64_t M, int64_t nb, double* A, int64_t lda, int* d_info, int64_t col0, hipStream_t s);
 int trsm_rlt_flow(int64_t M, int64_t n, const double* L, int64_t lda, double* B, int64_t ldb, bool identity_rows, int* d_info,
-                  hipStream_t s, double* inplace_tile = nullptr);   // potrf.hip: X L' = B by dataflow launches (B == L: in place)
+                  hipStream_t s, double* inplace_tile = nullptr, int64_t inplace_tile_n = 0);   // potrf.hip: X L' = B by dataflow launches (B == L: in place; inplace_tile holds inplace_tile_n^2 doubles)
 int potrf_panel_rows(int64_t M, int64_t nb, double* tile, int64_t ldt, double* rows, int64_t ldr, int* d_info, int64_t col0, hipStream_t s);
 // panel_flow.hip: one panel (diagonal dpotrf + the rows below) as ONE dataflow launch; GPC_EUNSUPPORTED outside its domain
 int panel_flow(int64_t M, int64_t nbk, double* P, int64_t lda, int* d_info, int64_t col0, hipStream_t s, int64_t zero_row0 = -1,

@@ -682,6 +682,22 @@ struct RcclComm : GridComm {
     HIPOPS_CHECK(hipMalloc((void**)&scratch, sizeof(double) * SCRATCH));
     return GPC_OK;
   }
+  // communicators made by the caller (grid_make_local_collective: one process, one rank thread per GPU); null = a group of one
+  int adopt(ncclComm_t world, ncclComm_t row, ncclComm_t col, int rank, int pr, int pc, GridOps* ops)
+  {
+    main = (hipStream_t)ops->native_stream(ST_MAIN);
+    comm[AX_WORLD] = world;
+    comm[AX_ROW] = row;
+    comm[AX_COL] = col;
+    size[AX_WORLD] = pr * pc;
+    size[AX_ROW] = pc;
+    size[AX_COL] = pr;
+    me[AX_ROW] = rank % pc;
+    me[AX_COL] = rank / pc;
+    me[AX_WORLD] = rank;
+    HIPOPS_CHECK(hipMalloc((void**)&scratch, sizeof(double) * SCRATCH));
+    return GPC_OK;
+  }
   ~RcclComm() override
   {
     if(scratch) (void)hipFree(scratch);
@@ -836,6 +852,56 @@ int grid_make_collective_comm(std::unique_ptr<GridComm>& out, int rank, int nran
   GPC_CHECK(c->init(rank, nranks, pr, pc, uid, ops));
   out.reset(c.release());
   return GPC_OK;
+}
+
+// One process, one rank per GPU (gpc_grid_create_local on distinct devices -- the path the C++ CGp / `gp learn` takes): RCCL
+// communicators for the world, every process row and every process column, each made by ncclCommInitRank for all its members
+// inside one group call from the creating thread (RCCL's single-thread / multi-device form); afterwards each rank's own thread
+// drives its communicators.  GPC_EUNSUPPORTED when librccl cannot be opened (the caller then uses the in-process board).
+int grid_make_local_collective(std::vector<std::unique_ptr<GridComm>>& out, int pr, int pc, const int* devices,
+                               const std::vector<GridOps*>& ops)
+{
+  RcclApi* api = rccl_api();
+  if(!api) return GPC_EUNSUPPORTED;
+  const int P = pr * pc;
+  int cur = 0;
+  HIPOPS_CHECK(hipGetDevice(&cur));
+  std::vector<ncclComm_t> world((size_t)P, nullptr), row((size_t)P, nullptr), col((size_t)P, nullptr);
+  // ngroups groups of gsize members; member i of group g is rank base(g) + i * stride
+  auto make = [&](int ngroups, int gsize, int gstride, int mstride, std::vector<ncclComm_t>& dst) -> int {
+    std::vector<ncclUniqueId> ids((size_t)ngroups);
+    for(int g = 0; g < ngroups; g++) RCCL_CHECK(api->GetUniqueId(&ids[(size_t)g]));
+    RCCL_CHECK(api->GroupStart());
+    for(int g = 0; g < ngroups; g++)
+      for(int i = 0; i < gsize; i++) {
+        const int rank = g * gstride + i * mstride;
+        HIPOPS_CHECK(hipSetDevice(devices[rank]));
+        RCCL_CHECK(api->CommInitRank(&dst[(size_t)rank], gsize, ids[(size_t)g], i));
+      }
+    RCCL_CHECK(api->GroupEnd());
+    return GPC_OK;
+  };
+  const bool force = grid_force_collectives();                       // (tests: the collectives of groups of one are issued too)
+  int rc = make(1, P, 0, 1, world);
+  if(rc == GPC_OK && (pc > 1 || force)) rc = make(pr, pc, pc, 1, row);      // process row r: ranks r pc + c
+  if(rc == GPC_OK && (pr > 1 || force)) rc = make(pc, pr, 1, pc, col);      // process column c: ranks r pc + c
+  for(int rank = 0; rank < P && rc == GPC_OK; rank++) {
+    rc = hipSetDevice(devices[rank]) == hipSuccess ? GPC_OK : GPC_EHIP;
+    std::unique_ptr<RcclComm> c(new RcclComm(api));
+    if(rc == GPC_OK) rc = c->adopt(world[(size_t)rank], row[(size_t)rank], col[(size_t)rank], rank, pr, pc, ops[(size_t)rank]);
+    if(rc == GPC_OK) {
+      world[(size_t)rank] = row[(size_t)rank] = col[(size_t)rank] = nullptr;     // owned by the RcclComm from here on
+      out.emplace_back(c.release());
+    }
+  }
+  if(rc != GPC_OK) {
+    out.clear();
+    for(int rank = 0; rank < P; rank++)
+      for(ncclComm_t c : {row[(size_t)rank], col[(size_t)rank], world[(size_t)rank]})
+        if(c) (void)api->CommDestroy(c);
+  }
+  (void)hipSetDevice(cur);
+  return rc;
 }
 
 }  // namespace

@@ -8,6 +8,7 @@
 //   grid_make_ops(int device)              -> std::unique_ptr<GridOps>
 //   grid_enter(int device)                 make `device` current on the calling thread (status code)
 //   grid_make_collective_comm(...)         the RCCL communicator (or GPC_EUNSUPPORTED)
+//   grid_make_local_collective(...)        RCCL communicators for the ranks of ONE process on distinct devices (or GPC_EUNSUPPORTED)
 //   grid_unique_id(void* uid)              fill GPC_GRID_UID_BYTES
 #include <new>
 #include <chrono>
@@ -67,32 +68,53 @@ int GRID_API(create_local)(gpc_grid** out, int pr, int pc, int64_t nb, const int
   const int P = pr * pc;
   int cur = 0;
   GRID_CHECK(grid_current_device(&cur));
-  std::shared_ptr<LocalBoard> board(new LocalBoard(pr, pc));
-  std::vector<gpc_grid*> made;
+  std::vector<std::unique_ptr<GridOps>> ops;
+  std::vector<int> dev((size_t)P, cur);
   for(int rank = 0; rank < P; rank++) {
-    const int dev = devices ? devices[rank] : cur;
-    int rc = grid_enter(dev);
-    std::unique_ptr<GridOps> ops;
+    if(devices) dev[(size_t)rank] = devices[rank];
+    int rc = grid_enter(dev[(size_t)rank]);
     if(rc == GPC_OK) {
-      ops = grid_make_ops(dev);
-      if(!ops) rc = GPC_ENODEV;
+      ops.push_back(grid_make_ops(dev[(size_t)rank]));
+      if(!ops.back()) rc = GPC_ENODEV;
     }
     if(rc != GPC_OK) {
-      for(gpc_grid* g : made) delete g;
+      ops.clear();
       (void)grid_enter(cur);
       return rc;
     }
-    gpc_grid* g = new gpc_grid();
-    g->device = dev;
-    std::unique_ptr<GridComm> comm;
-    if(P == 1) comm.reset(new SelfComm());
-    else comm.reset(new LocalComm(board, rank / pc, rank % pc));
-    g->gp.reset(new GridGp(std::move(ops), std::move(comm), pr, pc, rank / pc, rank % pc, nb));
-    made.push_back(g);
   }
   (void)grid_enter(cur);
-  if(devices) GRID_CHECK(grid_enable_peers(devices, P));
-  for(int rank = 0; rank < P; rank++) out[rank] = made[(size_t)rank];
+  // Ranks on DISTINCT devices exchange over RCCL (ncclSend / ncclRecv / ncclBroadcast on xGMI), like the one-process-per-GPU
+  // form; ranks that share a device (the tests of a one-GPU box: RCCL refuses two ranks on one device) -- or a build whose
+  // librccl cannot be opened, or GPC_GRID_LOCAL_TRANSPORT=board -- use the in-process board (peer copies ordered by events).
+  bool distinct = devices != nullptr && (P > 1 || grid_force_collectives());
+  for(int i = 0; i < P && distinct; i++)
+    for(int j = 0; j < i; j++)
+      if(dev[(size_t)i] == dev[(size_t)j]) distinct = false;
+  if(const char* e = getenv("GPC_GRID_LOCAL_TRANSPORT"))
+    if(strcmp(e, "board") == 0) distinct = false;
+  std::vector<std::unique_ptr<GridComm>> comms;
+  if(distinct) {
+    std::vector<GridOps*> raw;
+    for(auto& o : ops) raw.push_back(o.get());
+    const int rc = grid_make_local_collective(comms, pr, pc, dev.data(), raw);
+    if(rc == GPC_EUNSUPPORTED) comms.clear();
+    else if(rc != GPC_OK) return rc;
+  }
+  if(comms.empty()) {
+    std::shared_ptr<LocalBoard> board(new LocalBoard(pr, pc));
+    for(int rank = 0; rank < P; rank++) {
+      if(P == 1) comms.emplace_back(new SelfComm());
+      else comms.emplace_back(new LocalComm(board, rank / pc, rank % pc));
+    }
+    if(devices) GRID_CHECK(grid_enable_peers(devices, P));
+  }
+  for(int rank = 0; rank < P; rank++) {
+    gpc_grid* g = new gpc_grid();
+    g->device = dev[(size_t)rank];
+    g->gp.reset(new GridGp(std::move(ops[(size_t)rank]), std::move(comms[(size_t)rank]), pr, pc, rank / pc, rank % pc, nb));
+    out[rank] = g;
+  }
   return GPC_OK;
 }
 

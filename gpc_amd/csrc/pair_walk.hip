@@ -638,8 +638,14 @@ int pair_walk_grad_cross(const KSpecDev& ks, const double* X, int64_t N, int64_t
   dim3 grid;
   walk_grid(N, N2, &per, &grid);
   const int64_t nwg = (int64_t)grid.x * grid.y;
-  const int n_plain = ks.n_rbf > 2 ? 2 : 1;     // scalar passes on the raw inputs: rbf terms two at a time; the first also gives sum G, sum G x.x2
-  const size_t nprep = 64 + (size_t)N + (size_t)N2 + (ks.n_ard ? (size_t)N * (size_t)(D + 1) + (size_t)N2 * (size_t)(D + dp + 1) : 0);
+  // Scalar passes: the rbf terms two at a time on inputs CENTRED by the mean of X2 -- d2 = |xi|^2 + |xj|^2 - 2 xi.xj loses
+  // eps |x|^2 / d2 of its accuracy on inputs far from the origin, which the scalar kernels this walk replaces did not (they formed
+  // differences), and pair_walk_gradx centres for the same reason --; the first of them also gives sum G.  sum G x.x2 (the linear
+  // term's) needs the ACTUAL dot products: a pass on the raw inputs -- the only one when there is no rbf term.
+  const int n_plain = ks.n_rbf > 2 ? 2 : (ks.n_rbf > 0 ? 1 : 0);
+  const bool centred = ks.n_rbf > 0;
+  const size_t nprep = 64 + (size_t)N + (size_t)N2 + (centred ? ((size_t)N + (size_t)N2) * (size_t)(D + 1) : 0) +
+                       (ks.n_ard ? (size_t)N * (size_t)(D + 1) + (size_t)N2 * (size_t)(D + dp + 1) : 0);
   void* wx = nullptr;
   GPC_CHECK(workspace(WS_XSCALED, sizeof(double) * nprep, &wx));
   void* wp = nullptr;
@@ -673,18 +679,24 @@ int pair_walk_grad_cross(const KSpecDev& ks, const double* X, int64_t N, int64_t
     }
     return GPC_OK;
   };
-  const bool plain_needed = ks.n_rbf > 0 || ks.lin_var != 0.0 || ks.bias_var != 0.0 || ks.n_ard == 0;
-  if(plain_needed) {
-    hipLaunchKernelGGL(pw_prep_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, X, ldx, N, (int)D, (const double*)nullptr,
-                       (const double*)nullptr, (double*)nullptr, (double*)nullptr, (int)D, nA);
-    hipLaunchKernelGGL(pw_prep_kernel, dim3((unsigned)((N2 + 255) / 256)), dim3(256), 0, s, X2, ldx2, N2, (int)D, (const double*)nullptr,
-                       (const double*)nullptr, (double*)nullptr, (double*)nullptr, (int)D, nB);
+  const bool raw_needed = ks.lin_var != 0.0 || (!centred && (ks.bias_var != 0.0 || ks.n_ard == 0));
+  const bool plain_needed = centred || raw_needed;
+  if(centred || ks.n_ard) hipLaunchKernelGGL(pw_mean_kernel, dim3((unsigned)D), dim3(256), 0, s, X2, ldx2, N2, mean);
+  if(centred) {
+    double* XcA = cur;  cur += (size_t)N * D;
+    double* ncA = cur;  cur += N;
+    double* XcB = cur;  cur += (size_t)N2 * D;
+    double* ncB = cur;  cur += N2;
+    hipLaunchKernelGGL(pw_prep_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, X, ldx, N, (int)D, mean,
+                       (const double*)nullptr, XcA, (double*)nullptr, (int)D, ncA);
+    hipLaunchKernelGGL(pw_prep_kernel, dim3((unsigned)((N2 + 255) / 256)), dim3(256), 0, s, X2, ldx2, N2, (int)D, mean,
+                       (const double*)nullptr, XcB, (double*)nullptr, (int)D, ncB);
     GPC_HIP_CHECK(hipGetLastError());
-    g.XA = X;  g.ldxa = ldx;  g.nA = nA;
-    g.XB = X2; g.ldxb = ldx2; g.nB = nB;
+    g.XA = XcA; g.ldxa = N;  g.nA = ncA;
+    g.XB = XcB; g.ldxb = N2; g.nB = ncB;
     g.XTB = nullptr;
     for(int p = 0; p < n_plain; p++) {
-      const int t0 = 2 * p, ne = (ks.n_rbf - t0 >= 2) ? 2 : (ks.n_rbf - t0 == 1 ? 1 : 0);
+      const int t0 = 2 * p, ne = (ks.n_rbf - t0 >= 2) ? 2 : 1;
       for(int q = 0; q < 2; q++) {
         g.hiw[q] = q < ne ? ks.rbf_hiw[t0 + q] : 0.0;
         g.coef[q] = 0.0;
@@ -697,17 +709,29 @@ int pair_walk_grad_cross(const KSpecDev& ks, const double* X, int64_t N, int64_t
         S[2 * (t0 + q)] = sums[(size_t)(2 * q)];
         S[2 * (t0 + q) + 1] = sums[(size_t)(2 * q + 1)];
       }
-      if(p == 0) {
-        S[10] = sums[4];
-        S[11] = sums[5];
-      }
+      if(p == 0) S[10] = sums[4];
     }
+  }
+  if(raw_needed) {
+    hipLaunchKernelGGL(pw_prep_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, X, ldx, N, (int)D, (const double*)nullptr,
+                       (const double*)nullptr, (double*)nullptr, (double*)nullptr, (int)D, nA);
+    hipLaunchKernelGGL(pw_prep_kernel, dim3((unsigned)((N2 + 255) / 256)), dim3(256), 0, s, X2, ldx2, N2, (int)D, (const double*)nullptr,
+                       (const double*)nullptr, (double*)nullptr, (double*)nullptr, (int)D, nB);
+    GPC_HIP_CHECK(hipGetLastError());
+    g.XA = X;  g.ldxa = ldx;  g.nA = nA;
+    g.XB = X2; g.ldxb = ldx2; g.nB = nB;
+    g.XTB = nullptr;
+    g.hiw[0] = g.hiw[1] = g.coef[0] = g.coef[1] = 0.0;
+    GPC_CHECK((launch_walk<1, false, false>(g, grid, s)));
+    std::vector<double> sums;
+    GPC_CHECK(fetch(PW_NP, &sums));
+    S[10] = sums[4];
+    S[11] = sums[5];
   }
   if(ks.n_ard) {
     double hsc[32];
     for(int q = 0; q < 32; q++) hsc[q] = q < D ? sqrt(ks.ard_scale[0][q]) : 1.0;
     GPC_HIP_CHECK(hipMemcpyAsync(scd, hsc, sizeof(hsc), hipMemcpyHostToDevice, s));
-    hipLaunchKernelGGL(pw_mean_kernel, dim3((unsigned)D), dim3(256), 0, s, X2, ldx2, N2, mean);
     double* XsA = cur;  cur += (size_t)N * D;
     double* nAs = cur;  cur += N;
     double* XsB = cur;  cur += (size_t)N2 * D;

@@ -792,7 +792,7 @@ int potrf_panel_rows(int64_t M, int64_t nb, double* tile, int64_t ldt, double* r
 // including the diagonal tiles holds V = L^-T (the lower parts of the diagonal tiles are zero, L's strictly-lower tiles are
 // still L's).
 int trsm_rlt_flow(int64_t M, int64_t n, const double* L, int64_t lda, double* B, int64_t ldb, bool identity_rows, int* d_info, hipStream_t s,
-                  double* inplace_tile)
+                  double* inplace_tile, int64_t inplace_tile_n)
 {
   if(n < 128 || M < 1 || panel_flow_maxrows() < 8192) return GPC_EUNSUPPORTED;
   if(identity_rows && M > n) return GPC_EUNSUPPORTED;
@@ -803,7 +803,11 @@ int trsm_rlt_flow(int64_t M, int64_t n, const double* L, int64_t lda, double* B,
   static const int64_t nb_env = [] { const char* e = getenv("GPC_TRTRI_NB"); return e ? atoll(e) : (int64_t)0; }();   // measurement aid
   // (width: the launch's work is rows x nbk^2 at the dataflow blocks' rate, the product's 2 rows (n - kend) nbk at the chip's;
   //  one launch for everything only while the whole problem is small)
-  const int64_t NB = nb_env >= 64 ? (nb_env / 64) * 64 : ((n <= 4096 && M <= 4096) ? 4096 : 1024);
+  int64_t NB = nb_env >= 64 ? (nb_env / 64) * 64 : ((n <= 4096 && M <= 4096) ? 4096 : 1024);
+  if(inplace) {      // a panel's diagonal tile is copied into the caller's inplace_tile_n x inplace_tile_n scratch: no wider
+    if(inplace_tile_n < 64) return GPC_EINVAL;
+    if(NB > inplace_tile_n) NB = (inplace_tile_n / 64) * 64;
+  }
   // What a panel does is decided from sizes alone, so that nothing below can find itself outside the kernels' domain AFTER
   // earlier panels have overwritten B (round 3 returned GPC_EUNSUPPORTED from inside the loop for an identity tile that
   // straddles M above >= GPC_PANEL_INV_MINROWS dense rows; such a panel now takes the one-launch form):

@@ -1005,7 +1005,7 @@ static int potri_inplace_lower(int64_t N, double* A, int64_t lda, hipStream_t s)
   // zeroing has to come first: do the same checks here
   GPC_CHECK(zero_triangle(false, N, A, lda, s));     // the identity's strictly upper part (the old upper triangle is dead: dpotri + mirror)
   {
-    const int rc = trsm_rlt_flow(N, N, A, lda, A, lda, true, d_info, s, tileA);
+    const int rc = trsm_rlt_flow(N, N, A, lda, A, lda, true, d_info, s, tileA, tmax);
     if(rc != GPC_OK) return rc;   // GPC_EUNSUPPORTED: nothing but the (dead) upper triangle was touched
     int mark = 0;
     HostFetch f;

@@ -171,6 +171,14 @@ void onRanks(size_t n, F f)
 }
 }  // namespace
 
+int CGp::gridTransport() const
+{
+  if(!useGrid() || grids.empty()) return 0;
+  int64_t info[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  gpcCheck(gpc_grid_comm_info(grids[0], info));
+  return (int)info[3];
+}
+
 bool CGp::useGrid() const
 {
   if(gridDecided) return gridDecided > 0;

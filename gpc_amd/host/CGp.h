@@ -152,10 +152,16 @@ class CGp : public CProbabilisticOptimisable {
   mutable double lastJitter;
   mutable bool needInverse;
   // Multi-GPU (FTC): the N x N matrix spread over a pr x pc grid of GPUs, one host thread per rank inside this process
-  // (gpc_grid_create_local; the C++ driver and RCCL-free peer copies live below the C-ABI).  Chosen by GPC_GRID=PRxPC in
+  // (gpc_grid_create_local; the C++ driver and its RCCL exchange over xGMI live below the C-ABI).  Chosen by GPC_GRID=PRxPC in
   // the environment, or by itself when one N x N matrix does not fit the current GPU and the node has more of them.
-  // Likelihood, gradient, Alpha and predictions all run on the grid (the gradient from a replicated factor, gpc_grid_gradient).
+  // Likelihood, gradient, Alpha and predictions all run on the grid (the gradient from a block-cyclic K^-1, gpc_grid_gradient).
   bool useGrid() const;
+ public:
+  // which transport the multi-GPU grid of this model exchanges over (gpc_grid_comm_info out[3]: 1 RCCL, 2 the in-process board
+  // of same-device test ranks; 0 when the model runs on one GPU)
+  int gridTransport() const;
+
+ private:
   void gridUpdateK(const CMatrix* Xstar) const;
   void gridRelease() const;
   mutable std::vector<gpc_grid*> grids;

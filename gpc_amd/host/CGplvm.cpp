@@ -229,6 +229,15 @@ struct DeferScope {
   DeferScope() { (void)gpc_defer(1); }
   ~DeferScope() { (void)gpc_defer(0); }
 };
+// Spans from a deferred call to the flush that delivers its outputs; declared AFTER the outputs' storage.  If the scope is
+// left by an exception before done(), the postponed deliveries are dropped while their destinations still exist (they would
+// otherwise be written -- stack and heap that are gone -- by this thread's next synchronising call).
+struct PendingGuard {
+  bool armed;
+  PendingGuard() : armed(true) {}
+  void done() { armed = false; }
+  ~PendingGuard() { if(armed) (void)gpc_discard_pending(); }
+};
 }  // namespace
 
 void CGplvm::updateK() const
@@ -252,6 +261,7 @@ void CGplvm::updateK() const
   if(!dL) dL = devAlloc((size_t)N * N);
   { Timed t(1, "gram"); gpcCheck(gpc_gram_sym_f64(&ks, dX, N, q, N, dL, N, 0)); }                // _updateK, CGplvm.cpp:418-432
   int info = 0;
+  PendingGuard pending;      // (info and logDetK are written by the flush below)
   // LcholK.chol(), logDet(LcholK), invK.pdinv(LcholK) (CGplvm.cpp:441-444) in one pass: dL <- L, dK <- invK
   // (gpc_defer: the factorisation's info and log-determinant come back in the column dots' synchronisation two launches
   //  further on instead of one of their own -- the host issues the product and the dots while the device still factors)
@@ -264,6 +274,7 @@ void CGplvm::updateK() const
   quad.assign((size_t)d, 0.0);
   { Timed t(4, "coldot"); gpcCheck(gpc_coldot_f64(N, d, dA, N, dM, N, &quad[0], 0)); }
   gpcCheck(gpc_sync_pending(0));     // (nothing left unless the dots had no rows)
+  pending.done();
   if(info != 0) throw ndlexceptions::MatrixNonPosDef();
   KupToDate = true;
 }
@@ -298,6 +309,7 @@ double CGplvm::logLikelihoodGradient(CMatrix& g) const
   { Timed t(5, "covgrad_multi"); gpcCheck(gpc_covgrad_multi_f64(N, d, dK, N, dA, N, dG, N, 0)); }
   std::vector<double> gk(nk > 0 ? nk : 1, 0.0);
   std::vector<double> gx((size_t)N * q);
+  PendingGuard pending;      // (gx is written by the flush below)
   // dL/dX first and its copy to the host postponed (gpc_defer), the parameter sums second: ONE wait for both instead of two
   { Timed t(7, "kern_gradx"); gpcCheck(gpc_kern_gradx_f64(&ks, dX, N, q, N, dG, N, dGX, N, 0)); }      // getGradX + dotColCol loop, 573-604
   {
@@ -307,6 +319,7 @@ double CGplvm::logLikelihoodGradient(CMatrix& g) const
   }
   { Timed t(6, "kern_grad"); gpcCheck(gpc_kern_grad_f64(&ks, dX, N, q, N, dG, N, &gk[0], 0)); }      // getGradTransParams, CGplvm.cpp:589-596
   gpcCheck(gpc_sync_pending(0));     // (gx is there: kern_grad's wait brought it; this only covers a pass that did not wait)
+  pending.done();
   for(unsigned int t = 0; t < pkern->getNumTransforms(); t++) {
     const unsigned int idx = pkern->getTransformIndex(t);
     gk[idx] *= pkern->getTransformGradFact(pkern->getParam(idx), t);

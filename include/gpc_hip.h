@@ -94,6 +94,9 @@ int gpc_stream_sync(void* stream);
  * it reorders the waits of CGplvm::logLikelihood / logLikelihoodGradient (CGplvm.cpp:480-604). */
 int gpc_defer(int on);
 int gpc_sync_pending(void* stream);
+/* Drops the calling thread's postponed deliveries WITHOUT writing any destination or running any callback: for a caller that
+ * unwinds between a deferred call and its flush (the destinations are about to die).  Never fails. */
+int gpc_discard_pending(void);
 int gpc_workspace_release(void);                 /* free the library's grow-only scratch buffers */
 
 /* ---- Gram construction ----------------------------------------------------------------------------------------

@@ -298,6 +298,7 @@ int grid_enable_peers(const int*, int) { return GPC_OK; }
 bool grid_force_collectives() { return false; }
 int grid_unique_id(void*) { return GPC_EUNSUPPORTED; }   // RCCL lives in libgpc_hip.so only
 int grid_make_collective_comm(std::unique_ptr<GridComm>&, int, int, int, int, const void*, GridOps*) { return GPC_EUNSUPPORTED; }
+int grid_make_local_collective(std::vector<std::unique_ptr<GridComm>>&, int, int, const int*, const std::vector<GridOps*>&) { return GPC_EUNSUPPORTED; }
 
 }  // namespace
 

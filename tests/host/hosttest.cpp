@@ -188,7 +188,7 @@ static int testGp(int argc, char** argv)
 }
 
 // the model on a multi-GPU grid (GPC_GRID=PRxPC in the environment): what CGp gives there -- likelihood, Alpha through the
-// predictions, log|K| -- plus the refusal of the gradient.  gp_hosttest gpgrid X y Xs kernspec
+// predictions, log|K|, the gradient --, which transport it exchanges over, a few SCG iterations.  gp_hosttest gpgrid X y Xs kernspec [iters]
 static int testGpGrid(int argc, char** argv)
 {
   if(argc < 6) { std::fprintf(stderr, "usage: gp_hosttest gpgrid X y Xs kernspec [scg iterations]\n"); return 2; }
@@ -209,6 +209,7 @@ static int testGpGrid(int argc, char** argv)
   model.updateM();
   std::printf("ll %.17g\n", model.logLikelihood());
   std::printf("logdet %.17g\n", model.getLogDetK());
+  std::printf("grid_transport %d\n", model.gridTransport());
   CMatrix mu(Xs.getRows(), y.getCols()), var(Xs.getRows(), y.getCols());
   model.posteriorMeanVar(mu, var, Xs);
   printMat("mu", mu);

@@ -530,7 +530,8 @@ PAIR_WALK_TERMS = {
 
 @pytest.mark.parametrize("kname", sorted(PAIR_WALK_TERMS))
 @pytest.mark.parametrize("N,N2,D,shift", [(1500, 1700, 3, 0.0), (130, 20000, 8, 0.0), (5000, 513, 1, 0.0), (2048, 2048, 13, 40.0), (1100, 2300, 16, 0.0),
-                                          (1300, 1900, 20, -7.0), (1024, 2100, 32, 0.0)])
+                                          (1300, 1900, 20, -7.0), (1024, 2100, 32, 0.0),
+                                          (1200, 1500, 6, 3000.0)])      # |x|^2 ~ 5e7 d2: uncentred distances would be good to 1e-8 only
 def test_pair_walk_against_the_scalar_kernels(api, monkeypatch, kname, N, N2, D, shift):
     """The MFMA walk of pair_walk.hip (dL/dX of a cross and of a symmetric weight matrix, the cross-Gram parameter sums; round 4)
     against gplvm.hip's scalar kernels on the same inputs -- themselves held to the defining sums and the reference's fixtures by

@@ -332,6 +332,17 @@ mu, var = g.posterior()
 assert gc.rel(var, exp["var"]) < 1e-8
 path = _lib.load().gpc_grid_rccl_path().decode()
 assert "rccl" in path, path
+# the single-process form on "distinct devices" (gpc_grid_create_local with a device list: the path the C++ CGp / `gp learn`
+# takes on a multi-GPU node): communicators made by ncclCommInitRank inside one group call, adopted by the rank's thread
+gl = grid.create_local(1, 1, 128, devices=[0])[0]
+ci = gl.comm_info()
+assert ci["kind"] == "rccl" and ci["world"] == 1 and ci["row"] == 1 and ci["col"] == 1, ci
+gl.set_problem(gc.TERMS, X, Y, Xs)
+ld2, _, info2 = gl.update_k()
+assert info2 == 0 and ld2 == logdet
+assert gc.rel(gl.gradient(4), g.gradient(4)) < 1e-12
+assert gc.rel(gl.gradient(4), gc.expected_gradient(gc.TERMS, X, Y)) < 1e-8
+gl.destroy()
 print("RCCL-OK", path, g.stats()["collectives"])
 """ % (HERE, ROOT)
     r = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)

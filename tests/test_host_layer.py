@@ -105,8 +105,9 @@ def test_cgp_on_a_multi_gpu_grid(tmp_path, shape):
 @pytest.mark.gpu
 def test_cgp_grid_on_distinct_devices(tmp_path):
     """The path `gp learn` takes to several GPUs: the C++ CGp's in-process grid (gpc_grid_create_local: one host thread per
-    rank, LocalComm peer-to-peer copies, cross-device event waits) with every rank on a device OF ITS OWN -- no
-    GPC_GRID_DEVICES=same.  2 x 1 and 1 x 2 on two GPUs; 2 x 2 and 4 x 1 from four; 8 x 1, 4 x 2 and 2 x 4 on eight.  Against the
+    rank, RCCL communicators made inside one group call and driven by the rank threads) with every rank on a device OF ITS
+    OWN -- no GPC_GRID_DEVICES=same; the transport must report itself as RCCL (the in-process board of peer copies is what
+    same-device test ranks use, and GPC_GRID_LOCAL_TRANSPORT=board selects it here for comparison).  2 x 1 and 1 x 2 on two GPUs; 2 x 2 and 4 x 1 from four; 8 x 1, 4 x 2 and 2 x 4 on eight.  Against the
     single-GPU model and the compiled reference's golden of cfg 4's kernel.  Needs >= 2 GPUs; skips (with the reason) otherwise."""
     import torch
     n = torch.cuda.device_count()
@@ -125,6 +126,10 @@ def test_cgp_grid_on_distinct_devices(tmp_path):
         env = dict(os.environ, GPC_GRID=shape, GPC_GRID_NB="128")
         env.pop("GPC_GRID_DEVICES", None)
         v = _parse(_run([os.path.join(HOST, "gp_hosttest"), "gpgrid"] + args, env=env))
+        assert int(v["grid_transport"][0]) == 1, "ranks on distinct devices must exchange over RCCL"
+        if shape == "2x1":      # the board's peer copies between the same two devices give the same numbers
+            vb = _parse(_run([os.path.join(HOST, "gp_hosttest"), "gpgrid"] + args, env=dict(env, GPC_GRID_LOCAL_TRANSPORT="board")))
+            assert int(vb["grid_transport"][0]) == 2 and rel(vb["ll"], v["ll"]) < 1e-12 and rel(vb["grads"], v["grads"]) < 1e-10
         assert rel(v["ll"], g["ll"]) < 1e-8 and rel(v["logdet"], g["logdet"]) < 1e-8, shape
         assert rel(v["ll"], one["ll"]) < 1e-10 and rel(v["logdet"], one["logdet"]) < 1e-10, shape
         assert rel(v["mu"], one["mu"]) < 1e-8 and rel(v["var"], one["var"]) < 1e-8, shape
@@ -145,6 +150,7 @@ def test_gp_learn_on_a_grid_follows_the_single_gpu_run(tmp_path):
     one = _parse(_run([os.path.join(HOST, "gp_hosttest"), "gpgrid"] + args, env=dict(os.environ, GPC_GRID="1x1")))
     env = dict(os.environ, GPC_GRID="2x2", GPC_GRID_DEVICES="same", GPC_GRID_NB="128")
     v = _parse(_run([os.path.join(HOST, "gp_hosttest"), "gpgrid"] + args, env=env))
+    assert int(v["grid_transport"][0]) == 2 and int(one["grid_transport"][0]) == 0      # same-device ranks: the in-process board
     assert rel(v["grads"], one["grads"]) < 1e-8
     assert rel(v["opt_params_after"], one["opt_params_after"]) < 1e-5 and rel(v["ll_after"], one["ll_after"]) < 1e-7
     assert v["ll_after"][0] > v["ll"][0] + 10.0
