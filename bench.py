@@ -237,7 +237,7 @@ def cpu_reference_binary(cfg, sample_n):
         return {"value": None, "error": str(e)[:200]}
 
 
-def pmc_traffic(workload, single_gpu_path):
+def pmc_traffic(workload, single_gpu_path, kernel_pattern="gemm_nt_ring_kernel<1>"):
     """HBM bytes per trailing-update launch from the committed PMC passes of this command (tools/pmc_bench_traffic.sh ->
     profiles/rNN_pmc_bench_traffic.json).  REPLAYED, not collected in this run: counters need a rocprofv3 wrapper."""
     import glob
@@ -249,6 +249,8 @@ def pmc_traffic(workload, single_gpu_path):
     try:
         with open(files[-1]) as f:
             j = json.load(f)
+        if j.get("kernel_pattern", "gemm_nt_fast_kernel<4, 1,") != kernel_pattern:      # counters of another kernel's launches
+            return None, None
         return float(j["hbm_bytes_per_launch"]), os.path.relpath(files[-1], ROOT)
     except (OSError, ValueError, KeyError):
         return None, None
@@ -528,7 +530,12 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
-    syrk_n, syrk_ms, syrk_flops = api.profile_read(0, reset=True)
+    # trailing updates, two populations (potrf.hip): the ones that take the ring kernel (gemm_nt_ring_kernel<1>: 256 x 128 tiles,
+    # one persistent workgroup per CU -- every update with at least GPC_GEMM_RING_MINM rows, i.e. nearly all the flops) and the
+    # smaller ones on gemm_nt_fast_kernel<4, 1, false, true>.  The roofline's dominant kernel is the first whenever it ran.
+    rest_n, rest_ms, rest_flops = api.profile_read(0, reset=True)
+    ring_n, ring_ms, ring_flops = api.profile_read(2, reset=True)
+    syrk_n, syrk_ms, syrk_flops = rest_n + ring_n, rest_ms + ring_ms, rest_flops + ring_flops
     schedule_mismatch = None
     # (the default configuration: one trailing update per panel; look-ahead / GPC_GEMM_PF2=0 split it in U1 + U2)
     gemm_default = os.environ.get("GPC_GEMM_PF2", "2") != "0" and os.environ.get("GPC_PANEL_FLOW", "1") != "0"
@@ -543,19 +550,25 @@ def main():
         cnt = ctypes.c_int64(0)
         widths = (ctypes.c_int64 * 4096)()
         api.check(api.lib().gpc_potrf_panel_schedule(N, widths, 4096, ctypes.byref(cnt)))
-        syrk_bytes, k0, launches_expected = 0.0, 0, 0
+        syrk_bytes, k0, launches_expected, sched = 0.0, 0, 0, []
         for i in range(min(int(cnt.value), 4096)):
             nbp = int(widths[i])
             m = N - k0 - nbp
             if m > 0:
                 syrk_bytes += 8.0 * m * nbp + 8.0 * m * (m + 1)
+                sched.append(8.0 * m * nbp + 8.0 * m * (m + 1))
                 launches_expected += 1
             k0 += nbp
+        # (the ring kernel takes the LARGEST updates: the first ring_n / steps of the schedule)
+        ring_per_step = int(ring_n // max(1, args.steps))
+        ring_bytes = sum(sched[:ring_per_step]) * args.steps
         # (a dataflow time-out's retry on the launch chain, a jitter retry, or a switch that changes the schedule: reported in
         #  the line -- roofline.schedule_mismatch -- instead of losing the measurement)
         if launches_expected * args.steps != syrk_n:
             schedule_mismatch = {"profiled_launches": int(syrk_n), "schedule_launches": launches_expected * args.steps}
         syrk_bytes *= args.steps
+    if g is not None:
+        ring_bytes = 0.0
 
     phases = None
     if rank == 0 and g is None and not replicas and os.environ.get("GPC_BENCH_PHASES", "1") == "1":
@@ -621,22 +634,35 @@ def main():
         probe, ticks, tick_ghz = ctypes.c_double(0.0), ctypes.c_double(0.0), ctypes.c_double(0.0)
         api.check(api.lib().gpc_probe_mfma_f64(ctypes.byref(probe), ctypes.byref(ticks), ctypes.byref(tick_ghz), api.stream()))
         cus = torch.cuda.get_device_properties(device).multi_processor_count
-        achieved = syrk_flops / (syrk_ms * 1e-3) * 1e-12 if syrk_ms > 0 else 0.0
+        all_tflops = syrk_flops / (syrk_ms * 1e-3) * 1e-12 if syrk_ms > 0 else 0.0
+        on_ring = ring_n > 0 and g is None
+        # the dominant kernel: the ring kernel's launches when there are any (they carry > 90 % of the factor's flops at cfg 3)
+        dom_n, dom_ms, dom_flops, dom_bytes = (ring_n, ring_ms, ring_flops, ring_bytes) if on_ring else (syrk_n, syrk_ms, syrk_flops, syrk_bytes)
+        achieved = dom_flops / (dom_ms * 1e-3) * 1e-12 if dom_ms > 0 else 0.0
         potrf_flops = N ** 3 / 3.0
-        traffic, traffic_src = pmc_traffic(args.workload if not args.n else "custom", g is None)
+        traffic, traffic_src = pmc_traffic(args.workload if not args.n else "custom", g is None,
+                                           "gemm_nt_ring_kernel<1>" if on_ring else "gemm_nt_fast_kernel<4, 1,")
         jobs = world if replicas else 1
         roof = {"bound": "mfma",
-                "kernel": "gemm_nt_fast_kernel<4, 1, false, true> (trailing updates U1+U2 of %s)"
-                          % ("the grid's rank 0, 2-D staircase" if g is not None else "gpc_potrf_f64"),
+                "kernel": ("gemm_nt_ring_kernel<1> (the trailing updates of gpc_potrf_f64 with >= GPC_GEMM_RING_MINM rows: %.1f %% of all "
+                           "trailing-update flops)" % (100.0 * ring_flops / max(syrk_flops, 1.0))) if on_ring else
+                          ("gemm_nt_fast_kernel<4, 1, false, true> (trailing updates U1+U2 of %s)"
+                           % ("the grid's rank 0, 2-D staircase" if g is not None else "gpc_potrf_f64")),
                 "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": traffic,
                 "traffic_unit": "HBM bytes per launch = (2 x FETCH_SIZE + WRITE_SIZE) x 1024",
                 "traffic_source": None if traffic is None else
                 "REPLAYED from %s (separate rocprofv3 --pmc passes of this command; not collected in this run)" % traffic_src,
-                "algorithmic_bytes_per_launch": syrk_bytes / max(1, syrk_n),
-                "launches_per_step": syrk_n / max(1, args.steps),
-                "avg_launch_ms": syrk_ms / max(1, syrk_n),
-                "algorithmic_flops_per_launch": syrk_flops / max(1, syrk_n),
+                "algorithmic_bytes_per_launch": dom_bytes / max(1, dom_n),
+                "launches_per_step": dom_n / max(1, args.steps),
+                "avg_launch_ms": dom_ms / max(1, dom_n),
+                "algorithmic_flops_per_launch": dom_flops / max(1, dom_n),
+                # every trailing update of the factor, both kernels together (what rounds 1-4 reported as `achieved`)
+                "all_trailing_updates": {"launches_per_step": syrk_n / max(1, args.steps), "tflops": all_tflops,
+                                         "frac": all_tflops / FP64_MFMA_PEAK_TFLOPS, "ms_per_step": syrk_ms / max(1, args.steps)},
+                "smaller_updates": None if not on_ring else
+                {"kernel": "gemm_nt_fast_kernel<4, 1, false, true>", "launches_per_step": rest_n / max(1, args.steps),
+                 "avg_launch_ms": rest_ms / max(1, rest_n), "tflops": rest_flops / max(rest_ms * 1e-3, 1e-30) * 1e-12},
                 "schedule_mismatch": schedule_mismatch,
                 "mfma_f64_probe_tflops": probe.value,
                 # a v_mfma_f64_16x16x4 occupies a SIMD's matrix pipe for 64 shader cycles (PMC: SQ_VALU_MFMA_BUSY_CYCLES), so

@@ -23,6 +23,7 @@
 #include <math.h>
 #include <stdlib.h>
 #include <atomic>
+#include <type_traits>
 
 namespace gpc {
 
@@ -68,6 +69,7 @@ struct GemmArgs {
   double* part;          // workgroup of its own writing alpha * (its partial product) to part + piece * part_stride (M x N,
   int64_t part_stride;   // leading dimension M); split_combine_kernel adds the pieces in order.  For products with few tiles
                          // and a long k (the GP-LVM's K^-1 = V V' at N = 1000: 36 tiles, one round of 64 stages each)
+  int ring_stagger;      // ring kernel: start the workgroups apart in time (GPC_GEMM_RING_STAGGER, default 1)
   int atomic_c;          // beta == 1: accumulate into C with no-return fp64 atomics instead of load + add + store
   int tri;               // 0 full, 1 lower (i >= j, C square), 2 upper (i <= j, C square),
                          // 3 lower trapezoid (i >= j, M >= N, full enumeration with skipped tiles)
@@ -402,10 +404,16 @@ __global__ void __launch_bounds__(256, 2) gemm_f64_kernel(const GemmArgs g)
 //     loads two consecutive k of two adjacent rows (8 threads = one 128-byte run of a row) -- into the [m][k] image
 //     (row stride 18 doubles, conflict-free for the fragment reads like the [k][m] one); everything else is the NT kernel.
 //     k-start / k-end / staircase / split-k stay NT-only.
-template <int NWN, int ROLE, bool SPLITK = false, bool PF2 = false, bool A_KC = false, bool B_KC = false>
+//   * GLDS (round 5, measurement variant, GPC_GEMM_GLDS=1): the operands of stage kt + 1 go from global memory STRAIGHT into the
+//     other LDS buffer (global_load_lds_dwordx4: a wave's 64 x 16 bytes are one 128-double k-row of the [k][m] image, so the
+//     lane-linear destination is exactly the image), issued behind the first MFMA group of stage kt and awaited at the stage's
+//     barrier: no staging registers, no ds_write, but only ONE stage of latency cover (two LDS buffers per workgroup are what two
+//     workgroups per CU leave room for), against the register form's two.
+template <int NWN, int ROLE, bool SPLITK = false, bool PF2 = false, bool A_KC = false, bool B_KC = false, bool GLDS = false>
 __global__ void __launch_bounds__(128 * NWN, NWN) gemm_nt_fast_kernel(const GemmArgs g)
 {
   static_assert(!(A_KC || B_KC) || (NWN == 4 && !SPLITK), "k-contiguous operands: eight-wave, unsplit instances only");
+  static_assert(!GLDS || (NWN == 4 && !SPLITK && !PF2 && !A_KC && !B_KC), "direct-to-LDS staging: the plain NT eight-wave instance");
   constexpr int NT = 256 / (64 * NWN) * 2;  // n-subtiles per wave: NWN=2 -> 4, NWN=4 -> 2
   constexpr int NL = 8 / (2 * NWN);         // double2 loads per operand per thread per stage: 2 or 1... see below
   static_assert(NWN == 2 || NWN == 4, "wave grid");
@@ -506,6 +514,20 @@ __global__ void __launch_bounds__(128 * NWN, NWN) gemm_nt_fast_kernel(const Gemm
   // alternate (the loop runs in pairs of stages so that each set is named statically)
   double2_t ra2_[PASSES], rb2_[PASSES];
   constexpr bool kPF2 = PF2;
+  typedef __attribute__((address_space(3))) void lds_void_t;
+  typedef const __attribute__((address_space(1))) void glb_void_t;
+  // direct-to-LDS: this wave's k-rows (t >> 6) + KROWS i of one operand of the stage at `buf` (the hardware adds 16 bytes per lane)
+  auto glds_stage = [&](double* buf) {
+#pragma unroll
+    for(int i = 0; i < PASSES; i++) {
+      double* rowa = buf + ((t >> 6) + KROWS * i) * STRIDE_MC;
+      __builtin_amdgcn_global_load_lds((glb_void_t*)(pa + i * stepa), (lds_void_t*)rowa, 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((glb_void_t*)(pb + i * stepb), (lds_void_t*)(rowa + OP_ELEMS), 16, 0, 0);
+    }
+  };
+  if(GLDS) {
+    if(KT > 0) glds_stage(lds);
+  } else
   if(KT > 0) {
 #pragma unroll
     for(int i = 0; i < PASSES; i++) {
@@ -560,14 +582,18 @@ __global__ void __launch_bounds__(128 * NWN, NWN) gemm_nt_fast_kernel(const Gemm
         // issue the loads behind the first MFMA group
         pa += stagea;
         pb += stageb;
+        if(GLDS) {
+          glds_stage(nxt);
+        } else {
 #pragma unroll
-        for(int i = 0; i < PASSES; i++) {
-          la[i] = *reinterpret_cast<const double2_t*>(pa + i * stepa);
-          lb[i] = *reinterpret_cast<const double2_t*>(pb + i * stepb);
+          for(int i = 0; i < PASSES; i++) {
+            la[i] = *reinterpret_cast<const double2_t*>(pa + i * stepa);
+            lb[i] = *reinterpret_cast<const double2_t*>(pb + i * stepb);
+          }
         }
       }
     }
-    if(more) {
+    if(more && !GLDS) {
 #pragma unroll
       for(int i = 0; i < PASSES; i++) {
         *reinterpret_cast<double2_t*>(nxt + lwa + i * LPA) = sa[i];
@@ -577,7 +603,7 @@ __global__ void __launch_bounds__(128 * NWN, NWN) gemm_nt_fast_kernel(const Gemm
     __syncthreads();
   };
   if(!kPF2) {
-    for(int64_t kt = 0; kt < KT; kt++) stage(kt, ra_, rb_, ra_, rb_, 1);
+    for(int64_t kt = 0; kt < KT; kt++) stage(kt, ra_, rb_, ra_, rb_, 1);   // (GLDS: the register sets are unused)
   } else {
     // even stages: set 1 (ra_) holds stage kt + 1, stage kt + 2 is loaded into set 2; odd stages the other way round
     int64_t kt = 0;
@@ -622,6 +648,301 @@ __global__ void __launch_bounds__(128 * NWN, NWN) gemm_nt_fast_kernel(const Gemm
   }
 }
 
+
+// ---- ring form (round 5): one workgroup of SIXTEEN waves per CU, a 256 x 128 tile, operands straight from global memory into
+// a ring of three LDS stages (global_load_lds_dwordx4: a wave's 64 x 16 bytes are 128 consecutive rows of one k-row of the
+// [k][m] image, so the lane-linear destination IS the image -- no staging registers, no ds_write), two stages in flight:
+//   * per stage a wave issues three such loads (k-row `wave` of A's two row halves and of B): 3 x 16 = the stage's 48 KB;
+//   * ONE barrier per stage, placed after the stage's second k-step: by then a wave has issued ALL fragment reads of the stage
+//     (the last two k-steps' fragments wait in registers), so the barrier frees the stage's buffer for the loads of stage s + 3
+//     at once, and the MFMAs that follow it need nothing from LDS -- the reads of stage s + 1 run in their shadow;
+//   * the loads of stage s + 3, issued behind barrier s, are awaited (s_waitcnt vmcnt(3): the three newer ones keep flying)
+//     before barrier s + 2: two full stages (~7 us) of cover from three buffers.
+// 256 x 128 per workgroup moves a quarter less operand data per flop than two 128 x 128 tiles.  NT form, tri 0 / 1, K a
+// multiple of 16 and at least 96, M a multiple of 256, N of 128, even leading dimensions.
+constexpr int R_BM = 256, R_BN = 128, R_SA = 272, R_SB = 144;
+constexpr int R_STAGE = BK * (R_SA + R_SB);          // doubles per stage: 6656 = 53 248 B
+constexpr int R_LDS_BYTES = 3 * R_STAGE * 8;         // 159 744 B of the CU's 163 840
+
+// logical tile id -> tile coordinates (in 256 x 128 tiles); false: no such tile
+__device__ __forceinline__ bool ring_tile(const GemmArgs& g, const unsigned L, const unsigned total, int& ti, int& tj)
+{
+  if(L >= total) return false;
+  const unsigned sm = (unsigned)((g.M + 1023) / 1024);
+  if(g.tri == 1) {
+    // ONLY the tiles that reach the lower triangle, super-tile (1024 x 1024) by super-tile: super-row R holds R full super-tiles
+    // (32 tiles each) and a diagonal one (the 20 tiles with tj <= 2 ti + 1); before row R: 16 R^2 + 4 R.  The last super-row
+    // has h <= 4 tile rows.
+    const unsigned tm = (unsigned)((g.M + R_BM - 1) / R_BM), h = tm - 4u * (sm - 1u);
+    const unsigned cum_last = 16u * (sm - 1u) * (sm - 1u) + 4u * (sm - 1u);
+    unsigned R, rem, rows;
+    if(L >= cum_last) {
+      R = sm - 1u;
+      rem = L - cum_last;
+      rows = h;
+    } else {
+      int r = (int)((sqrt(16.0 + 64.0 * (double)L) - 4.0) * (1.0 / 32.0));
+      while(16u * (unsigned)(r + 1) * (unsigned)(r + 1) + 4u * (unsigned)(r + 1) <= L) r++;
+      while(16u * (unsigned)r * (unsigned)r + 4u * (unsigned)r > L) r--;
+      R = (unsigned)r;
+      rem = L - (16u * R * R + 4u * R);
+      rows = 4u;
+    }
+    if(rem < 8u * rows * R) {
+      const unsigned sj = rem / (8u * rows), w = rem % (8u * rows);
+      ti = (int)(R * 4u + w % rows);
+      tj = (int)(sj * 8u + w / rows);
+    } else {
+      const unsigned q = rem - 8u * rows * R;
+      const unsigned a = q < 2u ? 0u : (q < 6u ? 1u : (q < 12u ? 2u : 3u));
+      ti = (int)(R * 4u + a);
+      tj = (int)(R * 8u + (q - a * (a + 1u)));
+    }
+  } else {
+    const unsigned sidx = L >> 5, w = L & 31u;
+    ti = (int)((sidx % sm) * 4u + (w & 3u));
+    tj = (int)((sidx / sm) * 8u + (w >> 2));
+  }
+  return ti * R_BM < (int)g.M && tj * R_BN < (int)g.N;
+}
+
+// Persistent: one workgroup per CU walks its share of the tiles; the ring of stages runs on ACROSS tile boundaries -- while a
+// tile's last three stages are multiplied the first three of the next tile are already on their way, and the epilogue
+// (64 no-return atomics per thread) sits between two matrix blocks whose operands are in LDS already.  Hardware block b runs
+// on XCD b % 8: XCD x owns the contiguous range [x C, (x + 1) C) of logical tile ids and its 32 workgroups take 32 consecutive
+// ids per round -- one 1024 x 1024 super-tile of C whose operand slabs they share in the XCD's L2.
+template <int ROLE>
+__global__ void __launch_bounds__(1024, 1) gemm_nt_ring_kernel(const GemmArgs g, const unsigned total, const unsigned per_xcd)
+{
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const int t = threadIdx.x, lane = t & 63, wm = (t >> 6) & 3, wn = t >> 8;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);      // uniform: the loads' LDS destinations stay on the scalar unit
+  const int KT = (int)(g.K / BK);
+  const unsigned xcd = blockIdx.x & 7u, wg = blockIdx.x >> 3, nwg = gridDim.x >> 3;
+  const unsigned Lend = (xcd + 1u) * per_xcd < total ? (xcd + 1u) * per_xcd : total;
+  // the next valid tile at or after logical id L (stepping by the XCD's workgroup count)
+  auto find = [&](unsigned L, int& ti, int& tj) -> unsigned {
+    while(L < Lend && !ring_tile(g, L, total, ti, tj)) L += nwg;
+    return L < Lend ? L : 0xffffffffu;
+  };
+  int cti = 0, ctj = 0;
+  unsigned cur = find(xcd * per_xcd + wg, cti, ctj);
+  if(cur == 0xffffffffu) return;
+  const int64_t stagea = (int64_t)BK * g.lda * 8, stageb = (int64_t)BK * g.ldb * 8;
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) double*)lds;      // LDS byte address of the ring
+  // global_load_lds_dwordx4 (saddr form): LDS[M0 + 16 lane] <- 16 bytes at sbase + voff.  hipcc neither counts it in vmcnt nor
+  // knows that it writes LDS: the waits below are this kernel's own
+#define R_GLDS(voff, sbase, ldsaddr)                                                                                          \
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(ldsaddr) : "memory")
+  // ... and the second half of A's k-row through the instruction's offset, which moves the source AND the destination (same M0)
+#define R_GLDS2(voff, sbase, ldsaddr)                                                                                         \
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1\n\tglobal_load_lds_dwordx4 %0, %1 offset:1024" ::"v"(voff), "s"(sbase), "s"(ldsaddr) : "memory")
+  const unsigned wA = (unsigned)(wave * R_SA * 8), wB = (unsigned)((BK * R_SA + wave * R_SB) * 8);
+  // load cursor: three stages ahead of the arithmetic; a uniform base per operand, advanced on the scalar unit, plus a constant
+  // 32-bit offset per lane (rows clamped into the matrix)
+  // (M is a multiple of 256 and N of 128 on this path: no row needs clamping, every lane's offset is 16 bytes per lane in both operands)
+  const char *sa = nullptr, *sb = nullptr;
+  const unsigned v16 = 16u * (threadIdx.x & 63);
+  const int Mi = (int)g.M, Ni = (int)g.N;      // (the launcher admits M, N < 2^31)
+  auto aim = [&](const int ti, const int tj) {
+    sa = reinterpret_cast<const char*>(g.A + (int64_t)ti * R_BM + (int64_t)wave * g.lda);
+    sb = reinterpret_cast<const char*>(g.B + (int64_t)tj * R_BN + (int64_t)wave * g.ldb);
+  };
+  unsigned lslot = lds0;      // ring slot the load cursor writes next
+  auto issue = [&]() {
+    R_GLDS2(v16, sa, lslot + wA);
+    R_GLDS(v16, sb, lslot + wB);
+    sa += stagea;
+    sb += stageb;
+    lslot = lslot == lds0 + 2 * R_STAGE * 8 ? lds0 : lslot + R_STAGE * 8;
+  };
+  double4_t acc[4][2];
+  // fragment reads: ds_read_b64 with the whole in-slot offset as the instruction's immediate (hipcc pairs them into ds_read2_b64,
+  // whose 8-bit offsets cost two address additions per k-step on the vector unit the matrix instructions need)
+  const unsigned fa = (unsigned)((wm * 64 + (lane & 15) + (lane >> 4) * R_SA) * 8);
+  const unsigned fb = (unsigned)((BK * R_SA + wn * 32 + (lane & 15) + (lane >> 4) * R_SB) * 8);
+  struct Frag { double a[4], b[2]; };
+#define R_DSR(dst, addr, off) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
+  auto read = [&](Frag& f, const unsigned pa, const unsigned pb, auto kk_t) {
+    constexpr int kk = decltype(kk_t)::value;
+    R_DSR(f.a[0], pa, kk * 4 * R_SA * 8);
+    R_DSR(f.a[1], pa, kk * 4 * R_SA * 8 + 128);
+    R_DSR(f.a[2], pa, kk * 4 * R_SA * 8 + 256);
+    R_DSR(f.a[3], pa, kk * 4 * R_SA * 8 + 384);
+    R_DSR(f.b[0], pb, kk * 4 * R_SB * 8);
+    R_DSR(f.b[1], pb, kk * 4 * R_SB * 8 + 128);
+  };
+  // the fragment is an in / out operand of its own wait: the matrix instructions that use it cannot be moved above it
+#define R_WAIT(f, cnt) asm volatile("s_waitcnt lgkmcnt(" #cnt ")" : "+v"(f.a[0]), "+v"(f.a[1]), "+v"(f.a[2]), "+v"(f.a[3]), "+v"(f.b[0]), "+v"(f.b[1]))
+  auto mma1 = [&](const Frag& f, const int i) {
+    const int tn = i >> 2, tm = i & 3;
+    acc[tm][tn] = __builtin_amdgcn_mfma_f64_16x16x4f64(f.b[tn], f.a[tm], acc[tm][tn], 0, 0, 0);
+  };
+  auto mma = [&](const Frag& f) {
+#pragma unroll
+    for(int i = 0; i < 8; i++) mma1(f, i);
+  };
+  using K0 = std::integral_constant<int, 0>;
+  using K1 = std::integral_constant<int, 1>;
+  using K2 = std::integral_constant<int, 2>;
+  using K3 = std::integral_constant<int, 3>;
+  // The workgroups start a fraction of a microsecond apart, spread over ~50 us.  Every tile takes the same time, so workgroups
+  // that start together reach their epilogues together, for ever: 256 CUs x 512 KB of read-modify-write at one instant take
+  // HBM ~25 us, and the third stage of the next tile -- whose wait counts every operation in flight -- stands still for most of
+  // that (measured: 16 us per tile).  Apart by 0.2 us each, an epilogue has the memory system nearly to itself.
+  if(g.ring_stagger) {
+    const unsigned slotn = (blockIdx.x * 37u) & 255u;
+    for(unsigned q = 0; q < slotn; q++) __builtin_amdgcn_s_sleep(7);
+  }
+  // prologue: the first tile's first three stages on their way and awaited
+  aim(cti, ctj);
+  issue();
+  issue();
+  issue();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  Frag f0, f1, f2, f3;
+  unsigned slot = lds0;       // ring slot the arithmetic reads
+  read(f0, slot + fa, slot + fb, K0());
+  read(f1, slot + fa, slot + fb, K1());
+  const double alpha = g.alpha, beta = g.beta;
+  // Invariant at the start of a tile: its first THREE stages are in LDS, waited for by every wave before the epilogue of the tile
+  // before it (or in the prologue), and the first two k-steps' fragments are on their way to f0 / f1.  The waits of a tile's
+  // first two stages therefore name no loads -- they could not: the previous tile's 64 atomics per thread are still on their
+  // way, they complete out of order with the loads, and a count cannot tell the two apart.  From the third stage on the count
+  // is back to "all but the newest three".  ONE loop body serves every stage (a boundary stage differs in scalar values only).
+  for(;;) {
+#pragma unroll
+    for(int i = 0; i < 4; i++)
+#pragma unroll
+      for(int j = 0; j < 2; j++) acc[i][j] = (double4_t){0.0, 0.0, 0.0, 0.0};
+    int nti = 0, ntj = 0;
+    const unsigned nxt = find(cur + nwg, nti, ntj);
+    const bool has_next = nxt != 0xffffffffu;
+#pragma unroll 1
+    for(int s = 0; s < KT; s++) {
+      if(s + 3 == KT && has_next) aim(nti, ntj);      // the load cursor moves on to the next tile's first three stages
+      // (at the end of the last tile the cursor stays on the last stage: it is fetched again into a free slot, so that the count
+      //  of loads in flight stays what the waits assume -- and nothing beyond the operands is touched)
+      const bool advance = has_next || s + 4 < KT;
+      const unsigned nslot = slot == lds0 + 2 * R_STAGE * 8 ? lds0 : slot + R_STAGE * 8;
+      const unsigned pa = slot + fa, pb = slot + fb, na = nslot + fa, nbb = nslot + fb;
+      R_WAIT(f0, 6);      // (f0 and f1 were requested in this order; f1's six reads may still be out)
+      mma(f0);
+      read(f2, pa, pb, K2());
+      R_WAIT(f1, 6);
+      mma(f1);
+      read(f3, pa, pb, K3());
+      // the next stage has landed (the three loads of the one after it may still fly) and every fragment of this one is in registers
+      if(s >= 2) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      R_WAIT(f2, 0);
+      R_WAIT(f3, 0);
+      __builtin_amdgcn_s_barrier();
+      // behind the barrier every wave of the CU stands at the same instruction: the loads' issue and the first fragment reads
+      // go BETWEEN the matrix instructions, whose operands are in registers already
+      mma1(f2, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      R_GLDS2(v16, sa, slot + wA);
+      __builtin_amdgcn_sched_barrier(0);
+      mma1(f2, 1);
+      mma1(f2, 2);
+      __builtin_amdgcn_sched_barrier(0);
+      R_GLDS(v16, sb, slot + wB);
+      __builtin_amdgcn_sched_barrier(0);
+      mma1(f2, 3);
+      sa += advance ? stagea : 0;
+      sb += advance ? stageb : 0;
+      __builtin_amdgcn_sched_barrier(0);
+      read(f0, na, nbb, K0());
+      __builtin_amdgcn_sched_barrier(0);
+      mma1(f2, 4);
+      mma1(f2, 5);
+      mma1(f2, 6);
+      mma1(f2, 7);
+      __builtin_amdgcn_sched_barrier(0);
+      read(f1, na, nbb, K1());
+      __builtin_amdgcn_sched_barrier(0);
+      mma(f3);
+      slot = nslot;
+    }
+    // the next tile's three stages (or the repeated fetches past the end) have landed; f0 / f1 hold its first fragments
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    R_WAIT(f0, 0);
+    R_WAIT(f1, 0);
+    // epilogue of tile (cti, ctj): lane l, register r of acc[tm][tn] is C(m0 + wm 64 + tm 16 + (l & 15), n0 + wn 32 + tn 16 + (l >> 4) + 4 r)
+    {
+      const int m0 = cti * R_BM, n0 = ctj * R_BN;
+      const bool full_mn = (m0 + R_BM <= Mi) && (n0 + R_BN <= Ni);
+      const bool diag_tile = g.tri == 1 && (m0 < n0 + R_BN);
+      const int tl = threadIdx.x;
+      const int mb = m0 + ((tl >> 6) & 3) * 64 + (tl & 15), nbs = n0 + (tl >> 8) * 32 + ((tl >> 4) & 3);
+      double* p0 = g.C + mb + (int64_t)nbs * g.ldc;
+#pragma unroll
+      for(int tn = 0; tn < 2; tn++)
+#pragma unroll
+        for(int r = 0; r < 4; r++) {
+#pragma unroll
+          for(int tm = 0; tm < 4; tm++) {
+            const int m = mb + tm * 16, n = nbs + tn * 16 + 4 * r;
+            bool ok = full_mn || (m < Mi && n < Ni);
+            if(diag_tile) ok = ok && (m >= n);
+            if(ok) {
+              double* p = p0 + tm * 16 + (int64_t)(tn * 16 + 4 * r) * g.ldc;
+              double v = alpha * acc[tm][tn][r];
+              if(g.atomic_c) {
+                (void)unsafeAtomicAdd(p, v);
+              } else {
+                if(beta != 0.0) v += beta * (*p);
+                *p = v;
+              }
+            }
+          }
+          __builtin_amdgcn_sched_barrier(0);      // (four at a time: all 32 products formed first would not fit the registers)
+        }
+    }
+    if(!has_next) break;
+    cur = nxt;
+    cti = nti;
+    ctj = ntj;
+  }
+#undef R_GLDS
+#undef R_GLDS2
+#undef R_DSR
+#undef R_WAIT
+}
+
+template <int ROLE>
+int launch_ring(const GemmArgs& g, hipStream_t s)
+{
+  static std::atomic<uint64_t> attr_set{0};
+  static std::atomic<int> cus{0};
+  auto kern = gemm_nt_ring_kernel<ROLE>;
+  int dev = 0;
+  GPC_HIP_CHECK(hipGetDevice(&dev));
+  if(!(attr_set.load() >> (dev & 63) & 1)) {
+    GPC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, R_LDS_BYTES));
+    attr_set.fetch_or(1ull << (dev & 63));
+  }
+  if(cus.load() == 0) {
+    int n = 0;
+    GPC_HIP_CHECK(hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev));
+    cus.store(n >= 8 ? (n / 8) * 8 : 8);
+  }
+  const uint64_t sm = (uint64_t)((g.M + 1023) / 1024), sn = (uint64_t)((g.N + 1023) / 1024);
+  uint64_t total = sm * sn * 32;
+  if(g.tri == 1) {
+    const uint64_t tm = (uint64_t)((g.M + R_BM - 1) / R_BM), h = tm - 4 * (sm - 1);
+    total = 16 * (sm - 1) * (sm - 1) + 4 * (sm - 1) + 8 * h * (sm - 1) + h * (h + 1);
+  }
+  // per XCD a whole number of rounds of its workgroups, so that a round's 32 ids are one super-tile's wherever possible
+  const uint64_t nwg = (uint64_t)cus.load() / 8;
+  uint64_t per_xcd = (total + 7) / 8;
+  per_xcd = ((per_xcd + nwg - 1) / nwg) * nwg;
+  hipLaunchKernelGGL(kern, dim3((unsigned)cus.load()), dim3(1024), R_LDS_BYTES, s, g, (unsigned)total, (unsigned)per_xcd);
+  GPC_HIP_CHECK(hipGetLastError());
+  return GPC_OK;
+}
 
 // C(m, n) = beta C(m, n) + sum over the pieces, in piece order (deterministic), on the part of C the product writes
 __global__ void __launch_bounds__(256) split_combine_kernel(const GemmArgs g)
@@ -707,9 +1028,31 @@ bool gemm_two_ahead()
 
 namespace {
 
+template <int ROLE>
+int launch_fast_glds(const GemmArgs& g, unsigned grid, hipStream_t s)
+{
+  static std::atomic<uint64_t> attr_set{0};
+  auto kern = gemm_nt_fast_kernel<4, ROLE, false, false, false, false, true>;
+  int dev = 0;
+  GPC_HIP_CHECK(hipGetDevice(&dev));
+  if(!(attr_set.load() >> (dev & 63) & 1)) {
+    GPC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES));
+    attr_set.fetch_or(1ull << (dev & 63));
+  }
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), GEMM_LDS_BYTES, s, g);
+  GPC_HIP_CHECK(hipGetLastError());
+  return GPC_OK;
+}
+
 template <int NWN>
 int launch_fast(const GemmArgs& g, unsigned grid, hipStream_t s)
 {
+  static const int glds = [] { const char* e = getenv("GPC_GEMM_GLDS"); return e ? atoi(e) : 0; }();
+  if(NWN == 4 && glds) {
+    if(g_gemm_trailing == 1) return launch_fast_glds<1>(g, grid, s);
+    if(g_gemm_trailing == 3) return launch_fast_glds<3>(g, grid, s);
+    if(g_gemm_trailing == 0) return launch_fast_glds<0>(g, grid, s);
+  }
   if(g_gemm_trailing == 2) return launch_fast_role<NWN, 2>(g, grid, s);   // slab update inside a Cholesky panel
   if(NWN == 4 && g_gemm_trailing == 3 && gemm_two_ahead()) return launch_fast_role<4, 3, true>(g, grid, s);   // SolveScope
   if(NWN == 4 && g_gemm_trailing && gemm_two_ahead()) return launch_fast_role<4, 1, true>(g, grid, s);
@@ -741,6 +1084,23 @@ int launch(const GemmArgs& g, unsigned grid, hipStream_t s)
 static int gemm_ex(bool transa, bool transb, int64_t M, int64_t N, int64_t K, double alpha, const double* A, int64_t lda,
                    const double* B, int64_t ldb, double beta, double* C, int64_t ldc, int tri, const Stair2D* st2,
                    hipStream_t s);
+
+// The ring form (gemm_nt_ring_kernel) takes an NT product from GPC_GEMM_RING_MINM rows: below, its 256 x 128 tiles are too few
+// per CU (M = 16 384: 16.25 rounds of one tile per CU cost 17) and the 128 x 128 form is level or ahead (tools/ring_msweep.py:
+// M = 12 288 / 16 384 / 20 480 / 32 768 / 49 152 at K = 1536: 65.3 / 68.6 / 70.1 / 72.4 / 73.0 against 66.8 / 68.5 / 69.5 / 70.5 / 70.8)
+bool gemm_takes_ring(int64_t M, int64_t N, int64_t K, const double* A, int64_t lda, const double* B, int64_t ldb, int64_t ldc, int tri)
+{
+  static const int ring = [] { const char* e = getenv("GPC_GEMM_RING"); return e ? atoi(e) : 1; }();
+  static const int64_t ring_minm = [] { const char* e = getenv("GPC_GEMM_RING_MINM"); return e ? atoll(e) : (int64_t)18432; }();
+  if(g_gemm_variant < 0) {
+    const char* e = getenv("GPC_GEMM_VARIANT");
+    g_gemm_variant = e ? atoi(e) : 2;
+    if(g_gemm_variant < 0 || g_gemm_variant > 2) g_gemm_variant = 2;
+  }
+  const bool vec = ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B)) & 15) == 0 && (lda % 2 == 0) && (ldb % 2 == 0);
+  return ring && g_gemm_variant == 2 && vec && K >= 96 && (K % BK) == 0 && (ldc % 2) == 0 && (tri == 0 || tri == 1) && M >= ring_minm &&
+         N >= ring_minm && (M % R_BM) == 0 && (N % R_BN) == 0 && M < 0x7fffffff && N < 0x7fffffff && g_gemm_kstart == 0 && g_gemm_kend == 0;
+}
 
 int gemm(bool transa, bool transb, int64_t M, int64_t N, int64_t K, double alpha, const double* A, int64_t lda,
          const double* B, int64_t ldb, double beta, double* C, int64_t ldc, int tri, hipStream_t s)
@@ -790,6 +1150,10 @@ static int gemm_ex(bool transa, bool transb, int64_t M, int64_t N, int64_t K, do
     use_atomic = e ? (atoi(e) != 0) : 1;
   }
   g.atomic_c = (beta == 1.0 && use_atomic) ? 1 : 0;
+  {
+    static const int stag = [] { const char* e = getenv("GPC_GEMM_RING_STAGGER"); return e ? atoi(e) : 1; }();
+    g.ring_stagger = stag;
+  }
   g.ksplit = 1;
   g.part = nullptr;
   g.part_stride = 0;
@@ -919,6 +1283,11 @@ static int gemm_ex(bool transa, bool transb, int64_t M, int64_t N, int64_t K, do
     if(a_kc && b_kc) return (kc_pf2 > 0) ? launch_fast_kc<true, true, true>(g, grid, s) : launch_fast_kc<true, true, false>(g, grid, s);
     if(a_kc) return (kc_pf2 != 0) ? launch_fast_kc<true, false, true>(g, grid, s) : launch_fast_kc<true, false, false>(g, grid, s);
     return (kc_pf2 != 0) ? launch_fast_kc<false, true, true>(g, grid, s) : launch_fast_kc<false, true, false>(g, grid, s);
+  }
+  if(!g.kstart && !g.kend && !a_kc && !b_kc && gemm_takes_ring(M, N, K, A, lda, B, ldb, ldc, tri)) {
+    if(g_gemm_trailing == 1) return launch_ring<1>(g, s);
+    if(g_gemm_trailing == 3) return launch_ring<3>(g, s);
+    return launch_ring<0>(g, s);
   }
   if(g_gemm_variant > 0 && !a_kc && !b_kc && vec && g.K > 0 && (g.K % BK) == 0 && (M % 2) == 0 && (N % 2) == 0) {
     // few tiles and a long k: one round of workgroups would each walk the whole k-range while most of the chip idles

@@ -197,7 +197,8 @@ int pair_walk_grad_cross(const KSpecDev& ks, const double* X, int64_t N, int64_t
                          int64_t D, const double* G, int64_t ldg, double* S, hipStream_t s);
 
 // Optional HIP-event instrumentation of the dominant launches (bench.py's roofline leg; off by default).
-enum ProfKind { PROF_SYRK = 0, PROF_GRAM = 1, PROF_NKINDS = 2 };
+enum ProfKind { PROF_SYRK = 0, PROF_GRAM = 1, PROF_SYRK_RING = 2, PROF_NKINDS = 3 };   // SYRK: trailing updates on the 128 x 128 kernel; SYRK_RING: on the ring kernel
+bool gemm_takes_ring(int64_t M, int64_t N, int64_t K, const double* A, int64_t lda, const double* B, int64_t ldb, int64_t ldc, int tri);   // gemm_f64.hip: an NT product of this shape runs on gemm_nt_ring_kernel
 void prof_begin(int kind, double algorithmic_work, hipStream_t s);
 void prof_end(int kind, hipStream_t s);
 

@@ -967,10 +967,12 @@ int potrf_lower(int64_t N, double* A, int64_t lda, int* d_info, hipStream_t s, i
       if(mt > 0) {
         const double* L21 = A + kend + k0 * lda;
         double* A22 = A + kend + kend * lda;
-        prof_begin(PROF_SYRK, (double)mt * (double)(mt + 1) * (double)nbk, s);  // lower-triangle SYRK flops
+        // (two populations for the profile: the updates that take the ring kernel -- the bulk of the flops -- and the smaller ones)
+        const int kind = gemm_takes_ring(mt, mt, nbk, L21, lda, L21, lda, lda, 1) ? PROF_SYRK_RING : PROF_SYRK;
+        prof_begin(kind, (double)mt * (double)(mt + 1) * (double)nbk, s);  // lower-triangle SYRK flops
         TrailingScope role;
         GPC_CHECK(gemm(false, true, mt, mt, nbk, -1.0, L21, lda, L21, lda, 1.0, A22, lda, 1, s));
-        prof_end(PROF_SYRK, s);
+        prof_end(kind, s);
       }
     }
     return GPC_OK;

@@ -12,7 +12,7 @@ struct Rec {
 bool g_on = false;
 std::vector<Rec> g_recs[PROF_NKINDS];
 std::vector<Rec> g_pool;
-bool g_open[PROF_NKINDS] = {false, false};
+bool g_open[PROF_NKINDS] = {false, false, false};
 
 Rec take()
 {
