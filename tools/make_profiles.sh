@@ -23,12 +23,12 @@ for wl in cfg3 cfg2; do
   timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/kt_$wl -o t -- python $R/bench.py --workload $wl --steps $steps --warmup 1 --no-cpu-baseline > $OUT/bench_${wl}_under_trace.json 2> /dev/null
   summ /tmp/kt_$wl "python bench.py --workload $wl --steps $steps --warmup 1 --no-cpu-baseline" > $OUT/kernel_trace_${wl}.txt
 done
-# 2. PMC passes on ONE big trailing-update launch (tools/one_syrk.py: M=16384, K=512, 3 launches), separate runs
+# 2. PMC passes on ONE big trailing-update launch (tools/one_syrk.py: M=32768, K=1536 -- the ring kernel -- 3 launches), separate runs
 pmc() { # name counters...
   n=$1; shift
   rm -rf /tmp/pmc_$n
-  timeout 300 rocprofv3 --pmc "$@" -d /tmp/pmc_$n -o p -- python $R/tools/one_syrk.py 2 16384 512 > /dev/null 2>&1
-  echo "# rocprofv3 --pmc $* -- python tools/one_syrk.py 2 16384 512   (per-dispatch sums over all XCDs/SEs)" > $OUT/pmc_syrk_$n.txt
+  timeout 300 rocprofv3 --pmc "$@" -d /tmp/pmc_$n -o p -- python $R/tools/one_syrk.py 2 32768 1536 > /dev/null 2>&1
+  echo "# rocprofv3 --pmc $* -- python tools/one_syrk.py 2 32768 1536   (gemm_nt_ring_kernel; per-dispatch sums over all XCDs/SEs)" > $OUT/pmc_syrk_$n.txt
   python $R/tools/pmc_query.py /tmp/pmc_$n gemm >> $OUT/pmc_syrk_$n.txt 2>&1
 }
 pmc mfma SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE

@@ -1,14 +1,16 @@
 # regenerates the committed rNN profiles on the GPU box: PMC traffic of the bench command first (bench.py replays it), the
 # default and cfg 2 lines, kernel traces and counters (make_profiles.sh, pmc_kgrad.sh), gradient / gemm / DTC / GP-LVM timings
+TAG=${1:-r05}
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-bash tools/pmc_bench_traffic.sh r04 > gpurun_out/r47_pmc_bench.log 2>&1
-cp gpurun_out/profiles_r04/pmc_bench_traffic.json profiles/r04_pmc_bench_traffic.json
-python bench.py > gpurun_out/profiles_r04/bench_default.json 2> gpurun_out/r47_bench_default.err
-python bench.py --workload cfg2 --steps 20 --warmup 3 > gpurun_out/profiles_r04/bench_cfg2.json 2> gpurun_out/r47_bench_cfg2.err
-bash tools/make_profiles.sh r04 > gpurun_out/r47_make_profiles.log 2>&1
-bash tools/pmc_kgrad.sh r04 > gpurun_out/r47_pmc_kgrad.log 2>&1
-for D in 4 8 16 32; do python tools/grad_bench.py 65536 $D 2>/dev/null | grep "kern_grad"; done > gpurun_out/profiles_r04/grad_timings.txt 2>&1
-python tools/gemm_forms.py 2>/dev/null > gpurun_out/profiles_r04/gemm_forms.txt
-python tools/dtc_bench.py 2>/dev/null | tail -5 > gpurun_out/profiles_r04/dtc.txt
-for i in 1 2 3; do gpc_amd/host/gplvm -v 3 -s 1 learn -k rbf -i 1 -# 100 tests/golden/oilTrain.svml /tmp/oil.model 2>&1 | grep -i "evaluations\|seconds\|took" | tail -2; done > gpurun_out/profiles_r04/gplvm_cfg5.txt 2>&1
+mkdir -p gpurun_out/profiles_$TAG
+bash tools/pmc_bench_traffic.sh $TAG > gpurun_out/regen_pmc_bench.log 2>&1
+cp gpurun_out/profiles_$TAG/pmc_bench_traffic.json profiles/$TAG_pmc_bench_traffic.json
+python bench.py > gpurun_out/profiles_$TAG/bench_default.json 2> gpurun_out/regen_bench_default.err
+python bench.py --workload cfg2 --steps 20 --warmup 3 > gpurun_out/profiles_$TAG/bench_cfg2.json 2> gpurun_out/regen_bench_cfg2.err
+bash tools/make_profiles.sh $TAG > gpurun_out/regen_make_profiles.log 2>&1
+bash tools/pmc_kgrad.sh $TAG > gpurun_out/regen_pmc_kgrad.log 2>&1
+for D in 4 8 16 32; do python tools/grad_bench.py 65536 $D 2>/dev/null | grep "kern_grad"; done > gpurun_out/profiles_$TAG/grad_timings.txt 2>&1
+python tools/gemm_forms.py 2>/dev/null > gpurun_out/profiles_$TAG/gemm_forms.txt
+python tools/dtc_bench.py 2>/dev/null | tail -5 > gpurun_out/profiles_$TAG/dtc.txt
+for i in 1 2 3; do gpc_amd/host/gplvm -v 3 -s 1 learn -k rbf -i 1 -# 100 tests/golden/oilTrain.svml /tmp/oil.model 2>&1 | grep -i "evaluations\|seconds\|took" | tail -2; done > gpurun_out/profiles_$TAG/gplvm_cfg5.txt 2>&1
