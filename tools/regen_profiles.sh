@@ -5,7 +5,7 @@ cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 mkdir -p gpurun_out/profiles_$TAG
 bash tools/pmc_bench_traffic.sh $TAG > gpurun_out/regen_pmc_bench.log 2>&1
-cp gpurun_out/profiles_$TAG/pmc_bench_traffic.json profiles/$TAG_pmc_bench_traffic.json
+cp gpurun_out/profiles_$TAG/pmc_bench_traffic.json profiles/${TAG}_pmc_bench_traffic.json
 python bench.py > gpurun_out/profiles_$TAG/bench_default.json 2> gpurun_out/regen_bench_default.err
 python bench.py --workload cfg2 --steps 20 --warmup 3 > gpurun_out/profiles_$TAG/bench_cfg2.json 2> gpurun_out/regen_bench_cfg2.err
 bash tools/make_profiles.sh $TAG > gpurun_out/regen_make_profiles.log 2>&1
