@@ -669,6 +669,24 @@ __device__ __forceinline__ bool ring_tile(const GemmArgs& g, const unsigned L, c
 {
   if(L >= total) return false;
   const unsigned sm = (unsigned)((g.M + 1023) / 1024);
+  if(g.tri == 5) {
+    // 2-D block-cyclic staircase (grid.hip): the 1024 x 1024 super-tiles with a valid tile, column by column (st_first / st_cum,
+    // as the 128 x 128 form enumerates them); inside, tiles above the global diagonal are skipped
+    const unsigned L5 = L >> 5, w = L & 31u;
+    int lo = 0, hi = g.super_n;
+    while(hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if(g.st_cum[mid] <= L5) lo = mid;
+      else hi = mid;
+    }
+    ti = (int)(((unsigned)g.st_first[lo] + (L5 - g.st_cum[lo])) * 4u + (w & 3u));
+    tj = (int)((unsigned)lo * 8u + (w >> 2));
+    if(ti * R_BM >= (int)g.M || tj * R_BN >= (int)g.N) return false;
+    const int64_t m0 = (int64_t)ti * R_BM, n0 = (int64_t)tj * R_BN, rt = m0 / g.stair_nb, ct = n0 / g.stair_nb;
+    const int64_t I = stair_row(g, rt), J = g.st_J0 + ct * g.st_pc;
+    if(I < J) return false;
+    return I > J || (m0 - rt * g.stair_nb) + R_BM - 1 >= (n0 - ct * g.stair_nb);
+  }
   if(g.tri == 1) {
     // ONLY the tiles that reach the lower triangle, super-tile (1024 x 1024) by super-tile: super-row R holds R full super-tiles
     // (32 tiles each) and a diagonal one (the 20 tiles with tj <= 2 ti + 1); before row R: 16 R^2 + 4 R.  The last super-row
@@ -746,7 +764,15 @@ __global__ void __launch_bounds__(1024, 1) gemm_nt_ring_kernel(const GemmArgs g,
   const int Mi = (int)g.M, Ni = (int)g.N;      // (the launcher admits M, N < 2^31)
   auto aim = [&](const int ti, const int tj) {
     sa = reinterpret_cast<const char*>(g.A + (int64_t)ti * R_BM + (int64_t)wave * g.lda);
-    sb = reinterpret_cast<const char*>(g.B + (int64_t)tj * R_BN + (int64_t)wave * g.ldb);
+    if(g.tri == 5) {      // the column operand is kept tile by tile (voff: where the nb x nb tile of this column starts)
+      const int64_t n0 = (int64_t)tj * R_BN, ct = n0 / g.stair_nb;
+      const int64_t vo = g.voff[g.st_jl0 + ct];      // (uniform, but loaded through the vector path: back to scalar registers)
+      const uint64_t vou = ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(vo >> 32)) << 32) |
+                           (unsigned)__builtin_amdgcn_readfirstlane((int)(vo & 0xffffffff));
+      sb = reinterpret_cast<const char*>(g.B + (int64_t)vou + (n0 - ct * g.stair_nb) + (int64_t)wave * g.ldb);
+    } else {
+      sb = reinterpret_cast<const char*>(g.B + (int64_t)tj * R_BN + (int64_t)wave * g.ldb);
+    }
   };
   unsigned lslot = lds0;      // ring slot the load cursor writes next
   auto issue = [&]() {
@@ -874,7 +900,14 @@ __global__ void __launch_bounds__(1024, 1) gemm_nt_ring_kernel(const GemmArgs g,
     {
       const int m0 = cti * R_BM, n0 = ctj * R_BN;
       const bool full_mn = (m0 + R_BM <= Mi) && (n0 + R_BN <= Ni);
-      const bool diag_tile = g.tri == 1 && (m0 < n0 + R_BN);
+      bool diag_tile = g.tri == 1 && (m0 < n0 + R_BN);
+      int dshift = 0;      // (m - m0) + dshift >= (n - n0) <=> on or below the diagonal
+      if(g.tri == 1) dshift = m0 - n0;
+      if(g.tri == 5) {
+        const int64_t rt = m0 / g.stair_nb, ct = n0 / g.stair_nb;
+        diag_tile = stair_row(g, rt) == g.st_J0 + ct * g.st_pc;
+        dshift = (int)((m0 - rt * g.stair_nb) - (n0 - ct * g.stair_nb));
+      }
       const int tl = threadIdx.x;
       const int mb = m0 + ((tl >> 6) & 3) * 64 + (tl & 15), nbs = n0 + (tl >> 8) * 32 + ((tl >> 4) & 3);
       double* p0 = g.C + mb + (int64_t)nbs * g.ldc;
@@ -886,7 +919,7 @@ __global__ void __launch_bounds__(1024, 1) gemm_nt_ring_kernel(const GemmArgs g,
           for(int tm = 0; tm < 4; tm++) {
             const int m = mb + tm * 16, n = nbs + tn * 16 + 4 * r;
             bool ok = full_mn || (m < Mi && n < Ni);
-            if(diag_tile) ok = ok && (m >= n);
+            if(diag_tile) ok = ok && ((m - m0) + dshift >= (n - n0));
             if(ok) {
               double* p = p0 + tm * 16 + (int64_t)(tn * 16 + 4 * r) * g.ldc;
               double v = alpha * acc[tm][tn][r];
@@ -935,6 +968,7 @@ int launch_ring(const GemmArgs& g, hipStream_t s)
     const uint64_t tm = (uint64_t)((g.M + R_BM - 1) / R_BM), h = tm - 4 * (sm - 1);
     total = 16 * (sm - 1) * (sm - 1) + 4 * (sm - 1) + 8 * h * (sm - 1) + h * (h + 1);
   }
+  if(g.tri == 5) total = (uint64_t)g.st_cum[g.super_n] * 32;
   // per XCD a whole number of rounds of its workgroups, so that a round's 32 ids are one super-tile's wherever possible
   const uint64_t nwg = (uint64_t)cus.load() / 8;
   uint64_t per_xcd = (total + 7) / 8;
@@ -1268,7 +1302,30 @@ static int gemm_ex(bool transa, bool transb, int64_t M, int64_t N, int64_t K, do
     g_gemm_variant = e ? atoi(e) : 2;
     if(g_gemm_variant < 0 || g_gemm_variant > 2) g_gemm_variant = 2;
   }
-  if(tri == 5) return g_gemm_variant == 1 ? launch_fast<2>(g, grid, s) : launch_fast<4>(g, grid, s);
+  if(tri == 5) {
+    // the ring form on the block's first whole 256-row tiles (a grid rank's extra rows -- right-hand sides riding below the matrix,
+    // a multiple of 16 -- stay with the 128 x 128 form as a second, small launch)
+    static const int ring = [] { const char* e = getenv("GPC_GEMM_RING"); return e ? atoi(e) : 1; }();
+    static const int64_t ring_tiles = [] { const char* e = getenv("GPC_GEMM_RING_MINTILES"); return e ? atoll(e) : (int64_t)5120; }();
+    const int64_t M256 = (M / R_BM) * R_BM;
+    if(ring && g_gemm_variant == 2 && vec && g.K >= 96 && (ldc % 2) == 0 && g.stair_nb % R_BM == 0 && M256 >= 2048 && M < 0x7fffffff &&
+       N < 0x7fffffff && (M256 == M || (M256 % g.stair_nb) == 0) && (int64_t)g.st_cum[g.super_n] * 32 >= ring_tiles) {
+      int rc = GPC_OK;
+      if(M256 < M) {      // rows M256 .. M-1: tile rows past every column tile of the block (M256 is a whole number of nb-tiles)
+        Stair2D rest = *st2;
+        rest.I0 = st2->I0 + (M256 / g.stair_nb) * st2->pr;
+        rest.il0 = st2->il0 + M256 / g.stair_nb;
+        rc = gemm_ex(false, true, M - M256, N, K, alpha, A + M256, lda, B, ldb, beta, C + M256, ldc, 5, &rest, s);
+        if(rc != GPC_OK) return rc;
+        // the super-tile table of the rows that remain: recomputed for M256 rows by the call below
+        return gemm_ex(false, true, M256, N, K, alpha, A, lda, B, ldb, beta, C, ldc, 5, st2, s);
+      }
+      if(g_gemm_trailing == 1) return launch_ring<1>(g, s);
+      if(g_gemm_trailing == 3) return launch_ring<3>(g, s);
+      return launch_ring<0>(g, s);
+    }
+    return g_gemm_variant == 1 ? launch_fast<2>(g, grid, s) : launch_fast<4>(g, grid, s);
+  }
   // NN / TN / TT (round 4): the fast kernel with the k-contiguous operand(s) staged by rows.  Even M and N as for NT: a thread
   // stages a PAIR of operand rows either way (one clamp per pair keeps the distance between its two loads uniform); odd sizes
   // and k-ranges that are not whole stages stay on the generic kernel below.
