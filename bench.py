@@ -646,8 +646,9 @@ def main():
         roof = {"bound": "mfma",
                 "kernel": ("gemm_nt_ring_kernel<1> (the trailing updates of gpc_potrf_f64 with >= GPC_GEMM_RING_MINM rows: %.1f %% of all "
                            "trailing-update flops)" % (100.0 * ring_flops / max(syrk_flops, 1.0))) if on_ring else
-                          ("gemm_nt_fast_kernel<4, 1, false, true> (trailing updates U1+U2 of %s)"
-                           % ("the grid's rank 0, 2-D staircase" if g is not None else "gpc_potrf_f64")),
+                          ("gemm_nt_ring_kernel<1> where a launch has >= 5120 tiles of 256 x 128, else gemm_nt_fast_kernel<4, 1, false, true> "
+                           "(trailing updates U1 + U2 of the grid's rank 0, 2-D staircase; both kernels in one population)" if g is not None
+                           else "gemm_nt_fast_kernel<4, 1, false, true> (trailing updates of gpc_potrf_f64)"),
                 "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": traffic,
                 "traffic_unit": "HBM bytes per launch = (2 x FETCH_SIZE + WRITE_SIZE) x 1024",

@@ -167,12 +167,12 @@ class Params(object):
 
 # share of the chip a panel-stream kernel takes from the trailing update that runs beside it
 CHIP_SHARE = {"trsm_rlt": 1.0, "potrf_tile": 0.5, "potrf_panel": 1.0, "copy": 0.3, "zero": 0.3, "gram": 1.0, "small": 0.05,
-              "gemm": 0.5, "trsm_l": 0.5, "kern_grad": 1.0, "update": 1.0}
+              "gemm": 0.5, "trsm_l": 0.5, "kern_grad": 1.0, "update": 1.0, "inv_update": 1.0}
 
 
 def op_ms(o, costs, nb):
     k = o["op"]
-    if k == "update":
+    if k in ("update", "inv_update"):      # (the distributed inverse's updates are the same launch: priced alike)
         return costs.update_ms(o["k"], o["flops"])
     if k == "trsm_rlt":
         return costs.trsm_ms(o["n"], o["rows"])

@@ -7,6 +7,8 @@ mkdir -p gpurun_out/profiles_$TAG
 bash tools/pmc_bench_traffic.sh $TAG > gpurun_out/regen_pmc_bench.log 2>&1
 cp gpurun_out/profiles_$TAG/pmc_bench_traffic.json profiles/${TAG}_pmc_bench_traffic.json
 python bench.py > gpurun_out/profiles_$TAG/bench_default.json 2> gpurun_out/regen_bench_default.err
+GPC_BENCH_GRID=1 python bench.py --no-cpu-baseline > gpurun_out/profiles_$TAG/bench_cfg3_grid_1x1.json 2> gpurun_out/regen_bench_grid.err
+python tools/grid_costs.py gpurun_out/profiles_$TAG/grid_costs.json > gpurun_out/regen_grid_costs.log 2>&1
 python bench.py --workload cfg2 --steps 20 --warmup 3 > gpurun_out/profiles_$TAG/bench_cfg2.json 2> gpurun_out/regen_bench_cfg2.err
 bash tools/make_profiles.sh $TAG > gpurun_out/regen_make_profiles.log 2>&1
 bash tools/pmc_kgrad.sh $TAG > gpurun_out/regen_pmc_kgrad.log 2>&1
