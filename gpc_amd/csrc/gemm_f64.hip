@@ -69,7 +69,6 @@ struct GemmArgs {
   double* part;          // workgroup of its own writing alpha * (its partial product) to part + piece * part_stride (M x N,
   int64_t part_stride;   // leading dimension M); split_combine_kernel adds the pieces in order.  For products with few tiles
                          // and a long k (the GP-LVM's K^-1 = V V' at N = 1000: 36 tiles, one round of 64 stages each)
-  int ring_stagger;      // ring kernel: start the workgroups apart in time (GPC_GEMM_RING_STAGGER, default 1)
   int atomic_c;          // beta == 1: accumulate into C with no-return fp64 atomics instead of load + add + store
   int tri;               // 0 full, 1 lower (i >= j, C square), 2 upper (i <= j, C square),
                          // 3 lower trapezoid (i >= j, M >= N, full enumeration with skipped tiles)
@@ -404,16 +403,10 @@ __global__ void __launch_bounds__(256, 2) gemm_f64_kernel(const GemmArgs g)
 //     loads two consecutive k of two adjacent rows (8 threads = one 128-byte run of a row) -- into the [m][k] image
 //     (row stride 18 doubles, conflict-free for the fragment reads like the [k][m] one); everything else is the NT kernel.
 //     k-start / k-end / staircase / split-k stay NT-only.
-//   * GLDS (round 5, measurement variant, GPC_GEMM_GLDS=1): the operands of stage kt + 1 go from global memory STRAIGHT into the
-//     other LDS buffer (global_load_lds_dwordx4: a wave's 64 x 16 bytes are one 128-double k-row of the [k][m] image, so the
-//     lane-linear destination is exactly the image), issued behind the first MFMA group of stage kt and awaited at the stage's
-//     barrier: no staging registers, no ds_write, but only ONE stage of latency cover (two LDS buffers per workgroup are what two
-//     workgroups per CU leave room for), against the register form's two.
-template <int NWN, int ROLE, bool SPLITK = false, bool PF2 = false, bool A_KC = false, bool B_KC = false, bool GLDS = false>
+template <int NWN, int ROLE, bool SPLITK = false, bool PF2 = false, bool A_KC = false, bool B_KC = false>
 __global__ void __launch_bounds__(128 * NWN, NWN) gemm_nt_fast_kernel(const GemmArgs g)
 {
   static_assert(!(A_KC || B_KC) || (NWN == 4 && !SPLITK), "k-contiguous operands: eight-wave, unsplit instances only");
-  static_assert(!GLDS || (NWN == 4 && !SPLITK && !PF2 && !A_KC && !B_KC), "direct-to-LDS staging: the plain NT eight-wave instance");
   constexpr int NT = 256 / (64 * NWN) * 2;  // n-subtiles per wave: NWN=2 -> 4, NWN=4 -> 2
   constexpr int NL = 8 / (2 * NWN);         // double2 loads per operand per thread per stage: 2 or 1... see below
   static_assert(NWN == 2 || NWN == 4, "wave grid");
@@ -514,20 +507,6 @@ __global__ void __launch_bounds__(128 * NWN, NWN) gemm_nt_fast_kernel(const Gemm
   // alternate (the loop runs in pairs of stages so that each set is named statically)
   double2_t ra2_[PASSES], rb2_[PASSES];
   constexpr bool kPF2 = PF2;
-  typedef __attribute__((address_space(3))) void lds_void_t;
-  typedef const __attribute__((address_space(1))) void glb_void_t;
-  // direct-to-LDS: this wave's k-rows (t >> 6) + KROWS i of one operand of the stage at `buf` (the hardware adds 16 bytes per lane)
-  auto glds_stage = [&](double* buf) {
-#pragma unroll
-    for(int i = 0; i < PASSES; i++) {
-      double* rowa = buf + ((t >> 6) + KROWS * i) * STRIDE_MC;
-      __builtin_amdgcn_global_load_lds((glb_void_t*)(pa + i * stepa), (lds_void_t*)rowa, 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((glb_void_t*)(pb + i * stepb), (lds_void_t*)(rowa + OP_ELEMS), 16, 0, 0);
-    }
-  };
-  if(GLDS) {
-    if(KT > 0) glds_stage(lds);
-  } else
   if(KT > 0) {
 #pragma unroll
     for(int i = 0; i < PASSES; i++) {
@@ -582,18 +561,14 @@ __global__ void __launch_bounds__(128 * NWN, NWN) gemm_nt_fast_kernel(const Gemm
         // issue the loads behind the first MFMA group
         pa += stagea;
         pb += stageb;
-        if(GLDS) {
-          glds_stage(nxt);
-        } else {
 #pragma unroll
-          for(int i = 0; i < PASSES; i++) {
-            la[i] = *reinterpret_cast<const double2_t*>(pa + i * stepa);
-            lb[i] = *reinterpret_cast<const double2_t*>(pb + i * stepb);
-          }
+        for(int i = 0; i < PASSES; i++) {
+          la[i] = *reinterpret_cast<const double2_t*>(pa + i * stepa);
+          lb[i] = *reinterpret_cast<const double2_t*>(pb + i * stepb);
         }
       }
     }
-    if(more && !GLDS) {
+    if(more) {
 #pragma unroll
       for(int i = 0; i < PASSES; i++) {
         *reinterpret_cast<double2_t*>(nxt + lwa + i * LPA) = sa[i];
@@ -603,7 +578,7 @@ __global__ void __launch_bounds__(128 * NWN, NWN) gemm_nt_fast_kernel(const Gemm
     __syncthreads();
   };
   if(!kPF2) {
-    for(int64_t kt = 0; kt < KT; kt++) stage(kt, ra_, rb_, ra_, rb_, 1);   // (GLDS: the register sets are unused)
+    for(int64_t kt = 0; kt < KT; kt++) stage(kt, ra_, rb_, ra_, rb_, 1);
   } else {
     // even stages: set 1 (ra_) holds stage kt + 1, stage kt + 2 is loaded into set 2; odd stages the other way round
     int64_t kt = 0;
@@ -812,14 +787,6 @@ __global__ void __launch_bounds__(1024, 1) gemm_nt_ring_kernel(const GemmArgs g,
   using K1 = std::integral_constant<int, 1>;
   using K2 = std::integral_constant<int, 2>;
   using K3 = std::integral_constant<int, 3>;
-  // The workgroups start a fraction of a microsecond apart, spread over ~50 us.  Every tile takes the same time, so workgroups
-  // that start together reach their epilogues together, for ever: 256 CUs x 512 KB of read-modify-write at one instant take
-  // HBM ~25 us, and the third stage of the next tile -- whose wait counts every operation in flight -- stands still for most of
-  // that (measured: 16 us per tile).  Apart by 0.2 us each, an epilogue has the memory system nearly to itself.
-  if(g.ring_stagger) {
-    const unsigned slotn = (blockIdx.x * 37u) & 255u;
-    for(unsigned q = 0; q < slotn; q++) __builtin_amdgcn_s_sleep(7);
-  }
   // prologue: the first tile's first three stages on their way and awaited
   aim(cti, ctj);
   issue();
@@ -1062,31 +1029,9 @@ bool gemm_two_ahead()
 
 namespace {
 
-template <int ROLE>
-int launch_fast_glds(const GemmArgs& g, unsigned grid, hipStream_t s)
-{
-  static std::atomic<uint64_t> attr_set{0};
-  auto kern = gemm_nt_fast_kernel<4, ROLE, false, false, false, false, true>;
-  int dev = 0;
-  GPC_HIP_CHECK(hipGetDevice(&dev));
-  if(!(attr_set.load() >> (dev & 63) & 1)) {
-    GPC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES));
-    attr_set.fetch_or(1ull << (dev & 63));
-  }
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), GEMM_LDS_BYTES, s, g);
-  GPC_HIP_CHECK(hipGetLastError());
-  return GPC_OK;
-}
-
 template <int NWN>
 int launch_fast(const GemmArgs& g, unsigned grid, hipStream_t s)
 {
-  static const int glds = [] { const char* e = getenv("GPC_GEMM_GLDS"); return e ? atoi(e) : 0; }();
-  if(NWN == 4 && glds) {
-    if(g_gemm_trailing == 1) return launch_fast_glds<1>(g, grid, s);
-    if(g_gemm_trailing == 3) return launch_fast_glds<3>(g, grid, s);
-    if(g_gemm_trailing == 0) return launch_fast_glds<0>(g, grid, s);
-  }
   if(g_gemm_trailing == 2) return launch_fast_role<NWN, 2>(g, grid, s);   // slab update inside a Cholesky panel
   if(NWN == 4 && g_gemm_trailing == 3 && gemm_two_ahead()) return launch_fast_role<4, 3, true>(g, grid, s);   // SolveScope
   if(NWN == 4 && g_gemm_trailing && gemm_two_ahead()) return launch_fast_role<4, 1, true>(g, grid, s);
@@ -1184,10 +1129,6 @@ static int gemm_ex(bool transa, bool transb, int64_t M, int64_t N, int64_t K, do
     use_atomic = e ? (atoi(e) != 0) : 1;
   }
   g.atomic_c = (beta == 1.0 && use_atomic) ? 1 : 0;
-  {
-    static const int stag = [] { const char* e = getenv("GPC_GEMM_RING_STAGGER"); return e ? atoi(e) : 1; }();
-    g.ring_stagger = stag;
-  }
   g.ksplit = 1;
   g.part = nullptr;
   g.part_stride = 0;

@@ -1,6 +1,6 @@
 """Single-GPU kernel times the grid model (tools/grid_model.py) replays the scheduler's trace against: the staircase
 trailing update as a function of its size, the panel's triangular solve, the diagonal tile's factorisation, device copies,
-the cross-Gram build, the gap between two small launches.  Writes JSON (default profiles/r03_grid_costs.json).
+the cross-Gram build, the gap between two small launches.  Writes JSON (default profiles/r05_grid_costs.json).
 usage (GPU box): python tools/grid_costs.py [out.json]"""
 import ctypes
 import json
@@ -14,7 +14,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from gpc_amd import _lib, api  # noqa: E402
 import torch  # noqa: E402
 
-out_path = sys.argv[1] if len(sys.argv) > 1 else "profiles/r03_grid_costs.json"
+out_path = sys.argv[1] if len(sys.argv) > 1 else "profiles/r05_grid_costs.json"
 lib = _lib.load()
 f = lib.gpc_bench_update
 f.restype = ctypes.c_int

@@ -8,12 +8,12 @@ from them and which grid shape / exchange to pick, without a hand-written formul
      for every rank of a pr x pc grid over a recording GridOps / GridComm: every kernel, copy, event record / wait and
      exchange, in host issue order, with its stream and size;
   2. this file replays those traces as a discrete-event simulation: two in-order streams per GPU with HIP event
-     semantics, kernels at the times MEASURED on one MI355X (tools/grid_costs.py -> profiles/r03_grid_costs.json: the
+     semantics, kernels at the times MEASURED on one MI355X (tools/grid_costs.py -> profiles/r05_grid_costs.json: the
      staircase update by size, the panel solve, the tile factorisation, copies), exchanges matched across ranks and
      priced as latency + bytes / link bandwidth (parameters: xGMI is point to point, one link per pair of GPUs), panel-
      stream kernels taking their share of the chip away from the trailing update that runs beside them.
 
-usage: python tools/grid_model.py [--costs profiles/r03_grid_costs.json] [--link-gbs 50,100] [--workload cfg3,cfg4]
+usage: python tools/grid_model.py [--costs profiles/r05_grid_costs.json] [--link-gbs 50,100] [--workload cfg3,cfg4]
                                   [--shapes 1x1,1x2,2x1,2x2,4x1,2x4,4x2,8x1] [--nb 1024] [--json out.json]
 tests/test_grid_model.py pins the trace to gpc_grid_stats and the P = 1 replay to the measured single-GPU grid run.
 """
@@ -449,7 +449,7 @@ def predict(costs, workload, pr, pc, nb, par, lookahead=1):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--costs", default=os.path.join(ROOT, "profiles", "r03_grid_costs.json"))
+    ap.add_argument("--costs", default=os.path.join(ROOT, "profiles", "r05_grid_costs.json"))
     ap.add_argument("--link-gbs", default="50,100")
     ap.add_argument("--alpha-us", type=float, default=25.0)
     ap.add_argument("--workload", default="cfg3,cfg4")
