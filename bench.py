@@ -537,8 +537,6 @@ def main():
     ring_n, ring_ms, ring_flops = api.profile_read(2, reset=True)
     syrk_n, syrk_ms, syrk_flops = rest_n + ring_n, rest_ms + ring_ms, rest_flops + ring_flops
     schedule_mismatch = None
-    # (the default configuration: one trailing update per panel; look-ahead / GPC_GEMM_PF2=0 split it in U1 + U2)
-    gemm_default = os.environ.get("GPC_GEMM_PF2", "2") != "0" and os.environ.get("GPC_PANEL_FLOW", "1") != "0"
     gram_n, gram_ms, gram_bytes = api.profile_read(1, reset=True)
     gstats = g.stats() if g is not None else None
     if g is not None:

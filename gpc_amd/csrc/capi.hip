@@ -306,7 +306,6 @@ int HostFetch::finish(hipStream_t s)
 }
 
 int potri_full(bool lower, int64_t N, double* A, int64_t lda, hipStream_t s);
-void release_lookahead();     // potrf.hip
 void release_profile();       // profile.hip
 
 // the calling thread's scratch slots
@@ -907,7 +906,6 @@ extern "C" int gpc_shutdown(void)
   for(int d = 0; d < n; d++)
     if(hipSetDevice(d) == hipSuccess) (void)hipDeviceSynchronize();
   (void)hipSetDevice(cur);
-  gpc::release_lookahead();
   gpc::release_profile();
   gpc::release_workspace();
   (void)hipGetLastError();

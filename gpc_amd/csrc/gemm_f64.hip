@@ -1014,18 +1014,9 @@ int launch_fast_kc(const GemmArgs& g, unsigned grid, hipStream_t s)
 
 }  // namespace
 
-// Trailing updates load their operands TWO stages ahead (PF2 instance of the fast kernel: 124 VGPRs, still four waves per
-// SIMD): 64.2 -> 69.3 TFLOP/s at N = 65 536.  The kernel then leaves no room for a panel kernel beside it, so potrf.hip
-// drops its look-ahead and sends every panel through the dataflow kernel when this is on.  GPC_GEMM_PF2=0 restores the
-// one-stage-ahead kernel (and with it the look-ahead and the 24 576-row dataflow limit).  Every other large product takes the
-// same instance (potri 58.3 -> 59.1 TFLOP/s at N = 32 768, a lone 32 768 x 512 syrk 63.0 -> 64.7, the grid gradient 528 ->
-// 510 ms); GPC_GEMM_PF2=1 keeps it to the trailing updates.
-bool gemm_two_ahead()
-{
-  static int pf2 = -1;
-  if(pf2 < 0) { const char* e = getenv("GPC_GEMM_PF2"); pf2 = e ? (atoi(e) != 0) : 1; }
-  return pf2 != 0;
-}
+// The 128 x 128 kernel loads its operands TWO stages ahead (PF2 instance: 124 VGPRs, still four waves per SIMD): 64.2 -> 69.3
+// TFLOP/s at N = 65 536 when it was introduced.  The one-stage-ahead instance (GPC_GEMM_PF2=0) was retired in round 5.
+bool gemm_two_ahead() { return true; }
 
 namespace {
 
@@ -1033,11 +1024,9 @@ template <int NWN>
 int launch_fast(const GemmArgs& g, unsigned grid, hipStream_t s)
 {
   if(g_gemm_trailing == 2) return launch_fast_role<NWN, 2>(g, grid, s);   // slab update inside a Cholesky panel
-  if(NWN == 4 && g_gemm_trailing == 3 && gemm_two_ahead()) return launch_fast_role<4, 3, true>(g, grid, s);   // SolveScope
-  if(NWN == 4 && g_gemm_trailing && gemm_two_ahead()) return launch_fast_role<4, 1, true>(g, grid, s);
-  static int pf2_all = -1;
-  if(pf2_all < 0) { const char* e = getenv("GPC_GEMM_PF2"); pf2_all = (!e || atoi(e) >= 2) ? 1 : 0; }   // 1 = trailing updates only
-  if(NWN == 4 && pf2_all) return launch_fast_role<4, 0, true>(g, grid, s);
+  if(NWN == 4 && g_gemm_trailing == 3) return launch_fast_role<4, 3, true>(g, grid, s);   // SolveScope
+  if(NWN == 4 && g_gemm_trailing) return launch_fast_role<4, 1, true>(g, grid, s);
+  if(NWN == 4) return launch_fast_role<4, 0, true>(g, grid, s);
   return g_gemm_trailing ? launch_fast_role<NWN, 1>(g, grid, s) : launch_fast_role<NWN, 0>(g, grid, s);
 }
 

@@ -11,10 +11,9 @@
 //   described below factors everything when GPC_PANEL_FLOW=0, after a dataflow time-out, and the panels taller than
 //   GPC_PANEL_FLOW_MAXROWS.  After panel k is final its trailing update A22 -= L21 * L21' (depth NB, the fp64 MFMA tiles of
 //   gemm_f64.hip, N^3/3 of the flops) is ONE launch.
-//   LOOK-AHEAD is OFF by default: the trailing-update kernel (operands two stages ahead) fills every CU's registers and LDS,
-//   so a panel kernel launched beside it does not start before it drains.  With GPC_GEMM_PF2=0 (one stage ahead) the
-//   round-2 form returns: look-ahead from N >= 28 672 -- the update split in U1(k) (the columns of panel k+1) and U2(k) (the
-//   rest), panels on a second, high-priority stream (per host thread) -- and dataflow panels up to 24 576 rows.
+//   There is no look-ahead on one GPU: the trailing-update kernels fill every CU's registers and LDS, so a panel kernel launched
+//   beside one does not start before it drains (measured in rounds 2-4: 1393 against 1389 ms at cfg 3, slower below N = 32 768;
+//   the switch GPC_LOOKAHEAD and the one-stage-ahead update it needed, GPC_GEMM_PF2=0, were retired in round 5).
 //   Inside a panel of the launch chain, two levels: 128-column slabs of two 64-column steps, per slab
 //     potf2_blk_kernel          one workgroup, the 64 x 64 diagonal block in registers, columns 8 at a time (the four waves
 //                               exchange their shares through LDS once per 8 columns, every wave then factors the 64 x 8 block
@@ -46,7 +45,6 @@ namespace {
 constexpr int JB = 64;
 
 int64_t g_nb_outer = 0;
-int g_lookahead = -1;
 
 // Factor the n x n (n <= 64) diagonal block at A (lower, in place).  col0 = global index of the block's first
 // column, for `info`.  Thread t owns row r = t & 63 and, at outer step jq, the columns c = 4 (q + jq) + g in register
@@ -559,57 +557,6 @@ int panel_solve_rt(const double* Lbb, int64_t lda, int nb, double* B, int64_t ld
 
 namespace {
 
-// second stream + event pool for the look-ahead (created once per host thread and device).  Trivially destructible on
-// purpose: gpc_shutdown runs from atexit, i.e. AFTER the exiting thread's thread_local destructors -- a std::vector here
-// would already be destroyed when release_lookahead_impl() walks it.  The pool is a raw array freed only there.
-struct LookAhead {
-  hipStream_t panel;
-  int dev;
-  hipEvent_t* ev;
-  size_t count, cap, next;
-  hipEvent_t get()
-  {
-    if(next == count) {
-      if(count == cap) {
-        const size_t ncap = cap ? 2 * cap : 256;
-        hipEvent_t* ne = static_cast<hipEvent_t*>(realloc(ev, ncap * sizeof(hipEvent_t)));
-        if(!ne) return nullptr;
-        ev = ne;
-        cap = ncap;
-      }
-      hipEvent_t e;
-      if(hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
-      ev[count++] = e;
-    }
-    return ev[next++];
-  }
-};
-static_assert(std::is_trivially_destructible<LookAhead>::value, "must survive thread_local destruction (atexit order)");
-thread_local LookAhead g_la = {nullptr, -1, nullptr, 0, 0, 0};   // per host thread, like the scratch buffers (capi.hip)
-
-void release_lookahead_impl()
-{
-  for(size_t i = 0; i < g_la.count; i++) (void)hipEventDestroy(g_la.ev[i]);
-  free(g_la.ev);
-  g_la.ev = nullptr;
-  g_la.count = g_la.cap = g_la.next = 0;
-  if(g_la.panel) (void)hipStreamDestroy(g_la.panel);
-  g_la.panel = nullptr;
-}
-
-int ensure_lookahead()
-{
-  int dev = 0;
-  GPC_HIP_CHECK(hipGetDevice(&dev));
-  if(g_la.panel && g_la.dev == dev) return GPC_OK;
-  int lo = 0, hi = 0;
-  GPC_HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));
-  GPC_HIP_CHECK(hipStreamCreateWithPriority(&g_la.panel, hipStreamNonBlocking, hi));
-  g_la.dev = dev;
-  g_la.count = g_la.next = 0;   // (events of another device's pool are abandoned, not reused across devices)
-  return GPC_OK;
-}
-
 // Is the dataflow panel kernel (panel_flow.hip) in use, and up to how many rows?  GPC_PANEL_FLOW=0 turns it off (the launch
 // chain below then factors every panel), GPC_PANEL_FLOW_MAXROWS moves the height above which the chain takes over (on a tall
 // panel the chain's products are chip-wide GEMMs, the dataflow blocks' are one CU each: 1504 vs 1474 ms at N = 65 536 when
@@ -621,7 +568,7 @@ static int64_t panel_flow_maxrows()
   if(maxrows < 0) {
     const char* e = getenv("GPC_PANEL_FLOW");
     const char* m = getenv("GPC_PANEL_FLOW_MAXROWS");
-    maxrows = (e && atoi(e) == 0) ? 0 : (m ? atoll(m) : (gemm_two_ahead() ? (int64_t(1) << 40) : 24576));
+    maxrows = (e && atoi(e) == 0) ? 0 : (m ? atoll(m) : (int64_t(1) << 40));
   }
   return maxrows;
 }
@@ -751,7 +698,6 @@ int factor_panel(int64_t N, double* A, int64_t lda, int64_t k0, int64_t nbk, int
 
 }  // namespace
 
-void release_lookahead() { release_lookahead_impl(); }   // gpc_shutdown (capi.hip)
 
 // Factor one tall panel (M x nb, M >= nb): diagonal blocks + substitution solve + in-panel updates.  Used by the
 // multi-GPU grid when one rank holds the whole panel (grid.hip: a 1 x pc grid).
@@ -944,92 +890,24 @@ static int64_t panel_width(int64_t rem)
 int potrf_lower(int64_t N, double* A, int64_t lda, int* d_info, hipStream_t s, int64_t col0)
 {
   if(N <= 0) return GPC_OK;
-  // Look-ahead pays only on large matrices: the panel kernels of a tall panel fill the chip themselves, so running them
-  // beside U2 mostly moves time around (N = 65 536: 1.497 -> 1.477 s), and below N ~ 32 768 the contention for CU
-  // slots (a panel workgroup has to wait for trailing-update workgroups to retire) costs more than the overlap wins
-  // (N = 8192: 10.65 ms without, 11.06 ms with).  GPC_LOOKAHEAD = 0 / 1 forces it off / on, unset = by size -- and off at
-  // every size with the two-stage-ahead trailing update (gemm_two_ahead()): that kernel's 124 VGPRs x 4 waves leave a panel
-  // kernel no SIMD to sit on, so the overlap is gone and only the contention remains (N = 65 536: 1450 ms with, 1435 without).
-  if(g_lookahead < 0) {
-    const char* e = getenv("GPC_LOOKAHEAD");
-    g_lookahead = e ? (atoi(e) != 0 ? 1 : 0) : 2;
-  }
-  const bool la = (g_lookahead == 1 || (g_lookahead == 2 && N >= 28672 && !gemm_two_ahead())) && N > 2 * panel_width(N);
-
-  if(!la) {
-    int64_t nbk = 0;
-    for(int64_t k0 = 0; k0 < N; k0 += nbk) {
-      const int64_t NB = panel_width(N - k0);
-      nbk = (N - k0 < NB) ? (N - k0) : NB;
-      const int64_t kend = k0 + nbk;
-      GPC_CHECK(factor_panel(N, A, lda, k0, nbk, d_info, s, col0));
-      const int64_t mt = N - kend;
-      if(mt > 0) {
-        const double* L21 = A + kend + k0 * lda;
-        double* A22 = A + kend + kend * lda;
-        // (two populations for the profile: the updates that take the ring kernel -- the bulk of the flops -- and the smaller ones)
-        const int kind = gemm_takes_ring(mt, mt, nbk, L21, lda, L21, lda, lda, 1) ? PROF_SYRK_RING : PROF_SYRK;
-        prof_begin(kind, (double)mt * (double)(mt + 1) * (double)nbk, s);  // lower-triangle SYRK flops
-        TrailingScope role;
-        GPC_CHECK(gemm(false, true, mt, mt, nbk, -1.0, L21, lda, L21, lda, 1.0, A22, lda, 1, s));
-        prof_end(kind, s);
-      }
-    }
-    return GPC_OK;
-  }
-
-  // ---- look-ahead: panels on g_la.panel, trailing updates on the caller's stream ------------------------------------
-  GPC_CHECK(ensure_lookahead());
-  hipStream_t sp = g_la.panel;
-  g_la.next = 0;
-  hipEvent_t e0 = g_la.get();
-  if(!e0) return GPC_EHIP;
-  GPC_HIP_CHECK(hipEventRecord(e0, s));           // everything queued before this call (the Gram build, memset of info)
-  GPC_HIP_CHECK(hipStreamWaitEvent(sp, e0, 0));
-  int64_t nbk = (N < panel_width(N)) ? N : panel_width(N), nb_next = 0;
-  GPC_CHECK(factor_panel(N, A, lda, 0, nbk, d_info, sp, col0));
-  hipEvent_t e_panel = g_la.get();
-  if(!e_panel) return GPC_EHIP;
-  GPC_HIP_CHECK(hipEventRecord(e_panel, sp));
-
-  for(int64_t k0 = 0; k0 < N; k0 += nbk, nbk = nb_next) {
+  int64_t nbk = 0;
+  for(int64_t k0 = 0; k0 < N; k0 += nbk) {
+    const int64_t NB = panel_width(N - k0);
+    nbk = (N - k0 < NB) ? (N - k0) : NB;
     const int64_t kend = k0 + nbk;
+    GPC_CHECK(factor_panel(N, A, lda, k0, nbk, d_info, s, col0));
     const int64_t mt = N - kend;
-    if(mt <= 0) break;
-    const int64_t NB = panel_width(mt);
-    const double* L21 = A + kend + k0 * lda;
-    double* A22 = A + kend + kend * lda;
-    const int64_t nb1 = (mt < NB) ? mt : NB;       // width of the next panel
-    nb_next = nb1;
-    GPC_HIP_CHECK(hipStreamWaitEvent(s, e_panel, 0));  // panel k is final
-    // U1(k): the columns of panel k+1 (lower trapezoid mt x nb1)
-    prof_begin(PROF_SYRK, (2.0 * (double)mt - (double)nb1 + 1.0) * (double)nb1 * (double)nbk, s);
-    {
+    if(mt > 0) {
+      const double* L21 = A + kend + k0 * lda;
+      double* A22 = A + kend + kend * lda;
+      // (two populations for the profile: the updates that take the ring kernel -- the bulk of the flops -- and the smaller ones)
+      const int kind = gemm_takes_ring(mt, mt, nbk, L21, lda, L21, lda, lda, 1) ? PROF_SYRK_RING : PROF_SYRK;
+      prof_begin(kind, (double)mt * (double)(mt + 1) * (double)nbk, s);  // lower-triangle SYRK flops
       TrailingScope role;
-      GPC_CHECK(gemm(false, true, mt, nb1, nbk, -1.0, L21, lda, L21, lda, 1.0, A22, lda, 3, s));
-    }
-    prof_end(PROF_SYRK, s);
-    hipEvent_t e_u1 = g_la.get();
-    if(!e_u1) return GPC_EHIP;
-    GPC_HIP_CHECK(hipEventRecord(e_u1, s));
-    // panel k+1 on the panel stream, concurrently with U2(k)
-    GPC_HIP_CHECK(hipStreamWaitEvent(sp, e_u1, 0));
-    GPC_CHECK(factor_panel(N, A, lda, kend, nb1, d_info, sp, col0));
-    e_panel = g_la.get();
-    if(!e_panel) return GPC_EHIP;
-    GPC_HIP_CHECK(hipEventRecord(e_panel, sp));
-    // U2(k): everything right of panel k+1
-    const int64_t m2 = mt - nb1;
-    if(m2 > 0) {
-      const double* L2 = L21 + nb1;
-      double* A33 = A22 + nb1 + nb1 * lda;
-      prof_begin(PROF_SYRK, (double)m2 * (double)(m2 + 1) * (double)nbk, s);
-      TrailingScope role;
-      GPC_CHECK(gemm(false, true, m2, m2, nbk, -1.0, L2, lda, L2, lda, 1.0, A33, lda, 1, s));
-      prof_end(PROF_SYRK, s);
+      GPC_CHECK(gemm(false, true, mt, mt, nbk, -1.0, L21, lda, L21, lda, 1.0, A22, lda, 1, s));
+      prof_end(kind, s);
     }
   }
-  GPC_HIP_CHECK(hipStreamWaitEvent(s, e_panel, 0));  // join: the caller's stream sees the finished factor
   return GPC_OK;
 }
 
@@ -1098,8 +976,9 @@ extern "C" int gpc_potrf_panel_schedule(int64_t N, int64_t* widths, int64_t cap,
   return GPC_OK;
 }
 
+// (retired in round 5: there is no look-ahead on one GPU any more -- see the head of this file; kept as a no-op for callers)
 extern "C" int gpc_set_potrf_lookahead(int on)
 {
-  gpc::g_lookahead = on ? 1 : 0;
+  (void)on;
   return GPC_OK;
 }

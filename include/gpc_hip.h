@@ -390,10 +390,9 @@ int gpc_set_potrf_blocking(int64_t nb_outer, int64_t jb_inner);   /* nb_outer = 
 /* The schedule that policy produces for an N x N matrix: widths[i] = columns of panel i (at most cap of them are written),
  * *count = number of panels.  bench.py prices the trailing updates' algorithmic bytes from it. */
 int gpc_potrf_panel_schedule(int64_t N, int64_t* widths, int64_t cap, int64_t* count);
-/* Look-ahead of depth 1 in gpc_potrf_f64 (panel k+1 on a second, high-priority HIP stream while the trailing update
- * of panel k runs).  OFF by default since the trailing update loads its operands two stages ahead (it fills every CU's
- * register file, so a panel kernel beside it cannot start: DESIGN.md 3.2); env GPC_LOOKAHEAD=1 or this call turn it on,
- * GPC_GEMM_PF2=0 restores the by-size rule (on from N = 28 672) together with the one-stage-ahead update. */
+/* RETIRED (round 5), kept as a no-op for existing callers: look-ahead of depth 1 in gpc_potrf_f64.  The trailing-update kernels
+ * fill every CU's registers and LDS, so a panel kernel launched beside one starts when it drains; measured slower or level at
+ * every size in rounds 2-4.  The multi-GPU grid's look-ahead (gpc_grid_set_lookahead) is unaffected. */
 int gpc_set_potrf_lookahead(int on);
 /* GEMM kernel variant for the A*B^T shapes: 0 generic, 1 fast 4-wave, 2 fast 8-wave (default; env GPC_GEMM_VARIANT). */
 int gpc_set_gemm_variant(int variant);
