@@ -507,6 +507,7 @@ struct HipOps : GridOps {
       HIPOPS_CHECK(hipGetLastError());
       return GPC_OK;
     }
+    if(ta == 'N' && tb == 'N') return gpc_gemm_f64('N', 'N', M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, st[s]);   // (skinny products: split-k kernel)
     return gpc::gemm(ta == 'T', tb == 'T', M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, 0, st[s]);
   }
   int trsm_llt(const double* Lkk, int64_t ldl, int64_t n, double* B, int64_t ldb, int64_t nrhs, int s) override
