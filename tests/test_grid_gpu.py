@@ -292,6 +292,59 @@ def _free_port():
     return p
 
 
+@pytest.mark.parametrize("pr,pc,N,nb,d", [(2, 2, 8192, 512, 1), (4, 1, 12288, 256, 0), (2, 4, 16384, 256, 2), (1, 1, 4096, 512, 1)])
+def test_staircase_updates_on_the_ring_kernel(pr, pc, N, nb, d):
+    """The ring form of the trailing update (gemm_nt_ring_kernel: 256 x 128 tiles, one persistent workgroup per CU) on the grid's
+    2-D staircase -- tile-addressed column operand, global-diagonal test, reflected rounds, the right-hand sides' extra rows as a
+    second launch on the 128 x 128 form.  By default it takes launches of >= 5120 tiles only (a rank's block of cfg 3 / cfg 4);
+    GPC_GEMM_RING_MINTILES=1 puts every update AND every update of the distributed inverse on it at a size numpy can check:
+    factor, log|K|, Alpha, the gradient.  (A subprocess: the threshold is read once per process.)"""
+    code = r"""
+import os, sys, numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import grid_common as gc
+from gpc_amd import grid
+pr, pc, N, nb, d = %d, %d, %d, %d, %d
+terms = [("rbf", [0.7, 0.9]), ("white", [0.05])]
+X, Y, _ = gc.make_problem(N, 4, max(d, 1), 0, 17)
+Yd = Y if d else None
+grids = grid.create_local(pr, pc, nb)
+def work(g, rank):
+    g.set_problem(terms, X, Yd, None)
+    ld, jit, info = g.update_k()
+    out = {"ld": ld, "info": info, "tiles": g.local_tiles()}
+    if d:
+        out["alpha"] = g.alpha()
+        out["grad"] = g.gradient(3)
+    return out
+res = grid.run_local(grids, work)
+for g in grids:
+    g.destroy()
+K = gc.kern(terms, X, X, True)
+Lw = np.linalg.cholesky(K)
+L = grid.assemble_factor([r["tiles"] for r in res], N, nb)
+assert all(r["info"] == 0 for r in res)
+assert gc.rel(L, Lw) < 1e-9, gc.rel(L, Lw)
+want = 2.0 * np.log(np.diag(Lw)).sum()
+assert abs(res[0]["ld"] - want) <= 1e-10 * abs(want)
+if d:
+    import scipy.linalg as sla
+    al = sla.cho_solve((Lw, True), Y)
+    assert gc.rel(res[0]["alpha"], al) < 1e-8
+    Ki = sla.cho_solve((Lw, True), np.eye(N))
+    C = -0.5 * (d * Ki - al @ al.T)
+    d2 = (X * X).sum(1)[:, None] + (X * X).sum(1)[None, :] - 2.0 * X @ X.T
+    np.fill_diagonal(d2, 0.0)
+    kt = np.exp(-0.5 * 0.7 * d2)
+    gw = np.array([float((C * (-0.5 * 0.9 * d2 * kt)).sum()), float((C * kt).sum()), float(np.trace(C))])
+    assert gc.rel(res[0]["grad"], gw) < 1e-8, (res[0]["grad"], gw)
+print("RING-STAIR-OK")
+""" % (HERE, ROOT, pr, pc, N, nb, d)
+    env = dict(os.environ, GPC_GEMM_RING_MINTILES="1")
+    r = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+    assert r.returncode == 0 and "RING-STAIR-OK" in r.stdout.decode(), r.stdout.decode()[-3000:]
+
+
 def test_two_processes_sharing_the_gpu_over_gloo(tmp_path):
     import torch.multiprocessing as mp
     import grid_worker
