@@ -796,8 +796,9 @@ __global__ void __launch_bounds__(1024, 1) gemm_nt_ring_kernel(const GemmArgs g,
   __builtin_amdgcn_s_barrier();
   Frag f0, f1, f2, f3;
   unsigned slot = lds0;       // ring slot the arithmetic reads
-  read(f0, slot + fa, slot + fb, K0());
-  read(f1, slot + fa, slot + fb, K1());
+  unsigned pa = slot + fa, pb = slot + fb;      // ... and this lane's fragment addresses in it (carried from stage to stage: two
+  read(f0, pa, pb, K0());                       //     vector additions per stage, not four)
+  read(f1, pa, pb, K1());
   const double alpha = g.alpha, beta = g.beta;
   // Invariant at the start of a tile: its first THREE stages are in LDS, waited for by every wave before the epilogue of the tile
   // before it (or in the prologue), and the first two k-steps' fragments are on their way to f0 / f1.  The waits of a tile's
@@ -819,7 +820,7 @@ __global__ void __launch_bounds__(1024, 1) gemm_nt_ring_kernel(const GemmArgs g,
       //  of loads in flight stays what the waits assume -- and nothing beyond the operands is touched)
       const bool advance = has_next || s + 4 < KT;
       const unsigned nslot = slot == lds0 + 2 * R_STAGE * 8 ? lds0 : slot + R_STAGE * 8;
-      const unsigned pa = slot + fa, pb = slot + fb, na = nslot + fa, nbb = nslot + fb;
+      const unsigned na = nslot + fa, nbb = nslot + fb;
       R_WAIT(f0, 6);      // (f0 and f1 were requested in this order; f1's six reads may still be out)
       mma(f0);
       read(f2, pa, pb, K2());
@@ -858,6 +859,8 @@ __global__ void __launch_bounds__(1024, 1) gemm_nt_ring_kernel(const GemmArgs g,
       __builtin_amdgcn_sched_barrier(0);
       mma(f3);
       slot = nslot;
+      pa = na;
+      pb = nbb;
     }
     // the next tile's three stages (or the repeated fetches past the end) have landed; f0 / f1 hold its first fragments
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
