@@ -23,6 +23,7 @@
 #include <math.h>
 #include <stdlib.h>
 #include <atomic>
+#include <string.h>
 #include <type_traits>
 
 namespace gpc {
@@ -639,8 +640,31 @@ constexpr int R_BM = 256, R_BN = 128, R_SA = 272, R_SB = 144;
 constexpr int R_STAGE = BK * (R_SA + R_SB);          // doubles per stage: 6656 = 53 248 B
 constexpr int R_LDS_BYTES = 3 * R_STAGE * 8;         // 159 744 B of the CU's 163 840
 
+// The ring kernel's own, lean arguments: 32-bit sizes and staircase parameters (the launcher admits M, N, K < 2^31).  hipcc keeps
+// every scalar argument in scalar registers for the whole kernel; GemmArgs' 64-bit fields left the stage loop short of them.
+struct RingArgs {
+  const double* A;
+  const double* B;
+  double* C;
+  const int64_t* voff;
+  double alpha, beta;
+  int64_t lda, ldb, ldc;
+  int M, N, K, tri, atomic_c, super_n;
+  int stair_nb, st_I0, st_pr, st_J0, st_pc, st_jl0, st_il0, st_refl_r;
+};
+struct StairTab {      // tri 5: see GemmArgs::st_cum / st_first (read by index from the argument segment, never register-resident)
+  uint32_t cum[MAX_SUPER_COLS + 1];
+  uint16_t first[MAX_SUPER_COLS];
+};
+__device__ __forceinline__ int ring_stair_row(const RingArgs& g, int t)
+{
+  if(g.st_refl_r < 0) return g.st_I0 + t * g.st_pr;
+  const int il = g.st_il0 + t;
+  return g.st_pr * il + ((il & 1) ? g.st_pr - 1 - g.st_refl_r : g.st_refl_r);
+}
+
 // logical tile id -> tile coordinates (in 256 x 128 tiles); false: no such tile
-__device__ __forceinline__ bool ring_tile(const GemmArgs& g, const unsigned L, const unsigned total, int& ti, int& tj)
+__device__ __forceinline__ bool ring_tile(const RingArgs& g, const StairTab& tab, const unsigned L, const unsigned total, int& ti, int& tj)
 {
   if(L >= total) return false;
   const unsigned sm = (unsigned)((g.M + 1023) / 1024);
@@ -651,14 +675,14 @@ __device__ __forceinline__ bool ring_tile(const GemmArgs& g, const unsigned L, c
     int lo = 0, hi = g.super_n;
     while(hi - lo > 1) {
       const int mid = (lo + hi) >> 1;
-      if(g.st_cum[mid] <= L5) lo = mid;
+      if(tab.cum[mid] <= L5) lo = mid;
       else hi = mid;
     }
-    ti = (int)(((unsigned)g.st_first[lo] + (L5 - g.st_cum[lo])) * 4u + (w & 3u));
+    ti = (int)(((unsigned)tab.first[lo] + (L5 - tab.cum[lo])) * 4u + (w & 3u));
     tj = (int)((unsigned)lo * 8u + (w >> 2));
-    if(ti * R_BM >= (int)g.M || tj * R_BN >= (int)g.N) return false;
-    const int64_t m0 = (int64_t)ti * R_BM, n0 = (int64_t)tj * R_BN, rt = m0 / g.stair_nb, ct = n0 / g.stair_nb;
-    const int64_t I = stair_row(g, rt), J = g.st_J0 + ct * g.st_pc;
+    if(ti * R_BM >= g.M || tj * R_BN >= g.N) return false;
+    const int m0 = ti * R_BM, n0 = tj * R_BN, rt = m0 / g.stair_nb, ct = n0 / g.stair_nb;
+    const int I = ring_stair_row(g, rt), J = g.st_J0 + ct * g.st_pc;
     if(I < J) return false;
     return I > J || (m0 - rt * g.stair_nb) + R_BM - 1 >= (n0 - ct * g.stair_nb);
   }
@@ -696,7 +720,7 @@ __device__ __forceinline__ bool ring_tile(const GemmArgs& g, const unsigned L, c
     ti = (int)((sidx % sm) * 4u + (w & 3u));
     tj = (int)((sidx / sm) * 8u + (w >> 2));
   }
-  return ti * R_BM < (int)g.M && tj * R_BN < (int)g.N;
+  return ti * R_BM < g.M && tj * R_BN < g.N;
 }
 
 // Persistent: one workgroup per CU walks its share of the tiles; the ring of stages runs on ACROSS tile boundaries -- while a
@@ -705,17 +729,17 @@ __device__ __forceinline__ bool ring_tile(const GemmArgs& g, const unsigned L, c
 // on XCD b % 8: XCD x owns the contiguous range [x C, (x + 1) C) of logical tile ids and its 32 workgroups take 32 consecutive
 // ids per round -- one 1024 x 1024 super-tile of C whose operand slabs they share in the XCD's L2.
 template <int ROLE>
-__global__ void __launch_bounds__(1024, 1) gemm_nt_ring_kernel(const GemmArgs g, const unsigned total, const unsigned per_xcd)
+__global__ void __launch_bounds__(1024, 1) gemm_nt_ring_kernel(const RingArgs g, const StairTab tab, const unsigned total, const unsigned per_xcd)
 {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const int t = threadIdx.x, lane = t & 63, wm = (t >> 6) & 3, wn = t >> 8;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);      // uniform: the loads' LDS destinations stay on the scalar unit
-  const int KT = (int)(g.K / BK);
+  const int KT = g.K / BK;
   const unsigned xcd = blockIdx.x & 7u, wg = blockIdx.x >> 3, nwg = gridDim.x >> 3;
   const unsigned Lend = (xcd + 1u) * per_xcd < total ? (xcd + 1u) * per_xcd : total;
   // the next valid tile at or after logical id L (stepping by the XCD's workgroup count)
   auto find = [&](unsigned L, int& ti, int& tj) -> unsigned {
-    while(L < Lend && !ring_tile(g, L, total, ti, tj)) L += nwg;
+    while(L < Lend && !ring_tile(g, tab, L, total, ti, tj)) L += nwg;
     return L < Lend ? L : 0xffffffffu;
   };
   int cti = 0, ctj = 0;
@@ -736,15 +760,15 @@ __global__ void __launch_bounds__(1024, 1) gemm_nt_ring_kernel(const GemmArgs g,
   // (M is a multiple of 256 and N of 128 on this path: no row needs clamping, every lane's offset is 16 bytes per lane in both operands)
   const char *sa = nullptr, *sb = nullptr;
   const unsigned v16 = 16u * (threadIdx.x & 63);
-  const int Mi = (int)g.M, Ni = (int)g.N;      // (the launcher admits M, N < 2^31)
+  const int Mi = g.M, Ni = g.N;
   auto aim = [&](const int ti, const int tj) {
     sa = reinterpret_cast<const char*>(g.A + (int64_t)ti * R_BM + (int64_t)wave * g.lda);
     if(g.tri == 5) {      // the column operand is kept tile by tile (voff: where the nb x nb tile of this column starts)
-      const int64_t n0 = (int64_t)tj * R_BN, ct = n0 / g.stair_nb;
+      const int n0 = tj * R_BN, ct = n0 / g.stair_nb;
       const int64_t vo = g.voff[g.st_jl0 + ct];      // (uniform, but loaded through the vector path: back to scalar registers)
       const uint64_t vou = ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(vo >> 32)) << 32) |
                            (unsigned)__builtin_amdgcn_readfirstlane((int)(vo & 0xffffffff));
-      sb = reinterpret_cast<const char*>(g.B + (int64_t)vou + (n0 - ct * g.stair_nb) + (int64_t)wave * g.ldb);
+      sb = reinterpret_cast<const char*>(g.B + (int64_t)vou + (int64_t)(n0 - ct * g.stair_nb) + (int64_t)wave * g.ldb);
     } else {
       sb = reinterpret_cast<const char*>(g.B + (int64_t)tj * R_BN + (int64_t)wave * g.ldb);
     }
@@ -874,9 +898,9 @@ __global__ void __launch_bounds__(1024, 1) gemm_nt_ring_kernel(const GemmArgs g,
       int dshift = 0;      // (m - m0) + dshift >= (n - n0) <=> on or below the diagonal
       if(g.tri == 1) dshift = m0 - n0;
       if(g.tri == 5) {
-        const int64_t rt = m0 / g.stair_nb, ct = n0 / g.stair_nb;
-        diag_tile = stair_row(g, rt) == g.st_J0 + ct * g.st_pc;
-        dshift = (int)((m0 - rt * g.stair_nb) - (n0 - ct * g.stair_nb));
+        const int rt = m0 / g.stair_nb, ct = n0 / g.stair_nb;
+        diag_tile = ring_stair_row(g, rt) == g.st_J0 + ct * g.st_pc;
+        dshift = (m0 - rt * g.stair_nb) - (n0 - ct * g.stair_nb);
       }
       const int tl = threadIdx.x;
       const int mb = m0 + ((tl >> 6) & 3) * 64 + (tl & 15), nbs = n0 + (tl >> 8) * 32 + ((tl >> 4) & 3);
@@ -943,7 +967,21 @@ int launch_ring(const GemmArgs& g, hipStream_t s)
   const uint64_t nwg = (uint64_t)cus.load() / 8;
   uint64_t per_xcd = (total + 7) / 8;
   per_xcd = ((per_xcd + nwg - 1) / nwg) * nwg;
-  hipLaunchKernelGGL(kern, dim3((unsigned)cus.load()), dim3(1024), R_LDS_BYTES, s, g, (unsigned)total, (unsigned)per_xcd);
+  RingArgs a;
+  a.A = g.A; a.B = g.B; a.C = g.C; a.voff = g.voff;
+  a.alpha = g.alpha; a.beta = g.beta;
+  a.lda = g.lda; a.ldb = g.ldb; a.ldc = g.ldc;
+  a.M = (int)g.M; a.N = (int)g.N; a.K = (int)g.K; a.tri = g.tri; a.atomic_c = g.atomic_c; a.super_n = g.super_n;
+  a.stair_nb = (int)g.stair_nb; a.st_I0 = (int)g.st_I0; a.st_pr = (int)g.st_pr; a.st_J0 = (int)g.st_J0; a.st_pc = (int)g.st_pc;
+  a.st_jl0 = (int)g.st_jl0; a.st_il0 = (int)g.st_il0; a.st_refl_r = g.st_refl_r;
+  StairTab tab;
+  if(g.tri == 5) {
+    memcpy(tab.cum, g.st_cum, sizeof(tab.cum));
+    memcpy(tab.first, g.st_first, sizeof(tab.first));
+  } else {
+    tab.cum[0] = 0;
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)cus.load()), dim3(1024), R_LDS_BYTES, s, a, tab, (unsigned)total, (unsigned)per_xcd);
   GPC_HIP_CHECK(hipGetLastError());
   return GPC_OK;
 }
