@@ -728,7 +728,7 @@ __device__ __forceinline__ bool ring_tile(const RingArgs& g, const StairTab& tab
 // (64 no-return atomics per thread) sits between two matrix blocks whose operands are in LDS already.  Hardware block b runs
 // on XCD b % 8: XCD x owns the contiguous range [x C, (x + 1) C) of logical tile ids and its 32 workgroups take 32 consecutive
 // ids per round -- one 1024 x 1024 super-tile of C whose operand slabs they share in the XCD's L2.
-template <int ROLE>
+template <int ROLE, bool STAIR>
 __global__ void __launch_bounds__(1024, 1) gemm_nt_ring_kernel(const RingArgs g, const StairTab tab, const unsigned total, const unsigned per_xcd)
 {
   extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -763,7 +763,7 @@ __global__ void __launch_bounds__(1024, 1) gemm_nt_ring_kernel(const RingArgs g,
   const int Mi = g.M, Ni = g.N;
   auto aim = [&](const int ti, const int tj) {
     sa = reinterpret_cast<const char*>(g.A + (int64_t)ti * R_BM + (int64_t)wave * g.lda);
-    if(g.tri == 5) {      // the column operand is kept tile by tile (voff: where the nb x nb tile of this column starts)
+    if(STAIR) {      // the column operand is kept tile by tile (voff: where the nb x nb tile of this column starts)
       const int n0 = tj * R_BN, ct = n0 / g.stair_nb;
       const int64_t vo = g.voff[g.st_jl0 + ct];      // (uniform, but loaded through the vector path: back to scalar registers)
       const uint64_t vou = ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(vo >> 32)) << 32) |
@@ -819,72 +819,96 @@ __global__ void __launch_bounds__(1024, 1) gemm_nt_ring_kernel(const RingArgs g,
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   Frag f0, f1, f2, f3;
-  unsigned slot = lds0;       // ring slot the arithmetic reads
-  unsigned pa = slot + fa, pb = slot + fb;      // ... and this lane's fragment addresses in it (carried from stage to stage: two
-  read(f0, pa, pb, K0());                       //     vector additions per stage, not four)
-  read(f1, pa, pb, K1());
+  // This lane's fragment addresses in the three ring slots.  Every vector instruction in the stage loop is paid for in matrix-pipe
+  // time (four address additions per stage: 73.4-73.5 TFLOP/s at m = 49 152, K = 1536; two: 74.1-74.3), so the stage body exists
+  // once per slot with its addresses as constants: up to two stages to reach slot 0, whole turns of the ring, up to two more.
+  // (The staircase instance keeps the one-body form with two additions per stage: its column operand's base passes through a
+  //  vector load, and with seven copies of the body hipcc then carries that base in vector registers, which the loads reject.)
+  const unsigned pa0 = lds0 + fa, pa1 = pa0 + R_STAGE * 8, pa2 = pa1 + R_STAGE * 8;
+  const unsigned pb0 = lds0 + fb, pb1 = pb0 + R_STAGE * 8, pb2 = pb1 + R_STAGE * 8;
+  int q = 0;                  // ring slot the tile's next stage reads
+  read(f0, pa0, pb0, K0());
+  read(f1, pa0, pb0, K1());
   const double alpha = g.alpha, beta = g.beta;
+  int s = 0;
+  bool has_next = false;
+  int nti = 0, ntj = 0;
+  auto stage = [&](const unsigned pa, const unsigned pb, const unsigned na, const unsigned nbb, const unsigned slot) {
+    if(s + 3 == KT && has_next) aim(nti, ntj);      // the load cursor moves on to the next tile's first three stages
+    // (at the end of the last tile the cursor stays on the last stage: it is fetched again into a free slot, so that the count
+    //  of loads in flight stays what the waits assume -- and nothing beyond the operands is touched)
+    const bool advance = has_next || s + 4 < KT;
+    R_WAIT(f0, 6);      // (f0 and f1 were requested in this order; f1's six reads may still be out)
+    mma(f0);
+    read(f2, pa, pb, K2());
+    R_WAIT(f1, 6);
+    mma(f1);
+    read(f3, pa, pb, K3());
+    // the next stage has landed (the three loads of the one after it may still fly) and every fragment of this one is in registers
+    if(s >= 2) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    R_WAIT(f2, 0);
+    R_WAIT(f3, 0);
+    __builtin_amdgcn_s_barrier();
+    // behind the barrier every wave of the CU stands at the same instruction: the loads' issue and the first fragment reads
+    // go BETWEEN the matrix instructions, whose operands are in registers already
+    mma1(f2, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    R_GLDS2(v16, sa, slot + wA);
+    __builtin_amdgcn_sched_barrier(0);
+    mma1(f2, 1);
+    mma1(f2, 2);
+    __builtin_amdgcn_sched_barrier(0);
+    R_GLDS(v16, sb, slot + wB);
+    __builtin_amdgcn_sched_barrier(0);
+    mma1(f2, 3);
+    sa += advance ? stagea : 0;
+    sb += advance ? stageb : 0;
+    __builtin_amdgcn_sched_barrier(0);
+    read(f0, na, nbb, K0());
+    __builtin_amdgcn_sched_barrier(0);
+    mma1(f2, 4);
+    mma1(f2, 5);
+    mma1(f2, 6);
+    mma1(f2, 7);
+    __builtin_amdgcn_sched_barrier(0);
+    read(f1, na, nbb, K1());
+    __builtin_amdgcn_sched_barrier(0);
+    mma(f3);
+    s++;
+    __builtin_amdgcn_sched_barrier(0);
+  };
   // Invariant at the start of a tile: its first THREE stages are in LDS, waited for by every wave before the epilogue of the tile
   // before it (or in the prologue), and the first two k-steps' fragments are on their way to f0 / f1.  The waits of a tile's
   // first two stages therefore name no loads -- they could not: the previous tile's 64 atomics per thread are still on their
   // way, they complete out of order with the loads, and a count cannot tell the two apart.  From the third stage on the count
-  // is back to "all but the newest three".  ONE loop body serves every stage (a boundary stage differs in scalar values only).
+  // is back to "all but the newest three".  A boundary stage differs from the others in scalar values only.
   for(;;) {
 #pragma unroll
     for(int i = 0; i < 4; i++)
 #pragma unroll
       for(int j = 0; j < 2; j++) acc[i][j] = (double4_t){0.0, 0.0, 0.0, 0.0};
-    int nti = 0, ntj = 0;
     const unsigned nxt = find(cur + nwg, nti, ntj);
-    const bool has_next = nxt != 0xffffffffu;
+    has_next = nxt != 0xffffffffu;
+    s = 0;
+    if(!STAIR) {
+      if(q == 1 && s < KT) { stage(pa1, pb1, pa2, pb2, lds0 + R_STAGE * 8); q = 2; }
+      if(q == 2 && s < KT) { stage(pa2, pb2, pa0, pb0, lds0 + 2 * R_STAGE * 8); q = 0; }
 #pragma unroll 1
-    for(int s = 0; s < KT; s++) {
-      if(s + 3 == KT && has_next) aim(nti, ntj);      // the load cursor moves on to the next tile's first three stages
-      // (at the end of the last tile the cursor stays on the last stage: it is fetched again into a free slot, so that the count
-      //  of loads in flight stays what the waits assume -- and nothing beyond the operands is touched)
-      const bool advance = has_next || s + 4 < KT;
-      const unsigned nslot = slot == lds0 + 2 * R_STAGE * 8 ? lds0 : slot + R_STAGE * 8;
-      const unsigned na = nslot + fa, nbb = nslot + fb;
-      R_WAIT(f0, 6);      // (f0 and f1 were requested in this order; f1's six reads may still be out)
-      mma(f0);
-      read(f2, pa, pb, K2());
-      R_WAIT(f1, 6);
-      mma(f1);
-      read(f3, pa, pb, K3());
-      // the next stage has landed (the three loads of the one after it may still fly) and every fragment of this one is in registers
-      if(s >= 2) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      R_WAIT(f2, 0);
-      R_WAIT(f3, 0);
-      __builtin_amdgcn_s_barrier();
-      // behind the barrier every wave of the CU stands at the same instruction: the loads' issue and the first fragment reads
-      // go BETWEEN the matrix instructions, whose operands are in registers already
-      mma1(f2, 0);
-      __builtin_amdgcn_sched_barrier(0);
-      R_GLDS2(v16, sa, slot + wA);
-      __builtin_amdgcn_sched_barrier(0);
-      mma1(f2, 1);
-      mma1(f2, 2);
-      __builtin_amdgcn_sched_barrier(0);
-      R_GLDS(v16, sb, slot + wB);
-      __builtin_amdgcn_sched_barrier(0);
-      mma1(f2, 3);
-      sa += advance ? stagea : 0;
-      sb += advance ? stageb : 0;
-      __builtin_amdgcn_sched_barrier(0);
-      read(f0, na, nbb, K0());
-      __builtin_amdgcn_sched_barrier(0);
-      mma1(f2, 4);
-      mma1(f2, 5);
-      mma1(f2, 6);
-      mma1(f2, 7);
-      __builtin_amdgcn_sched_barrier(0);
-      read(f1, na, nbb, K1());
-      __builtin_amdgcn_sched_barrier(0);
-      mma(f3);
-      slot = nslot;
-      pa = na;
-      pb = nbb;
+      while(s + 3 <= KT) {
+        stage(pa0, pb0, pa1, pb1, lds0);
+        stage(pa1, pb1, pa2, pb2, lds0 + R_STAGE * 8);
+        stage(pa2, pb2, pa0, pb0, lds0 + 2 * R_STAGE * 8);
+      }
+      if(s < KT) { stage(pa0, pb0, pa1, pb1, lds0); q = 1; }
+      if(s < KT) { stage(pa1, pb1, pa2, pb2, lds0 + R_STAGE * 8); q = 2; }
+    } else {
+#pragma unroll 1
+      while(s < KT) {
+        const unsigned sl = lds0 + (unsigned)q * (R_STAGE * 8), nq = q == 2 ? 0 : q + 1, nsl = lds0 + nq * (R_STAGE * 8);
+        stage(sl + fa, sl + fb, nsl + fa, nsl + fb, sl);
+        q = (int)nq;
+      }
     }
     // the next tile's three stages (or the repeated fetches past the end) have landed; f0 / f1 hold its first fragments
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -942,14 +966,15 @@ __global__ void __launch_bounds__(1024, 1) gemm_nt_ring_kernel(const RingArgs g,
 template <int ROLE>
 int launch_ring(const GemmArgs& g, hipStream_t s)
 {
-  static std::atomic<uint64_t> attr_set{0};
+  static std::atomic<uint64_t> attr_set[2];      // by instance (staircase or not): one bit per device
   static std::atomic<int> cus{0};
-  auto kern = gemm_nt_ring_kernel<ROLE>;
+  const int inst = g.tri == 5 ? 1 : 0;
+  auto kern = inst ? gemm_nt_ring_kernel<ROLE, true> : gemm_nt_ring_kernel<ROLE, false>;
   int dev = 0;
   GPC_HIP_CHECK(hipGetDevice(&dev));
-  if(!(attr_set.load() >> (dev & 63) & 1)) {
+  if(!(attr_set[inst].load() >> (dev & 63) & 1)) {
     GPC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, R_LDS_BYTES));
-    attr_set.fetch_or(1ull << (dev & 63));
+    attr_set[inst].fetch_or(1ull << (dev & 63));
   }
   if(cus.load() == 0) {
     int n = 0;
