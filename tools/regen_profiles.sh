@@ -9,6 +9,8 @@ cp gpurun_out/profiles_$TAG/pmc_bench_traffic.json profiles/${TAG}_pmc_bench_tra
 python bench.py > gpurun_out/profiles_$TAG/bench_default.json 2> gpurun_out/regen_bench_default.err
 GPC_BENCH_GRID=1 python bench.py --no-cpu-baseline > gpurun_out/profiles_$TAG/bench_cfg3_grid_1x1.json 2> gpurun_out/regen_bench_grid.err
 python tools/grid_costs.py gpurun_out/profiles_$TAG/grid_costs.json > gpurun_out/regen_grid_costs.log 2>&1
+python bench.py --workload cfg4 --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/profiles_$TAG/bench_cfg4_1gpu.json 2> gpurun_out/regen_bench_cfg4.err
+python tools/posterior_bench.py 65536 1024 > gpurun_out/profiles_$TAG/posterior_cfg3.txt 2>&1
 python bench.py --workload cfg2 --steps 20 --warmup 3 > gpurun_out/profiles_$TAG/bench_cfg2.json 2> gpurun_out/regen_bench_cfg2.err
 bash tools/make_profiles.sh $TAG > gpurun_out/regen_make_profiles.log 2>&1
 bash tools/pmc_kgrad.sh $TAG > gpurun_out/regen_pmc_kgrad.log 2>&1
