@@ -237,7 +237,7 @@ def cpu_reference_binary(cfg, sample_n):
         return {"value": None, "error": str(e)[:200]}
 
 
-def pmc_traffic(workload, single_gpu_path, kernel_pattern="gemm_nt_ring_kernel<1>"):
+def pmc_traffic(workload, single_gpu_path, kernel_pattern="gemm_nt_ring_kernel<1,"):
     """HBM bytes per trailing-update launch from the committed PMC passes of this command (tools/pmc_bench_traffic.sh ->
     profiles/rNN_pmc_bench_traffic.json).  REPLAYED, not collected in this run: counters need a rocprofv3 wrapper."""
     import glob
@@ -530,8 +530,8 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
-    # trailing updates, two populations (potrf.hip): the ones that take the ring kernel (gemm_nt_ring_kernel<1>: 256 x 128 tiles,
-    # one persistent workgroup per CU -- every update with at least GPC_GEMM_RING_MINM rows, i.e. nearly all the flops) and the
+    # trailing updates, two populations (potrf.hip): the ones that take the ring kernel (gemm_nt_ring_kernel<1,: 256 x 128 tiles,
+    # one persistent workgroup per CU -- every update with at least GPC_GEMM_RING_MINTILES = 5120 such tiles = 18 432 rows, i.e. nearly all the flops) and the
     # smaller ones on gemm_nt_fast_kernel<4, 1, false, true>.  The roofline's dominant kernel is the first whenever it ran.
     rest_n, rest_ms, rest_flops = api.profile_read(0, reset=True)
     ring_n, ring_ms, ring_flops = api.profile_read(2, reset=True)
@@ -639,12 +639,12 @@ def main():
         achieved = dom_flops / (dom_ms * 1e-3) * 1e-12 if dom_ms > 0 else 0.0
         potrf_flops = N ** 3 / 3.0
         traffic, traffic_src = pmc_traffic(args.workload if not args.n else "custom", g is None,
-                                           "gemm_nt_ring_kernel<1>" if on_ring else "gemm_nt_fast_kernel<4, 1,")
+                                           "gemm_nt_ring_kernel<1," if on_ring else "gemm_nt_fast_kernel<4, 1,")
         jobs = world if replicas else 1
         roof = {"bound": "mfma",
-                "kernel": ("gemm_nt_ring_kernel<1> (the trailing updates of gpc_potrf_f64 with >= GPC_GEMM_RING_MINM rows: %.1f %% of all "
+                "kernel": ("gemm_nt_ring_kernel<1, false> (the trailing updates of gpc_potrf_f64 with >= 18 432 rows: %.1f %% of all "
                            "trailing-update flops)" % (100.0 * ring_flops / max(syrk_flops, 1.0))) if on_ring else
-                          ("gemm_nt_ring_kernel<1> where a launch has >= 5120 tiles of 256 x 128, else gemm_nt_fast_kernel<4, 1, false, true> "
+                          ("gemm_nt_ring_kernel<1, true> where a launch has >= 5120 tiles of 256 x 128, else gemm_nt_fast_kernel<4, 1, false, true> "
                            "(trailing updates U1 + U2 of the grid's rank 0, 2-D staircase; both kernels in one population)" if g is not None
                            else "gemm_nt_fast_kernel<4, 1, false, true> (trailing updates of gpc_potrf_f64)"),
                 "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",

@@ -1119,21 +1119,27 @@ static int gemm_ex(bool transa, bool transb, int64_t M, int64_t N, int64_t K, do
                    const double* B, int64_t ldb, double beta, double* C, int64_t ldc, int tri, const Stair2D* st2,
                    hipStream_t s);
 
-// The ring form (gemm_nt_ring_kernel) takes an NT product from GPC_GEMM_RING_MINM rows: below, its 256 x 128 tiles are too few
-// per CU (M = 16 384: 16.25 rounds of one tile per CU cost 17) and the 128 x 128 form is level or ahead (tools/ring_msweep.py:
-// M = 12 288 / 16 384 / 20 480 / 32 768 / 49 152 at K = 1536: 65.3 / 68.6 / 70.1 / 72.4 / 73.0 against 66.8 / 68.5 / 69.5 / 70.5 / 70.8)
+// The ring form (gemm_nt_ring_kernel) takes an NT product with at least GPC_GEMM_RING_MINTILES (5120) tiles of 256 x 128 -- twenty
+// rounds of one tile per CU; a lower-triangular product reaches that at 18 432 rows.  Below, its tiles are too few per CU (M =
+// 16 384: 16.25 rounds cost 17) and the 128 x 128 form is level or ahead (tools/ring_msweep.py: M = 12 288 / 16 384 / 20 480 /
+// 32 768 / 49 152 at K = 1536: 65.3 / 68.6 / 70.1 / 72.4 / 73.0 against 66.8 / 68.5 / 69.5 / 70.5 / 70.8).  Rectangular products
+// count the same way (dpotri's rank-1024 updates of a few thousand rows against tens of thousands of columns).
 bool gemm_takes_ring(int64_t M, int64_t N, int64_t K, const double* A, int64_t lda, const double* B, int64_t ldb, int64_t ldc, int tri)
 {
   static const int ring = [] { const char* e = getenv("GPC_GEMM_RING"); return e ? atoi(e) : 1; }();
-  static const int64_t ring_minm = [] { const char* e = getenv("GPC_GEMM_RING_MINM"); return e ? atoll(e) : (int64_t)18432; }();
+  static const int64_t ring_tiles = [] { const char* e = getenv("GPC_GEMM_RING_MINTILES"); return e ? atoll(e) : (int64_t)5120; }();
   if(g_gemm_variant < 0) {
     const char* e = getenv("GPC_GEMM_VARIANT");
     g_gemm_variant = e ? atoi(e) : 2;
     if(g_gemm_variant < 0 || g_gemm_variant > 2) g_gemm_variant = 2;
   }
   const bool vec = ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B)) & 15) == 0 && (lda % 2 == 0) && (ldb % 2 == 0);
-  return ring && g_gemm_variant == 2 && vec && K >= 96 && (K % BK) == 0 && (ldc % 2) == 0 && (tri == 0 || tri == 1) && M >= ring_minm &&
-         N >= ring_minm && (M % R_BM) == 0 && (N % R_BN) == 0 && M < 0x7fffffff && N < 0x7fffffff && g_gemm_kstart == 0 && g_gemm_kend == 0;
+  if(!(ring && g_gemm_variant == 2 && vec && K >= 96 && (K % BK) == 0 && K < 0x7fffffff && (ldc % 2) == 0 && (tri == 0 || tri == 1) &&
+       M > 0 && N > 0 && (M % R_BM) == 0 && (N % R_BN) == 0 && M < 0x7fffffff && N < 0x7fffffff && g_gemm_kstart == 0 && g_gemm_kend == 0))
+    return false;
+  const int64_t tm = M / R_BM, tn = N / R_BN;
+  const int64_t count = tri == 1 ? tm * (tm + 1) : tm * tn;      // lower: tile row ti holds the 2 ti + 2 tile columns that reach the diagonal
+  return count >= ring_tiles;
 }
 
 int gemm(bool transa, bool transb, int64_t M, int64_t N, int64_t K, double alpha, const double* A, int64_t lda,

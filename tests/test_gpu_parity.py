@@ -1206,13 +1206,13 @@ print("RESULT", info, repr(ld), int(b"timed out" in msg), res[0][2], repr(res[0]
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("env", [{"GPC_GEMM_RING": "0"}, {"GPC_GEMM_RING_MINM": "2048"}, {"GPC_PANEL_FLOW_LEAN": "1"},
+@pytest.mark.parametrize("env", [{"GPC_GEMM_RING": "0"}, {"GPC_GEMM_RING_MINTILES": "64"}, {"GPC_PANEL_FLOW_LEAN": "1"},
                                  {"GPC_NB_TABLE": "2048=2048,8192=512", "GPC_PANEL_FLOW_MAXROWS": "3000"},
                                  {"GPC_PANEL_INV_MINROWS": "1024"}, {"GPC_PANEL_INV_MINROWS": "512", "GPC_NB": "512"},
                                  {"GPC_PANEL_INV_MINROWS": "1024", "GPC_GEMM_KEND_LPT": "0"}, {"GPC_PANEL_FLOW_LEAN_MINROWS": "1024"},
                                  {"GPC_PANEL_INV_MINROWS": "512", "GPC_NB": "1536"}])
 def test_alternative_kernel_configurations_factor_the_same_matrix(env):
-    """The A/B switches of DESIGN's appendix select other DEVICE code paths (the 128 x 128 trailing update everywhere, the ring kernel from 2048 rows, the
+    """The A/B switches of DESIGN's appendix select other DEVICE code paths (the 128 x 128 trailing update everywhere, the ring kernel from 64 tiles (2048 rows), the
     two-per-CU dataflow panel kernel -- for every launch, or from 1024 rows --, other panel widths with the launch chain for tall
     panels, the tile-inverse form of a panel -- which the default configuration only takes from 28 672 rows -- at this size, with its
     k-limited product in either tile order and over two super-tile columns); each must still be a correct

@@ -7,8 +7,8 @@ export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/profiles_$TAG
 mkdir -p $OUT; cd /tmp
-# GPC_BENCH_PHASES=0: nothing but the timed steps runs, so the dispatches named gemm_nt_ring_kernel<1> are exactly the trailing
-# updates of ONE factor that take the ring kernel (round 5: every update with >= GPC_GEMM_RING_MINM rows; the smaller ones stay on
+# GPC_BENCH_PHASES=0: nothing but the timed steps runs, so the dispatches named gemm_nt_ring_kernel<1, are exactly the trailing
+# updates of ONE factor that take the ring kernel (round 5: every update with >= 5120 tiles of 256 x 128 = 18 432 rows; the smaller ones stay on
 # gemm_nt_fast_kernel<4, 1, ...> and are collected beside them)
 export GPC_BENCH_PHASES=0
 CMD="python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline"
@@ -20,7 +20,7 @@ done
 python - $OUT/pmc_bench_traffic.json <<'PY'
 import sqlite3, glob, json, sys, collections
 res = {"command": "GPC_BENCH_PHASES=0 rocprofv3 --pmc <C> -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline  (C = FETCH_SIZE, WRITE_SIZE; separate passes)",
-       "kernel": "gemm_nt_ring_kernel<1> (the trailing-update launches that take the ring kernel)", "kernel_pattern": "gemm_nt_ring_kernel<1>",
+       "kernel": "gemm_nt_ring_kernel<1, false> (the trailing-update launches that take the ring kernel)", "kernel_pattern": "gemm_nt_ring_kernel<1,",
        "units": "counter values are KB summed over the 8 XCDs per dispatch"}
 def collect(pattern):
     out = {}
@@ -36,7 +36,7 @@ def collect(pattern):
                 tot += v; n += 1; dur += d
         out[c] = {"dispatches": n, "sum_kb": tot, "avg_kb_per_dispatch": tot / max(n, 1), "sum_duration_ms_under_pmc": dur / 1e6}
     return out
-res.update(collect("gemm_nt_ring_kernel<1>"))
+res.update(collect("gemm_nt_ring_kernel<1,"))
 small = collect("gemm_nt_fast_kernel<4, 1,")
 res["smaller_updates_gemm_nt_fast_kernel"] = dict(small, hbm_bytes_per_launch=(2.0 * small["FETCH_SIZE"]["avg_kb_per_dispatch"] + small["WRITE_SIZE"]["avg_kb_per_dispatch"]) * 1024.0)
 f, w = res["FETCH_SIZE"], res["WRITE_SIZE"]
