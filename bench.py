@@ -251,6 +251,8 @@ def pmc_traffic(workload, single_gpu_path, kernel_pattern="gemm_nt_ring_kernel<1
             j = json.load(f)
         if j.get("kernel_pattern", "gemm_nt_fast_kernel<4, 1,") != kernel_pattern:      # counters of another kernel's launches
             return None, None
+        if not j.get("FETCH_SIZE", {}).get("dispatches"):                                # (a file that matched no dispatch)
+            return None, None
         return float(j["hbm_bytes_per_launch"]), os.path.relpath(files[-1], ROOT)
     except (OSError, ValueError, KeyError):
         return None, None
