@@ -467,10 +467,18 @@ __global__ void __launch_bounds__(128 * NWN, NWN) gemm_nt_fast_kernel(const Gemm
     KT = KT - kt0 < per ? KT - kt0 : per;
     if(KT < 0) KT = 0;
   }
-  const double* pa = g.A + ra + ((int64_t)(t >> 6) + kfirst) * g.lda;
-  const double* pb = Bop + rb + ((int64_t)(t >> 6) + kfirst) * g.ldb;
-  int64_t stepa = (int64_t)KROWS * g.lda, stepb = (int64_t)KROWS * g.ldb;
-  int64_t stagea = (int64_t)BK * g.lda, stageb = (int64_t)BK * g.ldb;
+  // Staging loads as UNIFORM base + per-lane 32-bit byte offset (round 5): the base is advanced on the scalar unit, the offset never
+  // changes, so the loads cost no vector instruction (round 4 advanced four 64-bit per-lane pointers per stage; every vector
+  // instruction in this loop is paid for in matrix-pipe time, see the ring kernel).  The lane offsets stay below 2^32: two rows of
+  // a tile (m-contiguous operand) or 128 rows x lda doubles (k-contiguous: lda < 2^22 doubles is checked by the launcher).
+  const int wk = __builtin_amdgcn_readfirstlane(t >> 6);      // this wave's k-row within a pass (uniform)
+  const int64_t tile_a = A_KC ? (m0 > g.M - BM ? (g.M > BM ? g.M - BM : 0) : m0) : 0;      // (k-contiguous: the tile's first row, kept inside the matrix)
+  const int64_t tile_b = B_KC ? (n0 > g.N - BN ? (g.N > BN ? g.N - BN : 0) : n0) : 0;
+  const char* sa = reinterpret_cast<const char*>(g.A + ((int64_t)wk + kfirst) * g.lda);
+  const char* sb = reinterpret_cast<const char*>(Bop + ((int64_t)wk + kfirst) * g.ldb);
+  unsigned va = (unsigned)(ra * 8), vb = (unsigned)(rb * 8);
+  int64_t stepa = (int64_t)KROWS * g.lda * 8, stepb = (int64_t)KROWS * g.ldb * 8;      // bytes between a thread's passes
+  int64_t stagea = (int64_t)BK * g.lda * 8, stageb = (int64_t)BK * g.ldb * 8;         // ... and between stages
   const int lds_w = (t >> 6) * STRIDE_MC + 2 * lane;  // [k][m] image, k = (t>>6) + KROWS*i
   // k-contiguous operand: thread = (rows 2 (t >> 3), +1; k = 2 (t & 7), +1): the two passes are ADJACENT rows, so their distance
   // is the leading dimension (uniform, like the m-contiguous form's) and one clamp -- the row pair into the matrix -- serves
@@ -480,18 +488,21 @@ __global__ void __launch_bounds__(128 * NWN, NWN) gemm_nt_fast_kernel(const Gemm
     int64_t r0 = m0 + 2 * (t >> 3);
     if(r0 > g.M - 2) r0 = g.M - 2;
     if(r0 < 0) r0 = 0;
-    pa = g.A + 2 * (t & 7) + r0 * g.lda;
-    stepa = g.lda;
-    stagea = BK;
+    sa = reinterpret_cast<const char*>(g.A + tile_a * g.lda);
+    va = (unsigned)(((r0 - tile_a) * g.lda + 2 * (t & 7)) * 8);
+    stepa = g.lda * 8;
+    stagea = BK * 8;
   }
   if(B_KC) {
     int64_t r0 = n0 + 2 * (t >> 3);
     if(r0 > g.N - 2) r0 = g.N - 2;
     if(r0 < 0) r0 = 0;
-    pb = g.B + 2 * (t & 7) + r0 * g.ldb;
-    stepb = g.ldb;
-    stageb = BK;
+    sb = reinterpret_cast<const char*>(g.B + tile_b * g.ldb);
+    vb = (unsigned)(((r0 - tile_b) * g.ldb + 2 * (t & 7)) * 8);
+    stepb = g.ldb * 8;
+    stageb = BK * 8;
   }
+  auto ld2 = [](const char* base, const unsigned off) -> double2_t { return *reinterpret_cast<const double2_t*>(base + off); };
   const int lwa = A_KC ? lds_wk : lds_w, lwb = B_KC ? lds_wk : lds_w;
   constexpr int LPA = A_KC ? STRIDE_KC : KROWS * STRIDE_MC;   // LDS distance between the passes of one operand
   constexpr int LPB = B_KC ? STRIDE_KC : KROWS * STRIDE_MC;
@@ -511,8 +522,8 @@ __global__ void __launch_bounds__(128 * NWN, NWN) gemm_nt_fast_kernel(const Gemm
   if(KT > 0) {
 #pragma unroll
     for(int i = 0; i < PASSES; i++) {
-      ra_[i] = *reinterpret_cast<const double2_t*>(pa + i * stepa);
-      rb_[i] = *reinterpret_cast<const double2_t*>(pb + i * stepb);
+      ra_[i] = ld2(sa + i * stepa, va);
+      rb_[i] = ld2(sb + i * stepb, vb);
     }
 #pragma unroll
     for(int i = 0; i < PASSES; i++) {
@@ -520,75 +531,113 @@ __global__ void __launch_bounds__(128 * NWN, NWN) gemm_nt_fast_kernel(const Gemm
       *reinterpret_cast<double2_t*>(lds + OP_ELEMS + lwb + i * LPB) = rb_[i];
     }
     if(PF2 && KT > 1) {   // stage 1 into the first set
-      pa += stagea;
-      pb += stageb;
+      sa += stagea;
+      sb += stageb;
 #pragma unroll
       for(int i = 0; i < PASSES; i++) {
-        ra_[i] = *reinterpret_cast<const double2_t*>(pa + i * stepa);
-        rb_[i] = *reinterpret_cast<const double2_t*>(pb + i * stepb);
+        ra_[i] = ld2(sa + i * stepa, va);
+        rb_[i] = ld2(sb + i * stepb, vb);
       }
     }
   }
   __syncthreads();
 
   // fragment (row = base + s*16 + (lane & 15), k = kk*4 + (lane >> 4)): [k][m] image: + s*16 + kk*4*STRIDE_MC; [m][k]: + s*16*STRIDE_KC + kk*4
-  const int fa = A_KC ? (wm * 64 + (lane & 15)) * STRIDE_KC + (lane >> 4) : wm * 64 + (lane & 15) + (lane >> 4) * STRIDE_MC;
-  const int fb = B_KC ? (wn * (16 * NT) + (lane & 15)) * STRIDE_KC + (lane >> 4) : wn * (16 * NT) + (lane & 15) + (lane >> 4) * STRIDE_MC;
-  constexpr int FSA = A_KC ? 16 * STRIDE_KC : 16, FKA = A_KC ? 4 : 4 * STRIDE_MC;
-  constexpr int FSB = B_KC ? 16 * STRIDE_KC : 16, FKB = B_KC ? 4 : 4 * STRIDE_MC;
+  // Read by ds_read_b64 with the whole offset -- buffer, k-step, sub-tile -- as the instruction's immediate (inline asm: hipcc
+  // pairs plain loads into ds_read2_b64, whose 8-bit offsets cost about seven address additions per stage on the vector unit the
+  // matrix instructions need).  hipcc does not count these reads: each fragment is an in / out operand of its own wait.
+  const unsigned lbase = (unsigned)(size_t)(__attribute__((address_space(3))) double*)lds;
+  const unsigned fa = lbase + 8u * (unsigned)(A_KC ? (wm * 64 + (lane & 15)) * STRIDE_KC + (lane >> 4) : wm * 64 + (lane & 15) + (lane >> 4) * STRIDE_MC);
+  const unsigned fb = lbase + 8u * (unsigned)(OP_ELEMS + (B_KC ? (wn * (16 * NT) + (lane & 15)) * STRIDE_KC + (lane >> 4)
+                                                                 : wn * (16 * NT) + (lane & 15) + (lane >> 4) * STRIDE_MC));
+  constexpr int FSA = 8 * (A_KC ? 16 * STRIDE_KC : 16), FKA = 8 * (A_KC ? 4 : 4 * STRIDE_MC);      // bytes
+  constexpr int FSB = 8 * (B_KC ? 16 * STRIDE_KC : 16), FKB = 8 * (B_KC ? 4 : 4 * STRIDE_MC);
+#define F_DSR(dst, addr, off) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
+  struct Frag { double a[4], b[NT]; };
+  const int KTi = (int)KT;      // (32-bit loop control stays on the scalar unit; 64-bit comparisons went through the vector one)
 
-  // one stage: its 4 k-steps of MFMAs; behind the first of them the loads of stage `kt + ahead` into (la, lb); at its end the
-  // registers (sa, sb) -- stage kt + 1 -- go to the other LDS buffer
-  auto stage = [&](const int64_t kt, double2_t (&la)[PASSES], double2_t (&lb)[PASSES], double2_t (&sa)[PASSES],
-                   double2_t (&sb)[PASSES], const int ahead) {
-    const double* As = lds + (kt & 1) * STAGE_ELEMS;
-    const double* Bs = As + OP_ELEMS;
-    double* nxt = lds + ((kt + 1) & 1) * STAGE_ELEMS;
-    const bool more = (kt + 1 < KT);
-    const bool load = (kt + ahead < KT);
-#pragma unroll
-    for(int kk = 0; kk < 4; kk++) {
-      double a[4], b[NT];
-#pragma unroll
-      for(int s = 0; s < 4; s++) a[s] = As[fa + s * FSA + kk * FKA];
-#pragma unroll
-      for(int s = 0; s < NT; s++) b[s] = Bs[fb + s * FSB + kk * FKB];
+  // one stage (PAR: which LDS buffer it reads): its 4 k-steps of MFMAs; behind the first of them the loads of stage `kt + ahead`
+  // into (la, lb); at its end the registers (sa_, sb_) -- stage kt + 1 -- go to the other LDS buffer
+  auto stage = [&](auto par_t, const int kt, double2_t (&la)[PASSES], double2_t (&lb)[PASSES], double2_t (&sa_)[PASSES],
+                   double2_t (&sb_)[PASSES], const int ahead) {
+    constexpr int PAR = decltype(par_t)::value;
+    double* nxt = lds + (1 - PAR) * STAGE_ELEMS;
+    const bool more = (kt + 1 < KTi);
+    const bool load = (kt + ahead < KTi);
+    Frag f[2];
+    auto read = [&](Frag& q, auto kk_t) {
+      constexpr int kk = decltype(kk_t)::value;
+      F_DSR(q.a[0], fa, PAR * STAGE_ELEMS * 8 + kk * FKA);
+      F_DSR(q.a[1], fa, PAR * STAGE_ELEMS * 8 + kk * FKA + FSA);
+      F_DSR(q.a[2], fa, PAR * STAGE_ELEMS * 8 + kk * FKA + 2 * FSA);
+      F_DSR(q.a[3], fa, PAR * STAGE_ELEMS * 8 + kk * FKA + 3 * FSA);
+      F_DSR(q.b[0], fb, PAR * STAGE_ELEMS * 8 + kk * FKB);
+      F_DSR(q.b[1], fb, PAR * STAGE_ELEMS * 8 + kk * FKB + FSB);
+      if(NT == 4) {
+        F_DSR(q.b[NT - 2], fb, PAR * STAGE_ELEMS * 8 + kk * FKB + 2 * FSB);
+        F_DSR(q.b[NT - 1], fb, PAR * STAGE_ELEMS * 8 + kk * FKB + 3 * FSB);
+      }
+    };
+    auto wait = [&](Frag& q) {
+      if(NT == 2) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(q.a[0]), "+v"(q.a[1]), "+v"(q.a[2]), "+v"(q.a[3]), "+v"(q.b[0]), "+v"(q.b[1]));
+      else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(q.a[0]), "+v"(q.a[1]), "+v"(q.a[2]), "+v"(q.a[3]), "+v"(q.b[0]), "+v"(q.b[1]), "+v"(q.b[NT - 2]), "+v"(q.b[NT - 1]));
+    };
+    auto mma = [&](const Frag& q) {
 #pragma unroll
       for(int tn = 0; tn < NT; tn++)
 #pragma unroll
-        for(int tm = 0; tm < 4; tm++)
-          acc[tm][tn] = __builtin_amdgcn_mfma_f64_16x16x4f64(b[tn], a[tm], acc[tm][tn], 0, 0, 0);
-      if(kk == 0 && load) {
-        // issue the loads behind the first MFMA group
-        pa += stagea;
-        pb += stageb;
+        for(int tm = 0; tm < 4; tm++) acc[tm][tn] = __builtin_amdgcn_mfma_f64_16x16x4f64(q.b[tn], q.a[tm], acc[tm][tn], 0, 0, 0);
+    };
+    read(f[0], std::integral_constant<int, 0>());
+    wait(f[0]);
+    mma(f[0]);
+    if(load) {
+      // issue the loads behind the first MFMA group
+      sa += stagea;
+      sb += stageb;
 #pragma unroll
-        for(int i = 0; i < PASSES; i++) {
-          la[i] = *reinterpret_cast<const double2_t*>(pa + i * stepa);
-          lb[i] = *reinterpret_cast<const double2_t*>(pb + i * stepb);
-        }
+      for(int i = 0; i < PASSES; i++) {
+        la[i] = ld2(sa + i * stepa, va);
+        lb[i] = ld2(sb + i * stepb, vb);
       }
     }
+    read(f[1], std::integral_constant<int, 1>());
+    wait(f[1]);
+    mma(f[1]);
+    read(f[0], std::integral_constant<int, 2>());
+    wait(f[0]);
+    mma(f[0]);
+    read(f[1], std::integral_constant<int, 3>());
+    wait(f[1]);
+    mma(f[1]);
     if(more) {
 #pragma unroll
       for(int i = 0; i < PASSES; i++) {
-        *reinterpret_cast<double2_t*>(nxt + lwa + i * LPA) = sa[i];
-        *reinterpret_cast<double2_t*>(nxt + OP_ELEMS + lwb + i * LPB) = sb[i];
+        *reinterpret_cast<double2_t*>(nxt + lwa + i * LPA) = sa_[i];
+        *reinterpret_cast<double2_t*>(nxt + OP_ELEMS + lwb + i * LPB) = sb_[i];
       }
     }
     __syncthreads();
   };
+  using P0 = std::integral_constant<int, 0>;
+  using P1 = std::integral_constant<int, 1>;
   if(!kPF2) {
-    for(int64_t kt = 0; kt < KT; kt++) stage(kt, ra_, rb_, ra_, rb_, 1);
+    int kt = 0;
+    for(; kt + 1 < KTi; kt += 2) {
+      stage(P0(), kt, ra_, rb_, ra_, rb_, 1);
+      stage(P1(), kt + 1, ra_, rb_, ra_, rb_, 1);
+    }
+    if(kt < KTi) stage(P0(), kt, ra_, rb_, ra_, rb_, 1);
   } else {
     // even stages: set 1 (ra_) holds stage kt + 1, stage kt + 2 is loaded into set 2; odd stages the other way round
-    int64_t kt = 0;
-    for(; kt + 1 < KT; kt += 2) {
-      stage(kt, ra2_, rb2_, ra_, rb_, 2);
-      stage(kt + 1, ra_, rb_, ra2_, rb2_, 2);
+    int kt = 0;
+    for(; kt + 1 < KTi; kt += 2) {
+      stage(P0(), kt, ra2_, rb2_, ra_, rb_, 2);
+      stage(P1(), kt + 1, ra_, rb_, ra2_, rb2_, 2);
     }
-    if(kt < KT) stage(kt, ra2_, rb2_, ra_, rb_, 2);
+    if(kt < KTi) stage(P0(), kt, ra2_, rb2_, ra_, rb_, 2);
   }
+#undef F_DSR
 
   const double alpha = g.alpha, beta = g.beta;
   const bool full_mn = (m0 + BM <= g.M) && (n0 + BN <= g.N);
@@ -1332,8 +1381,9 @@ static int gemm_ex(bool transa, bool transb, int64_t M, int64_t N, int64_t K, do
   // stages a PAIR of operand rows either way (one clamp per pair keeps the distance between its two loads uniform); odd sizes
   // and k-ranges that are not whole stages stay on the generic kernel below.
   static const int fast_kc = [] { const char* e = getenv("GPC_GEMM_FAST_KC"); return e ? atoi(e) : 1; }();
+  // (a k-contiguous operand's per-lane staging offset spans up to 3 x 128 rows of it: 384 lda doubles must stay below 2^32 bytes)
   if(fast_kc && g_gemm_variant == 2 && (a_kc || b_kc) && vec && g.K > 0 && (g.K % BK) == 0 && (M % 2) == 0 && (N % 2) == 0 &&
-     (tri == 0 || tri == 1 || tri == 2 || tri == 3)) {
+     (tri == 0 || tri == 1 || tri == 2 || tri == 3) && lda < 1300000 && ldb < 1300000) {
     g.kstart = g.kend = 0;
     // operands two stages ahead (GPC_GEMM_KC_PF2, default by form): the row-staged instances sit at the 128-register limit of
     // four waves per SIMD, the TN one over it (24 spilled registers: 65.5 TFLOP/s at M = N = K = 8192 against 68.7 one stage
