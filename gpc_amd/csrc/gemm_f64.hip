@@ -894,7 +894,11 @@ __global__ void __launch_bounds__(1024, 1) gemm_nt_ring_kernel(const RingArgs g,
     mma(f1);
     read(f3, pa, pb, K3());
     // the next stage has landed (the three loads of the one after it may still fly) and every fragment of this one is in registers
+#ifdef GPC_RING_ABL_LATEWAIT      // (timing only, tools/ring_abl.sh: is the third stage's wait held up by the tile before's atomics?)
+    if(s >= GPC_RING_ABL_LATEWAIT) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+#else
     if(s >= 2) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+#endif
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     R_WAIT(f2, 0);
     R_WAIT(f3, 0);
@@ -990,9 +994,19 @@ __global__ void __launch_bounds__(1024, 1) gemm_nt_ring_kernel(const RingArgs g,
             if(ok) {
               double* p = p0 + tm * 16 + (int64_t)(tn * 16 + 4 * r) * g.ldc;
               double v = alpha * acc[tm][tn][r];
+#if defined(GPC_RING_ABL_STORE)      // (timing only: what a plain store costs where the atomic stands)
+              if(g.atomic_c) {
+                *p = v;
+              } else {
+#elif defined(GPC_RING_ABL_NOEPI)
+              if(g.atomic_c) {
+                if(v == 1.2345e300) *p = v;
+              } else {
+#else
               if(g.atomic_c) {
                 (void)unsafeAtomicAdd(p, v);
               } else {
+#endif
                 if(beta != 0.0) v += beta * (*p);
                 *p = v;
               }
