@@ -1407,6 +1407,13 @@ static int gemm_ex(bool transa, bool transb, int64_t M, int64_t N, int64_t K, do
     if(a_kc) return (kc_pf2 != 0) ? launch_fast_kc<true, false, true>(g, grid, s) : launch_fast_kc<true, false, false>(g, grid, s);
     return (kc_pf2 != 0) ? launch_fast_kc<false, true, true>(g, grid, s) : launch_fast_kc<false, true, false>(g, grid, s);
   }
+  // GPC_GEMM_LOG=1 (measurement aid): one line per product on stderr -- shape, role, k-limits, and whether the ring form takes it
+  static const int gemm_log = [] { const char* e = getenv("GPC_GEMM_LOG"); return e ? atoi(e) : 0; }();
+  if(gemm_log)
+    fprintf(stderr, "gpc gemm %c%c M=%lld N=%lld K=%lld tri=%d role=%d kstart=%d kend=%d beta=%g ld=%lld,%lld,%lld ring=%d\n", transa ? 'T' : 'N',
+            transb ? 'T' : 'N', (long long)M, (long long)N, (long long)K, tri, g_gemm_trailing, g.kstart, g.kend, beta, (long long)lda,
+            (long long)ldb, (long long)ldc,
+            (int)(!g.kstart && !g.kend && !a_kc && !b_kc && gemm_takes_ring(M, N, K, A, lda, B, ldb, ldc, tri)));
   if(!g.kstart && !g.kend && !a_kc && !b_kc && gemm_takes_ring(M, N, K, A, lda, B, ldb, ldc, tri)) {
     if(g_gemm_trailing == 1) return launch_ring<1>(g, s);
     if(g_gemm_trailing == 3) return launch_ring<3>(g, s);
