@@ -322,7 +322,11 @@ __global__ void __launch_bounds__(256, 2) kern_grad_sym_kernel(const KSpecDev ks
         for(int tm = 0; tm < 4; tm++) {
           const int64_t gi = i0 + wm * 64 + tm * 16 + (lane & 15);
           const int64_t gic = (KFAST || gi < g.N) ? gi : (g.N - 1);
+#ifdef GPC_KG_ABL_NOLOAD
+          double v = (double)(gic & 7);
+#else
           double v = g.cg[gic + gjc * g.ldc];
+#endif
           if(ND > 0) {   // covGrad from invK: same operations as covgrad_kernel / covgrad_multi_kernel, element by element
             double aa = 0.0;
 #pragma unroll
@@ -358,7 +362,11 @@ __global__ void __launch_bounds__(256, 2) kern_grad_sym_kernel(const KSpecDev ks
     // FAST (round 4): a full tile strictly left of the diagonal block -- all but two tiles of a walk -- has no edge masks and no
     // diagonal elements: no selects around the loads, no 64-bit compares in the sums, weight 2 folded into the final sums
     // MODE 1 = the fast form (KG_FAST) with the table-driven exponential of gpc_exp.hpp; MODE 2 the general form with ocml's
+#ifdef GPC_KG_ABL_NOEXP      // (timing-only builds, tools/kgrad_abl.sh: -DGPC_KG_ABL_NOEXP / _NOLOAD / _NOMMA take one ingredient out)
+#define KG_EXP(x) (x)
+#else
 #define KG_EXP(x) ((MODE == 1 && NK <= 2 && GPC_KG_TABLE_EXP) ? gpc_exp_tab((x), Etab) : exp(x))
+#endif
 #define KG_FAST (MODE == 1)
 #include "kern_grad_sym_tile.inc"
 #undef KG_FAST
@@ -601,7 +609,11 @@ __global__ void __launch_bounds__(64 * NW, OCC) kern_grad_ard_sym_kernel(const K
         for(int tm = 0; tm < TM; tm++) {
           const int64_t gi = i0 + wm * RW + tm * 16 + (lane & 15);
           const int64_t gic = (KFAST || gi < g.N) ? gi : (g.N - 1);
+#ifdef GPC_KG_ABL_NOLOAD
+          double v = (double)(gic & 7);
+#else
           double v = g.cg[gic + gjc * g.ldc];
+#endif
           if(ND > 0) {
             double aa = 0.0;
 #pragma unroll
@@ -632,7 +644,11 @@ __global__ void __launch_bounds__(64 * NW, OCC) kern_grad_ard_sym_kernel(const K
 
     const bool mirror = (j0 + GMJ <= i0);
     // FAST (round 4): full tiles strictly left of the diagonal block -- no edge masks, no diagonal elements, weight 2
+#ifdef GPC_KG_ABL_NOEXP
+#define KG_EXP(x) (x)
+#else
 #define KG_EXP(x) (MODE == 1 ? gpc_exp_tab((x), Etab) : exp(x))
+#endif
 #define KG_FAST (MODE == 1)
 #include "kern_grad_ard_tile.inc"
 #undef KG_FAST
