@@ -213,6 +213,12 @@ constexpr int GMI = 128, GMJ = 64, GSJ = 80, GMDC = 32, GSI = 144;
 #ifndef GPC_KG_LEAN_NK
 #define GPC_KG_LEAN_NK 4
 #endif
+#ifndef GPC_KG_TABLE_MAXNK      // the table exponential up to this many k-steps (D <= 8), ocml's above (A/B builds move it)
+#define GPC_KG_TABLE_MAXNK 2
+#endif
+#ifndef GPC_KG_XPREF_MINNK      // the next tile's first half of covGrad requested a half ahead from this many k-steps on
+#define GPC_KG_XPREF_MINNK 3
+#endif
 typedef double gdouble4 __attribute__((ext_vector_type(4)));
 
 // MODE (round 4): the walk is two launches.  MODE 1 takes the full tiles strictly left of a row block's diagonal block -- all but
@@ -339,7 +345,7 @@ __global__ void __launch_bounds__(256, 2) kern_grad_sym_kernel(const KSpecDev ks
     };
   // (D <= 8: with the table exponential the two live halves across the loop edge spill 200 registers -- 4.3 -> 22 ms --, so there
   //  the first half of a tile is requested at its top as before)
-  constexpr bool XPREF = KFAST && !LEAN && NK > 2;
+  constexpr bool XPREF = KFAST && !LEAN && NK >= GPC_KG_XPREF_MINNK;
   if(XPREF) load_cg(0, jt0 * GMJ);
 
   for(int64_t jt = jt0; jt < jt1; jt++) {
@@ -365,7 +371,7 @@ __global__ void __launch_bounds__(256, 2) kern_grad_sym_kernel(const KSpecDev ks
 #ifdef GPC_KG_ABL_NOEXP      // (timing-only builds, tools/kgrad_abl.sh: -DGPC_KG_ABL_NOEXP / _NOLOAD / _NOMMA take one ingredient out)
 #define KG_EXP(x) (x)
 #else
-#define KG_EXP(x) ((MODE == 1 && NK <= 2 && GPC_KG_TABLE_EXP) ? gpc_exp_tab((x), Etab) : exp(x))
+#define KG_EXP(x) ((MODE == 1 && NK <= GPC_KG_TABLE_MAXNK && GPC_KG_TABLE_EXP) ? gpc_exp_tab((x), Etab) : exp(x))
 #endif
 #define KG_FAST (MODE == 1)
 #include "kern_grad_sym_tile.inc"
