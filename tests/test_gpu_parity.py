@@ -128,6 +128,55 @@ def test_syrk_touches_one_triangle(api, uplo, trans, N, K):
     assert np.array_equal(other(out, k), other(C, k))     # the other triangle is untouched, bit for bit
 
 
+@pytest.mark.gpu
+def test_ring_kernel_products_vs_numpy():
+    """The persistent ring kernel (gemm_f64.hip, round 5) on products numpy can check: GPC_GEMM_RING_MINTILES=1 sends every NT product
+    of 256 x 128 tiles to it, GPC_GEMM_LOG=1 says so per product (asserted: a silent fall-back to the 128 x 128 kernel would test
+    nothing).  k-loops of 6 ... 64 stages (the three-slot ring entered and left at every phase), one tile and many per workgroup,
+    lower-triangular products whose last super-tile row is partial, the three epilogues (atomic beta = 1, store beta = 0, general
+    beta), and operands / results that are windows of larger arrays (leading dimensions larger than the sizes)."""
+    import subprocess
+    import sys
+    code = r'''
+import numpy as np, sys
+sys.path.insert(0, %r)
+from gpc_amd import api
+rng = np.random.RandomState(5)
+worst = 0.0
+cases = 0
+# (M, N, K, alpha, beta): plain products C = alpha A B' + beta C
+for (M, N, K, alpha, beta) in [(256, 128, 96, 1.0, 0.0), (512, 384, 112, -1.0, 1.0), (768, 2560, 128, 1.5, -0.5), (2048, 1280, 160, -1.0, 1.0),
+                               (4096, 3968, 1024, -1.0, 1.0), (256, 8192, 208, 2.0, 0.0), (8192, 128, 304, -1.0, 1.0)]:
+    A, B, C = rng.randn(M + 6, K + 2), rng.randn(N + 4, K), rng.randn(M + 2, N + 8)
+    Ad, Bd, Cd = api.from_host(A), api.from_host(B), api.from_host(C)
+    api.gemm(Ad[2:2 + M, :K], Bd[4:4 + N, :], Cd[2:2 + M, 8:8 + N], "N", "T", alpha=alpha, beta=beta)
+    want = C.copy()
+    want[2:2 + M, 8:8 + N] = alpha * A[2:2 + M, :K] @ B[4:4 + N].T + beta * C[2:2 + M, 8:8 + N]
+    got = api.to_host(Cd)
+    worst = max(worst, float(np.abs(got - want).max()) / K)       # (the frame around the window must come back untouched: it is in the max)
+    cases += 1
+# lower-triangular rank-K updates C = alpha A A' + beta C, the other triangle untouched
+for (M, K, alpha, beta) in [(256, 96, -1.0, 1.0), (1024, 1024, -1.0, 1.0), (1280, 208, -1.0, 1.0), (2304, 160, 1.0, 0.0), (3328, 1536, -1.0, 1.0),
+                            (5120, 112, 0.5, 2.0)]:
+    A, C = rng.randn(M, K), rng.randn(M, M)
+    Cd = api.from_host(C)
+    api.syrk(api.from_host(A), Cd, "L", "N", alpha=alpha, beta=beta)
+    got = api.to_host(Cd)
+    full = alpha * A @ A.T + beta * C
+    worst = max(worst, float(np.abs(np.tril(got) - np.tril(full)).max()) / K)
+    assert np.array_equal(np.triu(got, 1), np.triu(C, 1)), (M, K)
+    cases += 1
+print("RESULT", cases, repr(worst))
+''' % ROOT
+    env = dict(os.environ, GPC_GEMM_RING_MINTILES="1", GPC_GEMM_LOG="1")
+    r = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    f = [ln for ln in r.stdout.decode().splitlines() if ln.startswith("RESULT")][0].split()
+    lines = [ln for ln in r.stderr.decode().splitlines() if ln.startswith("gpc gemm")]
+    assert len(lines) == int(f[1]) == 13 and all(ln.rstrip().endswith("ring=1") for ln in lines), lines
+    assert float(f[2]) < 1e-13, f
+
+
 # ---- Cholesky -----------------------------------------------------------------------------------------------------------
 
 def test_chol_fixture(api, golden):
