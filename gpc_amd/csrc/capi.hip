@@ -170,7 +170,7 @@ static bool host_gather_on()
 }
 
 // Postponed fetches of this thread (HostFetch::defer): their pieces sit in [0, g_pending_used) of the staging buffer.  A raw
-// pointer, freed by release_workspace: thread_local objects with destructors do not survive the atexit order (see LookAhead).
+// pointer, freed by release_workspace: thread_local objects with destructors do not survive the atexit order (see AuxStream, potrf.hip).
 struct PendingFetch {
   HostFetch::Piece pieces[8];
   int n;
@@ -307,6 +307,7 @@ int HostFetch::finish(hipStream_t s)
 
 int potri_full(bool lower, int64_t N, double* A, int64_t lda, hipStream_t s);
 void release_profile();       // profile.hip
+void release_aux_stream();    // potrf.hip: the run-ahead stream and its events (trsm_rlt_flow)
 
 // the calling thread's scratch slots
 static void release_workspace()
@@ -908,6 +909,7 @@ extern "C" int gpc_shutdown(void)
   for(int d = 0; d < n; d++)
     if(hipSetDevice(d) == hipSuccess) (void)hipDeviceSynchronize();
   (void)hipSetDevice(cur);
+  gpc::release_aux_stream();
   gpc::release_profile();
   gpc::release_workspace();
   (void)hipGetLastError();

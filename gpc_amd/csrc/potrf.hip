@@ -557,6 +557,47 @@ int panel_solve_rt(const double* Lbb, int64_t lda, int nb, double* B, int64_t ld
 
 namespace {
 
+// A second stream + an event pool per host thread and device, for work that runs AHEAD of the caller's stream (trsm_rlt_flow's
+// tile inversions).  Trivially destructible on purpose: gpc_shutdown runs from atexit, i.e. after the exiting thread's
+// thread_local destructors -- a std::vector here would already be gone when release_aux_stream() walks it.
+struct AuxStream {
+  hipStream_t st;
+  int dev;
+  hipEvent_t* ev;
+  size_t count, cap, next;
+  hipEvent_t get()
+  {
+    if(next == count) {
+      if(count == cap) {
+        const size_t ncap = cap ? 2 * cap : 256;
+        hipEvent_t* ne = static_cast<hipEvent_t*>(realloc(ev, ncap * sizeof(hipEvent_t)));
+        if(!ne) return nullptr;
+        ev = ne;
+        cap = ncap;
+      }
+      hipEvent_t e;
+      if(hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
+      ev[count++] = e;
+    }
+    return ev[next++];
+  }
+};
+static_assert(std::is_trivially_destructible<AuxStream>::value, "must survive thread_local destruction (atexit order)");
+thread_local AuxStream g_aux = {nullptr, -1, nullptr, 0, 0, 0};
+
+int ensure_aux_stream()
+{
+  int dev = 0;
+  GPC_HIP_CHECK(hipGetDevice(&dev));
+  if(g_aux.st && g_aux.dev == dev) return GPC_OK;
+  int lo = 0, hi = 0;
+  GPC_HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+  GPC_HIP_CHECK(hipStreamCreateWithPriority(&g_aux.st, hipStreamNonBlocking, hi));
+  g_aux.dev = dev;
+  g_aux.count = g_aux.next = 0;   // (events of another device's pool are abandoned, not reused across devices)
+  return GPC_OK;
+}
+
 // Is the dataflow panel kernel (panel_flow.hip) in use, and up to how many rows?  GPC_PANEL_FLOW=0 turns it off (the launch
 // chain below then factors every panel), GPC_PANEL_FLOW_MAXROWS moves the height above which the chain takes over (on a tall
 // panel the chain's products are chip-wide GEMMs, the dataflow blocks' are one CU each: 1504 vs 1474 ms at N = 65 536 when
@@ -698,6 +739,15 @@ int factor_panel(int64_t N, double* A, int64_t lda, int64_t k0, int64_t nbk, int
 
 }  // namespace
 
+void release_aux_stream()     // gpc_shutdown (capi.hip)
+{
+  for(size_t i = 0; i < g_aux.count; i++) (void)hipEventDestroy(g_aux.ev[i]);
+  free(g_aux.ev);
+  g_aux.ev = nullptr;
+  g_aux.count = g_aux.cap = g_aux.next = 0;
+  if(g_aux.st) (void)hipStreamDestroy(g_aux.st);
+  g_aux.st = nullptr;
+}
 
 // Factor one tall panel (M x nb, M >= nb): diagonal blocks + substitution solve + in-panel updates.  Used by the
 // multi-GPU grid when one rank holds the whole panel (grid.hip: a 1 x pc grid).
@@ -767,6 +817,79 @@ int trsm_rlt_flow(int64_t M, int64_t n, const double* L, int64_t lda, double* B,
     if(identity_rows && rows > dense) return 0;
     return 2;
   };
+  // A DENSE right-hand side against many panels (the predictive variance's k(X*, X) L^-T: 1024 rows, 64 panels at cfg 3): the
+  // panel's launch is bound by its chain of sixteen column blocks (0.15 ms: a quarter of the chip idle for 10 of the solve's 76
+  // ms), and that chain does not depend on the right-hand side at all once the panel is taken through the INVERSE of its
+  // diagonal tile.  So the tiles are inverted on a second stream, up to three panels ahead of the caller's, which is left with
+  // the chip-wide products only: rows := rows L_bb^-T (k-limited) and the update of the columns to the right.  The inversions
+  // find their CUs in the gaps of those products (high-priority stream; they need no more than a few CUs at a time).
+  // Rounding: an explicit inverse of a 1024 x 1024 diagonal tile, as in the factorisation's tall panels (panel_by_inverse).
+  // Measured (tools/posterior_bench.py, N = 65 536): 1024 rows 75.6 -> 72.3 ms, 128 rows 54.9 -> 49.4; the trailing product beside an
+  // inversion is not slowed (1360 us either way), the inversion takes the product's whole time (1.3 ms against 0.14 alone) and so
+  // stays hidden until the products get short at the end of the sweep.  4096 rows: 257.7 -> 259.2 (the rows' own product with the
+  // inverse costs what the launch did), hence up to 2048 rows.  The launch's two-per-CU form on the second stream: slower (75.3).
+  // GPC_TRSM_AHEAD=0: off (every panel one dataflow launch on the caller's stream, as before round 5).
+  static const int ahead_env = [] { const char* e = getenv("GPC_TRSM_AHEAD"); return e ? atoi(e) : 1; }();
+  if(ahead_env && !identity_rows && !inplace && NB == 1024 && n >= 4 * NB && M >= 2 && M <= 2048 && panel_flow_maxrows() >= 2 * NB) {
+    constexpr int DEPTH = 3;
+    const int64_t npan = (n + NB - 1) / NB;
+    void* wa = nullptr;
+    GPC_CHECK(workspace(WS_AUG, sizeof(double) * (size_t)DEPTH * (size_t)NB * (size_t)NB, &wa));
+    double* ring = static_cast<double*>(wa);
+    void* wt = nullptr;
+    GPC_CHECK(workspace(WS_PANEL_TMP, sizeof(double) * (size_t)M * (size_t)NB, &wt));
+    double* T = static_cast<double*>(wt);
+    GPC_CHECK(ensure_aux_stream());
+    hipStream_t sp = g_aux.st;
+    g_aux.next = 0;
+    hipEvent_t e0 = g_aux.get();
+    if(!e0) return GPC_EHIP;
+    GPC_HIP_CHECK(hipEventRecord(e0, s));          // the factor is final, the scratch buffers' previous users are done
+    GPC_HIP_CHECK(hipStreamWaitEvent(sp, e0, 0));
+    std::vector<hipEvent_t> ready((size_t)npan, nullptr), consumed((size_t)npan, nullptr);
+    // a panel goes through its tile's inverse when the tile is whole blocks of 64 (the last, ragged one may not be)
+    auto by_inverse = [&](int64_t j) { const int64_t w = (n - j * NB < NB) ? n - j * NB : NB; return w % 64 == 0 && w >= 128; };
+    auto invert = [&](int64_t j) -> int {
+      if(!by_inverse(j)) return GPC_OK;
+      const int64_t k0 = j * NB, w = (n - k0 < NB) ? n - k0 : NB;
+      double* Li = ring + (size_t)(j % DEPTH) * (size_t)NB * (size_t)NB;
+      if(j >= DEPTH && consumed[(size_t)(j - DEPTH)]) GPC_HIP_CHECK(hipStreamWaitEvent(sp, consumed[(size_t)(j - DEPTH)], 0));
+      GPC_CHECK(set_identity(w, w, Li, w, sp));
+      GPC_CHECK(panel_flow_given(w, w, Li, w, L + k0 + k0 * lda, lda, n - k0, w, 0, w, d_info, sp));
+      GPC_CHECK(transpose_inplace(w, Li, w, sp));     // L_bb^-T (upper) -> L_bb^-1 (lower): the [n][k] operand
+      ready[(size_t)j] = g_aux.get();
+      if(!ready[(size_t)j]) return GPC_EHIP;
+      GPC_HIP_CHECK(hipEventRecord(ready[(size_t)j], sp));
+      return GPC_OK;
+    };
+    for(int64_t j = 0; j < DEPTH && j < npan; j++) GPC_CHECK(invert(j));
+    for(int64_t j = 0; j < npan; j++) {
+      const int64_t k0 = j * NB, w = (n - k0 < NB) ? n - k0 : NB, kend = k0 + w;
+      double* Bp = B + k0 * ldb;
+      if(by_inverse(j)) {
+        const double* Li = ring + (size_t)(j % DEPTH) * (size_t)NB * (size_t)NB;
+        GPC_HIP_CHECK(hipMemcpy2DAsync(T, sizeof(double) * (size_t)M, Bp, sizeof(double) * (size_t)ldb, sizeof(double) * (size_t)M, (size_t)w,
+                                       hipMemcpyDeviceToDevice, s));
+        GPC_HIP_CHECK(hipStreamWaitEvent(s, ready[(size_t)j], 0));
+        {
+          KEndScope ke;
+          GPC_CHECK(gemm(false, true, M, w, w, 1.0, T, M, Li, w, 0.0, Bp, ldb, 0, s));
+        }
+        consumed[(size_t)j] = g_aux.get();
+        if(!consumed[(size_t)j]) return GPC_EHIP;
+        GPC_HIP_CHECK(hipEventRecord(consumed[(size_t)j], s));
+      } else {
+        // (the ragged last panel: nothing is in flight on the other stream any more -- its last inversion was awaited above)
+        GPC_CHECK(panel_flow_given(M, w, Bp, ldb, L + k0 + k0 * lda, lda, n - k0, w, (int64_t)1 << 24, w, d_info, s));
+      }
+      if(j + DEPTH < npan) GPC_CHECK(invert(j + DEPTH));
+      if(kend < n) {
+        SolveScope role;
+        GPC_CHECK(gemm(false, true, M, n - kend, w, -1.0, Bp, ldb, L + kend + k0 * lda, lda, 1.0, B + kend * ldb, ldb, 0, s));
+      }
+    }
+    return GPC_OK;
+  }
   int64_t nbk = 0;
   for(int64_t k0 = 0; k0 < n; k0 += nbk) {
     const int64_t rem = n - k0;

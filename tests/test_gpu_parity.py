@@ -376,6 +376,42 @@ def test_trsm_vs_numpy(api, side, uplo, trans, diag, M, Nrhs):
     assert rel(api.to_host(Bd), ref) < 1e-10
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("ahead", ["1", "0"])
+def test_trsm_right_lower_trans_over_many_panels(ahead):
+    """X L' = B for a dense B against a factor of more than four 1024-column panels (the predictive variance's solve): with
+    GPC_TRSM_AHEAD=1 (default) the panels' diagonal tiles are inverted on a second stream, up to three panels ahead, and the
+    caller's stream runs chip-wide products only (potrf.hip: trsm_rlt_flow); with 0 every panel is one dataflow launch.  Both
+    against numpy, with a ragged last panel (n = 5000: 904 columns, not whole 64-blocks), n = 4096 + 128 (a last panel of 128), two
+    rows and 1024 rows, and B a window of a larger array; the two settings must also agree with each other to rounding."""
+    import subprocess
+    import sys
+    code = r'''
+import numpy as np, sys, scipy.linalg as sl
+sys.path.insert(0, %r)
+from gpc_amd import api
+rng = np.random.RandomState(11)
+worst = 0.0
+for (M, n) in [(2, 4096), (130, 5000), (1024, 4224), (66, 7168)]:
+    G = rng.randn(n, 40)
+    K = G @ G.T / 40.0 + 2.0 * np.eye(n)
+    L = np.linalg.cholesky(K)
+    B = rng.randn(M + 4, n + 2)
+    Bd = api.from_host(B)
+    api.trsm(api.from_host(L), Bd[2:2 + M, 2:2 + n], "R", "L", "T", "N", 0.5)
+    want = B.copy()
+    want[2:2 + M, 2:2 + n] = 0.5 * sl.solve_triangular(L, B[2:2 + M, 2:2 + n].T, lower=True).T
+    got = api.to_host(Bd)
+    worst = max(worst, float(np.abs(got - want).max() / np.abs(want).max()))
+print("RESULT", repr(worst))
+''' % ROOT
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, GPC_TRSM_AHEAD=ahead), stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       timeout=900)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    f = [ln for ln in r.stdout.decode().splitlines() if ln.startswith("RESULT")][0].split()
+    assert float(f[1]) < 1e-11, f
+
+
 def test_transpose_symmetrize_zero(api):
     for N in (1, 31, 32, 33, 100, 1000):
         A = np.random.RandomState(N).randn(N, N)
