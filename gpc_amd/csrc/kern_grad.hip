@@ -220,6 +220,19 @@ constexpr int GMI = 128, GMJ = 64, GSJ = 80, GMDC = 32, GSI = 144;
 #define GPC_KG_XPREF_MINNK 3
 #endif
 typedef double gdouble4 __attribute__((ext_vector_type(4)));
+typedef double gdouble2 __attribute__((ext_vector_type(2)));
+// Which row of a wave's patch lane l holds in its 16-row MFMA tile tm.  The matrix instruction does not care (any permutation of
+// the patch's rows, applied to the operand fragments, the row norms and covGrad alike); with tiles 2t, 2t + 1 interleaved -- rows
+// 2 (l & 15) and 2 (l & 15) + 1 of a 32-row group -- the pair's operand fragment is ONE ds_read_b128 and the pair's two covGrad loads share
+// their cache lines (N = 65 536, same box, against tile-major rows: rbf D = 4 / 8 / 16 / 32 4.33 / 4.51 / 5.54 / 6.64 -> 4.17 / 4.24 /
+// 5.35 / 6.45 ms, rbfard 5.43 / 5.66 / 7.29 / 9.66 -> 5.33 / 5.50 / 7.15 / 9.36).  The same pairing for covGrad itself -- one global_load_dwordx4 for a lane's two
+// values instead of two dwordx2 -- was built and LOSES heavily (rbf D = 8 / 32: 4.99 / 6.84 against 4.22 / 6.33 ms; rbfard 8.83 /
+// 10.66 against 5.36 / 9.04): it stays two 8-byte loads.  -DGPC_KG_OLDROW restores tile-major rows (A/B builds).
+#ifdef GPC_KG_OLDROW
+#define KG_ROW(tm) ((tm) * 16 + (lane & 15))
+#else
+#define KG_ROW(tm) (32 * ((tm) >> 1) + 2 * (lane & 15) + ((tm) & 1))
+#endif
 
 // MODE (round 4): the walk is two launches.  MODE 1 takes the full tiles strictly left of a row block's diagonal block -- all but
 // two tiles of its walk --, which need no edge masks, no diagonal test and carry weight 2: ONE predicate-free form of the tile
@@ -231,7 +244,7 @@ __global__ void __launch_bounds__(256, 2) kern_grad_sym_kernel(const KSpecDev ks
 {
   __shared__ double Xj[2][GMDC * GSJ];
   __shared__ double Nj[2][GMJ];
-  __shared__ double Xi[NK > 2 ? GMDC * GSI : 1];
+  __shared__ __attribute__((aligned(16))) double Xi[NK > 2 ? GMDC * GSI : 1];
   __shared__ double sh[4];
   __shared__ double Etab[64];
   gpc_exp_tab_fill(Etab);      // the table of gpc_exp.hpp; published by the first tile's barrier
@@ -272,7 +285,7 @@ __global__ void __launch_bounds__(256, 2) kern_grad_sym_kernel(const KSpecDev ks
     for(int kk = 0; kk < (AF_LDS ? 1 : NK); kk++)
 #pragma unroll
       for(int tm = 0; tm < 4; tm++) {
-        int64_t gi = i0 + wm * 64 + tm * 16 + (lane & 15);
+        int64_t gi = i0 + wm * 64 + KG_ROW(tm);
         if(gi > g.N - 1) gi = g.N - 1;
         int kr = kk * 4 + (lane >> 4);
         if(kr > dc - 1) kr = dc - 1;
@@ -283,7 +296,7 @@ __global__ void __launch_bounds__(256, 2) kern_grad_sym_kernel(const KSpecDev ks
   double ai[ND > 0 ? ND : 1][4];   // fused covGrad: A(i, o) of this lane's four rows
 #pragma unroll
   for(int tm = 0; tm < 4; tm++) {
-    int64_t gi = i0 + wm * 64 + tm * 16 + (lane & 15);
+    int64_t gi = i0 + wm * 64 + KG_ROW(tm);
     if(gi > g.N - 1) gi = g.N - 1;
     ni[tm] = g.n1[gi];
 #pragma unroll
@@ -326,7 +339,7 @@ __global__ void __launch_bounds__(256, 2) kern_grad_sym_kernel(const KSpecDev ks
         for(int o = 0; o < ND; o++) aj[o] = g.A[gjc + (int64_t)o * g.lda];
 #pragma unroll
         for(int tm = 0; tm < 4; tm++) {
-          const int64_t gi = i0 + wm * 64 + tm * 16 + (lane & 15);
+          const int64_t gi = i0 + wm * 64 + KG_ROW(tm);
           const int64_t gic = (KFAST || gi < g.N) ? gi : (g.N - 1);
 #ifdef GPC_KG_ABL_NOLOAD
           double v = (double)(gic & 7);
@@ -506,7 +519,7 @@ __global__ void __launch_bounds__(64 * NW, OCC) kern_grad_ard_sym_kernel(const K
   constexpr int XTS = (DP == 16) ? 17 : 49;
   __shared__ double XjT[2][GMJ * XTS];
   __shared__ double Nj[2][GMJ];
-  __shared__ double Xi[NK > 2 ? GMDC * GSI : 1];
+  __shared__ __attribute__((aligned(16))) double Xi[NK > 2 ? GMDC * GSI : 1];
   constexpr int NT = 64 * NW;           // threads
   constexpr int RW = 256 / NW;          // rows of a wave's patch: 64 or 32
   constexpr int TM = RW / 16;           // its 16-row MFMA tiles: 4 or 2
@@ -550,7 +563,7 @@ __global__ void __launch_bounds__(64 * NW, OCC) kern_grad_ard_sym_kernel(const K
     for(int kk = 0; kk < (AF_LDS ? 1 : NK); kk++)
 #pragma unroll
       for(int tm = 0; tm < TM; tm++) {
-        int64_t gi = i0 + wm * RW + tm * 16 + (lane & 15);
+        int64_t gi = i0 + wm * RW + KG_ROW(tm);
         if(gi > g.N - 1) gi = g.N - 1;
         int kr = kk * 4 + (lane >> 4);
         if(kr > dc - 1) kr = dc - 1;
@@ -561,7 +574,7 @@ __global__ void __launch_bounds__(64 * NW, OCC) kern_grad_ard_sym_kernel(const K
   double ai[ND > 0 ? ND : 1][TM];
 #pragma unroll
   for(int tm = 0; tm < TM; tm++) {
-    int64_t gi = i0 + wm * RW + tm * 16 + (lane & 15);
+    int64_t gi = i0 + wm * RW + KG_ROW(tm);
     if(gi > g.N - 1) gi = g.N - 1;
     ni[tm] = g.n1[gi];
 #pragma unroll
@@ -613,7 +626,7 @@ __global__ void __launch_bounds__(64 * NW, OCC) kern_grad_ard_sym_kernel(const K
         for(int o = 0; o < ND; o++) aj[o] = g.A[gjc + (int64_t)o * g.lda];
 #pragma unroll
         for(int tm = 0; tm < TM; tm++) {
-          const int64_t gi = i0 + wm * RW + tm * 16 + (lane & 15);
+          const int64_t gi = i0 + wm * RW + KG_ROW(tm);
           const int64_t gic = (KFAST || gi < g.N) ? gi : (g.N - 1);
 #ifdef GPC_KG_ABL_NOLOAD
           double v = (double)(gic & 7);
@@ -696,7 +709,7 @@ __global__ void __launch_bounds__(64 * NW, OCC) kern_grad_ard_sym_kernel(const K
       double v = 0.0;
 #pragma unroll
       for(int tm = 0; tm < TM; tm++) {
-        int64_t gi = i0 + wm * RW + tm * 16 + (lane & 15);
+        int64_t gi = i0 + wm * RW + KG_ROW(tm);
         if(gi > g.N - 1) gi = g.N - 1;                              // (rows past the end carry zero weights)
         const double x = (q < dc) ? g.X[gi + (int64_t)q * g.ldx] : 0.0;
         v += x * fma(rho[tm], x, -2.0 * Y1[tm][qx][r]);
