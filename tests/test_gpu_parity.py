@@ -874,6 +874,17 @@ def test_cfg3_full_size_properties(api):
     Z = Kfull @ (inv @ E)
     assert float((Z - E).abs().max()) < 1e-9
     assert torch.equal(inv[idx, :], inv[:, idx].t())
+    del Kfull, Z
+    # prediction at 256 points: the solve k(X*, X) L^-T of gpc_gp_posterior_f64 (its 64 panels through tile inverses formed on a
+    # second stream, potrf.hip: trsm_rlt_flow) against the same quantities from the EXPLICIT inverse -- another algorithm altogether
+    Xs = api.from_host(synth.make_xstar(256, c["D"], 99))
+    mu, var = api.gp_posterior(ks, Xd, L, alpha, Xs)
+    kx = api.gram_cross(ks, Xd, Xs)                                           # N x 256
+    want_mu = kx.t() @ alpha
+    want_var = api.gram_diag(ks, Xs).reshape(-1) - (kx * (inv @ kx)).sum(dim=0)
+    assert float((mu - want_mu).abs().max()) < 1e-9 * max(1.0, float(want_mu.abs().max()))
+    assert float((var.reshape(-1) - want_var).abs().max()) < 1e-9
+    assert float(var.min()) > 0.0
 
 
 @pytest.mark.parametrize("N", [1, 40, 64, 65, 500, 1000, 1023, 1100, 2048, 2049, 4133, 5120, 5122, 6145])
