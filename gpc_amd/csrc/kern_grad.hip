@@ -231,7 +231,10 @@ typedef double gdouble2 __attribute__((ext_vector_type(2)));
 #ifdef GPC_KG_OLDROW
 #define KG_ROW(tm) ((tm) * 16 + (lane & 15))
 #else
-#define KG_ROW(tm) (32 * ((tm) >> 1) + 2 * (lane & 15) + ((tm) & 1))
+// (MODE 2 -- the diagonal blocks' general tiles -- keeps tile-major rows: interleaved, its instances spill 15-40 registers more, which
+//  shows where those tiles are most of the walk: N = 8192, D = 8 0.165 -> 0.208 ms.  The two modes are separate launches with separate
+//  partial sums, so each may deal its rows as it likes.)
+#define KG_ROW(tm) (MODE == 1 ? (32 * ((tm) >> 1) + 2 * (lane & 15) + ((tm) & 1)) : ((tm) * 16 + (lane & 15)))
 #endif
 
 // MODE (round 4): the walk is two launches.  MODE 1 takes the full tiles strictly left of a row block's diagonal block -- all but
