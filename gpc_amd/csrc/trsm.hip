@@ -402,7 +402,34 @@ __device__ __forceinline__ void flow_publish(double* p, double x)
                      __HIP_MEMORY_SCOPE_AGENT);
 }
 
-template <bool FWD>
+// two dependencies at once: both values are requested before either is awaited, so the one memory round trip that a poll costs
+// (its wait also covers every operand load issued before it: loads return in order) is paid once per PAIR of blocks
+__device__ __forceinline__ void flow_poll2(const double* p0, const double* p1, bool need0, bool need1, int* ctl, int* sticky, double& x0,
+                                           double& x1)
+{
+  const unsigned long long* q0 = reinterpret_cast<const unsigned long long*>(p0);
+  const unsigned long long* q1 = reinterpret_cast<const unsigned long long*>(p1);
+  x0 = x1 = 0.0;
+  for(int it = 0; it < (1 << 23); it++) {
+    const unsigned long long v0 = need0 ? __hip_atomic_load(q0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+    const unsigned long long v1 = need1 ? __hip_atomic_load(q1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+    if(v0 != FLOW_SENT && v1 != FLOW_SENT) {
+      x0 = __longlong_as_double((long long)v0);
+      x1 = __longlong_as_double((long long)v1);
+      return;
+    }
+    if((it & 1023) == 1023 && __hip_atomic_load(&ctl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
+    __builtin_amdgcn_s_sleep(1);
+  }
+  atomicExch(&ctl[1], 1);
+  atomicExch(sticky, 1);
+  x0 = x1 = __longlong_as_double(0x7FF8000000000000ll);
+}
+
+// NR: right-hand sides the instance carries (1 or NR).  With ONE -- alpha of a single-output GP, the bench's case -- the
+// backward solve's per-lane sums are 16 registers instead of 64 values x 2, and both loops then keep their operand blocks TWO
+// dependencies ahead in three rotating register sets (round 5).
+template <bool FWD, int NR>
 __global__ void __launch_bounds__(256, 2) trsv_flow_kernel(const double* __restrict__ L, int64_t ldl, double* __restrict__ B,
                                                         int64_t ldb, int64_t M, int d, int unit, double* __restrict__ Xf,
                                                         int* __restrict__ ctl, int* __restrict__ sticky)
@@ -410,8 +437,8 @@ __global__ void __launch_bounds__(256, 2) trsv_flow_kernel(const double* __restr
   __shared__ double P[64 * 65];
   __shared__ double T2[64 * 65];   // the inverse of the diagonal block on its way to registers; later the backward solve's turning patch
   __shared__ double Dinv[64];
-  __shared__ double Y[FLOW_MAXRHS * 64];
-  __shared__ double Red[3][FLOW_MAXRHS][64];
+  __shared__ double Y[NR * 64];
+  __shared__ double Red[3][NR][64];
   __shared__ int tk_s;
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
   if(t == 0) tk_s = atomicAdd(&ctl[0], 1);
@@ -460,9 +487,14 @@ __global__ void __launch_bounds__(256, 2) trsv_flow_kernel(const double* __restr
   }
   __syncthreads();
   // my 16 coefficients of the final product: forward x = Linv r, backward x = Linv' r; row lane, columns 16 w .. 16 w + 15
+  // (the forward one-RHS instance takes them after its loop instead -- T2 stays what it is there, the product they feed is off the
+  //  critical path, and the loop's three operand sets need the 32 registers)
+  constexpr bool PM_LATE = FWD && NR == 1;
   double pm[16];
+  if(!PM_LATE) {
 #pragma unroll
-  for(int u = 0; u < 16; u++) pm[u] = FWD ? T2[(16 * w + u) * 65 + lane] : T2[lane * 65 + 16 * w + u];
+    for(int u = 0; u < 16; u++) pm[u] = FWD ? T2[(16 * w + u) * 65 + lane] : T2[lane * 65 + 16 * w + u];
+  }
 
   // (round 4) The LAST dependency -- the neighbouring block, whose x arrives last -- is kept out of the loop below: with
   // Mi = Linv L(i, i-1) (forward; backward Linv' L(i+1, i)') formed now, long before that x can be there, the step on the
@@ -519,18 +551,51 @@ __global__ void __launch_bounds__(256, 2) trsv_flow_kernel(const double* __restr
     // (P[j * 65 + m] = Mi(m, j) stays there: wave 0 takes its row at the very end, when the loop's registers are free)
   }
 
-  double tot[FLOW_MAXRHS];   // (wave 0) sum over the dependencies, per right-hand side, for row / column `lane` of my block
+  double tot[NR];   // (wave 0) sum over the dependencies, per right-hand side, for row / column `lane` of my block
 #pragma unroll
-  for(int v = 0; v < FLOW_MAXRHS; v++) tot[v] = 0.0;
+  for(int v = 0; v < NR; v++) tot[v] = 0.0;
 
   if(FWD) {
     // L_ij (rows of my block, 64 columns of block j): lane = row, this wave takes columns 16 w .. 16 w + 15
     const int64_t row = b0 + ((lane < nb) ? lane : 0);
     const double* Lrow = L + row + (int64_t)(16 * w) * ldl;
-    double a[16], an[16], acc[FLOW_MAXRHS];
+    double a[16], an[16], acc[NR];
 #pragma unroll
-    for(int v = 0; v < FLOW_MAXRHS; v++) acc[v] = 0.0;
+    for(int v = 0; v < NR; v++) acc[v] = 0.0;
     const int64_t jend = ib - 1;          // (block ib - 1 is the last dependency: see above)
+    if(NR == 1) {
+      // dependencies in PAIRS, four operand sets: the pair after next is requested before this pair's values are polled for
+      double a1[16], a2[16], a3[16];
+      auto load = [&](int64_t j, double (&r)[16]) {
+        if(j < jend) {
+#pragma unroll
+          for(int u = 0; u < 16; u++) r[u] = Lrow[(j * 64 + u) * ldl];
+        }
+      };
+      auto use2 = [&](int64_t j, const double (&r0)[16], const double (&r1)[16]) {
+        double x0, x1;
+        const int64_t e = 16 * w + (lane & 15);
+        flow_poll2(&Xf[j * 64 + e], &Xf[(j + 1 < jend ? j + 1 : j) * 64 + e], true, j + 1 < jend, ctl, sticky, x0, x1);
+#pragma unroll
+        for(int u = 0; u < 16; u++) acc[0] += r0[u] * readlane_f64(x0, u);
+        if(j + 1 < jend) {
+#pragma unroll
+          for(int u = 0; u < 16; u++) acc[0] += r1[u] * readlane_f64(x1, u);
+        }
+      };
+      load(0, a);
+      load(1, a1);
+      for(int64_t j = 0; j < jend; j += 4) {
+        load(j + 2, a2);
+        load(j + 3, a3);
+        use2(j, a, a1);
+        if(j + 2 < jend) {
+          load(j + 4, a);
+          load(j + 5, a1);
+          use2(j + 2, a2, a3);
+        }
+      }
+    } else {
     if(jend > 0) {
 #pragma unroll
       for(int u = 0; u < 16; u++) a[u] = Lrow[(int64_t)u * ldl];
@@ -544,7 +609,7 @@ __global__ void __launch_bounds__(256, 2) trsv_flow_kernel(const double* __restr
       // them round with v_readlane: no LDS staging, no barrier in this loop -- the four waves run ahead of each other and
       // keep more of L in flight
 #pragma unroll
-      for(int v = 0; v < FLOW_MAXRHS; v++)
+      for(int v = 0; v < NR; v++)
         if(v < d) {
           const double xv = flow_poll(&Xf[j * 64 + 16 * w + (lane & 15) + (int64_t)v * M], ctl, sticky);
 #pragma unroll
@@ -553,15 +618,16 @@ __global__ void __launch_bounds__(256, 2) trsv_flow_kernel(const double* __restr
 #pragma unroll
       for(int u = 0; u < 16; u++) a[u] = an[u];
     }
+    }
     if(w > 0) {
 #pragma unroll
-      for(int v = 0; v < FLOW_MAXRHS; v++)
+      for(int v = 0; v < NR; v++)
         if(v < d) Red[w - 1][v][lane] = acc[v];
     }
     __syncthreads();
     if(w == 0) {
 #pragma unroll
-      for(int v = 0; v < FLOW_MAXRHS; v++)
+      for(int v = 0; v < NR; v++)
         if(v < d) tot[v] = ((acc[v] + Red[0][v][lane]) + Red[1][v][lane]) + Red[2][v][lane];
     }
   } else {
@@ -569,9 +635,9 @@ __global__ void __launch_bounds__(256, 2) trsv_flow_kernel(const double* __restr
     // lane polls the x_j element of its own row, so the loop has no barrier; the per-lane partial sums are reduced
     // across lanes once, after the last dependency
     const double* Lcol = L + (b0 + (int64_t)(16 * w)) * ldl;
-    double a[16], an[16], acc[FLOW_MAXRHS][16];
+    double a[16], an[16], acc[NR][16];
 #pragma unroll
-    for(int v = 0; v < FLOW_MAXRHS; v++)
+    for(int v = 0; v < NR; v++)
 #pragma unroll
       for(int u = 0; u < 16; u++) acc[v][u] = 0.0;
     auto load_blk = [&](int64_t j, double (&r)[16]) {
@@ -584,21 +650,53 @@ __global__ void __launch_bounds__(256, 2) trsv_flow_kernel(const double* __restr
       }
     };
     const int64_t jend = ib + 1;          // (block ib + 1 is the last dependency: see above)
+    if(NR == 1) {
+      // dependencies nblk - 1, nblk - 2, ..., jend + 1 ("step t" is block nblk - 1 - t, T of them) in PAIRS, four operand sets
+      double a1[16], a2[16], a3[16];
+      const int64_t T = nblk - 1 - jend;
+      auto loadt = [&](int64_t t, double (&r)[16]) {
+        if(t < T) load_blk(nblk - 1 - t, r);
+      };
+      auto use2 = [&](int64_t t, const double (&r0)[16], const double (&r1)[16]) {
+        const int64_t j0 = nblk - 1 - t, j1 = (t + 1 < T) ? j0 - 1 : j0;
+        double x0, x1;
+        flow_poll2(&Xf[j0 * 64 + lane], &Xf[j1 * 64 + lane], j0 * 64 + lane < M, t + 1 < T, ctl, sticky, x0, x1);
+#pragma unroll
+        for(int u = 0; u < 16; u++) acc[0][u] += r0[u] * x0;
+        if(t + 1 < T) {
+#pragma unroll
+          for(int u = 0; u < 16; u++) acc[0][u] += r1[u] * x1;
+        }
+      };
+      loadt(0, a);
+      loadt(1, a1);
+      for(int64_t t = 0; t < T; t += 4) {
+        loadt(t + 2, a2);
+        loadt(t + 3, a3);
+        use2(t, a, a1);
+        if(t + 2 < T) {
+          loadt(t + 4, a);
+          loadt(t + 5, a1);
+          use2(t + 2, a2, a3);
+        }
+      }
+    } else {
     if(jend + 1 < nblk) load_blk(nblk - 1, a);
     for(int64_t j = nblk - 1; j > jend; j--) {
       if(j - 1 > jend) load_blk(j - 1, an);
-      double xj[FLOW_MAXRHS];
+      double xj[NR];
 #pragma unroll
-      for(int v = 0; v < FLOW_MAXRHS; v++)
+      for(int v = 0; v < NR; v++)
         xj[v] = (v < d && j * 64 + lane < M) ? flow_poll(&Xf[j * 64 + lane + (int64_t)v * M], ctl, sticky) : 0.0;
 #pragma unroll
-      for(int v = 0; v < FLOW_MAXRHS; v++)
+      for(int v = 0; v < NR; v++)
         if(v < d) {
 #pragma unroll
           for(int u = 0; u < 16; u++) acc[v][u] += a[u] * xj[v];
         }
 #pragma unroll
       for(int u = 0; u < 16; u++) a[u] = an[u];
+    }
     }
     // cross-lane reduction through LDS: Tr[c * 65 + lane], then a thread owns column c = lane and a quarter of the 64
     // partial sums
@@ -609,7 +707,7 @@ __global__ void __launch_bounds__(256, 2) trsv_flow_kernel(const double* __restr
       for(int u = 0; u < 16; u++) {
         double val = 0.0;
 #pragma unroll
-        for(int vv = 0; vv < FLOW_MAXRHS; vv++) val = (vv == v) ? acc[vv][u] : val;
+        for(int vv = 0; vv < NR; vv++) val = (vv == v) ? acc[vv][u] : val;
         Tr[(16 * w + u) * 65 + lane] = val;
       }
       __syncthreads();
@@ -621,22 +719,26 @@ __global__ void __launch_bounds__(256, 2) trsv_flow_kernel(const double* __restr
       if(w == 0) {
         const double tv = ((sacc + Red[0][0][lane]) + Red[1][0][lane]) + Red[2][0][lane];
 #pragma unroll
-        for(int vv = 0; vv < FLOW_MAXRHS; vv++) tot[vv] = (vv == v) ? tv : tot[vv];
+        for(int vv = 0; vv < NR; vv++) tot[vv] = (vv == v) ? tv : tot[vv];
       }
     }
   }
   __syncthreads();
   if(w == 0) {
 #pragma unroll
-    for(int v = 0; v < FLOW_MAXRHS; v++)
+    for(int v = 0; v < NR; v++)
       if(v < d) Y[v * 64 + lane] -= tot[v];
   }
   __syncthreads();
   // x = M r with the inverse block: every wave its 16 columns, summed through Red in a fixed order
   {
-    double part[FLOW_MAXRHS];
+    if(PM_LATE) {
 #pragma unroll
-    for(int v = 0; v < FLOW_MAXRHS; v++) {
+      for(int u = 0; u < 16; u++) pm[u] = T2[(16 * w + u) * 65 + lane];
+    }
+    double part[NR];
+#pragma unroll
+    for(int v = 0; v < NR; v++) {
       part[v] = 0.0;
       if(v < d) {
 #pragma unroll
@@ -645,13 +747,13 @@ __global__ void __launch_bounds__(256, 2) trsv_flow_kernel(const double* __restr
     }
     if(w > 0) {
 #pragma unroll
-      for(int v = 0; v < FLOW_MAXRHS; v++)
+      for(int v = 0; v < NR; v++)
         if(v < d) Red[w - 1][v][lane] = part[v];
     }
     __syncthreads();
     if(w == 0) {
 #pragma unroll
-      for(int v = 0; v < FLOW_MAXRHS; v++)
+      for(int v = 0; v < NR; v++)
         if(v < d) {
           double x = ((part[v] + Red[0][v][lane]) + Red[1][v][lane]) + Red[2][v][lane];      // z
           if(has_last) {
@@ -718,12 +820,21 @@ int trsv_lower(bool tr, bool unit, int64_t M, int64_t d, const double* L, int64_
     int* sticky = static_cast<int*>(wi) + SOLVE_FAULT_WORD;
     hipLaunchKernelGGL(flow_init_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s,
                        reinterpret_cast<unsigned long long*>(Xout), n, ctl);
-    if(!tr)
-      hipLaunchKernelGGL(trsv_flow_kernel<true>, dim3((unsigned)nblk), dim3(256), 0, s, L, ldl, B, ldb, M, (int)d, unit ? 1 : 0,
-                         Xout, ctl, sticky);
-    else
-      hipLaunchKernelGGL(trsv_flow_kernel<false>, dim3((unsigned)nblk), dim3(256), 0, s, L, ldl, B, ldb, M, (int)d, unit ? 1 : 0,
-                         Xout, ctl, sticky);
+    static const int deep = [] { const char* e = getenv("GPC_TRSV_DEEP"); return e ? atoi(e) : 1; }();   // 0: the four-RHS instance for one RHS too (A/B)
+#define GPC_TRSV_LAUNCH(F, R) hipLaunchKernelGGL((trsv_flow_kernel<F, R>), dim3((unsigned)nblk), dim3(256), 0, s, L, ldl, B, ldb, M, (int)d, unit ? 1 : 0, Xout, ctl, sticky)
+    // One right-hand side (alpha of a single-output GP), N = 65 536, same box: the backward solve 3.83 -> 3.33 ms = 4.49 -> 5.16 TB/s
+    // with the one-RHS instance, dependencies in pairs (N = 131 072: 13.06 -> 11.91).  The forward solve's one-RHS instance LOSES
+    // (3.38 -> 3.59; three rotating sets 3.74): its row panel's blocks lie 64 ldl doubles apart, and more of them in flight is more
+    // pages in flight; it keeps the general instance (GPC_TRSV_DEEP=2 launches it for A/B, 0 the general one for both).
+    if(d == 1 && deep == 2 && !tr) {
+      GPC_TRSV_LAUNCH(true, 1);       // (A/B only)
+    } else if(d == 1 && deep && tr) {
+      GPC_TRSV_LAUNCH(false, 1);
+    } else {
+      if(!tr) GPC_TRSV_LAUNCH(true, FLOW_MAXRHS);
+      else GPC_TRSV_LAUNCH(false, FLOW_MAXRHS);
+    }
+#undef GPC_TRSV_LAUNCH
     GPC_HIP_CHECK(hipGetLastError());
     return GPC_OK;
   }

@@ -1,19 +1,24 @@
-#!/usr/bin/env python
-"""The two triangular solves of CGp::updateAlpha on a synthetic lower factor (run on the GPU box)."""
-import sys, os
+"""The two triangular solves behind alpha = K^-1 m, timed apart (one right-hand side; forward L y = m, backward L' x = y).
+usage (GPU box): python tools/trsv_bench.py [N]"""
+import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from gpc_amd import api
-N = int(sys.argv[1]) if len(sys.argv) > 1 else 32768
-d = int(sys.argv[2]) if len(sys.argv) > 2 else 1
-L = torch.rand((N, N), dtype=torch.float64, device="cuda").t() * (0.5 / N)
-L.diagonal().fill_(1.0)
-y = torch.randn((d, N), dtype=torch.float64, device="cuda").t()
-a = api.empty(N, d)
-api.gp_alpha(L, y, out=a); torch.cuda.synchronize()
-e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-e0.record()
-for _ in range(3): api.gp_alpha(L, y, out=a)
-e1.record(); torch.cuda.synchronize()
-ms = e0.elapsed_time(e1) / 3
-print("N=%d d=%d alpha (2 solves) %.3f ms  %.0f GB/s algorithmic (2 x 4N^2 bytes)" % (N, d, ms, 8.0 * N * N / ms * 1e-6))
+
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
+X = torch.randn((8, N), dtype=torch.float64, device="cuda").t()
+ks = api.kspec([("rbf", [1.0, 1.0]), ("white", [0.1])])
+L = api.empty(N, N); api.gram_sym(ks, X, L); api.potrf(L, "L")
+y = torch.randn((1, N), dtype=torch.float64, device="cuda").t()
+
+def timed(fn, reps=5):
+    fn(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+for name, tr in (("forward  L y = m ", "N"), ("backward L' x = y", "T")):
+    t = timed(lambda: api.trsm(L, y, "L", "L", tr, "N"))
+    print("N=%d %s %.3f ms  %.0f GB/s of 4N^2 bytes" % (N, name, t, 4.0 * N * N / t * 1e-6))
