@@ -1038,6 +1038,20 @@ int trsm(char side, char uplo, char trans, char diag, int64_t M, int64_t Nrhs, d
     const char* e = getenv("GPC_TRSV");
     fast_rhs = e ? atoi(e) : 1;
   }
+  // Five to a few dozen right-hand sides against a large lower factor (alpha of a GP with many outputs): the blocked substitution's
+  // products are 64-deep and a few columns wide, the row-per-thread kernel below takes N / 64 launches -- N = 65 536, forward solve:
+  // 8 columns 28.2 ms, 32 columns 79.8 ms, where reading L once is 4 -- so the columns go through the dataflow dtrsv four at a time
+  // (8: 11 ms, 32: 44.5 ms; N = 8192, 32 columns 9.0 -> 3.3 ms).  From ~56 columns on the products win again (64: 80.7 against 89.6).
+  // GPC_TRSM_GROUPS=0: off.
+  static const int groups = [] { const char* e = getenv("GPC_TRSM_GROUPS"); return e ? atoi(e) : 1; }();
+  if(groups && fast_rhs && sd == 'L' && ul == 'L' && Nrhs > FLOW_MAXRHS && Nrhs <= 56 && M >= 4096) {
+    GPC_CHECK(scale_matrix(M, Nrhs, alpha, B, ldb, s));
+    for(int64_t c = 0; c < Nrhs; c += FLOW_MAXRHS) {
+      const int64_t nc = (Nrhs - c < FLOW_MAXRHS) ? (Nrhs - c) : FLOW_MAXRHS;
+      GPC_CHECK(trsv_lower(tc != 'N', dg == 'U', M, nc, A, lda, B + c * ldb, ldb, s));
+    }
+    return GPC_OK;
+  }
   if(fast_rhs && sd == 'L' && ul == 'L' && Nrhs > 0 && Nrhs <= TV_MAXRHS && M > 0) {
     GPC_CHECK(scale_matrix(M, Nrhs, alpha, B, ldb, s));
     return trsv_lower(tc != 'N', dg == 'U', M, Nrhs, A, lda, B, ldb, s);

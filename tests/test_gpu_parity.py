@@ -376,6 +376,22 @@ def test_trsm_vs_numpy(api, side, uplo, trans, diag, M, Nrhs):
     assert rel(api.to_host(Bd), ref) < 1e-10
 
 
+@pytest.mark.parametrize("trans,diag", [("N", "N"), ("T", "N"), ("N", "U")])
+@pytest.mark.parametrize("M,Nrhs", [(4096, 5), (4100, 17), (5000, 56), (4096, 57)])
+def test_trsm_left_lower_a_few_dozen_columns(api, trans, diag, M, Nrhs):
+    """Five to 56 right-hand sides against a lower factor of >= 4096 rows go through the dataflow dtrsv four columns at a time
+    (trsm.hip: alpha of a many-output GP); 57 columns take the blocked substitution.  Against scipy, B a window of a larger array."""
+    import scipy.linalg as sl
+    rng = np.random.RandomState(M + Nrhs)
+    T = np.tril(rng.randn(M, M)) / np.sqrt(M) + 2.0 * np.eye(M)
+    B = rng.randn(M + 2, Nrhs + 1)
+    Bd = api.from_host(B)
+    api.trsm(api.from_host(T), Bd[2:, 1:], "L", "L", trans, diag, 1.25)
+    want = B.copy()
+    want[2:, 1:] = 1.25 * sl.solve_triangular(T, B[2:, 1:], lower=True, trans=(1 if trans == "T" else 0), unit_diagonal=(diag == "U"))
+    assert rel(api.to_host(Bd), want) < 1e-10
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("ahead", ["1", "0"])
 def test_trsm_right_lower_trans_over_many_panels(ahead):

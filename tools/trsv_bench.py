@@ -22,3 +22,9 @@ def timed(fn, reps=5):
 for name, tr in (("forward  L y = m ", "N"), ("backward L' x = y", "T")):
     t = timed(lambda: api.trsm(L, y, "L", "L", tr, "N"))
     print("N=%d %s %.3f ms  %.0f GB/s of 4N^2 bytes" % (N, name, t, 4.0 * N * N / t * 1e-6))
+
+# a few dozen right-hand sides (alpha of a many-output GP): four at a time through the dataflow kernel (GPC_TRSM_GROUPS)
+for nr in (8, 32, 64):
+    Y = torch.randn((nr, N), dtype=torch.float64, device="cuda").t()
+    t = timed(lambda: api.trsm(L, Y, "L", "L", "N", "N"), 2)
+    print("N=%d forward solve, %d right-hand sides %.3f ms" % (N, nr, t))
