@@ -402,6 +402,14 @@ __device__ __forceinline__ void flow_publish(double* p, double x)
                      __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// The first look at a dependency, WITHOUT waiting: the caller issues its operand loads next and compares afterwards, so that the
+// answer (an L2 round trip) is not queued behind those loads (HBM round trips; loads return in order).  FLOW_SENT back = not there
+// yet: flow_poll() then.  Measured on the solves of alpha: see trsv_lower.
+__device__ __forceinline__ unsigned long long flow_peek(const double* p)
+{
+  return __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // two dependencies at once: both values are requested before either is awaited, so the one memory round trip that a poll costs
 // (its wait also covers every operand load issued before it: loads return in order) is paid once per PAIR of blocks
 __device__ __forceinline__ void flow_poll2(const double* p0, const double* p1, bool need0, bool need1, int* ctl, int* sticky, double& x0,
@@ -429,6 +437,9 @@ __device__ __forceinline__ void flow_poll2(const double* p0, const double* p1, b
 // NR: right-hand sides the instance carries (1 or NR).  With ONE -- alpha of a single-output GP, the bench's case -- the
 // backward solve's per-lane sums are 16 registers instead of 64 values x 2, and both loops then keep their operand blocks TWO
 // dependencies ahead in three rotating register sets (round 5).
+#ifndef GPC_TRSV_PEEK
+#define GPC_TRSV_PEEK 1      // (-DGPC_TRSV_PEEK=0: every dependency through the waiting poll, operand loads first: A/B builds)
+#endif
 template <bool FWD, int NR>
 __global__ void __launch_bounds__(256, 2) trsv_flow_kernel(const double* __restrict__ L, int64_t ldl, double* __restrict__ B,
                                                         int64_t ldb, int64_t M, int d, int unit, double* __restrict__ Xf,
@@ -440,6 +451,7 @@ __global__ void __launch_bounds__(256, 2) trsv_flow_kernel(const double* __restr
   __shared__ double Y[NR * 64];
   __shared__ double Red[3][NR][64];
   __shared__ int tk_s;
+  constexpr bool PEEK = GPC_TRSV_PEEK != 0;
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
   if(t == 0) tk_s = atomicAdd(&ctl[0], 1);
   __syncthreads();
@@ -601,6 +613,9 @@ __global__ void __launch_bounds__(256, 2) trsv_flow_kernel(const double* __restr
       for(int u = 0; u < 16; u++) a[u] = Lrow[(int64_t)u * ldl];
     }
     for(int64_t j = 0; j < jend; j++) {
+      unsigned long long pk[NR];      // (the look at x_j goes out BEFORE the next block's loads: flow_peek)
+#pragma unroll
+      for(int v = 0; v < NR; v++) pk[v] = (v < d && PEEK) ? flow_peek(&Xf[j * 64 + 16 * w + (lane & 15) + (int64_t)v * M]) : FLOW_SENT;
       if(j + 1 < jend) {
 #pragma unroll
         for(int u = 0; u < 16; u++) an[u] = Lrow[((j + 1) * 64 + u) * ldl];
@@ -611,7 +626,8 @@ __global__ void __launch_bounds__(256, 2) trsv_flow_kernel(const double* __restr
 #pragma unroll
       for(int v = 0; v < NR; v++)
         if(v < d) {
-          const double xv = flow_poll(&Xf[j * 64 + 16 * w + (lane & 15) + (int64_t)v * M], ctl, sticky);
+          const double xv = (pk[v] != FLOW_SENT) ? __longlong_as_double((long long)pk[v])
+                                                 : flow_poll(&Xf[j * 64 + 16 * w + (lane & 15) + (int64_t)v * M], ctl, sticky);
 #pragma unroll
           for(int u = 0; u < 16; u++) acc[v] += a[u] * readlane_f64(xv, u);
         }
@@ -657,10 +673,19 @@ __global__ void __launch_bounds__(256, 2) trsv_flow_kernel(const double* __restr
       auto loadt = [&](int64_t t, double (&r)[16]) {
         if(t < T) load_blk(nblk - 1 - t, r);
       };
-      auto use2 = [&](int64_t t, const double (&r0)[16], const double (&r1)[16]) {
+      auto use2 = [&](int64_t t, const double (&r0)[16], const double (&r1)[16], auto&& prefetch) {
         const int64_t j0 = nblk - 1 - t, j1 = (t + 1 < T) ? j0 - 1 : j0;
+        const bool need0 = j0 * 64 + lane < M, need1 = t + 1 < T;
+        const unsigned long long p0 = (need0 && PEEK) ? flow_peek(&Xf[j0 * 64 + lane]) : (need0 ? FLOW_SENT : 0ull);
+        const unsigned long long p1 = (need1 && PEEK) ? flow_peek(&Xf[j1 * 64 + lane]) : (need1 ? FLOW_SENT : 0ull);
+        prefetch();      // (behind the look at the pair's values: flow_peek)
         double x0, x1;
-        flow_poll2(&Xf[j0 * 64 + lane], &Xf[j1 * 64 + lane], j0 * 64 + lane < M, t + 1 < T, ctl, sticky, x0, x1);
+        if(p0 != FLOW_SENT && p1 != FLOW_SENT) {
+          x0 = __longlong_as_double((long long)p0);
+          x1 = __longlong_as_double((long long)p1);
+        } else {
+          flow_poll2(&Xf[j0 * 64 + lane], &Xf[j1 * 64 + lane], need0, need1, ctl, sticky, x0, x1);
+        }
 #pragma unroll
         for(int u = 0; u < 16; u++) acc[0][u] += r0[u] * x0;
         if(t + 1 < T) {
@@ -671,23 +696,22 @@ __global__ void __launch_bounds__(256, 2) trsv_flow_kernel(const double* __restr
       loadt(0, a);
       loadt(1, a1);
       for(int64_t t = 0; t < T; t += 4) {
-        loadt(t + 2, a2);
-        loadt(t + 3, a3);
-        use2(t, a, a1);
-        if(t + 2 < T) {
-          loadt(t + 4, a);
-          loadt(t + 5, a1);
-          use2(t + 2, a2, a3);
-        }
+        use2(t, a, a1, [&] { loadt(t + 2, a2); loadt(t + 3, a3); });
+        if(t + 2 < T) use2(t + 2, a2, a3, [&] { loadt(t + 4, a); loadt(t + 5, a1); });
       }
     } else {
     if(jend + 1 < nblk) load_blk(nblk - 1, a);
     for(int64_t j = nblk - 1; j > jend; j--) {
+      unsigned long long pk[NR];
+#pragma unroll
+      for(int v = 0; v < NR; v++) pk[v] = (v < d && j * 64 + lane < M && PEEK) ? flow_peek(&Xf[j * 64 + lane + (int64_t)v * M]) : FLOW_SENT;
       if(j - 1 > jend) load_blk(j - 1, an);
       double xj[NR];
 #pragma unroll
       for(int v = 0; v < NR; v++)
-        xj[v] = (v < d && j * 64 + lane < M) ? flow_poll(&Xf[j * 64 + lane + (int64_t)v * M], ctl, sticky) : 0.0;
+        xj[v] = (v < d && j * 64 + lane < M) ? ((pk[v] != FLOW_SENT) ? __longlong_as_double((long long)pk[v])
+                                                                      : flow_poll(&Xf[j * 64 + lane + (int64_t)v * M], ctl, sticky))
+                                             : 0.0;
 #pragma unroll
       for(int v = 0; v < NR; v++)
         if(v < d) {
