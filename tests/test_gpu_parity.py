@@ -376,6 +376,25 @@ def test_trsm_vs_numpy(api, side, uplo, trans, diag, M, Nrhs):
     assert rel(api.to_host(Bd), ref) < 1e-10
 
 
+@pytest.mark.parametrize("M", [65, 128, 129, 192, 256, 257, 320, 321, 384, 448, 449, 512, 513, 640, 1000])
+def test_trsv_every_dependency_count(api, M):
+    """The dataflow dtrsv with one right-hand side: the backward solve's one-RHS instance takes its dependencies in pairs, four
+    operand sets in rotation (trsm.hip) -- block counts 2 ... 16 put every remainder of that rotation (0 ... 5 dependencies past a
+    whole turn, an odd one left over, none at all) and ragged last blocks through it; forward and backward, one and three
+    right-hand sides, against scipy."""
+    import scipy.linalg as sl
+    rng = np.random.RandomState(M)
+    T = np.tril(rng.randn(M, M)) / np.sqrt(M) + 2.0 * np.eye(M)
+    Td = api.from_host(T)
+    for nr in (1, 3):
+        for trans in ("N", "T"):
+            B = rng.randn(M, nr)
+            Bd = api.from_host(B)
+            api.trsm(Td, Bd, "L", "L", trans, "N", 1.0)
+            want = sl.solve_triangular(T, B, lower=True, trans=(1 if trans == "T" else 0))
+            assert rel(api.to_host(Bd), want) < 1e-11, (nr, trans)
+
+
 @pytest.mark.parametrize("trans,diag", [("N", "N"), ("T", "N"), ("N", "U")])
 @pytest.mark.parametrize("M,Nrhs", [(4096, 5), (4100, 17), (5000, 56), (4096, 57)])
 def test_trsm_left_lower_a_few_dozen_columns(api, trans, diag, M, Nrhs):
@@ -408,7 +427,7 @@ sys.path.insert(0, %r)
 from gpc_amd import api
 rng = np.random.RandomState(11)
 worst = 0.0
-for (M, n) in [(2, 4096), (130, 5000), (1024, 4224), (66, 7168)]:
+for (M, n) in [(2, 4096), (130, 5000), (1024, 4224), (66, 7168), (2048, 4096), (2050, 4160), (64, 4094)]:
     G = rng.randn(n, 40)
     K = G @ G.T / 40.0 + 2.0 * np.eye(n)
     L = np.linalg.cholesky(K)
