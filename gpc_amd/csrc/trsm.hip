@@ -1139,7 +1139,9 @@ static int potri_inplace_lower(int64_t N, double* A, int64_t lda, hipStream_t s)
   static const int use_flow = [] { const char* e = getenv("GPC_TRSM_FLOW"); return e ? atoi(e) : 1; }();
   if(!use_flow) return GPC_EUNSUPPORTED;   // (the launch chain's form of the solve is not in place)
   const int64_t wenv = [] { const char* e = getenv("GPC_POTRI_LAUUM_NB"); return e ? atoll(e) : (int64_t)0; }();
-  const int64_t w = (wenv >= 128 && wenv <= 4096) ? (wenv / 128) * 128 : 1024;
+  // (second phase 4096 wide from N = 32 768: a quarter of the launches, products four times as deep on the ring kernel -- N = 32 768 /
+  //  49 152 / 65 536: 359.6 / 1155.2 / 2632 -> 356.4 / 1144.0 / 2606 ms, 2048 wide 358.1 / 1145.7 / 2612; level at 24 576)
+  const int64_t w = (wenv >= 128 && wenv <= 4096) ? (wenv / 128) * 128 : (N >= 32768 ? 4096 : 1024);
   // (a problem of <= 4096 columns is ONE dataflow launch, whose "tile" is the whole factor: in place only in name there)
   const int64_t tmax = N <= 4096 ? N : (w > 1024 ? w : 1024);
   void* ws = nullptr;
